@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py -- forward ELBO steps/sec of the conv-GP hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--scaling weak|strong]
+
+One "step" = one forward ELBO evaluation of a synthetic minibatch (compute_log_likelihood semantics:
+S = 10 samples, all layers, data term + all KLs, scalar read back to the host), inputs already resident
+in HBM, nothing cached across steps.  At N = 1 the workload is BASELINE.json configs[1] (MNIST 1-layer
+M = 256, batch 32) in its conv-layer + head form (K_uf + Cholesky + conditional); noise comes from the
+counter-based device RNG, as the reference draws it inside its graph.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the minibatch images are sharded over the
+ranks; every rank runs the same step on its shard and ONE RCCL all-reduce (1 x fp64) of the data term per
+step joins them.  --scaling weak (default): 32 images per GPU (global batch 32*N), value counts
+batch-32-equivalent steps (images/s / 32); --scaling strong: global batch fixed at 32.
+Rank 0 prints ONE JSON line.  torch is used only as host plumbing (gloo barrier / broadcast / max).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from deepcgp_amd import device as dev                    # noqa: E402
+from deepcgp_amd import synthetic as syn                 # noqa: E402
+from deepcgp_amd.dist import shard_range, init_rccl      # noqa: E402
+from deepcgp_amd.models import build_from_spec           # noqa: E402
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix peak (datasheet; the guide lists no fp64 row): 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def conv_geometry(c, rows):
+    P = ((c["H"] - c["f"]) // c["s"] + 1) * ((c["W"] - c["f"]) // c["s"] + 1)
+    return P, c["f"] * c["f"] * c["C"], rows * P
+
+
+def cpu_baseline(name, S, batch, budget_s=30.0):
+    """The oracle (NumPy/OpenBLAS fp64 restatement in the reference's operation order) timed on the host."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_build import oracle_model
+    spec, X, Y = syn.make_config(name, S=S)
+    X, Y = X[:batch], Y[:batch]
+    model = oracle_model(spec, X, Y)
+    rng = np.random.default_rng(0)
+    small = oracle_model(spec, X[:2], Y[:2])
+    small.num_samples = 1
+    small.compute_log_likelihood(X[:2], Y[:2], rng=rng)          # warm BLAS / page in
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 3 and (not times or time.perf_counter() - t_all + times[-1] < budget_s):
+        t0 = time.perf_counter()
+        model.compute_log_likelihood(X, Y, rng=rng)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "ELBO steps/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d full forward ELBO steps of the same workload (batch %d, S=%d) with the float64 NumPy/OpenBLAS "
+                      "oracle in the reference's operation order; median %.2f s/step; not TensorFlow" % (len(times), batch, S, med)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=str, default="cfg2_mnist_CH_M256", choices=sorted(syn.CONFIGS))
+    ap.add_argument("--scaling", type=str, default="weak", choices=["weak", "strong"])
+    ap.add_argument("--samples", type=int, default=10)
+    ap.add_argument("--dedup-layer0", action="store_true",
+                    help="evaluate layer 0 on the distinct images only (exact; off by default so that the step does "
+                         "the same work as the reference, which tiles the batch S times)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    td = None
+    if world > 1:
+        import torch
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group("gloo", rank=rank, world_size=world)
+
+    ctx = dev.Context(local_rank if dev.device_count() > local_rank else 0)
+    dev._default_ctx = ctx
+    if world > 1:
+        def bcast(b):
+            t = torch.tensor(list(b), dtype=torch.uint8)
+            td.broadcast(t, src=0)
+            return bytes(t.tolist())
+        init_rccl(ctx, rank, world, bcast)
+
+    cfg = syn.CONFIGS[args.config]
+    S = args.samples
+    per_rank_batch = cfg["batch"]
+    if args.scaling == "weak":
+        global_batch = cfg["batch"] * world
+        lo, hi = rank * cfg["batch"], (rank + 1) * cfg["batch"]
+    else:
+        global_batch = cfg["batch"]
+        lo, hi = shard_range(global_batch, rank, world)
+        per_rank_batch = hi - lo
+    seed = 1234 + list(syn.CONFIGS).index(args.config)
+    spec = syn.make_spec(cfg["hwc"], cfg["convs"], cfg["head"], cfg["M"], S=S, num_data=cfg["num_data"], seed=seed)
+    Xg, Yg = syn.make_batch(cfg["hwc"], global_batch, seed=seed)
+    model = build_from_spec(spec, Xg[lo:hi], Yg[lo:hi])
+    model.dedup_layer0 = bool(args.dedup_layer0)
+    dX, dY = ctx.to_device(Xg[lo:hi]), ctx.to_device(Yg[lo:hi], np.int32)
+    scale = float(spec["num_data"]) / float(global_batch)
+
+    def step(i):
+        return model.compute_log_likelihood(dX, dY, seed=i, scale=scale)
+
+    def barrier():
+        ctx.sync()
+        if td is not None:
+            td.barrier()
+        ctx.sync()
+
+    elbo = None
+    for i in range(args.warmup):
+        elbo = step(i)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        elbo = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    timing = ctx.timing()
+    ctx.timing_enable(False)
+    # the same K steps without event brackets: how much the instrumentation costs
+    barrier()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt_plain = time.perf_counter() - t1
+    if td is not None:
+        t = torch.tensor([dt, dt_plain], dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt, dt_plain = float(t[0]), float(t[1])
+
+    if rank == 0:
+        units_per_step = global_batch / float(cfg["batch"])        # batch-32-equivalent ELBO steps per step
+        value = units_per_step * args.steps / dt
+        out = {
+            "metric": "forward ELBO steps/sec (batch=%d-equivalent), MNIST M=256 1-layer" % cfg["batch"]
+                      if args.config.startswith("cfg2") else "forward ELBO steps/sec (batch=%d-equivalent)" % cfg["batch"],
+            "value": value, "unit": "ELBO steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.config, "variant": "conv layer + head" if cfg["convs"] else "head only",
+                       "M": cfg["M"], "per_gpu_batch": per_rank_batch, "global_batch": global_batch, "num_samples": S,
+                       "image": list(cfg["hwc"]), "layers": len(cfg["convs"]) + 1, "noise": "device Philox RNG",
+                       "dedup_layer0": bool(args.dedup_layer0), "parallelism": "image-sharded x%d, RCCL all-reduce of 1 f64" % world},
+            "elbo": elbo,
+            "ms_per_step_without_event_timing": 1e3 * dt_plain / args.steps,
+        }
+        # ---- roofline of the dominant kernel: the R-batched L_q^T A product with fused square-reduce ----
+        rows0 = per_rank_batch if (args.dedup_layer0 and cfg["convs"]) else per_rank_batch * S
+        kern = {k: {"launches": v[0], "avg_us": 1e3 * v[1] / max(v[0], 1)} for k, v in timing.items()}
+        out["kernel_times_us"] = {k: round(v["avg_us"], 2) for k, v in sorted(kern.items())}
+        if cfg["convs"]:
+            c = spec["convs"][0]
+            P, L, Kc = conv_geometry(c, rows0)
+            M, R = c["M"], c["R"]
+            nl = len(cfg["convs"]) + 1
+            # gemm_cond_s3 is launched once per layer; layer 0 dominates -- use its algorithmic flops only when it
+            # is the only conv layer, else report the sum over layers per step
+            flops_s3 = 0.0
+            rows = rows0
+            for ci, cc in enumerate(spec["convs"]):
+                Pc, Lc, Kcc = conv_geometry(cc, rows if ci == 0 else per_rank_batch * S)
+                flops_s3 += float(cc["R"]) * cc["M"] ** 2 * Kcc
+            flops_s3 += float(spec["head"]["R"]) * spec["head"]["M"] ** 2 * per_rank_batch * S
+            t_s3 = timing.get("gemm_cond_s3", (0, 0.0))
+            per_step_ms = t_s3[1] / max(args.steps, 1)
+            ach = flops_s3 / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else None
+            out["roofline"] = {"kernel": "gemm_tn_kernel<128,128> (stage 3: T_r = Lq_r^T A, fused sum of squares; %d launches/step)" % nl,
+                               "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": (ach / FP64_MFMA_PEAK_TFLOPS) if ach else None, "traffic": None,
+                               "algorithmic_flops_per_step": flops_s3, "ms_per_step_in_kernel": per_step_ms,
+                               "note": "algorithmic flops = sum_layers R*M^2*K (triangular product counted as M^2 per column, SURVEY 8(d)); fp64 MFMA peak"}
+            # K_uf sweep (layer 0): algorithmic bytes 8*(N'*H*W*C + M*L + P*M*N')
+            bytes_kuf = 8.0 * (rows0 * c["H"] * c["W"] * c["C"] + M * L + float(P) * M * rows0)
+            t_kuf = timing.get("kuf", (0, 0.0))
+            n_conv = len(cfg["convs"])
+            if t_kuf[0] and n_conv == 1:
+                us = 1e3 * t_kuf[1] / t_kuf[0]
+                gbs = bytes_kuf / (us * 1e-6) / 1e9
+                out["roofline_kuf"] = {"kernel": "patch_rbf_kernel (K_uf sweep, layer 0)", "bound": "hbm", "achieved": gbs,
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                       "algorithmic_bytes_per_launch": bytes_kuf, "avg_us": us}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.config, S, cfg["batch"])
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if td is not None:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

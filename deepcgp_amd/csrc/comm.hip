@@ -1,0 +1,114 @@
+// comm.hip -- multi-GPU: one process per GPU, one RCCL communicator per ctx, collectives on the ctx stream.
+// The forward ELBO needs exactly one collective per step: a 1-element fp64 sum all-reduce of the
+// per-GPU data term; KL terms are replicated and computed redundantly.
+// librccl is dlopen()ed on first use so that libdcgp.so loads on hosts without it.
+#include <dlfcn.h>
+
+#include "layer_impl.h"
+
+namespace {
+
+// the few RCCL entry points we need, with the NCCL ABI (rccl.h): ncclUniqueId is 128 bytes
+struct UniqueId { char internal[128]; };
+typedef int (*fn_get_unique_id)(UniqueId*);
+typedef int (*fn_comm_init_rank)(void** comm, int nranks, UniqueId id, int rank);
+typedef int (*fn_comm_destroy)(void* comm);
+typedef int (*fn_all_reduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t s);
+typedef const char* (*fn_get_error_string)(int);
+
+struct Rccl {
+  void* h = nullptr;
+  fn_get_unique_id get_unique_id = nullptr;
+  fn_comm_init_rank comm_init_rank = nullptr;
+  fn_comm_destroy comm_destroy = nullptr;
+  fn_all_reduce all_reduce = nullptr;
+  fn_get_error_string get_error_string = nullptr;
+};
+Rccl g_rccl;
+
+bool rccl_load() {
+  if (g_rccl.h) return true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) {
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) return false;
+  g_rccl.get_unique_id = (fn_get_unique_id)dlsym(h, "ncclGetUniqueId");
+  g_rccl.comm_init_rank = (fn_comm_init_rank)dlsym(h, "ncclCommInitRank");
+  g_rccl.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
+  g_rccl.all_reduce = (fn_all_reduce)dlsym(h, "ncclAllReduce");
+  g_rccl.get_error_string = (fn_get_error_string)dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce) {
+    dlclose(h);
+    return false;
+  }
+  g_rccl.h = h;
+  return true;
+}
+
+constexpr int kNcclFloat64 = 8;   // ncclDouble
+constexpr int kNcclSum = 0;       // ncclSum
+
+}  // namespace
+
+int allreduce_sum_f64_async(dcgp_ctx* ctx, double* buf_dev, int n) {
+  if (!ctx->comm) return ctx_fail(ctx, DCGP_ERR_RCCL, "allreduce: no communicator on this ctx");
+  int rc = g_rccl.all_reduce(buf_dev, buf_dev, (size_t)n, kNcclFloat64, kNcclSum, ctx->comm, ctx->stream);
+  if (rc != 0)
+    return ctx_fail(ctx, DCGP_ERR_RCCL, "ncclAllReduce failed: %s",
+                    g_rccl.get_error_string ? g_rccl.get_error_string(rc) : "?");
+  return DCGP_OK;
+}
+
+extern "C" {
+
+int dcgp_comm_unique_id(unsigned char* out_128bytes) {
+  if (!out_128bytes) return DCGP_ERR_ARG;
+  if (!rccl_load()) return DCGP_ERR_RCCL;
+  UniqueId id;
+  if (g_rccl.get_unique_id(&id) != 0) return DCGP_ERR_RCCL;
+  memcpy(out_128bytes, id.internal, 128);
+  return DCGP_OK;
+}
+
+int dcgp_comm_init_rank(dcgp_ctx* ctx, int nranks, int rank, const unsigned char* id_128bytes) {
+  if (!ctx || !id_128bytes || nranks <= 0 || rank < 0 || rank >= nranks)
+    return ctx ? ctx_fail(ctx, DCGP_ERR_ARG, "comm_init_rank: bad args") : DCGP_ERR_ARG;
+  if (!rccl_load()) return ctx_fail(ctx, DCGP_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
+  if (ctx->comm) dcgp_comm_destroy(ctx);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  UniqueId id;
+  memcpy(id.internal, id_128bytes, 128);
+  void* comm = nullptr;
+  int rc = g_rccl.comm_init_rank(&comm, nranks, id, rank);
+  if (rc != 0)
+    return ctx_fail(ctx, DCGP_ERR_RCCL, "ncclCommInitRank failed: %s",
+                    g_rccl.get_error_string ? g_rccl.get_error_string(rc) : "?");
+  ctx->comm = comm;
+  ctx->nranks = nranks;
+  ctx->rank = rank;
+  return DCGP_OK;
+}
+
+int dcgp_comm_destroy(dcgp_ctx* ctx) {
+  if (!ctx) return DCGP_ERR_ARG;
+  if (ctx->comm && g_rccl.comm_destroy) {
+    hipStreamSynchronize(ctx->stream);
+    g_rccl.comm_destroy(ctx->comm);
+  }
+  ctx->comm = nullptr;
+  ctx->nranks = 1;
+  ctx->rank = 0;
+  return DCGP_OK;
+}
+
+int dcgp_allreduce_sum_f64(dcgp_ctx* ctx, double* buf_dev, int n) {
+  if (!ctx || !buf_dev || n <= 0) return ctx ? ctx_fail(ctx, DCGP_ERR_ARG, "allreduce: bad args") : DCGP_ERR_ARG;
+  DCGP_TRY(allreduce_sum_f64_async(ctx, buf_dev, n));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}
+
+}  // extern "C"

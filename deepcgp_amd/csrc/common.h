@@ -1,0 +1,126 @@
+// Internal declarations shared by the libdcgp.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dcgp.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline long round_up_l(long x, long m) { return (x + m - 1) / m * m; }
+
+struct TimingAcc {
+  int launches = 0;
+  double ms = 0.0;
+};
+struct PendingEvent {
+  std::string name;
+  hipEvent_t start, stop;
+};
+
+struct dcgp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // named, grow-only device workspaces owned by the ctx
+  std::map<std::string, std::pair<void*, size_t>> ws;
+  // timing
+  bool timing = false;
+  std::map<std::string, TimingAcc> tim;
+  std::vector<PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+  // pinned host scratch for small result read-backs
+  double* h_scratch = nullptr;   // 64 doubles
+  int* h_info = nullptr;         // 16 ints
+  // RCCL
+  void* comm = nullptr;
+  int nranks = 1, rank = 0;
+};
+
+int ctx_fail(dcgp_ctx* ctx, int code, const char* fmt, ...);
+void* ws_get(dcgp_ctx* ctx, const std::string& name, size_t bytes);   // nullptr on failure
+void timing_flush(dcgp_ctx* ctx);
+
+#define HIP_TRY(ctx, call)                                                               \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return ctx_fail((ctx), DCGP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                      __FILE__, __LINE__);                                               \
+  } while (0)
+
+#define DCGP_TRY(call)        \
+  do {                        \
+    int s_ = (call);          \
+    if (s_ != DCGP_OK) return s_; \
+  } while (0)
+
+#define LAUNCH_CHECK(ctx)                                                                \
+  do {                                                                                   \
+    hipError_t e_ = hipGetLastError();                                                   \
+    if (e_ != hipSuccess)                                                                \
+      return ctx_fail((ctx), DCGP_ERR_HIP, "kernel launch failed: %s (%s:%d)",           \
+                      hipGetErrorString(e_), __FILE__, __LINE__);                        \
+  } while (0)
+
+// RAII bracket: records start/stop events around the launches issued in its scope when timing is on.
+struct ScopedTimer {
+  dcgp_ctx* ctx;
+  bool on;
+  PendingEvent pe;
+  ScopedTimer(dcgp_ctx* c, const char* name);
+  ~ScopedTimer();
+};
+
+// ------------------------------------------------------------------------------------------------
+// internal device-side building blocks (defined in the .hip files)
+// ------------------------------------------------------------------------------------------------
+
+// C[i][j] = sum_k Wt[k][i] * B[k][j]  (both operands k-major), optional triangular structure of W,
+// optional store of C, optional fused per-column sum of squares (partial per row block).
+struct GemmArgs {
+  const double* Wt = nullptr; long wBatch = 0; int ldw = 0;
+  const double* B = nullptr;  long bBatch = 0; int ldb = 0;
+  double* C = nullptr;        long cBatch = 0; int ldc = 0;
+  double* colsq = nullptr;    long sBatch = 0; long sRowBlk = 0;   // colsq[batch*sBatch + rb*sRowBlk + j]
+  int Mi = 0, Mk = 0, Kc = 0;  // rows of C, contraction length, columns
+  int nW = 1, nB = 1;          // batch = nW * nB, bz -> (iw = bz / nB, ib = bz % nB)
+  int tri = 0;                 // 0 dense, 1: W lower (k <= i), 2: W upper (k >= i)
+  int b_lower = 0;             // B[k][j] == 0 for k < j (skip those k tiles)
+};
+int gemm_tn(dcgp_ctx* ctx, const GemmArgs& a, int* n_row_blocks_out);
+int gemm_row_block(int Mi);   // BM the dispatcher will pick for this Mi
+
+// patch-RBF sweep (kuf / head Kzx)
+struct PatchRbfArgs {
+  const double* X = nullptr;   // [n_mod, H, W, C]; image of column block n is X[n % n_mod]
+  int n_mod = 0;
+  int N = 0, H = 0, W = 0, C = 0, f = 0, s = 0, Ho = 0, Wo = 0, P = 0, L = 0;
+  const double* ZT = nullptr;  // [Lp, Mp] k-major, zero padded
+  const double* zn = nullptr;  // [Mp] |z|^2 (unscaled)
+  int M = 0, Mp = 0, Lp = 0;
+  double variance = 1, inv_l2 = 1;
+  // write mode: out[m*sM + n*sN + p*sP]
+  double* out = nullptr; long sM = 0, sN = 0, sP = 0;
+  // reduce mode (head Kzx): out[m*sM + n*sN] = scale * sum_p w[p] k
+  const double* w = nullptr; double scale = 1; int reduce = 0;
+};
+int patch_rbf(dcgp_ctx* ctx, const PatchRbfArgs& a, const char* timer_name);
+int head_kdiag(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, int C, int f, int s, double variance,
+               double inv_l2, const double* w, double* out_N);
+
+// small-matrix helpers (rbf.hip / chol.hip / misc.hip)
+int rbf_gram_padded(dcgp_ctx* ctx, const double* Z, int M, int L, double variance, double inv_l2, double jitter,
+                    double* out, int ld, int Mp);                       // out [Mp, ld], pad diag = 1
+int z_transpose_norms(dcgp_ctx* ctx, const double* Z, int M, int L, double* ZT, int Mp, int Lp, double* zn);
+int potrf_batched(dcgp_ctx* ctx, double* const* d_ptrs, double** h_ptrs, int batch, int Mp, int ld,
+                  int* d_info);   // d_info[b] = 0 or 1-based failing column
+int trtri_batched(dcgp_ctx* ctx, double* const* d_L, double* const* d_Linv, double* const* d_LinvT,
+                  int batch, int Mp, int ld);
+int pad_copy(dcgp_ctx* ctx, const double* src, int rows, int cols, int lds, double* dst, int ldd, int rows_p,
+             int cols_p, int mode, int batch, long src_batch, long dst_batch);   // mode 0 full, 1 lower-tri, 2: +I on pad diag

@@ -1,0 +1,407 @@
+// cond.hip -- the doubly-stochastic SVGP conditional (conv_gp/conditionals.py:6-67) and the scalar
+// terms around it (gauss_kl, RobustMax variational expectations, reparameterisation).
+//
+// With Lm = chol(Kmm) and Linv = inv(Lm) the reference's per-patch triangular solves become three
+// k-major matrix-core products on the [M x (P*N)] Kuf matrix (gemm.hip):
+//     A1 = Linv  Kuf            lower-triangular W      -> s1[j]   = sum_m A1[m,j]^2        (:31-33,:40)
+//     A  = Linv' A1             upper-triangular W                                           (:44-47)
+//     T_r= Lq_r' A  (no store)  upper-triangular W, x R -> s2[r,j] = sum_m T_r[m,j]^2        (:55-65)
+//     mu[r,j] = sum_m q_mu[m,r] A[m,j]                                                       (:50)
+// and a fused epilogue forms var = Knn - s1 + s2, the N x (P*R) output layout of
+// conv_gp/layers.py:128-131 and the sample mean + z*sqrt(var + jitter).
+#include "layer_impl.h"
+
+namespace {
+
+// mu[r][j] = sum_k qmu[k][r] * A[k][j]; thread per column, 8 outputs per pass
+__global__ __launch_bounds__(256) void mean_kernel(const double* __restrict__ A, long lda, int Mk,
+                                                   const double* __restrict__ qmu, int R, double* __restrict__ mu,
+                                                   long ldm, int Kc) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * 8;
+  const int nr = min(8, R - r0);
+  __shared__ double q[64][8];
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k0 = 0; k0 < Mk; k0 += 64) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 8; idx += 256) {
+      int kk = idx >> 3, rr = idx & 7;
+      q[kk][rr] = (k0 + kk < Mk && rr < nr) ? qmu[(long)(k0 + kk) * R + r0 + rr] : 0.0;
+    }
+    __syncthreads();
+    if (j < Kc) {
+      const int kmax = min(64, Mk - k0);
+      for (int kk = 0; kk < kmax; ++kk) {
+        double a = A[(long)(k0 + kk) * lda + j];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) acc[rr] += q[kk][rr] * a;
+      }
+    }
+  }
+  if (j < Kc)
+    for (int rr = 0; rr < nr; ++rr) mu[(long)(r0 + rr) * ldm + j] = acc[rr];
+}
+
+// ---- counter-based RNG (Philox4x32-10) + Box-Muller, one normal per element -------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ double philox_normal(uint64_t seed, uint32_t stream, uint64_t idx) {
+  uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), stream, 0x5eed5eedu};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  // 53-bit uniform in (0,1] and a 32-bit angle
+  uint64_t bits = ((uint64_t)c[0] << 21) ^ (uint64_t)(c[1] >> 11);
+  double u1 = ((double)(bits & ((1ull << 53) - 1)) + 1.0) * (1.0 / 9007199254740992.0);
+  double u2 = ((double)c[2] + 0.5) * (1.0 / 4294967296.0);
+  return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+}
+
+// 64 columns x R per block: phase 1 gathers the per-row-block partial sums (column-contiguous reads),
+// phase 2 writes the (column, r) pairs r-fastest == the N x (P*R) layout (contiguous writes).
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* vm = sm;                 // [R][65]
+  double* vv = sm + a.R * 65;      // [R][65]
+  const int j0 = blockIdx.x * 64, tid = threadIdx.x;
+  for (int idx = tid; idx < 64 * a.R; idx += 256) {
+    int jj = idx & 63, r = idx >> 6, j = j0 + jj;
+    double m = 0.0, v = 0.0;
+    if (j < a.Kc) {
+      double s1 = 0.0;
+      for (int b = 0; b < a.nrb1; ++b) s1 += a.s1p[(long)b * a.ldk + j];
+      double s2 = 0.0;
+      if (a.s2p)
+        for (int b = 0; b < a.nrb3; ++b) s2 += a.s2p[((long)r * a.nrb3 + b) * a.ldk + j];
+      double knn = a.knn_vec ? a.knn_vec[j] : a.knn_scalar;
+      v = (knn - s1) + s2;
+      m = a.mu[(long)r * a.ldk + j];
+      if (a.idm && r == 0) {
+        int n = j / a.P, p = j - n * a.P;
+        int oh = p / a.Wo, ow = p - oh * a.Wo;
+        int c0 = a.f / 2;
+        m += a.X[(((long)(n % a.n_mod) * a.H + oh * a.s + c0) * a.W + ow * a.s + c0) * a.C];
+      }
+    }
+    vm[r * 65 + jj] = m;
+    vv[r * 65 + jj] = v;
+  }
+  __syncthreads();
+  const int total = 64 * a.R;
+  for (int idx = tid; idx < total; idx += 256) {
+    int jj = idx / a.R, r = idx - jj * a.R, j = j0 + jj;
+    if (j >= a.Kc) continue;
+    double m = vm[r * 65 + jj], v = vv[r * 65 + jj];
+    long e = (long)j * a.R + r;
+    for (int s = 0; s < a.rep; ++s) {
+      long o = (long)s * a.rep_stride + e;
+      if (a.out_mean) a.out_mean[o] = m;
+      if (a.out_var) a.out_var[o] = v;
+      if (a.out_sample) {
+        double zz = a.z ? a.z[o] : philox_normal(a.seed, a.stream_id, (uint64_t)o);
+        a.out_sample[o] = m + zz * sqrt(v + a.jitter);
+      }
+    }
+  }
+}
+
+// ---- KL small terms: one block ------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void kl_small_kernel(const double* __restrict__ LpinvT, const double* __restrict__ Lp,
+                                                        const double* __restrict__ Lq, const double* __restrict__ qmu,
+                                                        const double* __restrict__ tp, long tp_count, int M, int Mp,
+                                                        int R, int white, double* __restrict__ kl4) {
+  __shared__ double red[4][1024];
+  const int tid = threadIdx.x;
+  double mah = 0.0, ldq = 0.0, ldp = 0.0, tr = 0.0;
+  for (int idx = tid; idx < M * R; idx += 1024) {
+    int i = idx % M, r = idx / M;
+    double al;
+    if (white) {
+      al = qmu[(long)i * R + r];
+    } else {
+      al = 0.0;   // alpha = inv(Lp) q_mu  (row i of inv(Lp) = column i of LpinvT, entries k <= i)
+      for (int k = 0; k <= i; ++k) al += LpinvT[(long)k * Mp + i] * qmu[(long)k * R + r];
+    }
+    mah += al * al;
+    double d = Lq[((long)r * Mp + i) * Mp + i];
+    ldq += log(d * d);
+  }
+  if (!white)
+    for (int i = tid; i < M; i += 1024) {
+      double d = Lp[(long)i * Mp + i];
+      ldp += log(d * d);
+    }
+  if (white) {
+    for (long idx = tid; idx < (long)R * Mp * Mp; idx += 1024) {
+      double v = Lq[idx];
+      tr += v * v;
+    }
+  } else {
+    for (long idx = tid; idx < tp_count; idx += 1024) tr += tp[idx];
+  }
+  red[0][tid] = mah; red[1][tid] = ldq; red[2][tid] = ldp; red[3][tid] = tr;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o)
+      for (int q = 0; q < 4; ++q) red[q][tid] += red[q][tid + o];
+    __syncthreads();
+  }
+  if (tid < 4) kl4[tid] = red[tid][0];
+}
+
+// ---- RobustMax variational expectations: 32 lanes per row, lane g < 20 owns one Gauss-Hermite node ----
+__global__ __launch_bounds__(256) void varexp_kernel(const double* __restrict__ mu, const double* __restrict__ var,
+                                                     const int32_t* __restrict__ y, int n_rows, int n_labels, int K,
+                                                     double eps, const double* __restrict__ gh,
+                                                     double* __restrict__ out, int predict) {
+  const int tid = threadIdx.x, g = tid & 31;
+  const int slot = blockIdx.x * 8 + (tid >> 5);
+  // predict mode: slot = row * K + class, output the class probability
+  const int row = predict ? slot / K : slot;
+  const int yi_p = predict ? slot % K : 0;
+  const bool live = row < n_rows;
+  double contrib = 0.0;
+  if (live && g < 20) {
+    const int yi = predict ? yi_p : y[row % n_labels];
+    const double* m = mu + (long)row * K;
+    const double* v = var + (long)row * K;
+    double t = m[yi] + gh[g] * sqrt(fmax(2.0 * v[yi], 1e-10));
+    double prod = 1.0;
+    for (int k = 0; k < K; ++k) {
+      if (k == yi) continue;
+      double dist = (t - m[k]) / sqrt(fmax(v[k], 1e-10));
+      double cdf = 0.5 * (1.0 + erf(dist * 0.70710678118654752440));
+      prod *= cdf * (1.0 - 2e-4) + 1e-4;
+    }
+    contrib = prod * gh[20 + g] * 0.56418958354775628695;   // w / sqrt(pi)
+  }
+  for (int o = 1; o < 32; o <<= 1) contrib += __shfl_xor(contrib, o);
+  if (live && g == 0) {
+    double p = contrib;
+    if (predict)
+      out[slot] = p * (1.0 - eps) + (1.0 - p) * (eps / (K - 1.0));
+    else
+      out[row] = p * log(1.0 - eps) + (1.0 - p) * log(eps / (K - 1.0));
+  }
+}
+
+__global__ __launch_bounds__(1024) void reduce_sum_kernel(const double* __restrict__ in, long n, double scale,
+                                                          double* __restrict__ out) {
+  __shared__ double red[1024];
+  double s = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) s += in[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+__global__ void reparam_kernel(const double* __restrict__ mean, const double* __restrict__ var,
+                               const double* __restrict__ z, size_t n, double jitter, double* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = mean[i] + z[i] * sqrt(var[i] + jitter);
+}
+
+// Gauss-Hermite nodes/weights (physicists' convention, numpy.polynomial.hermite.hermgauss) by Newton
+// iteration on the orthonormal recurrence.
+void hermgauss_host(int n, double* x, double* w) {
+  const double PIM4 = 0.7511255444649425;
+  const int m = (n + 1) / 2;
+  double z = 0.0;
+  for (int i = 0; i < m; ++i) {
+    if (i == 0) z = sqrt((double)(2 * n + 1)) - 1.85575 * pow((double)(2 * n + 1), -0.16667);
+    else if (i == 1) z -= 1.14 * pow((double)n, 0.426) / z;
+    else if (i == 2) z = 1.86 * z - 0.86 * x[0];
+    else if (i == 3) z = 1.91 * z - 0.91 * x[1];
+    else z = 2.0 * z - x[i - 2];
+    double pp = 0.0;
+    for (int it = 0; it < 100; ++it) {
+      double p1 = PIM4, p2 = 0.0;
+      for (int j = 0; j < n; ++j) {
+        double p3 = p2;
+        p2 = p1;
+        p1 = z * sqrt(2.0 / (j + 1)) * p2 - sqrt((double)j / (j + 1)) * p3;
+      }
+      pp = sqrt(2.0 * n) * p2;
+      double z1 = z;
+      z = z1 - p1 / pp;
+      if (fabs(z - z1) <= 1e-15 * fmax(1.0, fabs(z))) break;
+    }
+    x[i] = z;
+    x[n - 1 - i] = -z;
+    w[i] = 2.0 / (pp * pp);
+    w[n - 1 - i] = w[i];
+  }
+}
+
+}  // namespace
+
+const double* gauss_hermite_table(dcgp_ctx* ctx) {
+  auto it = ctx->ws.find("gh20");
+  if (it != ctx->ws.end()) return (const double*)it->second.first;
+  double* d = (double*)ws_get(ctx, "gh20", 40 * sizeof(double));
+  if (!d) return nullptr;
+  double h[40];
+  hermgauss_host(20, h, h + 20);
+  // ascending node order like numpy (irrelevant for the sum, kept for readability of dumps)
+  for (int i = 0; i < 10; ++i) {
+    double tx = h[i]; h[i] = h[19 - i]; h[19 - i] = tx;
+    double tw = h[20 + i]; h[20 + i] = h[39 - i]; h[39 - i] = tw;
+  }
+  hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream);
+  hipStreamSynchronize(ctx->stream);
+  return d;
+}
+
+int reduce_sum(dcgp_ctx* ctx, const double* in, long n, double scale, double* out) {
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, in, n, scale, out);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
+int varexp_rows(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t* y, int n_rows, int n_labels, int K,
+                double eps, double* out_rows, int predict) {
+  const double* gh = gauss_hermite_table(ctx);
+  if (!gh) return DCGP_ERR_ALLOC;
+  long slots = predict ? (long)n_rows * K : n_rows;
+  hipLaunchKernelGGL(varexp_kernel, dim3((unsigned)((slots + 7) / 8)), dim3(256), 0, ctx->stream, mu, var, y, n_rows,
+                     n_labels, K, eps, gh, out_rows, predict);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
+int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, int white, bool have_qsqrt,
+              const char* pfx, CondScratch* out) {
+  const int Mp = g.Mp, R = g.R;
+  const int BM = gemm_row_block(Mp), nrb = (Mp + BM - 1) / BM;
+  std::string p(pfx);
+  CondScratch sc;
+  sc.ldb = ldb;
+  sc.nrb1 = sc.nrb3 = nrb;
+  sc.A1 = (double*)ws_get(ctx, p + "A1", (size_t)Mp * ldb * sizeof(double));
+  sc.A2 = white ? sc.A1 : (double*)ws_get(ctx, p + "A2", (size_t)Mp * ldb * sizeof(double));
+  sc.s1p = (double*)ws_get(ctx, p + "s1p", (size_t)nrb * ldb * sizeof(double));
+  sc.s2p = have_qsqrt ? (double*)ws_get(ctx, p + "s2p", (size_t)R * nrb * ldb * sizeof(double)) : nullptr;
+  sc.mu = (double*)ws_get(ctx, p + "mu", (size_t)R * ldb * sizeof(double));
+  if (!sc.A1 || !sc.A2 || !sc.s1p || !sc.mu || (have_qsqrt && !sc.s2p)) return DCGP_ERR_ALLOC;
+  {
+    ScopedTimer t(ctx, "gemm_cond_s1");
+    GemmArgs a;
+    a.Wt = g.LinvT; a.ldw = Mp;
+    a.B = B; a.ldb = (int)ldb;
+    a.C = sc.A1; a.ldc = (int)ldb;
+    a.colsq = sc.s1p; a.sRowBlk = ldb;
+    a.Mi = Mp; a.Mk = Mp; a.Kc = Kc; a.tri = 1;
+    DCGP_TRY(gemm_tn(ctx, a, nullptr));
+  }
+  if (!white) {
+    ScopedTimer t(ctx, "gemm_cond_s2");
+    GemmArgs a;
+    a.Wt = g.Linv; a.ldw = Mp;
+    a.B = sc.A1; a.ldb = (int)ldb;
+    a.C = sc.A2; a.ldc = (int)ldb;
+    a.Mi = Mp; a.Mk = Mp; a.Kc = Kc; a.tri = 2;
+    DCGP_TRY(gemm_tn(ctx, a, nullptr));
+  }
+  if (have_qsqrt) {
+    ScopedTimer t(ctx, "gemm_cond_s3");
+    GemmArgs a;
+    a.Wt = g.Lq; a.ldw = Mp; a.wBatch = (long)Mp * Mp; a.nW = R;
+    a.B = sc.A2; a.ldb = (int)ldb;
+    a.colsq = sc.s2p; a.sBatch = (long)nrb * ldb; a.sRowBlk = ldb;
+    a.Mi = Mp; a.Mk = Mp; a.Kc = Kc; a.tri = 2;
+    DCGP_TRY(gemm_tn(ctx, a, nullptr));
+  }
+  {
+    ScopedTimer t(ctx, "cond_mean");
+    dim3 grid((Kc + 255) / 256, (R + 7) / 8);
+    hipLaunchKernelGGL(mean_kernel, grid, dim3(256), 0, ctx->stream, sc.A2, ldb, Mp, g.qmu, R, sc.mu, ldb, Kc);
+    LAUNCH_CHECK(ctx);
+  }
+  *out = sc;
+  return DCGP_OK;
+}
+
+int finalize_layer(dcgp_ctx* ctx, const FinalizeArgs& a) {
+  if (a.Kc <= 0) return DCGP_OK;
+  ScopedTimer t(ctx, "finalize");
+  size_t lds = (size_t)2 * a.R * 65 * sizeof(double);
+  if (lds > 150 * 1024) return ctx_fail(ctx, DCGP_ERR_ARG, "finalize: R=%d too large", a.R);
+  hipLaunchKernelGGL(finalize_kernel, dim3((a.Kc + 63) / 64), dim3(256), lds, ctx->stream, a);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
+int kl_layer(dcgp_ctx* ctx, const GpMats& g, const double* Lp, const double* LpinvT, int white, const char* pfx,
+             double* kl4) {
+  const int Mp = g.Mp, R = g.R;
+  double* tp = nullptr;
+  long tp_count = 0;
+  if (!white) {
+    const int BM = gemm_row_block(Mp), nrb = (Mp + BM - 1) / BM;
+    tp_count = (long)R * nrb * Mp;
+    tp = (double*)ws_get(ctx, std::string(pfx) + "kl_tp", (size_t)tp_count * sizeof(double));
+    if (!tp) return DCGP_ERR_ALLOC;
+    ScopedTimer t(ctx, "gemm_kl");
+    GemmArgs a;   // || inv(Lp) Lq_r ||_F^2 for every r
+    a.Wt = LpinvT; a.ldw = Mp;
+    a.B = g.Lq; a.ldb = Mp; a.bBatch = (long)Mp * Mp; a.nB = R;
+    a.colsq = tp; a.sBatch = (long)nrb * Mp; a.sRowBlk = Mp;
+    a.Mi = Mp; a.Mk = Mp; a.Kc = Mp; a.tri = 1; a.b_lower = 1;
+    DCGP_TRY(gemm_tn(ctx, a, nullptr));
+  }
+  hipLaunchKernelGGL(kl_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, LpinvT, Lp, g.Lq, g.qmu, tp, tp_count, g.M,
+                     Mp, R, white, kl4);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
+int reparam_async(dcgp_ctx* ctx, const double* mean, const double* var, const double* z, size_t n, double jitter,
+                  double* out) {
+  if (n == 0) return DCGP_OK;
+  hipLaunchKernelGGL(reparam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, mean, var, z, n,
+                     jitter, out);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
+extern "C" int dcgp_reparam(dcgp_ctx* ctx, const double* mean, const double* var, const double* z, size_t n,
+                            double jitter, double* out) {
+  if (!ctx || !mean || !var || !z || !out) return ctx ? ctx_fail(ctx, DCGP_ERR_ARG, "reparam: null pointer") : DCGP_ERR_ARG;
+  if (n == 0) return DCGP_OK;
+  hipLaunchKernelGGL(reparam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, mean, var, z, n,
+                     jitter, out);
+  LAUNCH_CHECK(ctx);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}
+
+extern "C" int dcgp_robustmax_varexp(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t* y, int n, int K,
+                                     double eps, double* out_n) {
+  if (!ctx || !mu || !var || !y || !out_n || n <= 0 || K < 2)
+    return ctx ? ctx_fail(ctx, DCGP_ERR_ARG, "robustmax_varexp: bad args") : DCGP_ERR_ARG;
+  DCGP_TRY(varexp_rows(ctx, mu, var, y, n, n, K, eps, out_n, 0));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}
+
+extern "C" int dcgp_robustmax_predict(dcgp_ctx* ctx, const double* mu, const double* var, int n, int K, double eps,
+                                      double* out_p) {
+  if (!ctx || !mu || !var || !out_p || n <= 0 || K < 2)
+    return ctx ? ctx_fail(ctx, DCGP_ERR_ARG, "robustmax_predict: bad args") : DCGP_ERR_ARG;
+  DCGP_TRY(varexp_rows(ctx, mu, var, nullptr, n, 1, K, eps, out_p, 1));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}

@@ -1,0 +1,200 @@
+// Context, memory, error and HIP-event timing plumbing of libdcgp.so.
+#include <cstdarg>
+#include <cstring>
+
+#include "common.h"
+
+int ctx_fail(dcgp_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+void* ws_get(dcgp_ctx* ctx, const std::string& name, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  auto it = ctx->ws.find(name);
+  if (it != ctx->ws.end() && it->second.second >= bytes) return it->second.first;
+  if (it != ctx->ws.end()) {
+    // in-flight kernels may still use the old buffer
+    hipStreamSynchronize(ctx->stream);
+    hipFree(it->second.first);
+    ctx->ws.erase(it);
+  }
+  void* p = nullptr;
+  size_t cap = (bytes + 255) / 256 * 256;
+  if (hipMalloc(&p, cap) != hipSuccess) {
+    ctx_fail(ctx, DCGP_ERR_ALLOC, "workspace '%s': hipMalloc(%zu) failed", name.c_str(), cap);
+    return nullptr;
+  }
+  ctx->ws[name] = {p, cap};
+  return p;
+}
+
+ScopedTimer::ScopedTimer(dcgp_ctx* c, const char* name) : ctx(c), on(c->timing) {
+  if (!on) return;
+  pe.name = name;
+  auto take = [&](hipEvent_t& e) {
+    if (!ctx->event_pool.empty()) {
+      e = ctx->event_pool.back();
+      ctx->event_pool.pop_back();
+    } else {
+      hipEventCreate(&e);
+    }
+  };
+  take(pe.start);
+  take(pe.stop);
+  hipEventRecord(pe.start, ctx->stream);
+}
+ScopedTimer::~ScopedTimer() {
+  if (!on) return;
+  hipEventRecord(pe.stop, ctx->stream);
+  ctx->pending.push_back(pe);
+}
+
+void timing_flush(dcgp_ctx* ctx) {
+  if (ctx->pending.empty()) return;
+  hipStreamSynchronize(ctx->stream);
+  for (auto& pe : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
+      auto& acc = ctx->tim[pe.name];
+      acc.launches += 1;
+      acc.ms += ms;
+    }
+    ctx->event_pool.push_back(pe.start);
+    ctx->event_pool.push_back(pe.stop);
+  }
+  ctx->pending.clear();
+}
+
+extern "C" {
+
+int dcgp_device_count(int* count) {
+  if (!count) return DCGP_ERR_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  *count = n;
+  return DCGP_OK;
+}
+
+int dcgp_ctx_create(int device, dcgp_ctx** out) {
+  if (!out) return DCGP_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return DCGP_ERR_HIP;
+  if (hipSetDevice(device) != hipSuccess) return DCGP_ERR_HIP;
+  dcgp_ctx* c = new dcgp_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return DCGP_ERR_HIP;
+  }
+  if (hipHostMalloc((void**)&c->h_scratch, 64 * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_info, 16 * sizeof(int)) != hipSuccess) {
+    hipStreamDestroy(c->stream);
+    delete c;
+    return DCGP_ERR_ALLOC;
+  }
+  *out = c;
+  return DCGP_OK;
+}
+
+int dcgp_ctx_destroy(dcgp_ctx* ctx) {
+  if (!ctx) return DCGP_ERR_ARG;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  dcgp_comm_destroy(ctx);
+  for (auto& kv : ctx->ws) hipFree(kv.second.first);
+  for (auto& pe : ctx->pending) {
+    hipEventDestroy(pe.start);
+    hipEventDestroy(pe.stop);
+  }
+  for (auto e : ctx->event_pool) hipEventDestroy(e);
+  hipHostFree(ctx->h_scratch);
+  hipHostFree(ctx->h_info);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return DCGP_OK;
+}
+
+const char* dcgp_last_error(dcgp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int dcgp_malloc(dcgp_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx || !dptr) return DCGP_ERR_ARG;
+  *dptr = nullptr;
+  if (bytes == 0) bytes = 16;
+  if (hipMalloc(dptr, bytes) != hipSuccess) return ctx_fail(ctx, DCGP_ERR_ALLOC, "hipMalloc(%zu) failed", bytes);
+  return DCGP_OK;
+}
+int dcgp_free(dcgp_ctx* ctx, void* dptr) {
+  if (!ctx) return DCGP_ERR_ARG;
+  if (!dptr) return DCGP_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipFree(dptr));
+  return DCGP_OK;
+}
+int dcgp_h2d(dcgp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return DCGP_ERR_ARG;
+  if (!bytes) return DCGP_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}
+int dcgp_d2h(dcgp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return DCGP_ERR_ARG;
+  if (!bytes) return DCGP_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}
+int dcgp_memset(dcgp_ctx* ctx, void* dptr, int value, size_t bytes) {
+  if (!ctx || (bytes && !dptr)) return DCGP_ERR_ARG;
+  if (!bytes) return DCGP_OK;
+  HIP_TRY(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}
+int dcgp_sync(dcgp_ctx* ctx) {
+  if (!ctx) return DCGP_ERR_ARG;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}
+
+int dcgp_timing_enable(dcgp_ctx* ctx, int on) {
+  if (!ctx) return DCGP_ERR_ARG;
+  timing_flush(ctx);
+  ctx->timing = on != 0;
+  return DCGP_OK;
+}
+int dcgp_timing_reset(dcgp_ctx* ctx) {
+  if (!ctx) return DCGP_ERR_ARG;
+  timing_flush(ctx);
+  ctx->tim.clear();
+  return DCGP_OK;
+}
+int dcgp_timing_query(dcgp_ctx* ctx, const char* name, int* launches, double* total_ms) {
+  if (!ctx || !name) return DCGP_ERR_ARG;
+  timing_flush(ctx);
+  auto it = ctx->tim.find(name);
+  if (launches) *launches = it == ctx->tim.end() ? 0 : it->second.launches;
+  if (total_ms) *total_ms = it == ctx->tim.end() ? 0.0 : it->second.ms;
+  return DCGP_OK;
+}
+int dcgp_timing_names(dcgp_ctx* ctx, char* buf, size_t buflen) {
+  if (!ctx || !buf || buflen == 0) return DCGP_ERR_ARG;
+  timing_flush(ctx);
+  std::string s;
+  for (auto& kv : ctx->tim) {
+    if (!s.empty()) s += ";";
+    s += kv.first;
+  }
+  strncpy(buf, s.c_str(), buflen - 1);
+  buf[buflen - 1] = 0;
+  return DCGP_OK;
+}
+
+}  // extern "C"

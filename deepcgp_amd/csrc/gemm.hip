@@ -1,0 +1,227 @@
+// gemm.hip -- the matrix-core workhorse of the conditional (conv_gp/conditionals.py:31-65).
+//
+//   C[i][j] = sum_k Wt[k][i] * B[k][j]        (fp64, v_mfma_f64_16x16x4_f64)
+//
+// Both operands are k-major so that every LDS fill is a plain row copy and every MFMA operand read
+// is a 16-double contiguous ds_read_b64 group.  W may be lower/upper triangular (the triangular
+// solves of the reference are applied as products with the inverted factor, and L_r^T A is an
+// upper-triangular product): k tiles that are structurally zero are skipped per workgroup AND per
+// wave.  The epilogue optionally stores C and/or reduces sum_i C[i][j]^2 per column (the
+// reduce_sum(square(A), 1) / reduce_sum(square(LTA), 1) of conditionals.py:40,65) so the
+// R x M x (P*N) intermediate of the reference is never materialised.
+//
+// Tile: BM x BN output per workgroup, BK = 16; waves in a WAVES_M x WAVES_N grid, each owning
+// FM x FN 16x16 accumulator fragments (4 f64 per lane each).  Register-staged double buffering:
+// the global loads of k-tile t+1 are issued before the MFMAs of k-tile t and written to the other
+// LDS buffer afterwards -- one barrier per k-tile.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+__host__ __device__ constexpr int lds_ld(int b) { return (b % 32 == 0) ? b + 16 : b + 32; }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(GemmArgs a, int n_col_tiles,
+                                                                         int n_row_blocks) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int WMR = BM / WAVES_M, WNC = BN / WAVES_N;   // wave tile
+  constexpr int FM = WMR / 16, FN = WNC / 16;
+  constexpr int LDW = lds_ld(BM), LDB = lds_ld(BN);
+  constexpr int W_CHUNKS = BK * BM / 2, B_CHUNKS = BK * BN / 2;   // 16-byte chunks per tile
+  constexpr int NLW = (W_CHUNKS + NT - 1) / NT, NLB = (B_CHUNKS + NT - 1) / NT;
+  static_assert(W_CHUNKS % NT == 0 || W_CHUNKS < NT, "W tile / thread mismatch");
+  static_assert(B_CHUNKS % NT == 0, "B tile / thread mismatch");
+
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Ws = smem;                       // [2][BK][LDW]
+  double* Bs = smem + 2 * BK * LDW;        // [2][BK][LDB]
+
+  // ---- XCD-aware decode: workgroups that share a B column strip (all batches / row blocks of one
+  // column tile) get consecutive ids on ONE XCD (dispatch places linear id b on XCD b % 8).
+  const int batch = a.nW * a.nB;
+  const long nwg = (long)n_col_tiles * n_row_blocks * batch;
+  long orig = blockIdx.x;
+  long q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+  long wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+  const int inner = n_row_blocks * batch;
+  const int ct = (int)(wgid / inner);
+  int rem = (int)(wgid % inner);
+  // heavy (long-k) row blocks first within a column strip
+  const int bz = rem / n_row_blocks;
+  int rb = rem % n_row_blocks;
+  if (a.tri == 1) rb = n_row_blocks - 1 - rb;
+  const int iw = bz / a.nB, ib = bz % a.nB;
+
+  const int i0 = rb * BM, j0 = ct * BN;
+  const double* __restrict__ Wt = a.Wt + (long)iw * a.wBatch;
+  const double* __restrict__ Bm = a.B + (long)ib * a.bBatch;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int lrow = lane >> 4, lcol = lane & 15;
+
+  // k range of this workgroup (multiples of BK)
+  int klo = 0, khi = a.Mk;
+  if (a.tri == 1) khi = min(a.Mk, i0 + BM);
+  if (a.tri == 2) klo = min(i0, a.Mk);
+  if (a.b_lower) klo = max(klo, (j0 / BK) * BK);
+  const int wave_i_lo = i0 + wm * WMR, wave_i_hi = wave_i_lo + WMR - 1;
+
+  d4 acc[FM][FN];
+#pragma unroll
+  for (int x = 0; x < FM; ++x)
+#pragma unroll
+    for (int y = 0; y < FN; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+
+  double2 rw[NLW], rbv[NLB];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int c = 0; c < NLW; ++c) {
+      int ch = tid + c * NT;
+      rw[c] = double2{0.0, 0.0};
+      if (ch < W_CHUNKS) {
+        int row = ch / (BM / 2), col = (ch % (BM / 2)) * 2;
+        int k = k0 + row, i = i0 + col;
+        if (k < a.Mk && i < a.Mi) rw[c] = *reinterpret_cast<const double2*>(Wt + (long)k * a.ldw + i);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NLB; ++c) {
+      int ch = tid + c * NT;
+      int row = ch / (BN / 2), col = (ch % (BN / 2)) * 2;
+      int k = k0 + row, j = j0 + col;
+      rbv[c] = double2{0.0, 0.0};
+      if (k < a.Mk && j < a.Kc) rbv[c] = *reinterpret_cast<const double2*>(Bm + (long)k * a.ldb + j);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    double* w = Ws + buf * BK * LDW;
+    double* b = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int c = 0; c < NLW; ++c) {
+      int ch = tid + c * NT;
+      if (ch < W_CHUNKS) {
+        int row = ch / (BM / 2), col = (ch % (BM / 2)) * 2;
+        *reinterpret_cast<double2*>(w + row * LDW + col) = rw[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NLB; ++c) {
+      int ch = tid + c * NT;
+      int row = ch / (BN / 2), col = (ch % (BN / 2)) * 2;
+      *reinterpret_cast<double2*>(b + row * LDB + col) = rbv[c];
+    }
+  };
+
+  if (klo < khi) {
+    load_tile(klo);
+    store_tile(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = klo; k0 < khi; k0 += BK) {
+    const bool has_next = k0 + BK < khi;
+    if (has_next) load_tile(k0 + BK);
+    // per-wave structural-zero skip inside the diagonal region
+    bool need = true;
+    if (a.tri == 1 && k0 > wave_i_hi) need = false;
+    if (a.tri == 2 && k0 + BK - 1 < wave_i_lo) need = false;
+    if (need) {
+      const double* w = Ws + buf * BK * LDW + wm * WMR + lcol;
+      const double* b = Bs + buf * BK * LDB + wn * WNC + lcol;
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 4) {
+        double av[FM], bv[FN];
+#pragma unroll
+        for (int x = 0; x < FM; ++x) av[x] = w[(kk + lrow) * LDW + x * 16];
+#pragma unroll
+        for (int y = 0; y < FN; ++y) bv[y] = b[(kk + lrow) * LDB + y * 16];
+#pragma unroll
+        for (int x = 0; x < FM; ++x)
+#pragma unroll
+          for (int y = 0; y < FN; ++y)
+            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
+      }
+    }
+    if (has_next) store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------
+  const int bzl = iw * a.nB + ib;
+  if (a.C) {
+    double* C = a.C + (long)bzl * a.cBatch;
+#pragma unroll
+    for (int x = 0; x < FM; ++x)
+#pragma unroll
+      for (int y = 0; y < FN; ++y) {
+        int j = j0 + wn * WNC + y * 16 + lcol;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          int i = wave_i_lo + x * 16 + lrow + 4 * v;
+          if (i < a.Mi && j < a.Kc) C[(long)i * a.ldc + j] = acc[x][y][v];
+        }
+      }
+  }
+  if (a.colsq) {
+    // per-lane partial over this wave's rows, then over the 4 lane groups, then over WAVES_M via LDS
+    __syncthreads();   // LDS tiles are dead; reuse as [WAVES_M][BN]
+    double* red = smem;
+#pragma unroll
+    for (int y = 0; y < FN; ++y) {
+      double s = 0.0;
+#pragma unroll
+      for (int x = 0; x < FM; ++x)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) s += acc[x][y][v] * acc[x][y][v];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lrow == 0) red[wm * BN + wn * WNC + y * 16 + lcol] = s;
+    }
+    __syncthreads();
+    if (tid < BN) {
+      double s = 0.0;
+#pragma unroll
+      for (int m = 0; m < WAVES_M; ++m) s += red[m * BN + tid];
+      int j = j0 + tid;
+      if (j < a.Kc) a.colsq[(long)bzl * a.sBatch + (long)rb * a.sRowBlk + j] = s;
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
+  const int nct = (a.Kc + BN - 1) / BN, nrb = (a.Mi + BM - 1) / BM;
+  if (nrb_out) *nrb_out = nrb;
+  const long nwg = (long)nct * nrb * a.nW * a.nB;
+  if (nwg == 0) return DCGP_OK;
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  size_t lds = (size_t)(2 * BK * lds_ld(BM) + 2 * BK * lds_ld(BN)) * sizeof(double);
+  size_t red = (size_t)WAVES_M * BN * sizeof(double);
+  if (red > lds) lds = red;
+  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WAVES_M, WAVES_N>), dim3((unsigned)nwg), dim3(NT), lds, ctx->stream,
+                     a, nct, nrb);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
+}  // namespace
+
+int gemm_row_block(int Mi) { return Mi >= 128 ? 128 : (Mi >= 64 ? 64 : (Mi >= 32 ? 32 : 16)); }
+
+int gemm_tn(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
+  if (!a.Wt || !a.B || a.Mi <= 0 || a.Mk <= 0 || a.Kc <= 0) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_tn: bad args");
+  // operands are fetched as 16-byte pairs: rows must be 16-byte aligned, and an odd column count needs
+  // one column of (ignored) padding behind it
+  if ((a.ldw & 1) || (a.ldb & 1) || (a.Mi & 1) || ((a.Kc & 1) && a.ldb <= a.Kc))
+    return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_tn: leading dimensions / extents must be even");
+  switch (gemm_row_block(a.Mi)) {
+    case 128: return launch<128, 128, 4, 2>(ctx, a, nrb_out);
+    case 64: return launch<64, 128, 2, 2>(ctx, a, nrb_out);
+    case 32: return launch<32, 128, 1, 2>(ctx, a, nrb_out);
+    default: return launch<16, 128, 1, 2>(ctx, a, nrb_out);
+  }
+}

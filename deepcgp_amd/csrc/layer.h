@@ -1,0 +1,64 @@
+// Internal: device-resident state of one GP layer and the shared forward building blocks.
+#pragma once
+#include "common.h"
+
+// Geometry of a patch view (FullView, conv_gp/views.py:20-30,56-68)
+struct ViewGeom {
+  int H = 0, W = 0, C = 0, f = 0, s = 0, Ho = 0, Wo = 0, P = 0, L = 0;
+  void set(int H_, int W_, int C_, int f_, int s_) {
+    H = H_; W = W_; C = C_; f = f_; s = s_;
+    Ho = (H - f) / s + 1; Wo = (W - f) / s + 1; P = Ho * Wo; L = f * f * C;
+  }
+};
+
+// Padded M x M operands of one layer ([Mp x Mp], ld = Mp) living in device memory.
+struct GpMats {
+  int M = 0, Mp = 0, R = 0;
+  double* K = nullptr;      // Kuu (live Z) -> overwritten by its Cholesky factor L
+  double* Linv = nullptr;   // inv(L)
+  double* LinvT = nullptr;  // inv(L)^T
+  double* Kp = nullptr;     // prior Kuu(Z0) -> its factor (conv layers, non-white); may alias K
+  double* Lpinv = nullptr;
+  double* LpinvT = nullptr;
+  double* Lq = nullptr;     // [R][Mp][Mp] lower-masked q_sqrt, zero padded
+  double* qmu = nullptr;    // [Mp][R], zero padded rows
+};
+
+// A = inv(L) Kuf etc. on a k-major Kuf matrix B [Mp x ldb] with Kc columns.
+// Produces partial column sums s1p [nrb1][ldb], s2p [R][nrb3][ldb], and mu [R][ldb].
+struct CondScratch {
+  double *A1 = nullptr, *A2 = nullptr, *s1p = nullptr, *s2p = nullptr, *mu = nullptr;
+  int nrb1 = 0, nrb3 = 0;
+  long ldb = 0;
+};
+int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, int white, bool have_qsqrt,
+              const char* ws_prefix, CondScratch* out);
+
+struct FinalizeArgs {
+  const double* s1p = nullptr; int nrb1 = 0;
+  const double* s2p = nullptr; int nrb3 = 0;    // nullptr -> no q_sqrt term
+  const double* mu = nullptr;
+  long ldk = 0;                  // leading dimension (padded column count) of the above
+  int Kc = 0, R = 0;
+  double knn_scalar = 0.0; const double* knn_vec = nullptr;   // Knn per column (vector wins if set)
+  // output: element (j, r) of replica s at  s*rep_stride + j*R + r
+  int rep = 1; long rep_stride = 0;
+  const double* z = nullptr;     // same indexing as the output; nullptr + want sample -> device RNG
+  uint64_t seed = 0; uint32_t stream_id = 0;
+  double jitter = 0.0;
+  double *out_sample = nullptr, *out_mean = nullptr, *out_var = nullptr;
+  // Conv2dMean (conv_gp/mean_functions.py:28-41): adds the centre pixel of channel 0 to map r == 0
+  const double* X = nullptr; int idm = 0; int n_mod = 0; int H = 0, W = 0, C = 0, f = 0, s = 0, Wo = 0, P = 0;
+};
+int finalize_layer(dcgp_ctx* ctx, const FinalizeArgs& a);
+
+// KL pieces of one layer -> kl4[0..3] = {mahalanobis, logdet_q, logdet_p, trace} (device)
+int kl_layer(dcgp_ctx* ctx, const GpMats& g, const double* Lp, const double* LpinvT, int white, const char* ws_prefix,
+             double* kl4);
+
+int varexp_rows(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t* y, int n_rows, int n_labels, int K,
+                double eps, double* out_rows, int predict);
+const double* gauss_hermite_table(dcgp_ctx* ctx);   // [40]: 20 nodes then 20 weights (device)
+
+// deterministic single-block sum of n doubles, scaled: out[0] = scale * sum
+int reduce_sum(dcgp_ctx* ctx, const double* in, long n, double scale, double* out);

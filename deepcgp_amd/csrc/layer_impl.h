@@ -1,0 +1,181 @@
+// Internal (header-only): device-resident layer state and the per-layer forward building blocks
+// shared by model.hip (model-level path) and ops.hip (single-operator C-ABI entry points).
+#pragma once
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "layer.h"
+
+int additive_kdiag_async(dcgp_ctx* ctx, int N, int P, double variance, const double* w, double* out_N);
+int reparam_async(dcgp_ctx* ctx, const double* mean, const double* var, const double* z, size_t n, double jitter,
+                  double* out);
+int allreduce_sum_f64_async(dcgp_ctx* ctx, double* buf_dev, int n);
+
+struct LayerState {
+  dcgp_ctx* ctx = nullptr;
+  bool is_head = false;
+  ViewGeom v;
+  int M = 0, Mp = 0, R = 0, Lp = 0;
+  int white = 0, identity_mean = 0, kernel_type = 0;
+  double variance = 1.0, ls = 1.0;
+  bool has_qsqrt = true;
+  // parameters in the caller's layout (device)
+  double *Z = nullptr, *Z0 = nullptr, *q_mu = nullptr, *q_sqrt = nullptr, *w = nullptr;
+  // derived every step
+  GpMats g;
+  double *ZT = nullptr, *zn = nullptr;
+  std::vector<void*> owned;
+
+  ~LayerState() {
+    for (void* p : owned) hipFree(p);
+  }
+  double* dalloc(size_t n_doubles) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (n_doubles ? n_doubles : 2) * sizeof(double)) != hipSuccess) return nullptr;
+    owned.push_back(p);
+    return (double*)p;
+  }
+  int init(dcgp_ctx* c, bool head, int H, int W, int C, int f, int s, int M_, int R_, int white_, int idm, int ktype,
+           double var, double ls_, bool need_prior = true) {
+    ctx = c; is_head = head;
+    if (H <= 0 || W <= 0 || C <= 0 || f <= 0 || s <= 0 || f > H || f > W || M_ <= 0 || R_ <= 0)
+      return ctx_fail(c, DCGP_ERR_ARG, "layer: bad geometry H=%d W=%d C=%d f=%d s=%d M=%d R=%d", H, W, C, f, s, M_, R_);
+    if (!(var > 0.0) || !(ls_ > 0.0)) return ctx_fail(c, DCGP_ERR_ARG, "layer: variance and lengthscale must be > 0");
+    v.set(H, W, C, f, s);
+    M = M_; R = R_; white = white_; identity_mean = idm; kernel_type = ktype; variance = var; ls = ls_;
+    Mp = round_up(M, 16);
+    Lp = round_up(v.L, 4);
+    g.M = M; g.Mp = Mp; g.R = R;
+    size_t mm = (size_t)Mp * Mp;
+    Z = dalloc((size_t)M * v.L);
+    Z0 = head ? nullptr : dalloc((size_t)M * v.L);
+    q_mu = dalloc((size_t)M * R);
+    q_sqrt = dalloc((size_t)R * M * M);
+    w = head ? dalloc(v.P) : nullptr;
+    g.K = dalloc(mm); g.Linv = dalloc(mm); g.LinvT = dalloc(mm);
+    if (!head && !white && need_prior) { g.Kp = dalloc(mm); g.Lpinv = dalloc(mm); g.LpinvT = dalloc(mm); }
+    g.Lq = dalloc((size_t)R * mm);
+    g.qmu = dalloc((size_t)Mp * R);
+    ZT = dalloc((size_t)Lp * Mp);
+    zn = dalloc(Mp);
+    for (void* p : owned)
+      if (!p) return ctx_fail(c, DCGP_ERR_ALLOC, "layer: device allocation failed");
+    return DCGP_OK;
+  }
+  int upload(double* dst, const double* src_host, size_t n) {
+    if (!src_host) return ctx_fail(ctx, DCGP_ERR_ARG, "layer: null parameter array");
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src_host, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DCGP_OK;
+  }
+  // step 1 of the forward: everything that depends only on this layer's parameters
+  int prepare(double jitter) {
+    const double inv_l2 = 1.0 / (ls * ls);
+    DCGP_TRY(rbf_gram_padded(ctx, Z, M, v.L, variance, inv_l2, jitter, g.K, Mp, Mp));
+    if (g.Kp) DCGP_TRY(rbf_gram_padded(ctx, Z0, M, v.L, variance, inv_l2, jitter, g.Kp, Mp, Mp));
+    DCGP_TRY(z_transpose_norms(ctx, Z, M, v.L, ZT, Mp, Lp, zn));
+    if (has_qsqrt)
+      DCGP_TRY(pad_copy(ctx, q_sqrt, M, M, M, g.Lq, Mp, Mp, Mp, 1, R, (long)M * M, (long)Mp * Mp));
+    DCGP_TRY(pad_copy(ctx, q_mu, M, R, R, g.qmu, R, Mp, R, 0, 1, 0, 0));
+    return DCGP_OK;
+  }
+};
+
+// batched factorisation of a set of [Mp x Mp] matrices that share Mp
+struct FactorGroup {
+  int Mp = 0;
+  std::vector<double*> K, Linv, LinvT;
+  double **dK = nullptr, **dLinv = nullptr, **dLinvT = nullptr;
+  int* d_info = nullptr;
+  bool uploaded = false;
+  void release() {
+    if (dK) hipFree(dK);
+    if (dLinv) hipFree(dLinv);
+    if (dLinvT) hipFree(dLinvT);
+    if (d_info) hipFree(d_info);
+    dK = dLinv = dLinvT = nullptr; d_info = nullptr; uploaded = false;
+  }
+  int upload(dcgp_ctx* ctx) {
+    if (uploaded) return DCGP_OK;
+    const size_t n = K.size();
+    if (hipMalloc((void**)&dK, n * sizeof(double*)) != hipSuccess || hipMalloc((void**)&dLinv, n * sizeof(double*)) != hipSuccess ||
+        hipMalloc((void**)&dLinvT, n * sizeof(double*)) != hipSuccess || hipMalloc((void**)&d_info, n * sizeof(int)) != hipSuccess)
+      return ctx_fail(ctx, DCGP_ERR_ALLOC, "factor group: allocation failed");
+    HIP_TRY(ctx, hipMemcpy(dK, K.data(), n * sizeof(double*), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dLinv, Linv.data(), n * sizeof(double*), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dLinvT, LinvT.data(), n * sizeof(double*), hipMemcpyHostToDevice));
+    uploaded = true;
+    return DCGP_OK;
+  }
+  int run(dcgp_ctx* ctx) {
+    DCGP_TRY(upload(ctx));
+    DCGP_TRY(potrf_batched(ctx, dK, nullptr, (int)K.size(), Mp, Mp, d_info));
+    DCGP_TRY(trtri_batched(ctx, dK, dLinv, dLinvT, (int)K.size(), Mp, Mp));
+    return DCGP_OK;
+  }
+};
+
+// ConvLayer.conditional_ND (+ sampling) on `rows` input images taken as X[(n % n_mod)]
+static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, int rows, int n_mod, int rep, long rep_stride,
+                 const double* z, uint64_t seed, uint32_t stream_id, double jitter, double* out_sample, double* out_mean,
+                 double* out_var, const std::string& pfx) {
+  const int Mp = L.Mp, P = L.v.P;
+  const long Kc = (long)rows * P;
+  if (Kc > 0x7fffff00L) return ctx_fail(ctx, DCGP_ERR_ARG, "conv layer: %ld patch columns exceed the 32-bit tile index", Kc);
+  const long ldb = round_up_l(Kc, 128);
+  double* B = (double*)ws_get(ctx, pfx + "Kuf", (size_t)Mp * ldb * sizeof(double));
+  if (!B) return DCGP_ERR_ALLOC;
+  if (Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));
+  PatchRbfArgs a;
+  a.X = X; a.N = rows; a.n_mod = n_mod;
+  a.H = L.v.H; a.W = L.v.W; a.C = L.v.C; a.f = L.v.f; a.s = L.v.s; a.Ho = L.v.Ho; a.Wo = L.v.Wo; a.P = P; a.L = L.v.L;
+  a.ZT = L.ZT; a.zn = L.zn; a.M = L.M; a.Mp = Mp; a.Lp = L.Lp;
+  a.variance = L.variance; a.inv_l2 = 1.0 / (L.ls * L.ls);
+  a.out = B; a.sM = ldb; a.sN = P; a.sP = 1;
+  DCGP_TRY(patch_rbf(ctx, a, "kuf"));
+  CondScratch sc;
+  DCGP_TRY(cond_core(ctx, L.g, B, ldb, (int)Kc, L.white, L.has_qsqrt, pfx.c_str(), &sc));
+  FinalizeArgs fa;
+  fa.s1p = sc.s1p; fa.nrb1 = sc.nrb1; fa.s2p = sc.s2p; fa.nrb3 = sc.nrb3; fa.mu = sc.mu; fa.ldk = ldb;
+  fa.Kc = (int)Kc; fa.R = L.R; fa.knn_scalar = L.variance;
+  fa.rep = rep; fa.rep_stride = rep_stride; fa.z = z; fa.seed = seed; fa.stream_id = stream_id; fa.jitter = jitter;
+  fa.out_sample = out_sample; fa.out_mean = out_mean; fa.out_var = out_var;
+  if (L.identity_mean) {
+    fa.X = X; fa.idm = 1; fa.H = L.v.H; fa.W = L.v.W; fa.C = L.v.C; fa.f = L.v.f; fa.s = L.v.s; fa.Wo = L.v.Wo; fa.P = P;
+    fa.n_mod = n_mod;
+  }
+  return finalize_layer(ctx, fa);
+}
+
+// SVGP head: Kzx / Kdiag from the conv kernel, then the shared conditional
+static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, int rows, int n_mod, double* kd, double* out_mean,
+                 double* out_var, const std::string& pfx) {
+  const int Mp = L.Mp;
+  const long ldb = round_up_l(rows, 128);
+  double* B = (double*)ws_get(ctx, pfx + "Kzx", (size_t)Mp * ldb * sizeof(double));
+  if (!B) return DCGP_ERR_ALLOC;
+  if (Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));
+  const double inv_l2 = 1.0 / (L.ls * L.ls);
+  PatchRbfArgs a;
+  a.X = X; a.N = rows; a.n_mod = n_mod;
+  a.H = L.v.H; a.W = L.v.W; a.C = L.v.C; a.f = L.v.f; a.s = L.v.s; a.Ho = L.v.Ho; a.Wo = L.v.Wo; a.P = L.v.P; a.L = L.v.L;
+  a.ZT = L.ZT; a.zn = L.zn; a.M = L.M; a.Mp = Mp; a.Lp = L.Lp;
+  a.variance = L.variance; a.inv_l2 = inv_l2;
+  a.out = B; a.sM = ldb; a.sN = 1; a.sP = 0;
+  a.w = L.w; a.scale = 1.0 / (double)L.v.P; a.reduce = 1;
+  DCGP_TRY(patch_rbf(ctx, a, "head_kzx"));
+  if (L.kernel_type == 0) {
+    DCGP_TRY(head_kdiag(ctx, X, rows, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s, L.variance, inv_l2, L.w, kd));
+  } else {
+    DCGP_TRY(additive_kdiag_async(ctx, rows, L.v.P, L.variance, L.w, kd));
+  }
+  CondScratch sc;
+  DCGP_TRY(cond_core(ctx, L.g, B, ldb, rows, L.white, L.has_qsqrt, pfx.c_str(), &sc));
+  FinalizeArgs fa;
+  fa.s1p = sc.s1p; fa.nrb1 = sc.nrb1; fa.s2p = sc.s2p; fa.nrb3 = sc.nrb3; fa.mu = sc.mu; fa.ldk = ldb;
+  fa.Kc = rows; fa.R = L.R; fa.knn_vec = kd;
+  fa.out_mean = out_mean; fa.out_var = out_var;
+  return finalize_layer(ctx, fa);
+}
+

@@ -1,0 +1,332 @@
+// model.hip -- device-resident layers and the model-level forward (DGP_Base.propagate /
+// _build_likelihood of doubly_stochastic_dgp; ConvLayer.conditional_ND of conv_gp/layers.py:96-135;
+// SVGP_Layer.conditional_ND with the ConvKernel head of conv_gp/kernels.py:79-136).
+//
+// Per forward step, on ONE stream, nothing cached across steps:
+//   1. every layer: Kuu(Z) (+ prior Kuu(Z0)), padded q_sqrt / q_mu, Z^T and |z|^2
+//   2. ONE batched Cholesky + ONE batched triangular inverse for all M x M matrices of the model
+//   3. KL terms (one GEMM + one small kernel per layer)
+//   4. conv layers: patch-RBF sweep -> 3 conditional GEMMs -> mean -> finalize (+ sample)
+//   5. head: Kzx (patch sweep reduced over patches), Kdiag, conditional, RobustMax expectations
+//   6. (multi-GPU) all-reduce of the data term, ELBO assembly, one 32-byte read-back.
+#include <cstring>
+#include <memory>
+
+#include "layer_impl.h"
+
+struct dcgp_model {
+  dcgp_ctx* ctx = nullptr;
+  int S = 1;
+  double jitter = 1e-3;
+  std::vector<std::unique_ptr<LayerState>> layers;   // conv layers..., head last (once set)
+  bool has_head = false;
+  bool keep_outputs = false;
+  std::vector<FactorGroup> groups;
+  bool groups_built = false;
+  // per-layer outputs of the most recent forward
+  struct Out { double *sample = nullptr, *mean = nullptr, *var = nullptr; int rows = 0, width = 0; size_t cap = 0; };
+  std::vector<Out> outs;
+  double* d_scal = nullptr;   // [0]=data, [1..3] out, then 4 per layer KL pieces
+  double* d_ve = nullptr; size_t ve_cap = 0;
+  double* d_kd = nullptr; size_t kd_cap = 0;
+  int id = 0;
+
+  ~dcgp_model() {
+    for (auto& gr : groups) gr.release();
+    for (auto& o : outs) { hipFree(o.sample); hipFree(o.mean); hipFree(o.var); }
+    hipFree(d_scal); hipFree(d_ve); hipFree(d_kd);
+  }
+};
+
+namespace {
+
+int g_model_counter = 0;
+
+int build_groups(dcgp_model* m) {
+  if (m->groups_built) return DCGP_OK;
+  for (auto& gr : m->groups) gr.release();
+  m->groups.clear();
+  auto add = [&](int Mp, double* K, double* Linv, double* LinvT) {
+    for (auto& gr : m->groups)
+      if (gr.Mp == Mp) { gr.K.push_back(K); gr.Linv.push_back(Linv); gr.LinvT.push_back(LinvT); return; }
+    FactorGroup gr;
+    gr.Mp = Mp; gr.K.push_back(K); gr.Linv.push_back(Linv); gr.LinvT.push_back(LinvT);
+    m->groups.push_back(gr);
+  };
+  for (auto& l : m->layers) {
+    add(l->Mp, l->g.K, l->g.Linv, l->g.LinvT);
+    if (l->g.Kp) add(l->Mp, l->g.Kp, l->g.Lpinv, l->g.LpinvT);
+  }
+  m->groups_built = true;
+  return DCGP_OK;
+}
+
+int ensure(dcgp_ctx* ctx, double** p, size_t* cap, size_t n) {
+  if (*cap >= n && *p) return DCGP_OK;
+  if (*p) { hipStreamSynchronize(ctx->stream); hipFree(*p); *p = nullptr; }
+  if (hipMalloc((void**)p, (n ? n : 2) * sizeof(double)) != hipSuccess) return ctx_fail(ctx, DCGP_ERR_ALLOC, "model: allocation failed");
+  *cap = n;
+  return DCGP_OK;
+}
+
+int ensure_out(dcgp_model* m, int li, int rows, int width, bool need_mv) {
+  auto& o = m->outs[li];
+  size_t n = (size_t)rows * width;
+  if (o.cap < n) {
+    hipStreamSynchronize(m->ctx->stream);
+    hipFree(o.sample); hipFree(o.mean); hipFree(o.var);
+    o.sample = o.mean = o.var = nullptr;
+    if (hipMalloc((void**)&o.sample, n * sizeof(double)) != hipSuccess || hipMalloc((void**)&o.mean, n * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&o.var, n * sizeof(double)) != hipSuccess)
+      return ctx_fail(m->ctx, DCGP_ERR_ALLOC, "model: output allocation failed");
+    o.cap = n;
+  }
+  (void)need_mv;
+  o.rows = rows; o.width = width;
+  return DCGP_OK;
+}
+
+struct CombineArgs {
+  int nl;
+  int M[8], R[8], white[8];
+  double scale;
+};
+__global__ void combine_kernel(const double* __restrict__ scal_in, double* __restrict__ out, CombineArgs c) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double kl = 0.0;
+  for (int l = 0; l < c.nl; ++l) {
+    const double* k4 = scal_in + 4 + 4 * l;
+    double two = k4[0] - (double)c.M[l] * c.R[l] - k4[1] + k4[3];
+    if (!c.white[l]) two += (double)c.R[l] * k4[2];
+    kl += 0.5 * two;
+  }
+  double data = scal_in[0];
+  out[0] = data * c.scale - kl;
+  out[1] = data;
+  out[2] = kl;
+}
+
+int read_info(dcgp_model* m, int* info_host) {
+  dcgp_ctx* ctx = m->ctx;
+  int bad = 0;
+  for (auto& gr : m->groups) {
+    std::vector<int> h(gr.K.size());
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), gr.d_info, h.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int v : h)
+      if (v && !bad) bad = v;
+  }
+  if (info_host) *info_host = bad;
+  if (bad) return ctx_fail(ctx, DCGP_ERR_NOT_PD, "Cholesky: matrix not positive definite at column %d", bad);
+  return DCGP_OK;
+}
+
+// layers 0..n-1 forward.  Returns device pointers of the last layer's mean/var and its row count.
+int forward_all(dcgp_model* m, const double* X, int N, int S, const double* const* zs, uint64_t seed, int dedup,
+                bool need_kl, int* rows_last) {
+  dcgp_ctx* ctx = m->ctx;
+  if (!m->has_head) return ctx_fail(ctx, DCGP_ERR_ARG, "model has no head layer");
+  const int nl = (int)m->layers.size();
+  if (nl > 8) return ctx_fail(ctx, DCGP_ERR_ARG, "at most 8 layers supported");
+  DCGP_TRY(build_groups(m));
+  if (!m->d_scal && hipMalloc((void**)&m->d_scal, 64 * sizeof(double)) != hipSuccess)
+    return ctx_fail(ctx, DCGP_ERR_ALLOC, "model: allocation failed");
+  m->outs.resize(nl);
+  for (auto& l : m->layers) DCGP_TRY(l->prepare(m->jitter));
+  for (auto& gr : m->groups) DCGP_TRY(gr.run(ctx));
+  const std::string mp = "m" + std::to_string(m->id) + "_";
+  if (need_kl) {
+    for (int li = 0; li < nl; ++li) {
+      LayerState& L = *m->layers[li];
+      const double* Lp = L.g.Kp ? L.g.Kp : L.g.K;
+      const double* LpinvT = L.g.Kp ? L.g.LpinvT : L.g.LinvT;
+      DCGP_TRY(kl_layer(ctx, L.g, Lp, LpinvT, L.white, (mp + std::to_string(li)).c_str(), m->d_scal + 4 + 4 * li));
+    }
+  }
+  // propagate
+  const double* F = X;
+  int rows = dedup ? N : S * N;   // rows entering the current layer
+  int n_mod = N;                  // layer 0 reads image (row % N): tile(X, [S,1,1]) without materialising it
+  for (int li = 0; li < nl; ++li) {
+    LayerState& L = *m->layers[li];
+    const std::string pfx = mp + std::to_string(li) + "_";
+    const double* z = zs ? zs[li] : nullptr;
+    if (!L.is_head) {
+      const int width = L.v.P * L.R;
+      const bool expand = dedup && li == 0;          // N distinct images -> S*N sampled rows
+      const int out_rows = expand ? S * N : rows;
+      DCGP_TRY(ensure_out(m, li, out_rows, width, true));
+      auto& o = m->outs[li];
+      DCGP_TRY(conv_forward(ctx, L, F, rows, n_mod, expand ? S : 1, (long)N * width, z, seed, (uint32_t)(li + 1 + 64 * ctx->rank),
+                            m->jitter, o.sample, m->keep_outputs ? o.mean : nullptr, m->keep_outputs ? o.var : nullptr, pfx));
+      F = o.sample;
+      rows = out_rows;
+      n_mod = rows;
+    } else {
+      DCGP_TRY(ensure_out(m, li, rows, L.R, true));
+      auto& o = m->outs[li];
+      DCGP_TRY(ensure(ctx, &m->d_kd, &m->kd_cap, (size_t)rows));
+      DCGP_TRY(head_forward(ctx, L, F, rows, n_mod, m->d_kd, o.mean, o.var, pfx));
+      if (m->keep_outputs) {
+        // the head's sample is not needed by the ELBO; produce it only on request
+        size_t n = (size_t)rows * L.R;
+        if (z) {
+          DCGP_TRY(reparam_async(ctx, o.mean, o.var, z, n, m->jitter, o.sample));
+        } else {
+          HIP_TRY(ctx, hipMemcpyAsync(o.sample, o.mean, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+      }
+    }
+  }
+  *rows_last = rows;
+  return DCGP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcgp_model_create(dcgp_ctx* ctx, int num_samples, double jitter, dcgp_model** out) {
+  if (!ctx || !out || num_samples <= 0 || !(jitter >= 0.0)) return ctx ? ctx_fail(ctx, DCGP_ERR_ARG, "model_create: bad args") : DCGP_ERR_ARG;
+  dcgp_model* m = new dcgp_model();
+  m->ctx = ctx; m->S = num_samples; m->jitter = jitter; m->id = ++g_model_counter;
+  *out = m;
+  return DCGP_OK;
+}
+
+int dcgp_model_destroy(dcgp_model* model) {
+  if (!model) return DCGP_ERR_ARG;
+  hipStreamSynchronize(model->ctx->stream);
+  delete model;
+  return DCGP_OK;
+}
+
+int dcgp_model_set_keep_outputs(dcgp_model* model, int on) {
+  if (!model) return DCGP_ERR_ARG;
+  model->keep_outputs = on != 0;
+  return DCGP_OK;
+}
+
+int dcgp_model_add_conv_layer(dcgp_model* model, int H, int W, int C, int f, int stride, int M, int R, int white,
+                              int identity_mean, double variance, double lengthscale, const double* Z_host,
+                              const double* Z0_host, const double* q_mu_host, const double* q_sqrt_host) {
+  if (!model) return DCGP_ERR_ARG;
+  dcgp_ctx* ctx = model->ctx;
+  if (model->has_head) return ctx_fail(ctx, DCGP_ERR_ARG, "conv layers must be added before the head");
+  if (identity_mean && (f % 2 == 0)) return ctx_fail(ctx, DCGP_ERR_ARG, "Conv2dMean supports odd filter sizes only");
+  std::unique_ptr<LayerState> L(new LayerState());
+  DCGP_TRY(L->init(ctx, false, H, W, C, f, stride, M, R, white, identity_mean, 0, variance, lengthscale));
+  DCGP_TRY(L->upload(L->Z, Z_host, (size_t)M * L->v.L));
+  DCGP_TRY(L->upload(L->Z0, Z0_host ? Z0_host : Z_host, (size_t)M * L->v.L));
+  DCGP_TRY(L->upload(L->q_mu, q_mu_host, (size_t)M * R));
+  DCGP_TRY(L->upload(L->q_sqrt, q_sqrt_host, (size_t)R * M * M));
+  model->layers.push_back(std::move(L));
+  model->groups_built = false;
+  return DCGP_OK;
+}
+
+int dcgp_model_set_head(dcgp_model* model, int H, int W, int C, int f, int stride, int M, int R, int white,
+                        int kernel_type, double variance, double lengthscale, const double* Z_host, const double* w_host,
+                        const double* q_mu_host, const double* q_sqrt_host) {
+  if (!model) return DCGP_ERR_ARG;
+  dcgp_ctx* ctx = model->ctx;
+  if (model->has_head) return ctx_fail(ctx, DCGP_ERR_ARG, "head already set");
+  if (kernel_type != 0 && kernel_type != 1) return ctx_fail(ctx, DCGP_ERR_ARG, "Invalid last layer kernel");
+  std::unique_ptr<LayerState> L(new LayerState());
+  DCGP_TRY(L->init(ctx, true, H, W, C, f, stride, M, R, white, 0, kernel_type, variance, lengthscale));
+  DCGP_TRY(L->upload(L->Z, Z_host, (size_t)M * L->v.L));
+  DCGP_TRY(L->upload(L->w, w_host, (size_t)L->v.P));
+  DCGP_TRY(L->upload(L->q_mu, q_mu_host, (size_t)M * R));
+  DCGP_TRY(L->upload(L->q_sqrt, q_sqrt_host, (size_t)R * M * M));
+  model->layers.push_back(std::move(L));
+  model->has_head = true;
+  model->groups_built = false;
+  return DCGP_OK;
+}
+
+int dcgp_model_set_param(dcgp_model* model, int layer, const char* which, const double* value_host, size_t count) {
+  if (!model || !which || !value_host) return DCGP_ERR_ARG;
+  dcgp_ctx* ctx = model->ctx;
+  if (layer < 0 || layer >= (int)model->layers.size()) return ctx_fail(ctx, DCGP_ERR_ARG, "set_param: no layer %d", layer);
+  LayerState& L = *model->layers[layer];
+  auto expect = [&](size_t n) { return count == n ? DCGP_OK : ctx_fail(ctx, DCGP_ERR_ARG, "set_param(%s): expected %zu values, got %zu", which, n, count); };
+  if (!strcmp(which, "Z")) { DCGP_TRY(expect((size_t)L.M * L.v.L)); return L.upload(L.Z, value_host, count); }
+  if (!strcmp(which, "Z0")) {
+    if (!L.Z0) return ctx_fail(ctx, DCGP_ERR_ARG, "set_param: the head has no frozen prior Z");
+    DCGP_TRY(expect((size_t)L.M * L.v.L)); return L.upload(L.Z0, value_host, count);
+  }
+  if (!strcmp(which, "q_mu")) { DCGP_TRY(expect((size_t)L.M * L.R)); return L.upload(L.q_mu, value_host, count); }
+  if (!strcmp(which, "q_sqrt")) { DCGP_TRY(expect((size_t)L.R * L.M * L.M)); return L.upload(L.q_sqrt, value_host, count); }
+  if (!strcmp(which, "w")) {
+    if (!L.w) return ctx_fail(ctx, DCGP_ERR_ARG, "set_param: only the head has patch weights");
+    DCGP_TRY(expect((size_t)L.v.P)); return L.upload(L.w, value_host, count);
+  }
+  if (!strcmp(which, "variance")) { DCGP_TRY(expect(1)); if (!(value_host[0] > 0)) return ctx_fail(ctx, DCGP_ERR_ARG, "variance must be > 0"); L.variance = value_host[0]; return DCGP_OK; }
+  if (!strcmp(which, "lengthscale")) { DCGP_TRY(expect(1)); if (!(value_host[0] > 0)) return ctx_fail(ctx, DCGP_ERR_ARG, "lengthscale must be > 0"); L.ls = value_host[0]; return DCGP_OK; }
+  return ctx_fail(ctx, DCGP_ERR_ARG, "set_param: unknown parameter '%s'", which);
+}
+
+int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
+                      const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, double* out_host,
+                      int* info_host) {
+  if (!model || !X || !y || N <= 0 || !out_host) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "elbo_forward: bad args") : DCGP_ERR_ARG;
+  dcgp_ctx* ctx = model->ctx;
+  if (info_host) *info_host = 0;
+  int rows = 0;
+  const int S = model->S;
+  DCGP_TRY(forward_all(model, X, N, S, z_per_layer_host, seed, dedup_layer0, true, &rows));
+  const int nl = (int)model->layers.size();
+  LayerState& H = *model->layers[nl - 1];
+  auto& o = model->outs[nl - 1];
+  DCGP_TRY(ensure(ctx, &model->d_ve, &model->ve_cap, (size_t)rows));
+  DCGP_TRY(varexp_rows(ctx, o.mean, o.var, y, rows, N, H.R, 1e-3, model->d_ve, 0));
+  // rows == S*N normally; a head-only model under dedup has rows == N with S identical copies
+  const double inv_s = (rows == S * N) ? 1.0 / S : 1.0;
+  DCGP_TRY(reduce_sum(ctx, model->d_ve, rows, inv_s, model->d_scal));
+  if (ctx->comm) DCGP_TRY(allreduce_sum_f64_async(ctx, model->d_scal, 1));
+  CombineArgs c;
+  c.nl = nl; c.scale = scale;
+  for (int l = 0; l < nl; ++l) { c.M[l] = model->layers[l]->M; c.R[l] = model->layers[l]->R; c.white[l] = model->layers[l]->white; }
+  hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, ctx->stream, model->d_scal, model->d_scal + 1, c);
+  LAUNCH_CHECK(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scratch, model->d_scal + 1, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  out_host[0] = ctx->h_scratch[0]; out_host[1] = ctx->h_scratch[1]; out_host[2] = ctx->h_scratch[2];
+  return read_info(model, info_host);
+}
+
+int dcgp_model_propagate(dcgp_model* model, const double* X, int N, int S, const double* const* z_per_layer_host,
+                         uint64_t seed, double* out_fmean, double* out_fvar, int* info_host) {
+  if (!model || !X || N <= 0 || S <= 0) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "propagate: bad args") : DCGP_ERR_ARG;
+  dcgp_ctx* ctx = model->ctx;
+  if (info_host) *info_host = 0;
+  int rows = 0;
+  DCGP_TRY(forward_all(model, X, N, S, z_per_layer_host, seed, 0, false, &rows));
+  const int nl = (int)model->layers.size();
+  auto& o = model->outs[nl - 1];
+  size_t n = (size_t)rows * o.width;
+  if (out_fmean) HIP_TRY(ctx, hipMemcpyAsync(out_fmean, o.mean, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  if (out_fvar) HIP_TRY(ctx, hipMemcpyAsync(out_fvar, o.var, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return read_info(model, info_host);
+}
+
+int dcgp_model_layer_output(dcgp_model* model, int layer, double* out_sample, double* out_mean, double* out_var,
+                            int* rows, int* width) {
+  if (!model) return DCGP_ERR_ARG;
+  dcgp_ctx* ctx = model->ctx;
+  if (layer < 0 || layer >= (int)model->outs.size()) return ctx_fail(ctx, DCGP_ERR_ARG, "layer_output: no output for layer %d", layer);
+  auto& o = model->outs[layer];
+  if (rows) *rows = o.rows;
+  if (width) *width = o.width;
+  size_t n = (size_t)o.rows * o.width * sizeof(double);
+  if ((out_mean || out_var || (out_sample && model->layers[layer]->is_head)) && !model->keep_outputs)
+    return ctx_fail(ctx, DCGP_ERR_ARG, "layer_output: enable dcgp_model_set_keep_outputs before the forward pass");
+  if (out_sample) HIP_TRY(ctx, hipMemcpyAsync(out_sample, o.sample, n, hipMemcpyDeviceToDevice, ctx->stream));
+  if (out_mean) HIP_TRY(ctx, hipMemcpyAsync(out_mean, o.mean, n, hipMemcpyDeviceToDevice, ctx->stream));
+  if (out_var) HIP_TRY(ctx, hipMemcpyAsync(out_var, o.var, n, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}
+
+}  // extern "C"

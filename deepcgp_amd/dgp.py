@@ -1,0 +1,198 @@
+"""DGP_Base -- the model-level counterpart of doubly_stochastic_dgp.dgp.DGP_Base as the reference uses
+it (/root/reference/conv_gp/models.py:65-70, conv_gp/utils/tensorboard.py:22-35, conv_gp/utils/log.py:62):
+``propagate``, ``predict_y``, ``compute_log_likelihood`` and ``parameters``.  The whole forward ELBO of a
+minibatch is ONE call into the HIP library (``dcgp_elbo_forward``); parameters live on the device and
+are pushed when changed (``sync_parameters``)."""
+import ctypes as C
+
+import numpy as np
+
+from . import device as dev
+from .kernels import JITTER
+from .layers import ConvLayer, SVGP_Layer
+
+
+class Parameter:
+    """Minimal stand-in for a gpflow Param: ``pathname`` + value access (conv_gp/experiment.py:56-62)."""
+
+    def __init__(self, pathname, getter, setter):
+        self.pathname = pathname
+        self._get, self._set = getter, setter
+
+    @property
+    def value(self):
+        return self._get()
+
+    def assign(self, v):
+        self._set(v)
+
+
+class DGP_Base:
+    def __init__(self, X, Y, likelihood, layers, minibatch_size=None, num_samples=1, name='DGP', num_data=None):
+        self.X = np.ascontiguousarray(X, np.float64)
+        self.Y = np.ascontiguousarray(np.reshape(Y, (-1,)), np.int32)
+        self.likelihood = likelihood
+        self.layers = list(layers)
+        self.num_samples = int(num_samples)
+        self.minibatch_size = minibatch_size
+        self.name = name
+        self.num_data = int(num_data if num_data is not None else self.X.shape[0])
+        self.dedup_layer0 = False     # exact optimisation: layer 0 sees S identical copies of the batch
+        self._ctx = None
+        self._model = None
+        self._batch_rng = np.random.RandomState(0)    # Minibatch(seed=0)
+        if not self.layers or not isinstance(self.layers[-1], SVGP_Layer):
+            raise ValueError("the last layer must be an SVGP_Layer")
+        for l in self.layers[:-1]:
+            if not isinstance(l, ConvLayer):
+                raise ValueError("hidden layers must be ConvLayer instances")
+
+    # ---- device model -----------------------------------------------------------------------------
+    def _ptr(self, a):
+        return np.ascontiguousarray(a, np.float64).ctypes.data
+
+    def _build(self):
+        if self._model is not None:
+            return
+        ctx = self._ctx = dev.get_context()
+        L = dev.lib()
+        h = C.c_void_p()
+        ctx._check(L.dcgp_model_create(ctx.handle, self.num_samples, JITTER, C.byref(h)))
+        self._model = h.value
+        for l in self.layers[:-1]:
+            v = l.view
+            keep = [np.ascontiguousarray(a, np.float64) for a in (l.feature.Z, l.Z_prior, l.q_mu, l.q_sqrt)]
+            ctx._check(L.dcgp_model_add_conv_layer(
+                self._model, v.input_size[0], v.input_size[1], l.feature_maps_in, v.filter_size, v.stride,
+                l.num_inducing, l.gp_count, int(l.white), int(l.identity_mean), l.base_kernel.variance,
+                l.base_kernel.lengthscales, *[a.ctypes.data for a in keep]))
+        h_ = self.layers[-1]
+        v = h_.kern.view
+        keep = [np.ascontiguousarray(a, np.float64) for a in (h_.feature.Z, h_.kern.patch_weights, h_.q_mu, h_.q_sqrt)]
+        ctx._check(L.dcgp_model_set_head(
+            self._model, v.input_size[0], v.input_size[1], v.feature_maps, v.filter_size, v.stride,
+            h_.num_inducing, h_.num_outputs, int(h_.white), int(h_.kern.kernel_type), h_.kern.base_kernel.variance,
+            h_.kern.base_kernel.lengthscales, *[a.ctypes.data for a in keep]))
+
+    def sync_parameters(self):
+        """Push the current Python-side parameter values to the device copy."""
+        self._build()
+        L, ctx = dev.lib(), self._ctx
+
+        def push(li, which, val):
+            a = np.ascontiguousarray(np.atleast_1d(val), np.float64)
+            ctx._check(L.dcgp_model_set_param(self._model, li, which.encode(), a.ctypes.data, a.size))
+        for li, l in enumerate(self.layers):
+            head = li == len(self.layers) - 1
+            kern = l.kern.base_kernel if head else l.base_kernel
+            push(li, "Z", l.feature.Z)
+            push(li, "q_mu", l.q_mu)
+            push(li, "q_sqrt", l.q_sqrt)
+            push(li, "variance", kern.variance)
+            push(li, "lengthscale", kern.lengthscales)
+            if head:
+                push(li, "w", l.kern.patch_weights)
+            else:
+                push(li, "Z0", l.Z_prior)
+
+    @property
+    def parameters(self):
+        """Objects with ``pathname`` + ``value`` in the reference's checkpoint naming
+        (DGP/layers/<i>/..., notebooks/Inspect.ipynb cell 6)."""
+        out = []
+        for i, l in enumerate(self.layers):
+            head = i == len(self.layers) - 1
+            base = "%s/layers/%d" % (self.name, i)
+            kern = l.kern.base_kernel if head else l.base_kernel
+            kpath = base + ("/kern/base_kernel" if head else "/conv_kernel/base_kernel")
+            out.append(Parameter(kpath + "/variance", lambda k=kern: np.array(k.variance), lambda v, k=kern: setattr(k, "variance", float(v))))
+            out.append(Parameter(kpath + "/lengthscales", lambda k=kern: np.array(k.lengthscales), lambda v, k=kern: setattr(k, "lengthscales", float(v))))
+            out.append(Parameter(base + "/feature/Z", lambda l=l: l.feature.Z, lambda v, l=l: setattr(l.feature, "Z", np.array(v, np.float64))))
+            out.append(Parameter(base + "/q_mu", lambda l=l: l.q_mu, lambda v, l=l: setattr(l, "q_mu", np.array(v, np.float64))))
+            out.append(Parameter(base + "/q_sqrt", lambda l=l: l.q_sqrt, lambda v, l=l: setattr(l, "q_sqrt", np.array(v, np.float64))))
+            if head:
+                out.append(Parameter(base + "/kern/patch_weights", lambda l=l: l.kern.patch_weights,
+                                     lambda v, l=l: setattr(l.kern, "patch_weights", np.array(v, np.float64))))
+        return out
+
+    # ---- forward ----------------------------------------------------------------------------------
+    def _z_table(self, zs, N, S):
+        if zs is None:
+            return None, []
+        ctx, keep = self._ctx, []
+        arr = (C.c_void_p * len(self.layers))()
+        for i, z in enumerate(zs):
+            if z is None:
+                arr[i] = None
+                continue
+            D = self.layers[i].num_outputs
+            dz = ctx.to_device(np.reshape(z, (S, N, D)))
+            keep.append(dz)
+            arr[i] = dz.ptr
+        return arr, keep
+
+    def compute_log_likelihood(self, X=None, Y=None, zs=None, seed=0, scale=None, return_parts=False):
+        """ELBO of an explicit minibatch: sum_n E_q log p(y_n | f_n) * num_data / batch - sum_l KL_l
+        (doubly_stochastic_dgp DGP_Base._build_likelihood; explicit feeds as at
+        conv_gp/utils/tensorboard.py:32-35).  Without arguments a minibatch of ``minibatch_size`` is drawn."""
+        self._build()
+        if X is None:
+            idx = self._batch_rng.choice(self.X.shape[0], size=min(self.minibatch_size or self.X.shape[0], self.X.shape[0]), replace=False)
+            X, Y = self.X[idx], self.Y[idx]
+        ctx, L = self._ctx, dev.lib()
+        dX = ctx.as_device(np.reshape(X, (np.shape(X)[0], -1)) if not isinstance(X, dev.DeviceArray) else X)
+        dY = ctx.as_device(np.reshape(Y, (-1,)) if not isinstance(Y, dev.DeviceArray) else Y, np.int32)
+        N = dX.shape[0]
+        if scale is None:
+            scale = float(self.num_data) / float(N)
+        arr, keep = self._z_table(zs, N, self.num_samples)
+        out = (C.c_double * 3)()
+        info = C.c_int(0)
+        rc = L.dcgp_elbo_forward(self._model, dX.ptr, dY.ptr, N, float(scale), arr, int(seed), int(self.dedup_layer0), out, C.byref(info))
+        ctx._check(rc, info)
+        if return_parts:
+            return out[0], out[1], out[2]
+        return out[0]
+
+    def propagate(self, X, full_cov=False, S=1, zs=None, seed=0):
+        """(Fs, Fmeans, Fvars): per layer S x N x D_l arrays (doubly_stochastic_dgp DGP_Base.propagate)."""
+        if full_cov:
+            raise NotImplementedError("full_cov=True is outside the accelerated hot path")
+        self._build()
+        ctx, L = self._ctx, dev.lib()
+        X = np.ascontiguousarray(np.reshape(X, (np.shape(X)[0], -1)), np.float64)
+        N = X.shape[0]
+        dX = ctx.to_device(X)
+        # the device model was created with num_samples; propagate takes S explicitly
+        arr, keep = self._z_table(zs, N, S)
+        ctx._check(L.dcgp_model_set_keep_outputs(self._model, 1))
+        info = C.c_int(0)
+        try:
+            rc = L.dcgp_model_propagate(self._model, dX.ptr, N, int(S), arr, int(seed), None, None, C.byref(info))
+            ctx._check(rc, info)
+            Fs, Fm, Fv = [], [], []
+            for i, l in enumerate(self.layers):
+                D = l.num_outputs
+                bufs = [ctx.empty((S, N, D)) for _ in range(3)]
+                rows, width = C.c_int(0), C.c_int(0)
+                ctx._check(L.dcgp_model_layer_output(self._model, i, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, C.byref(rows), C.byref(width)))
+                assert rows.value == S * N and width.value == D, (rows.value, width.value, S, N, D)
+                Fs.append(bufs[0].numpy()), Fm.append(bufs[1].numpy()), Fv.append(bufs[2].numpy())
+        finally:
+            L.dcgp_model_set_keep_outputs(self._model, 0)
+        return Fs, Fm, Fv
+
+    def predict_y(self, X, S, zs=None, seed=0):
+        """(mean, var) of p(y*) per sample: S x N x num_classes (used at conv_gp/utils/log.py:62-66)."""
+        _, Fm, Fv = self.propagate(X, S=S, zs=zs, seed=seed)
+        Sn, N, D = Fm[-1].shape
+        m, v = self.likelihood.predict_mean_and_var(Fm[-1].reshape(Sn * N, D), Fv[-1].reshape(Sn * N, D))
+        return m.reshape(Sn, N, -1), v.reshape(Sn, N, -1)
+
+    def KL(self):
+        return float(sum(l.KL() for l in self.layers))
+
+    def close(self):
+        if self._model is not None:
+            dev.lib().dcgp_model_destroy(self._model)
+            self._model = None

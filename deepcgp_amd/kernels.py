@@ -1,0 +1,161 @@
+"""Kernels of the conv-GP path -- same surface as /root/reference/conv_gp/kernels.py, backed by HIP.
+
+``RBF`` stands in for gpflow.kernels.RBF with a scalar lengthscale (what conv_gp/models.py:114-117
+builds); the patch kernels keep the reference's names, constructor arguments and method names.
+"""
+import numpy as np
+
+from . import device as dev
+
+JITTER = 1e-3    # settings.jitter from /root/reference/gpflowrc:11
+
+
+class RBF:
+    """gpflow.kernels.RBF(input_dim, variance, lengthscales) -- parameters + Kuu-type evaluations on device."""
+
+    def __init__(self, input_dim, variance=1.0, lengthscales=1.0):
+        self.input_dim = int(input_dim)
+        self.variance = float(variance)
+        self.lengthscales = float(lengthscales)
+        if not (self.variance > 0 and self.lengthscales > 0):
+            raise ValueError("variance and lengthscales must be positive")
+
+    def K(self, X, X2=None):
+        if X2 is not None:
+            raise NotImplementedError("cross-covariances are evaluated by the fused patch kernels")
+        return self._gram(X, 0.0)
+
+    def _gram(self, Z, jitter):
+        ctx = dev.get_context()
+        Z = np.ascontiguousarray(Z, np.float64)
+        M, L = Z.shape
+        if L != self.input_dim:
+            raise ValueError("expected inputs of length %d, got %d" % (self.input_dim, L))
+        dZ, out = ctx.to_device(Z), ctx.empty((M, M))
+        ctx._check(dev.lib().dcgp_kuu_rbf(ctx.handle, dZ.ptr, M, L, self.variance, self.lengthscales, float(jitter), out.ptr))
+        return out.numpy()
+
+    def Kdiag(self, X):
+        return np.full(np.shape(X)[0], self.variance)
+
+
+class AdditivePatchKernel:
+    """K(x, x') = mean_i w_i k(x[i], x'[i]) (conv_gp/kernels.py:15-77); Kzx / Kdiag / Kzz only --
+    the full K() of the reference is off the training path."""
+
+    kernel_type = 1
+
+    def __init__(self, base_kernel, view, patch_weights=None):
+        self.base_kernel = base_kernel
+        self.view = view
+        self.patch_length = view.patch_length
+        self.patch_count = view.patch_count
+        self.image_size = self.view.input_size
+        if patch_weights is None or np.size(patch_weights) != self.patch_count:      # kernels.py:26-27
+            patch_weights = np.ones(self.patch_count)
+        self.patch_weights = np.array(patch_weights, np.float64)
+
+    def _reshape_X(self, ND_X):
+        ND_X = np.ascontiguousarray(ND_X, np.float64)
+        size = list(self.view.input_size)
+        if len(size) == 2:
+            size = size + [self.view.feature_maps]
+        return ND_X.reshape([ND_X.shape[0]] + size)
+
+    def _geom(self, X):
+        N, H, W, Cc = X.shape
+        return N, H, W, Cc, self.view.filter_size, self.view.stride
+
+    def Kzx(self, ML_Z, ND_X):
+        ctx = dev.get_context()
+        X = self._reshape_X(ND_X)
+        Z = np.ascontiguousarray(ML_Z, np.float64)
+        N, H, W, Cc, f, s = self._geom(X)
+        M = Z.shape[0]
+        if N == 0:
+            return np.zeros((M, 0))
+        dX, dZ, dw = ctx.to_device(X), ctx.to_device(Z), ctx.to_device(self.patch_weights)
+        out = ctx.empty((M, N))
+        ctx._check(dev.lib().dcgp_convkernel_kzx(ctx.handle, dX.ptr, N, H, W, Cc, f, s, dZ.ptr, M,
+                                                 self.base_kernel.variance, self.base_kernel.lengthscales, dw.ptr, out.ptr))
+        return out.numpy()
+
+    def Kdiag(self, ND_X):
+        ctx = dev.get_context()
+        N = np.shape(ND_X)[0]
+        if N == 0:
+            return np.zeros((0,))
+        dw, out = ctx.to_device(self.patch_weights), ctx.empty((N,))
+        ctx._check(dev.lib().dcgp_additive_kdiag(ctx.handle, N, self.patch_count, self.base_kernel.variance, dw.ptr, out.ptr))
+        return out.numpy()
+
+    def Kzz(self, Z):
+        return self.base_kernel.K(Z)
+
+
+class ConvKernel(AdditivePatchKernel):
+    """Weighted convolutional kernel of the classification head (conv_gp/kernels.py:79-136)."""
+
+    kernel_type = 0
+
+    def Kdiag(self, ND_X):
+        ctx = dev.get_context()
+        X = self._reshape_X(ND_X)
+        N, H, W, Cc, f, s = self._geom(X)
+        if N == 0:
+            return np.zeros((0,))
+        dX, dw, out = ctx.to_device(X), ctx.to_device(self.patch_weights), ctx.empty((N,))
+        ctx._check(dev.lib().dcgp_convkernel_kdiag(ctx.handle, dX.ptr, N, H, W, Cc, f, s, self.base_kernel.variance,
+                                                   self.base_kernel.lengthscales, dw.ptr, out.ptr))
+        return out.numpy()
+
+
+def _sample(tensor, count):
+    return tensor[np.random.choice(np.arange(tensor.shape[0]), count)]
+
+
+def _sample_patches(HW_image, N, patch_size, patch_length):
+    """conv_gp/kernels.py:139-145 (imported by the reference's notebooks)."""
+    out = np.zeros((N, patch_length))
+    for i in range(N):
+        y = np.random.randint(0, HW_image.shape[0] - patch_size)
+        x = np.random.randint(0, HW_image.shape[1] - patch_size)
+        out[i] = HW_image[y:y + patch_size, x:x + patch_size].reshape(patch_length)
+    return out
+
+
+def _cluster_patches(NHWC_X, M, patch_size):
+    """k-means of 100*M random patches (conv_gp/kernels.py:147-164): one-off host-side init."""
+    from sklearn import cluster
+    NHWC = NHWC_X.shape
+    patch_length = patch_size ** 2 * NHWC[3]
+    patches = np.zeros((M * 100, patch_length))
+    for i in range(M * 100):
+        patches[i] = _sample_patches(_sample(NHWC_X, 1)[0], 1, patch_size, patch_length)
+    k_means = cluster.KMeans(n_clusters=M, init='random', n_init=1)
+    k_means.fit(patches)
+    return k_means.cluster_centers_
+
+
+class PatchInducingFeatures:
+    """conv_gp/kernels.py:166-170 (InducingPointsBase: ``Z`` and ``len``)."""
+
+    def __init__(self, Z):
+        self.Z = np.array(Z, np.float64)
+
+    def __len__(self):
+        return self.Z.shape[0]
+
+    @classmethod
+    def from_images(cls, NHWC_X, M, patch_size):
+        return cls(_cluster_patches(NHWC_X, M, patch_size))
+
+
+def Kuu(feature, kern, jitter=0.0):
+    """dispatch at conv_gp/kernels.py:172-174."""
+    return kern.base_kernel._gram(feature.Z, jitter)
+
+
+def Kuf(feature, kern, Xnew):
+    """dispatch at conv_gp/kernels.py:176-178."""
+    return kern.Kzx(feature.Z, Xnew)

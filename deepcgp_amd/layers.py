@@ -1,0 +1,256 @@
+"""Layers of the conv-GP path -- same surface as /root/reference/conv_gp/layers.py plus the two layer
+classes the reference takes from doubly_stochastic_dgp (``Layer``, ``SVGP_Layer``), backed by HIP."""
+import ctypes as C
+
+import numpy as np
+
+from . import device as dev
+from .conditionals import conditional
+from .kernels import JITTER, Kuu as _Kuu, Kuf as _Kuf
+from .views import FullView
+
+
+def _potrf(A):
+    ctx = dev.get_context()
+    A = np.ascontiguousarray(A, np.float64)
+    M = A.shape[0]
+    dA, info = ctx.to_device(A), C.c_int(0)
+    ctx._check(dev.lib().dcgp_potrf_lower(ctx.handle, dA.ptr, M, C.byref(info)), info)
+    return dA.numpy()
+
+
+def gauss_kl(q_mu, q_sqrt, K=None):
+    """gpflow.kullback_leiblers.gauss_kl (call sites conv_gp/layers.py:145,147)."""
+    ctx = dev.get_context()
+    q_mu = np.ascontiguousarray(q_mu, np.float64)
+    M, R = q_mu.shape
+    dmu, dsq = ctx.to_device(q_mu), ctx.to_device(q_sqrt)
+    dK = ctx.to_device(K) if K is not None else None
+    out, info = C.c_double(0.0), C.c_int(0)
+    rc = dev.lib().dcgp_gauss_kl(ctx.handle, dmu.ptr, dsq.ptr, dK.ptr if dK else None, M, R, C.byref(out), C.byref(info))
+    ctx._check(rc, info)
+    return out.value
+
+
+def reparameterize(mean, var, z, full_cov=False):
+    """doubly_stochastic_dgp.utils.reparameterize: mean + z * sqrt(var + jitter)."""
+    if full_cov:
+        raise NotImplementedError
+    if var is None:
+        return mean
+    ctx = dev.get_context()
+    mean = np.ascontiguousarray(mean, np.float64)
+    dm, dv, dz = ctx.to_device(mean), ctx.to_device(var), ctx.to_device(z)
+    out = ctx.empty(mean.shape)
+    ctx._check(dev.lib().dcgp_reparam(ctx.handle, dm.ptr, dv.ptr, dz.ptr, mean.size, JITTER, out.ptr))
+    return out.numpy()
+
+
+class MultiOutputConvKernel:
+    """conv_gp/layers.py:12-50."""
+
+    def __init__(self, base_kernel, input_dim, patch_count):
+        self.base_kernel = base_kernel
+        self.input_dim = input_dim
+        self.patch_count = patch_count
+
+    def Kuu(self, ML_Z):
+        return self.base_kernel._gram(ML_Z, JITTER)
+
+    def Kuf(self, ML_Z, PNL_patches):
+        """patch_count x M x N.  PNL_patches may be the P x N x L array of the reference, or an
+        ``(NHWC_X, view)`` pair -- the latter is the fused form that never materialises patches."""
+        ctx = dev.get_context()
+        Z = np.ascontiguousarray(ML_Z, np.float64)
+        M = Z.shape[0]
+        if isinstance(PNL_patches, tuple):
+            X, view = PNL_patches
+            X = np.ascontiguousarray(X, np.float64)
+            N, H, W, Cc = X.shape
+            f, s = view.filter_size, view.stride
+        else:
+            # every patch is a 1x1 "image" with L channels, filter 1: same sweep, no gather
+            PNL = np.ascontiguousarray(PNL_patches, np.float64)
+            P, N, L = PNL.shape
+            X = np.ascontiguousarray(np.transpose(PNL, (1, 0, 2))).reshape(N, P, 1, L)
+            H, W, Cc, f, s = P, 1, L, 1, 1
+        P = ((H - f) // s + 1) * ((W - f) // s + 1)
+        if N == 0:
+            return np.zeros((P, M, 0))
+        dX, dZ, out = ctx.to_device(X), ctx.to_device(Z), ctx.empty((P, M, N))
+        ctx._check(dev.lib().dcgp_kuf_patches_rbf(ctx.handle, dX.ptr, N, H, W, Cc, f, s, dZ.ptr, M,
+                                                  self.base_kernel.variance, self.base_kernel.lengthscales, out.ptr, 0))
+        return out.numpy()
+
+    def Kdiag(self, PNL_patches):
+        P, N = np.shape(PNL_patches)[:2]
+        return np.full((P, N), self.base_kernel.variance)
+
+
+class Layer:
+    """doubly_stochastic_dgp.layers.Layer: conditional_SND / sample_from_conditional on top of a
+    subclass's conditional_ND (subclassed at conv_gp/layers.py:52)."""
+
+    num_outputs = None
+
+    def conditional_ND(self, X, full_cov=False):
+        raise NotImplementedError
+
+    def KL(self):
+        return 0.0
+
+    def conditional_SND(self, X, full_cov=False):
+        if full_cov:
+            raise NotImplementedError("full_cov=True is outside the accelerated hot path")
+        X = np.asarray(X, np.float64)
+        S, N, D = X.shape
+        mean, var = self.conditional_ND(X.reshape(S * N, D))
+        return mean.reshape(S, N, self.num_outputs), var.reshape(S, N, self.num_outputs)
+
+    def sample_from_conditional(self, X, z=None, full_cov=False):
+        mean, var = self.conditional_SND(X, full_cov=full_cov)
+        if z is None:
+            z = np.random.standard_normal(mean.shape)
+        samples = reparameterize(mean, var, np.reshape(z, mean.shape))
+        return samples, mean, var
+
+
+class ConvLayer(Layer):
+    """conv_gp/layers.py:52-161.  ``mean_function`` is None / 'zero' (gpflow Zero) or 'conv2d'
+    (Conv2dMean, conv_gp/mean_functions.py:28-41)."""
+
+    def __init__(self, base_kernel, mean_function, feature=None, view=None, white=False, gp_count=1,
+                 q_mu=None, q_sqrt=None, **kwargs):
+        self.base_kernel = base_kernel
+        self.view = view
+        self.feature_maps_in = self.view.feature_maps
+        self.gp_count = int(gp_count)
+        self.patch_count = self.view.patch_count
+        self.patch_length = self.view.patch_length
+        self.num_outputs = self.patch_count * self.gp_count
+        self.conv_kernel = MultiOutputConvKernel(base_kernel, int(np.prod(view.input_size)) * view.feature_maps,
+                                                 patch_count=self.patch_count)
+        self.white = bool(white)
+        self.feature = feature
+        self.num_inducing = len(feature)
+        # the KL prior is built on the *initial* Z (conv_gp/layers.py:149-152)
+        self.Z_prior = np.array(feature.Z, np.float64)
+        if q_mu is None:
+            q_mu = self._initial_q_mu()
+        self.q_mu = np.array(q_mu, np.float64)
+        if q_sqrt is None:
+            if not self.white:
+                q_sqrt = self._init_q_S()
+            else:
+                q_sqrt = np.tile(np.eye(self.num_inducing)[None, :, :], [self.gp_count, 1, 1])
+        self.q_sqrt = np.array(q_sqrt, np.float64)
+        self.mean_function = mean_function
+        self._build_prior_cholesky()
+
+    @property
+    def identity_mean(self):
+        mf = self.mean_function
+        return bool(mf) and (mf == 'conv2d' or getattr(mf, 'is_conv2d_mean', False))
+
+    def conditional_ND(self, ND_X, full_cov=False):
+        """mean, var of q(f | m, S), each N x (patch_count * gp_count), HWC column order."""
+        if full_cov:
+            raise NotImplementedError("full_cov=True is outside the accelerated hot path")
+        return self._forward(ND_X, None)[1:]
+
+    def _forward(self, ND_X, z):
+        ctx = dev.get_context()
+        ND_X = np.ascontiguousarray(ND_X, np.float64)
+        N = ND_X.shape[0]
+        v = self.view
+        H, W = v.input_size[0], v.input_size[1]
+        if ND_X.shape[1] != H * W * self.feature_maps_in:
+            raise ValueError("expected N x %d inputs, got %s" % (H * W * self.feature_maps_in, ND_X.shape))
+        D = self.num_outputs
+        if N == 0:
+            return np.zeros((0, D)), np.zeros((0, D)), np.zeros((0, D))
+        dX, dZ = ctx.to_device(ND_X), ctx.to_device(self.feature.Z)
+        dmu, dsq = ctx.to_device(self.q_mu), ctx.to_device(self.q_sqrt)
+        dz = ctx.to_device(np.reshape(z, (N, D))) if z is not None else None
+        ds = ctx.empty((N, D)) if z is not None else None
+        dm, dv = ctx.empty((N, D)), ctx.empty((N, D))
+        info = C.c_int(0)
+        rc = dev.lib().dcgp_conv_layer_forward(
+            ctx.handle, dX.ptr, N, H, W, self.feature_maps_in, v.filter_size, v.stride, dZ.ptr,
+            self.num_inducing, self.gp_count, self.base_kernel.variance, self.base_kernel.lengthscales,
+            dmu.ptr, dsq.ptr, int(self.white), int(self.identity_mean), dz.ptr if dz else None, JITTER,
+            ds.ptr if ds else None, dm.ptr, dv.ptr, C.byref(info))
+        ctx._check(rc, info)
+        return (ds.numpy() if ds else None), dm.numpy(), dv.numpy()
+
+    def sample_from_conditional(self, X, z=None, full_cov=False):
+        if full_cov:
+            raise NotImplementedError("full_cov=True is outside the accelerated hot path")
+        X = np.asarray(X, np.float64)
+        S, N, D = X.shape
+        if z is None:
+            z = np.random.standard_normal((S, N, self.num_outputs))
+        s, m, v = self._forward(X.reshape(S * N, D), np.reshape(z, (S * N, self.num_outputs)))
+        shape = (S, N, self.num_outputs)
+        return s.reshape(shape), m.reshape(shape), v.reshape(shape)
+
+    def KL(self):
+        """KL[q(u) || p(u)] summed over the gp_count GPs (conv_gp/layers.py:137-147)."""
+        if self.white:
+            return gauss_kl(self.q_mu, self.q_sqrt, K=None)
+        return gauss_kl(self.q_mu, self.q_sqrt, self.conv_kernel.Kuu(self.Z_prior))
+
+    def _build_prior_cholesky(self):
+        self.MM_Ku_prior = self.conv_kernel.Kuu(self.Z_prior)
+
+    def _init_q_S(self):
+        MM_Lu = _potrf(self.conv_kernel.Kuu(self.feature.Z))
+        return np.tile(MM_Lu[None, :, :], [self.gp_count, 1, 1])
+
+    def _initial_q_mu(self):
+        return np.zeros((self.num_inducing, self.gp_count))
+
+
+class SVGP_Layer(Layer):
+    """doubly_stochastic_dgp.layers.SVGP_Layer in the fork's signature (conv_gp/models.py:192-198)."""
+
+    def __init__(self, kern, num_outputs, feature=None, mean_function=None, white=False, q_mu=None, q_sqrt=None):
+        self.kern = kern
+        self.num_outputs = int(num_outputs)
+        self.feature = feature
+        self.num_inducing = len(feature)
+        self.white = bool(white)
+        self.mean_function = mean_function
+        if q_mu is None:
+            q_mu = np.zeros((self.num_inducing, self.num_outputs))
+        self.q_mu = np.array(q_mu, np.float64)
+        if q_sqrt is None:
+            if self.white:
+                q_sqrt = np.tile(np.eye(self.num_inducing)[None], [self.num_outputs, 1, 1])
+            else:
+                Lu = _potrf(_Kuu(self.feature, self.kern, jitter=JITTER))
+                q_sqrt = np.tile(Lu[None], [self.num_outputs, 1, 1])
+        self.q_sqrt = np.array(q_sqrt, np.float64)
+
+    def conditional_ND(self, X, full_cov=False):
+        if full_cov:
+            raise NotImplementedError("full_cov=True is outside the accelerated hot path")
+        ctx = dev.get_context()
+        X = np.ascontiguousarray(X, np.float64)
+        N, M, R = X.shape[0], self.num_inducing, self.num_outputs
+        if N == 0:
+            return np.zeros((0, R)), np.zeros((0, R))
+        Ku = _Kuu(self.feature, self.kern, jitter=JITTER)
+        Kuf = _Kuf(self.feature, self.kern, X)
+        Kdiag = self.kern.Kdiag(X)
+        d = [ctx.to_device(a) for a in (Kuf, Ku, Kdiag, self.q_mu, self.q_sqrt)]
+        mean, var, info = ctx.empty((N, R)), ctx.empty((N, R)), C.c_int(0)
+        rc = dev.lib().dcgp_svgp_conditional(ctx.handle, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr,
+                                             int(self.white), M, N, R, mean.ptr, var.ptr, C.byref(info))
+        ctx._check(rc, info)
+        return mean.numpy(), var.numpy()
+
+    def KL(self):
+        if self.white:
+            return gauss_kl(self.q_mu, self.q_sqrt, K=None)
+        return gauss_kl(self.q_mu, self.q_sqrt, _Kuu(self.feature, self.kern, jitter=JITTER))

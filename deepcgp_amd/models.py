@@ -1,0 +1,161 @@
+"""Model assembly -- the counterpart of /root/reference/conv_gp/models.py (ModelBuilder) plus a builder
+from the neutral model spec used by the benchmarks and parity tests (deepcgp_amd.synthetic)."""
+import numpy as np
+
+from .dgp import DGP_Base
+from .kernels import RBF, ConvKernel, AdditivePatchKernel, PatchInducingFeatures
+from .layers import ConvLayer, SVGP_Layer
+from .likelihoods import MultiClass
+from .views import FullView
+
+
+def parse_ints(int_string):
+    """conv_gp/models.py:14-18."""
+    if int_string == '':
+        return []
+    return [int(i) for i in int_string.split(',')]
+
+
+def build_layers_from_spec(spec):
+    layers = []
+    for c in spec["convs"]:
+        view = FullView((c["H"], c["W"]), c["f"], c["C"], c["s"])
+        layer = ConvLayer(RBF(view.patch_length, c["variance"], c["ls"]), c.get("mean_function"),
+                          feature=PatchInducingFeatures(c["Z"]), view=view, white=c["white"], gp_count=c["R"],
+                          q_mu=c["q_mu"], q_sqrt=c["q_sqrt"])
+        layer.Z_prior = np.array(c.get("Z0", c["Z"]), np.float64)
+        layer._build_prior_cholesky()
+        layers.append(layer)
+    h = spec["head"]
+    view = FullView((h["H"], h["W"], h["C"]), h["f"], h["C"], h["s"])
+    cls = AdditivePatchKernel if h.get("kernel", "conv") == "add" else ConvKernel
+    kern = cls(RBF(view.patch_length, h["variance"], h["ls"]), view, patch_weights=h["w"])
+    layers.append(SVGP_Layer(kern=kern, num_outputs=h["R"], feature=PatchInducingFeatures(h["Z"]),
+                             mean_function=None, white=h["white"], q_mu=h["q_mu"], q_sqrt=h["q_sqrt"]))
+    return layers
+
+
+def build_from_spec(spec, X, Y):
+    """DGP_Base on the HIP path from a model spec (see deepcgp_amd.synthetic)."""
+    return DGP_Base(X, Y, likelihood=MultiClass(10), layers=build_layers_from_spec(spec),
+                    num_samples=spec["S"], minibatch_size=None, num_data=spec["num_data"], name='DGP')
+
+
+def identity_conv(NHWC_X, filter_size, feature_maps_in, feature_maps_out, stride, count=1000):
+    """Propagate random images through IdentityConv2dMean to initialise the next layer
+    (conv_gp/models.py:29-33, conv_gp/mean_functions.py:6-26)."""
+    X = NHWC_X[np.random.choice(np.arange(NHWC_X.shape[0]), size=min(count, NHWC_X.shape[0]))]
+    n, H, W, C = X.shape
+    Ho, Wo = (H - filter_size) // stride + 1, (W - filter_size) // stride + 1
+    c0 = filter_size // 2
+    centre = X[:, c0:c0 + (Ho - 1) * stride + 1:stride, c0:c0 + (Wo - 1) * stride + 1:stride, :].sum(-1)
+    return np.repeat(centre[..., None], feature_maps_out, axis=-1)
+
+
+class ModelBuilder(object):
+    """Same flags and construction order as conv_gp/models.py:35-198 (checkpoint loading: :200-240)."""
+
+    def __init__(self, flags, NHWC_X_train, Y_train, model_path=None):
+        self.flags = flags
+        self.X_train = NHWC_X_train
+        self.Y_train = Y_train
+        self.model_path = model_path
+        self.global_step = None
+
+    def build(self):
+        Ms = parse_ints(self.flags.M)
+        feature_maps = parse_ints(self.flags.feature_maps)
+        strides = parse_ints(self.flags.strides)
+        filter_sizes = parse_ints(self.flags.filter_sizes)
+        loaded = {}
+        if getattr(self.flags, "load_model", None) is not None:
+            self.global_step, loaded = self._load_layer_parameters(Ms)
+        assert len(strides) == len(filter_sizes)
+        assert len(feature_maps) == (len(Ms) - 1)
+        conv_layers, H_X = self._conv_layers(Ms[0:-1], feature_maps, strides, filter_sizes, loaded)
+        last = self._last_layer(H_X, Ms[-1], filter_sizes[-1], strides[-1], self._last_layer_parameters(loaded))
+        X = self.X_train.reshape(-1, int(np.prod(self.X_train.shape[1:])))
+        return DGP_Base(X, self.Y_train, likelihood=MultiClass(10), num_samples=self.flags.num_samples,
+                        layers=conv_layers + [last], minibatch_size=self.flags.batch_size, name='DGP')
+
+    def _conv_layers(self, Ms, feature_maps, strides, filter_sizes, loaded):
+        H_X, layers = self.X_train, []
+        for i in range(len(feature_maps)):
+            layer, H_X = self._conv_layer(H_X, Ms[i], feature_maps[i], filter_sizes[i], strides[i], loaded.get(i))
+            layers.append(layer)
+        return layers, H_X
+
+    def _conv_layer(self, NHWC_X, M, feature_map, filter_size, stride, layer_params=None):
+        layer_params = layer_params or {}
+        NHWC = NHWC_X.shape
+        view = FullView(input_size=NHWC[1:3], filter_size=filter_size, feature_maps=NHWC[3], stride=stride)
+        conv_mean = 'conv2d' if getattr(self.flags, "identity_mean", False) else None
+        H_X = identity_conv(NHWC_X, filter_size, NHWC[3], feature_map, stride)
+        if len(layer_params) == 0:
+            conv_features = PatchInducingFeatures.from_images(NHWC_X, M, filter_size)
+        else:
+            conv_features = PatchInducingFeatures(layer_params.get('Z'))
+        patch_length = filter_size ** 2 * NHWC[3]
+        if self.flags.base_kernel == 'rbf':
+            base_kernel = RBF(patch_length, variance=float(layer_params.get('base_kernel/variance', 5.0)),
+                              lengthscales=float(layer_params.get('base_kernel/lengthscales', 5.0)))
+        elif self.flags.base_kernel == 'acos':
+            raise NotImplementedError("ArcCosine base kernel is not on the accelerated path yet (SURVEY.md 8 f-4)")
+        else:
+            raise ValueError("Not a valid base-kernel value")
+        q_mu, q_sqrt = layer_params.get('q_mu'), layer_params.get('q_sqrt')
+        conv_layer = ConvLayer(base_kernel=base_kernel, mean_function=conv_mean, feature=conv_features, view=view,
+                               white=self.flags.white, gp_count=feature_map, q_mu=q_mu, q_sqrt=q_sqrt)
+        if q_sqrt is None:
+            conv_layer.q_sqrt = conv_layer.q_sqrt * 1e-5      # start with low variance (models.py:136-138)
+        return conv_layer, H_X
+
+    def _last_layer(self, H_X, M, filter_size, stride, layer_params=None):
+        layer_params = layer_params or {}
+        NHWC = H_X.shape
+        Z, q_mu, q_sqrt = layer_params.get('Z'), layer_params.get('q_mu'), layer_params.get('q_sqrt')
+        if Z is not None:
+            saved = int(np.sqrt(Z.shape[1] / NHWC[3]))
+            if filter_size != saved:
+                print("filter_size {} != {} for last layer. Resetting parameters.".format(filter_size, saved))
+                Z = q_mu = q_sqrt = None
+        if self.flags.last_kernel == 'rbf':
+            raise NotImplementedError("RBF-ARD head is not on the accelerated path yet (SURVEY.md 8 f-4)")
+        variance = float(layer_params.get('base_kernel/variance', 5.0))
+        lengthscales = float(layer_params.get('base_kernel/lengthscales', 5.0))
+        input_dim = filter_size ** 2 * NHWC[3]
+        view = FullView(input_size=NHWC[1:], filter_size=filter_size, feature_maps=NHWC[3], stride=stride)
+        inducing = PatchInducingFeatures.from_images(H_X, M, filter_size) if Z is None else PatchInducingFeatures(Z)
+        patch_weights = layer_params.get('patch_weights')
+        if self.flags.last_kernel == 'conv':
+            kernel = ConvKernel(RBF(input_dim, variance=variance, lengthscales=lengthscales), view, patch_weights)
+        elif self.flags.last_kernel == 'add':
+            kernel = AdditivePatchKernel(RBF(input_dim, variance=variance, lengthscales=lengthscales), view, patch_weights)
+        else:
+            raise ValueError("Invalid last layer kernel")
+        return SVGP_Layer(kern=kernel, num_outputs=10, feature=inducing, mean_function=None,
+                          white=self.flags.white, q_mu=q_mu, q_sqrt=q_sqrt)
+
+    def _load_layer_parameters(self, Ms):
+        parameters = np.load(self.model_path, allow_pickle=True).item()
+        global_step = parameters.pop('global_step')
+        layer_params = {}
+        for key, value in parameters.items():
+            if 'layers' not in key:
+                continue
+            parts = key.split('/')
+            layer, path = int(parts[2]), "/".join(parts[3:])
+            vals = layer_params.setdefault(layer, {})
+            for tag in ('q_mu', 'q_sqrt', 'Z', 'base_kernel/variance', 'base_kernel/lengthscales', 'patch_weights'):
+                if tag in path:
+                    vals[tag] = value
+                    break
+        stored, model_layers = max(layer_params.keys()) + 1, len(Ms)
+        assert stored <= model_layers, "Can't load model if it has more layers than the one being built"
+        if stored != model_layers:
+            layer_params[model_layers - 1] = layer_params.pop(stored - 1)
+        return global_step, layer_params
+
+    def _last_layer_parameters(self, layer_params):
+        keys = list(layer_params.keys())
+        return layer_params[max(keys)] if keys else None

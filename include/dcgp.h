@@ -1,0 +1,192 @@
+/*
+ * dcgp.h -- C-ABI of libdcgp.so: the MI355X (gfx950) conv-GP forward / ELBO hot path of DeepCGP.
+ *
+ * The reference (kekeblom/DeepCGP) has no FFI seam: the path is Python methods that build
+ * TensorFlow graph nodes.  Every entry point below therefore names the reference *method* it
+ * replaces (file:line under the reference tree); the Python classes in deepcgp_amd/ keep the
+ * reference's names and call these through ctypes (see INTEGRATION.md for the binding).
+ *
+ * Conventions
+ *   - every array is float64 ("double"), C-contiguous row-major, resident in DEVICE memory unless
+ *     the parameter name ends in _host; labels are int32;
+ *   - every function returns a status (DCGP_OK == 0); dcgp_last_error(ctx) gives the message;
+ *   - one ctx <-> one device <-> one HIP stream; a ctx is not thread-safe; calls are stream-ordered
+ *     and have completed (stream synchronised) on return unless stated otherwise;
+ *   - the caller owns every buffer it allocates with dcgp_malloc; the library owns only internal
+ *     workspaces hanging off the ctx / model;
+ *   - "not positive definite" (the reference's tf.errors.InvalidArgumentError from tf.cholesky,
+ *     conv_gp/experiment.py:45) is DCGP_ERR_NOT_PD with the 1-based failing column in *info.
+ */
+#ifndef DCGP_H
+#define DCGP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCGP_OK 0
+#define DCGP_ERR_ARG (-1)      /* bad argument (NULL, non-positive size, unsupported shape)      */
+#define DCGP_ERR_HIP (-2)      /* a HIP runtime call failed                                       */
+#define DCGP_ERR_NOT_PD (-3)   /* Cholesky hit a non-positive pivot                               */
+#define DCGP_ERR_RCCL (-4)     /* an RCCL call failed / communicator missing                      */
+#define DCGP_ERR_ALLOC (-5)    /* device allocation failed                                        */
+
+typedef struct dcgp_ctx dcgp_ctx;
+typedef struct dcgp_model dcgp_model;
+
+/* ---- context, memory, errors ------------------------------------------------------------- */
+int dcgp_ctx_create(int device, dcgp_ctx** out);
+int dcgp_ctx_destroy(dcgp_ctx* ctx);
+const char* dcgp_last_error(dcgp_ctx* ctx);
+int dcgp_device_count(int* count);
+int dcgp_malloc(dcgp_ctx* ctx, size_t bytes, void** dptr);
+int dcgp_free(dcgp_ctx* ctx, void* dptr);
+int dcgp_h2d(dcgp_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int dcgp_d2h(dcgp_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int dcgp_memset(dcgp_ctx* ctx, void* dptr, int value, size_t bytes);
+int dcgp_sync(dcgp_ctx* ctx);
+
+/* ---- per-kernel HIP-event timing (bench.py's roofline leg) -------------------------------- */
+/* When enabled, the launches of the named kernel families ("kuf", "gemm_cond", "potrf", "trtri",
+ * "head_kzx", "head_kdiag", ...) are bracketed by hipEvents on the ctx stream.                 */
+int dcgp_timing_enable(dcgp_ctx* ctx, int on);
+int dcgp_timing_reset(dcgp_ctx* ctx);
+int dcgp_timing_query(dcgp_ctx* ctx, const char* name, int* launches, double* total_ms);
+int dcgp_timing_names(dcgp_ctx* ctx, char* buf, size_t buflen);   /* ';'-separated list */
+
+/* ---- patch view: FullView.extract_patches / extract_patches_PNL (conv_gp/views.py:32-54) --- */
+/* X [N,H,W,C] -> out [N,P,L] (pnl == 0) or [P,N,L] (pnl != 0); VALID window, dilation 1;
+ * p = oh*W' + ow, l = (kh*f + kw)*C + c.                                                         */
+int dcgp_extract_patches(dcgp_ctx* ctx, const double* X, int N, int H, int W, int C, int f, int stride,
+                         double* out, int pnl);
+
+/* ---- inducing-patch kernel matrices ------------------------------------------------------- */
+/* MultiOutputConvKernel.Kuu (conv_gp/layers.py:18-21) == RBF.K(Z) + jitter*I; also the dispatch
+ * Kuu(feature, kern, jitter) of conv_gp/kernels.py:172-174.  Z [M,L] -> out [M,M].               */
+int dcgp_kuu_rbf(dcgp_ctx* ctx, const double* Z, int M, int L, double variance, double lengthscale,
+                 double jitter, double* out_MM);
+/* FullView.extract_patches_PNL + MultiOutputConvKernel.Kuf (conv_gp/views.py:40-44,
+ * conv_gp/layers.py:23-32) fused: the patches are gathered from an LDS-staged image and never
+ * materialised.  X [N,H,W,C], Z [M,L] -> out.  layout 0: [P,M,N] (the reference's Kuf layout);
+ * layout 1: [M, N*P] with column n*P + p (the layout the fused conditional consumes).            */
+int dcgp_kuf_patches_rbf(dcgp_ctx* ctx, const double* X, int N, int H, int W, int C, int f, int stride,
+                         const double* Z, int M, double variance, double lengthscale,
+                         double* out, int layout);
+
+/* ---- dense M x M factorisations ------------------------------------------------------------ */
+/* tf.cholesky (conv_gp/conditionals.py:29, layers.py:151,156): in place, lower factor, strict
+ * upper triangle zeroed.  *info_host = 0, or the 1-based column of the first non-positive pivot
+ * (return value DCGP_ERR_NOT_PD).                                                                */
+int dcgp_potrf_lower(dcgp_ctx* ctx, double* A_MM, int M, int* info_host);
+/* inverse of a lower-triangular factor (the form in which the triangular solves of
+ * conv_gp/conditionals.py:31-33,44-47 are applied on the matrix cores).                          */
+int dcgp_trtri_lower(dcgp_ctx* ctx, const double* L_MM, int M, double* Linv_MM);
+
+/* ---- the conditional ---------------------------------------------------------------------- */
+/* conditional(Kmn, Kmm, Knn, f, full_cov=False, q_sqrt, white) of conv_gp/conditionals.py:6-67.
+ * Kmn [P,M,N], Kmm [M,M] (not overwritten), Knn [P,N], f [M,R], q_sqrt [R,M,M] lower-triangular
+ * (its strict upper triangle is ignored, matrix_band_part at :55) or NULL.
+ * out_mean [N,P,R], out_var [R,P,N].                                                            */
+int dcgp_conditional(dcgp_ctx* ctx, const double* Kmn, const double* Kmm, const double* Knn,
+                     const double* f, const double* q_sqrt, int white, int P, int M, int N, int R,
+                     double* out_mean, double* out_var, int* info_host);
+
+/* ConvLayer.conditional_ND (conv_gp/layers.py:96-135) for the Zero mean function, fused end to
+ * end (patch gather -> Kuf -> Cholesky -> conditional), plus Layer.sample_from_conditional's
+ * reparameterisation when z != NULL.  X [N, H*W*C]; out_* [N, P*R] (column p*R + r); any of the
+ * three outputs may be NULL.  z [N, P*R].  identity_mean != 0 adds Conv2dMean
+ * (conv_gp/mean_functions.py:28-41; odd filter sizes only).                                      */
+int dcgp_conv_layer_forward(dcgp_ctx* ctx, const double* X, int N, int H, int W, int C, int f, int stride,
+                            const double* Z, int M, int R, double variance, double lengthscale,
+                            const double* q_mu, const double* q_sqrt, int white, int identity_mean,
+                            const double* z, double jitter,
+                            double* out_sample, double* out_mean, double* out_var, int* info_host);
+
+/* ---- classification-head kernels ----------------------------------------------------------- */
+/* ConvKernel.Kzx (conv_gp/kernels.py:117-133) / AdditivePatchKernel.Kzx (:63-74; identical
+ * arithmetic): out[m,n] = (1/P) sum_p w[p] k(Z[m], x[n,p]).  X [N,H,W,C], Z [M,L], w [P] -> [M,N] */
+int dcgp_convkernel_kzx(dcgp_ctx* ctx, const double* X, int N, int H, int W, int C, int f, int stride,
+                        const double* Z, int M, double variance, double lengthscale, const double* w,
+                        double* out_MN);
+/* ConvKernel.Kdiag (conv_gp/kernels.py:106-115): out[n] = (1/P^2) sum_{p,p'} w[p] w[p'] k(x[n,p], x[n,p']). */
+int dcgp_convkernel_kdiag(dcgp_ctx* ctx, const double* X, int N, int H, int W, int C, int f, int stride,
+                          double variance, double lengthscale, const double* w, double* out_N);
+/* AdditivePatchKernel.Kdiag (conv_gp/kernels.py:53-61): out[n] = variance * mean_p w[p].        */
+int dcgp_additive_kdiag(dcgp_ctx* ctx, int N, int P, double variance, const double* w, double* out_N);
+
+/* doubly_stochastic_dgp SVGP_Layer.conditional_ND (call site conv_gp/models.py:192-198) given
+ * Kuf [M,N], Ku [M,M] (jitter already added), Kdiag [N]; out_mean, out_var [N,R].               */
+int dcgp_svgp_conditional(dcgp_ctx* ctx, const double* Kuf, const double* Ku, const double* Kdiag,
+                          const double* q_mu, const double* q_sqrt, int white, int M, int N, int R,
+                          double* out_mean, double* out_var, int* info_host);
+
+/* ---- KL, likelihood, sampling --------------------------------------------------------------- */
+/* gpflow.kullback_leiblers.gauss_kl(q_mu, q_sqrt, K) (call sites conv_gp/layers.py:145,147);
+ * K == NULL is the whitened prior.  q_mu [M,R], q_sqrt [R,M,M], K [M,M].                         */
+int dcgp_gauss_kl(dcgp_ctx* ctx, const double* q_mu, const double* q_sqrt, const double* K, int M, int R,
+                  double* out_host, int* info_host);
+/* gpflow MultiClass(K) + RobustMax(eps).variational_expectations, 20 Gauss-Hermite points (call
+ * site conv_gp/models.py:67).  mu, var [n,K]; y [n] int32 -> out [n].                            */
+int dcgp_robustmax_varexp(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t* y, int n,
+                          int K, double eps, double* out_n);
+/* MultiClass.predict_mean_and_var: per-class probabilities [n,K].                                */
+int dcgp_robustmax_predict(dcgp_ctx* ctx, const double* mu, const double* var, int n, int K, double eps,
+                           double* out_p);
+/* doubly_stochastic_dgp.utils.reparameterize: out = mean + z*sqrt(var + jitter), n elements.     */
+int dcgp_reparam(dcgp_ctx* ctx, const double* mean, const double* var, const double* z, size_t n,
+                 double jitter, double* out);
+
+/* ---- model-level path: DGP_Base.propagate / _build_likelihood (doubly_stochastic_dgp, call sites
+ *      conv_gp/models.py:65-70, conv_gp/utils/tensorboard.py:32) ------------------------------- */
+int dcgp_model_create(dcgp_ctx* ctx, int num_samples, double jitter, dcgp_model** out);
+int dcgp_model_destroy(dcgp_model* model);
+/* ConvLayer (conv_gp/layers.py:52-94).  Parameter arrays are HOST pointers, copied to the device.
+ * Z0 is the frozen initial Z of the KL prior (conv_gp/layers.py:149-152); NULL -> Z.             */
+int dcgp_model_add_conv_layer(dcgp_model* model, int H, int W, int C, int f, int stride, int M, int R,
+                              int white, int identity_mean, double variance, double lengthscale,
+                              const double* Z_host, const double* Z0_host,
+                              const double* q_mu_host, const double* q_sqrt_host);
+/* SVGP_Layer(kern=ConvKernel|AdditivePatchKernel) (conv_gp/models.py:169-198).
+ * kernel_type 0 = ConvKernel, 1 = AdditivePatchKernel.                                           */
+int dcgp_model_set_head(dcgp_model* model, int H, int W, int C, int f, int stride, int M, int R,
+                        int white, int kernel_type, double variance, double lengthscale,
+                        const double* Z_host, const double* w_host,
+                        const double* q_mu_host, const double* q_sqrt_host);
+/* keep every layer's (sample, mean, var) of the next forward passes for dcgp_model_layer_output   */
+int dcgp_model_set_keep_outputs(dcgp_model* model, int on);
+/* Push a changed parameter: which = "Z", "Z0", "q_mu", "q_sqrt", "w", "variance", "lengthscale".  */
+int dcgp_model_set_param(dcgp_model* model, int layer, const char* which, const double* value_host,
+                         size_t count);
+
+/* One forward ELBO evaluation of a minibatch (compute_log_likelihood semantics):
+ *   X [N, H*W*C], y [N] int32 (device).  z_per_layer_host: array of num_layers DEVICE pointers,
+ *   each [S, N, D_l] standard-normal noise (entries may be NULL -> counter-based device RNG with
+ *   `seed`); NULL -> RNG for all layers.  scale = num_data / global_batch.  dedup_layer0 != 0
+ *   evaluates the first layer on the N distinct images only (propagate() tiles X S times, so the
+ *   S copies are identical; results are bit-identical either way).
+ *   If the ctx holds a communicator (dcgp_comm_init_rank) the data term is all-reduced (sum) over
+ *   the ranks before scaling.  out_host[0] = ELBO, [1] = sum_n E_q log p(y_n) (global), [2] = sum KL. */
+int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
+                      const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0,
+                      double* out_host, int* info_host);
+/* DGP_Base.propagate(X, S) -> last layer's Fmean, Fvar [S*N, R] (device buffers owned by caller) */
+int dcgp_model_propagate(dcgp_model* model, const double* X, int N, int S,
+                         const double* const* z_per_layer_host, uint64_t seed,
+                         double* out_fmean, double* out_fvar, int* info_host);
+/* Output of layer `layer` from the most recent forward: sample/mean/var [rows, D_l] device->device copy. */
+int dcgp_model_layer_output(dcgp_model* model, int layer, double* out_sample, double* out_mean,
+                            double* out_var, int* rows, int* width);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------ */
+int dcgp_comm_unique_id(unsigned char* out_128bytes);
+int dcgp_comm_init_rank(dcgp_ctx* ctx, int nranks, int rank, const unsigned char* id_128bytes);
+int dcgp_comm_destroy(dcgp_ctx* ctx);
+int dcgp_allreduce_sum_f64(dcgp_ctx* ctx, double* buf_dev, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCGP_H */

@@ -1,0 +1,180 @@
+"""GPU parity of the model-level path (one dcgp_elbo_forward call per minibatch) against the oracle, the
+committed golden vectors, and -- at BASELINE.json's full sizes -- through size-independent properties."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from deepcgp_amd import synthetic as syn
+from deepcgp_amd.models import build_from_spec
+from deepcgp_amd.dist import shard_batch, assemble_elbo
+from oracle_build import oracle_model
+from golden.make_golden import unflatten_spec
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+RTOL = 1e-9          # fp64 end to end; the north star's bar is 1e-4
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_vectors(ctx, path):
+    d = np.load(path)
+    spec = unflatten_spec(d)
+    nl = len(spec["convs"]) + 1
+    zs = [d["z%d" % i] for i in range(nl)]
+    model = build_from_spec(spec, d["X"], d["Y"])
+    Fs, Fm, Fv = model.propagate(d["X"], S=spec["S"], zs=zs)
+    for i in range(nl):
+        assert rel(Fm[i], d["Fmean%d" % i]) < RTOL, ("Fmean", i)
+        assert rel(Fv[i], d["Fvar%d" % i]) < RTOL, ("Fvar", i)
+        assert rel(Fs[i], d["Fs%d" % i]) < RTOL, ("Fs", i)
+    elbo, data, kl = model.compute_log_likelihood(d["X"], d["Y"], zs=zs, return_parts=True)
+    assert abs(elbo - float(d["elbo"])) <= RTOL * abs(float(d["elbo"]))
+    assert abs(data - float(d["data_term"])) <= RTOL * abs(float(d["data_term"]))
+    assert abs(kl - float(d["kl"])) <= RTOL * abs(float(d["kl"]))
+    # layer-0 de-duplication is exact: the S copies of the batch are identical
+    model.dedup_layer0 = True
+    assert model.compute_log_likelihood(d["X"], d["Y"], zs=zs) == elbo
+    # per-layer KL through the operator API agrees with the fused path
+    assert abs(model.KL() - kl) <= 1e-10 * abs(kl)
+    model.close()
+
+
+@pytest.mark.parametrize("white", [False, True])
+@pytest.mark.parametrize("case", ["cfg1_small", "ch_M40", "three_layer_cifar"])
+def test_elbo_vs_oracle_midsize(ctx, case, white):
+    if case == "cfg1_small":        # BASELINE configs[0] geometry (28x28x1, head f5 s1, P = 576, M = 32), S = 2, 4 images
+        hwc, convs, head, M, N, S = (28, 28, 1), [], (5, 1), 32, 4, 2
+    elif case == "ch_M40":          # configs[1] geometry with M not a multiple of 16
+        hwc, convs, head, M, N, S = (28, 28, 1), [(5, 2, 10)], (5, 1), 40, 3, 2
+    else:                           # configs[3] geometry (CIFAR 3-layer), small M
+        hwc, convs, head, M, N, S = (32, 32, 3), [(4, 2, 10), (5, 1, 10)], (5, 1), 24, 2, 2
+    spec = syn.make_spec(hwc, convs, head, M, S=S, num_data=50000, seed=42, white=white, conv_q_sqrt_scale=0.2)
+    X, Y = syn.make_batch(hwc, N, seed=42)
+    zs = syn.make_noise(spec, N, seed=42)
+    ref = oracle_model(spec, X, Y)
+    model = build_from_spec(spec, X, Y)
+    e, dt, kl = model.compute_log_likelihood(X, Y, zs=zs, return_parts=True)
+    assert abs(dt - ref.data_term(X, Y, zs=zs)) <= RTOL * abs(dt)
+    assert abs(kl - ref.KL()) <= RTOL * max(abs(kl), 1.0)
+    assert abs(e - ref.compute_log_likelihood(X, Y, zs=zs)) <= RTOL * abs(e)
+    pm, pv = model.predict_y(X, S, zs=zs)
+    om, ov = ref.predict_y(X, S, zs=zs)
+    assert rel(pm, om) < RTOL and rel(pv, ov) < RTOL
+    model.close()
+
+
+def test_init_state_models_ill_conditioned(ctx):
+    """Reference initial state (q_mu = 0, q_sqrt = 1e-5 chol(Kuu), conv_gp/models.py:136-138) on smooth
+    images: var ~ 1e-3 from catastrophic cancellation in Kdiag - sum A^2 -- the case all-fp32 fails."""
+    hwc = (28, 28, 1)
+    spec = syn.make_spec(hwc, [(5, 2, 10)], (5, 1), M=96, S=2, num_data=60000, seed=7, q_mu_random=False)
+    X, Y = syn.make_batch(hwc, 3, seed=7)
+    zs = syn.make_noise(spec, 3, seed=7)
+    ref, model = oracle_model(spec, X, Y), build_from_spec(spec, X, Y)
+    _, Fm, Fv = model.propagate(X, S=2, zs=zs)
+    _, om, ov = ref.propagate(X, S=2, zs=zs)
+    assert np.min(ov[0]) < 0.1            # the cancellation regime is actually reached
+    for i in range(2):
+        assert rel(Fm[i], om[i]) < 1e-8 and np.max(np.abs(Fv[i] - ov[i]) / np.maximum(np.abs(ov[i]), 1e-6)) < 1e-6
+    e = model.compute_log_likelihood(X, Y, zs=zs)
+    assert abs(e - ref.compute_log_likelihood(X, Y, zs=zs)) <= 1e-8 * abs(e)
+    model.close()
+
+
+def test_parameter_push_and_frozen_prior(ctx):
+    hwc = (12, 12, 1)
+    spec = syn.make_spec(hwc, [(3, 2, 4)], (3, 1), M=10, S=2, num_data=500, seed=5, conv_q_sqrt_scale=0.3)
+    X, Y = syn.make_batch(hwc, 4, seed=5)
+    zs = syn.make_noise(spec, 4, seed=5)
+    model = build_from_spec(spec, X, Y)
+    e0 = model.compute_log_likelihood(X, Y, zs=zs)
+    rng = np.random.default_rng(0)
+    # train-like update: Z, q_mu, hyper-parameters move; the KL prior keeps the initial Z (conv_gp/layers.py:149-152)
+    spec["convs"][0]["Z"] = spec["convs"][0]["Z"] + 0.1 * rng.standard_normal(spec["convs"][0]["Z"].shape)
+    spec["convs"][0]["q_mu"] = rng.standard_normal(spec["convs"][0]["q_mu"].shape)
+    spec["convs"][0]["variance"], spec["convs"][0]["ls"] = 3.0, 4.0
+    spec["head"]["w"] = 0.5 + rng.random(spec["head"]["w"].shape)
+    l0, h = model.layers[0], model.layers[1]
+    l0.feature.Z, l0.q_mu = spec["convs"][0]["Z"], spec["convs"][0]["q_mu"]
+    l0.base_kernel.variance, l0.base_kernel.lengthscales = 3.0, 4.0
+    h.kern.patch_weights = spec["head"]["w"]
+    model.sync_parameters()
+    e1 = model.compute_log_likelihood(X, Y, zs=zs)
+    ref = oracle_model(spec, X, Y).compute_log_likelihood(X, Y, zs=zs)
+    assert e1 != e0 and abs(e1 - ref) <= RTOL * abs(ref)
+    names = [p.pathname for p in model.parameters]
+    assert "DGP/layers/0/conv_kernel/base_kernel/variance" in names and "DGP/layers/1/kern/patch_weights" in names
+    assert "DGP/layers/0/feature/Z" in names and "DGP/layers/1/q_sqrt" in names
+    model.close()
+
+
+def test_device_rng_path(ctx):
+    hwc = (12, 12, 1)
+    spec = syn.make_spec(hwc, [(3, 2, 4)], (3, 1), M=10, S=50, num_data=500, seed=5, conv_q_sqrt_scale=1.0)
+    X, Y = syn.make_batch(hwc, 4, seed=5)
+    model = build_from_spec(spec, X, Y)
+    a = model.compute_log_likelihood(X, Y, seed=1)
+    assert a == model.compute_log_likelihood(X, Y, seed=1) and a != model.compute_log_likelihood(X, Y, seed=2)
+    Fs, Fm, Fv = model.propagate(X, S=400, seed=3)
+    zhat = (Fs[0] - Fm[0]) / np.sqrt(Fv[0] + 1e-3)            # recovered standard normals
+    assert abs(zhat.mean()) < 0.01 and abs(zhat.std() - 1.0) < 0.01
+    assert abs(np.mean(zhat ** 3)) < 0.03 and abs(np.mean(zhat ** 4) - 3.0) < 0.1
+    model.close()
+
+
+def test_shards_sum_to_full_batch_on_gpu(ctx):
+    hwc = (28, 28, 1)
+    spec = syn.make_spec(hwc, [(5, 2, 10)], (5, 1), M=32, S=3, num_data=60000, seed=9, conv_q_sqrt_scale=0.2)
+    X, Y = syn.make_batch(hwc, 7, seed=9)
+    zs = syn.make_noise(spec, 7, seed=9)
+    model = build_from_spec(spec, X, Y)
+    full, data, kl = model.compute_log_likelihood(X, Y, zs=zs, return_parts=True)
+    for world in (2, 4):
+        tot = 0.0
+        for rank in range(world):
+            Xs, Ys, zl = shard_batch(X, Y, zs, rank, world)
+            tot += model.compute_log_likelihood(Xs, Ys, zs=zl, return_parts=True)[1]
+        assert abs(assemble_elbo(tot, kl, spec["num_data"], 7) - full) <= 1e-12 * abs(full)
+    model.close()
+
+
+@pytest.mark.parametrize("name", ["cfg2_mnist_CH_M256", "cfg2_mnist_H_M256"])
+def test_full_size_properties(ctx, name):
+    """BASELINE configs[1] at full size (M = 256, batch 32, S = 10): properties that need no oracle run."""
+    spec, X, Y = syn.make_config(name)
+    zs = syn.make_noise(spec, X.shape[0], seed=1)
+    model = build_from_spec(spec, X, Y)
+    e, data, kl = model.compute_log_likelihood(X, Y, zs=zs, return_parts=True)
+    assert np.isfinite([e, data, kl]).all() and kl > 0 and data < 0
+    assert abs(e - (data * spec["num_data"] / X.shape[0] - kl)) <= 1e-12 * abs(e)
+    model.dedup_layer0 = True
+    assert model.compute_log_likelihood(X, Y, zs=zs) == e                      # exact de-duplication
+    model.dedup_layer0 = False
+    perm = np.random.default_rng(0).permutation(X.shape[0])                     # image order is irrelevant
+    e_p = model.compute_log_likelihood(X[perm], Y[perm], zs=[z[:, perm] for z in zs])
+    assert abs(e_p - e) <= 1e-11 * abs(e)
+    lo = model.compute_log_likelihood(X[:16], Y[:16], zs=[z[:, :16] for z in zs], return_parts=True)[1]
+    hi = model.compute_log_likelihood(X[16:], Y[16:], zs=[z[:, 16:] for z in zs], return_parts=True)[1]
+    assert abs((lo + hi) - data) <= 1e-11 * abs(data)                           # shard additivity
+    model.close()
+
+
+def test_full_size_cfg2_vs_oracle(ctx):
+    """The headline configuration against the oracle itself on a reduced batch (S = 2, 4 images, full M = 256)."""
+    spec, X, Y = syn.make_config("cfg2_mnist_CH_M256", S=2)
+    X, Y = X[:4], Y[:4]
+    zs = syn.make_noise(spec, 4, seed=2)
+    model, ref = build_from_spec(spec, X, Y), oracle_model(spec, X, Y)
+    e, data, kl = model.compute_log_likelihood(X, Y, zs=zs, return_parts=True)
+    assert abs(data - ref.data_term(X, Y, zs=zs)) <= 1e-8 * abs(data)
+    assert abs(kl - ref.KL()) <= 1e-8 * abs(kl)
+    assert abs(e - ref.compute_log_likelihood(X, Y, zs=zs)) <= 1e-8 * abs(e)
+    model.close()

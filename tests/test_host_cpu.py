@@ -1,0 +1,101 @@
+"""CPU: host-side logic and the C-ABI surface (no compute calls without a GPU)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from deepcgp_amd import device as dev, synthetic as syn
+from deepcgp_amd.dist import shard_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = dev.lib()
+    declared = dev.declared_symbols()
+    assert len(declared) >= 40
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(dev._SIGS) == declared            # the ctypes table covers the whole header, nothing more
+
+
+def test_no_device_fails_loudly():
+    if dev.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(dev.DcgpError):
+        dev.Context(0)
+
+
+def test_null_ctx_is_an_argument_error():
+    L = dev.lib()
+    assert L.dcgp_sync(None) == dev.ERR_ARG
+    assert L.dcgp_kuu_rbf(None, None, 4, 4, 1.0, 1.0, 0.0, None) == dev.ERR_ARG
+    assert L.dcgp_model_destroy(None) == dev.ERR_ARG
+    n = ctypes.c_int(-1)
+    assert L.dcgp_device_count(ctypes.byref(n)) == 0 and n.value >= 0
+
+
+def test_fullview_host_geometry():
+    from deepcgp_amd.views import FullView
+    v = FullView((28, 28), 5, 1)
+    assert (v.patch_count, v.patch_length, v.out_image_height, v.out_image_width) == (576, 25, 24, 24)
+    v = FullView((28, 28), 5, 1, stride=2)
+    assert (v.patch_count, v.out_image_height) == (144, 12)
+    v = FullView((32, 32), 4, 3, stride=2)
+    assert (v.patch_count, v.patch_length) == (225, 48)
+    v = FullView((15, 15, 10), 5, 10)
+    assert (v.patch_count, v.patch_length, v.dilation, v.patch_shape) == (121, 250, 1, [5, 5])
+    with pytest.raises(ValueError):
+        FullView((4, 4), 5, 1)
+
+
+def test_parse_ints_and_flags():
+    from deepcgp_amd.models import parse_ints
+    from deepcgp_amd.arguments import default_parser, train_steps
+    assert parse_ints('') == [] and parse_ints('384,384') == [384, 384]
+    flags = default_parser().parse_args(['--name', 'x'])
+    assert (flags.M, flags.feature_maps, flags.filter_sizes, flags.strides) == ('384,384', '10', '5,5', '2,1')
+    assert flags.batch_size == 32 and flags.num_samples == 10 and not flags.white and flags.last_kernel == 'conv'
+    assert train_steps(flags) == 5
+
+
+def test_synthetic_configs_shapes():
+    spec, X, Y = syn.make_config("cfg1_mnist_H_M32", S=2)
+    assert X.shape == (32, 784) and Y.shape == (32,) and spec["head"]["Z"].shape == (32, 25) and not spec["convs"]
+    spec = syn.make_spec((28, 28, 1), [(5, 2, 10)], (5, 1), M=8, S=2)
+    c, h = spec["convs"][0], spec["head"]
+    assert (c["H"], c["W"], c["C"]) == (28, 28, 1) and (h["H"], h["W"], h["C"]) == (12, 12, 10)
+    assert h["Z"].shape == (8, 250) and h["w"].shape == (64,) and c["q_sqrt"].shape == (10, 8, 8)
+    assert syn.layer_output_dims(spec) == [1440, 10]
+    zs = syn.make_noise(spec, 3)
+    assert [z.shape for z in zs] == [(2, 3, 1440), (2, 3, 10)]
+    spec3 = syn.make_spec((32, 32, 3), [(4, 2, 10), (5, 1, 10)], (5, 1), M=4, S=1)
+    assert [(c["H"], c["C"]) for c in spec3["convs"]] == [(32, 3), (15, 10)] and spec3["head"]["H"] == 11
+
+
+def test_shard_range():
+    for n in (0, 1, 7, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def test_two_rank_gloo_elbo_allreduce():
+    """world_size-2 run of the N>1 assembly path on CPU: gloo all-reduce of the per-rank data term."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
+    worker = os.path.join(ROOT, "tests", "gloo_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker], env=dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    vals = [float(o.strip().splitlines()[-1].split()[-1]) for o in outs]
+    assert vals[0] == vals[1]
+    assert "OK" in outs[0]

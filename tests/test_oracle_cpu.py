@@ -1,0 +1,187 @@
+"""CPU: pins the oracle (test infrastructure) -- known-answer tests, agreement with the independent
+restatement oracle/alt.py, the shape facts the reference's own tests hold, and the committed golden vectors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from deepcgp_amd import synthetic as syn
+from oracle import alt
+from oracle.gpflow_ref import RBF, gauss_kl, MultiClass, JITTER
+from oracle.views import FullView
+from oracle.layers import ConvLayer, MultiOutputConvKernel
+from oracle.kernels import ConvKernel, AdditivePatchKernel
+from oracle.conditionals import conditional
+from oracle.dgp import SVGP_Layer
+from oracle_build import oracle_model
+from golden.make_golden import unflatten_spec
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def test_reference_test_shape_facts():
+    # /root/reference/tests/test_mean_functions.py:25,35 -- FullView((28,28),5,1) has 576 patches
+    v = FullView((28, 28), 5, 1)
+    assert v.patch_count == 576 and v.patch_length == 25
+    assert v.extract_patches_PNL(np.zeros((10, 28, 28, 1))).shape == (576, 10, 25)
+    # /root/reference/tests/test_mean_functions.py:41-46 -- filter 3 on 28x28 gives 676 positions
+    assert FullView((28, 28), 3, 1).patch_count == 676
+    # /root/reference/tests/test_conv_kernel.py:58-68 -- Kuf is patch_count x M x N
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((2, 28, 28, 1))
+    v3 = FullView((28, 28), 3, 1)
+    mok = MultiOutputConvKernel(RBF(9), 784, v3.patch_count)
+    Z = rng.standard_normal((16, 9))
+    assert mok.Kuf(Z, v3.extract_patches_PNL(X)).shape == (676, 16, 2)
+    # /root/reference/tests/test_conv_kernel.py:46-56 -- Kuu is M x M with rbf(Z0,Z0) + jitter on the diagonal
+    Kuu = mok.Kuu(Z)
+    assert Kuu.shape == (16, 16)
+    np.testing.assert_allclose(np.diag(Kuu), 1.0 + JITTER, rtol=1e-14)
+
+
+def test_patch_index_maps():
+    # p = oh*W' + ow ; l = (kh*f + kw)*C + c  (/root/reference/tests/test_views.py:33-34 checks one patch this way)
+    rng = np.random.default_rng(1)
+    H, W, C, f, s = 9, 7, 3, 4, 2
+    X = rng.standard_normal((2, H, W, C))
+    v = FullView((H, W), f, C, s)
+    pat = v.extract_patches(X)
+    for (n, oh, ow, kh, kw, c) in [(0, 0, 0, 0, 0, 0), (1, 2, 1, 3, 2, 1), (0, 1, 0, 2, 3, 2)]:
+        p, l = oh * v.out_image_width + ow, (kh * f + kw) * C + c
+        assert pat[n, p, l] == X[n, oh * s + kh, ow * s + kw, c]
+    np.testing.assert_array_equal(pat, alt.patches_NPL(X, f, s))
+    np.testing.assert_array_equal(pat[0, 0], X[0, 0:f, 0:f, :].ravel())
+
+
+@pytest.mark.parametrize("white", [False, True])
+def test_conditional_matches_closed_form(white):
+    rng = np.random.default_rng(2)
+    H, W, C, f, s, M, R, N = 8, 8, 2, 3, 1, 6, 3, 4
+    X = rng.standard_normal((N, H, W, C))
+    v = FullView((H, W), f, C, s)
+    Z = rng.standard_normal((M, v.patch_length))
+    q_mu = rng.standard_normal((M, R))
+    q_sqrt = np.tril(rng.standard_normal((R, M, M))) * 0.3 + np.eye(M)
+    layer = ConvLayer(RBF(v.patch_length, 5.0, 5.0), None, Z, v, white=white, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
+    m, var = layer.conditional_ND(X.reshape(N, -1))
+    m2, v2 = alt.conv_layer_moments(X, f, s, Z, 5.0, 5.0, q_mu, q_sqrt, white)
+    np.testing.assert_allclose(m, m2, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(var, v2, rtol=0, atol=1e-10)
+    kp = None if white else alt.rbf(Z, Z, 5.0, 5.0) + JITTER * np.eye(M)
+    np.testing.assert_allclose(layer.KL(), alt.gauss_kl(q_mu, q_sqrt, kp), rtol=1e-11)
+
+
+def test_known_answers():
+    rng = np.random.default_rng(3)
+    H, W, C, f, s, M, R, N = 10, 10, 1, 5, 2, 12, 4, 3
+    X = rng.standard_normal((N, H * W * C))
+    v = FullView((H, W), f, C, s)
+    Z = rng.standard_normal((M, v.patch_length))
+    k = RBF(v.patch_length, 5.0, 5.0)
+    # (1) not white, q_mu = 0, q_sqrt = chol(Kuu): mean = 0, var = Kdiag; KL = 0  (state of conv_gp/layers.py:154-161)
+    l0 = ConvLayer(k, None, Z, v, gp_count=R)
+    m, var = l0.conditional_ND(X)
+    assert np.max(np.abs(m)) == 0.0
+    np.testing.assert_allclose(var, 5.0, rtol=0, atol=1e-11)
+    assert abs(l0.KL()) < 1e-9
+    # (2) white, q_mu = 0, q_sqrt = I: var = Kdiag  (conv_gp/layers.py:89); KL = 0
+    l1 = ConvLayer(k, None, Z, v, white=True, gp_count=R)
+    m, var = l1.conditional_ND(X)
+    np.testing.assert_allclose(var, 5.0, rtol=0, atol=1e-11)
+    assert abs(l1.KL()) < 1e-12
+    # (3) a patch equal to an inducing patch and q_sqrt -> 0: var -> O(jitter), mean -> row of K^-1 K . q_mu
+    Xi = rng.standard_normal((1, H, W, C))
+    Mz = 6
+    Zp = v.extract_patches(Xi)[0, :Mz].copy()
+    q_mu6 = rng.standard_normal((Mz, R))
+    l2 = ConvLayer(k, None, Zp, v, gp_count=R, q_mu=q_mu6, q_sqrt=np.tile(np.eye(Mz)[None], [R, 1, 1]) * 1e-9)
+    m, var = l2.conditional_ND(Xi.reshape(1, -1))
+    var = var.reshape(v.patch_count, R)
+    assert np.all(var[:Mz] < 5 * JITTER) and np.all(var[:Mz] > 0)
+    Kuu = k.K(Zp) + JITTER * np.eye(Mz)
+    np.testing.assert_allclose(m.reshape(v.patch_count, R)[:Mz], k.K(Zp) @ np.linalg.solve(Kuu, q_mu6), atol=1e-9)
+    q_mu = rng.standard_normal((M, R))
+    # (4) RBF Kdiag == variance, Kuu diagonal == variance + jitter
+    np.testing.assert_array_equal(k.Kdiag(Z), np.full(M, 5.0))
+    # (5) S-replication invariance of layer 0 (propagate tiles X S times)
+    m1, v1 = ConvLayer(k, None, Z, v, gp_count=R, q_mu=q_mu).conditional_ND(np.tile(X, [3, 1]))
+    np.testing.assert_array_equal(m1[:N], m1[N:2 * N])
+    np.testing.assert_array_equal(v1[:N], v1[2 * N:])
+
+
+def test_head_and_likelihood_against_alt():
+    rng = np.random.default_rng(4)
+    H, W, C, f, s, M, R, N = 7, 7, 3, 3, 1, 8, 10, 5
+    X = rng.standard_normal((N, H * W * C))
+    v = FullView((H, W, C), f, C, s)
+    w = rng.random(v.patch_count) + 0.5
+    Z = rng.standard_normal((M, v.patch_length))
+    q_mu = rng.standard_normal((M, R))
+    q_sqrt = np.tril(rng.standard_normal((R, M, M))) * 0.3 + np.eye(M)
+    kern = ConvKernel(RBF(v.patch_length, 5.0, 5.0), v, w)
+    Xi = X.reshape(N, H, W, C)
+    np.testing.assert_allclose(kern.Kzx(Z, X), alt.conv_kernel_Kzx(Xi, f, s, Z, 5.0, 5.0, w), atol=1e-12)
+    np.testing.assert_allclose(kern.Kdiag(X), alt.conv_kernel_Kdiag(Xi, f, s, 5.0, 5.0, w), atol=1e-12)
+    add = AdditivePatchKernel(RBF(v.patch_length, 5.0, 5.0), v, w)
+    np.testing.assert_allclose(add.Kzx(Z, X), kern.Kzx(Z, X), atol=1e-14)       # identical arithmetic
+    np.testing.assert_allclose(add.Kdiag(X), np.full(N, 5.0 * w.mean()), atol=1e-14)
+    for white in (False, True):
+        head = SVGP_Layer(kern, R, Z, None, white, q_mu, q_sqrt)
+        m, var = head.conditional_ND(X)
+        m2, v2 = alt.svgp_head_moments(Xi, f, s, Z, 5.0, 5.0, w, q_mu, q_sqrt, white)
+        np.testing.assert_allclose(m, m2, atol=1e-10)
+        np.testing.assert_allclose(var, v2, atol=1e-10)
+        kp = None if white else alt.rbf(Z, Z, 5.0, 5.0) + JITTER * np.eye(M)
+        np.testing.assert_allclose(head.KL(), alt.gauss_kl(q_mu, q_sqrt, kp), rtol=1e-11)
+        np.testing.assert_allclose(head.KL(), gauss_kl(q_mu, q_sqrt, kp), rtol=1e-12)
+    mu, var, y = rng.standard_normal((6, 10)), rng.random((6, 10)) + 0.1, rng.integers(0, 10, 6)
+    lik = MultiClass(10)
+    np.testing.assert_allclose(lik.variational_expectations(mu, var, y), alt.robustmax_varexp(mu, var, y), rtol=1e-12)
+    p, _ = lik.predict_mean_and_var(mu, var)
+    assert np.all(p > 0) and np.all(p < 1)
+    # one dominant class with tiny variance: every clamped cdf factor saturates at 1 - 1e-4
+    mu2 = np.zeros((1, 10)); mu2[0, 3] = 50.0
+    p_sat = (1 - 1e-4) ** 9
+    np.testing.assert_allclose(lik.variational_expectations(mu2, np.full((1, 10), 1e-3), [3]),
+                               p_sat * np.log(1 - 1e-3) + (1 - p_sat) * np.log(1e-3 / 9), rtol=1e-10)
+
+
+def test_conditional_q_sqrt_rank_error():
+    with pytest.raises(ValueError):
+        conditional(np.zeros((1, 2, 3)), np.eye(2), np.zeros((1, 3)), np.zeros((2, 1)), q_sqrt=np.zeros((2, 2)))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_vectors_pin_the_oracle(path):
+    d = np.load(path)
+    spec = unflatten_spec(d)
+    nl = len(spec["convs"]) + 1
+    zs = [d["z%d" % i] for i in range(nl)]
+    model = oracle_model(spec, d["X"], d["Y"])
+    Fs, Fm, Fv = model.propagate(d["X"], S=spec["S"], zs=zs)
+    for i in range(nl):
+        np.testing.assert_allclose(Fs[i], d["Fs%d" % i], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(Fm[i], d["Fmean%d" % i], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(Fv[i], d["Fvar%d" % i], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(model.compute_log_likelihood(d["X"], d["Y"], zs=zs), float(d["elbo"]), rtol=1e-12)
+    e2, d2, k2 = alt.elbo(spec, d["X"], d["Y"], zs, spec["num_data"])
+    np.testing.assert_allclose([e2, d2, k2], [float(d["elbo"]), float(d["data_term"]), float(d["kl"])], rtol=1e-10)
+
+
+def test_shard_sum_equals_full_batch():
+    # the multi-GPU decomposition: sum of per-shard data terms == full-batch data term (N not divisible too)
+    from deepcgp_amd.dist import shard_batch, assemble_elbo
+    hwc = (10, 10, 1)
+    spec = syn.make_spec(hwc, [(3, 2, 3)], (3, 1), M=6, S=2, num_data=777, seed=8, conv_q_sqrt_scale=0.3)
+    X, Y = syn.make_batch(hwc, 7, seed=8)
+    zs = syn.make_noise(spec, 7, seed=8)
+    model = oracle_model(spec, X, Y)
+    full = model.compute_log_likelihood(X, Y, zs=zs)
+    for world in (1, 2, 4, 8):
+        total = 0.0
+        for rank in range(world):
+            Xs, Ys, zl = shard_batch(X, Y, zs, rank, world)
+            if len(Xs):
+                total += model.data_term(Xs, Ys, zs=zl)
+        np.testing.assert_allclose(assemble_elbo(total, model.KL(), spec["num_data"], 7), full, rtol=1e-12)
