@@ -45,6 +45,55 @@ __device__ __forceinline__ void tile64_mfma(const double* __restrict__ A, long s
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// wavefront-level 32x32 routines: lane r (< 32; lanes 32..63 mirror) holds row r of the block in registers.
+// Wave-uniform values (pivots, multipliers) are broadcast with v_readlane (no LDS crossbar); reciprocal
+// square roots come from v_rsq_f64 + two Newton steps instead of the long sqrt / divide sequences.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double bcast_lane(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rsqrt_nr(double p) {
+  double y = __builtin_amdgcn_rsq(p);
+  y = y * fma(-0.5 * p * y, y, 1.5);
+  y = y * fma(-0.5 * p * y, y, 1.5);
+  return y;
+}
+// in-place Cholesky of the rows held in a[]; returns 0 or the 1-based column of the first bad pivot
+__device__ __forceinline__ int wave_potrf32(double (&a)[NB], int r) {
+  int fail = 0;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    const double piv = bcast_lane(a[c], c);
+    if (!(piv > 0.0) && fail == 0) fail = c + 1;
+    const double y = rsqrt_nr(piv);
+    double d = piv * y;
+    d = fma(0.5 * y, fma(-d, d, piv), d);       // one correction step: d = sqrt(piv) to ~1 ulp
+    if (r == c) a[c] = d;
+    else if (r > c) a[c] = a[c] * y;
+#pragma unroll
+    for (int cc = c + 1; cc < NB; ++cc) {
+      const double v = bcast_lane(a[c], cc);      // L[cc][c]
+      if (r >= cc) a[cc] = fma(-a[c], v, a[cc]);
+    }
+  }
+  return fail;
+}
+// inverse of the lower-triangular rows in a[]: lane c returns column c of the inverse in x[]
+__device__ __forceinline__ void wave_trtri32(const double (&a)[NB], int c, double (&x)[NB]) {
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    const double dinv = 1.0 / bcast_lane(a[r], r);
+    double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < r; ++q) s = fma(-bcast_lane(a[q], r), x[q], s);   // x[q] == 0 for q < c
+    x[r] = s * dinv;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // potrf panel: factor diag block (wave 0, registers) + row-per-lane trsm of the rows below
 // grid (max(1, ceil(rows_below / 256)), batch), block 256
@@ -52,6 +101,7 @@ __device__ __forceinline__ void tile64_mfma(const double* __restrict__ A, long s
 __global__ __launch_bounds__(256) void potrf_panel_kernel(double* const* __restrict__ ptrs, int Mp, int ld, int j,
                                                            int* __restrict__ info) {
   __shared__ double D[NB][NB + 1];
+  __shared__ double Dr[NB];   // reciprocal diagonal of the factored block
   double* __restrict__ A = ptrs[blockIdx.y];
   const int tid = threadIdx.x;
   const int nb = min(NB, Mp - j);
@@ -63,27 +113,18 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* const* __restr
   }
   __syncthreads();
   if (tid < 64) {
-    const int r = tid & 31;   // lanes 32..63 mirror lanes 0..31 (keeps shuffles wave-uniform)
+    const int r = tid & 31;   // lanes 32..63 mirror lanes 0..31
     double a[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) a[c] = D[r][c];
-    int fail = 0;
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      double piv = __shfl(a[c], c);
-      if (!(piv > 0.0) && fail == 0) fail = c + 1;
-      double d = sqrt(piv);
-      if (r == c) a[c] = d;
-      else if (r > c) a[c] = a[c] / d;
-#pragma unroll
-      for (int cc = c + 1; cc < NB; ++cc) {
-        double v = __shfl(a[c], cc);
-        if (r >= cc) a[cc] -= a[c] * v;
-      }
-    }
+    const int fail = wave_potrf32(a, r);
     if (tid < 32) {
 #pragma unroll
       for (int c = 0; c < NB; ++c) D[r][c] = (c <= r) ? a[c] : 0.0;
+      double diag = a[0];
+#pragma unroll
+      for (int c = 1; c < NB; ++c) diag = (c == r) ? a[c] : diag;
+      Dr[r] = 1.0 / diag;
     }
     if (tid == 0 && fail && blockIdx.x == 0 && info[blockIdx.y] == 0) info[blockIdx.y] = j + fail;
   }
@@ -113,10 +154,9 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* const* __restr
     }
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-      double s = x[c];
+      x[c] = x[c] * Dr[c];
 #pragma unroll
-      for (int q = 0; q < c; ++q) s -= x[q] * D[c][q];
-      x[c] = s / D[c][c];
+      for (int q = c + 1; q < NB; ++q) x[q] = fma(-x[c], D[q][c], x[q]);
     }
 #pragma unroll
     for (int c = 0; c < NB; c += 2) *reinterpret_cast<double2*>(Ar + c) = double2{x[c], x[c + 1]};
@@ -173,18 +213,16 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(double* const* __restric
     Xs[r][c] = 0.0;
   }
   __syncthreads();
-  if (tid < NB) {
-    const int c = tid;
-    double x[NB];
+  {
+    const int c = tid & 31;
+    double a[NB], x[NB];
 #pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      double sacc = (r == c) ? 1.0 : 0.0;
+    for (int q = 0; q < NB; ++q) a[q] = D[c][q];
+    wave_trtri32(a, c, x);
+    if (tid < NB) {
 #pragma unroll
-      for (int q = 0; q < r; ++q) sacc -= D[r][q] * ((q >= c) ? x[q] : 0.0);
-      x[r] = (r >= c) ? sacc / D[r][r] : 0.0;
+      for (int r = 0; r < NB; ++r) Xs[r][c] = x[r];
     }
-#pragma unroll
-    for (int r = 0; r < NB; ++r) Xs[r][c] = x[r];
   }
   __syncthreads();
   // write the block row of X: zeros left/right of the diagonal block, inverse on it

@@ -13,35 +13,6 @@
 
 namespace {
 
-// mu[r][j] = sum_k qmu[k][r] * A[k][j]; thread per column, 8 outputs per pass
-__global__ __launch_bounds__(256) void mean_kernel(const double* __restrict__ A, long lda, int Mk,
-                                                   const double* __restrict__ qmu, int R, double* __restrict__ mu,
-                                                   long ldm, int Kc) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  const int r0 = blockIdx.y * 8;
-  const int nr = min(8, R - r0);
-  __shared__ double q[64][8];
-  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int k0 = 0; k0 < Mk; k0 += 64) {
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 64 * 8; idx += 256) {
-      int kk = idx >> 3, rr = idx & 7;
-      q[kk][rr] = (k0 + kk < Mk && rr < nr) ? qmu[(long)(k0 + kk) * R + r0 + rr] : 0.0;
-    }
-    __syncthreads();
-    if (j < Kc) {
-      const int kmax = min(64, Mk - k0);
-      for (int kk = 0; kk < kmax; ++kk) {
-        double a = A[(long)(k0 + kk) * lda + j];
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) acc[rr] += q[kk][rr] * a;
-      }
-    }
-  }
-  if (j < Kc)
-    for (int rr = 0; rr < nr; ++rr) mu[(long)(r0 + rr) * ldm + j] = acc[rr];
-}
-
 // ---- counter-based RNG (Philox4x32-10) + Box-Muller, one normal per element -------------------
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
@@ -114,9 +85,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
   }
 }
 
-// ---- KL small terms: one block ------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void kl_small_kernel(const double* __restrict__ LpinvT, const double* __restrict__ Lp,
-                                                        const double* __restrict__ Lq, const double* __restrict__ qmu,
+// ---- KL small terms: one block.  ap / tp are the per-row-block column sums of squares of inv(Lp) q_mu and
+// inv(Lp) Lq_r produced by the GEMM epilogue; this kernel adds them up together with the log-determinants.
+__global__ __launch_bounds__(1024) void kl_small_kernel(const double* __restrict__ Lp, const double* __restrict__ Lq,
+                                                        const double* __restrict__ qmu, int Rp,
+                                                        const double* __restrict__ ap, long ap_count,
                                                         const double* __restrict__ tp, long tp_count, int M, int Mp,
                                                         int R, int white, double* __restrict__ kl4) {
   __shared__ double red[4][1024];
@@ -124,29 +97,25 @@ __global__ __launch_bounds__(1024) void kl_small_kernel(const double* __restrict
   double mah = 0.0, ldq = 0.0, ldp = 0.0, tr = 0.0;
   for (int idx = tid; idx < M * R; idx += 1024) {
     int i = idx % M, r = idx / M;
-    double al;
     if (white) {
-      al = qmu[(long)i * R + r];
-    } else {
-      al = 0.0;   // alpha = inv(Lp) q_mu  (row i of inv(Lp) = column i of LpinvT, entries k <= i)
-      for (int k = 0; k <= i; ++k) al += LpinvT[(long)k * Mp + i] * qmu[(long)k * R + r];
+      double al = qmu[(long)i * Rp + r];
+      mah += al * al;
     }
-    mah += al * al;
     double d = Lq[((long)r * Mp + i) * Mp + i];
     ldq += log(d * d);
   }
-  if (!white)
+  if (!white) {
+    for (long idx = tid; idx < ap_count; idx += 1024) mah += ap[idx];
     for (int i = tid; i < M; i += 1024) {
       double d = Lp[(long)i * Mp + i];
       ldp += log(d * d);
     }
-  if (white) {
+    for (long idx = tid; idx < tp_count; idx += 1024) tr += tp[idx];
+  } else {
     for (long idx = tid; idx < (long)R * Mp * Mp; idx += 1024) {
       double v = Lq[idx];
       tr += v * v;
     }
-  } else {
-    for (long idx = tid; idx < tp_count; idx += 1024) tr += tp[idx];
   }
   red[0][tid] = mah; red[1][tid] = ldq; red[2][tid] = ldp; red[3][tid] = tr;
   __syncthreads();
@@ -294,7 +263,7 @@ int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc,
   sc.A2 = white ? sc.A1 : (double*)ws_get(ctx, p + "A2", (size_t)Mp * ldb * sizeof(double));
   sc.s1p = (double*)ws_get(ctx, p + "s1p", (size_t)nrb * ldb * sizeof(double));
   sc.s2p = have_qsqrt ? (double*)ws_get(ctx, p + "s2p", (size_t)R * nrb * ldb * sizeof(double)) : nullptr;
-  sc.mu = (double*)ws_get(ctx, p + "mu", (size_t)R * ldb * sizeof(double));
+  sc.mu = (double*)ws_get(ctx, p + "mu", (size_t)g.Rp * ldb * sizeof(double));
   if (!sc.A1 || !sc.A2 || !sc.s1p || !sc.mu || (have_qsqrt && !sc.s2p)) return DCGP_ERR_ALLOC;
   {
     ScopedTimer t(ctx, "gemm_cond_s1");
@@ -325,10 +294,14 @@ int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc,
     DCGP_TRY(gemm_tn(ctx, a, nullptr));
   }
   {
+    // mu[r][j] = sum_k q_mu[k][r] A[k][j]  (conditionals.py:50): a 16-row dense product on the same kernel
     ScopedTimer t(ctx, "cond_mean");
-    dim3 grid((Kc + 255) / 256, (R + 7) / 8);
-    hipLaunchKernelGGL(mean_kernel, grid, dim3(256), 0, ctx->stream, sc.A2, ldb, Mp, g.qmu, R, sc.mu, ldb, Kc);
-    LAUNCH_CHECK(ctx);
+    GemmArgs a;
+    a.Wt = g.qmu; a.ldw = g.Rp;
+    a.B = sc.A2; a.ldb = (int)ldb;
+    a.C = sc.mu; a.ldc = (int)ldb;
+    a.Mi = g.Rp; a.Mk = Mp; a.Kc = Kc; a.tri = 0;
+    DCGP_TRY(gemm_tn(ctx, a, nullptr));
   }
   *out = sc;
   return DCGP_OK;
@@ -347,13 +320,15 @@ int finalize_layer(dcgp_ctx* ctx, const FinalizeArgs& a) {
 int kl_layer(dcgp_ctx* ctx, const GpMats& g, const double* Lp, const double* LpinvT, int white, const char* pfx,
              double* kl4) {
   const int Mp = g.Mp, R = g.R;
-  double* tp = nullptr;
-  long tp_count = 0;
+  double *tp = nullptr, *ap = nullptr;
+  long tp_count = 0, ap_count = 0;
   if (!white) {
     const int BM = gemm_row_block(Mp), nrb = (Mp + BM - 1) / BM;
     tp_count = (long)R * nrb * Mp;
+    ap_count = (long)nrb * g.Rp;
     tp = (double*)ws_get(ctx, std::string(pfx) + "kl_tp", (size_t)tp_count * sizeof(double));
-    if (!tp) return DCGP_ERR_ALLOC;
+    ap = (double*)ws_get(ctx, std::string(pfx) + "kl_ap", (size_t)ap_count * sizeof(double));
+    if (!tp || !ap) return DCGP_ERR_ALLOC;
     ScopedTimer t(ctx, "gemm_kl");
     GemmArgs a;   // || inv(Lp) Lq_r ||_F^2 for every r
     a.Wt = LpinvT; a.ldw = Mp;
@@ -361,9 +336,15 @@ int kl_layer(dcgp_ctx* ctx, const GpMats& g, const double* Lp, const double* Lpi
     a.colsq = tp; a.sBatch = (long)nrb * Mp; a.sRowBlk = Mp;
     a.Mi = Mp; a.Mk = Mp; a.Kc = Mp; a.tri = 1; a.b_lower = 1;
     DCGP_TRY(gemm_tn(ctx, a, nullptr));
+    GemmArgs b;   // || inv(Lp) q_mu ||_F^2 (padded columns of qmu are zero)
+    b.Wt = LpinvT; b.ldw = Mp;
+    b.B = g.qmu; b.ldb = g.Rp;
+    b.colsq = ap; b.sRowBlk = g.Rp;
+    b.Mi = Mp; b.Mk = Mp; b.Kc = g.Rp; b.tri = 1;
+    DCGP_TRY(gemm_tn(ctx, b, nullptr));
   }
-  hipLaunchKernelGGL(kl_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, LpinvT, Lp, g.Lq, g.qmu, tp, tp_count, g.M,
-                     Mp, R, white, kl4);
+  hipLaunchKernelGGL(kl_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, Lp, g.Lq, g.qmu, g.Rp, ap, ap_count, tp,
+                     tp_count, g.M, Mp, R, white, kl4);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }

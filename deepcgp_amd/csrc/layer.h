@@ -13,7 +13,7 @@ struct ViewGeom {
 
 // Padded M x M operands of one layer ([Mp x Mp], ld = Mp) living in device memory.
 struct GpMats {
-  int M = 0, Mp = 0, R = 0;
+  int M = 0, Mp = 0, R = 0, Rp = 0;   // Rp = R rounded up to 16 (column padding of qmu)
   double* K = nullptr;      // Kuu (live Z) -> overwritten by its Cholesky factor L
   double* Linv = nullptr;   // inv(L)
   double* LinvT = nullptr;  // inv(L)^T
@@ -21,7 +21,7 @@ struct GpMats {
   double* Lpinv = nullptr;
   double* LpinvT = nullptr;
   double* Lq = nullptr;     // [R][Mp][Mp] lower-masked q_sqrt, zero padded
-  double* qmu = nullptr;    // [Mp][R], zero padded rows
+  double* qmu = nullptr;    // [Mp][Rp], zero padded rows and columns
 };
 
 // A = inv(L) Kuf etc. on a k-major Kuf matrix B [Mp x ldb] with Kc columns.

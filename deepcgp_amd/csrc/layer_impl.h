@@ -46,7 +46,7 @@ struct LayerState {
     M = M_; R = R_; white = white_; identity_mean = idm; kernel_type = ktype; variance = var; ls = ls_;
     Mp = round_up(M, 16);
     Lp = round_up(v.L, 4);
-    g.M = M; g.Mp = Mp; g.R = R;
+    g.M = M; g.Mp = Mp; g.R = R; g.Rp = round_up(R, 16);
     size_t mm = (size_t)Mp * Mp;
     Z = dalloc((size_t)M * v.L);
     Z0 = head ? nullptr : dalloc((size_t)M * v.L);
@@ -56,7 +56,7 @@ struct LayerState {
     g.K = dalloc(mm); g.Linv = dalloc(mm); g.LinvT = dalloc(mm);
     if (!head && !white && need_prior) { g.Kp = dalloc(mm); g.Lpinv = dalloc(mm); g.LpinvT = dalloc(mm); }
     g.Lq = dalloc((size_t)R * mm);
-    g.qmu = dalloc((size_t)Mp * R);
+    g.qmu = dalloc((size_t)Mp * g.Rp);
     ZT = dalloc((size_t)Lp * Mp);
     zn = dalloc(Mp);
     for (void* p : owned)
@@ -77,7 +77,7 @@ struct LayerState {
     DCGP_TRY(z_transpose_norms(ctx, Z, M, v.L, ZT, Mp, Lp, zn));
     if (has_qsqrt)
       DCGP_TRY(pad_copy(ctx, q_sqrt, M, M, M, g.Lq, Mp, Mp, Mp, 1, R, (long)M * M, (long)Mp * Mp));
-    DCGP_TRY(pad_copy(ctx, q_mu, M, R, R, g.qmu, R, Mp, R, 0, 1, 0, 0));
+    DCGP_TRY(pad_copy(ctx, q_mu, M, R, R, g.qmu, g.Rp, Mp, g.Rp, 0, 1, 0, 0));
     return DCGP_OK;
   }
 };

@@ -56,16 +56,16 @@ int tmp_gp_build(dcgp_ctx* ctx, TmpGp& t, const std::string& pfx, int M, int R, 
   const int Mp = round_up(M, 16);
   const size_t mm = (size_t)Mp * Mp;
   GpMats& g = t.g;
-  g.M = M; g.Mp = Mp; g.R = R;
+  g.M = M; g.Mp = Mp; g.R = R; g.Rp = round_up(R, 16);
   g.K = (double*)ws_get(ctx, pfx + "K", mm * sizeof(double));
   g.Linv = (double*)ws_get(ctx, pfx + "Linv", mm * sizeof(double));
   g.LinvT = (double*)ws_get(ctx, pfx + "LinvT", mm * sizeof(double));
   g.Lq = (double*)ws_get(ctx, pfx + "Lq", (size_t)R * mm * sizeof(double));
-  g.qmu = (double*)ws_get(ctx, pfx + "qmu", (size_t)Mp * R * sizeof(double));
+  g.qmu = (double*)ws_get(ctx, pfx + "qmu", (size_t)Mp * g.Rp * sizeof(double));
   if (!g.K || !g.Linv || !g.LinvT || !g.Lq || !g.qmu) return DCGP_ERR_ALLOC;
   if (Kmm) DCGP_TRY(pad_copy(ctx, Kmm, M, M, M, g.K, Mp, Mp, Mp, 2, 1, 0, 0));
   if (q_sqrt) DCGP_TRY(pad_copy(ctx, q_sqrt, M, M, M, g.Lq, Mp, Mp, Mp, 1, R, (long)M * M, (long)Mp * Mp));
-  if (q_mu) DCGP_TRY(pad_copy(ctx, q_mu, M, R, R, g.qmu, R, Mp, R, 0, 1, 0, 0));
+  if (q_mu) DCGP_TRY(pad_copy(ctx, q_mu, M, R, R, g.qmu, g.Rp, Mp, g.Rp, 0, 1, 0, 0));
   if (Kmm) {
     t.fg.Mp = Mp;
     t.fg.K = {g.K}; t.fg.Linv = {g.Linv}; t.fg.LinvT = {g.LinvT};

@@ -18,43 +18,79 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // Kuu
 // ---------------------------------------------------------------------------------------------
-__global__ void rbf_gram_kernel(const double* __restrict__ Z, int M, int L, double variance, double inv_l2,
-                                double jitter, double* __restrict__ out, int ld, int Mp) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  int i = blockIdx.y;
-  if (j >= ld || i >= Mp) return;
-  double v = 0.0;
-  if (i < M && j < M) {
-    const double* zi = Z + (long)i * L;
-    const double* zj = Z + (long)j * L;
-    double ni = 0.0, nj = 0.0, dot = 0.0;
-    for (int l = 0; l < L; ++l) {
-      double a = zi[l], b = zj[l];
-      ni += a * a;
-      nj += b * b;
-      dot += a * b;
+// 32x32 output tile per 256-thread block; Z rows staged through LDS in chunks of 32 columns.
+__global__ __launch_bounds__(256) void rbf_gram_kernel(const double* __restrict__ Z, int M, int L, double variance,
+                                                       double inv_l2, double jitter, double* __restrict__ out, int ld,
+                                                       int Mp) {
+  __shared__ double Zi[32][33], Zj[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // ty in 0..7
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  double dot[4] = {0, 0, 0, 0}, ni[4] = {0, 0, 0, 0}, nj = 0.0;
+  for (int l0 = 0; l0 < L; l0 += 32) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
+      int r = idx >> 5, c = idx & 31;
+      Zi[r][c] = (i0 + r < M && l0 + c < L) ? Z[(long)(i0 + r) * L + l0 + c] : 0.0;
+      Zj[r][c] = (j0 + r < M && l0 + c < L) ? Z[(long)(j0 + r) * L + l0 + c] : 0.0;
     }
-    double d2 = (ni + nj - 2.0 * dot) * inv_l2;   // GPflow square_dist form, no clamp
-    v = variance * exp(-0.5 * d2);
-    if (i == j) v += jitter;
-  } else if (i == j && i < Mp) {
-    v = 1.0;   // identity on the padding so that factorisations of the padded matrix stay valid
+    __syncthreads();
+#pragma unroll 8
+    for (int l = 0; l < 32; ++l) {
+      const double b = Zj[tx][l];
+      nj = fma(b, b, nj);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double a = Zi[ty + 8 * q][l];
+        dot[q] = fma(a, b, dot[q]);
+        ni[q] = fma(a, a, ni[q]);
+      }
+    }
   }
-  out[(long)i * ld + j] = v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = i0 + ty + 8 * q, j = j0 + tx;
+    if (i >= Mp || j >= ld) continue;
+    double v = 0.0;
+    if (i < M && j < M) {
+      double d2 = (ni[q] + nj - 2.0 * dot[q]) * inv_l2;   // GPflow square_dist form, no clamp
+      v = variance * exp(-0.5 * d2);
+      if (i == j) v += jitter;
+    } else if (i == j) {
+      v = 1.0;   // identity on the padding so that factorisations of the padded matrix stay valid
+    }
+    out[(long)i * ld + j] = v;
+  }
 }
 
-// ZT[l][m] = Z[m][l] (zero padded to [Lp][Mp]) and zn[m] = |Z[m]|^2
-__global__ void z_transpose_kernel(const double* __restrict__ Z, int M, int L, double* __restrict__ ZT, int Mp,
-                                   int Lp, double* __restrict__ zn) {
-  int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= Mp) return;
-  double n2 = 0.0;
-  for (int l = 0; l < Lp; ++l) {
-    double v = (m < M && l < L) ? Z[(long)m * L + l] : 0.0;
-    ZT[(long)l * Mp + m] = v;
-    n2 += v * v;
+// ZT[l][m] = Z[m][l] (zero padded to [Lp][Mp]) and zn[m] = |Z[m]|^2; one block per 32 rows of Z
+__global__ __launch_bounds__(256) void z_transpose_kernel(const double* __restrict__ Z, int M, int L, double* __restrict__ ZT, int Mp,
+                                                          int Lp, double* __restrict__ zn) {
+  __shared__ double t[32][33];
+  __shared__ double nrm[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int m0 = blockIdx.x * 32;
+  double acc = 0.0;   // partial |z|^2 of row (m0 + tx) over the l's this thread row visits
+  for (int l0 = 0; l0 < Lp; l0 += 32) {
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      int m = m0 + r, l = l0 + tx;
+      t[r][tx] = (m < M && l < L) ? Z[(long)m * L + l] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      int l = l0 + r, m = m0 + tx;
+      double v = t[tx][r];
+      if (l < Lp && m < Mp) ZT[(long)l * Mp + m] = v;
+      acc = fma(v, v, acc);
+    }
   }
-  zn[m] = n2;
+  nrm[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && m0 + tx < Mp) {
+    double s2 = 0.0;
+    for (int q = 0; q < 8; ++q) s2 += nrm[q][tx];
+    zn[m0 + tx] = s2;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -339,14 +375,14 @@ __global__ void extract_patches_kernel(const double* __restrict__ X, int N, int 
 
 int rbf_gram_padded(dcgp_ctx* ctx, const double* Z, int M, int L, double variance, double inv_l2, double jitter,
                     double* out, int ld, int Mp) {
-  dim3 grid((ld + 127) / 128, Mp);
-  hipLaunchKernelGGL(rbf_gram_kernel, grid, dim3(128), 0, ctx->stream, Z, M, L, variance, inv_l2, jitter, out, ld, Mp);
+  dim3 grid((ld + 31) / 32, (Mp + 31) / 32);
+  hipLaunchKernelGGL(rbf_gram_kernel, grid, dim3(256), 0, ctx->stream, Z, M, L, variance, inv_l2, jitter, out, ld, Mp);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }
 
 int z_transpose_norms(dcgp_ctx* ctx, const double* Z, int M, int L, double* ZT, int Mp, int Lp, double* zn) {
-  hipLaunchKernelGGL(z_transpose_kernel, dim3((Mp + 63) / 64), dim3(64), 0, ctx->stream, Z, M, L, ZT, Mp, Lp, zn);
+  hipLaunchKernelGGL(z_transpose_kernel, dim3((Mp + 31) / 32), dim3(256), 0, ctx->stream, Z, M, L, ZT, Mp, Lp, zn);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }

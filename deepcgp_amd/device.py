@@ -10,7 +10,7 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdcgp.so")
+LIB_PATH = os.environ.get("DCGP_LIB", os.path.join(_HERE, "libdcgp.so"))   # DCGP_LIB: A/B builds only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dcgp.h")
 
 DCGP_OK, ERR_ARG, ERR_HIP, ERR_NOT_PD, ERR_RCCL, ERR_ALLOC = 0, -1, -2, -3, -4, -5
