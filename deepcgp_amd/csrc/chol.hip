@@ -2,10 +2,11 @@
 //
 //   * potrf_batched : blocked right-looking Cholesky (tf.cholesky at conv_gp/conditionals.py:29 and
 //                     conv_gp/layers.py:151,156).  Panel width 32: the 32x32 diagonal block is factored by
-//                     ONE wavefront entirely in registers (lane r owns row r; pivots and multipliers move
-//                     with wave shuffles, no barriers), the rows below are solved against it one row per
-//                     lane (wavefront-level trsm panel), and the trailing matrix gets a rank-32 update on
-//                     the matrix cores (v_mfma_f64_16x16x4_f64), lower tiles only.
+//                     ONE wavefront (lane r owns row r in registers; the scaled pivot column goes through a
+//                     32-entry LDS line that every lane reads back as a broadcast -- no barriers, no divisions:
+//                     v_rsq_f64 + Newton), the rows below are solved against it one row per lane
+//                     (wavefront-level trsm panel), and the trailing matrix gets a rank-32 update on the
+//                     matrix cores (v_mfma_f64_16x16x4_f64, operands staged through LDS), lower tiles only.
 //   * trtri_batched : inverse of the lower factor by recursive doubling
 //                     inv([A 0; C B]) = [inv(A) 0; -inv(B) C inv(A)  inv(B)]   (log2(M/32) levels, every
 //                     level a batch of independent MFMA products) -- the triangular solves of
@@ -19,37 +20,49 @@ namespace {
 constexpr int NB = 32;
 
 // ---------------------------------------------------------------------------------------------
-// generic 64x64 MFMA tile with arbitrary operand strides (operands read straight from L2)
+// 64x64 output tile, operands staged through LDS in k chunks of 32 (coalesced global reads, conflict-free
+// ds_read_b64 operand fetches).  A(i,k) = A[i*sAi + k*sAk], B(k,j) = B[k*sBk + j*sBj].
 //   acc[x][y][v] -> row (wm*32 + x*16 + lrow + 4v), col (wn*32 + y*16 + lcol) of the tile
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void tile64_mfma(const double* __restrict__ A, long sAi, long sAk, int m_valid,
+struct TileLds {
+  double As[64][NB + 1];   // [i][k]
+  double Bs[NB][64 + 1];   // [k][j]
+};
+
+__device__ __forceinline__ void tile64_mfma(TileLds& t, const double* __restrict__ A, long sAi, long sAk, int m_valid,
                                             const double* __restrict__ B, long sBk, long sBj, int n_valid, int kdim,
-                                            int wm, int wn, int lrow, int lcol, d4 (&acc)[2][2]) {
-  for (int kk = 0; kk < kdim; kk += 4) {
-    double av[2], bv[2];
-    const int k = kk + lrow;
+                                            int tid, d4 (&acc)[2][2]) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lrow = lane >> 4, lcol = lane & 15;
+  const bool a_kfast = sAk == 1, b_jfast = sBj == 1;
+  for (int k0 = 0; k0 < kdim; k0 += NB) {
+    __syncthreads();
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      int i = wm * 32 + x * 16 + lcol;
-      av[x] = (i < m_valid && k < kdim) ? A[i * sAi + k * sAk] : 0.0;
+    for (int e = 0; e < 8; ++e) {
+      const int idx = tid + e * 256;   // 2048 elements each
+      const int ai = a_kfast ? idx >> 5 : idx & 63, ak = a_kfast ? idx & 31 : idx >> 6;
+      t.As[ai][ak] = (ai < m_valid && k0 + ak < kdim) ? A[ai * sAi + (k0 + ak) * sAk] : 0.0;
+      const int bj = b_jfast ? idx & 63 : idx >> 5, bk = b_jfast ? idx >> 6 : idx & 31;
+      t.Bs[bk][bj] = (bj < n_valid && k0 + bk < kdim) ? B[(k0 + bk) * sBk + bj * sBj] : 0.0;
     }
+    __syncthreads();
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      int j = wn * 32 + y * 16 + lcol;
-      bv[y] = (j < n_valid && k < kdim) ? B[k * sBk + j * sBj] : 0.0;
+    for (int kk = 0; kk < NB; kk += 4) {
+      double av[2], bv[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) av[x] = t.As[wm * 32 + x * 16 + lcol][kk + lrow];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) bv[y] = t.Bs[kk + lrow][wn * 32 + y * 16 + lcol];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
     }
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
   }
 }
 
-
 // ---------------------------------------------------------------------------------------------
-// wavefront-level 32x32 routines: lane r (< 32; lanes 32..63 mirror) holds row r of the block in registers.
-// Wave-uniform values (pivots, multipliers) are broadcast with v_readlane (no LDS crossbar); reciprocal
-// square roots come from v_rsq_f64 + two Newton steps instead of the long sqrt / divide sequences.
+// wavefront-level 32x32 routines (lanes 32..63 mirror lanes 0..31)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double bcast_lane(double v, int lane) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -62,8 +75,11 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
   y = y * fma(-0.5 * p * y, y, 1.5);
   return y;
 }
-// in-place Cholesky of the rows held in a[]; returns 0 or the 1-based column of the first bad pivot
-__device__ __forceinline__ int wave_potrf32(double (&a)[NB], int r) {
+// In-place Cholesky of the block whose row r sits in a[] of lane r.  Step c: the pivot comes over with one
+// v_readlane pair, every lane scales its column-c entry, writes it to the LDS line `col` and reads the 31-c
+// multipliers L[cc][c] back as uniform-address (broadcast) loads.  Entries above the diagonal pick up garbage
+// that is never read.  Returns 0 or the 1-based column of the first non-positive pivot.
+__device__ __forceinline__ int wave_potrf32(double (&a)[NB], int r, double (&col)[NB]) {
   int fail = 0;
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
@@ -71,37 +87,41 @@ __device__ __forceinline__ int wave_potrf32(double (&a)[NB], int r) {
     if (!(piv > 0.0) && fail == 0) fail = c + 1;
     const double y = rsqrt_nr(piv);
     double d = piv * y;
-    d = fma(0.5 * y, fma(-d, d, piv), d);       // one correction step: d = sqrt(piv) to ~1 ulp
-    if (r == c) a[c] = d;
-    else if (r > c) a[c] = a[c] * y;
+    d = fma(0.5 * y, fma(-d, d, piv), d);       // sqrt(piv) to ~1 ulp
+    a[c] = (r == c) ? d : a[c] * y;
+    col[r] = a[c];
+    double m[NB];
 #pragma unroll
-    for (int cc = c + 1; cc < NB; ++cc) {
-      const double v = bcast_lane(a[c], cc);      // L[cc][c]
-      if (r >= cc) a[cc] = fma(-a[c], v, a[cc]);
-    }
+    for (int cc = c + 1; cc < NB; ++cc) m[cc] = col[cc];
+#pragma unroll
+    for (int cc = c + 1; cc < NB; ++cc) a[cc] = fma(-a[c], m[cc], a[cc]);
   }
   return fail;
 }
-// inverse of the lower-triangular rows in a[]: lane c returns column c of the inverse in x[]
-__device__ __forceinline__ void wave_trtri32(const double (&a)[NB], int c, double (&x)[NB]) {
+// Column c of inv(L) for a 32x32 lower-triangular L held in LDS (D) with its reciprocal diagonal (Dr):
+// forward substitution, the row of L being read as broadcast loads once per step.
+__device__ __forceinline__ void lane_trtri32(const double (*D)[NB + 1], const double* Dr, int c, double (&x)[NB]) {
 #pragma unroll
   for (int r = 0; r < NB; ++r) {
-    const double dinv = 1.0 / bcast_lane(a[r], r);
+    double row[NB];
+#pragma unroll
+    for (int q = 0; q < r; ++q) row[q] = D[r][q];
     double s = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-    for (int q = 0; q < r; ++q) s = fma(-bcast_lane(a[q], r), x[q], s);   // x[q] == 0 for q < c
-    x[r] = s * dinv;
+    for (int q = 0; q < r; ++q) s = fma(-row[q], x[q], s);   // x[q] == 0 for q < c
+    x[r] = s * Dr[r];
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// potrf panel: factor diag block (wave 0, registers) + row-per-lane trsm of the rows below
+// potrf panel: factor diag block (wave 0) + row-per-lane trsm of the rows below
 // grid (max(1, ceil(rows_below / 256)), batch), block 256
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void potrf_panel_kernel(double* const* __restrict__ ptrs, int Mp, int ld, int j,
                                                            int* __restrict__ info) {
   __shared__ double D[NB][NB + 1];
-  __shared__ double Dr[NB];   // reciprocal diagonal of the factored block
+  __shared__ double Dr[NB];    // reciprocal diagonal of the factored block
+  __shared__ double col[NB];   // pivot-column broadcast line
   double* __restrict__ A = ptrs[blockIdx.y];
   const int tid = threadIdx.x;
   const int nb = min(NB, Mp - j);
@@ -113,11 +133,11 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* const* __restr
   }
   __syncthreads();
   if (tid < 64) {
-    const int r = tid & 31;   // lanes 32..63 mirror lanes 0..31
+    const int r = tid & 31;
     double a[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) a[c] = D[r][c];
-    const int fail = wave_potrf32(a, r);
+    const int fail = wave_potrf32(a, r, col);
     if (tid < 32) {
 #pragma unroll
       for (int c = 0; c < NB; ++c) D[r][c] = (c <= r) ? a[c] : 0.0;
@@ -141,7 +161,7 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* const* __restr
       A[(long)(j + r) * ld + j + nb + c] = 0.0;
     }
   }
-  // rows below: x * L11^T = a  (forward substitution, one row per thread)
+  // rows below: x * L11^T = a  (right-looking forward substitution, one row per thread)
   const int row = j + NB + blockIdx.x * 256 + tid;
   if (row < Mp) {
     double x[NB];
@@ -164,8 +184,9 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* const* __restr
 }
 
 // trailing update A22 -= L21 L21^T, lower 64x64 tiles only. grid (tile pairs, batch)
-__global__ __launch_bounds__(256) void potrf_update_kernel(double* const* __restrict__ ptrs, int Mp, int ld, int j,
-                                                            int nt) {
+__global__ __launch_bounds__(256, 4) void potrf_update_kernel(double* const* __restrict__ ptrs, int Mp, int ld, int j,
+                                                               int nt) {
+  __shared__ TileLds t;
   double* __restrict__ A = ptrs[blockIdx.y];
   int pair = blockIdx.x, tc = 0;
   while (pair >= nt - tc) {   // column-major enumeration of the lower triangle: tc <= tr
@@ -182,7 +203,7 @@ __global__ __launch_bounds__(256) void potrf_update_kernel(double* const* __rest
   for (int x = 0; x < 2; ++x)
 #pragma unroll
     for (int y = 0; y < 2; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
-  tile64_mfma(A + (long)r0 * ld + j, ld, 1, Mp - r0, A + (long)c0 * ld + j, 1, ld, Mp - c0, NB, wm, wn, lrow, lcol, acc);
+  tile64_mfma(t, A + (long)r0 * ld + j, ld, 1, Mp - r0, A + (long)c0 * ld + j, 1, ld, Mp - c0, NB, tid, acc);
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -197,11 +218,12 @@ __global__ __launch_bounds__(256) void potrf_update_kernel(double* const* __rest
 // ---------------------------------------------------------------------------------------------
 // trtri
 // ---------------------------------------------------------------------------------------------
-// level 0: invert every 32x32 diagonal block (thread c solves column c); off-diagonal of Linv zeroed.
+// level 0: invert every 32x32 diagonal block (lane c solves column c); the rest of the block row of X is zeroed.
 __global__ __launch_bounds__(64) void trtri_diag_kernel(double* const* __restrict__ Lp, double* const* __restrict__ Xp,
                                                          int Mp, int ld) {
   __shared__ double D[NB][NB + 1];
   __shared__ double Xs[NB][NB + 1];
+  __shared__ double Dr[NB];
   const double* __restrict__ L = Lp[blockIdx.y];
   double* __restrict__ X = Xp[blockIdx.y];
   const int s = blockIdx.x * NB, nb = min(NB, Mp - s), tid = threadIdx.x;
@@ -210,19 +232,15 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(double* const* __restric
     double v = (r == c) ? 1.0 : 0.0;
     if (r < nb && c < nb && c <= r) v = L[(long)(s + r) * ld + s + c];
     D[r][c] = v;
-    Xs[r][c] = 0.0;
   }
   __syncthreads();
-  {
-    const int c = tid & 31;
-    double a[NB], x[NB];
+  if (tid < NB) Dr[tid] = 1.0 / D[tid][tid];
+  __syncthreads();
+  if (tid < NB) {
+    double x[NB];
+    lane_trtri32(D, Dr, tid, x);
 #pragma unroll
-    for (int q = 0; q < NB; ++q) a[q] = D[c][q];
-    wave_trtri32(a, c, x);
-    if (tid < NB) {
-#pragma unroll
-      for (int r = 0; r < NB; ++r) Xs[r][c] = x[r];
-    }
+    for (int r = 0; r < NB; ++r) Xs[r][tid] = x[r];
   }
   __syncthreads();
   // write the block row of X: zeros left/right of the diagonal block, inverse on it
@@ -235,9 +253,10 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(double* const* __restric
 }
 
 // one merge level: mode 0: T = C * inv(A);  mode 1: X21 = -inv(B) * T.   grid (tiles, pairs, batch)
-__global__ __launch_bounds__(256) void trtri_merge_kernel(double* const* __restrict__ Lp, double* const* __restrict__ Xp,
-                                                           double* __restrict__ Tbase, long Tstride, int Mp, int ld,
-                                                           int h, int mode) {
+__global__ __launch_bounds__(256, 4) void trtri_merge_kernel(double* const* __restrict__ Lp, double* const* __restrict__ Xp,
+                                                              double* __restrict__ Tbase, long Tstride, int Mp, int ld,
+                                                              int h, int mode) {
+  __shared__ TileLds t;
   const double* __restrict__ L = Lp[blockIdx.z];
   double* __restrict__ X = Xp[blockIdx.z];
   double* __restrict__ T = Tbase + (long)blockIdx.z * Tstride;
@@ -259,14 +278,14 @@ __global__ __launch_bounds__(256) void trtri_merge_kernel(double* const* __restr
   double alpha;
   if (mode == 0) {
     // T[hb x h] = C[hb x h] * Ainv[h x h]
-    tile64_mfma(L + o21 + (long)ti * 64 * ld, ld, 1, hb - ti * 64, X + (long)s * ld + s + tj * 64, ld, 1, h - tj * 64, h,
-                wm, wn, lrow, lcol, acc);
+    tile64_mfma(t, L + o21 + (long)ti * 64 * ld, ld, 1, hb - ti * 64, X + (long)s * ld + s + tj * 64, ld, 1, h - tj * 64, h,
+                tid, acc);
     out = T + o21;
     alpha = 1.0;
   } else {
     // X21[hb x h] = -Binv[hb x hb] * T[hb x h]
-    tile64_mfma(X + (long)(s + h) * ld + (s + h) + (long)ti * 64 * ld, ld, 1, hb - ti * 64, T + o21 + tj * 64, ld, 1,
-                h - tj * 64, (hb + 3) & ~3, wm, wn, lrow, lcol, acc);
+    tile64_mfma(t, X + (long)(s + h) * ld + (s + h) + (long)ti * 64 * ld, ld, 1, hb - ti * 64, T + o21 + tj * 64, ld, 1,
+                h - tj * 64, hb, tid, acc);
     out = X + o21;
     alpha = -1.0;
   }

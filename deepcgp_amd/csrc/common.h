@@ -25,7 +25,9 @@ struct PendingEvent {
 
 struct dcgp_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;    // the stream launches go to (temporarily swapped to stream2 for the side branch)
+  hipStream_t stream2 = nullptr;   // side stream: factorisation chain + KL terms
+  hipEvent_t ev_fork = nullptr, ev_factor = nullptr, ev_kl = nullptr;
   std::string err;
   // named, grow-only device workspaces owned by the ctx
   std::map<std::string, std::pair<void*, size_t>> ws;
@@ -94,7 +96,7 @@ struct GemmArgs {
   int b_lower = 0;             // B[k][j] == 0 for k < j (skip those k tiles)
 };
 int gemm_tn(dcgp_ctx* ctx, const GemmArgs& a, int* n_row_blocks_out);
-int gemm_row_block(int Mi);   // BM the dispatcher will pick for this Mi
+int gemm_row_block(int Mi, int Kc, int batch);   // BM the dispatcher picks (callers size partial-sum buffers with it)
 
 // patch-RBF sweep (kuf / head Kzx)
 struct PatchRbfArgs {

@@ -254,15 +254,16 @@ int varexp_rows(dcgp_ctx* ctx, const double* mu, const double* var, const int32_
 int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, int white, bool have_qsqrt,
               const char* pfx, CondScratch* out) {
   const int Mp = g.Mp, R = g.R;
-  const int BM = gemm_row_block(Mp), nrb = (Mp + BM - 1) / BM;
+  const int BM1 = gemm_row_block(Mp, Kc, 1), BM3 = gemm_row_block(Mp, Kc, R);
+  const int nrb = (Mp + BM1 - 1) / BM1, nrb3 = (Mp + BM3 - 1) / BM3;
   std::string p(pfx);
   CondScratch sc;
   sc.ldb = ldb;
-  sc.nrb1 = sc.nrb3 = nrb;
+  sc.nrb1 = nrb; sc.nrb3 = nrb3;
   sc.A1 = (double*)ws_get(ctx, p + "A1", (size_t)Mp * ldb * sizeof(double));
   sc.A2 = white ? sc.A1 : (double*)ws_get(ctx, p + "A2", (size_t)Mp * ldb * sizeof(double));
   sc.s1p = (double*)ws_get(ctx, p + "s1p", (size_t)nrb * ldb * sizeof(double));
-  sc.s2p = have_qsqrt ? (double*)ws_get(ctx, p + "s2p", (size_t)R * nrb * ldb * sizeof(double)) : nullptr;
+  sc.s2p = have_qsqrt ? (double*)ws_get(ctx, p + "s2p", (size_t)R * nrb3 * ldb * sizeof(double)) : nullptr;
   sc.mu = (double*)ws_get(ctx, p + "mu", (size_t)g.Rp * ldb * sizeof(double));
   if (!sc.A1 || !sc.A2 || !sc.s1p || !sc.mu || (have_qsqrt && !sc.s2p)) return DCGP_ERR_ALLOC;
   {
@@ -289,7 +290,7 @@ int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc,
     GemmArgs a;
     a.Wt = g.Lq; a.ldw = Mp; a.wBatch = (long)Mp * Mp; a.nW = R;
     a.B = sc.A2; a.ldb = (int)ldb;
-    a.colsq = sc.s2p; a.sBatch = (long)nrb * ldb; a.sRowBlk = ldb;
+    a.colsq = sc.s2p; a.sBatch = (long)nrb3 * ldb; a.sRowBlk = ldb;
     a.Mi = Mp; a.Mk = Mp; a.Kc = Kc; a.tri = 2;
     DCGP_TRY(gemm_tn(ctx, a, nullptr));
   }
@@ -323,9 +324,10 @@ int kl_layer(dcgp_ctx* ctx, const GpMats& g, const double* Lp, const double* Lpi
   double *tp = nullptr, *ap = nullptr;
   long tp_count = 0, ap_count = 0;
   if (!white) {
-    const int BM = gemm_row_block(Mp), nrb = (Mp + BM - 1) / BM;
+    const int BM = gemm_row_block(Mp, Mp, R), nrb = (Mp + BM - 1) / BM;
+    const int BMa = gemm_row_block(Mp, g.Rp, 1), nrba = (Mp + BMa - 1) / BMa;
     tp_count = (long)R * nrb * Mp;
-    ap_count = (long)nrb * g.Rp;
+    ap_count = (long)nrba * g.Rp;
     tp = (double*)ws_get(ctx, std::string(pfx) + "kl_tp", (size_t)tp_count * sizeof(double));
     ap = (double*)ws_get(ctx, std::string(pfx) + "kl_ap", (size_t)ap_count * sizeof(double));
     if (!tp || !ap) return DCGP_ERR_ALLOC;

@@ -19,8 +19,8 @@ void* ws_get(dcgp_ctx* ctx, const std::string& name, size_t bytes) {
   auto it = ctx->ws.find(name);
   if (it != ctx->ws.end() && it->second.second >= bytes) return it->second.first;
   if (it != ctx->ws.end()) {
-    // in-flight kernels may still use the old buffer
-    hipStreamSynchronize(ctx->stream);
+    // in-flight kernels (either stream) may still use the old buffer
+    hipDeviceSynchronize();
     hipFree(it->second.first);
     ctx->ws.erase(it);
   }
@@ -58,6 +58,7 @@ ScopedTimer::~ScopedTimer() {
 void timing_flush(dcgp_ctx* ctx) {
   if (ctx->pending.empty()) return;
   hipStreamSynchronize(ctx->stream);
+  hipStreamSynchronize(ctx->stream2);
   for (auto& pe : ctx->pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
@@ -89,7 +90,11 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return DCGP_ERR_HIP;
   dcgp_ctx* c = new dcgp_ctx();
   c->device = device;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_factor, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_kl, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return DCGP_ERR_HIP;
   }
@@ -106,7 +111,7 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
 int dcgp_ctx_destroy(dcgp_ctx* ctx) {
   if (!ctx) return DCGP_ERR_ARG;
   hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
+  hipDeviceSynchronize();
   dcgp_comm_destroy(ctx);
   for (auto& kv : ctx->ws) hipFree(kv.second.first);
   for (auto& pe : ctx->pending) {
@@ -116,6 +121,10 @@ int dcgp_ctx_destroy(dcgp_ctx* ctx) {
   for (auto e : ctx->event_pool) hipEventDestroy(e);
   hipHostFree(ctx->h_scratch);
   hipHostFree(ctx->h_info);
+  hipEventDestroy(ctx->ev_fork);
+  hipEventDestroy(ctx->ev_factor);
+  hipEventDestroy(ctx->ev_kl);
+  hipStreamDestroy(ctx->stream2);
   hipStreamDestroy(ctx->stream);
   delete ctx;
   return DCGP_OK;

@@ -14,6 +14,8 @@
 // FM x FN 16x16 accumulator fragments (4 f64 per lane each).  Register-staged double buffering:
 // the global loads of k-tile t+1 are issued before the MFMAs of k-tile t and written to the other
 // LDS buffer afterwards -- one barrier per k-tile.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -22,8 +24,11 @@ constexpr int BK = 16;
 
 __host__ __device__ constexpr int lds_ld(int b) { return (b % 32 == 0) ? b + 16 : b + 32; }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(GemmArgs a, int n_col_tiles,
+template <int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0>
+// second launch-bound argument = waves per SIMD the register budget must allow: it caps the kernel at 128 (64 for the
+// 16-wave tile) unified registers, which also keeps the MFMA accumulators in VGPRs -- the AGPR form of
+// v_mfma_f64_16x16x4_f64 measured ~1.6x slower on gfx950 (tools/mfma_peak.hip vs tools/fp64_mix.hip).
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 8 : 4) void gemm_tn_kernel(GemmArgs a, int n_col_tiles,
                                                                          int n_row_blocks) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int WMR = BM / WAVES_M, WNC = BN / WAVES_N;   // wave tile
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(GemmArgs
   int buf = 0;
   for (int k0 = klo; k0 < khi; k0 += BK) {
     const bool has_next = k0 + BK < khi;
-    if (has_next) load_tile(k0 + BK);
+    if (has_next && !(ABL & 1)) load_tile(k0 + BK);
     // per-wave structural-zero skip inside the diagonal region
     bool need = true;
     if (a.tri == 1 && k0 > wave_i_hi) need = false;
@@ -135,9 +140,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(GemmArgs
       for (int kk = 0; kk < BK; kk += 4) {
         double av[FM], bv[FN];
 #pragma unroll
-        for (int x = 0; x < FM; ++x) av[x] = w[(kk + lrow) * LDW + x * 16];
+        for (int x = 0; x < FM; ++x) av[x] = (ABL & 8) ? (double)(kk + x) : w[(kk + lrow) * LDW + x * 16];
 #pragma unroll
-        for (int y = 0; y < FN; ++y) bv[y] = b[(kk + lrow) * LDB + y * 16];
+        for (int y = 0; y < FN; ++y) bv[y] = (ABL & 8) ? (double)(lane + y) : b[(kk + lrow) * LDB + y * 16];
 #pragma unroll
         for (int x = 0; x < FM; ++x)
 #pragma unroll
@@ -145,8 +150,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(GemmArgs
             acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
       }
     }
-    if (has_next) store_tile(buf ^ 1);
-    __syncthreads();
+    if (has_next && !(ABL & 2)) store_tile(buf ^ 1);
+    if (!(ABL & 4)) __syncthreads();
     buf ^= 1;
   }
 
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(GemmArgs
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0>
 int launch(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
   const int nct = (a.Kc + BN - 1) / BN, nrb = (a.Mi + BM - 1) / BM;
   if (nrb_out) *nrb_out = nrb;
@@ -202,7 +207,7 @@ int launch(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
   size_t lds = (size_t)(2 * BK * lds_ld(BM) + 2 * BK * lds_ld(BN)) * sizeof(double);
   size_t red = (size_t)WAVES_M * BN * sizeof(double);
   if (red > lds) lds = red;
-  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WAVES_M, WAVES_N>), dim3((unsigned)nwg), dim3(NT), lds, ctx->stream,
+  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WAVES_M, WAVES_N, ABL>), dim3((unsigned)nwg), dim3(NT), lds, ctx->stream,
                      a, nct, nrb);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
@@ -210,7 +215,24 @@ int launch(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
 
 }  // namespace
 
-int gemm_row_block(int Mi) { return Mi >= 128 ? 128 : (Mi >= 64 ? 64 : (Mi >= 32 ? 32 : 16)); }
+static int gemm_variant() {
+  static int v = -1;   // DCGP_GEMM_ABLATE: tuning / timing experiments (ablations 1..15 give wrong results)
+  if (v < 0) { const char* e = getenv("DCGP_GEMM_ABLATE"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
+// Row-block height for an Mi x Kc product with `batch` independent instances.  Large problems use 128-row tiles
+// (best reuse); problems that would not even put one workgroup on every CU use shorter tiles -- their run time is
+// the serial k-chain of ONE workgroup (Mk/16 steps of BM*128*16*2 flops on one CU), so shorter tiles shorten it.
+int gemm_row_block(int Mi, int Kc, int batch) {
+  if (Mi < 128) return Mi >= 64 ? 64 : (Mi >= 32 ? 32 : 16);
+  const int v = gemm_variant();
+  if (v == 128 || v == 64 || v == 32) return v;
+  const long nct = (Kc + 127) / 128;
+  for (int bm = 128; bm > 32; bm >>= 1)
+    if (nct * ((Mi + bm - 1) / bm) * batch >= 512) return bm;
+  return 32;
+}
 
 int gemm_tn(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
   if (!a.Wt || !a.B || a.Mi <= 0 || a.Mk <= 0 || a.Kc <= 0) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_tn: bad args");
@@ -218,10 +240,19 @@ int gemm_tn(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
   // one column of (ignored) padding behind it
   if ((a.ldw & 1) || (a.ldb & 1) || (a.Mi & 1) || ((a.Kc & 1) && a.ldb <= a.Kc))
     return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_tn: leading dimensions / extents must be even");
-  switch (gemm_row_block(a.Mi)) {
-    case 128: return launch<128, 128, 4, 2>(ctx, a, nrb_out);
-    case 64: return launch<64, 128, 2, 2>(ctx, a, nrb_out);
-    case 32: return launch<32, 128, 1, 2>(ctx, a, nrb_out);
-    default: return launch<16, 128, 1, 2>(ctx, a, nrb_out);
+  switch (gemm_row_block(a.Mi, a.Kc, a.nW * a.nB)) {
+    case 128:
+      switch (gemm_variant()) {
+        case 1: return launch<128, 128, 4, 2, 1>(ctx, a, nrb_out);
+        case 7: return launch<128, 128, 4, 2, 7>(ctx, a, nrb_out);
+        case 15: return launch<128, 128, 4, 2, 15>(ctx, a, nrb_out);
+        case 100: return launch<128, 128, 4, 2>(ctx, a, nrb_out);
+        default: return launch<128, 128, 4, 4>(ctx, a, nrb_out);   // 16 waves: +6% over 8 waves (more MFMA-phase waves per SIMD)
+      }
+    // short tiles = small problems whose run time is one workgroup's serial k-chain: spread each tile over 16
+    // (8) waves with one or two accumulator fragments each so that the chain is a handful of MFMAs per k-step
+    case 64: return launch<64, 128, 4, 4>(ctx, a, nrb_out);
+    case 32: return launch<32, 128, 2, 8>(ctx, a, nrb_out);
+    default: return launch<16, 128, 1, 8>(ctx, a, nrb_out);
   }
 }

@@ -119,7 +119,7 @@ struct FactorGroup {
 // ConvLayer.conditional_ND (+ sampling) on `rows` input images taken as X[(n % n_mod)]
 static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, int rows, int n_mod, int rep, long rep_stride,
                  const double* z, uint64_t seed, uint32_t stream_id, double jitter, double* out_sample, double* out_mean,
-                 double* out_var, const std::string& pfx) {
+                 double* out_var, const std::string& pfx, hipEvent_t factor_done = nullptr) {
   const int Mp = L.Mp, P = L.v.P;
   const long Kc = (long)rows * P;
   if (Kc > 0x7fffff00L) return ctx_fail(ctx, DCGP_ERR_ARG, "conv layer: %ld patch columns exceed the 32-bit tile index", Kc);
@@ -134,6 +134,7 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   a.variance = L.variance; a.inv_l2 = 1.0 / (L.ls * L.ls);
   a.out = B; a.sM = ldb; a.sN = P; a.sP = 1;
   DCGP_TRY(patch_rbf(ctx, a, "kuf"));
+  if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));   // inv(L) comes from the side stream
   CondScratch sc;
   DCGP_TRY(cond_core(ctx, L.g, B, ldb, (int)Kc, L.white, L.has_qsqrt, pfx.c_str(), &sc));
   FinalizeArgs fa;
@@ -150,7 +151,7 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
 
 // SVGP head: Kzx / Kdiag from the conv kernel, then the shared conditional
 static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, int rows, int n_mod, double* kd, double* out_mean,
-                 double* out_var, const std::string& pfx) {
+                 double* out_var, const std::string& pfx, hipEvent_t factor_done = nullptr) {
   const int Mp = L.Mp;
   const long ldb = round_up_l(rows, 128);
   double* B = (double*)ws_get(ctx, pfx + "Kzx", (size_t)Mp * ldb * sizeof(double));
@@ -170,6 +171,7 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   } else {
     DCGP_TRY(additive_kdiag_async(ctx, rows, L.v.P, L.variance, L.w, kd));
   }
+  if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
   CondScratch sc;
   DCGP_TRY(cond_core(ctx, L.g, B, ldb, rows, L.white, L.has_qsqrt, pfx.c_str(), &sc));
   FinalizeArgs fa;

@@ -133,16 +133,33 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     return ctx_fail(ctx, DCGP_ERR_ALLOC, "model: allocation failed");
   m->outs.resize(nl);
   for (auto& l : m->layers) DCGP_TRY(l->prepare(m->jitter));
-  for (auto& gr : m->groups) DCGP_TRY(gr.run(ctx));
   const std::string mp = "m" + std::to_string(m->id) + "_";
-  if (need_kl) {
-    for (int li = 0; li < nl; ++li) {
+  // The replicated M x M stage (batched Cholesky + inverse, then the KL terms) is a serial, few-CU chain: it
+  // runs on the side stream, overlapped with the first layer's K_uf sweep (which only needs Z) and, for the KL
+  // part, with the conditional GEMMs.  ev_factor gates the first GEMM, ev_kl gates the ELBO assembly.
+  hipStream_t main_s = ctx->stream;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_s));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+  ctx->stream = ctx->stream2;
+  int rc = DCGP_OK;
+  for (auto& gr : m->groups)
+    if ((rc = gr.run(ctx)) != DCGP_OK) break;
+  if (rc == DCGP_OK && hipEventRecord(ctx->ev_factor, ctx->stream2) != hipSuccess) rc = DCGP_ERR_HIP;
+  if (rc == DCGP_OK && need_kl) {
+    for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
       LayerState& L = *m->layers[li];
       const double* Lp = L.g.Kp ? L.g.Kp : L.g.K;
       const double* LpinvT = L.g.Kp ? L.g.LpinvT : L.g.LinvT;
-      DCGP_TRY(kl_layer(ctx, L.g, Lp, LpinvT, L.white, (mp + std::to_string(li)).c_str(), m->d_scal + 4 + 4 * li));
+      rc = kl_layer(ctx, L.g, Lp, LpinvT, L.white, (mp + std::to_string(li)).c_str(), m->d_scal + 4 + 4 * li);
     }
   }
+  if (rc == DCGP_OK && hipEventRecord(ctx->ev_kl, ctx->stream2) != hipSuccess) rc = DCGP_ERR_HIP;
+  ctx->stream = main_s;
+  if (rc != DCGP_OK) {
+    hipStreamSynchronize(ctx->stream2);
+    return rc;
+  }
+  bool factor_waited = false;
   // propagate
   const double* F = X;
   int rows = dedup ? N : S * N;   // rows entering the current layer
@@ -158,7 +175,9 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       DCGP_TRY(ensure_out(m, li, out_rows, width, true));
       auto& o = m->outs[li];
       DCGP_TRY(conv_forward(ctx, L, F, rows, n_mod, expand ? S : 1, (long)N * width, z, seed, (uint32_t)(li + 1 + 64 * ctx->rank),
-                            m->jitter, o.sample, m->keep_outputs ? o.mean : nullptr, m->keep_outputs ? o.var : nullptr, pfx));
+                            m->jitter, o.sample, m->keep_outputs ? o.mean : nullptr, m->keep_outputs ? o.var : nullptr, pfx,
+                            factor_waited ? nullptr : ctx->ev_factor));
+      factor_waited = true;
       F = o.sample;
       rows = out_rows;
       n_mod = rows;
@@ -166,7 +185,8 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       DCGP_TRY(ensure_out(m, li, rows, L.R, true));
       auto& o = m->outs[li];
       DCGP_TRY(ensure(ctx, &m->d_kd, &m->kd_cap, (size_t)rows));
-      DCGP_TRY(head_forward(ctx, L, F, rows, n_mod, m->d_kd, o.mean, o.var, pfx));
+      DCGP_TRY(head_forward(ctx, L, F, rows, n_mod, m->d_kd, o.mean, o.var, pfx, factor_waited ? nullptr : ctx->ev_factor));
+      factor_waited = true;
       if (m->keep_outputs) {
         // the head's sample is not needed by the ELBO; produce it only on request
         size_t n = (size_t)rows * L.R;
@@ -178,6 +198,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       }
     }
   }
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_kl, 0));   // join the side stream
   *rows_last = rows;
   return DCGP_OK;
 }

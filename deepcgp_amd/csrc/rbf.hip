@@ -108,7 +108,7 @@ __device__ __forceinline__ int patch_base(int p, int P, int Wo, int s, int W, in
 }
 
 // grid: (p tiles [write mode] or 1 [reduce mode], Mp/64, N); block 256 = 4 waves as 2 (m) x 2 (p)
-__global__ __launch_bounds__(256) void patch_rbf_kernel(PatchRbfArgs a) {
+__global__ __launch_bounds__(256, 4) void patch_rbf_kernel(PatchRbfArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int HWC = a.H * a.W * a.C;
   double* img = smem;                                   // [HWC] (+pad to even)
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void patch_rbf_kernel(PatchRbfArgs a) {
 // ConvKernel.Kdiag: per image sum_{p,p'} w_p w_p' k(x_p, x_p') / P^2, upper triangle of 64x64 patch
 // tile pairs (symmetry: off-diagonal pairs count twice).  grid (pairs, N); partial[n][pair].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_kdiag_kernel(const double* __restrict__ X, int n_mod, int H, int W, int C, int f,
+__global__ __launch_bounds__(256, 4) void head_kdiag_kernel(const double* __restrict__ X, int n_mod, int H, int W, int C, int f,
                                                           int s, int Ho, int Wo, int P, int L, double variance,
                                                           double inv_l2, const double* __restrict__ w,
                                                           double* __restrict__ partial, int n_pairs, int p_tiles) {

@@ -4,7 +4,8 @@
 #include <cstdio>
 typedef double d4 __attribute__((ext_vector_type(4)));
 template <int NACC>
-__global__ __launch_bounds__(256) void mfma_loop(double* out, int iters) {
+__global__ __launch_bounds__(256) void mfma_loop(double* out, int iters, unsigned long long* clk = nullptr) {
+  unsigned long long c0 = clock64(), w0 = wall_clock64();
   d4 acc[NACC];
   for (int i = 0; i < NACC; ++i) acc[i] = d4{0, 0, 0, 0};
   double a = threadIdx.x * 1e-3, b = threadIdx.x * 2e-3 + 1.0;
@@ -15,6 +16,7 @@ __global__ __launch_bounds__(256) void mfma_loop(double* out, int iters) {
   double s = 0;
   for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }
 __global__ void copy4(const double4* __restrict__ in, double4* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -32,10 +34,15 @@ void run(int blocks, int iters, double* d) {
   hipEventCreate(&e0); hipEventCreate(&e1);
   mfma_loop<NACC><<<blocks, 256>>>(d, 10);
   hipEventRecord(e0);
-  mfma_loop<NACC><<<blocks, 256>>>(d, iters);
+  unsigned long long* clk; hipMalloc(&clk, 16);
+  mfma_loop<NACC><<<blocks, 256>>>(d, iters, clk);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+  int wcr = 0; hipDeviceGetAttribute(&wcr, hipDeviceAttributeWallClockRate, 0);
+  printf("   shader cycles %llu, wall ticks %llu (wall clock rate %d kHz) -> shader clock %.3f GHz; cycles/MFMA/wave %.1f\n", h[0], h[1], wcr,
+         (double)h[0] / ((double)h[1] / (wcr * 1e3)) / 1e9, (double)h[0] / ((double)iters * NACC));
   double flops = (double)blocks * 4 * iters * NACC * 2.0 * 16 * 16 * 4;
   printf("mfma_f64_16x16x4: blocks=%d waves/CU=%d nacc=%d  %.2f TFLOP/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz)\n", blocks, blocks * 4 / 256,
          NACC, flops / ms / 1e9, 2.4e9 * ms * 1e-3 / ((double)blocks * 4 * iters * NACC / 1024.0));
