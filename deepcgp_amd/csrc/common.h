@@ -33,6 +33,7 @@ struct dcgp_ctx {
   std::map<std::string, std::pair<void*, size_t>> ws;
   // timing
   bool timing = false;
+  int timing_mode = 0;   // 1: every bracketed kernel family; 2: only the roofline kernels (gemm_cond_s3, kuf)
   std::map<std::string, TimingAcc> tim;
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;

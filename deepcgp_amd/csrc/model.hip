@@ -313,6 +313,7 @@ int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int 
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scratch, model->d_scal + 1, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   out_host[0] = ctx->h_scratch[0]; out_host[1] = ctx->h_scratch[1]; out_host[2] = ctx->h_scratch[2];
+  if (ctx->timing) timing_flush(ctx);   // both streams are drained here: resolve and recycle this step's events
   return read_info(model, info_host);
 }
 

@@ -198,8 +198,9 @@ class Context:
         self._check(lib().dcgp_sync(self.handle))
 
     # timing ------------------------------------------------------------------------------------
-    def timing_enable(self, on=True):
-        self._check(lib().dcgp_timing_enable(self.handle, int(bool(on))))
+    def timing_enable(self, on=1):
+        """0 off, 1 every kernel family, 2 only the roofline kernels (least perturbation)."""
+        self._check(lib().dcgp_timing_enable(self.handle, int(on)))
 
     def timing_reset(self):
         self._check(lib().dcgp_timing_reset(self.handle))

@@ -178,3 +178,24 @@ def test_full_size_cfg2_vs_oracle(ctx):
     assert abs(kl - ref.KL()) <= 1e-8 * abs(kl)
     assert abs(e - ref.compute_log_likelihood(X, Y, zs=zs)) <= 1e-8 * abs(e)
     model.close()
+
+
+def test_rccl_single_rank_allreduce_path(ctx):
+    """The N>1 code path on one GPU: a 1-rank RCCL communicator, the in-stream all-reduce inside
+    dcgp_elbo_forward and the explicit dcgp_allreduce_sum_f64 entry point."""
+    from deepcgp_amd import device as dev
+    hwc = (12, 12, 1)
+    spec = syn.make_spec(hwc, [(3, 2, 4)], (3, 1), M=10, S=2, num_data=500, seed=5, conv_q_sqrt_scale=0.3)
+    X, Y = syn.make_batch(hwc, 4, seed=5)
+    zs = syn.make_noise(spec, 4, seed=5)
+    model = build_from_spec(spec, X, Y)
+    e0 = model.compute_log_likelihood(X, Y, zs=zs)
+    ctx.comm_init(1, 0, dev.comm_unique_id())
+    try:
+        assert model.compute_log_likelihood(X, Y, zs=zs) == e0
+        buf = ctx.to_device(np.array([1.5, -2.0, 3.25]))
+        ctx.allreduce_sum(buf)
+        np.testing.assert_array_equal(buf.numpy(), [1.5, -2.0, 3.25])
+    finally:
+        dev.lib().dcgp_comm_destroy(ctx.handle)
+    model.close()
