@@ -13,105 +13,11 @@
 //                     conv_gp/conditionals.py:31-33,44-47 are then applied as products with inv(L).
 //   All matrices of a model (every layer's Kuu and KL prior) go through ONE batched call per step so the
 //   serial panel chain is paid once.
-#include "common.h"
+#include "chol_dev.h"
 
 namespace {
 
-constexpr int NB = 32;
-
-// ---------------------------------------------------------------------------------------------
-// 64x64 output tile, operands staged through LDS in k chunks of 32 (coalesced global reads, conflict-free
-// ds_read_b64 operand fetches).  A(i,k) = A[i*sAi + k*sAk], B(k,j) = B[k*sBk + j*sBj].
-//   acc[x][y][v] -> row (wm*32 + x*16 + lrow + 4v), col (wn*32 + y*16 + lcol) of the tile
-// ---------------------------------------------------------------------------------------------
-struct TileLds {
-  double As[64][NB + 1];   // [i][k]
-  double Bs[NB][64 + 1];   // [k][j]
-};
-
-__device__ __forceinline__ void tile64_mfma(TileLds& t, const double* __restrict__ A, long sAi, long sAk, int m_valid,
-                                            const double* __restrict__ B, long sBk, long sBj, int n_valid, int kdim,
-                                            int tid, d4 (&acc)[2][2]) {
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, lrow = lane >> 4, lcol = lane & 15;
-  const bool a_kfast = sAk == 1, b_jfast = sBj == 1;
-  for (int k0 = 0; k0 < kdim; k0 += NB) {
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int idx = tid + e * 256;   // 2048 elements each
-      const int ai = a_kfast ? idx >> 5 : idx & 63, ak = a_kfast ? idx & 31 : idx >> 6;
-      t.As[ai][ak] = (ai < m_valid && k0 + ak < kdim) ? A[ai * sAi + (k0 + ak) * sAk] : 0.0;
-      const int bj = b_jfast ? idx & 63 : idx >> 5, bk = b_jfast ? idx >> 6 : idx & 31;
-      t.Bs[bk][bj] = (bj < n_valid && k0 + bk < kdim) ? B[(k0 + bk) * sBk + bj * sBj] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < NB; kk += 4) {
-      double av[2], bv[2];
-#pragma unroll
-      for (int x = 0; x < 2; ++x) av[x] = t.As[wm * 32 + x * 16 + lcol][kk + lrow];
-#pragma unroll
-      for (int y = 0; y < 2; ++y) bv[y] = t.Bs[kk + lrow][wn * 32 + y * 16 + lcol];
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// wavefront-level 32x32 routines (lanes 32..63 mirror lanes 0..31)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double bcast_lane(double v, int lane) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double rsqrt_nr(double p) {
-  double y = __builtin_amdgcn_rsq(p);
-  y = y * fma(-0.5 * p * y, y, 1.5);
-  y = y * fma(-0.5 * p * y, y, 1.5);
-  return y;
-}
-// In-place Cholesky of the block whose row r sits in a[] of lane r.  Step c: the pivot comes over with one
-// v_readlane pair, every lane scales its column-c entry, writes it to the LDS line `col` and reads the 31-c
-// multipliers L[cc][c] back as uniform-address (broadcast) loads.  Entries above the diagonal pick up garbage
-// that is never read.  Returns 0 or the 1-based column of the first non-positive pivot.
-__device__ __forceinline__ int wave_potrf32(double (&a)[NB], int r, double (&col)[NB]) {
-  int fail = 0;
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    const double piv = bcast_lane(a[c], c);
-    if (!(piv > 0.0) && fail == 0) fail = c + 1;
-    const double y = rsqrt_nr(piv);
-    double d = piv * y;
-    d = fma(0.5 * y, fma(-d, d, piv), d);       // sqrt(piv) to ~1 ulp
-    a[c] = (r == c) ? d : a[c] * y;
-    col[r] = a[c];
-    double m[NB];
-#pragma unroll
-    for (int cc = c + 1; cc < NB; ++cc) m[cc] = col[cc];
-#pragma unroll
-    for (int cc = c + 1; cc < NB; ++cc) a[cc] = fma(-a[c], m[cc], a[cc]);
-  }
-  return fail;
-}
-// Column c of inv(L) for a 32x32 lower-triangular L held in LDS (D) with its reciprocal diagonal (Dr):
-// forward substitution, the row of L being read as broadcast loads once per step.
-__device__ __forceinline__ void lane_trtri32(const double (*D)[NB + 1], const double* Dr, int c, double (&x)[NB]) {
-#pragma unroll
-  for (int r = 0; r < NB; ++r) {
-    double row[NB];
-#pragma unroll
-    for (int q = 0; q < r; ++q) row[q] = D[r][q];
-    double s = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-    for (int q = 0; q < r; ++q) s = fma(-row[q], x[q], s);   // x[q] == 0 for q < c
-    x[r] = s * Dr[r];
-  }
-}
+using namespace chol_dev;
 
 // ---------------------------------------------------------------------------------------------
 // potrf panel: factor diag block (wave 0) + row-per-lane trsm of the rows below

@@ -1,0 +1,307 @@
+// chol_fused.hip -- right-looking blocked Cholesky with the inverse of the factor folded into the same launches.
+//
+// The replicated M x M stage is a serial chain; what it costs is the NUMBER of dependent launches and the latency
+// inside each (launch + memory round trips), not flops.  A textbook right-looking potrf (panel, update) followed by
+// a recursive-doubling trtri took 23 dependent launches at M = 256.  Here panel j is ONE launch whose workgroups
+// are independent of each other because each recomputes the small shared pieces it needs:
+//     every workgroup : L_jj = chol(A[j,j])   (one wavefront: registers + LDS broadcast line), and the 32-column
+//                       panel rows it touches, L[rows,j] = A[rows,j] L_jj^-T (one row per lane)
+//     trailing tile   : A[ri,rc] -= L[ri,j] L[rc,j]^T                      (matrix cores, k = 32)
+//     inverse tile    : with Y the running product of block Gauss transforms applied to I (inv(L) row blocks
+//                       < j are final):  Ynew = inv(L_jj) Y[j,cols]  ->  final rows of inv(L);
+//                       Y[rows,cols] -= L[rows,j] Ynew for the rows below (matrix cores, k = 32)
+// so every launch has constant depth (k = 32) and the chain is M/32 launches + 2 (finish, transpose) for both
+// tf.cholesky (conv_gp/conditionals.py:29, layers.py:151,156) and the inverse the triangular solves
+// (conditionals.py:31-33,44-47) are applied with.  Final values go to separate buffers (other workgroups of the
+// same launch still read the working copies).  All matrices of a model are batched in grid.y.
+#include "chol_dev.h"
+
+using namespace chol_dev;
+
+namespace {
+
+struct RlArgs {
+  double* const* A;      // working matrices (destroyed): trailing part updated in place
+  double* Lout;          // [batch][Mp][ld] final factor (lower), then copied back over A by the finish kernel
+  double* Y;             // [batch][Mp][ld] running inverse (scratch) or nullptr
+  double* const* Linv;   // final inv(L) (must be zero-filled before the first panel) or nullptr
+  int Mp, ld, j, nt, nT, nct;
+  int* info;
+};
+
+__device__ __forceinline__ void load_diag(const double* __restrict__ A, int ld, int j, int nb, double (*D)[NB + 1], int tid) {
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int r = idx / NB, c = idx % NB;
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r < nb && c < nb && c <= r) v = A[(long)(j + r) * ld + j + c];
+    D[r][c] = v;
+  }
+}
+// rows [r0, r0+64) of the panel columns -> U[64][33] (zero beyond the matrix)
+__device__ __forceinline__ void load_panel_rows(const double* __restrict__ A, int ld, int Mp, int j, int nb, int r0,
+                                                double (*U)[NB + 1], int tid) {
+  for (int idx = tid; idx < 64 * NB; idx += 256) {
+    const int i = idx / NB, c = idx % NB;
+    U[i][c] = (r0 + i < Mp && c < nb) ? A[(long)(r0 + i) * ld + j + c] : 0.0;
+  }
+}
+// U[row] <- U[row] L_jj^-T  (right-looking forward substitution, one row per thread, 64 rows)
+__device__ __forceinline__ void trsm_rows(double (*U)[NB + 1], const double (*D)[NB + 1], const double* Dr, int row) {
+  double x[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) x[c] = U[row][c];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    x[c] = x[c] * Dr[c];
+#pragma unroll
+    for (int q = c + 1; q < NB; ++q) x[q] = fma(-x[c], D[q][c], x[q]);
+  }
+#pragma unroll
+  for (int c = 0; c < NB; ++c) U[row][c] = x[c];
+}
+
+__global__ __launch_bounds__(256, 4) void chol_rl_kernel(RlArgs a) {
+  __shared__ double D[NB][NB + 1];
+  __shared__ double Dr[NB];
+  __shared__ double col[NB];
+  __shared__ double Ui[64][NB + 1];
+  __shared__ double Uc[64][NB + 1];
+  __shared__ double Xs[NB][NB + 1];   // inv(L_jj)
+  __shared__ double Ts[NB][64 + 1];   // Ynew tile
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lrow = lane >> 4, lcol = lane & 15;
+  const int Mp = a.Mp, ld = a.ld, j = a.j, nb = min(NB, Mp - j);
+  double* __restrict__ A = a.A[b];
+  double* __restrict__ Lout = a.Lout + (long)b * Mp * ld;
+  const int below0 = j + NB;   // first row below the panel block
+
+  // ---- shared prologue: L_jj ----
+  load_diag(A, ld, j, nb, D, tid);
+  const bool only_diag = a.nT == 0 && a.nct == 0;
+  const bool is_trailing = (int)blockIdx.x < a.nT;
+  int ti = 0, tc = 0, rt = -1, ct = 0;
+  if (only_diag) {
+  } else if (is_trailing) {
+    int pair = blockIdx.x;
+    while (pair >= a.nt - tc) {   // column-major enumeration of the lower triangle: tc <= ti
+      pair -= a.nt - tc;
+      ++tc;
+    }
+    ti = tc + pair;
+    load_panel_rows(A, ld, Mp, j, nb, below0 + ti * 64, Ui, tid);
+    if (tc != ti) load_panel_rows(A, ld, Mp, j, nb, below0 + tc * 64, Uc, tid);
+  } else {
+    const int y = blockIdx.x - a.nT;
+    rt = y / a.nct - 1;   // -1: the panel's own row block, else row tile below
+    ct = y % a.nct;
+    if (rt >= 0) load_panel_rows(A, ld, Mp, j, nb, below0 + rt * 64, Ui, tid);
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int r = tid & 31;
+    double av[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) av[c] = D[r][c];
+    const int fail = wave_potrf32(av, r, col);
+    if (tid < 32) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c) D[r][c] = (c <= r) ? av[c] : 0.0;
+      double diag = av[0];
+#pragma unroll
+      for (int c = 1; c < NB; ++c) diag = (c == r) ? av[c] : diag;
+      Dr[r] = 1.0 / diag;
+    }
+    if (tid == 0 && fail && blockIdx.x == 0 && a.info[b] == 0) a.info[b] = j + fail;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {   // publish L_jj (final)
+    for (int idx = tid; idx < nb * nb; idx += 256) {
+      const int r = idx / nb, c = idx % nb;
+      Lout[(long)(j + r) * ld + j + c] = D[r][c];
+    }
+  }
+  if (only_diag) return;
+
+  d4 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+
+  if (is_trailing) {
+    // ---- trailing tile (ti, tc): A[ri, rc] -= L[ri,j] L[rc,j]^T ----
+    if (tid < 64) trsm_rows(Ui, D, Dr, tid);
+    else if (tid < 128 && tc != ti) trsm_rows(Uc, D, Dr, tid - 64);
+    __syncthreads();
+    const int ri0 = below0 + ti * 64, rc0 = below0 + tc * 64;
+    double (*Ub)[NB + 1] = (tc == ti) ? Ui : Uc;
+    if (tc == ti) {   // the diagonal tiles publish the panel rows of L (final)
+      for (int idx = tid; idx < 64 * NB; idx += 256) {
+        const int i = idx / NB, c = idx % NB;
+        if (ri0 + i < Mp && c < nb) Lout[(long)(ri0 + i) * ld + j + c] = Ui[i][c];
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < NB; kk += 4) {
+      double avv[2], bvv[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) avv[x] = Ui[wm * 32 + x * 16 + lcol][kk + lrow];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) bvv[y] = Ub[wn * 32 + y * 16 + lcol][kk + lrow];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(avv[x], bvv[y], acc[x][y], 0, 0, 0);
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int i = ri0 + wm * 32 + x * 16 + lrow + 4 * v, jj = rc0 + wn * 32 + y * 16 + lcol;
+          if (i < Mp && jj < Mp && jj <= i) A[(long)i * ld + jj] -= acc[x][y][v];
+        }
+    return;
+  }
+
+  // ---- inverse tile (rt, ct): columns [c0, c0+64) of the running inverse ----
+  double* __restrict__ Y = a.Y + (long)b * Mp * ld;
+  double* __restrict__ Linv = a.Linv[b];
+  const int c0 = ct * 64;
+  if (tid < NB) {
+    double x[NB];
+    lane_trtri32(D, Dr, tid, x);
+#pragma unroll
+    for (int r = 0; r < NB; ++r) Xs[r][tid] = x[r];
+  }
+  // Y[j + q, c0 + c] before this step: stored values left of column j, identity inside [j, j+32), zero beyond
+  for (int idx = tid; idx < NB * 64; idx += 256) {
+    const int q = idx >> 6, c = idx & 63, gc = c0 + c;
+    double v = 0.0;
+    if (q < nb && gc < j) v = Y[(long)(j + q) * ld + gc];
+    else if (gc == j + q) v = 1.0;
+    Ts[q][c] = v;
+  }
+  if (rt >= 0 && tid >= 64 && tid < 128) trsm_rows(Ui, D, Dr, tid - 64);
+  __syncthreads();
+  // Ynew = inv(L_jj) * Yold  (lower-triangular 32x32 times 32x64), each thread 8 outputs, kept in registers
+  double yn[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int idx = tid + e * 256, r = idx >> 6, c = idx & 63;
+    double s = 0.0;
+    for (int q = 0; q <= r; ++q) s = fma(Xs[r][q], Ts[q][c], s);
+    yn[e] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int idx = tid + e * 256, r = idx >> 6, c = idx & 63;
+    Ts[r][c] = yn[e];
+  }
+  __syncthreads();
+  if (rt < 0) {
+    // final rows j .. j+31 of inv(L)
+    for (int idx = tid; idx < NB * 64; idx += 256) {
+      const int r = idx >> 6, c = idx & 63, gc = c0 + c;
+      if (r < nb && gc < j + nb) Linv[(long)(j + r) * ld + gc] = Ts[r][c];
+    }
+    return;
+  }
+  // rows below: Y[rows, cols] -= L[rows,j] Ynew
+  const int r0 = below0 + rt * 64;
+#pragma unroll
+  for (int kk = 0; kk < NB; kk += 4) {
+    double avv[2], bvv[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) avv[x] = Ui[wm * 32 + x * 16 + lcol][kk + lrow];
+#pragma unroll
+    for (int y = 0; y < 2; ++y) bvv[y] = Ts[kk + lrow][wn * 32 + y * 16 + lcol];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(avv[x], bvv[y], acc[x][y], 0, 0, 0);
+  }
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int i = r0 + wm * 32 + x * 16 + lrow + 4 * v, gc = c0 + wn * 32 + y * 16 + lcol;
+        if (i < Mp && gc < j + nb) {
+          const double old = (gc < j) ? Y[(long)i * ld + gc] : 0.0;   // identity part is zero below the diagonal
+          Y[(long)i * ld + gc] = old - acc[x][y][v];
+        }
+      }
+}
+
+// final factor back over A (lower triangle from Lout, strict upper triangle zero).  grid (Mp, batch)
+__global__ void chol_finish_kernel(double* const* __restrict__ Ap, const double* __restrict__ Lout, int Mp, int ld) {
+  double* __restrict__ A = Ap[blockIdx.y];
+  const double* __restrict__ L = Lout + (long)blockIdx.y * Mp * ld;
+  const int i = blockIdx.x;
+  for (int c = threadIdx.x; c < Mp; c += blockDim.x) A[(long)i * ld + c] = (c <= i) ? L[(long)i * ld + c] : 0.0;
+}
+
+// D = S^T and (zero_upper) S's strict upper triangle cleared in the same pass.  grid (Mp/32, Mp/32, batch)
+__global__ void transpose_b_kernel(double* const* __restrict__ Sp, double* const* __restrict__ Dp, int Mp, int ld) {
+  __shared__ double t[32][33];
+  const double* __restrict__ S = Sp[blockIdx.z];
+  double* __restrict__ D = Dp[blockIdx.z];
+  int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    int i = by + r, jj = bx + threadIdx.x;
+    t[r][threadIdx.x] = (i < Mp && jj < Mp) ? S[(long)i * ld + jj] : 0.0;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    int i = bx + r, jj = by + threadIdx.x;
+    if (i < Mp && jj < Mp) D[(long)i * ld + jj] = t[threadIdx.x][r];
+  }
+}
+
+__global__ void zero_rows_kernel(double* const* __restrict__ Xp, int Mp, int ld) {
+  double* __restrict__ X = Xp[blockIdx.y];
+  for (int c = threadIdx.x; c < ld; c += blockDim.x) X[(long)blockIdx.x * ld + c] = 0.0;
+}
+
+}  // namespace
+
+// Cholesky factor in place (strict upper triangle zeroed) and, when d_Linv != nullptr, inv(L) (+ its transpose).
+int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_Linv, double* const* d_LinvT, int batch,
+                           int Mp, int ld, int* d_info) {
+  if (batch <= 0) return DCGP_OK;
+  ScopedTimer t(ctx, "factor_chain");
+  const size_t mm = (size_t)Mp * ld;
+  double* Lout = (double*)ws_get(ctx, "chol_Lout", (size_t)batch * mm * sizeof(double));
+  double* Y = d_Linv ? (double*)ws_get(ctx, "chol_Y", (size_t)batch * mm * sizeof(double)) : nullptr;
+  if (!Lout || (d_Linv && !Y)) return DCGP_ERR_ALLOC;
+  HIP_TRY(ctx, hipMemsetAsync(d_info, 0, sizeof(int) * batch, ctx->stream));
+  if (d_Linv) {
+    hipLaunchKernelGGL(zero_rows_kernel, dim3(Mp, batch), dim3(128), 0, ctx->stream, d_Linv, Mp, ld);
+    LAUNCH_CHECK(ctx);
+  }
+  for (int j = 0; j < Mp; j += NB) {
+    RlArgs a;
+    a.A = d_A; a.Lout = Lout; a.Y = Y; a.Linv = d_Linv; a.Mp = Mp; a.ld = ld; a.j = j; a.info = d_info;
+    const int below = Mp - (j + NB);
+    a.nt = below > 0 ? (below + 63) / 64 : 0;
+    a.nT = a.nt * (a.nt + 1) / 2;
+    a.nct = d_Linv ? (min(j + NB, Mp) + 63) / 64 : 0;
+    const int nY = d_Linv ? (1 + a.nt) * a.nct : 0;
+    const int gx = a.nT + nY;
+    // gx == 0: last panel of a plain potrf -- only L_jj is left; one workgroup factors and publishes it
+    hipLaunchKernelGGL(chol_rl_kernel, dim3(gx > 0 ? gx : 1, batch), dim3(256), 0, ctx->stream, a);
+    LAUNCH_CHECK(ctx);
+  }
+  hipLaunchKernelGGL(chol_finish_kernel, dim3(Mp, batch), dim3(128), 0, ctx->stream, d_A, (const double*)Lout, Mp, ld);
+  LAUNCH_CHECK(ctx);
+  if (d_Linv && d_LinvT) {
+    dim3 grid((Mp + 31) / 32, (Mp + 31) / 32, batch);
+    hipLaunchKernelGGL(transpose_b_kernel, grid, dim3(32, 8), 0, ctx->stream, d_Linv, d_LinvT, Mp, ld);
+    LAUNCH_CHECK(ctx);
+  }
+  return DCGP_OK;
+}

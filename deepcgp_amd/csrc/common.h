@@ -125,5 +125,8 @@ int potrf_batched(dcgp_ctx* ctx, double* const* d_ptrs, double** h_ptrs, int bat
                   int* d_info);   // d_info[b] = 0 or 1-based failing column
 int trtri_batched(dcgp_ctx* ctx, double* const* d_L, double* const* d_Linv, double* const* d_LinvT,
                   int batch, int Mp, int ld);
+// left-looking fused Cholesky (+ inverse of the factor when d_Linv != nullptr): one launch per 32-wide panel
+int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_Linv, double* const* d_LinvT, int batch,
+                           int Mp, int ld, int* d_info);
 int pad_copy(dcgp_ctx* ctx, const double* src, int rows, int cols, int lds, double* dst, int ldd, int rows_p,
              int cols_p, int mode, int batch, long src_batch, long dst_batch);   // mode 0 full, 1 lower-tri, 2: +I on pad diag

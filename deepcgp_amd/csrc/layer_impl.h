@@ -1,6 +1,7 @@
 // Internal (header-only): device-resident layer state and the per-layer forward building blocks
 // shared by model.hip (model-level path) and ops.hip (single-operator C-ABI entry points).
 #pragma once
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -110,8 +111,13 @@ struct FactorGroup {
   }
   int run(dcgp_ctx* ctx) {
     DCGP_TRY(upload(ctx));
-    DCGP_TRY(potrf_batched(ctx, dK, nullptr, (int)K.size(), Mp, Mp, d_info));
-    DCGP_TRY(trtri_batched(ctx, dK, dLinv, dLinvT, (int)K.size(), Mp, Mp));
+    static const bool legacy = getenv("DCGP_CHOL_LEGACY") != nullptr;   // A/B: right-looking potrf + recursive trtri
+    if (legacy) {
+      DCGP_TRY(potrf_batched(ctx, dK, nullptr, (int)K.size(), Mp, Mp, d_info));
+      DCGP_TRY(trtri_batched(ctx, dK, dLinv, dLinvT, (int)K.size(), Mp, Mp));
+    } else {
+      DCGP_TRY(factor_inverse_batched(ctx, dK, dLinv, dLinvT, (int)K.size(), Mp, Mp, d_info));
+    }
     return DCGP_OK;
   }
 };

@@ -41,7 +41,8 @@ def test_golden_vectors(ctx, path):
     assert abs(kl - float(d["kl"])) <= RTOL * abs(float(d["kl"]))
     # layer-0 de-duplication is exact: the S copies of the batch are identical
     model.dedup_layer0 = True
-    assert model.compute_log_likelihood(d["X"], d["Y"], zs=zs) == elbo
+    e_d = model.compute_log_likelihood(d["X"], d["Y"], zs=zs)
+    assert e_d == elbo if spec["convs"] else abs(e_d - elbo) <= 1e-13 * abs(elbo)
     # per-layer KL through the operator API agrees with the fused path
     assert abs(model.KL() - kl) <= 1e-10 * abs(kl)
     model.close()
@@ -156,7 +157,11 @@ def test_full_size_properties(ctx, name):
     assert np.isfinite([e, data, kl]).all() and kl > 0 and data < 0
     assert abs(e - (data * spec["num_data"] / X.shape[0] - kl)) <= 1e-12 * abs(e)
     model.dedup_layer0 = True
-    assert model.compute_log_likelihood(X, Y, zs=zs) == e                      # exact de-duplication
+    e_d = model.compute_log_likelihood(X, Y, zs=zs)
+    if spec["convs"]:
+        assert e_d == e                   # exact de-duplication: the S copies give bit-identical rows
+    else:
+        assert abs(e_d - e) <= 1e-13 * abs(e)   # head-only: N rows are summed instead of S*N (other rounding order)
     model.dedup_layer0 = False
     perm = np.random.default_rng(0).permutation(X.shape[0])                     # image order is irrelevant
     e_p = model.compute_log_likelihood(X[perm], Y[perm], zs=[z[:, perm] for z in zs])
