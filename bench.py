@@ -85,6 +85,9 @@ def main():
                     help="evaluate layer 0 on the distinct images only (exact; off by default so that the step does "
                          "the same work as the reference, which tiles the batch S times)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm", type=str, default="rccl", choices=["rccl", "gloo"],
+                    help="N > 1: rccl = in-stream ncclAllReduce inside dcgp_elbo_forward (default); gloo = host "
+                         "all-reduce of the per-rank data term (debug / fallback when RCCL cannot initialise)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,7 +112,21 @@ def main():
             t = torch.tensor(list(b), dtype=torch.uint8)
             td.broadcast(t, src=0)
             return bytes(t.tolist())
-        init_rccl(ctx, rank, world, bcast)
+        comm = args.comm
+        if comm == "rccl":
+            ok = 1
+            try:
+                init_rccl(ctx, rank, world, bcast)
+            except Exception as exc:          # noqa: BLE001 -- any failure must reach the collective vote below
+                ok = 0
+                print("rank %d: RCCL init failed (%s); falling back to the host all-reduce" % (rank, exc), file=sys.stderr)
+            vote = torch.tensor([ok], dtype=torch.int32)
+            td.all_reduce(vote, op=td.ReduceOp.MIN)
+            if int(vote[0]) == 0:
+                dev.lib().dcgp_comm_destroy(ctx.handle)
+                comm = "gloo(fallback)"
+    else:
+        comm = "none"
 
     cfg = syn.CONFIGS[args.config]
     S = args.samples
@@ -130,6 +147,12 @@ def main():
     scale = float(spec["num_data"]) / float(global_batch)
 
     def step(i):
+        if comm.startswith("gloo"):
+            # host-side join: the local data term comes back, is summed over ranks with gloo, ELBO assembled here
+            _, data, kl = model.compute_log_likelihood(dX, dY, seed=i, scale=scale, return_parts=True)
+            t = torch.tensor([data], dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+            return float(t[0]) * scale - kl
         return model.compute_log_likelihood(dX, dY, seed=i, scale=scale)
 
     def barrier():
@@ -184,7 +207,7 @@ def main():
             "config": {"workload": args.config, "variant": "conv layer + head" if cfg["convs"] else "head only",
                        "M": cfg["M"], "per_gpu_batch": per_rank_batch, "global_batch": global_batch, "num_samples": S,
                        "image": list(cfg["hwc"]), "layers": len(cfg["convs"]) + 1, "noise": "device Philox RNG",
-                       "dedup_layer0": bool(args.dedup_layer0), "parallelism": "image-sharded x%d, RCCL all-reduce of 1 f64" % world},
+                       "dedup_layer0": bool(args.dedup_layer0), "parallelism": "image-sharded x%d, %s all-reduce of 1 f64" % (world, comm)},
             "elbo": elbo,
             "ms_per_step_without_event_timing": 1e3 * dt_plain / args.steps,
         }
