@@ -180,7 +180,7 @@ int dcgp_timing_enable(dcgp_ctx* ctx, int on) {
   ctx->timing = on != 0;
   ctx->timing_mode = on;
   // pre-create events so that the timed region never pays hipEventCreate
-  while (ctx->timing && ctx->event_pool.size() < 256) {
+  while (ctx->timing && ctx->event_pool.size() < 1536) {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) break;
     ctx->event_pool.push_back(e);

@@ -9,6 +9,7 @@
 //   4. conv layers: patch-RBF sweep -> 3 conditional GEMMs -> mean -> finalize (+ sample)
 //   5. head: Kzx (patch sweep reduced over patches), Kdiag, conditional, RobustMax expectations
 //   6. (multi-GPU) all-reduce of the data term, ELBO assembly, one 32-byte read-back.
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -140,11 +141,12 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   hipStream_t main_s = ctx->stream;
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_s));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-  ctx->stream = ctx->stream2;
+  static const bool no_side = getenv("DCGP_NO_SIDE_STREAM") != nullptr;   // A/B switch: everything on one stream
+  if (!no_side) ctx->stream = ctx->stream2;
   int rc = DCGP_OK;
   for (auto& gr : m->groups)
     if ((rc = gr.run(ctx)) != DCGP_OK) break;
-  if (rc == DCGP_OK && hipEventRecord(ctx->ev_factor, ctx->stream2) != hipSuccess) rc = DCGP_ERR_HIP;
+  if (rc == DCGP_OK && hipEventRecord(ctx->ev_factor, ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
   if (rc == DCGP_OK && need_kl) {
     for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
       LayerState& L = *m->layers[li];
@@ -153,7 +155,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       rc = kl_layer(ctx, L.g, Lp, LpinvT, L.white, (mp + std::to_string(li)).c_str(), m->d_scal + 4 + 4 * li);
     }
   }
-  if (rc == DCGP_OK && hipEventRecord(ctx->ev_kl, ctx->stream2) != hipSuccess) rc = DCGP_ERR_HIP;
+  if (rc == DCGP_OK && hipEventRecord(ctx->ev_kl, ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
   ctx->stream = main_s;
   if (rc != DCGP_OK) {
     hipStreamSynchronize(ctx->stream2);
@@ -313,7 +315,7 @@ int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int 
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scratch, model->d_scal + 1, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   out_host[0] = ctx->h_scratch[0]; out_host[1] = ctx->h_scratch[1]; out_host[2] = ctx->h_scratch[2];
-  if (ctx->timing) timing_flush(ctx);   // both streams are drained here: resolve and recycle this step's events
+  if (ctx->timing && ctx->pending.size() > 512) timing_flush(ctx);   // both streams are drained here; resolve lazily
   return read_info(model, info_host);
 }
 

@@ -204,3 +204,29 @@ def test_rccl_single_rank_allreduce_path(ctx):
     finally:
         dev.lib().dcgp_comm_destroy(ctx.handle)
     model.close()
+
+
+def test_model_builder_from_flags(ctx):
+    """ModelBuilder with the reference's flag names (conv_gp/models.py:43-70): k-means patch init, identity-conv
+    propagation of the init images, q_sqrt scaled by 1e-5; the built model evaluates and its initial KL is ~0 for the
+    head and finite for the conv layer."""
+    from deepcgp_amd.arguments import default_parser
+    from deepcgp_amd.models import ModelBuilder
+    rng = np.random.default_rng(0)
+    np.random.seed(0)
+    X = rng.standard_normal((40, 12, 12, 1))
+    Y = rng.integers(0, 10, (40, 1))
+    flags = default_parser().parse_args(['--name', 't', '-M', '6,7', '--feature-maps', '3', '--filter-sizes', '3,3',
+                                         '--strides', '2,1', '--num-samples', '2', '--batch-size', '8'])
+    model = ModelBuilder(flags, X, Y).build()
+    assert [type(l).__name__ for l in model.layers] == ['ConvLayer', 'SVGP_Layer']
+    conv, head = model.layers
+    assert conv.num_outputs == 5 * 5 * 3 and conv.feature.Z.shape == (6, 9) and head.feature.Z.shape == (7, 27)
+    assert np.max(np.abs(conv.q_sqrt)) < 1e-3 and head.q_sqrt.shape == (10, 7, 7)
+    e = model.compute_log_likelihood(X[:8].reshape(8, -1), Y[:8], seed=1)
+    assert np.isfinite(e)
+    assert abs(head.KL()) < 1e-8 and np.isfinite(conv.KL()) and conv.KL() > 0
+    with pytest.raises(AssertionError):
+        flags.feature_maps = '3,3'
+        ModelBuilder(flags, X, Y).build()
+    model.close()
