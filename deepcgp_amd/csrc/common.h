@@ -27,7 +27,7 @@ struct dcgp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;    // the stream launches go to (temporarily swapped to stream2 for the side branch)
   hipStream_t stream2 = nullptr;   // side stream: factorisation chain + KL terms
-  hipEvent_t ev_fork = nullptr, ev_factor = nullptr, ev_kl = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_factor = nullptr, ev_prep = nullptr, ev_kl = nullptr;
   std::string err;
   // named, grow-only device workspaces owned by the ctx
   std::map<std::string, std::pair<void*, size_t>> ws;

@@ -251,8 +251,33 @@ int varexp_rows(dcgp_ctx* ctx, const double* mu, const double* var, const int32_
   return DCGP_OK;
 }
 
+// The conditional with the second triangular solve folded into the SMALL operands.  The reference computes
+//     A1 = inv(L) Kuf ;  A = inv(L)^T A1 ;  mean = A^T q_mu ;  var += sum_m (Lq_r^T A)^2      (conditionals.py:31-65)
+// Since Lq_r^T inv(L)^T A1 = (inv(L) Lq_r)^T A1 and q_mu^T inv(L)^T A1 = (inv(L) q_mu)^T A1, the M x (P*N) product
+// with inv(L)^T is replaced by two M x M-sized products (cond_prep: G_r = inv(L) Lq_r, still lower triangular, and
+// alpha = inv(L) q_mu) that run next to the factorisation on the side stream.  Whitened case: G = Lq, alpha = q_mu.
+int cond_prep(dcgp_ctx* ctx, GpMats& g, int white, bool have_qsqrt) {
+  const int Mp = g.Mp, R = g.R;
+  if (white) return DCGP_OK;   // G / alpha alias Lq / qmu (set by the owner of g)
+  ScopedTimer t(ctx, "gemm_prep");
+  if (have_qsqrt) {
+    GemmArgs a;   // G_r = inv(L) Lq_r : lower x lower
+    a.Wt = g.LinvT; a.ldw = Mp;
+    a.B = g.Lq; a.ldb = Mp; a.bBatch = (long)Mp * Mp; a.nB = R;
+    a.C = g.G; a.ldc = Mp; a.cBatch = (long)Mp * Mp;
+    a.Mi = Mp; a.Mk = Mp; a.Kc = Mp; a.tri = 1; a.b_lower = 1;
+    DCGP_TRY(gemm_tn(ctx, a, nullptr));
+  }
+  GemmArgs b;     // alpha = inv(L) q_mu
+  b.Wt = g.LinvT; b.ldw = Mp;
+  b.B = g.qmu; b.ldb = g.Rp;
+  b.C = g.alpha; b.ldc = g.Rp;
+  b.Mi = Mp; b.Mk = Mp; b.Kc = g.Rp; b.tri = 1;
+  return gemm_tn(ctx, b, nullptr);
+}
+
 int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, int white, bool have_qsqrt,
-              const char* pfx, CondScratch* out) {
+              const char* pfx, CondScratch* out, hipEvent_t prep_done) {
   const int Mp = g.Mp, R = g.R;
   const int BM1 = gemm_row_block(Mp, Kc, 1), BM3 = gemm_row_block(Mp, Kc, R);
   const int nrb = (Mp + BM1 - 1) / BM1, nrb3 = (Mp + BM3 - 1) / BM3;
@@ -261,13 +286,12 @@ int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc,
   sc.ldb = ldb;
   sc.nrb1 = nrb; sc.nrb3 = nrb3;
   sc.A1 = (double*)ws_get(ctx, p + "A1", (size_t)Mp * ldb * sizeof(double));
-  sc.A2 = white ? sc.A1 : (double*)ws_get(ctx, p + "A2", (size_t)Mp * ldb * sizeof(double));
   sc.s1p = (double*)ws_get(ctx, p + "s1p", (size_t)nrb * ldb * sizeof(double));
   sc.s2p = have_qsqrt ? (double*)ws_get(ctx, p + "s2p", (size_t)R * nrb3 * ldb * sizeof(double)) : nullptr;
   sc.mu = (double*)ws_get(ctx, p + "mu", (size_t)g.Rp * ldb * sizeof(double));
-  if (!sc.A1 || !sc.A2 || !sc.s1p || !sc.mu || (have_qsqrt && !sc.s2p)) return DCGP_ERR_ALLOC;
+  if (!sc.A1 || !sc.s1p || !sc.mu || (have_qsqrt && !sc.s2p)) return DCGP_ERR_ALLOC;
   {
-    ScopedTimer t(ctx, "gemm_cond_s1");
+    ScopedTimer t(ctx, "gemm_cond_s1");   // A1 = inv(L) Kuf, s1 = sum_m A1^2
     GemmArgs a;
     a.Wt = g.LinvT; a.ldw = Mp;
     a.B = B; a.ldb = (int)ldb;
@@ -276,30 +300,22 @@ int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc,
     a.Mi = Mp; a.Mk = Mp; a.Kc = Kc; a.tri = 1;
     DCGP_TRY(gemm_tn(ctx, a, nullptr));
   }
-  if (!white) {
-    ScopedTimer t(ctx, "gemm_cond_s2");
-    GemmArgs a;
-    a.Wt = g.Linv; a.ldw = Mp;
-    a.B = sc.A1; a.ldb = (int)ldb;
-    a.C = sc.A2; a.ldc = (int)ldb;
-    a.Mi = Mp; a.Mk = Mp; a.Kc = Kc; a.tri = 2;
-    DCGP_TRY(gemm_tn(ctx, a, nullptr));
-  }
+  if (prep_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, prep_done, 0));   // G / alpha come from the side stream
   if (have_qsqrt) {
-    ScopedTimer t(ctx, "gemm_cond_s3");
+    ScopedTimer t(ctx, "gemm_cond_s3");   // T_r = G_r^T A1 (upper-triangular product), s2 = sum_m T_r^2, never stored
     GemmArgs a;
-    a.Wt = g.Lq; a.ldw = Mp; a.wBatch = (long)Mp * Mp; a.nW = R;
-    a.B = sc.A2; a.ldb = (int)ldb;
+    a.Wt = g.G; a.ldw = Mp; a.wBatch = (long)Mp * Mp; a.nW = R;
+    a.B = sc.A1; a.ldb = (int)ldb;
     a.colsq = sc.s2p; a.sBatch = (long)nrb3 * ldb; a.sRowBlk = ldb;
     a.Mi = Mp; a.Mk = Mp; a.Kc = Kc; a.tri = 2;
     DCGP_TRY(gemm_tn(ctx, a, nullptr));
   }
   {
-    // mu[r][j] = sum_k q_mu[k][r] A[k][j]  (conditionals.py:50): a 16-row dense product on the same kernel
+    // mu[r][j] = sum_k alpha[k][r] A1[k][j]  (conditionals.py:50): a 16-row dense product on the same kernel
     ScopedTimer t(ctx, "cond_mean");
     GemmArgs a;
-    a.Wt = g.qmu; a.ldw = g.Rp;
-    a.B = sc.A2; a.ldb = (int)ldb;
+    a.Wt = g.alpha; a.ldw = g.Rp;
+    a.B = sc.A1; a.ldb = (int)ldb;
     a.C = sc.mu; a.ldc = (int)ldb;
     a.Mi = g.Rp; a.Mk = Mp; a.Kc = Kc; a.tri = 0;
     DCGP_TRY(gemm_tn(ctx, a, nullptr));

@@ -95,6 +95,7 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
       hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_factor, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_kl, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return DCGP_ERR_HIP;
@@ -124,6 +125,7 @@ int dcgp_ctx_destroy(dcgp_ctx* ctx) {
   hipHostFree(ctx->h_info);
   hipEventDestroy(ctx->ev_fork);
   hipEventDestroy(ctx->ev_factor);
+  hipEventDestroy(ctx->ev_prep);
   hipEventDestroy(ctx->ev_kl);
   hipStreamDestroy(ctx->stream2);
   hipStreamDestroy(ctx->stream);

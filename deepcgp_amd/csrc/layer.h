@@ -22,17 +22,22 @@ struct GpMats {
   double* LpinvT = nullptr;
   double* Lq = nullptr;     // [R][Mp][Mp] lower-masked q_sqrt, zero padded
   double* qmu = nullptr;    // [Mp][Rp], zero padded rows and columns
+  // derived by cond_prep after the factorisation (alias Lq / qmu in the whitened case):
+  double* G = nullptr;      // [R][Mp][Mp]  G_r = inv(L) Lq_r   (lower triangular)
+  double* alpha = nullptr;  // [Mp][Rp]     alpha = inv(L) q_mu
 };
 
 // A = inv(L) Kuf etc. on a k-major Kuf matrix B [Mp x ldb] with Kc columns.
 // Produces partial column sums s1p [nrb1][ldb], s2p [R][nrb3][ldb], and mu [R][ldb].
 struct CondScratch {
-  double *A1 = nullptr, *A2 = nullptr, *s1p = nullptr, *s2p = nullptr, *mu = nullptr;
+  double *A1 = nullptr, *s1p = nullptr, *s2p = nullptr, *mu = nullptr;
   int nrb1 = 0, nrb3 = 0;
   long ldb = 0;
 };
+// G and alpha of a layer (two small GEMMs on the current stream); must run after the factorisation of g.K
+int cond_prep(dcgp_ctx* ctx, GpMats& g, int white, bool have_qsqrt);
 int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, int white, bool have_qsqrt,
-              const char* ws_prefix, CondScratch* out);
+              const char* ws_prefix, CondScratch* out, hipEvent_t prep_done = nullptr);
 
 struct FinalizeArgs {
   const double* s1p = nullptr; int nrb1 = 0;

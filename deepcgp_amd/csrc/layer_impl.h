@@ -58,6 +58,8 @@ struct LayerState {
     if (!head && !white && need_prior) { g.Kp = dalloc(mm); g.Lpinv = dalloc(mm); g.LpinvT = dalloc(mm); }
     g.Lq = dalloc((size_t)R * mm);
     g.qmu = dalloc((size_t)Mp * g.Rp);
+    if (white) { g.G = g.Lq; g.alpha = g.qmu; }
+    else { g.G = dalloc((size_t)R * mm); g.alpha = dalloc((size_t)Mp * g.Rp); }
     ZT = dalloc((size_t)Lp * Mp);
     zn = dalloc(Mp);
     for (void* p : owned)
@@ -125,7 +127,8 @@ struct FactorGroup {
 // ConvLayer.conditional_ND (+ sampling) on `rows` input images taken as X[(n % n_mod)]
 static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, int rows, int n_mod, int rep, long rep_stride,
                  const double* z, uint64_t seed, uint32_t stream_id, double jitter, double* out_sample, double* out_mean,
-                 double* out_var, const std::string& pfx, hipEvent_t factor_done = nullptr) {
+                 double* out_var, const std::string& pfx, hipEvent_t factor_done = nullptr,
+                               hipEvent_t prep_done = nullptr) {
   const int Mp = L.Mp, P = L.v.P;
   const long Kc = (long)rows * P;
   if (Kc > 0x7fffff00L) return ctx_fail(ctx, DCGP_ERR_ARG, "conv layer: %ld patch columns exceed the 32-bit tile index", Kc);
@@ -142,7 +145,7 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   DCGP_TRY(patch_rbf(ctx, a, "kuf"));
   if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));   // inv(L) comes from the side stream
   CondScratch sc;
-  DCGP_TRY(cond_core(ctx, L.g, B, ldb, (int)Kc, L.white, L.has_qsqrt, pfx.c_str(), &sc));
+  DCGP_TRY(cond_core(ctx, L.g, B, ldb, (int)Kc, L.white, L.has_qsqrt, pfx.c_str(), &sc, prep_done));
   FinalizeArgs fa;
   fa.s1p = sc.s1p; fa.nrb1 = sc.nrb1; fa.s2p = sc.s2p; fa.nrb3 = sc.nrb3; fa.mu = sc.mu; fa.ldk = ldb;
   fa.Kc = (int)Kc; fa.R = L.R; fa.knn_scalar = L.variance;
@@ -157,7 +160,8 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
 
 // SVGP head: Kzx / Kdiag from the conv kernel, then the shared conditional
 static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, int rows, int n_mod, double* kd, double* out_mean,
-                 double* out_var, const std::string& pfx, hipEvent_t factor_done = nullptr) {
+                 double* out_var, const std::string& pfx, hipEvent_t factor_done = nullptr,
+                               hipEvent_t prep_done = nullptr) {
   const int Mp = L.Mp;
   const long ldb = round_up_l(rows, 128);
   double* B = (double*)ws_get(ctx, pfx + "Kzx", (size_t)Mp * ldb * sizeof(double));
@@ -179,7 +183,7 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   }
   if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
   CondScratch sc;
-  DCGP_TRY(cond_core(ctx, L.g, B, ldb, rows, L.white, L.has_qsqrt, pfx.c_str(), &sc));
+  DCGP_TRY(cond_core(ctx, L.g, B, ldb, rows, L.white, L.has_qsqrt, pfx.c_str(), &sc, prep_done));
   FinalizeArgs fa;
   fa.s1p = sc.s1p; fa.nrb1 = sc.nrb1; fa.s2p = sc.s2p; fa.nrb3 = sc.nrb3; fa.mu = sc.mu; fa.ldk = ldb;
   fa.Kc = rows; fa.R = L.R; fa.knn_vec = kd;

@@ -147,6 +147,9 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   for (auto& gr : m->groups)
     if ((rc = gr.run(ctx)) != DCGP_OK) break;
   if (rc == DCGP_OK && hipEventRecord(ctx->ev_factor, ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
+  // G_r = inv(L) Lq_r and alpha = inv(L) q_mu of every layer (cond_prep): gate the second conditional GEMM
+  for (int li = 0; li < nl && rc == DCGP_OK; ++li) rc = cond_prep(ctx, m->layers[li]->g, m->layers[li]->white, m->layers[li]->has_qsqrt);
+  if (rc == DCGP_OK && hipEventRecord(ctx->ev_prep, ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
   if (rc == DCGP_OK && need_kl) {
     for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
       LayerState& L = *m->layers[li];
@@ -178,7 +181,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       auto& o = m->outs[li];
       DCGP_TRY(conv_forward(ctx, L, F, rows, n_mod, expand ? S : 1, (long)N * width, z, seed, (uint32_t)(li + 1 + 64 * ctx->rank),
                             m->jitter, o.sample, m->keep_outputs ? o.mean : nullptr, m->keep_outputs ? o.var : nullptr, pfx,
-                            factor_waited ? nullptr : ctx->ev_factor));
+                            factor_waited ? nullptr : ctx->ev_factor, ctx->ev_prep));
       factor_waited = true;
       F = o.sample;
       rows = out_rows;
@@ -187,7 +190,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       DCGP_TRY(ensure_out(m, li, rows, L.R, true));
       auto& o = m->outs[li];
       DCGP_TRY(ensure(ctx, &m->d_kd, &m->kd_cap, (size_t)rows));
-      DCGP_TRY(head_forward(ctx, L, F, rows, n_mod, m->d_kd, o.mean, o.var, pfx, factor_waited ? nullptr : ctx->ev_factor));
+      DCGP_TRY(head_forward(ctx, L, F, rows, n_mod, m->d_kd, o.mean, o.var, pfx, factor_waited ? nullptr : ctx->ev_factor, ctx->ev_prep));
       factor_waited = true;
       if (m->keep_outputs) {
         // the head's sample is not needed by the ELBO; produce it only on request

@@ -52,7 +52,7 @@ struct TmpGp {
 };
 
 int tmp_gp_build(dcgp_ctx* ctx, TmpGp& t, const std::string& pfx, int M, int R, const double* Kmm, const double* q_mu,
-                 const double* q_sqrt, int* info_host) {
+                 const double* q_sqrt, int* info_host, int prep_white = -1) {
   const int Mp = round_up(M, 16);
   const size_t mm = (size_t)Mp * Mp;
   GpMats& g = t.g;
@@ -62,7 +62,9 @@ int tmp_gp_build(dcgp_ctx* ctx, TmpGp& t, const std::string& pfx, int M, int R, 
   g.LinvT = (double*)ws_get(ctx, pfx + "LinvT", mm * sizeof(double));
   g.Lq = (double*)ws_get(ctx, pfx + "Lq", (size_t)R * mm * sizeof(double));
   g.qmu = (double*)ws_get(ctx, pfx + "qmu", (size_t)Mp * g.Rp * sizeof(double));
-  if (!g.K || !g.Linv || !g.LinvT || !g.Lq || !g.qmu) return DCGP_ERR_ALLOC;
+  g.G = (double*)ws_get(ctx, pfx + "G", (size_t)R * mm * sizeof(double));
+  g.alpha = (double*)ws_get(ctx, pfx + "alpha", (size_t)Mp * g.Rp * sizeof(double));
+  if (!g.K || !g.Linv || !g.LinvT || !g.Lq || !g.qmu || !g.G || !g.alpha) return DCGP_ERR_ALLOC;
   if (Kmm) DCGP_TRY(pad_copy(ctx, Kmm, M, M, M, g.K, Mp, Mp, Mp, 2, 1, 0, 0));
   if (q_sqrt) DCGP_TRY(pad_copy(ctx, q_sqrt, M, M, M, g.Lq, Mp, Mp, Mp, 1, R, (long)M * M, (long)Mp * Mp));
   if (q_mu) DCGP_TRY(pad_copy(ctx, q_mu, M, R, R, g.qmu, g.Rp, Mp, g.Rp, 0, 1, 0, 0));
@@ -75,6 +77,8 @@ int tmp_gp_build(dcgp_ctx* ctx, TmpGp& t, const std::string& pfx, int M, int R, 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (info_host) *info_host = info;
     if (info) return ctx_fail(ctx, DCGP_ERR_NOT_PD, "Cholesky: matrix not positive definite at column %d", info);
+    if (prep_white == 1) { g.G = g.Lq; g.alpha = g.qmu; }
+    if (prep_white >= 0) DCGP_TRY(cond_prep(ctx, g, prep_white, q_sqrt != nullptr));
   }
   return DCGP_OK;
 }
@@ -175,7 +179,7 @@ int dcgp_conditional(dcgp_ctx* ctx, const double* Kmn, const double* Kmm, const 
   ARG_CHECK(ctx && Kmn && Kmm && Knn && f && out_mean && out_var && P > 0 && M > 0 && N > 0 && R > 0, "conditional: bad args");
   if (info_host) *info_host = 0;
   TmpGp t;
-  DCGP_TRY(tmp_gp_build(ctx, t, "op_cond_", M, R, Kmm, f, q_sqrt, info_host));
+  DCGP_TRY(tmp_gp_build(ctx, t, "op_cond_", M, R, Kmm, f, q_sqrt, info_host, white ? 1 : 0));
   const int Mp = t.g.Mp;
   const long Kc = (long)P * N, ldb = round_up_l(Kc, 128);
   double* B = (double*)ws_get(ctx, "op_cond_B", (size_t)Mp * ldb * sizeof(double));
@@ -200,7 +204,7 @@ int dcgp_svgp_conditional(dcgp_ctx* ctx, const double* Kuf, const double* Ku, co
   ARG_CHECK(ctx && Kuf && Ku && Kdiag && q_mu && out_mean && out_var && M > 0 && N > 0 && R > 0, "svgp_conditional: bad args");
   if (info_host) *info_host = 0;
   TmpGp t;
-  DCGP_TRY(tmp_gp_build(ctx, t, "op_svgp_", M, R, Ku, q_mu, q_sqrt, info_host));
+  DCGP_TRY(tmp_gp_build(ctx, t, "op_svgp_", M, R, Ku, q_mu, q_sqrt, info_host, white ? 1 : 0));
   const int Mp = t.g.Mp;
   const long ldb = round_up_l(N, 128);
   double* B = (double*)ws_get(ctx, "op_svgp_B", (size_t)Mp * ldb * sizeof(double));
@@ -245,6 +249,7 @@ int dcgp_conv_layer_forward(dcgp_ctx* ctx, const double* X, int N, int H, int W,
   if (rc != DCGP_OK) return rc;
   if (info_host) *info_host = info;
   if (info) return ctx_fail(ctx, DCGP_ERR_NOT_PD, "Cholesky: matrix not positive definite at column %d", info);
+  DCGP_TRY(cond_prep(ctx, L.g, white, L.has_qsqrt));
   DCGP_TRY(conv_forward(ctx, L, X, N, N, 1, 0, z, 0, 0, jitter, out_sample, out_mean, out_var, "op_conv_"));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return DCGP_OK;
