@@ -27,6 +27,19 @@ struct GpMats {
   double* alpha = nullptr;  // [Mp][Rp]     alpha = inv(L) q_mu
 };
 
+// parameter-only preparation of all layers in one launch (prep.hip)
+struct PrepLayerArgs {
+  const double *Z = nullptr, *Z0 = nullptr, *q_sqrt = nullptr, *q_mu = nullptr;
+  double *K = nullptr, *Kp = nullptr, *ZT = nullptr, *zn = nullptr, *Lq = nullptr, *qmu = nullptr;
+  int M = 0, Mp = 0, L = 0, Lp = 0, R = 0, Rp = 0;
+  double variance = 1.0, inv_l2 = 1.0, jitter = 0.0;
+};
+struct PrepArgs {
+  int nl = 0;
+  PrepLayerArgs l[8];
+};
+int prepare_all(dcgp_ctx* ctx, const PrepArgs& a);
+
 // A = inv(L) Kuf etc. on a k-major Kuf matrix B [Mp x ldb] with Kc columns.
 // Produces partial column sums s1p [nrb1][ldb], s2p [R][nrb3][ldb], and mu [R][ldb].
 struct CondScratch {

@@ -72,6 +72,14 @@ struct LayerState {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DCGP_OK;
   }
+  PrepLayerArgs prep_args(double jitter) const {
+    PrepLayerArgs p;
+    p.Z = Z; p.Z0 = Z0; p.q_sqrt = has_qsqrt ? q_sqrt : nullptr; p.q_mu = q_mu;
+    p.K = g.K; p.Kp = g.Kp; p.ZT = ZT; p.zn = zn; p.Lq = g.Lq; p.qmu = g.qmu;
+    p.M = M; p.Mp = Mp; p.L = v.L; p.Lp = Lp; p.R = R; p.Rp = g.Rp;
+    p.variance = variance; p.inv_l2 = 1.0 / (ls * ls); p.jitter = jitter;
+    return p;
+  }
   // step 1 of the forward: everything that depends only on this layer's parameters
   int prepare(double jitter) {
     const double inv_l2 = 1.0 / (ls * ls);
@@ -128,21 +136,25 @@ struct FactorGroup {
 static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, int rows, int n_mod, int rep, long rep_stride,
                  const double* z, uint64_t seed, uint32_t stream_id, double jitter, double* out_sample, double* out_mean,
                  double* out_var, const std::string& pfx, hipEvent_t factor_done = nullptr,
-                               hipEvent_t prep_done = nullptr) {
+                               hipEvent_t prep_done = nullptr, int phase = 3) {
+  // phase bit 0: the K_uf sweep (needs only Z); bit 1: conditional + finalize (needs the factorisation).  The model
+  // path enqueues bit 0 of its first layer BEFORE the long side-stream sequence so that the sweep is not held up
+  // by the host still enqueueing the factorisation chain.
   const int Mp = L.Mp, P = L.v.P;
   const long Kc = (long)rows * P;
   if (Kc > 0x7fffff00L) return ctx_fail(ctx, DCGP_ERR_ARG, "conv layer: %ld patch columns exceed the 32-bit tile index", Kc);
   const long ldb = round_up_l(Kc, 128);
   double* B = (double*)ws_get(ctx, pfx + "Kuf", (size_t)Mp * ldb * sizeof(double));
   if (!B) return DCGP_ERR_ALLOC;
-  if (Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));
+  if ((phase & 1) && Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));
   PatchRbfArgs a;
   a.X = X; a.N = rows; a.n_mod = n_mod;
   a.H = L.v.H; a.W = L.v.W; a.C = L.v.C; a.f = L.v.f; a.s = L.v.s; a.Ho = L.v.Ho; a.Wo = L.v.Wo; a.P = P; a.L = L.v.L;
   a.ZT = L.ZT; a.zn = L.zn; a.M = L.M; a.Mp = Mp; a.Lp = L.Lp;
   a.variance = L.variance; a.inv_l2 = 1.0 / (L.ls * L.ls);
   a.out = B; a.sM = ldb; a.sN = P; a.sP = 1;
-  DCGP_TRY(patch_rbf(ctx, a, "kuf"));
+  if (phase & 1) DCGP_TRY(patch_rbf(ctx, a, "kuf"));
+  if (!(phase & 2)) return DCGP_OK;
   if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));   // inv(L) comes from the side stream
   CondScratch sc;
   DCGP_TRY(cond_core(ctx, L.g, B, ldb, (int)Kc, L.white, L.has_qsqrt, pfx.c_str(), &sc, prep_done));
@@ -161,12 +173,12 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
 // SVGP head: Kzx / Kdiag from the conv kernel, then the shared conditional
 static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, int rows, int n_mod, double* kd, double* out_mean,
                  double* out_var, const std::string& pfx, hipEvent_t factor_done = nullptr,
-                               hipEvent_t prep_done = nullptr) {
+                               hipEvent_t prep_done = nullptr, int phase = 3) {
   const int Mp = L.Mp;
   const long ldb = round_up_l(rows, 128);
   double* B = (double*)ws_get(ctx, pfx + "Kzx", (size_t)Mp * ldb * sizeof(double));
   if (!B) return DCGP_ERR_ALLOC;
-  if (Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));
+  if ((phase & 1) && Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));
   const double inv_l2 = 1.0 / (L.ls * L.ls);
   PatchRbfArgs a;
   a.X = X; a.N = rows; a.n_mod = n_mod;
@@ -175,12 +187,15 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   a.variance = L.variance; a.inv_l2 = inv_l2;
   a.out = B; a.sM = ldb; a.sN = 1; a.sP = 0;
   a.w = L.w; a.scale = 1.0 / (double)L.v.P; a.reduce = 1;
-  DCGP_TRY(patch_rbf(ctx, a, "head_kzx"));
-  if (L.kernel_type == 0) {
-    DCGP_TRY(head_kdiag(ctx, X, rows, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s, L.variance, inv_l2, L.w, kd));
-  } else {
-    DCGP_TRY(additive_kdiag_async(ctx, rows, L.v.P, L.variance, L.w, kd));
+  if (phase & 1) {
+    DCGP_TRY(patch_rbf(ctx, a, "head_kzx"));
+    if (L.kernel_type == 0) {
+      DCGP_TRY(head_kdiag(ctx, X, rows, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s, L.variance, inv_l2, L.w, kd));
+    } else {
+      DCGP_TRY(additive_kdiag_async(ctx, rows, L.v.P, L.variance, L.w, kd));
+    }
   }
+  if (!(phase & 2)) return DCGP_OK;
   if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
   CondScratch sc;
   DCGP_TRY(cond_core(ctx, L.g, B, ldb, rows, L.white, L.has_qsqrt, pfx.c_str(), &sc, prep_done));

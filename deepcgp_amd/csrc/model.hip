@@ -133,13 +133,60 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   if (!m->d_scal && hipMalloc((void**)&m->d_scal, 64 * sizeof(double)) != hipSuccess)
     return ctx_fail(ctx, DCGP_ERR_ALLOC, "model: allocation failed");
   m->outs.resize(nl);
-  for (auto& l : m->layers) DCGP_TRY(l->prepare(m->jitter));
+  {
+    PrepArgs pa;
+    pa.nl = nl;
+    for (int li = 0; li < nl; ++li) pa.l[li] = m->layers[li]->prep_args(m->jitter);
+    DCGP_TRY(prepare_all(ctx, pa));   // Kuu / prior Kuu / Z^T / padded q_sqrt, q_mu of every layer: one launch
+  }
   const std::string mp = "m" + std::to_string(m->id) + "_";
-  // The replicated M x M stage (batched Cholesky + inverse, then the KL terms) is a serial, few-CU chain: it
-  // runs on the side stream, overlapped with the first layer's K_uf sweep (which only needs Z) and, for the KL
-  // part, with the conditional GEMMs.  ev_factor gates the first GEMM, ev_kl gates the ELBO assembly.
+  const int rows0 = dedup ? N : S * N;   // rows entering layer 0; it reads image (row % N): tile(X,[S,1,1]) is never formed
+
+  // One layer step.  phase 1 = the patch sweep(s) that need only Z, phase 2 = conditional + finalize, 3 = both.
+  auto layer_step = [&](int li, const double* F, int rows, int n_mod, int phase, int* out_rows_p) -> int {
+    LayerState& L = *m->layers[li];
+    const std::string pfx = mp + std::to_string(li) + "_";
+    const double* z = zs ? zs[li] : nullptr;
+    hipEvent_t fdone = (li == 0) ? ctx->ev_factor : nullptr;   // later layers are stream-ordered behind layer 0
+    if (!L.is_head) {
+      const int width = L.v.P * L.R;
+      const bool expand = dedup && li == 0;          // N distinct images -> S*N sampled rows
+      const int out_rows = expand ? S * N : rows;
+      DCGP_TRY(ensure_out(m, li, out_rows, width, true));
+      auto& o = m->outs[li];
+      DCGP_TRY(conv_forward(ctx, L, F, rows, n_mod, expand ? S : 1, (long)N * width, z, seed, (uint32_t)(li + 1 + 64 * ctx->rank),
+                            m->jitter, o.sample, m->keep_outputs ? o.mean : nullptr, m->keep_outputs ? o.var : nullptr, pfx,
+                            fdone, ctx->ev_prep, phase));
+      *out_rows_p = out_rows;
+    } else {
+      DCGP_TRY(ensure_out(m, li, rows, L.R, true));
+      auto& o = m->outs[li];
+      DCGP_TRY(ensure(ctx, &m->d_kd, &m->kd_cap, (size_t)rows));
+      DCGP_TRY(head_forward(ctx, L, F, rows, n_mod, m->d_kd, o.mean, o.var, pfx, fdone, ctx->ev_prep, phase));
+      if ((phase & 2) && m->keep_outputs) {
+        // the head's sample is not needed by the ELBO; produce it only on request
+        size_t n = (size_t)rows * L.R;
+        if (z) {
+          DCGP_TRY(reparam_async(ctx, o.mean, o.var, z, n, m->jitter, o.sample));
+        } else {
+          HIP_TRY(ctx, hipMemcpyAsync(o.sample, o.mean, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+      }
+      *out_rows_p = rows;
+    }
+    return DCGP_OK;
+  };
+
+  // The first layer's patch sweep needs only Z: enqueue it on the main stream BEFORE the long side-stream sequence,
+  // otherwise it sits behind the host still enqueueing the factorisation chain (~200 us of launch calls).
   hipStream_t main_s = ctx->stream;
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_s));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_s));   // the side stream depends on prepare() only, not on the sweep
+  int r_tmp = 0;
+  DCGP_TRY(layer_step(0, X, rows0, N, 1, &r_tmp));
+
+  // The replicated M x M stage (batched Cholesky + inverse, the small operands of the conditional, then the KL
+  // terms) is a serial, few-CU chain: it runs on the side stream, overlapped with that sweep and with the
+  // conditional GEMMs.  ev_factor gates the first GEMM, ev_prep the second, ev_kl the ELBO assembly.
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   static const bool no_side = getenv("DCGP_NO_SIDE_STREAM") != nullptr;   // A/B switch: everything on one stream
   if (!no_side) ctx->stream = ctx->stream2;
@@ -164,44 +211,15 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     hipStreamSynchronize(ctx->stream2);
     return rc;
   }
-  bool factor_waited = false;
   // propagate
   const double* F = X;
-  int rows = dedup ? N : S * N;   // rows entering the current layer
-  int n_mod = N;                  // layer 0 reads image (row % N): tile(X, [S,1,1]) without materialising it
+  int rows = rows0, n_mod = N;
   for (int li = 0; li < nl; ++li) {
-    LayerState& L = *m->layers[li];
-    const std::string pfx = mp + std::to_string(li) + "_";
-    const double* z = zs ? zs[li] : nullptr;
-    if (!L.is_head) {
-      const int width = L.v.P * L.R;
-      const bool expand = dedup && li == 0;          // N distinct images -> S*N sampled rows
-      const int out_rows = expand ? S * N : rows;
-      DCGP_TRY(ensure_out(m, li, out_rows, width, true));
-      auto& o = m->outs[li];
-      DCGP_TRY(conv_forward(ctx, L, F, rows, n_mod, expand ? S : 1, (long)N * width, z, seed, (uint32_t)(li + 1 + 64 * ctx->rank),
-                            m->jitter, o.sample, m->keep_outputs ? o.mean : nullptr, m->keep_outputs ? o.var : nullptr, pfx,
-                            factor_waited ? nullptr : ctx->ev_factor, ctx->ev_prep));
-      factor_waited = true;
-      F = o.sample;
-      rows = out_rows;
-      n_mod = rows;
-    } else {
-      DCGP_TRY(ensure_out(m, li, rows, L.R, true));
-      auto& o = m->outs[li];
-      DCGP_TRY(ensure(ctx, &m->d_kd, &m->kd_cap, (size_t)rows));
-      DCGP_TRY(head_forward(ctx, L, F, rows, n_mod, m->d_kd, o.mean, o.var, pfx, factor_waited ? nullptr : ctx->ev_factor, ctx->ev_prep));
-      factor_waited = true;
-      if (m->keep_outputs) {
-        // the head's sample is not needed by the ELBO; produce it only on request
-        size_t n = (size_t)rows * L.R;
-        if (z) {
-          DCGP_TRY(reparam_async(ctx, o.mean, o.var, z, n, m->jitter, o.sample));
-        } else {
-          HIP_TRY(ctx, hipMemcpyAsync(o.sample, o.mean, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        }
-      }
-    }
+    int out_rows = 0;
+    DCGP_TRY(layer_step(li, F, rows, n_mod, li == 0 ? 2 : 3, &out_rows));
+    if (!m->layers[li]->is_head) F = m->outs[li].sample;
+    rows = out_rows;
+    n_mod = rows;
   }
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_kl, 0));   // join the side stream
   *rows_last = rows;
