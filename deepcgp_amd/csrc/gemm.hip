@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
   if (a.tri == 1) khi = min(a.Mk, i0 + BM);
   if (a.tri == 2) klo = min(i0, a.Mk);
   if (a.b_lower) klo = max(klo, (j0 / BK) * BK);
-  const int wave_i_lo = i0 + wm * WMR, wave_i_hi = wave_i_lo + WMR - 1;
+  static_assert(FM == 1 || FM == 2, "one or two 16-row fragments per wave");
+  auto frag_off = [&](int x) { return (x == 0 ? wm : 2 * WAVES_M - 1 - wm) * 16; };   // row offset of fragment x in the block
 
   d4 acc[FM][FN];
 #pragma unroll
@@ -80,25 +82,41 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
 #pragma unroll
     for (int y = 0; y < FN; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
 
+  // Global fetch through buffer descriptors: the operand slab of this workgroup is a raw buffer (4 SGPRs), the
+  // k-tile advance is the scalar offset, and each thread keeps ONE constant 32-bit byte offset per chunk.  No
+  // 64-bit pointer lives in VGPRs across the loops (the kernel is held under a 64-VGPR cap to keep 8 waves per
+  // SIMD), and chunks outside the matrix (rows of C beyond Mi, columns beyond Kc) carry an out-of-range offset,
+  // which the hardware bounds check turns into zeros.
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr unsigned OOB = 0x80000000u;   // >= any slab size (the host refuses slabs of 2 GiB and more)
+  const int nkt = max(khi - klo, 0);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<double*>(Wt + (long)klo * a.ldw), 0, (int)((long)nkt * a.ldw * 8), 0x00020000);
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<double*>(Bm + (long)klo * a.ldb), 0, (int)((long)nkt * a.ldb * 8), 0x00020000);
   double2 rw[NLW], rbv[NLB];
-  auto load_tile = [&](int k0) {
+  unsigned woff[NLW], boff[NLB];
+#pragma unroll
+  for (int c = 0; c < NLW; ++c) {
+    const int ch = tid + c * NT, row = ch / (BM / 2), col = (ch % (BM / 2)) * 2;
+    woff[c] = (ch < W_CHUNKS && i0 + col < a.Mi) ? (unsigned)(row * a.ldw + i0 + col) * 8u : OOB;
+  }
+#pragma unroll
+  for (int c = 0; c < NLB; ++c) {
+    const int ch = tid + c * NT, row = ch / (BN / 2), col = (ch % (BN / 2)) * 2;
+    boff[c] = (j0 + col < a.Kc) ? (unsigned)(row * a.ldb + j0 + col) * 8u : OOB;
+  }
+  auto load_tile = [&](int k0) {   // Mk is a multiple of BK (callers pad), so every k row of a tile exists
+    const int sw = (k0 - klo) * a.ldw * 8, sb = (k0 - klo) * a.ldb * 8;
 #pragma unroll
     for (int c = 0; c < NLW; ++c) {
-      int ch = tid + c * NT;
-      rw[c] = double2{0.0, 0.0};
-      if (ch < W_CHUNKS) {
-        int row = ch / (BM / 2), col = (ch % (BM / 2)) * 2;
-        int k = k0 + row, i = i0 + col;
-        if (k < a.Mk && i < a.Mi) rw[c] = *reinterpret_cast<const double2*>(Wt + (long)k * a.ldw + i);
-      }
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)woff[c], sw, 0);
+      __builtin_memcpy(&rw[c], &v, 16);
     }
 #pragma unroll
     for (int c = 0; c < NLB; ++c) {
-      int ch = tid + c * NT;
-      int row = ch / (BN / 2), col = (ch % (BN / 2)) * 2;
-      int k = k0 + row, j = j0 + col;
-      rbv[c] = double2{0.0, 0.0};
-      if (k < a.Mk && j < a.Kc) rbv[c] = *reinterpret_cast<const double2*>(Bm + (long)k * a.ldb + j);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(brs, (int)boff[c], sb, 0);
+      __builtin_memcpy(&rbv[c], &v, 16);
     }
   };
   auto store_tile = [&](int buf) {
@@ -120,40 +138,69 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
     }
   };
 
+  // ---- k loop, split into phases by which of this wave's fragments are structurally non-zero ------------------
+  // A wave owns FM <= 2 fragments of 16 rows: fragment 0 = rows (wm) * 16, fragment 1 = rows (2 WAVES_M - 1 - wm) * 16
+  // of the row block -- an early and a late one, so that inside a DIAGONAL block of a triangular product every wave
+  // has the same number of fragment-steps (9 of 16 at BM = 128) and all waves of a workgroup finish together; with
+  // contiguous 32-row wave tiles they finish 4 : 3 : 2 : 1 and the workgroup holds its LDS and wave slots until the
+  // last one is done.  The skip is per fragment and, k being monotone, a sequence of at most five loops
+  // (none | frag 0 | both | frag 1 | none) with wave-uniform bounds -- no branch inside a loop body.
+  int buf = 0;
+  auto steps = [&](int kb, int ke, auto x0c, auto x1c) {
+    constexpr int X0 = decltype(x0c)::value, X1 = decltype(x1c)::value;
+    for (int k0 = kb; k0 < ke; k0 += BK) {
+      const bool has_next = k0 + BK < khi;
+      if (has_next && !(ABL & 1)) load_tile(k0 + BK);
+      if (X0 < X1) {
+        const double* w = Ws + buf * BK * LDW + lcol;
+        const double* b = Bs + buf * BK * LDB + wn * WNC + lcol;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+          double av[FM], bv[FN];
+#pragma unroll
+          for (int x = X0; x < X1; ++x) av[x] = (ABL & 8) ? (double)(kk + x) : w[(kk + lrow) * LDW + frag_off(x)];
+#pragma unroll
+          for (int y = 0; y < FN; ++y) bv[y] = (ABL & 8) ? (double)(lane + y) : b[(kk + lrow) * LDB + y * 16];
+#pragma unroll
+          for (int x = X0; x < X1; ++x)
+#pragma unroll
+            for (int y = 0; y < FN; ++y)
+              acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
+        }
+      }
+      if (has_next && !(ABL & 2)) store_tile(buf ^ 1);
+      if (!(ABL & 4)) __syncthreads();
+      buf ^= 1;
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using IF = std::integral_constant<int, FM>;
+  // phase bounds: none [klo,b0) | frag 0 [b0,b1) | all [b1,b2) | frag FM-1 [b2,b3) | none [b3,khi)
+  int b0 = klo, b1 = klo, b2 = khi, b3 = khi;
+  const int r_first = i0 + frag_off(0), r_last = i0 + frag_off(FM - 1);
+  if (a.tri == 2) {   // fragment live from k0 >= its first row on
+    b0 = min(max(r_first, klo), khi);
+    b1 = min(max(r_last, klo), khi);
+  }
+  if (a.tri == 1) {   // fragment live while k0 <= its last row
+    b2 = max(min(r_first + 16, khi), klo);
+    b3 = max(min(r_last + 16, khi), klo);
+  }
+  b0 = __builtin_amdgcn_readfirstlane(b0);   // wave-uniform by construction: keep the loop control scalar
+  b1 = __builtin_amdgcn_readfirstlane(b1);
+  b2 = __builtin_amdgcn_readfirstlane(b2);
+  b3 = __builtin_amdgcn_readfirstlane(b3);
   if (klo < khi) {
     load_tile(klo);
     store_tile(0);
   }
   __syncthreads();
-  int buf = 0;
-  for (int k0 = klo; k0 < khi; k0 += BK) {
-    const bool has_next = k0 + BK < khi;
-    if (has_next && !(ABL & 1)) load_tile(k0 + BK);
-    // per-wave structural-zero skip inside the diagonal region
-    bool need = true;
-    if (a.tri == 1 && k0 > wave_i_hi) need = false;
-    if (a.tri == 2 && k0 + BK - 1 < wave_i_lo) need = false;
-    if (need) {
-      const double* w = Ws + buf * BK * LDW + wm * WMR + lcol;
-      const double* b = Bs + buf * BK * LDB + wn * WNC + lcol;
-#pragma unroll
-      for (int kk = 0; kk < BK; kk += 4) {
-        double av[FM], bv[FN];
-#pragma unroll
-        for (int x = 0; x < FM; ++x) av[x] = (ABL & 8) ? (double)(kk + x) : w[(kk + lrow) * LDW + x * 16];
-#pragma unroll
-        for (int y = 0; y < FN; ++y) bv[y] = (ABL & 8) ? (double)(lane + y) : b[(kk + lrow) * LDB + y * 16];
-#pragma unroll
-        for (int x = 0; x < FM; ++x)
-#pragma unroll
-          for (int y = 0; y < FN; ++y)
-            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
-      }
-    }
-    if (has_next && !(ABL & 2)) store_tile(buf ^ 1);
-    if (!(ABL & 4)) __syncthreads();
-    buf ^= 1;
-  }
+  steps(klo, b0, I0{}, I0{});
+  if (FM == 2) steps(b0, b1, I0{}, I1{});
+  steps(b1, b2, I0{}, IF{});
+  if (FM == 2) steps(b2, b3, I1{}, IF{});
+  steps(b3, khi, I0{}, I0{});
 
   // ---- epilogue ----------------------------------------------------------------------------
   const int bzl = iw * a.nB + ib;
@@ -166,7 +213,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
         int j = j0 + wn * WNC + y * 16 + lcol;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          int i = wave_i_lo + x * 16 + lrow + 4 * v;
+          int i = i0 + frag_off(x) + lrow + 4 * v;
           if (i < a.Mi && j < a.Kc) C[(long)i * a.ldc + j] = acc[x][y][v];
         }
       }
@@ -240,6 +287,9 @@ int gemm_tn(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
   // one column of (ignored) padding behind it
   if ((a.ldw & 1) || (a.ldb & 1) || (a.Mi & 1) || ((a.Kc & 1) && a.ldb <= a.Kc))
     return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_tn: leading dimensions / extents must be even");
+  // k-tiles are fetched whole through 32-bit-offset buffer descriptors
+  if ((a.Mk % BK) || (long)a.Mk * a.ldw * 8 >= (1L << 31) || (long)a.Mk * a.ldb * 8 >= (1L << 31))
+    return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_tn: Mk must be a multiple of 16 and an operand slab (Mk x ld) under 2 GiB");
   switch (gemm_row_block(a.Mi, a.Kc, a.nW * a.nB)) {
     case 128:
       switch (gemm_variant()) {
