@@ -95,10 +95,8 @@ struct GemmArgs {
   int nW = 1, nB = 1;          // batch = nW * nB, bz -> (iw = bz / nB, ib = bz % nB)
   int tri = 0;                 // 0 dense, 1: W lower (k <= i), 2: W upper (k >= i)
   int b_lower = 0;             // B[k][j] == 0 for k < j (skip those k tiles)
-  int rchunk = 0;              // gemm_chain only: batch entries walked by one workgroup
 };
 int gemm_tn(dcgp_ctx* ctx, const GemmArgs& a, int* n_row_blocks_out);
-int gemm_chain(dcgp_ctx* ctx, const GemmArgs& a, int* n_row_blocks_out);   // gemm_chain.hip (nB == 1, colsq only, BM = 128)
 int gemm_row_block(int Mi, int Kc, int batch);   // BM the dispatcher picks (callers size partial-sum buffers with it)
 
 // patch-RBF sweep (kuf / head Kzx)

@@ -308,13 +308,7 @@ int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc,
     a.B = sc.A1; a.ldb = (int)ldb;
     a.colsq = sc.s2p; a.sBatch = (long)nrb3 * ldb; a.sRowBlk = ldb;
     a.Mi = Mp; a.Mk = Mp; a.Kc = Kc; a.tri = 2;
-    static const int rchunk_env = getenv("DCGP_RCHUNK") ? atoi(getenv("DCGP_RCHUNK")) : 0;
-    if (BM3 == 128 && rchunk_env > 0) {
-      a.rchunk = rchunk_env;
-      DCGP_TRY(gemm_chain(ctx, a, nullptr));
-    } else {
-      DCGP_TRY(gemm_tn(ctx, a, nullptr));
-    }
+    DCGP_TRY(gemm_tn(ctx, a, nullptr));
   }
   {
     // mu[r][j] = sum_k alpha[k][r] A1[k][j]  (conditionals.py:50): a 16-row dense product on the same kernel

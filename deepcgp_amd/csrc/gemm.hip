@@ -58,6 +58,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
   const int bz = rem / n_row_blocks;
   int rb = rem % n_row_blocks;
   if (a.tri == 1) rb = n_row_blocks - 1 - rb;
+  // Row blocks of a triangular product carry graded work.  Workgroups are handed to shader engines / CUs round-robin
+  // in id order, so a FIXED heavy,light,heavy,light... sequence parks all heavy blocks on the same engines and the
+  // launch lasts as long as a heavy-only queue (measured in MFMA-only mode: 19.6 us lost per workgroup turn vs 7.7 us
+  // with equal blocks).  Rotating the row-block order by the bit parity of the global (column tile, batch) index
+  // (Thue-Morse) is balanced over every power-of-two stride.
+  if (a.tri) rb = (rb + __popc(ct * batch + bz)) % n_row_blocks;
   const int iw = bz / a.nB, ib = bz % a.nB;
 
   const int i0 = rb * BM, j0 = ct * BN;
@@ -297,6 +303,10 @@ int gemm_tn(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
         case 7: return launch<128, 128, 4, 2, 7>(ctx, a, nrb_out);
         case 15: return launch<128, 128, 4, 2, 15>(ctx, a, nrb_out);
         case 100: return launch<128, 128, 4, 2>(ctx, a, nrb_out);
+        case 101: return launch<128, 128, 4, 4, 1>(ctx, a, nrb_out);
+        case 104: return launch<128, 128, 4, 4, 4>(ctx, a, nrb_out);
+        case 107: return launch<128, 128, 4, 4, 7>(ctx, a, nrb_out);
+        case 115: return launch<128, 128, 4, 4, 15>(ctx, a, nrb_out);
         default: return launch<128, 128, 4, 4>(ctx, a, nrb_out);   // 16 waves: +6% over 8 waves (more MFMA-phase waves per SIMD)
       }
     // short tiles = small problems whose run time is one workgroup's serial k-chain: spread each tile over 16
