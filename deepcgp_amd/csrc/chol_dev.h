@@ -85,6 +85,31 @@ __device__ __forceinline__ int wave_potrf32(double (&a)[NB], int r, double (&col
   }
   return fail;
 }
+// Cholesky AND inverse of the factor in the same 32 steps, on one full wavefront.  Lanes 0..31 hold the rows of the
+// block as in wave_potrf32; lane 32 + c holds column c of the inverse, started as the unit vector e_c.  Step c of
+// the right-looking forward substitution  x[c] /= L[c][c];  x[cc] -= L[cc][c] x[c]  uses exactly the scale (1/L[c][c])
+// and the multipliers L[cc][c] the factorisation step has just put in registers, and is the same instruction stream
+// as the row update  a[cc] -= a[c] L[cc][c]  -- so the upper half of the wavefront, idle otherwise, delivers inv(L_jj)
+// with no additional instruction, LDS access or latency.  `col` is a 64-entry LDS line (upper half is a write sink).
+__device__ __forceinline__ int wave_potrf_inv32(double (&v)[NB], int lane, double (&col)[2 * NB]) {
+  int fail = 0;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    const double piv = bcast_lane(v[c], c);
+    if (!(piv > 0.0) && fail == 0) fail = c + 1;
+    const double y = rsqrt_nr(piv);
+    double d = piv * y;
+    d = fma(0.5 * y, fma(-d, d, piv), d);       // sqrt(piv) to ~1 ulp
+    v[c] = (lane == c) ? d : v[c] * y;
+    col[lane] = v[c];
+    double m[NB];
+#pragma unroll
+    for (int cc = c + 1; cc < NB; ++cc) m[cc] = col[cc];
+#pragma unroll
+    for (int cc = c + 1; cc < NB; ++cc) v[cc] = fma(-v[c], m[cc], v[cc]);
+  }
+  return fail;
+}
 // Column c of inv(L) for a 32x32 lower-triangular L held in LDS (D) with its reciprocal diagonal (Dr):
 // forward substitution, the row of L being read as broadcast loads once per step.
 __device__ __forceinline__ void lane_trtri32(const double (*D)[NB + 1], const double* Dr, int c, double (&x)[NB]) {

@@ -18,6 +18,16 @@
 
 using namespace chol_dev;
 
+// phase timestamps for tools/chol_trace.hip (compiled out of the library)
+#ifdef CHOL_TRACE
+__device__ long long g_chol_trace[64 * 32];
+#define TR(k)                                                                                              \
+  if (tid == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                    \
+    g_chol_trace[(a.j / NB) * 32 + (blockIdx.x == 0 ? 0 : 16) + (k)] = wall_clock64();
+#else
+#define TR(k)
+#endif
+
 namespace {
 
 struct RlArgs {
@@ -45,41 +55,55 @@ __device__ __forceinline__ void load_panel_rows(const double* __restrict__ A, in
     U[i][c] = (r0 + i < Mp && c < nb) ? A[(long)(r0 + i) * ld + j + c] : 0.0;
   }
 }
-// U[row] <- U[row] L_jj^-T  (right-looking forward substitution, one row per thread, 64 rows)
-__device__ __forceinline__ void trsm_rows(double (*U)[NB + 1], const double (*D)[NB + 1], const double* Dr, int row) {
-  double x[NB];
+// P = U inv(L_jj)^T on the matrix cores (64 x 32 x 32): P[i][c] = sum_q U[i][q] X[c][q].  Wave (wm, wn) owns rows
+// wm*32 .. +31 and columns wn*16 .. +15; the result goes back over U after a barrier (both waves of a row block read
+// all of its columns).
+__device__ __forceinline__ void panel_solve_mfma(double (*U)[NB + 1], const double (*X)[NB + 1], int wm, int wn, int lrow,
+                                                 int lcol, d4 (&p)[2]) {
+  p[0] = d4{0.0, 0.0, 0.0, 0.0};
+  p[1] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int c = 0; c < NB; ++c) x[c] = U[row][c];
+  for (int kk = 0; kk < NB; kk += 4) {
+    const double bv = X[wn * 16 + lcol][kk + lrow];
 #pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    x[c] = x[c] * Dr[c];
-#pragma unroll
-    for (int q = c + 1; q < NB; ++q) x[q] = fma(-x[c], D[q][c], x[q]);
+    for (int x = 0; x < 2; ++x) p[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(U[wm * 32 + x * 16 + lcol][kk + lrow], bv, p[x], 0, 0, 0);
   }
+}
+__device__ __forceinline__ void panel_store(double (*U)[NB + 1], int wm, int wn, int lrow, int lcol, const d4 (&p)[2]) {
 #pragma unroll
-  for (int c = 0; c < NB; ++c) U[row][c] = x[c];
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) U[wm * 32 + x * 16 + lrow + 4 * v][wn * 16 + lcol] = p[x][v];
 }
 
-__global__ __launch_bounds__(256, 4) void chol_rl_kernel(RlArgs a) {
+__global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   __shared__ double D[NB][NB + 1];
-  __shared__ double Dr[NB];
-  __shared__ double col[NB];
+  __shared__ double col[2 * NB];
   __shared__ double Ui[64][NB + 1];
   __shared__ double Uc[64][NB + 1];
   __shared__ double Xs[NB][NB + 1];   // inv(L_jj)
-  __shared__ double Ts[NB][64 + 1];   // Ynew tile
+  __shared__ double Ts[NB][64 + 1];   // Y tile: old, then new
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, lrow = lane >> 4, lcol = lane & 15;
   const int Mp = a.Mp, ld = a.ld, j = a.j, nb = min(NB, Mp - j);
   double* __restrict__ A = a.A[b];
   double* __restrict__ Lout = a.Lout + (long)b * Mp * ld;
+  double* __restrict__ Y = a.Y ? a.Y + (long)b * Mp * ld : nullptr;
   const int below0 = j + NB;   // first row below the panel block
 
-  // ---- shared prologue: L_jj ----
+  // ---- prologue: every global read of this workgroup is issued here, in one latency ----
+  TR(0)
   load_diag(A, ld, j, nb, D, tid);
   const bool only_diag = a.nT == 0 && a.nct == 0;
   const bool is_trailing = (int)blockIdx.x < a.nT;
   int ti = 0, tc = 0, rt = -1, ct = 0;
+  double old[2][2][4];   // values the final read-modify-write subtracts from
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) old[x][y][v] = 0.0;
   if (only_diag) {
   } else if (is_trailing) {
     int pair = blockIdx.x;
@@ -90,30 +114,62 @@ __global__ __launch_bounds__(256, 4) void chol_rl_kernel(RlArgs a) {
     ti = tc + pair;
     load_panel_rows(A, ld, Mp, j, nb, below0 + ti * 64, Ui, tid);
     if (tc != ti) load_panel_rows(A, ld, Mp, j, nb, below0 + tc * 64, Uc, tid);
+    const int ri0 = below0 + ti * 64, rc0 = below0 + tc * 64;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int i = ri0 + wm * 32 + x * 16 + lrow + 4 * v, jj = rc0 + wn * 32 + y * 16 + lcol;
+          if (i < Mp && jj < Mp && jj <= i) old[x][y][v] = A[(long)i * ld + jj];
+        }
   } else {
-    const int y = blockIdx.x - a.nT;
-    rt = y / a.nct - 1;   // -1: the panel's own row block, else row tile below
-    ct = y % a.nct;
-    if (rt >= 0) load_panel_rows(A, ld, Mp, j, nb, below0 + rt * 64, Ui, tid);
+    const int yy = blockIdx.x - a.nT;
+    rt = yy / a.nct - 1;   // -1: the panel's own row block, else row tile below
+    ct = yy % a.nct;
+    const int c0 = ct * 64;
+    if (rt >= 0) {
+      load_panel_rows(A, ld, Mp, j, nb, below0 + rt * 64, Ui, tid);
+      const int r0 = below0 + rt * 64;
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int i = r0 + wm * 32 + x * 16 + lrow + 4 * v, gc = c0 + wn * 32 + y * 16 + lcol;
+            if (i < Mp && gc < j) old[x][y][v] = Y[(long)i * ld + gc];   // identity part is zero below the diagonal
+          }
+    }
+    // Y[j + q, c0 + c] before this step: stored values left of column j, identity inside [j, j+32), zero beyond
+    for (int idx = tid; idx < NB * 64; idx += 256) {
+      const int q = idx >> 6, c = idx & 63, gc = c0 + c;
+      double v = 0.0;
+      if (q < nb && gc < j) v = Y[(long)(j + q) * ld + gc];
+      else if (gc == j + q) v = 1.0;
+      Ts[q][c] = v;
+    }
   }
   __syncthreads();
+  TR(1)
+  // ---- L_jj and inv(L_jj): one wavefront ----
   if (tid < 64) {
-    const int r = tid & 31;
-    double av[NB];
+    double v[NB];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) av[c] = D[r][c];
-    const int fail = wave_potrf32(av, r, col);
-    if (tid < 32) {
+    for (int c = 0; c < NB; ++c) v[c] = (tid < NB) ? D[tid][c] : ((c == tid - NB) ? 1.0 : 0.0);
+    const int fail = wave_potrf_inv32(v, tid, col);
+    if (tid < NB) {
 #pragma unroll
-      for (int c = 0; c < NB; ++c) D[r][c] = (c <= r) ? av[c] : 0.0;
-      double diag = av[0];
+      for (int c = 0; c < NB; ++c) D[tid][c] = (c <= tid) ? v[c] : 0.0;
+    } else {
 #pragma unroll
-      for (int c = 1; c < NB; ++c) diag = (c == r) ? av[c] : diag;
-      Dr[r] = 1.0 / diag;
+      for (int r = 0; r < NB; ++r) Xs[r][tid - NB] = v[r];
     }
     if (tid == 0 && fail && blockIdx.x == 0 && a.info[b] == 0) a.info[b] = j + fail;
   }
   __syncthreads();
+  TR(2)
   if (blockIdx.x == 0) {   // publish L_jj (final)
     for (int idx = tid; idx < nb * nb; idx += 256) {
       const int r = idx / nb, c = idx % nb;
@@ -129,10 +185,15 @@ __global__ __launch_bounds__(256, 4) void chol_rl_kernel(RlArgs a) {
     for (int y = 0; y < 2; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
 
   if (is_trailing) {
-    // ---- trailing tile (ti, tc): A[ri, rc] -= L[ri,j] L[rc,j]^T ----
-    if (tid < 64) trsm_rows(Ui, D, Dr, tid);
-    else if (tid < 128 && tc != ti) trsm_rows(Uc, D, Dr, tid - 64);
+    // ---- trailing tile (ti, tc): panel rows L[r,j] = A[r,j] inv(L_jj)^T, then A[ri, rc] -= L[ri,j] L[rc,j]^T ----
+    d4 pi[2], pc[2];
+    panel_solve_mfma(Ui, Xs, wm, wn, lrow, lcol, pi);
+    if (tc != ti) panel_solve_mfma(Uc, Xs, wm, wn, lrow, lcol, pc);
     __syncthreads();
+    panel_store(Ui, wm, wn, lrow, lcol, pi);
+    if (tc != ti) panel_store(Uc, wm, wn, lrow, lcol, pc);
+    __syncthreads();
+    TR(3)
     const int ri0 = below0 + ti * 64, rc0 = below0 + tc * 64;
     double (*Ub)[NB + 1] = (tc == ti) ? Ui : Uc;
     if (tc == ti) {   // the diagonal tiles publish the panel rows of L (final)
@@ -160,47 +221,33 @@ __global__ __launch_bounds__(256, 4) void chol_rl_kernel(RlArgs a) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int i = ri0 + wm * 32 + x * 16 + lrow + 4 * v, jj = rc0 + wn * 32 + y * 16 + lcol;
-          if (i < Mp && jj < Mp && jj <= i) A[(long)i * ld + jj] -= acc[x][y][v];
+          if (i < Mp && jj < Mp && jj <= i) A[(long)i * ld + jj] = old[x][y][v] - acc[x][y][v];
         }
+    TR(4)
     return;
   }
 
   // ---- inverse tile (rt, ct): columns [c0, c0+64) of the running inverse ----
-  double* __restrict__ Y = a.Y + (long)b * Mp * ld;
   double* __restrict__ Linv = a.Linv[b];
   const int c0 = ct * 64;
-  if (tid < NB) {
-    double x[NB];
-    lane_trtri32(D, Dr, tid, x);
+  // Ynew = inv(L_jj) * Yold  (32 x 32 times 32 x 64) on the matrix cores: wave w owns columns w*16 .. +15
+  d4 yn[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
-    for (int r = 0; r < NB; ++r) Xs[r][tid] = x[r];
-  }
-  // Y[j + q, c0 + c] before this step: stored values left of column j, identity inside [j, j+32), zero beyond
-  for (int idx = tid; idx < NB * 64; idx += 256) {
-    const int q = idx >> 6, c = idx & 63, gc = c0 + c;
-    double v = 0.0;
-    if (q < nb && gc < j) v = Y[(long)(j + q) * ld + gc];
-    else if (gc == j + q) v = 1.0;
-    Ts[q][c] = v;
-  }
-  if (rt >= 0 && tid >= 64 && tid < 128) trsm_rows(Ui, D, Dr, tid - 64);
-  __syncthreads();
-  // Ynew = inv(L_jj) * Yold  (lower-triangular 32x32 times 32x64), each thread 8 outputs, kept in registers
-  double yn[8];
+  for (int kk = 0; kk < NB; kk += 4) {
+    const double bv = Ts[kk + lrow][wave * 16 + lcol];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int idx = tid + e * 256, r = idx >> 6, c = idx & 63;
-    double s = 0.0;
-    for (int q = 0; q <= r; ++q) s = fma(Xs[r][q], Ts[q][c], s);
-    yn[e] = s;
+    for (int x = 0; x < 2; ++x) yn[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[x * 16 + lcol][kk + lrow], bv, yn[x], 0, 0, 0);
   }
+  d4 pi[2];
+  if (rt >= 0) panel_solve_mfma(Ui, Xs, wm, wn, lrow, lcol, pi);
   __syncthreads();
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int idx = tid + e * 256, r = idx >> 6, c = idx & 63;
-    Ts[r][c] = yn[e];
-  }
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Ts[x * 16 + lrow + 4 * v][wave * 16 + lcol] = yn[x][v];
+  if (rt >= 0) panel_store(Ui, wm, wn, lrow, lcol, pi);
   __syncthreads();
+  TR(4)
   if (rt < 0) {
     // final rows j .. j+31 of inv(L)
     for (int idx = tid; idx < NB * 64; idx += 256) {
@@ -230,11 +277,9 @@ __global__ __launch_bounds__(256, 4) void chol_rl_kernel(RlArgs a) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int i = r0 + wm * 32 + x * 16 + lrow + 4 * v, gc = c0 + wn * 32 + y * 16 + lcol;
-        if (i < Mp && gc < j + nb) {
-          const double old = (gc < j) ? Y[(long)i * ld + gc] : 0.0;   // identity part is zero below the diagonal
-          Y[(long)i * ld + gc] = old - acc[x][y][v];
-        }
+        if (i < Mp && gc < j + nb) Y[(long)i * ld + gc] = old[x][y][v] - acc[x][y][v];
       }
+  TR(5)
 }
 
 // final factor back over A (lower triangle from Lout, strict upper triangle zero).  grid (Mp, batch)
