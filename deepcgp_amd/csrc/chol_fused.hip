@@ -10,7 +10,7 @@
 //     inverse tile    : with Y the running product of block Gauss transforms applied to I (inv(L) row blocks
 //                       < j are final):  Ynew = inv(L_jj) Y[j,cols]  ->  final rows of inv(L);
 //                       Y[rows,cols] -= L[rows,j] Ynew for the rows below (matrix cores, k = 32)
-// so every launch has constant depth (k = 32) and the chain is M/32 launches + 2 (finish, transpose) for both
+// so every launch has constant depth (k = 32) and the chain is M/32 launches + 1 (finish) for both
 // tf.cholesky (conv_gp/conditionals.py:29, layers.py:151,156) and the inverse the triangular solves
 // (conditionals.py:31-33,44-47) are applied with.  Final values go to separate buffers (other workgroups of the
 // same launch still read the working copies).  All matrices of a model are batched in grid.y.
@@ -34,7 +34,8 @@ struct RlArgs {
   double* const* A;      // working matrices (destroyed): trailing part updated in place
   double* Lout;          // [batch][Mp][ld] final factor (lower), then copied back over A by the finish kernel
   double* Y;             // [batch][Mp][ld] running inverse (scratch) or nullptr
-  double* const* Linv;   // final inv(L) (must be zero-filled before the first panel) or nullptr
+  double* const* Linv;   // final inv(L) or nullptr; every element is written by the chain (zeros included)
+  double* const* LinvT;  // its transpose, written in the same pass, or nullptr
   int Mp, ld, j, nt, nT, nct;
   int* info;
 };
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
 #pragma unroll
       for (int r = 0; r < NB; ++r) Xs[r][tid - NB] = v[r];
     }
-    if (tid == 0 && fail && blockIdx.x == 0 && a.info[b] == 0) a.info[b] = j + fail;
+    if (tid == 0 && blockIdx.x == 0 && (j == 0 || (fail && a.info[b] == 0))) a.info[b] = fail ? j + fail : 0;
   }
   __syncthreads();
   TR(2)
@@ -249,11 +250,22 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   __syncthreads();
   TR(4)
   if (rt < 0) {
-    // final rows j .. j+31 of inv(L)
-    for (int idx = tid; idx < NB * 64; idx += 256) {
-      const int r = idx >> 6, c = idx & 63, gc = c0 + c;
-      if (r < nb && gc < j + nb) Linv[(long)(j + r) * ld + gc] = Ts[r][c];
-    }
+    // final rows j .. j+31 of inv(L) -- and the same block of the transpose; the structural zeros to the right of the
+    // diagonal block are written too (the last column tile also covers everything beyond the tiles), so neither
+    // output needs clearing beforehand
+    double* __restrict__ LinvT = a.LinvT ? a.LinvT[b] : nullptr;
+    const int cend = (ct == a.nct - 1) ? Mp : c0 + 64;
+    for (int cb = c0; cb < cend; cb += 64)
+      for (int idx = tid; idx < NB * 64; idx += 256) {
+        const int r = idx >> 6, c = idx & 63, gc = cb + c;
+        if (r < nb && gc < Mp) Linv[(long)(j + r) * ld + gc] = (cb == c0 && gc < j + nb) ? Ts[r][c] : 0.0;
+      }
+    if (LinvT)
+      for (int cb = c0; cb < cend; cb += 64)
+        for (int idx = tid; idx < NB * 64; idx += 256) {
+          const int r = idx & 31, c = idx >> 5, gc = cb + c;   // r fastest: rows of the transpose are contiguous in r
+          if (r < nb && gc < Mp) LinvT[(long)gc * ld + j + r] = (cb == c0 && gc < j + nb) ? Ts[r][c] : 0.0;
+        }
     return;
   }
   // rows below: Y[rows, cols] -= L[rows,j] Ynew
@@ -290,28 +302,6 @@ __global__ void chol_finish_kernel(double* const* __restrict__ Ap, const double*
   for (int c = threadIdx.x; c < Mp; c += blockDim.x) A[(long)i * ld + c] = (c <= i) ? L[(long)i * ld + c] : 0.0;
 }
 
-// D = S^T and (zero_upper) S's strict upper triangle cleared in the same pass.  grid (Mp/32, Mp/32, batch)
-__global__ void transpose_b_kernel(double* const* __restrict__ Sp, double* const* __restrict__ Dp, int Mp, int ld) {
-  __shared__ double t[32][33];
-  const double* __restrict__ S = Sp[blockIdx.z];
-  double* __restrict__ D = Dp[blockIdx.z];
-  int bx = blockIdx.x * 32, by = blockIdx.y * 32;
-  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
-    int i = by + r, jj = bx + threadIdx.x;
-    t[r][threadIdx.x] = (i < Mp && jj < Mp) ? S[(long)i * ld + jj] : 0.0;
-  }
-  __syncthreads();
-  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
-    int i = bx + r, jj = by + threadIdx.x;
-    if (i < Mp && jj < Mp) D[(long)i * ld + jj] = t[threadIdx.x][r];
-  }
-}
-
-__global__ void zero_rows_kernel(double* const* __restrict__ Xp, int Mp, int ld) {
-  double* __restrict__ X = Xp[blockIdx.y];
-  for (int c = threadIdx.x; c < ld; c += blockDim.x) X[(long)blockIdx.x * ld + c] = 0.0;
-}
-
 }  // namespace
 
 // Cholesky factor in place (strict upper triangle zeroed) and, when d_Linv != nullptr, inv(L) (+ its transpose).
@@ -323,14 +313,9 @@ int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_L
   double* Lout = (double*)ws_get(ctx, "chol_Lout", (size_t)batch * mm * sizeof(double));
   double* Y = d_Linv ? (double*)ws_get(ctx, "chol_Y", (size_t)batch * mm * sizeof(double)) : nullptr;
   if (!Lout || (d_Linv && !Y)) return DCGP_ERR_ALLOC;
-  HIP_TRY(ctx, hipMemsetAsync(d_info, 0, sizeof(int) * batch, ctx->stream));
-  if (d_Linv) {
-    hipLaunchKernelGGL(zero_rows_kernel, dim3(Mp, batch), dim3(128), 0, ctx->stream, d_Linv, Mp, ld);
-    LAUNCH_CHECK(ctx);
-  }
   for (int j = 0; j < Mp; j += NB) {
     RlArgs a;
-    a.A = d_A; a.Lout = Lout; a.Y = Y; a.Linv = d_Linv; a.Mp = Mp; a.ld = ld; a.j = j; a.info = d_info;
+    a.A = d_A; a.Lout = Lout; a.Y = Y; a.Linv = d_Linv; a.LinvT = d_Linv ? d_LinvT : nullptr; a.Mp = Mp; a.ld = ld; a.j = j; a.info = d_info;
     const int below = Mp - (j + NB);
     a.nt = below > 0 ? (below + 63) / 64 : 0;
     a.nT = a.nt * (a.nt + 1) / 2;
@@ -343,10 +328,5 @@ int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_L
   }
   hipLaunchKernelGGL(chol_finish_kernel, dim3(Mp, batch), dim3(128), 0, ctx->stream, d_A, (const double*)Lout, Mp, ld);
   LAUNCH_CHECK(ctx);
-  if (d_Linv && d_LinvT) {
-    dim3 grid((Mp + 31) / 32, (Mp + 31) / 32, batch);
-    hipLaunchKernelGGL(transpose_b_kernel, grid, dim3(32, 8), 0, ctx->stream, d_Linv, d_LinvT, Mp, ld);
-    LAUNCH_CHECK(ctx);
-  }
   return DCGP_OK;
 }
