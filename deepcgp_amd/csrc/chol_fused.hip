@@ -81,9 +81,11 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   __shared__ double D[NB][NB + 1];
   __shared__ double col[2 * NB];
   __shared__ double Ui[64][NB + 1];
-  __shared__ double Uc[64][NB + 1];
+  __shared__ double UcTs[64 * (NB + 1)];   // trailing tiles: second panel row block; inverse tiles: the Y tile
   __shared__ double Xs[NB][NB + 1];   // inv(L_jj)
-  __shared__ double Ts[NB][64 + 1];   // Y tile: old, then new
+  double (*Uc)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(UcTs);
+  double (*Ts)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(UcTs);   // [NB][65]: old Y rows, then new
+  static_assert(NB * 65 <= 64 * (NB + 1), "Y tile fits the shared slot");
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, lrow = lane >> 4, lcol = lane & 15;
   const int Mp = a.Mp, ld = a.ld, j = a.j, nb = min(NB, Mp - j);

@@ -112,6 +112,8 @@ struct PatchRbfArgs {
   double* out = nullptr; long sM = 0, sN = 0, sP = 0;
   // reduce mode (head Kzx): out[m*sM + n*sN] = scale * sum_p w[p] k
   const double* w = nullptr; double scale = 1; int reduce = 0;
+  // the sweep runs beside the latency-bound side-stream chain: hold it to two workgroups per CU (see patch_rbf)
+  int share_cu = 0;
 };
 int patch_rbf(dcgp_ctx* ctx, const PatchRbfArgs& a, const char* timer_name);
 int head_kdiag(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, int C, int f, int s, double variance,

@@ -83,6 +83,14 @@ int dcgp_device_count(int* count) {
   return DCGP_OK;
 }
 
+// The side stream carries the latency-bound M x M chain (factorisation, conditional prep, KL) while the main stream
+// streams the patch sweep: highest priority, so its few short workgroups are placed ahead of the sweep's backlog.
+static hipError_t side_stream_create(hipStream_t* s) {
+  int lo = 0, hi = 0;
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+}
+
 int dcgp_ctx_create(int device, dcgp_ctx** out) {
   if (!out) return DCGP_ERR_ARG;
   *out = nullptr;
@@ -92,7 +100,7 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
   dcgp_ctx* c = new dcgp_ctx();
   c->device = device;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+      side_stream_create(&c->stream2) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_factor, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming) != hipSuccess ||

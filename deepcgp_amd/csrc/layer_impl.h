@@ -153,6 +153,7 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   a.ZT = L.ZT; a.zn = L.zn; a.M = L.M; a.Mp = Mp; a.Lp = L.Lp;
   a.variance = L.variance; a.inv_l2 = 1.0 / (L.ls * L.ls);
   a.out = B; a.sM = ldb; a.sN = P; a.sP = 1;
+  a.share_cu = phase == 1;
   if (phase & 1) DCGP_TRY(patch_rbf(ctx, a, "kuf"));
   if (!(phase & 2)) return DCGP_OK;
   if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));   // inv(L) comes from the side stream
@@ -187,6 +188,7 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   a.variance = L.variance; a.inv_l2 = inv_l2;
   a.out = B; a.sM = ldb; a.sN = 1; a.sP = 0;
   a.w = L.w; a.scale = 1.0 / (double)L.v.P; a.reduce = 1;
+  a.share_cu = phase == 1;
   if (phase & 1) {
     DCGP_TRY(patch_rbf(ctx, a, "head_kzx"));
     if (L.kernel_type == 0) {

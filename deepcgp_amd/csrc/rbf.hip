@@ -394,6 +394,13 @@ int patch_rbf(dcgp_ctx* ctx, const PatchRbfArgs& a, const char* timer_name) {
   const int HWC = a.H * a.W * a.C;
   size_t lds = (size_t)(((HWC + 1) & ~1) + PR_BK * PR_LDZ + 2 * PR_BM) * sizeof(double) + (size_t)a.Lp * sizeof(int);
   if (lds > 160 * 1024) return ctx_fail(ctx, DCGP_ERR_ARG, "patch_rbf: image of %d doubles does not fit LDS", HWC);
+  // A sweep that overlaps the factorisation chain would otherwise starve it: its thousands of short 128-VGPR
+  // workgroups refill every slot the moment it frees, and a chain workgroup (200 VGPRs, 50 KB LDS) never finds a
+  // whole CU's worth of room -- even from a high-priority stream the first panel waited for the entire sweep
+  // (56 us instead of 18).  Claiming 54 KB of LDS per workgroup caps the sweep at two per CU (half the register
+  // file, 108 KB LDS) and leaves a standing slot for the chain; the sweep gets slower (54 -> 76 us) but stays far
+  // shorter than the chain it hides behind.
+  if (a.share_cu && lds < 54 * 1024) lds = 54 * 1024;
   const int p_tiles = (a.P + PR_BP - 1) / PR_BP;
   dim3 grid(a.reduce ? 1 : p_tiles, (a.Mp + PR_BM - 1) / PR_BM, a.N);
   ScopedTimer t(ctx, timer_name);

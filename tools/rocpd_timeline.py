@@ -16,7 +16,7 @@ def main(db, which=-3):
     lo, hi = marks[int(which)], marks[int(which) + 1]
     t0 = rows[lo][1]
     for r in rows[lo:hi]:
-        nm = r[0].split("(")[0].replace("(anonymous namespace)::", "")[:60]
+        nm = r[0].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
         print("%9.1f us  +%8.1f us  q=%s  %s" % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[3] if qcol else "-", nm))
     print("step span: %.1f us" % ((rows[hi][1] - t0) / 1e3))
 
