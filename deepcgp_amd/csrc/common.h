@@ -27,7 +27,9 @@ struct dcgp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;    // the stream launches go to (temporarily swapped to stream2 for the side branch)
   hipStream_t stream2 = nullptr;   // side stream: factorisation chain + KL terms
-  hipEvent_t ev_fork = nullptr, ev_factor = nullptr, ev_prep = nullptr, ev_kl = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_factor = nullptr, ev_kl = nullptr;
+  hipEvent_t ev_prep[8] = {};   // per layer: G / alpha of layer l are ready (side stream)
+  hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;  // fork / join of a short side-stream excursion inside a layer
   std::string err;
   // named, grow-only device workspaces owned by the ctx
   std::map<std::string, std::pair<void*, size_t>> ws;

@@ -103,11 +103,17 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
       side_stream_create(&c->stream2) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_factor, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_aux2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_kl, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return DCGP_ERR_HIP;
   }
+  for (auto& e : c->ev_prep)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      delete c;
+      return DCGP_ERR_HIP;
+    }
   if (hipHostMalloc((void**)&c->h_scratch, 64 * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&c->h_info, 16 * sizeof(int)) != hipSuccess) {
     hipStreamDestroy(c->stream);
@@ -133,7 +139,10 @@ int dcgp_ctx_destroy(dcgp_ctx* ctx) {
   hipHostFree(ctx->h_info);
   hipEventDestroy(ctx->ev_fork);
   hipEventDestroy(ctx->ev_factor);
-  hipEventDestroy(ctx->ev_prep);
+  hipEventDestroy(ctx->ev_aux);
+  hipEventDestroy(ctx->ev_aux2);
+  for (auto& e : ctx->ev_prep)
+    if (e) hipEventDestroy(e);
   hipEventDestroy(ctx->ev_kl);
   hipStreamDestroy(ctx->stream2);
   hipStreamDestroy(ctx->stream);

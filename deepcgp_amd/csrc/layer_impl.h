@@ -189,18 +189,36 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   a.out = B; a.sM = ldb; a.sN = 1; a.sP = 0;
   a.w = L.w; a.scale = 1.0 / (double)L.v.P; a.reduce = 1;
   a.share_cu = phase == 1;
+  bool kd_on_side = false;
   if (phase & 1) {
-    DCGP_TRY(patch_rbf(ctx, a, "head_kzx"));
-    if (L.kernel_type == 0) {
-      DCGP_TRY(head_kdiag(ctx, X, rows, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s, L.variance, inv_l2, L.w, kd));
-    } else {
-      DCGP_TRY(additive_kdiag_async(ctx, rows, L.v.P, L.variance, L.w, kd));
+    // Kdiag (all patch pairs of an image) is needed by finalize only: it runs on the side stream beside the
+    // Kzx sweep and the conditional GEMMs instead of in front of them.
+    hipStream_t main_s = ctx->stream;
+    kd_on_side = main_s != ctx->stream2;
+    if (kd_on_side) {
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, main_s));   // X is ready at this point of the main stream
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_aux, 0));
+      ctx->stream = ctx->stream2;
     }
+    int rc;
+    if (L.kernel_type == 0) {
+      rc = head_kdiag(ctx, X, rows, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s, L.variance, inv_l2, L.w, kd);
+    } else {
+      rc = additive_kdiag_async(ctx, rows, L.v.P, L.variance, L.w, kd);
+    }
+    if (kd_on_side) {
+      if (rc == DCGP_OK && hipEventRecord(ctx->ev_aux2, ctx->stream2) != hipSuccess) rc = DCGP_ERR_HIP;
+      ctx->stream = main_s;
+    }
+    DCGP_TRY(rc);
+    DCGP_TRY(patch_rbf(ctx, a, "head_kzx"));
   }
   if (!(phase & 2)) return DCGP_OK;
   if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
   CondScratch sc;
   DCGP_TRY(cond_core(ctx, L.g, B, ldb, rows, L.white, L.has_qsqrt, pfx.c_str(), &sc, prep_done));
+  // join: with phase == 2 the excursion was started by the earlier phase-1 call on the same stream pair
+  if (ctx->stream != ctx->stream2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux2, 0));
   FinalizeArgs fa;
   fa.s1p = sc.s1p; fa.nrb1 = sc.nrb1; fa.s2p = sc.s2p; fa.nrb3 = sc.nrb3; fa.mu = sc.mu; fa.ldk = ldb;
   fa.Kc = rows; fa.R = L.R; fa.knn_vec = kd;

@@ -156,13 +156,13 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       auto& o = m->outs[li];
       DCGP_TRY(conv_forward(ctx, L, F, rows, n_mod, expand ? S : 1, (long)N * width, z, seed, (uint32_t)(li + 1 + 64 * ctx->rank),
                             m->jitter, o.sample, m->keep_outputs ? o.mean : nullptr, m->keep_outputs ? o.var : nullptr, pfx,
-                            fdone, ctx->ev_prep, phase));
+                            fdone, ctx->ev_prep[li], phase));
       *out_rows_p = out_rows;
     } else {
       DCGP_TRY(ensure_out(m, li, rows, L.R, true));
       auto& o = m->outs[li];
       DCGP_TRY(ensure(ctx, &m->d_kd, &m->kd_cap, (size_t)rows));
-      DCGP_TRY(head_forward(ctx, L, F, rows, n_mod, m->d_kd, o.mean, o.var, pfx, fdone, ctx->ev_prep, phase));
+      DCGP_TRY(head_forward(ctx, L, F, rows, n_mod, m->d_kd, o.mean, o.var, pfx, fdone, ctx->ev_prep[li], phase));
       if ((phase & 2) && m->keep_outputs) {
         // the head's sample is not needed by the ELBO; produce it only on request
         size_t n = (size_t)rows * L.R;
@@ -186,7 +186,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
 
   // The replicated M x M stage (batched Cholesky + inverse, the small operands of the conditional, then the KL
   // terms) is a serial, few-CU chain: it runs on the side stream, overlapped with that sweep and with the
-  // conditional GEMMs.  ev_factor gates the first GEMM, ev_prep the second, ev_kl the ELBO assembly.
+  // conditional GEMMs.  ev_factor gates the first GEMM, ev_prep[l] the second of layer l, ev_kl the ELBO assembly.
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   static const bool no_side = getenv("DCGP_NO_SIDE_STREAM") != nullptr;   // A/B switch: everything on one stream
   if (!no_side) ctx->stream = ctx->stream2;
@@ -195,8 +195,10 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     if ((rc = gr.run(ctx)) != DCGP_OK) break;
   if (rc == DCGP_OK && hipEventRecord(ctx->ev_factor, ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
   // G_r = inv(L) Lq_r and alpha = inv(L) q_mu of every layer (cond_prep): gate the second conditional GEMM
-  for (int li = 0; li < nl && rc == DCGP_OK; ++li) rc = cond_prep(ctx, m->layers[li]->g, m->layers[li]->white, m->layers[li]->has_qsqrt);
-  if (rc == DCGP_OK && hipEventRecord(ctx->ev_prep, ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
+  for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
+    rc = cond_prep(ctx, m->layers[li]->g, m->layers[li]->white, m->layers[li]->has_qsqrt);
+    if (rc == DCGP_OK && hipEventRecord(ctx->ev_prep[li], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;   // per layer: layer 0 does not wait for the others
+  }
   if (rc == DCGP_OK && need_kl) {
     for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
       LayerState& L = *m->layers[li];
