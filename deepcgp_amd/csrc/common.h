@@ -97,6 +97,7 @@ struct GemmArgs {
   int nW = 1, nB = 1;          // batch = nW * nB, bz -> (iw = bz / nB, ib = bz % nB)
   int tri = 0;                 // 0 dense, 1: W lower (k <= i), 2: W upper (k >= i)
   int b_lower = 0;             // B[k][j] == 0 for k < j (skip those k tiles)
+  int rb_major = 0;            // set by the launcher: workgroup order (see the kernel's decode)
 };
 int gemm_tn(dcgp_ctx* ctx, const GemmArgs& a, int* n_row_blocks_out);
 int gemm_row_block(int Mi, int Kc, int batch);   // BM the dispatcher picks (callers size partial-sum buffers with it)

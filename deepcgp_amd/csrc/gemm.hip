@@ -51,19 +51,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
   long orig = blockIdx.x;
   long q = nwg / 8, r = nwg % 8, xcd = orig % 8;
   long wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
-  const int inner = n_row_blocks * batch;
-  const int ct = (int)(wgid / inner);
-  int rem = (int)(wgid % inner);
-  // heavy (long-k) row blocks first within a column strip
-  const int bz = rem / n_row_blocks;
-  int rb = rem % n_row_blocks;
-  if (a.tri == 1) rb = n_row_blocks - 1 - rb;
-  // Row blocks of a triangular product carry graded work.  Workgroups are handed to shader engines / CUs round-robin
-  // in id order, so a FIXED heavy,light,heavy,light... sequence parks all heavy blocks on the same engines and the
-  // launch lasts as long as a heavy-only queue (measured in MFMA-only mode: 19.6 us lost per workgroup turn vs 7.7 us
-  // with equal blocks).  Rotating the row-block order by the bit parity of the global (column tile, batch) index
-  // (Thue-Morse) is balanced over every power-of-two stride.
-  if (a.tri) rb = (rb + __popc(ct * batch + bz)) % n_row_blocks;
+  if (a.rb_major) wgid = orig;   // ids stay interleaved over the XCDs: each XCD gets its share of the heavy blocks
+  int ct, bz, rb;
+  if (a.rb_major) {
+    // Launches of at most ~2 rounds: ALL heavy row blocks first, then the lighter ones -- the light blocks fill the
+    // tail while the heavy ones run, so the launch lasts one heavy block (mixed orders end with a heavy block that
+    // started late).  No fixed-stride heavy/light alternation either.
+    const int per = n_col_tiles * batch;
+    const int rbk = (int)(wgid / per), rem = (int)(wgid % per);
+    ct = rem / batch;
+    bz = rem % batch;
+    rb = (a.tri == 1) ? n_row_blocks - 1 - rbk : rbk;
+  } else {
+    const int inner = n_row_blocks * batch;
+    ct = (int)(wgid / inner);
+    const int rem = (int)(wgid % inner);
+    // heavy (long-k) row blocks first within a column strip
+    bz = rem / n_row_blocks;
+    rb = rem % n_row_blocks;
+    if (a.tri == 1) rb = n_row_blocks - 1 - rb;
+    // Row blocks of a triangular product carry graded work.  Workgroups are handed to shader engines / CUs round-robin
+    // in id order, so a FIXED heavy,light,heavy,light... sequence parks all heavy blocks on the same engines and the
+    // launch lasts as long as a heavy-only queue (measured in MFMA-only mode: 19.6 us lost per workgroup turn vs 7.7 us
+    // with equal blocks).  Rotating the row-block order by the bit parity of the global (column tile, batch) index
+    // (Thue-Morse) is balanced over every power-of-two stride.
+    if (a.tri) rb = (rb + __popc(ct * batch + bz)) % n_row_blocks;
+  }
   const int iw = bz / a.nB, ib = bz % a.nB;
 
   const int i0 = rb * BM, j0 = ct * BN;
@@ -260,8 +273,10 @@ int launch(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
   size_t lds = (size_t)(2 * BK * lds_ld(BM) + 2 * BK * lds_ld(BN)) * sizeof(double);
   size_t red = (size_t)WAVES_M * BN * sizeof(double);
   if (red > lds) lds = red;
+  GemmArgs k = a;
+  k.rb_major = a.tri != 0 && nwg <= 1024;
   hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WAVES_M, WAVES_N, ABL>), dim3((unsigned)nwg), dim3(NT), lds, ctx->stream,
-                     a, nct, nrb);
+                     k, nct, nrb);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }

@@ -27,7 +27,7 @@ struct dcgp_model {
   // per-layer outputs of the most recent forward
   struct Out { double *sample = nullptr, *mean = nullptr, *var = nullptr; int rows = 0, width = 0; size_t cap = 0; };
   std::vector<Out> outs;
-  double* d_scal = nullptr;   // [0]=data, [1..3] out, then 4 per layer KL pieces
+  double* d_scal = nullptr;   // [0]=data, [4 + 4l ..] 4 KL pieces of layer l, [40..43] ELBO, data term, KL, potrf status
   double* d_ve = nullptr; size_t ve_cap = 0;
   double* d_kd = nullptr; size_t kd_cap = 0;
   int id = 0;
@@ -91,6 +91,9 @@ struct CombineArgs {
   int nl;
   int M[8], R[8], white[8];
   double scale;
+  const int* info[16];   // per factor group: potrf status words (0 or the 1-based failing column)
+  int ninfo[16];
+  int ngroups;
 };
 __global__ void combine_kernel(const double* __restrict__ scal_in, double* __restrict__ out, CombineArgs c) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -105,6 +108,11 @@ __global__ void combine_kernel(const double* __restrict__ scal_in, double* __res
   out[0] = data * c.scale - kl;
   out[1] = data;
   out[2] = kl;
+  int bad = 0;   // first non-positive pivot of any factorisation: rides back with the result (one D2H, one sync)
+  for (int g = 0; g < c.ngroups; ++g)
+    for (int i = 0; i < c.ninfo[g]; ++i)
+      if (c.info[g][i] && !bad) bad = c.info[g][i];
+  out[3] = (double)bad;
 }
 
 int read_info(dcgp_model* m, int* info_host) {
@@ -333,13 +341,19 @@ int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int 
   CombineArgs c;
   c.nl = nl; c.scale = scale;
   for (int l = 0; l < nl; ++l) { c.M[l] = model->layers[l]->M; c.R[l] = model->layers[l]->R; c.white[l] = model->layers[l]->white; }
-  hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, ctx->stream, model->d_scal, model->d_scal + 1, c);
+  if (model->groups.size() > 16) return ctx_fail(ctx, DCGP_ERR_ARG, "model: too many factor groups");
+  c.ngroups = (int)model->groups.size();
+  for (int g = 0; g < c.ngroups; ++g) { c.info[g] = model->groups[g].d_info; c.ninfo[g] = (int)model->groups[g].K.size(); }
+  hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, ctx->stream, model->d_scal, model->d_scal + 40, c);
   LAUNCH_CHECK(ctx);
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scratch, model->d_scal + 1, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scratch, model->d_scal + 40, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   out_host[0] = ctx->h_scratch[0]; out_host[1] = ctx->h_scratch[1]; out_host[2] = ctx->h_scratch[2];
   if (ctx->timing && ctx->pending.size() > 512) timing_flush(ctx);   // both streams are drained here; resolve lazily
-  return read_info(model, info_host);
+  const int bad = (int)ctx->h_scratch[3];
+  if (info_host) *info_host = bad;
+  if (bad) return ctx_fail(ctx, DCGP_ERR_NOT_PD, "Cholesky: matrix not positive definite at column %d", bad);
+  return DCGP_OK;
 }
 
 int dcgp_model_propagate(dcgp_model* model, const double* X, int N, int S, const double* const* z_per_layer_host,
