@@ -92,21 +92,30 @@ __device__ __forceinline__ int wave_potrf32(double (&a)[NB], int r, double (&col
 // as the row update  a[cc] -= a[c] L[cc][c]  -- so the upper half of the wavefront, idle otherwise, delivers inv(L_jj)
 // with no additional instruction, LDS access or latency.  `col` is a 64-entry LDS line (upper half is a write sink).
 __device__ __forceinline__ int wave_potrf_inv32(double (&v)[NB], int lane, double (&col)[2 * NB]) {
+  // Latency shaping: the column is published UNSCALED (it is final one step early) and read back while the
+  // pivot's reciprocal square root is still being refined; the update then uses  v[cc] -= (v[c]/piv) u[cc]  with the
+  // unscaled multipliers u, so the LDS round trip is off the 32-step critical path.  The entry the next step pivots
+  // on is updated -- and published -- first.
   int fail = 0;
+  col[lane] = v[0];
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
+    double u[NB];
+#pragma unroll
+    for (int cc = c + 1; cc < NB; ++cc) u[cc] = col[cc];
     const double piv = bcast_lane(v[c], c);
     if (!(piv > 0.0) && fail == 0) fail = c + 1;
     const double y = rsqrt_nr(piv);
     double d = piv * y;
     d = fma(0.5 * y, fma(-d, d, piv), d);       // sqrt(piv) to ~1 ulp
+    const double t = v[c] * (y * y);
     v[c] = (lane == c) ? d : v[c] * y;
-    col[lane] = v[c];
-    double m[NB];
+    if (c + 1 < NB) {
+      v[c + 1] = fma(-t, u[c + 1], v[c + 1]);
+      col[lane] = v[c + 1];
+    }
 #pragma unroll
-    for (int cc = c + 1; cc < NB; ++cc) m[cc] = col[cc];
-#pragma unroll
-    for (int cc = c + 1; cc < NB; ++cc) v[cc] = fma(-v[c], m[cc], v[cc]);
+    for (int cc = c + 2; cc < NB; ++cc) v[cc] = fma(-t, u[cc], v[cc]);
   }
   return fail;
 }
