@@ -29,6 +29,8 @@ struct dcgp_ctx {
   hipStream_t stream2 = nullptr;   // side stream: factorisation chain + KL terms
   hipEvent_t ev_fork = nullptr, ev_factor = nullptr, ev_kl = nullptr;
   hipEvent_t ev_prep[8] = {};   // per layer: G / alpha of layer l are ready (side stream)
+  bool no_side = false;            // DCGP_NO_SIDE_STREAM: everything on the main stream (A/B switch; counter-collection runs, where
+                                   // the profiler serialises dispatches and cross-stream waits can deadlock it)
   hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;  // fork / join of a short side-stream excursion inside a layer
   std::string err;
   // named, grow-only device workspaces owned by the ctx

@@ -277,7 +277,7 @@ int cond_prep(dcgp_ctx* ctx, GpMats& g, int white, bool have_qsqrt) {
 }
 
 int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, int white, bool have_qsqrt,
-              const char* pfx, CondScratch* out, hipEvent_t prep_done) {
+              const char* pfx, CondScratch* out, hipEvent_t prep_done, bool head) {
   const int Mp = g.Mp, R = g.R;
   const int BM1 = gemm_row_block(Mp, Kc, 1), BM3 = gemm_row_block(Mp, Kc, R);
   const int nrb = (Mp + BM1 - 1) / BM1, nrb3 = (Mp + BM3 - 1) / BM3;
@@ -291,7 +291,7 @@ int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc,
   sc.mu = (double*)ws_get(ctx, p + "mu", (size_t)g.Rp * ldb * sizeof(double));
   if (!sc.A1 || !sc.s1p || !sc.mu || (have_qsqrt && !sc.s2p)) return DCGP_ERR_ALLOC;
   {
-    ScopedTimer t(ctx, "gemm_cond_s1");   // A1 = inv(L) Kuf, s1 = sum_m A1^2
+    ScopedTimer t(ctx, head ? "gemm_head_s1" : "gemm_cond_s1");   // A1 = inv(L) Kuf, s1 = sum_m A1^2
     GemmArgs a;
     a.Wt = g.LinvT; a.ldw = Mp;
     a.B = B; a.ldb = (int)ldb;
@@ -302,7 +302,7 @@ int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc,
   }
   if (prep_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, prep_done, 0));   // G / alpha come from the side stream
   if (have_qsqrt) {
-    ScopedTimer t(ctx, "gemm_cond_s3");   // T_r = G_r^T A1 (upper-triangular product), s2 = sum_m T_r^2, never stored
+    ScopedTimer t(ctx, head ? "gemm_head_s3" : "gemm_cond_s3");   // T_r = G_r^T A1 (upper-triangular product), s2 = sum_m T_r^2, never stored
     GemmArgs a;
     a.Wt = g.G; a.ldw = Mp; a.wBatch = (long)Mp * Mp; a.nW = R;
     a.B = sc.A1; a.ldb = (int)ldb;
@@ -312,7 +312,7 @@ int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc,
   }
   {
     // mu[r][j] = sum_k alpha[k][r] A1[k][j]  (conditionals.py:50): a 16-row dense product on the same kernel
-    ScopedTimer t(ctx, "cond_mean");
+    ScopedTimer t(ctx, head ? "head_mean" : "cond_mean");
     GemmArgs a;
     a.Wt = g.alpha; a.ldw = g.Rp;
     a.B = sc.A1; a.ldb = (int)ldb;

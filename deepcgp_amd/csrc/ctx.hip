@@ -99,6 +99,7 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return DCGP_ERR_HIP;
   dcgp_ctx* c = new dcgp_ctx();
   c->device = device;
+  c->no_side = getenv("DCGP_NO_SIDE_STREAM") != nullptr;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       side_stream_create(&c->stream2) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||

@@ -39,6 +39,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
   constexpr int NLW = (W_CHUNKS + NT - 1) / NT, NLB = (B_CHUNKS + NT - 1) / NT;
   static_assert(W_CHUNKS % NT == 0 || W_CHUNKS < NT, "W tile / thread mismatch");
   static_assert(B_CHUNKS % NT == 0, "B tile / thread mismatch");
+  // One k-row of either operand tile = 1 KiB = one wavefront x 16 B: the 128 x 128 tile of 16 waves is filled by
+  // LDS-DMA loads (buffer_load ... lds: wave-uniform LDS row base + lane * 16 B, so the row padding survives), no
+  // staging registers and no ds_write pass.  Other shapes stage through registers.
+  constexpr bool GLDS = BM == 128 && BN == 128 && NT == 1024 && !(ABL & 3);
 
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Ws = smem;                       // [2][BK][LDW]
@@ -125,20 +129,28 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
     const int ch = tid + c * NT, row = ch / (BN / 2), col = (ch % (BN / 2)) * 2;
     boff[c] = (j0 + col < a.Kc) ? (unsigned)(row * a.ldb + j0 + col) * 8u : OOB;
   }
-  auto load_tile = [&](int k0) {   // Mk is a multiple of BK (callers pad), so every k row of a tile exists
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably uniform: the LDS-DMA row base goes to M0
+  auto load_tile = [&](int k0, int nbuf) {   // Mk is a multiple of BK (callers pad), so every k row of a tile exists
     const int sw = (k0 - klo) * a.ldw * 8, sb = (k0 - klo) * a.ldb * 8;
+    if constexpr (GLDS) {
+      typedef __attribute__((address_space(3))) void* lds_ptr;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr)(Ws + nbuf * BK * LDW + wave_u * LDW), 16, (int)woff[0], sw, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_ptr)(Bs + nbuf * BK * LDB + wave_u * LDB), 16, (int)boff[0], sb, 0, 0);
+    } else {
 #pragma unroll
-    for (int c = 0; c < NLW; ++c) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)woff[c], sw, 0);
-      __builtin_memcpy(&rw[c], &v, 16);
-    }
+      for (int c = 0; c < NLW; ++c) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)woff[c], sw, 0);
+        __builtin_memcpy(&rw[c], &v, 16);
+      }
 #pragma unroll
-    for (int c = 0; c < NLB; ++c) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(brs, (int)boff[c], sb, 0);
-      __builtin_memcpy(&rbv[c], &v, 16);
+      for (int c = 0; c < NLB; ++c) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(brs, (int)boff[c], sb, 0);
+        __builtin_memcpy(&rbv[c], &v, 16);
+      }
     }
   };
   auto store_tile = [&](int buf) {
+    if constexpr (GLDS) return;
     double* w = Ws + buf * BK * LDW;
     double* b = Bs + buf * BK * LDB;
 #pragma unroll
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
     constexpr int X0 = decltype(x0c)::value, X1 = decltype(x1c)::value;
     for (int k0 = kb; k0 < ke; k0 += BK) {
       const bool has_next = k0 + BK < khi;
-      if (has_next && !(ABL & 1)) load_tile(k0 + BK);
+      if (has_next && !(ABL & 1)) load_tile(k0 + BK, buf ^ 1);
       if (X0 < X1) {
         const double* w = Ws + buf * BK * LDW + lcol;
         const double* b = Bs + buf * BK * LDB + wn * WNC + lcol;
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
   b2 = __builtin_amdgcn_readfirstlane(b2);
   b3 = __builtin_amdgcn_readfirstlane(b3);
   if (klo < khi) {
-    load_tile(klo);
+    load_tile(klo, 0);
     store_tile(0);
   }
   __syncthreads();

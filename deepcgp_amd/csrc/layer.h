@@ -50,7 +50,7 @@ struct CondScratch {
 // G and alpha of a layer (two small GEMMs on the current stream); must run after the factorisation of g.K
 int cond_prep(dcgp_ctx* ctx, GpMats& g, int white, bool have_qsqrt);
 int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, int white, bool have_qsqrt,
-              const char* ws_prefix, CondScratch* out, hipEvent_t prep_done = nullptr);
+              const char* ws_prefix, CondScratch* out, hipEvent_t prep_done = nullptr, bool head = false);   // head: timer labels only
 
 struct FinalizeArgs {
   const double* s1p = nullptr; int nrb1 = 0;

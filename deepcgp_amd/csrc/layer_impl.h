@@ -194,7 +194,7 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     // Kdiag (all patch pairs of an image) is needed by finalize only: it runs on the side stream beside the
     // Kzx sweep and the conditional GEMMs instead of in front of them.
     hipStream_t main_s = ctx->stream;
-    kd_on_side = main_s != ctx->stream2;
+    kd_on_side = main_s != ctx->stream2 && !ctx->no_side;
     if (kd_on_side) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, main_s));   // X is ready at this point of the main stream
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_aux, 0));
@@ -216,9 +216,9 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   if (!(phase & 2)) return DCGP_OK;
   if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
   CondScratch sc;
-  DCGP_TRY(cond_core(ctx, L.g, B, ldb, rows, L.white, L.has_qsqrt, pfx.c_str(), &sc, prep_done));
+  DCGP_TRY(cond_core(ctx, L.g, B, ldb, rows, L.white, L.has_qsqrt, pfx.c_str(), &sc, prep_done, true));
   // join: with phase == 2 the excursion was started by the earlier phase-1 call on the same stream pair
-  if (ctx->stream != ctx->stream2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux2, 0));
+  if (ctx->stream != ctx->stream2 && !ctx->no_side) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux2, 0));
   FinalizeArgs fa;
   fa.s1p = sc.s1p; fa.nrb1 = sc.nrb1; fa.s2p = sc.s2p; fa.nrb3 = sc.nrb3; fa.mu = sc.mu; fa.ldk = ldb;
   fa.Kc = rows; fa.R = L.R; fa.knn_vec = kd;

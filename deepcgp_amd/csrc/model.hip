@@ -196,7 +196,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   // terms) is a serial, few-CU chain: it runs on the side stream, overlapped with that sweep and with the
   // conditional GEMMs.  ev_factor gates the first GEMM, ev_prep[l] the second of layer l, ev_kl the ELBO assembly.
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-  static const bool no_side = getenv("DCGP_NO_SIDE_STREAM") != nullptr;   // A/B switch: everything on one stream
+  const bool no_side = ctx->no_side;   // A/B switch: everything on one stream
   if (!no_side) ctx->stream = ctx->stream2;
   int rc = DCGP_OK;
   for (auto& gr : m->groups)

@@ -100,7 +100,8 @@ def test_kuf(ctx, H, W, C, f, s, M):
 
 
 @pytest.mark.parametrize("white", [False, True])
-@pytest.mark.parametrize("P,M,N,R", [(3, 4, 5, 2), (6, 16, 5, 3), (2, 37, 130, 10), (4, 128, 40, 10), (1, 256, 64, 10)])
+@pytest.mark.parametrize("P,M,N,R", [(3, 4, 5, 2), (6, 16, 5, 3), (2, 37, 130, 10), (4, 128, 40, 10), (1, 256, 64, 10),
+                                     (16, 264, 144, 10)])   # Mp = 272: 128-row tiles overhang the matrix (zero-filled by the buffer bounds check)
 def test_conditional(ctx, white, P, M, N, R):
     from deepcgp_amd.conditionals import conditional
     rng = np.random.default_rng(7 * M + P)

@@ -2,7 +2,9 @@
 # usage (GPU box, repo root): tools/pmc_bench.sh <tag> "<counters>" [bench args]   -- counters in their own pass (kernel-trace only)
 TAG=$1; CNT=$2; shift; shift
 R=$PWD; export TMPDIR=/tmp; mkdir -p $R/gpurun_out
-cd /tmp && rocprofv3 --kernel-trace --pmc $CNT -d $R/gpurun_out/pmc_$TAG -o pmc --output-format csv -- python $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/pmc_${TAG}.log 2>&1
+# one stream only: the profiler serialises dispatches in counter mode and cross-stream event waits deadlocked it
+export DCGP_NO_SIDE_STREAM=1
+cd /tmp && timeout 240 rocprofv3 --kernel-trace --pmc $CNT -d $R/gpurun_out/pmc_$TAG -o pmc --output-format csv -- python $R/bench.py --profile "$@" > $R/gpurun_out/pmc_${TAG}.log 2>&1
 cd $R
 F=$(find gpurun_out/pmc_$TAG -name '*counter_collection.csv' | head -1)
 python - "$F" <<'PY'

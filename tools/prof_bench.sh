@@ -5,7 +5,7 @@ TAG=$1; shift
 R=$PWD
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
-cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o bench -- python $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/prof_${TAG}_bench.log 2>&1
+cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o bench -- python $R/bench.py --profile "$@" > $R/gpurun_out/prof_${TAG}_bench.log 2>&1
 cd $R
 DB=$(find gpurun_out/prof_$TAG -name '*.db' | head -1)
 python tools/rocpd_summary.py $DB gpurun_out/prof_${TAG}_kernel_stats.csv
@@ -14,7 +14,7 @@ python - "$TAG" <<'PY'
 import csv, json, sys
 tag = sys.argv[1]
 d = json.load(open('gpurun_out/prof_%s_bench.json' % tag))
-steps = 2 * d['steps'] + d['warmup']
+steps = d['steps'] + d['warmup']   # bench.py --profile runs exactly warmup + steps steps
 print('steps profiled', steps, 'ms/step', d['ms_per_step'])
 tot = 0
 for r in csv.DictReader(open('gpurun_out/prof_%s_kernel_stats.csv' % tag)):
