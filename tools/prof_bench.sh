@@ -20,6 +20,6 @@ tot = 0
 for r in csv.DictReader(open('gpurun_out/prof_%s_kernel_stats.csv' % tag)):
     per = float(r['TotalDurationNs']) / steps / 1e3
     tot += per
-    print('%-34s calls/step %5.1f avg_us %8.1f per-step_us %8.1f' % (r['Name'].split('::')[-1].split('(')[0][:34], int(r['Calls']) / steps, float(r['AverageNs']) / 1e3, per))
+    print('%-34s grid %9s calls/step %5.1f avg_us %8.1f per-step_us %8.1f' % (r['Name'].split('::')[-1].split('(')[0][:34], r['GridThreads'], int(r['Calls']) / steps, float(r['AverageNs']) / 1e3, per))
 print('sum of kernel time per step (us): %.1f' % tot)
 PY
