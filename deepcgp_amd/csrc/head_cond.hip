@@ -1,0 +1,175 @@
+// head_cond.hip -- the whole conditional of a FEW-column problem (the head: one column per image, a few hundred in
+// all) in ONE launch, for M <= 256.
+//
+// The generic route is four dependent launches -- A1 = inv(L) Kzx (+ sum of squares), T_r = G_r^T A1 (+ sum of
+// squares), mean = alpha^T A1, finalize -- of 13-17 us each at cfg2, every one of them nothing but a serial chain of
+// 16 k-steps that each wait a full memory latency: ~75 us with the gaps, at the very end of the step where nothing
+// can hide it.  Here a workgroup owns (16 columns, one output r) and runs both triangular products back to back:
+//     * the 16-column strip of Kzx is LDS-resident ([k][16], 32 KB), and A1 overwrites it in place when stage 1 ends;
+//     * wave w owns rows 16w..16w+15 and streams ONLY its own 16 columns of the W operands (inv(L)^T, then G_r) from
+//       global memory straight into MFMA A registers, three k-tiles ahead, and only its live k-tiles: w+1 in the
+//       lower-triangular stage, 16-w in the upper-triangular one -- no LDS staging, no barrier inside a k loop.
+//       (A first version staged whole W k-tiles through an LDS ring for all waves: 2 tiles = 64 KB in flight per CU
+//       against ~1.7 us of latency is 32 GB/s -- 27 us for the 1 MB a workgroup streams.);
+//     * sum_m A1^2, alpha_r^T A1 and sum_m T_r^2 are reduced from the accumulators, and mean / var leave the kernel
+//       in the [column][R] layout the likelihood reads (conv_gp/layers.py:128-134 semantics, full_cov = False).
+// A1 (and stage 1) is recomputed by the R workgroups of a strip: 8 extra MFMA k-tiles each, cheaper than a launch.
+#include "layer.h"
+
+namespace {
+
+constexpr int HC_MP = 256;             // largest padded M handled (16 waves x one 16-row fragment)
+constexpr int HC_BK = 16;
+constexpr int HC_BN = 16;
+constexpr int HC_D = 3;                // W k-tiles in flight per wave beside the one being multiplied
+
+struct HeadCondArgs {
+  const double* B; long ldb; int Kc;       // Kzx, k-major [Mp][ldb]
+  const double* LinvT;                     // [Mp][Mp]: Wt of stage 1 (lower-triangular W)
+  const double* G;                         // [R][Mp][Mp]: Wt of stage 3 (upper-triangular W), nullptr: no q_sqrt term
+  const double* alpha; int Rp;             // [Mp][Rp]
+  const double* kd;                        // Knn per column
+  int Mp, R;
+  double *out_mean, *out_var;              // [Kc][R]
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(1024, 4) void head_cond_kernel(HeadCondArgs a) {
+  __shared__ __attribute__((aligned(16))) double Bt[HC_MP * HC_BN];   // [k][16]: Kzx strip, then A1
+  __shared__ double red[3 * 16 * 16];
+
+  const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j0 = blockIdx.x * HC_BN, r = blockIdx.y;
+  const int Mp = a.Mp, nt = Mp / HC_BK;                  // k-tiles per stage
+  const bool s3 = a.G != nullptr;
+  const int i0 = wave * 16;                              // this wave's rows
+  const bool live = i0 < Mp;
+
+  const __amdgpu_buffer_rsrc_t brs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.B), 0, (int)((long)Mp * a.ldb * 8), 0x00020000);
+  const __amdgpu_buffer_rsrc_t lrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.LinvT), 0, Mp * Mp * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<double*>(s3 ? a.G + (long)r * Mp * Mp : a.LinvT), 0, Mp * Mp * 8, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+
+  double al[4];                          // alpha[row][r] of this lane's four accumulator rows
+#pragma unroll
+  for (int v = 0; v < 4; ++v) al[v] = live ? a.alpha[(long)(i0 + lrow + 4 * v) * a.Rp + r] : 0.0;
+  // Kzx strip by LDS-DMA: wave-instruction q covers rows 8q..8q+7 (8 lanes x 16 B per row); 2 per wave
+  {
+    const int rl = lane >> 3, cl = (lane & 7) * 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = wave * 2 + h, row = q * 8 + rl;
+      const unsigned off = (row < Mp) ? (unsigned)(((long)row * a.ldb + j0 + cl) * 8) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_ptr)(Bt + q * 8 * HC_BN), 16, (int)off, 0, 0, 0);
+    }
+  }
+
+  // A operand straight from global memory: lane (lrow, lcol) of k-substep q needs W^T[kt*16 + 4q + lrow][i0 + lcol].
+  // Each wave streams ONLY its 16 columns and only its live k-tiles, HC_D tiles ahead in registers -- no LDS staging
+  // and no barrier in the k loop (the B operand is the resident strip).
+  unsigned woff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) woff[q] = live ? (unsigned)(((4 * q + lrow) * Mp + i0 + lcol) * 8) : OOB;
+  auto ldw = [&](const __amdgpu_buffer_rsrc_t& rs, int kt, double (&dst)[4]) {
+    const int so = kt * HC_BK * Mp * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)woff[q], so, 0);
+      __builtin_memcpy(&dst[q], &v, 8);
+    }
+  };
+  d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+  // tiles [lo, hi) of one stage, prefetch distance HC_D (loads past the end re-read the last tile: static counts)
+  auto stage = [&](const __amdgpu_buffer_rsrc_t& rs, int lo, int hi) {
+    double wb[HC_D + 1][4];
+#pragma unroll
+    for (int u = 0; u < HC_D; ++u) ldw(rs, min(lo + u, hi - 1), wb[u]);
+    for (int kt = lo; kt < hi; kt += HC_D + 1) {
+#pragma unroll
+      for (int u = 0; u <= HC_D; ++u) {
+        if (kt + u < hi) {
+          ldw(rs, min(kt + u + HC_D, hi - 1), wb[(u + HC_D) % (HC_D + 1)]);
+          const double* b = Bt + (kt + u) * HC_BK * HC_BN + lcol;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wb[u][q], b[(4 * q + lrow) * HC_BN], acc, 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  __syncthreads();   // Kzx strip resident (drains the DMA queue)
+  double s1 = 0.0, mu = 0.0, s2 = 0.0;   // per-lane partials for column lcol
+  // ---- stage 1: A1 = inv(L) Kzx, lower-triangular W: k-tiles 0 .. wave ----
+  if (live) stage(lrs, 0, wave + 1);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const double x = live ? acc[v] : 0.0;
+    s1 = fma(x, x, s1);
+    mu = fma(al[v], x, mu);
+  }
+  __syncthreads();   // every wave is done reading the Kzx strip
+  if (live) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Bt[(i0 + lrow + 4 * v) * HC_BN + lcol] = acc[v];
+  }
+  __syncthreads();   // A1 published
+  // ---- stage 3: T_r = G_r^T A1, upper-triangular W: k-tiles wave .. nt-1 ----
+  if (s3) {
+    acc = d4{0.0, 0.0, 0.0, 0.0};
+    if (live) stage(grs, wave, nt);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) s2 = fma(acc[v], acc[v], s2);
+  }
+  // ---- reduce over the 4 row groups of a wave, then over the waves ----
+  s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+  mu += __shfl_xor(mu, 16); mu += __shfl_xor(mu, 32);
+  s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+  if (lrow == 0) {
+    red[(0 * 16 + wave) * 16 + lcol] = s1;
+    red[(1 * 16 + wave) * 16 + lcol] = mu;
+    red[(2 * 16 + wave) * 16 + lcol] = s2;
+  }
+  __syncthreads();
+  if (tid < HC_BN) {
+    double t1 = 0.0, tm = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      t1 += red[(0 * 16 + w) * 16 + tid];
+      tm += red[(1 * 16 + w) * 16 + tid];
+      t2 += red[(2 * 16 + w) * 16 + tid];
+    }
+    const int j = j0 + tid;
+    if (j < a.Kc) {
+      a.out_mean[(long)j * a.R + r] = tm;
+      a.out_var[(long)j * a.R + r] = a.kd[j] - t1 + t2;
+    }
+  }
+}
+
+}  // namespace
+
+bool head_cond_fused_ok(const GpMats& g) { return g.Mp <= HC_MP && g.Mp % HC_BK == 0; }
+
+// mean / var [Kc][R] of the conditional at Kc columns whose Kzx is B [Mp][ldb]; G / alpha from cond_prep
+int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, bool have_qsqrt, const double* kd,
+                    double* out_mean, double* out_var) {
+  if (Kc <= 0) return DCGP_OK;
+  if (!head_cond_fused_ok(g) || (long)g.Mp * ldb * 8 >= (1L << 31))
+    return ctx_fail(ctx, DCGP_ERR_ARG, "head_cond_fused: M = %d not supported", g.Mp);
+  ScopedTimer t(ctx, "head_cond");
+  HeadCondArgs a;
+  a.B = B; a.ldb = ldb; a.Kc = Kc;
+  a.LinvT = g.LinvT; a.G = have_qsqrt ? g.G : nullptr; a.alpha = g.alpha; a.Rp = g.Rp;
+  a.kd = kd; a.Mp = g.Mp; a.R = g.R;
+  a.out_mean = out_mean; a.out_var = out_var;
+  hipLaunchKernelGGL(head_cond_kernel, dim3((Kc + HC_BN - 1) / HC_BN, g.R), dim3(1024), 0, ctx->stream, a);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}

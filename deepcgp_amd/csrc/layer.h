@@ -52,6 +52,11 @@ int cond_prep(dcgp_ctx* ctx, GpMats& g, int white, bool have_qsqrt);
 int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, int white, bool have_qsqrt,
               const char* ws_prefix, CondScratch* out, hipEvent_t prep_done = nullptr, bool head = false);   // head: timer labels only
 
+// head_cond.hip: the whole conditional of a few-column problem in one launch (M <= 256): mean / var [Kc][R]
+bool head_cond_fused_ok(const GpMats& g);
+int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, bool have_qsqrt, const double* kd,
+                    double* out_mean, double* out_var);
+
 struct FinalizeArgs {
   const double* s1p = nullptr; int nrb1 = 0;
   const double* s2p = nullptr; int nrb3 = 0;    // nullptr -> no q_sqrt term

@@ -215,6 +215,13 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   }
   if (!(phase & 2)) return DCGP_OK;
   if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
+  static const bool unfused = getenv("DCGP_HEAD_UNFUSED") != nullptr;   // A/B switch
+  if (head_cond_fused_ok(L.g) && !unfused) {
+    // few columns (one per image): both triangular products, the mean and mean / var in one launch (head_cond.hip)
+    if (prep_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, prep_done, 0));
+    if (ctx->stream != ctx->stream2 && !ctx->no_side) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux2, 0));
+    return head_cond_fused(ctx, L.g, B, ldb, rows, L.has_qsqrt, kd, out_mean, out_var);
+  }
   CondScratch sc;
   DCGP_TRY(cond_core(ctx, L.g, B, ldb, rows, L.white, L.has_qsqrt, pfx.c_str(), &sc, prep_done, true));
   // join: with phase == 2 the excursion was started by the earlier phase-1 call on the same stream pair
