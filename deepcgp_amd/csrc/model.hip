@@ -14,6 +14,7 @@
 #include <memory>
 
 #include "layer_impl.h"
+#include <chrono>
 
 struct dcgp_model {
   dcgp_ctx* ctx = nullptr;
@@ -328,6 +329,7 @@ int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int 
   if (info_host) *info_host = 0;
   int rows = 0;
   const int S = model->S;
+  const auto host_t0 = std::chrono::steady_clock::now();
   DCGP_TRY(forward_all(model, X, N, S, z_per_layer_host, seed, dedup_layer0, true, &rows));
   const int nl = (int)model->layers.size();
   LayerState& H = *model->layers[nl - 1];
@@ -347,6 +349,11 @@ int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int 
   hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, ctx->stream, model->d_scal, model->d_scal + 40, c);
   LAUNCH_CHECK(ctx);
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scratch, model->d_scal + 40, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->timing) {   // host time to enqueue one step (everything before the wait), reported beside the kernel timers
+    auto& acc = ctx->tim["host_enqueue"];
+    acc.launches += 1;
+    acc.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+  }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   out_host[0] = ctx->h_scratch[0]; out_host[1] = ctx->h_scratch[1]; out_host[2] = ctx->h_scratch[2];
   if (ctx->timing && ctx->pending.size() > 512) timing_flush(ctx);   // both streams are drained here; resolve lazily
