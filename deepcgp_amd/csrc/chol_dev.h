@@ -91,32 +91,52 @@ __device__ __forceinline__ int wave_potrf32(double (&a)[NB], int r, double (&col
 // and the multipliers L[cc][c] the factorisation step has just put in registers, and is the same instruction stream
 // as the row update  a[cc] -= a[c] L[cc][c]  -- so the upper half of the wavefront, idle otherwise, delivers inv(L_jj)
 // with no additional instruction, LDS access or latency.  `col` is a 64-entry LDS line (upper half is a write sink).
+__device__ __forceinline__ double rcp_nr(double p) {
+  double r = __builtin_amdgcn_rcp(p);
+  r = fma(r, fma(-p, r, 1.0), r);
+  r = fma(r, fma(-p, r, 1.0), r);
+  return r;
+}
 __device__ __forceinline__ int wave_potrf_inv32(double (&v)[NB], int lane, double (&col)[2 * NB]) {
-  // Latency shaping: the column is published UNSCALED (it is final one step early) and read back while the
-  // pivot's reciprocal square root is still being refined; the update then uses  v[cc] -= (v[c]/piv) u[cc]  with the
-  // unscaled multipliers u, so the LDS round trip is off the 32-step critical path.  The entry the next step pivots
-  // on is updated -- and published -- first.
+  // Latency shaping.  (1) The 32-step recurrence never needs a square root: with the column kept UNSCALED,
+  //     v[cc] -= (v[c] / piv) u[cc]        (u = the unscaled column, piv = its diagonal entry)
+  // is the whole step, so the serial chain per step is readlane -> 1/piv -> one multiply -> the FMA that produces the
+  // next pivot.  All 1/sqrt(piv) scalings -- L[r][c] = v_r[c] / sqrt(piv_c), the inverse's x[c] / L_cc, the diagonal
+  // sqrt(piv) -- are applied once, after the loop, by 32 lanes in parallel.  (2) The column is final one step early
+  // and is published -- next pivot first -- while the previous step's other updates are still being issued, so the LDS
+  // round trip overlaps them.
   int fail = 0;
+  double mypiv = 1.0;
+  double ua[NB], ub[NB];   // unscaled column of the current / the next step (ping-pong: the reads for step c + 1 are
+                           // issued before the trailing updates of step c have consumed the current one)
   col[lane] = v[0];
 #pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    double u[NB];
+  for (int cc = 1; cc < NB; ++cc) ua[cc] = col[cc];
 #pragma unroll
-    for (int cc = c + 1; cc < NB; ++cc) u[cc] = col[cc];
+  for (int c = 0; c < NB; ++c) {
+    double (&u)[NB] = (c & 1) ? ub : ua;
+    double (&un)[NB] = (c & 1) ? ua : ub;
     const double piv = bcast_lane(v[c], c);
     if (!(piv > 0.0) && fail == 0) fail = c + 1;
-    const double y = rsqrt_nr(piv);
-    double d = piv * y;
-    d = fma(0.5 * y, fma(-d, d, piv), d);       // sqrt(piv) to ~1 ulp
-    const double t = v[c] * (y * y);
-    v[c] = (lane == c) ? d : v[c] * y;
+    mypiv = (lane == c) ? piv : mypiv;
+    const double t = v[c] * rcp_nr(piv);
     if (c + 1 < NB) {
       v[c + 1] = fma(-t, u[c + 1], v[c + 1]);
       col[lane] = v[c + 1];
+#pragma unroll
+      for (int cc = c + 2; cc < NB; ++cc) un[cc] = col[cc];
+      __builtin_amdgcn_sched_barrier(0);   // keep publish + read-back ahead of the trailing updates
     }
 #pragma unroll
     for (int cc = c + 2; cc < NB; ++cc) v[cc] = fma(-t, u[cc], v[cc]);
   }
+  // the deferred scalings: ys[c] = 1 / sqrt(piv_c) = 1 / L_cc
+  const double y = rsqrt_nr(mypiv);
+  double d = mypiv * y;
+  d = fma(0.5 * y, fma(-d, d, mypiv), d);       // sqrt(piv) to ~1 ulp
+  col[lane] = y;                                // lanes >= NB write the sink half
+#pragma unroll
+  for (int c = 0; c < NB; ++c) v[c] = (lane == c) ? d : v[c] * col[c];
   return fail;
 }
 // Column c of inv(L) for a 32x32 lower-triangular L held in LDS (D) with its reciprocal diagonal (Dr):
