@@ -40,20 +40,35 @@ struct RlArgs {
   int* info;
 };
 
+// The prologue loads are written as fully unrolled register batches (all global loads issued, then all LDS stores):
+// as rolled loops each iteration waited for its own load -- 4 + 8 + 8 serial memory latencies per workgroup.
 __device__ __forceinline__ void load_diag(const double* __restrict__ A, int ld, int j, int nb, double (*D)[NB + 1], int tid) {
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int r = idx / NB, c = idx % NB;
-    double v = (r == c) ? 1.0 : 0.0;
-    if (r < nb && c < nb && c <= r) v = A[(long)(j + r) * ld + j + c];
-    D[r][c] = v;
+  double t[NB * NB / 256];
+#pragma unroll
+  for (int e = 0; e < NB * NB / 256; ++e) {
+    const int idx = tid + e * 256, r = idx / NB, c = idx % NB;
+    t[e] = (r == c) ? 1.0 : 0.0;
+    if (r < nb && c < nb && c <= r) t[e] = A[(long)(j + r) * ld + j + c];
+  }
+#pragma unroll
+  for (int e = 0; e < NB * NB / 256; ++e) {
+    const int idx = tid + e * 256;
+    D[idx / NB][idx % NB] = t[e];
   }
 }
 // rows [r0, r0+64) of the panel columns -> U[64][33] (zero beyond the matrix)
 __device__ __forceinline__ void load_panel_rows(const double* __restrict__ A, int ld, int Mp, int j, int nb, int r0,
                                                 double (*U)[NB + 1], int tid) {
-  for (int idx = tid; idx < 64 * NB; idx += 256) {
-    const int i = idx / NB, c = idx % NB;
-    U[i][c] = (r0 + i < Mp && c < nb) ? A[(long)(r0 + i) * ld + j + c] : 0.0;
+  double t[64 * NB / 256];
+#pragma unroll
+  for (int e = 0; e < 64 * NB / 256; ++e) {
+    const int idx = tid + e * 256, i = idx / NB, c = idx % NB;
+    t[e] = (r0 + i < Mp && c < nb) ? A[(long)(r0 + i) * ld + j + c] : 0.0;
+  }
+#pragma unroll
+  for (int e = 0; e < 64 * NB / 256; ++e) {
+    const int idx = tid + e * 256;
+    U[idx / NB][idx % NB] = t[e];
   }
 }
 // P = U inv(L_jj)^T on the matrix cores (64 x 32 x 32): P[i][c] = sum_q U[i][q] X[c][q].  Wave (wm, wn) owns rows
@@ -146,12 +161,18 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
           }
     }
     // Y[j + q, c0 + c] before this step: stored values left of column j, identity inside [j, j+32), zero beyond
-    for (int idx = tid; idx < NB * 64; idx += 256) {
-      const int q = idx >> 6, c = idx & 63, gc = c0 + c;
-      double v = 0.0;
-      if (q < nb && gc < j) v = Y[(long)(j + q) * ld + gc];
-      else if (gc == j + q) v = 1.0;
-      Ts[q][c] = v;
+    double tt[NB * 64 / 256];
+#pragma unroll
+    for (int e = 0; e < NB * 64 / 256; ++e) {
+      const int idx = tid + e * 256, q = idx >> 6, c = idx & 63, gc = c0 + c;
+      tt[e] = 0.0;
+      if (q < nb && gc < j) tt[e] = Y[(long)(j + q) * ld + gc];
+      else if (gc == j + q) tt[e] = 1.0;
+    }
+#pragma unroll
+    for (int e = 0; e < NB * 64 / 256; ++e) {
+      const int idx = tid + e * 256;
+      Ts[idx >> 6][idx & 63] = tt[e];
     }
   }
   __syncthreads();
