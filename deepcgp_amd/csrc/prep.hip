@@ -18,8 +18,9 @@ __device__ void gram_task(const PrepLayerArgs& p, const double* __restrict__ Z, 
     double dot = 0.0, ni = 0.0, nj = 0.0;
     for (int l0 = 0; l0 < p.L; l0 += 32) {
       __syncthreads();
-      for (int idx = threadIdx.x; idx < 16 * 32; idx += 256) {
-        const int r = idx >> 5, c = idx & 31;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {   // 512 elements of each operand: both loads of both halves in flight together
+        const int idx = threadIdx.x + e * 256, r = idx >> 5, c = idx & 31;
         Zi[r][c] = (i0 + r < p.M && l0 + c < p.L) ? Z[(long)(i0 + r) * p.L + l0 + c] : 0.0;
         Zj[r][c] = (j0 + r < p.M && l0 + c < p.L) ? Z[(long)(j0 + r) * p.L + l0 + c] : 0.0;
       }
@@ -86,12 +87,26 @@ __global__ __launch_bounds__(256) void prepare_all_kernel(PrepArgs a) {
     case 2: transpose_task(p, bx, nbx); break;
     case 3:
       if (p.q_sqrt) {
-        const long total = (long)p.R * p.Mp * p.Mp;
-        for (long idx = (long)bx * 256 + threadIdx.x; idx < total; idx += (long)nbx * 256) {
-          const int j = (int)(idx % p.Mp);
-          const long t = idx / p.Mp;
-          const int i = (int)(t % p.Mp), r = (int)(t / p.Mp);
-          p.Lq[idx] = (i < p.M && j <= i) ? p.q_sqrt[((long)r * p.M + i) * p.M + j] : 0.0;
+        // batches of 8 loads per thread, then 8 stores: a rolled copy loop waits one memory latency per element
+        const long total = (long)p.R * p.Mp * p.Mp, stride = (long)nbx * 256;
+        for (long base = (long)bx * 256 + threadIdx.x; base < total; base += 8 * stride) {
+          double t8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const long idx = base + e * stride;
+            t8[e] = 0.0;
+            if (idx < total) {
+              const int j = (int)(idx % p.Mp);
+              const long t = idx / p.Mp;
+              const int i = (int)(t % p.Mp), r = (int)(t / p.Mp);
+              if (i < p.M && j <= i) t8[e] = p.q_sqrt[((long)r * p.M + i) * p.M + j];
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const long idx = base + e * stride;
+            if (idx < total) p.Lq[idx] = t8[e];
+          }
         }
       }
       break;

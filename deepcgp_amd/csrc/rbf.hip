@@ -122,7 +122,20 @@ __global__ __launch_bounds__(256, 4) void patch_rbf_kernel(PatchRbfArgs a) {
   const int n = blockIdx.z, m0 = blockIdx.y * PR_BM;
 
   const double* __restrict__ Xn = a.X + (long)(n % a.n_mod) * HWC;
-  for (int i = tid; i < HWC; i += 256) img[i] = Xn[i];
+  // image -> LDS in batches of 8 loads per thread: a rolled loop waits one memory latency per iteration
+  for (int i0 = 0; i0 < HWC; i0 += 8 * 256) {
+    double t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = i0 + e * 256 + tid;
+      t[e] = (i < HWC) ? Xn[i] : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = i0 + e * 256 + tid;
+      if (i < HWC) img[i] = t[e];
+    }
+  }
   for (int l = tid; l < a.Lp; l += 256) {
     int ll = l < a.L ? l : 0;
     int c = ll % a.C, t = ll / a.C;
@@ -263,7 +276,20 @@ __global__ __launch_bounds__(256, 4) void head_kdiag_kernel(const double* __rest
   const int tc = tr + pair;
 
   const double* __restrict__ Xn = X + (long)(n % n_mod) * HWC;
-  for (int i = tid; i < HWC; i += 256) img[i] = Xn[i];
+  // image -> LDS in batches of 8 loads per thread: a rolled loop waits one memory latency per iteration
+  for (int i0 = 0; i0 < HWC; i0 += 8 * 256) {
+    double t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = i0 + e * 256 + tid;
+      t[e] = (i < HWC) ? Xn[i] : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = i0 + e * 256 + tid;
+      if (i < HWC) img[i] = t[e];
+    }
+  }
   for (int l = tid; l < Lp; l += 256) {
     int ll = l < L ? l : 0;
     int c = ll % C, t = ll / C;
