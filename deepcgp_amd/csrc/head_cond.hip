@@ -153,6 +153,86 @@ __global__ __launch_bounds__(1024, 4) void head_cond_kernel(HeadCondArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The conditional's small operands for every layer in ONE launch:  G_r = inv(L) Lq_r  (r < R) and alpha = inv(L) q_mu.
+// Same structure as stage 1 above -- a 16-column strip of the right-hand side LDS-resident, each wave streaming its
+// own 16 columns of inv(L)^T -- with the product stored instead of reduced.  grid (Mp/16 strips, R + 1, layers):
+// y < R: strip x of Lq_r (lower triangular: k-tiles above the strip are structurally zero and skipped),
+// y == R: q_mu (x == 0 only).  The generic route was two latency-bound GEMM launches per layer (17 + 31 us at cfg2).
+struct PrepSolveLayer {
+  const double* LinvT; const double* Lq; const double* qmu; double* G; double* alpha;
+  int Mp, R, Rp, active;   // active == 0: whitened layer (G / alpha alias Lq / q_mu) or larger than HC_MP
+};
+struct PrepSolveArgs { PrepSolveLayer l[8]; };
+
+__global__ __launch_bounds__(1024, 4) void prep_solve_kernel(PrepSolveArgs args) {
+  __shared__ __attribute__((aligned(16))) double Bt[HC_MP * HC_BN];   // [k][16]
+  const PrepSolveLayer& a = args.l[blockIdx.z];
+  if (!a.active) return;
+  const int Mp = a.Mp;
+  const int strip = blockIdx.x, y = blockIdx.y;
+  const bool is_alpha = y == a.R;
+  if (y > a.R || strip * HC_BN >= (is_alpha ? a.Rp : Mp) || (!is_alpha && !a.Lq)) return;
+  const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i0 = wave * 16;
+  const bool live = i0 < Mp;
+  const double* __restrict__ B = is_alpha ? a.qmu : a.Lq + (long)y * Mp * Mp;
+  const int ldb = is_alpha ? a.Rp : Mp;
+  double* __restrict__ C = is_alpha ? a.alpha : a.G + (long)y * Mp * Mp;
+  const int c0 = strip * HC_BN;
+  const int kt_lo = is_alpha ? 0 : c0 / HC_BK;   // Lq lower triangular: rows k < c0 of the strip are zero
+
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(B), 0, Mp * ldb * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.LinvT), 0, Mp * Mp * 8, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  {
+    const int rl = lane >> 3, cl = (lane & 7) * 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = wave * 2 + h, row = q * 8 + rl;
+      const unsigned off = (row < Mp) ? (unsigned)((row * ldb + c0 + cl) * 8) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_ptr)(Bt + q * 8 * HC_BN), 16, (int)off, 0, 0, 0);
+    }
+  }
+  unsigned woff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) woff[q] = live ? (unsigned)(((4 * q + lrow) * Mp + i0 + lcol) * 8) : OOB;
+  auto ldw = [&](int kt, double (&dst)[4]) {
+    const int so = kt * HC_BK * Mp * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(lrs, (int)woff[q], so, 0);
+      __builtin_memcpy(&dst[q], &v, 8);
+    }
+  };
+  d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+  __syncthreads();   // strip resident
+  const int lo = kt_lo, hi = wave + 1;   // inv(L) lower triangular: k <= i
+  if (live && lo < hi) {
+    double wb[HC_D + 1][4];
+#pragma unroll
+    for (int u = 0; u < HC_D; ++u) ldw(min(lo + u, hi - 1), wb[u]);
+    for (int kt = lo; kt < hi; kt += HC_D + 1) {
+#pragma unroll
+      for (int u = 0; u <= HC_D; ++u) {
+        if (kt + u < hi) {
+          ldw(min(kt + u + HC_D, hi - 1), wb[(u + HC_D) % (HC_D + 1)]);
+          const double* b = Bt + (kt + u) * HC_BK * HC_BN + lcol;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wb[u][q], b[(4 * q + lrow) * HC_BN], acc, 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) C[(long)(i0 + lrow + 4 * v) * ldb + c0 + lcol] = acc[v];
+  }
+}
+
 }  // namespace
 
 bool head_cond_fused_ok(const GpMats& g) { return g.Mp <= HC_MP && g.Mp % HC_BK == 0; }
@@ -170,6 +250,26 @@ int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, i
   a.kd = kd; a.Mp = g.Mp; a.R = g.R;
   a.out_mean = out_mean; a.out_var = out_var;
   hipLaunchKernelGGL(head_cond_kernel, dim3((Kc + HC_BN - 1) / HC_BN, g.R), dim3(1024), 0, ctx->stream, a);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
+// G / alpha of up to 8 layers in one launch (replaces cond_prep for unwhitened layers with M <= 256)
+int prep_solve_all(dcgp_ctx* ctx, GpMats* const* gs, const int* white, const bool* have_qsqrt, int nl, bool* done) {
+  PrepSolveArgs a;
+  int any = 0, maxMp = 0, maxR = 0;
+  for (int i = 0; i < nl && i < 8; ++i) {
+    const GpMats& g = *gs[i];
+    PrepSolveLayer& l = a.l[i];
+    l.active = (!white[i] && head_cond_fused_ok(g) && g.Rp == HC_BN) ? 1 : 0;
+    done[i] = l.active != 0;
+    l.LinvT = g.LinvT; l.Lq = have_qsqrt[i] ? g.Lq : nullptr; l.qmu = g.qmu; l.G = g.G; l.alpha = g.alpha;
+    l.Mp = g.Mp; l.R = g.R; l.Rp = g.Rp;
+    if (l.active) { any = 1; maxMp = g.Mp > maxMp ? g.Mp : maxMp; maxR = g.R > maxR ? g.R : maxR; }
+  }
+  if (!any) return DCGP_OK;
+  ScopedTimer t(ctx, "prep_solve");
+  hipLaunchKernelGGL(prep_solve_kernel, dim3(maxMp / HC_BN, maxR + 1, nl < 8 ? nl : 8), dim3(1024), 0, ctx->stream, a);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }

@@ -57,6 +57,9 @@ bool head_cond_fused_ok(const GpMats& g);
 int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, bool have_qsqrt, const double* kd,
                     double* out_mean, double* out_var);
 
+// head_cond.hip: G / alpha of every layer in one launch; done[i] = false where layer i still needs cond_prep
+int prep_solve_all(dcgp_ctx* ctx, GpMats* const* gs, const int* white, const bool* have_qsqrt, int nl, bool* done);
+
 struct FinalizeArgs {
   const double* s1p = nullptr; int nrb1 = 0;
   const double* s2p = nullptr; int nrb3 = 0;    // nullptr -> no q_sqrt term

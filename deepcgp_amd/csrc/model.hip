@@ -204,8 +204,14 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     if ((rc = gr.run(ctx)) != DCGP_OK) break;
   if (rc == DCGP_OK && hipEventRecord(ctx->ev_factor, ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
   // G_r = inv(L) Lq_r and alpha = inv(L) q_mu of every layer (cond_prep): gate the second conditional GEMM
+  bool prep_done[8] = {};
+  if (rc == DCGP_OK) {   // every layer the one-launch route covers (unwhitened, M <= 256, <= 16 outputs): head_cond.hip
+    GpMats* gs[8]; int wh[8]; bool hq[8];
+    for (int li = 0; li < nl; ++li) { gs[li] = &m->layers[li]->g; wh[li] = m->layers[li]->white; hq[li] = m->layers[li]->has_qsqrt; }
+    rc = prep_solve_all(ctx, gs, wh, hq, nl, prep_done);
+  }
   for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
-    rc = cond_prep(ctx, m->layers[li]->g, m->layers[li]->white, m->layers[li]->has_qsqrt);
+    if (!prep_done[li]) rc = cond_prep(ctx, m->layers[li]->g, m->layers[li]->white, m->layers[li]->has_qsqrt);   // generic GEMMs
     if (rc == DCGP_OK && hipEventRecord(ctx->ev_prep[li], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;   // per layer: layer 0 does not wait for the others
   }
   if (rc == DCGP_OK && need_kl) {
