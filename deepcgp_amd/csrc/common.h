@@ -104,6 +104,27 @@ struct GemmArgs {
 int gemm_tn(dcgp_ctx* ctx, const GemmArgs& a, int* n_row_blocks_out);
 int gemm_row_block(int Mi, int Kc, int batch);   // BM the dispatcher picks (callers size partial-sum buffers with it)
 
+// The base kernel of a layer, evaluated from (x.z, |x|^2, |z|^2):
+//   type 0  gpflow RBF:           variance * exp(-(|x|^2 + |z|^2 - 2 x.z) / (2 l^2))     p1 = 1 / l^2 (square_dist form, no clamp)
+//   type 1  gpflow ArcCosine(0):  variance * (pi - theta) / pi,  theta = acos(1e-15 + (1 - 2e-15) cos),
+//           cos = (w x.z + b) / sqrt((w |x|^2 + b)(w |z|^2 + b)), argument clamped to <= 1    p1 = w (weight variance), p2 = b (bias variance)
+//   (conv_gp/models.py:113-121: --base-kernel rbf | acos; Kdiag = variance for both)
+struct BaseKernel {
+  int type = 0;
+  double variance = 1.0, p1 = 1.0, p2 = 0.0;
+  template <int T>   // the hot sweeps are instantiated per type: the acos code must not cost the RBF path registers
+  __host__ __device__ __forceinline__ double eval_as(double dot, double n1, double n2) const {
+    if (T == 0) return variance * exp(-0.5 * (n1 + n2 - 2.0 * dot) * p1);
+    const double c = (p1 * dot + p2) / sqrt((p1 * n1 + p2) * (p1 * n2 + p2));
+    // fmin: on a diagonal entry cos can round a few ulp above 1 (dot and norms are accumulated in different orders)
+    // and overshoot the reference's 1e-15 guard -- acos() would return NaN there, as the reference formula does
+    return variance * (1.0 - acos(fmin(1e-15 + (1.0 - 2e-15) * c, 1.0)) * 0.31830988618379067154);
+  }
+  __host__ __device__ __forceinline__ double eval(double dot, double n1, double n2) const {
+    return type == 0 ? eval_as<0>(dot, n1, n2) : eval_as<1>(dot, n1, n2);
+  }
+};
+
 // patch-RBF sweep (kuf / head Kzx)
 struct PatchRbfArgs {
   const double* X = nullptr;   // [n_mod, H, W, C]; image of column block n is X[n % n_mod]
@@ -112,7 +133,7 @@ struct PatchRbfArgs {
   const double* ZT = nullptr;  // [Lp, Mp] k-major, zero padded
   const double* zn = nullptr;  // [Mp] |z|^2 (unscaled)
   int M = 0, Mp = 0, Lp = 0;
-  double variance = 1, inv_l2 = 1;
+  BaseKernel bk;
   // write mode: out[m*sM + n*sN + p*sP]
   double* out = nullptr; long sM = 0, sN = 0, sP = 0;
   // reduce mode (head Kzx): out[m*sM + n*sN] = scale * sum_p w[p] k
@@ -121,11 +142,11 @@ struct PatchRbfArgs {
   int share_cu = 0;
 };
 int patch_rbf(dcgp_ctx* ctx, const PatchRbfArgs& a, const char* timer_name);
-int head_kdiag(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, int C, int f, int s, double variance,
-               double inv_l2, const double* w, double* out_N);
+int head_kdiag(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, int C, int f, int s, BaseKernel bk,
+               const double* w, double* out_N);
 
 // small-matrix helpers (rbf.hip / chol.hip / misc.hip)
-int rbf_gram_padded(dcgp_ctx* ctx, const double* Z, int M, int L, double variance, double inv_l2, double jitter,
+int rbf_gram_padded(dcgp_ctx* ctx, const double* Z, int M, int L, BaseKernel bk, double jitter,
                     double* out, int ld, int Mp);                       // out [Mp, ld], pad diag = 1
 int z_transpose_norms(dcgp_ctx* ctx, const double* Z, int M, int L, double* ZT, int Mp, int Lp, double* zn);
 int potrf_batched(dcgp_ctx* ctx, double* const* d_ptrs, double** h_ptrs, int batch, int Mp, int ld,

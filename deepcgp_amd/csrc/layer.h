@@ -32,7 +32,7 @@ struct PrepLayerArgs {
   const double *Z = nullptr, *Z0 = nullptr, *q_sqrt = nullptr, *q_mu = nullptr;
   double *K = nullptr, *Kp = nullptr, *ZT = nullptr, *zn = nullptr, *Lq = nullptr, *qmu = nullptr;
   int M = 0, Mp = 0, L = 0, Lp = 0, R = 0, Rp = 0;
-  double variance = 1.0, inv_l2 = 1.0, jitter = 0.0;
+  BaseKernel bk; double jitter = 0.0;
 };
 struct PrepArgs {
   int nl = 0;

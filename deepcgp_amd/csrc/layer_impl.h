@@ -20,6 +20,14 @@ struct LayerState {
   int M = 0, Mp = 0, R = 0, Lp = 0;
   int white = 0, identity_mean = 0, kernel_type = 0;
   double variance = 1.0, ls = 1.0;
+  int base_type = 0;             // 0: RBF(variance, ls); 1: ArcCosine order 0 (variance, weight variance = acos_w, bias variance = acos_b)
+  double acos_w = 1.0, acos_b = 1.0;
+  BaseKernel base() const {
+    BaseKernel b;
+    b.type = base_type; b.variance = variance;
+    if (base_type == 0) { b.p1 = 1.0 / (ls * ls); b.p2 = 0.0; } else { b.p1 = acos_w; b.p2 = acos_b; }
+    return b;
+  }
   bool has_qsqrt = true;
   // parameters in the caller's layout (device)
   double *Z = nullptr, *Z0 = nullptr, *q_mu = nullptr, *q_sqrt = nullptr, *w = nullptr;
@@ -77,14 +85,13 @@ struct LayerState {
     p.Z = Z; p.Z0 = Z0; p.q_sqrt = has_qsqrt ? q_sqrt : nullptr; p.q_mu = q_mu;
     p.K = g.K; p.Kp = g.Kp; p.ZT = ZT; p.zn = zn; p.Lq = g.Lq; p.qmu = g.qmu;
     p.M = M; p.Mp = Mp; p.L = v.L; p.Lp = Lp; p.R = R; p.Rp = g.Rp;
-    p.variance = variance; p.inv_l2 = 1.0 / (ls * ls); p.jitter = jitter;
+    p.bk = base(); p.jitter = jitter;
     return p;
   }
   // step 1 of the forward: everything that depends only on this layer's parameters
   int prepare(double jitter) {
-    const double inv_l2 = 1.0 / (ls * ls);
-    DCGP_TRY(rbf_gram_padded(ctx, Z, M, v.L, variance, inv_l2, jitter, g.K, Mp, Mp));
-    if (g.Kp) DCGP_TRY(rbf_gram_padded(ctx, Z0, M, v.L, variance, inv_l2, jitter, g.Kp, Mp, Mp));
+    DCGP_TRY(rbf_gram_padded(ctx, Z, M, v.L, base(), jitter, g.K, Mp, Mp));
+    if (g.Kp) DCGP_TRY(rbf_gram_padded(ctx, Z0, M, v.L, base(), jitter, g.Kp, Mp, Mp));
     DCGP_TRY(z_transpose_norms(ctx, Z, M, v.L, ZT, Mp, Lp, zn));
     if (has_qsqrt)
       DCGP_TRY(pad_copy(ctx, q_sqrt, M, M, M, g.Lq, Mp, Mp, Mp, 1, R, (long)M * M, (long)Mp * Mp));
@@ -151,7 +158,7 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   a.X = X; a.N = rows; a.n_mod = n_mod;
   a.H = L.v.H; a.W = L.v.W; a.C = L.v.C; a.f = L.v.f; a.s = L.v.s; a.Ho = L.v.Ho; a.Wo = L.v.Wo; a.P = P; a.L = L.v.L;
   a.ZT = L.ZT; a.zn = L.zn; a.M = L.M; a.Mp = Mp; a.Lp = L.Lp;
-  a.variance = L.variance; a.inv_l2 = 1.0 / (L.ls * L.ls);
+  a.bk = L.base();
   a.out = B; a.sM = ldb; a.sN = P; a.sP = 1;
   a.share_cu = phase == 1;
   if (phase & 1) DCGP_TRY(patch_rbf(ctx, a, "kuf"));
@@ -180,12 +187,11 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   double* B = (double*)ws_get(ctx, pfx + "Kzx", (size_t)Mp * ldb * sizeof(double));
   if (!B) return DCGP_ERR_ALLOC;
   if ((phase & 1) && Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));
-  const double inv_l2 = 1.0 / (L.ls * L.ls);
   PatchRbfArgs a;
   a.X = X; a.N = rows; a.n_mod = n_mod;
   a.H = L.v.H; a.W = L.v.W; a.C = L.v.C; a.f = L.v.f; a.s = L.v.s; a.Ho = L.v.Ho; a.Wo = L.v.Wo; a.P = L.v.P; a.L = L.v.L;
   a.ZT = L.ZT; a.zn = L.zn; a.M = L.M; a.Mp = Mp; a.Lp = L.Lp;
-  a.variance = L.variance; a.inv_l2 = inv_l2;
+  a.bk = L.base();
   a.out = B; a.sM = ldb; a.sN = 1; a.sP = 0;
   a.w = L.w; a.scale = 1.0 / (double)L.v.P; a.reduce = 1;
   a.share_cu = phase == 1;
@@ -202,7 +208,7 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     }
     int rc;
     if (L.kernel_type == 0) {
-      rc = head_kdiag(ctx, X, rows, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s, L.variance, inv_l2, L.w, kd);
+      rc = head_kdiag(ctx, X, rows, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s, L.base(), L.w, kd);
     } else {
       rc = additive_kdiag_async(ctx, rows, L.v.P, L.variance, L.w, kd);
     }

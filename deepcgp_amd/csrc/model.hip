@@ -324,6 +324,16 @@ int dcgp_model_set_param(dcgp_model* model, int layer, const char* which, const 
   }
   if (!strcmp(which, "variance")) { DCGP_TRY(expect(1)); if (!(value_host[0] > 0)) return ctx_fail(ctx, DCGP_ERR_ARG, "variance must be > 0"); L.variance = value_host[0]; return DCGP_OK; }
   if (!strcmp(which, "lengthscale")) { DCGP_TRY(expect(1)); if (!(value_host[0] > 0)) return ctx_fail(ctx, DCGP_ERR_ARG, "lengthscale must be > 0"); L.ls = value_host[0]; return DCGP_OK; }
+  if (!strcmp(which, "base_kernel")) {   // {type, variance, p1, p2}: 0 = RBF (p1 = lengthscale), 1 = ArcCosine order 0 (p1 = weight, p2 = bias variance)
+    DCGP_TRY(expect(4));
+    const int type = (int)value_host[0];
+    if ((type != 0 && type != 1) || !(value_host[1] > 0) || !(value_host[2] > 0) || (type == 1 && !(value_host[3] >= 0)))
+      return ctx_fail(ctx, DCGP_ERR_ARG, "set_param(base_kernel): bad kernel description");
+    if (type == 1 && L.is_head) return ctx_fail(ctx, DCGP_ERR_ARG, "set_param(base_kernel): the head kernels are RBF-based (conv_gp/models.py:160-187)");
+    L.base_type = type; L.variance = value_host[1];
+    if (type == 0) L.ls = value_host[2]; else { L.acos_w = value_host[2]; L.acos_b = value_host[3]; }
+    return DCGP_OK;
+  }
   return ctx_fail(ctx, DCGP_ERR_ARG, "set_param: unknown parameter '%s'", which);
 }
 

@@ -101,12 +101,34 @@ int additive_kdiag_async(dcgp_ctx* ctx, int N, int P, double variance, const dou
 
 extern "C" {
 
+static BaseKernel rbf_bk(double variance, double lengthscale) {
+  BaseKernel b;
+  b.type = 0; b.variance = variance; b.p1 = 1.0 / (lengthscale * lengthscale); b.p2 = 0.0;
+  return b;
+}
+static BaseKernel acos_bk(double variance, double weight_variance, double bias_variance) {
+  BaseKernel b;
+  b.type = 1; b.variance = variance; b.p1 = weight_variance; b.p2 = bias_variance;
+  return b;
+}
+static int kuu_impl(dcgp_ctx* ctx, const double* Z, int M, int L, BaseKernel bk, double jitter, double* out_MM) {
+  DCGP_TRY(rbf_gram_padded(ctx, Z, M, L, bk, jitter, out_MM, M, M));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}
+static int kuf_impl(dcgp_ctx* ctx, const double* X, int N, int H, int W, int C, int f, int stride, const double* Z, int M,
+                    BaseKernel bk, double* out, int layout);
+
 int dcgp_kuu_rbf(dcgp_ctx* ctx, const double* Z, int M, int L, double variance, double lengthscale, double jitter,
                  double* out_MM) {
   ARG_CHECK(ctx && Z && out_MM && M > 0 && L > 0 && variance > 0 && lengthscale > 0, "kuu_rbf: bad args");
-  DCGP_TRY(rbf_gram_padded(ctx, Z, M, L, variance, 1.0 / (lengthscale * lengthscale), jitter, out_MM, M, M));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return DCGP_OK;
+  return kuu_impl(ctx, Z, M, L, rbf_bk(variance, lengthscale), jitter, out_MM);
+}
+
+int dcgp_kuu_acos(dcgp_ctx* ctx, const double* Z, int M, int L, double variance, double weight_variance, double bias_variance,
+                  double jitter, double* out_MM) {
+  ARG_CHECK(ctx && Z && out_MM && M > 0 && L > 0 && variance > 0 && weight_variance > 0 && bias_variance >= 0, "kuu_acos: bad args");
+  return kuu_impl(ctx, Z, M, L, acos_bk(variance, weight_variance, bias_variance), jitter, out_MM);
 }
 
 int dcgp_kuf_patches_rbf(dcgp_ctx* ctx, const double* X, int N, int H, int W, int C, int f, int stride, const double* Z,
@@ -114,6 +136,19 @@ int dcgp_kuf_patches_rbf(dcgp_ctx* ctx, const double* X, int N, int H, int W, in
   ARG_CHECK(ctx && X && Z && out && N > 0 && M > 0 && f > 0 && stride > 0 && f <= H && f <= W && C > 0 && variance > 0 &&
                 lengthscale > 0 && (layout == 0 || layout == 1),
             "kuf_patches_rbf: bad args");
+  return kuf_impl(ctx, X, N, H, W, C, f, stride, Z, M, rbf_bk(variance, lengthscale), out, layout);
+}
+
+int dcgp_kuf_patches_acos(dcgp_ctx* ctx, const double* X, int N, int H, int W, int C, int f, int stride, const double* Z,
+                          int M, double variance, double weight_variance, double bias_variance, double* out, int layout) {
+  ARG_CHECK(ctx && X && Z && out && N > 0 && M > 0 && f > 0 && stride > 0 && f <= H && f <= W && C > 0 && variance > 0 &&
+                weight_variance > 0 && bias_variance >= 0 && (layout == 0 || layout == 1),
+            "kuf_patches_acos: bad args");
+  return kuf_impl(ctx, X, N, H, W, C, f, stride, Z, M, acos_bk(variance, weight_variance, bias_variance), out, layout);
+}
+
+static int kuf_impl(dcgp_ctx* ctx, const double* X, int N, int H, int W, int C, int f, int stride, const double* Z, int M,
+                    BaseKernel bk, double* out, int layout) {
   ViewGeom v;
   v.set(H, W, C, f, stride);
   const int Mp = round_up(M, 16), Lp = round_up(v.L, 4);
@@ -125,7 +160,7 @@ int dcgp_kuf_patches_rbf(dcgp_ctx* ctx, const double* X, int N, int H, int W, in
   a.X = X; a.N = N; a.n_mod = N;
   a.H = H; a.W = W; a.C = C; a.f = f; a.s = stride; a.Ho = v.Ho; a.Wo = v.Wo; a.P = v.P; a.L = v.L;
   a.ZT = ZT; a.zn = zn; a.M = M; a.Mp = Mp; a.Lp = Lp;
-  a.variance = variance; a.inv_l2 = 1.0 / (lengthscale * lengthscale);
+  a.bk = bk;
   a.out = out;
   if (layout == 0) { a.sP = (long)M * N; a.sM = N; a.sN = 1; }
   else { a.sM = (long)N * v.P; a.sN = v.P; a.sP = 1; }
@@ -270,7 +305,7 @@ int dcgp_convkernel_kzx(dcgp_ctx* ctx, const double* X, int N, int H, int W, int
   a.X = X; a.N = N; a.n_mod = N;
   a.H = H; a.W = W; a.C = C; a.f = f; a.s = stride; a.Ho = v.Ho; a.Wo = v.Wo; a.P = v.P; a.L = v.L;
   a.ZT = ZT; a.zn = zn; a.M = M; a.Mp = Mp; a.Lp = Lp;
-  a.variance = variance; a.inv_l2 = 1.0 / (lengthscale * lengthscale);
+  a.bk = rbf_bk(variance, lengthscale);
   a.out = out_MN; a.sM = N; a.sN = 1; a.sP = 0;
   a.w = w; a.scale = 1.0 / (double)v.P; a.reduce = 1;
   DCGP_TRY(patch_rbf(ctx, a, "head_kzx"));
@@ -282,7 +317,7 @@ int dcgp_convkernel_kdiag(dcgp_ctx* ctx, const double* X, int N, int H, int W, i
                           double lengthscale, const double* w, double* out_N) {
   ARG_CHECK(ctx && X && w && out_N && N > 0 && f > 0 && stride > 0 && f <= H && f <= W && C > 0 && variance > 0 &&
                 lengthscale > 0, "convkernel_kdiag: bad args");
-  DCGP_TRY(head_kdiag(ctx, X, N, N, H, W, C, f, stride, variance, 1.0 / (lengthscale * lengthscale), w, out_N));
+  DCGP_TRY(head_kdiag(ctx, X, N, N, H, W, C, f, stride, rbf_bk(variance, lengthscale), w, out_N));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return DCGP_OK;
 }

@@ -37,7 +37,7 @@ __device__ void gram_task(const PrepLayerArgs& p, const double* __restrict__ Z, 
     if (i < p.Mp && j < p.Mp) {
       double v = 0.0;
       if (i < p.M && j < p.M) {
-        v = p.variance * exp(-0.5 * (ni + nj - 2.0 * dot) * p.inv_l2);   // GPflow square_dist form, no clamp
+        v = p.bk.eval(dot, ni, nj);
         if (i == j) v += p.jitter;
       } else if (i == j) {
         v = 1.0;   // identity on the padding keeps the padded matrix factorisable

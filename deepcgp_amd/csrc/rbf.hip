@@ -19,8 +19,8 @@ namespace {
 // Kuu
 // ---------------------------------------------------------------------------------------------
 // 32x32 output tile per 256-thread block; Z rows staged through LDS in chunks of 32 columns.
-__global__ __launch_bounds__(256) void rbf_gram_kernel(const double* __restrict__ Z, int M, int L, double variance,
-                                                       double inv_l2, double jitter, double* __restrict__ out, int ld,
+__global__ __launch_bounds__(256) void rbf_gram_kernel(const double* __restrict__ Z, int M, int L, BaseKernel bk,
+                                                       double jitter, double* __restrict__ out, int ld,
                                                        int Mp) {
   __shared__ double Zi[32][33], Zj[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // ty in 0..7
@@ -52,8 +52,7 @@ __global__ __launch_bounds__(256) void rbf_gram_kernel(const double* __restrict_
     if (i >= Mp || j >= ld) continue;
     double v = 0.0;
     if (i < M && j < M) {
-      double d2 = (ni[q] + nj - 2.0 * dot[q]) * inv_l2;   // GPflow square_dist form, no clamp
-      v = variance * exp(-0.5 * d2);
+      v = bk.eval(dot[q], ni[q], nj);
       if (i == j) v += jitter;
     } else if (i == j) {
       v = 1.0;   // identity on the padding so that factorisations of the padded matrix stay valid
@@ -108,6 +107,7 @@ __device__ __forceinline__ int patch_base(int p, int P, int Wo, int s, int W, in
 }
 
 // grid: (p tiles [write mode] or 1 [reduce mode], Mp/64, N); block 256 = 4 waves as 2 (m) x 2 (p)
+template <int BT>
 __global__ __launch_bounds__(256, 4) void patch_rbf_kernel(PatchRbfArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int HWC = a.H * a.W * a.C;
@@ -215,8 +215,7 @@ __global__ __launch_bounds__(256, 4) void patch_rbf_kernel(PatchRbfArgs a) {
 #pragma unroll
         for (int y = 0; y < 2; ++y) {
           const int p = p0 + y * 16 + lcol;
-          double d2 = (znm + xn[y] - 2.0 * acc[x][y][v]) * a.inv_l2;
-          double kv = a.variance * exp(-0.5 * d2);
+          const double kv = a.bk.template eval_as<BT>(acc[x][y][v], xn[y], znm);
           if (a.reduce) {
             if (p < a.P) rsum[x][v] += a.w[p] * kv;
           } else if (m < a.M && p < a.P) {
@@ -252,9 +251,10 @@ __global__ __launch_bounds__(256, 4) void patch_rbf_kernel(PatchRbfArgs a) {
 // ConvKernel.Kdiag: per image sum_{p,p'} w_p w_p' k(x_p, x_p') / P^2, upper triangle of 64x64 patch
 // tile pairs (symmetry: off-diagonal pairs count twice).  grid (pairs, N); partial[n][pair].
 // ---------------------------------------------------------------------------------------------
+template <int BT>
 __global__ __launch_bounds__(256, 4) void head_kdiag_kernel(const double* __restrict__ X, int n_mod, int H, int W, int C, int f,
-                                                          int s, int Ho, int Wo, int P, int L, double variance,
-                                                          double inv_l2, const double* __restrict__ w,
+                                                          int s, int Ho, int Wo, int P, int L, BaseKernel bk,
+                                                          const double* __restrict__ w,
                                                           double* __restrict__ partial, int n_pairs, int p_tiles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int HWC = H * W * C;
@@ -355,8 +355,7 @@ __global__ __launch_bounds__(256, 4) void head_kdiag_kernel(const double* __rest
         const int qc = wn * 32 + y * 16 + lcol;
         const int pc = tc * 64 + qc;
         if (p < P && pc < P) {
-          double d2 = (xn[ql] + xn[64 + qc] - 2.0 * acc[x][y][v]) * inv_l2;
-          sum += w[p] * w[pc] * variance * exp(-0.5 * d2);
+          sum += w[p] * w[pc] * bk.template eval_as<BT>(acc[x][y][v], xn[ql], xn[64 + qc]);
         }
       }
     }
@@ -399,10 +398,10 @@ __global__ void extract_patches_kernel(const double* __restrict__ X, int N, int 
 
 }  // namespace
 
-int rbf_gram_padded(dcgp_ctx* ctx, const double* Z, int M, int L, double variance, double inv_l2, double jitter,
+int rbf_gram_padded(dcgp_ctx* ctx, const double* Z, int M, int L, BaseKernel bk, double jitter,
                     double* out, int ld, int Mp) {
   dim3 grid((ld + 31) / 32, (Mp + 31) / 32);
-  hipLaunchKernelGGL(rbf_gram_kernel, grid, dim3(256), 0, ctx->stream, Z, M, L, variance, inv_l2, jitter, out, ld, Mp);
+  hipLaunchKernelGGL(rbf_gram_kernel, grid, dim3(256), 0, ctx->stream, Z, M, L, bk, jitter, out, ld, Mp);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }
@@ -430,13 +429,14 @@ int patch_rbf(dcgp_ctx* ctx, const PatchRbfArgs& a, const char* timer_name) {
   const int p_tiles = (a.P + PR_BP - 1) / PR_BP;
   dim3 grid(a.reduce ? 1 : p_tiles, (a.Mp + PR_BM - 1) / PR_BM, a.N);
   ScopedTimer t(ctx, timer_name);
-  hipLaunchKernelGGL(patch_rbf_kernel, grid, dim3(256), lds, ctx->stream, a);
+  if (a.bk.type == 0) hipLaunchKernelGGL(patch_rbf_kernel<0>, grid, dim3(256), lds, ctx->stream, a);
+  else hipLaunchKernelGGL(patch_rbf_kernel<1>, grid, dim3(256), lds, ctx->stream, a);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }
 
-int head_kdiag(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, int C, int f, int s, double variance,
-               double inv_l2, const double* w, double* out_N) {
+int head_kdiag(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, int C, int f, int s, BaseKernel bk,
+               const double* w, double* out_N) {
   const int Ho = (H - f) / s + 1, Wo = (W - f) / s + 1, P = Ho * Wo, L = f * f * C;
   const int p_tiles = (P + 63) / 64, n_pairs = p_tiles * (p_tiles + 1) / 2;
   const int HWC = H * W * C, Lp = (L + 3) & ~3;
@@ -445,8 +445,12 @@ int head_kdiag(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, i
   size_t lds = (size_t)(((HWC + 1) & ~1) + 128 + 4) * sizeof(double) + (size_t)Lp * sizeof(int);
   if (lds > 160 * 1024) return ctx_fail(ctx, DCGP_ERR_ARG, "head_kdiag: image does not fit LDS");
   ScopedTimer t(ctx, "head_kdiag");
-  hipLaunchKernelGGL(head_kdiag_kernel, dim3(n_pairs, N), dim3(256), lds, ctx->stream, X, n_mod, H, W, C, f, s, Ho, Wo, P, L,
-                     variance, inv_l2, w, partial, n_pairs, p_tiles);
+  if (bk.type == 0)
+    hipLaunchKernelGGL(head_kdiag_kernel<0>, dim3(n_pairs, N), dim3(256), lds, ctx->stream, X, n_mod, H, W, C, f, s, Ho, Wo, P, L,
+                       bk, w, partial, n_pairs, p_tiles);
+  else
+    hipLaunchKernelGGL(head_kdiag_kernel<1>, dim3(n_pairs, N), dim3(256), lds, ctx->stream, X, n_mod, H, W, C, f, s, Ho, Wo, P, L,
+                       bk, w, partial, n_pairs, p_tiles);
   LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(kdiag_reduce_kernel, dim3((N + 127) / 128), dim3(128), 0, ctx->stream, partial, n_pairs, N,
                      1.0 / ((double)P * (double)P), out_N);

@@ -59,6 +59,8 @@ _SIGS = {
     "dcgp_extract_patches": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i],
     "dcgp_kuu_rbf": [_vp, _vp, _i, _i, _d, _d, _d, _vp],
     "dcgp_kuf_patches_rbf": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _d, _d, _vp, _i],
+    "dcgp_kuu_acos": [_vp, _vp, _i, _i, _d, _d, _d, _d, _vp],
+    "dcgp_kuf_patches_acos": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _d, _d, _d, _vp, _i],
     "dcgp_potrf_lower": [_vp, _vp, _i, _ip],
     "dcgp_trtri_lower": [_vp, _vp, _i, _vp],
     "dcgp_conditional": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _ip],

@@ -59,13 +59,17 @@ class DGP_Base:
         h = C.c_void_p()
         ctx._check(L.dcgp_model_create(ctx.handle, self.num_samples, JITTER, C.byref(h)))
         self._model = h.value
-        for l in self.layers[:-1]:
+        for li, l in enumerate(self.layers[:-1]):
             v = l.view
             keep = [np.ascontiguousarray(a, np.float64) for a in (l.feature.Z, l.Z_prior, l.q_mu, l.q_sqrt)]
             ctx._check(L.dcgp_model_add_conv_layer(
                 self._model, v.input_size[0], v.input_size[1], l.feature_maps_in, v.filter_size, v.stride,
                 l.num_inducing, l.gp_count, int(l.white), int(l.identity_mean), l.base_kernel.variance,
-                l.base_kernel.lengthscales, *[a.ctypes.data for a in keep]))
+                getattr(l.base_kernel, "lengthscales", 1.0), *[a.ctypes.data for a in keep]))
+            desc = np.ascontiguousarray(l.base_kernel._describe(), np.float64)
+            if desc[0] != 0.0:   # not the RBF the constructor call describes (ArcCosine, conv_gp/models.py:118-119)
+                ctx._check(L.dcgp_model_set_param(self._model, li, b"base_kernel",
+                                                  desc.ctypes.data, desc.size))
         h_ = self.layers[-1]
         v = h_.kern.view
         keep = [np.ascontiguousarray(a, np.float64) for a in (h_.feature.Z, h_.kern.patch_weights, h_.q_mu, h_.q_sqrt)]
@@ -88,8 +92,7 @@ class DGP_Base:
             push(li, "Z", l.feature.Z)
             push(li, "q_mu", l.q_mu)
             push(li, "q_sqrt", l.q_sqrt)
-            push(li, "variance", kern.variance)
-            push(li, "lengthscale", kern.lengthscales)
+            push(li, "base_kernel", kern._describe())
             if head:
                 push(li, "w", l.kern.patch_weights)
             else:
@@ -106,7 +109,9 @@ class DGP_Base:
             kern = l.kern.base_kernel if head else l.base_kernel
             kpath = base + ("/kern/base_kernel" if head else "/conv_kernel/base_kernel")
             out.append(Parameter(kpath + "/variance", lambda k=kern: np.array(k.variance), lambda v, k=kern: setattr(k, "variance", float(v))))
-            out.append(Parameter(kpath + "/lengthscales", lambda k=kern: np.array(k.lengthscales), lambda v, k=kern: setattr(k, "lengthscales", float(v))))
+            for pname in (("lengthscales",) if hasattr(kern, "lengthscales") else ("weight_variances", "bias_variance")):
+                out.append(Parameter(kpath + "/" + pname, lambda k=kern, n=pname: np.array(getattr(k, n)),
+                                     lambda v, k=kern, n=pname: setattr(k, n, float(v))))
             out.append(Parameter(base + "/feature/Z", lambda l=l: l.feature.Z, lambda v, l=l: setattr(l.feature, "Z", np.array(v, np.float64))))
             out.append(Parameter(base + "/q_mu", lambda l=l: l.q_mu, lambda v, l=l: setattr(l, "q_mu", np.array(v, np.float64))))
             out.append(Parameter(base + "/q_sqrt", lambda l=l: l.q_sqrt, lambda v, l=l: setattr(l, "q_sqrt", np.array(v, np.float64))))

@@ -38,6 +38,57 @@ class RBF:
     def Kdiag(self, X):
         return np.full(np.shape(X)[0], self.variance)
 
+    def _describe(self):
+        """{type, variance, p1, p2} of dcgp_model_set_param(..., "base_kernel", ...)."""
+        return [0.0, self.variance, self.lengthscales, 0.0]
+
+    def _kuf(self, ctx, dX, N, H, W, C, f, s, dZ, M, out, layout):
+        ctx._check(dev.lib().dcgp_kuf_patches_rbf(ctx.handle, dX.ptr, N, H, W, C, f, s, dZ.ptr, M, self.variance,
+                                                  self.lengthscales, out.ptr, layout))
+
+
+class ArcCosine:
+    """gpflow.kernels.ArcCosine(input_dim, order=0) -- the conv layers' base kernel under ``--base-kernel acos``
+    (conv_gp/models.py:118-119).  k = variance * (pi - theta) / pi with theta the angle between the augmented inputs,
+    <x, z> = weight_variances * x.z + bias_variance; Kdiag = variance.  Order 0 only."""
+
+    def __init__(self, input_dim, order=0, variance=1.0, weight_variances=1.0, bias_variance=1.0):
+        if order != 0:
+            raise NotImplementedError("only ArcCosine(order=0) is on the accelerated path (the reference uses order 0)")
+        self.input_dim = int(input_dim)
+        self.order = 0
+        self.variance = float(variance)
+        self.weight_variances = float(weight_variances)
+        self.bias_variance = float(bias_variance)
+        if not (self.variance > 0 and self.weight_variances > 0 and self.bias_variance >= 0):
+            raise ValueError("variance and weight_variances must be positive, bias_variance non-negative")
+
+    def K(self, X, X2=None):
+        if X2 is not None:
+            raise NotImplementedError("cross-covariances are evaluated by the fused patch kernels")
+        return self._gram(X, 0.0)
+
+    def _gram(self, Z, jitter):
+        ctx = dev.get_context()
+        Z = np.ascontiguousarray(Z, np.float64)
+        M, L = Z.shape
+        if L != self.input_dim:
+            raise ValueError("expected inputs of length %d, got %d" % (self.input_dim, L))
+        dZ, out = ctx.to_device(Z), ctx.empty((M, M))
+        ctx._check(dev.lib().dcgp_kuu_acos(ctx.handle, dZ.ptr, M, L, self.variance, self.weight_variances,
+                                           self.bias_variance, float(jitter), out.ptr))
+        return out.numpy()
+
+    def Kdiag(self, X):
+        return np.full(np.shape(X)[0], self.variance)
+
+    def _describe(self):
+        return [1.0, self.variance, self.weight_variances, self.bias_variance]
+
+    def _kuf(self, ctx, dX, N, H, W, C, f, s, dZ, M, out, layout):
+        ctx._check(dev.lib().dcgp_kuf_patches_acos(ctx.handle, dX.ptr, N, H, W, C, f, s, dZ.ptr, M, self.variance,
+                                                   self.weight_variances, self.bias_variance, out.ptr, layout))
+
 
 class AdditivePatchKernel:
     """K(x, x') = mean_i w_i k(x[i], x'[i]) (conv_gp/kernels.py:15-77); Kzx / Kdiag / Kzz only --

@@ -78,8 +78,7 @@ class MultiOutputConvKernel:
         if N == 0:
             return np.zeros((P, M, 0))
         dX, dZ, out = ctx.to_device(X), ctx.to_device(Z), ctx.empty((P, M, N))
-        ctx._check(dev.lib().dcgp_kuf_patches_rbf(ctx.handle, dX.ptr, N, H, W, Cc, f, s, dZ.ptr, M,
-                                                  self.base_kernel.variance, self.base_kernel.lengthscales, out.ptr, 0))
+        self.base_kernel._kuf(ctx, dX, N, H, W, Cc, f, s, dZ, M, out, 0)
         return out.numpy()
 
     def Kdiag(self, PNL_patches):
@@ -169,6 +168,8 @@ class ConvLayer(Layer):
         D = self.num_outputs
         if N == 0:
             return np.zeros((0, D)), np.zeros((0, D)), np.zeros((0, D))
+        if not hasattr(self.base_kernel, "lengthscales"):
+            return self._forward_composed(ND_X, z)
         dX, dZ = ctx.to_device(ND_X), ctx.to_device(self.feature.Z)
         dmu, dsq = ctx.to_device(self.q_mu), ctx.to_device(self.q_sqrt)
         dz = ctx.to_device(np.reshape(z, (N, D))) if z is not None else None
@@ -182,6 +183,29 @@ class ConvLayer(Layer):
             ds.ptr if ds else None, dm.ptr, dv.ptr, C.byref(info))
         ctx._check(rc, info)
         return (ds.numpy() if ds else None), dm.numpy(), dv.numpy()
+
+    def _forward_composed(self, ND_X, z):
+        """conditional_ND as the reference composes it (conv_gp/layers.py:108-135) from the operator-level calls --
+        Kuu, fused patches + Kuf, Kdiag, conditional -- for base kernels the one-call layer operator has no
+        signature for (ArcCosine); the model path (dcgp_elbo_forward) handles them natively."""
+        N = ND_X.shape[0]
+        v = self.view
+        X4 = ND_X.reshape(N, v.input_size[0], v.input_size[1], self.feature_maps_in)
+        MM_Kuu = self.conv_kernel.Kuu(self.feature.Z)
+        PMN_Kuf = self.conv_kernel.Kuf(self.feature.Z, (X4, v))
+        Knn = np.full((v.patch_count, N), self.base_kernel.variance)
+        mean, var = conditional(PMN_Kuf, MM_Kuu, Knn, self.q_mu, q_sqrt=self.q_sqrt, white=self.white)   # N x P x R, R x P x N
+        mean = mean.reshape(N, self.num_outputs)
+        var = np.transpose(var, (2, 1, 0)).reshape(N, self.num_outputs)
+        if self.identity_mean:
+            f, st = v.filter_size, v.stride
+            Ho, Wo = (v.input_size[0] - f) // st + 1, (v.input_size[1] - f) // st + 1
+            c0 = f // 2
+            centre = X4[:, c0:c0 + (Ho - 1) * st + 1:st, c0:c0 + (Wo - 1) * st + 1:st, 0]
+            mean = mean.copy()
+            mean.reshape(N, v.patch_count, self.gp_count)[:, :, 0] += centre.reshape(N, v.patch_count)
+        sample = None if z is None else reparameterize(mean, var, np.reshape(z, mean.shape))
+        return sample, mean, var
 
     def sample_from_conditional(self, X, z=None, full_cov=False):
         if full_cov:

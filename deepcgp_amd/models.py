@@ -3,7 +3,7 @@ from the neutral model spec used by the benchmarks and parity tests (deepcgp_amd
 import numpy as np
 
 from .dgp import DGP_Base
-from .kernels import RBF, ConvKernel, AdditivePatchKernel, PatchInducingFeatures
+from .kernels import RBF, ArcCosine, ConvKernel, AdditivePatchKernel, PatchInducingFeatures
 from .layers import ConvLayer, SVGP_Layer
 from .likelihoods import MultiClass
 from .views import FullView
@@ -20,7 +20,8 @@ def build_layers_from_spec(spec):
     layers = []
     for c in spec["convs"]:
         view = FullView((c["H"], c["W"]), c["f"], c["C"], c["s"])
-        layer = ConvLayer(RBF(view.patch_length, c["variance"], c["ls"]), c.get("mean_function"),
+        base = ArcCosine(view.patch_length, order=0) if c.get("base", "rbf") == "acos" else RBF(view.patch_length, c["variance"], c["ls"])
+        layer = ConvLayer(base, c.get("mean_function"),
                           feature=PatchInducingFeatures(c["Z"]), view=view, white=c["white"], gp_count=c["R"],
                           q_mu=c["q_mu"], q_sqrt=c["q_sqrt"])
         layer.Z_prior = np.array(c.get("Z0", c["Z"]), np.float64)
@@ -100,7 +101,7 @@ class ModelBuilder(object):
             base_kernel = RBF(patch_length, variance=float(layer_params.get('base_kernel/variance', 5.0)),
                               lengthscales=float(layer_params.get('base_kernel/lengthscales', 5.0)))
         elif self.flags.base_kernel == 'acos':
-            raise NotImplementedError("ArcCosine base kernel is not on the accelerated path yet (SURVEY.md 8 f-4)")
+            base_kernel = ArcCosine(patch_length, order=0)   # gpflow defaults: variance = weight = bias = 1 (models.py:119)
         else:
             raise ValueError("Not a valid base-kernel value")
         q_mu, q_sqrt = layer_params.get('q_mu'), layer_params.get('q_sqrt')

@@ -80,8 +80,17 @@ def _identity_conv(imgs, f, R, s):
     return np.repeat(centre[..., None], R, axis=-1)
 
 
+def _acos0(A, B, variance, wv, bv):
+    """ArcCosine(order=0) Gram matrix (host helper for synthetic q_sqrt initialisation only)."""
+    num = wv * (A @ B.T) + bv
+    da = np.sqrt(wv * np.sum(A * A, 1) + bv)
+    db = np.sqrt(wv * np.sum(B * B, 1) + bv)
+    theta = np.arccos(1e-15 + (1.0 - 2e-15) * num / da[:, None] / db[None, :])
+    return variance * (np.pi - theta) / np.pi
+
+
 def make_spec(hwc, convs, head, M, S=10, num_data=60000, seed=0, white=False, q_mu_random=True,
-              conv_q_sqrt_scale=1e-5, head_q_sqrt_scale=1.0, head_outputs=10, variance=5.0, ls=5.0):
+              conv_q_sqrt_scale=1e-5, head_q_sqrt_scale=1.0, head_outputs=10, variance=5.0, ls=5.0, base_kernel="rbf"):
     """Build a model spec (see module docstring) with seeded synthetic parameters."""
     rng = np.random.default_rng(seed)
     H, W, C = hwc
@@ -90,9 +99,12 @@ def make_spec(hwc, convs, head, M, S=10, num_data=60000, seed=0, white=False, q_
     h, w, c = H, W, C
     for (f, s, R) in convs:
         Z = _cut_patches(rng, init_imgs, M, f)
-        Kuu = _rbf(Z, Z, variance, ls) + JITTER * np.eye(M)
+        if base_kernel == "acos":   # conv layers only (conv_gp/models.py:113-121); gpflow defaults 1, 1, 1
+            Kuu = _acos0(Z, Z, 1.0, 1.0, 1.0) + JITTER * np.eye(M)
+        else:
+            Kuu = _rbf(Z, Z, variance, ls) + JITTER * np.eye(M)
         Lu = np.linalg.cholesky(Kuu)
-        layer = dict(H=h, W=w, C=c, f=f, s=s, M=M, R=R, Z=Z, Z0=Z.copy(), variance=variance, ls=ls,
+        layer = dict(H=h, W=w, C=c, f=f, s=s, M=M, R=R, Z=Z, Z0=Z.copy(), variance=variance, ls=ls, base=base_kernel,
                      q_mu=(rng.standard_normal((M, R)) if q_mu_random else np.zeros((M, R))),
                      q_sqrt=(np.tile(np.eye(M)[None], [R, 1, 1]) if white
                              else np.tile(Lu[None], [R, 1, 1]) * conv_q_sqrt_scale),

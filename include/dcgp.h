@@ -75,6 +75,14 @@ int dcgp_kuu_rbf(dcgp_ctx* ctx, const double* Z, int M, int L, double variance, 
 int dcgp_kuf_patches_rbf(dcgp_ctx* ctx, const double* X, int N, int H, int W, int C, int f, int stride,
                          const double* Z, int M, double variance, double lengthscale,
                          double* out, int layout);
+/* The same two matrices for the ArcCosine(order = 0) base kernel that `--base-kernel acos` selects for the conv
+ * layers (conv_gp/models.py:118-119; gpflow.kernels.ArcCosine: k = variance * (pi - theta) / pi,
+ * theta = acos(1e-15 + (1 - 2e-15) cos), cos from <x,z> = weight_variance * x.z + bias_variance; Kdiag = variance). */
+int dcgp_kuu_acos(dcgp_ctx* ctx, const double* Z, int M, int L, double variance, double weight_variance,
+                  double bias_variance, double jitter, double* out_MM);
+int dcgp_kuf_patches_acos(dcgp_ctx* ctx, const double* X, int N, int H, int W, int C, int f, int stride,
+                          const double* Z, int M, double variance, double weight_variance,
+                          double bias_variance, double* out, int layout);
 
 /* ---- dense M x M factorisations ------------------------------------------------------------ */
 /* tf.cholesky (conv_gp/conditionals.py:29, layers.py:151,156): in place, lower factor, strict
@@ -157,7 +165,9 @@ int dcgp_model_set_head(dcgp_model* model, int H, int W, int C, int f, int strid
                         const double* q_mu_host, const double* q_sqrt_host);
 /* keep every layer's (sample, mean, var) of the next forward passes for dcgp_model_layer_output   */
 int dcgp_model_set_keep_outputs(dcgp_model* model, int on);
-/* Push a changed parameter: which = "Z", "Z0", "q_mu", "q_sqrt", "w", "variance", "lengthscale".  */
+/* Push a changed parameter: which = "Z", "Z0", "q_mu", "q_sqrt", "w", "variance", "lengthscale", or
+ * "base_kernel" = {type, variance, p1, p2}: type 0 RBF (p1 = lengthscale), type 1 ArcCosine order 0 (p1 = weight
+ * variance, p2 = bias variance; conv layers only, conv_gp/models.py:113-121).                        */
 int dcgp_model_set_param(dcgp_model* model, int layer, const char* which, const double* value_host,
                          size_t count);
 

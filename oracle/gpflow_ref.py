@@ -43,6 +43,45 @@ class RBF:
         return np.full(np.shape(X)[0], self.variance, FLOAT)
 
 
+class ArcCosine:
+    """gpflow.kernels.ArcCosine(input_dim, order=0, variance=1, weight_variances=1, bias_variance=1), the conv
+    layers' base kernel under ``--base-kernel acos`` (construction conv_gp/models.py:118-119).
+
+    UNVERIFIED restatement of GPflow 1.2 (source not in /root/reference): with <x, z> = sum(weight_variances * x * z)
+    + bias_variance, cos = <x, z> / sqrt(<x, x> <z, z>), theta = acos(jitter + (1 - 2 jitter) cos), jitter = 1e-15,
+    K = variance * (1 / pi) * J_0(theta) with J_0(theta) = pi - theta; Kdiag = variance * (1 / pi) * J_0(0) = variance.
+    """
+
+    def __init__(self, input_dim, order=0, variance=1.0, weight_variances=1.0, bias_variance=1.0):
+        if order != 0:
+            raise NotImplementedError("order 0 only (what the reference constructs)")
+        self.input_dim = int(input_dim)
+        self.variance = float(variance)
+        self.weight_variances = float(weight_variances)
+        self.bias_variance = float(bias_variance)
+
+    def _weighted_product(self, X, X2=None):
+        if X2 is None:
+            return np.sum(self.weight_variances * np.square(X), axis=1) + self.bias_variance
+        return (self.weight_variances * X) @ X2.T + self.bias_variance
+
+    def K(self, X, X2=None):
+        X = np.asarray(X, FLOAT)
+        den = np.sqrt(self._weighted_product(X))
+        if X2 is None:
+            X2, den2 = X, den
+        else:
+            X2 = np.asarray(X2, FLOAT)
+            den2 = np.sqrt(self._weighted_product(X2))
+        cos_theta = self._weighted_product(X, X2) / den[:, None] / den2[None, :]
+        jitter = 1e-15
+        theta = np.arccos(jitter + (1.0 - 2.0 * jitter) * cos_theta)
+        return self.variance * (1.0 / np.pi) * (np.pi - theta)
+
+    def Kdiag(self, X):
+        return np.full(np.shape(X)[0], self.variance, FLOAT)
+
+
 def gauss_kl(q_mu, q_sqrt, K=None):
     """gpflow.kullback_leiblers.gauss_kl (call sites conv_gp/layers.py:145,147).
 

@@ -1,7 +1,7 @@
 """Test helper: build the oracle's DGP_Base from a neutral model spec (deepcgp_amd.synthetic)."""
 import numpy as np
 import oracle
-from oracle.gpflow_ref import RBF, MultiClass
+from oracle.gpflow_ref import RBF, ArcCosine, MultiClass
 from oracle.views import FullView
 from oracle.layers import ConvLayer
 from oracle.kernels import ConvKernel
@@ -12,7 +12,7 @@ def oracle_layers(spec):
     layers = []
     for c in spec["convs"]:
         view = FullView((c["H"], c["W"]), c["f"], c["C"], c["s"])
-        rbf = RBF(view.patch_length, c["variance"], c["ls"])
+        rbf = ArcCosine(view.patch_length, order=0) if c.get("base", "rbf") == "acos" else RBF(view.patch_length, c["variance"], c["ls"])
         layer = ConvLayer(rbf, None, c["Z"], view, white=c["white"], gp_count=c["R"],
                           q_mu=c["q_mu"], q_sqrt=c["q_sqrt"])
         layer.Z0 = np.array(c["Z0"], np.float64)

@@ -230,3 +230,32 @@ def test_model_builder_from_flags(ctx):
         flags.feature_maps = '3,3'
         ModelBuilder(flags, X, Y).build()
     model.close()
+
+
+def test_elbo_acos_base_kernel(ctx):
+    """--base-kernel acos (conv_gp/models.py:118-119): ArcCosine(order=0) conv layer + RBF ConvKernel head, whole ELBO and
+    layer moments against the oracle.  1e-8: acos() near cos = 1 is ill-conditioned in both implementations."""
+    hwc = (28, 28, 1)
+    spec = syn.make_spec(hwc, [(5, 2, 10)], (5, 1), M=48, S=2, num_data=60000, seed=21, base_kernel="acos", conv_q_sqrt_scale=0.2)
+    X, Y = syn.make_batch(hwc, 4, seed=21)
+    zs = syn.make_noise(spec, 4, seed=21)
+    ref, model = oracle_model(spec, X, Y), build_from_spec(spec, X, Y)
+    e, dt, kl = model.compute_log_likelihood(X, Y, zs=zs, return_parts=True)
+    assert abs(dt - ref.data_term(X, Y, zs=zs)) <= 1e-8 * abs(dt)
+    assert abs(kl - ref.KL()) <= 1e-8 * max(abs(kl), 1.0)
+    assert abs(e - ref.compute_log_likelihood(X, Y, zs=zs)) <= 1e-8 * abs(e)
+    _, Fm, Fv = model.propagate(X, S=2, zs=zs)
+    _, om, ov = ref.propagate(X, S=2, zs=zs)
+    # layer moments: 1e-6.  Kuu's diagonal is variance * (1 - acos(1 - 1e-15) / pi): a 1-ulp difference in cos moves it
+    # by ~7e-10, which inv(Kuu) (jitter 1e-3) can amplify a thousandfold -- conditioning of the reference formula
+    for i in range(2):
+        assert rel(Fm[i], om[i]) < 1e-6 and rel(Fv[i], ov[i]) < 1e-6
+    # parameter push: change the kernel's parameters, the device copy follows
+    model.layers[0].base_kernel.weight_variances = 0.6
+    model.layers[0].base_kernel.bias_variance = 0.4
+    ref.layers[0].conv_kernel.base_kernel.weight_variances = 0.6
+    ref.layers[0].conv_kernel.base_kernel.bias_variance = 0.4
+    model.sync_parameters()
+    e2 = model.compute_log_likelihood(X, Y, zs=zs)
+    assert abs(e2 - ref.compute_log_likelihood(X, Y, zs=zs)) <= 1e-8 * abs(e2) and e2 != e
+    model.close()

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle
-from oracle.gpflow_ref import RBF as ORBF, gauss_kl as o_gauss_kl, MultiClass as OMultiClass, JITTER
+from oracle.gpflow_ref import RBF as ORBF, ArcCosine as OArcCosine, gauss_kl as o_gauss_kl, MultiClass as OMultiClass, JITTER
 from oracle.views import FullView as OFullView
 from oracle.layers import MultiOutputConvKernel as OMOK, ConvLayer as OConvLayer
 from oracle.kernels import ConvKernel as OConvKernel, AdditivePatchKernel as OAdd, Kuu as o_Kuu
@@ -239,3 +239,54 @@ def test_robustmax(ctx, n):
     op, opv = olik.predict_mean_and_var(mu, var)
     close(p, op, 1e-11, "predict mean")
     close(pv, opv, 1e-11, "predict var")
+
+
+# ---- ArcCosine(order = 0) base kernel of the conv layers (--base-kernel acos, conv_gp/models.py:118-119) ----
+# tolerance 1e-8: theta = acos(cos) loses digits where patches are nearly parallel (cos -> 1), in the oracle and on
+# the device alike -- a property of the reference's formula, not of either implementation
+@pytest.mark.parametrize("H,W,C,f,s", [(8, 8, 1, 3, 1), (28, 28, 1, 5, 2), (12, 12, 10, 5, 1)])
+@pytest.mark.parametrize("M", [5, 64])
+def test_acos_kuu_kuf(ctx, H, W, C, f, s, M):
+    from deepcgp_amd.kernels import ArcCosine
+    from deepcgp_amd.layers import MultiOutputConvKernel
+    from deepcgp_amd.views import FullView
+    rng = np.random.default_rng(5)
+    N = 3
+    X = rng.standard_normal((N, H, W, C))
+    v, ov = FullView((H, W), f, C, s), OFullView((H, W), f, C, s)
+    Z = rng.standard_normal((M, v.patch_length))
+    k, ok = ArcCosine(v.patch_length, order=0, variance=1.7, weight_variances=0.8, bias_variance=0.3), \
+        OArcCosine(v.patch_length, order=0, variance=1.7, weight_variances=0.8, bias_variance=0.3)
+    mok, omok = MultiOutputConvKernel(k, H * W * C, v.patch_count), OMOK(ok, H * W * C, v.patch_count)
+    # Kuu: on the diagonal cos can round above the formula's 1e-15 guard (long patches) and the reference formula
+    # -- hence the oracle -- returns NaN there; the device clamps the acos argument.  Compare wherever the oracle is
+    # finite, require finite device values everywhere and the clamped value on the rest.
+    with np.errstate(invalid="ignore"):
+        ref = omok.Kuu(Z)
+    got = mok.Kuu(Z)
+    ok_ = np.isfinite(ref)
+    assert np.all(np.isfinite(got)) and np.all(ok_ | np.eye(M, dtype=bool))
+    close(np.where(ok_, got, 0.0), np.where(ok_, ref, 0.0), 1e-8, "Kuu acos")
+    assert np.allclose(got[~ok_], 1.7 + JITTER, rtol=0, atol=1e-7)
+    close(mok.Kuf(Z, (X, v)), omok.Kuf(Z, ov.extract_patches_PNL(X)), 1e-8, "Kuf acos")
+    close(mok.Kdiag(ov.extract_patches_PNL(X)), omok.Kdiag(ov.extract_patches_PNL(X)), 1e-15, "Kdiag acos")
+
+
+@pytest.mark.parametrize("white", [False, True])
+def test_acos_conv_layer(ctx, white):
+    from deepcgp_amd.kernels import ArcCosine, PatchInducingFeatures
+    from deepcgp_amd.layers import ConvLayer
+    from deepcgp_amd.views import FullView
+    rng = np.random.default_rng(12)
+    H, W, C, f, s, M, R, N = 12, 12, 3, 5, 1, 24, 4, 3
+    X = rng.standard_normal((N, H * W * C))
+    v, ov = FullView((H, W), f, C, s), OFullView((H, W), f, C, s)
+    Z, q_mu, q_sqrt = rand_spd_inputs(rng, M, R, v.patch_length, 0.2)
+    layer = ConvLayer(ArcCosine(v.patch_length, order=0), None, PatchInducingFeatures(Z), v, white=white, gp_count=R,
+                      q_mu=q_mu, q_sqrt=q_sqrt)
+    olayer = OConvLayer(OArcCosine(v.patch_length, order=0), None, Z, ov, white=white, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
+    m, var = layer.conditional_ND(X)
+    om, ovar = olayer.conditional_ND(X)
+    close(m, om, 1e-8, "mean")
+    close(var, ovar, 1e-8, "var")
+    close(layer.KL(), olayer.KL(), 1e-8, "KL")

@@ -185,3 +185,21 @@ def test_shard_sum_equals_full_batch():
             if len(Xs):
                 total += model.data_term(Xs, Ys, zs=zl)
         np.testing.assert_allclose(assemble_elbo(total, model.KL(), spec["num_data"], 7), full, rtol=1e-12)
+
+
+def test_arccosine_order0_known_answers():
+    """gpflow.kernels.ArcCosine(order=0) as the oracle restates it: k(x, x) ~ variance (theta = acos(1 - 1e-15)),
+    orthogonal augmented inputs give variance / 2, antiparallel ones ~0; weight / bias variances enter through
+    <x, z> = w x.z + b."""
+    from oracle.gpflow_ref import ArcCosine
+    k = ArcCosine(2, order=0, variance=3.0, weight_variances=1.0, bias_variance=0.0)
+    X = np.array([[1.0, 0.0], [0.0, 2.0], [-3.0, 0.0]])
+    K = k.K(X)
+    assert np.allclose(np.diag(K), 3.0, rtol=0, atol=1e-7) and np.all(np.diag(K) <= 3.0)
+    assert abs(K[0, 1] - 1.5) < 1e-12 and abs(K[0, 2]) < 1e-7
+    assert np.allclose(K, K.T) and np.allclose(k.Kdiag(X), 3.0)
+    kb = ArcCosine(2, order=0, variance=1.0, weight_variances=0.5, bias_variance=2.0)
+    x, z = np.array([[1.0, 2.0]]), np.array([[-1.0, 0.5]])
+    c = (0.5 * 0.0 + 2.0) / np.sqrt((0.5 * 5.0 + 2.0) * (0.5 * 1.25 + 2.0))
+    assert abs(kb.K(x, z)[0, 0] - (1.0 - np.arccos(1e-15 + (1 - 2e-15) * c) / np.pi)) < 1e-15
+    assert np.allclose(kb.K(x, z), kb.K(z, x).T)
