@@ -42,6 +42,16 @@ def build_from_spec(spec, X, Y):
                     num_samples=spec["S"], minibatch_size=None, num_data=spec["num_data"], name='DGP')
 
 
+def save_model_parameters(model, path, global_step=0):
+    """Write the reference's checkpoint: ``np.save(path, {param.pathname: value, 'global_step': int})``
+    (Experiment._save_model_parameters, conv_gp/experiment.py:56-64) -- readable by ``--load-model`` on either side
+    (ModelBuilder._load_layer_parameters, conv_gp/models.py:200-240)."""
+    params = {p.pathname: np.array(p.value) for p in model.parameters}
+    params['global_step'] = int(global_step)
+    np.save(path, params)
+    return params
+
+
 def identity_conv(NHWC_X, filter_size, feature_maps_in, feature_maps_out, stride, count=1000):
     """Propagate random images through IdentityConv2dMean to initialise the next layer
     (conv_gp/models.py:29-33, conv_gp/mean_functions.py:6-26)."""

@@ -226,6 +226,31 @@ def test_model_builder_from_flags(ctx):
     e = model.compute_log_likelihood(X[:8].reshape(8, -1), Y[:8], seed=1)
     assert np.isfinite(e)
     assert abs(head.KL()) < 1e-8 and np.isfinite(conv.KL()) and conv.KL() > 0
+    # checkpoint round trip in the reference's format (experiment.py:56-64 writes it, models.py:200-240 reads it):
+    # perturb the parameters, save, rebuild from the file -> same parameters, same ELBO
+    import tempfile
+    from deepcgp_amd.models import save_model_parameters
+    conv.q_mu = rng.standard_normal(conv.q_mu.shape)
+    head.q_mu = rng.standard_normal(head.q_mu.shape)
+    head.kern.patch_weights = 1.0 + 0.1 * rng.standard_normal(head.kern.patch_weights.shape)
+    conv.base_kernel.variance, head.kern.base_kernel.lengthscales = 3.5, 4.25
+    model.sync_parameters()
+    e1 = model.compute_log_likelihood(X[:8].reshape(8, -1), Y[:8], seed=1)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 't.npy')
+        saved = save_model_parameters(model, path, global_step=123)
+        assert 'DGP/layers/0/conv_kernel/base_kernel/variance' in saved and 'DGP/layers/1/kern/patch_weights' in saved
+        np.random.seed(0)
+        flags.load_model = 't'      # --load-model NAME (conv_gp/models.py:46-47); the experiment resolves the path
+        b2 = ModelBuilder(flags, X, Y, model_path=path)
+        m2 = b2.build()
+        flags.load_model = None
+    assert b2.global_step == 123
+    for p1, p2 in zip(model.parameters, m2.parameters):
+        assert p1.pathname == p2.pathname and np.array_equal(np.asarray(p1.value), np.asarray(p2.value)), p1.pathname
+    e2 = m2.compute_log_likelihood(X[:8].reshape(8, -1), Y[:8], seed=1)
+    assert e2 == e1 and e1 != e
+    m2.close()
     with pytest.raises(AssertionError):
         flags.feature_maps = '3,3'
         ModelBuilder(flags, X, Y).build()
