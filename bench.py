@@ -77,8 +77,8 @@ def cpu_baseline(name, S, batch, budget_s=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=str, default="cfg2_mnist_CH_M256", choices=sorted(syn.CONFIGS))
     ap.add_argument("--scaling", type=str, default="weak", choices=["weak", "strong"])
     ap.add_argument("--samples", type=int, default=10)
