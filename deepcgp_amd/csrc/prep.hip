@@ -16,15 +16,28 @@ __device__ void gram_task(const PrepLayerArgs& p, const double* __restrict__ Z, 
   for (int t = bx; t < nt * nt; t += nbx) {
     const int i0 = (t / nt) * 16, j0 = (t % nt) * 16;
     double dot = 0.0, ni = 0.0, nj = 0.0;
+    // chunks of 32 along the patch length, the next chunk's loads in flight while the current one is multiplied
+    // (the head's L = 250 means 8 chunks: rolled, each waited a full memory latency at the front of the step)
+    double ri[2], rj[2];
+    auto fetch = [&](int l0) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int idx = threadIdx.x + e * 256, r = idx >> 5, c = idx & 31;
+        ri[e] = (i0 + r < p.M && l0 + c < p.L) ? Z[(long)(i0 + r) * p.L + l0 + c] : 0.0;
+        rj[e] = (j0 + r < p.M && l0 + c < p.L) ? Z[(long)(j0 + r) * p.L + l0 + c] : 0.0;
+      }
+    };
+    fetch(0);
     for (int l0 = 0; l0 < p.L; l0 += 32) {
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {   // 512 elements of each operand: both loads of both halves in flight together
+      for (int e = 0; e < 2; ++e) {
         const int idx = threadIdx.x + e * 256, r = idx >> 5, c = idx & 31;
-        Zi[r][c] = (i0 + r < p.M && l0 + c < p.L) ? Z[(long)(i0 + r) * p.L + l0 + c] : 0.0;
-        Zj[r][c] = (j0 + r < p.M && l0 + c < p.L) ? Z[(long)(j0 + r) * p.L + l0 + c] : 0.0;
+        Zi[r][c] = ri[e];
+        Zj[r][c] = rj[e];
       }
       __syncthreads();
+      if (l0 + 32 < p.L) fetch(l0 + 32);
 #pragma unroll 8
       for (int l = 0; l < 32; ++l) {
         const double a = Zi[ty][l], b = Zj[tx][l];
@@ -54,13 +67,21 @@ __device__ void transpose_task(const PrepLayerArgs& p, int bx, int nbx) {
   for (int mb = bx; mb * 32 < p.Mp; mb += nbx) {
     const int m0 = mb * 32;
     double acc = 0.0;
+    double rz[4];   // this thread's 4 elements of the next 32 x 32 chunk (prefetched while the current one is written)
+    auto fetch = [&](int l0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = ty + 8 * e, m = m0 + r, l = l0 + tx;
+        rz[e] = (m < p.M && l < p.L) ? p.Z[(long)m * p.L + l] : 0.0;
+      }
+    };
+    fetch(0);
     for (int l0 = 0; l0 < p.Lp; l0 += 32) {
       __syncthreads();
-      for (int r = ty; r < 32; r += 8) {
-        const int m = m0 + r, l = l0 + tx;
-        t[r][tx] = (m < p.M && l < p.L) ? p.Z[(long)m * p.L + l] : 0.0;
-      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[ty + 8 * e][tx] = rz[e];
       __syncthreads();
+      if (l0 + 32 < p.Lp) fetch(l0 + 32);
       for (int r = ty; r < 32; r += 8) {
         const int l = l0 + r, m = m0 + tx;
         const double v = t[tx][r];
