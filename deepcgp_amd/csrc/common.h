@@ -134,6 +134,7 @@ struct PatchRbfArgs {
   const double* zn = nullptr;  // [Mp] |z|^2 (unscaled)
   int M = 0, Mp = 0, Lp = 0;
   BaseKernel bk;
+  const double* in_scale = nullptr;   // [H*W*C] or nullptr: the image is multiplied elementwise while it is staged (ARD head)
   // write mode: out[m*sM + n*sN + p*sP]
   double* out = nullptr; long sM = 0, sN = 0, sP = 0;
   // reduce mode (head Kzx): out[m*sM + n*sN] = scale * sum_p w[p] k

@@ -33,6 +33,7 @@ struct PrepLayerArgs {
   double *K = nullptr, *Kp = nullptr, *ZT = nullptr, *zn = nullptr, *Lq = nullptr, *qmu = nullptr;
   int M = 0, Mp = 0, L = 0, Lp = 0, R = 0, Rp = 0;
   BaseKernel bk; double jitter = 0.0;
+  const double* in_scale = nullptr;   // [L] or nullptr: Z is read as Z * in_scale (ARD lengthscales)
 };
 struct PrepArgs {
   int nl = 0;

@@ -31,6 +31,7 @@ struct LayerState {
   bool has_qsqrt = true;
   // parameters in the caller's layout (device)
   double *Z = nullptr, *Z0 = nullptr, *q_mu = nullptr, *q_sqrt = nullptr, *w = nullptr;
+  double* in_scale = nullptr;   // [L] 1 / ARD lengthscale per input dimension, or nullptr (set_param "ard_lengthscales"; single-patch head only)
   // derived every step
   GpMats g;
   double *ZT = nullptr, *zn = nullptr;
@@ -85,7 +86,7 @@ struct LayerState {
     p.Z = Z; p.Z0 = Z0; p.q_sqrt = has_qsqrt ? q_sqrt : nullptr; p.q_mu = q_mu;
     p.K = g.K; p.Kp = g.Kp; p.ZT = ZT; p.zn = zn; p.Lq = g.Lq; p.qmu = g.qmu;
     p.M = M; p.Mp = Mp; p.L = v.L; p.Lp = Lp; p.R = R; p.Rp = g.Rp;
-    p.bk = base(); p.jitter = jitter;
+    p.bk = base(); p.jitter = jitter; p.in_scale = in_scale;
     return p;
   }
   // step 1 of the forward: everything that depends only on this layer's parameters
@@ -194,6 +195,7 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   a.bk = L.base();
   a.out = B; a.sM = ldb; a.sN = 1; a.sP = 0;
   a.w = L.w; a.scale = 1.0 / (double)L.v.P; a.reduce = 1;
+  a.in_scale = L.in_scale;
   a.share_cu = phase == 1;
   bool kd_on_side = false;
   if (phase & 1) {

@@ -324,6 +324,20 @@ int dcgp_model_set_param(dcgp_model* model, int layer, const char* which, const 
   }
   if (!strcmp(which, "variance")) { DCGP_TRY(expect(1)); if (!(value_host[0] > 0)) return ctx_fail(ctx, DCGP_ERR_ARG, "variance must be > 0"); L.variance = value_host[0]; return DCGP_OK; }
   if (!strcmp(which, "lengthscale")) { DCGP_TRY(expect(1)); if (!(value_host[0] > 0)) return ctx_fail(ctx, DCGP_ERR_ARG, "lengthscale must be > 0"); L.ls = value_host[0]; return DCGP_OK; }
+  if (!strcmp(which, "ard_lengthscales")) {
+    // gpflow RBF(D, ARD=True) on the flattened features (--last-kernel rbf, conv_gp/models.py:160-168): a head whose
+    // single patch is the whole input (P == 1); x / l and Z / l are formed while the operands are staged
+    if (!L.is_head || L.v.P != 1) return ctx_fail(ctx, DCGP_ERR_ARG, "set_param(ard_lengthscales): only a single-patch head takes per-dimension lengthscales");
+    DCGP_TRY(expect((size_t)L.v.L));
+    std::vector<double> inv(count);
+    for (size_t i = 0; i < count; ++i) {
+      if (!(value_host[i] > 0)) return ctx_fail(ctx, DCGP_ERR_ARG, "lengthscales must be > 0");
+      inv[i] = 1.0 / value_host[i];
+    }
+    if (!L.in_scale && !(L.in_scale = L.dalloc(count))) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: device allocation failed");
+    L.ls = 1.0;
+    return L.upload(L.in_scale, inv.data(), count);
+  }
   if (!strcmp(which, "base_kernel")) {   // {type, variance, p1, p2}: 0 = RBF (p1 = lengthscale), 1 = ArcCosine order 0 (p1 = weight, p2 = bias variance)
     DCGP_TRY(expect(4));
     const int type = (int)value_host[0];

@@ -23,8 +23,9 @@ __device__ void gram_task(const PrepLayerArgs& p, const double* __restrict__ Z, 
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int idx = threadIdx.x + e * 256, r = idx >> 5, c = idx & 31;
-        ri[e] = (i0 + r < p.M && l0 + c < p.L) ? Z[(long)(i0 + r) * p.L + l0 + c] : 0.0;
-        rj[e] = (j0 + r < p.M && l0 + c < p.L) ? Z[(long)(j0 + r) * p.L + l0 + c] : 0.0;
+        const double sc = (p.in_scale && l0 + c < p.L) ? p.in_scale[l0 + c] : 1.0;
+        ri[e] = (i0 + r < p.M && l0 + c < p.L) ? Z[(long)(i0 + r) * p.L + l0 + c] * sc : 0.0;
+        rj[e] = (j0 + r < p.M && l0 + c < p.L) ? Z[(long)(j0 + r) * p.L + l0 + c] * sc : 0.0;
       }
     };
     fetch(0);
@@ -72,7 +73,7 @@ __device__ void transpose_task(const PrepLayerArgs& p, int bx, int nbx) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = ty + 8 * e, m = m0 + r, l = l0 + tx;
-        rz[e] = (m < p.M && l < p.L) ? p.Z[(long)m * p.L + l] : 0.0;
+        rz[e] = (m < p.M && l < p.L) ? p.Z[(long)m * p.L + l] * (p.in_scale ? p.in_scale[l] : 1.0) : 0.0;
       }
     };
     fetch(0);

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256, 4) void patch_rbf_kernel(PatchRbfArgs a) {
     for (int e = 0; e < 8; ++e) {
       const int i = i0 + e * 256 + tid;
       t[e] = (i < HWC) ? Xn[i] : 0.0;
+      if (a.in_scale && i < HWC) t[e] *= a.in_scale[i];   // ARD: x / lengthscales (gpflow RBF(ARD=True), conv_gp/models.py:160-168)
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {

@@ -71,12 +71,20 @@ class DGP_Base:
                 ctx._check(L.dcgp_model_set_param(self._model, li, b"base_kernel",
                                                   desc.ctypes.data, desc.size))
         h_ = self.layers[-1]
-        v = h_.kern.view
-        keep = [np.ascontiguousarray(a, np.float64) for a in (h_.feature.Z, h_.kern.patch_weights, h_.q_mu, h_.q_sqrt)]
+        if hasattr(h_.kern, "base_kernel"):      # ConvKernel / AdditivePatchKernel head (--last-kernel conv | add)
+            v = h_.kern.view
+            geom = (v.input_size[0], v.input_size[1], v.feature_maps, v.filter_size, v.stride)
+            ktype, base, weights = int(h_.kern.kernel_type), h_.kern.base_kernel, h_.kern.patch_weights
+        else:                                    # dense RBF head on the flattened features (--last-kernel rbf): one patch = the input
+            geom = (1, 1, h_.kern.input_dim, 1, 1)
+            ktype, base, weights = 0, h_.kern, np.ones(1)
+        keep = [np.ascontiguousarray(a, np.float64) for a in (h_.feature.Z, weights, h_.q_mu, h_.q_sqrt)]
         ctx._check(L.dcgp_model_set_head(
-            self._model, v.input_size[0], v.input_size[1], v.feature_maps, v.filter_size, v.stride,
-            h_.num_inducing, h_.num_outputs, int(h_.white), int(h_.kern.kernel_type), h_.kern.base_kernel.variance,
-            h_.kern.base_kernel.lengthscales, *[a.ctypes.data for a in keep]))
+            self._model, *geom, h_.num_inducing, h_.num_outputs, int(h_.white), ktype, base.variance,
+            1.0 if getattr(base, "ARD", False) else base.lengthscales, *[a.ctypes.data for a in keep]))
+        if getattr(base, "ARD", False):
+            ls = np.ascontiguousarray(base.lengthscales, np.float64)
+            ctx._check(L.dcgp_model_set_param(self._model, len(self.layers) - 1, b"ard_lengthscales", ls.ctypes.data, ls.size))
 
     def sync_parameters(self):
         """Push the current Python-side parameter values to the device copy."""
@@ -88,13 +96,16 @@ class DGP_Base:
             ctx._check(L.dcgp_model_set_param(self._model, li, which.encode(), a.ctypes.data, a.size))
         for li, l in enumerate(self.layers):
             head = li == len(self.layers) - 1
-            kern = l.kern.base_kernel if head else l.base_kernel
+            kern = (l.kern.base_kernel if hasattr(l.kern, "base_kernel") else l.kern) if head else l.base_kernel
             push(li, "Z", l.feature.Z)
             push(li, "q_mu", l.q_mu)
             push(li, "q_sqrt", l.q_sqrt)
             push(li, "base_kernel", kern._describe())
+            if getattr(kern, "ARD", False):
+                push(li, "ard_lengthscales", kern.lengthscales)
             if head:
-                push(li, "w", l.kern.patch_weights)
+                if hasattr(l.kern, "patch_weights"):
+                    push(li, "w", l.kern.patch_weights)
             else:
                 push(li, "Z0", l.Z_prior)
 
@@ -106,16 +117,17 @@ class DGP_Base:
         for i, l in enumerate(self.layers):
             head = i == len(self.layers) - 1
             base = "%s/layers/%d" % (self.name, i)
-            kern = l.kern.base_kernel if head else l.base_kernel
-            kpath = base + ("/kern/base_kernel" if head else "/conv_kernel/base_kernel")
+            dense = head and not hasattr(l.kern, "base_kernel")
+            kern = (l.kern if dense else l.kern.base_kernel) if head else l.base_kernel
+            kpath = base + (("/kern" if dense else "/kern/base_kernel") if head else "/conv_kernel/base_kernel")
             out.append(Parameter(kpath + "/variance", lambda k=kern: np.array(k.variance), lambda v, k=kern: setattr(k, "variance", float(v))))
             for pname in (("lengthscales",) if hasattr(kern, "lengthscales") else ("weight_variances", "bias_variance")):
                 out.append(Parameter(kpath + "/" + pname, lambda k=kern, n=pname: np.array(getattr(k, n)),
-                                     lambda v, k=kern, n=pname: setattr(k, n, float(v))))
+                                     lambda v, k=kern, n=pname: setattr(k, n, np.array(v, np.float64) if np.ndim(v) else float(v))))
             out.append(Parameter(base + "/feature/Z", lambda l=l: l.feature.Z, lambda v, l=l: setattr(l.feature, "Z", np.array(v, np.float64))))
             out.append(Parameter(base + "/q_mu", lambda l=l: l.q_mu, lambda v, l=l: setattr(l, "q_mu", np.array(v, np.float64))))
             out.append(Parameter(base + "/q_sqrt", lambda l=l: l.q_sqrt, lambda v, l=l: setattr(l, "q_sqrt", np.array(v, np.float64))))
-            if head:
+            if head and not dense:
                 out.append(Parameter(base + "/kern/patch_weights", lambda l=l: l.kern.patch_weights,
                                      lambda v, l=l: setattr(l.kern, "patch_weights", np.array(v, np.float64))))
         return out

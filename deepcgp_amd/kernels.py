@@ -11,28 +11,56 @@ JITTER = 1e-3    # settings.jitter from /root/reference/gpflowrc:11
 
 
 class RBF:
-    """gpflow.kernels.RBF(input_dim, variance, lengthscales) -- parameters + Kuu-type evaluations on device."""
+    """gpflow.kernels.RBF(input_dim, variance, lengthscales, ARD=False) -- parameters + evaluations on device.
+    Scalar lengthscale: the base kernel of the conv layers / ConvKernel heads (conv_gp/models.py:114-117,178-185).
+    ``ARD=True`` (one lengthscale per input dimension): the dense head of ``--last-kernel rbf`` on the flattened features
+    (conv_gp/models.py:160-168), used with ``InducingPoints``; inputs are divided by the lengthscales and the unit-
+    lengthscale kernel evaluated, which is gpflow's own formulation."""
 
-    def __init__(self, input_dim, variance=1.0, lengthscales=1.0):
+    def __init__(self, input_dim, variance=1.0, lengthscales=1.0, ARD=False):
         self.input_dim = int(input_dim)
         self.variance = float(variance)
-        self.lengthscales = float(lengthscales)
-        if not (self.variance > 0 and self.lengthscales > 0):
+        self.ARD = bool(ARD)
+        if self.ARD:
+            ls = np.asarray(lengthscales, np.float64)
+            self.lengthscales = np.full(self.input_dim, float(ls)) if ls.ndim == 0 else ls.reshape(self.input_dim).copy()
+        else:
+            self.lengthscales = float(lengthscales)
+        if not (self.variance > 0 and np.all(np.asarray(self.lengthscales) > 0)):
             raise ValueError("variance and lengthscales must be positive")
 
     def K(self, X, X2=None):
-        if X2 is not None:
-            raise NotImplementedError("cross-covariances are evaluated by the fused patch kernels")
-        return self._gram(X, 0.0)
+        return self._gram(X, 0.0) if X2 is None else self.Kzx(X, X2)
+
+    def _scaled(self, A):
+        A = np.ascontiguousarray(A, np.float64)
+        if A.shape[1] != self.input_dim:
+            raise ValueError("expected inputs of length %d, got %d" % (self.input_dim, A.shape[1]))
+        return np.ascontiguousarray(A / self.lengthscales) if self.ARD else A
 
     def _gram(self, Z, jitter):
         ctx = dev.get_context()
-        Z = np.ascontiguousarray(Z, np.float64)
+        Z = self._scaled(Z)
         M, L = Z.shape
-        if L != self.input_dim:
-            raise ValueError("expected inputs of length %d, got %d" % (self.input_dim, L))
         dZ, out = ctx.to_device(Z), ctx.empty((M, M))
-        ctx._check(dev.lib().dcgp_kuu_rbf(ctx.handle, dZ.ptr, M, L, self.variance, self.lengthscales, float(jitter), out.ptr))
+        ctx._check(dev.lib().dcgp_kuu_rbf(ctx.handle, dZ.ptr, M, L, self.variance, 1.0 if self.ARD else self.lengthscales,
+                                          float(jitter), out.ptr))
+        return out.numpy()
+
+    # gpflow's InducingPoints dispatch: Kuu = K(Z) + jitter I, Kuf = K(Z, X)
+    def Kzz(self, Z):
+        return self._gram(Z, 0.0)
+
+    def Kzx(self, Z, X):
+        """K(Z, X), M x N, for dense inputs: every row is a 1 x 1 image with D channels, one patch, weight 1."""
+        ctx = dev.get_context()
+        Z, X = self._scaled(Z), self._scaled(X)
+        (M, D), N = Z.shape, X.shape[0]
+        if N == 0:
+            return np.zeros((M, 0))
+        dX, dZ, dw, out = ctx.to_device(X), ctx.to_device(Z), ctx.to_device(np.ones(1)), ctx.empty((M, N))
+        ctx._check(dev.lib().dcgp_convkernel_kzx(ctx.handle, dX.ptr, N, 1, 1, D, 1, 1, dZ.ptr, M, self.variance,
+                                                 1.0 if self.ARD else self.lengthscales, dw.ptr, out.ptr))
         return out.numpy()
 
     def Kdiag(self, X):
@@ -40,9 +68,11 @@ class RBF:
 
     def _describe(self):
         """{type, variance, p1, p2} of dcgp_model_set_param(..., "base_kernel", ...)."""
-        return [0.0, self.variance, self.lengthscales, 0.0]
+        return [0.0, self.variance, 1.0 if self.ARD else self.lengthscales, 0.0]
 
     def _kuf(self, ctx, dX, N, H, W, C, f, s, dZ, M, out, layout):
+        if self.ARD:
+            raise NotImplementedError("ARD lengthscales belong to the dense head (conv_gp/models.py:160-168)")
         ctx._check(dev.lib().dcgp_kuf_patches_rbf(ctx.handle, dX.ptr, N, H, W, C, f, s, dZ.ptr, M, self.variance,
                                                   self.lengthscales, out.ptr, layout))
 
@@ -188,6 +218,16 @@ def _cluster_patches(NHWC_X, M, patch_size):
     return k_means.cluster_centers_
 
 
+class InducingPoints:
+    """gpflow.features.InducingPoints(Z) -- the dense head's feature (conv_gp/models.py:168)."""
+
+    def __init__(self, Z):
+        self.Z = np.array(Z, np.float64)
+
+    def __len__(self):
+        return self.Z.shape[0]
+
+
 class PatchInducingFeatures:
     """conv_gp/kernels.py:166-170 (InducingPointsBase: ``Z`` and ``len``)."""
 
@@ -203,8 +243,8 @@ class PatchInducingFeatures:
 
 
 def Kuu(feature, kern, jitter=0.0):
-    """dispatch at conv_gp/kernels.py:172-174."""
-    return kern.base_kernel._gram(feature.Z, jitter)
+    """dispatch at conv_gp/kernels.py:172-174 (patch features); gpflow's default for InducingPoints + a plain kernel."""
+    return (kern.base_kernel if hasattr(kern, "base_kernel") else kern)._gram(feature.Z, jitter)
 
 
 def Kuf(feature, kern, Xnew):

@@ -3,7 +3,7 @@ from the neutral model spec used by the benchmarks and parity tests (deepcgp_amd
 import numpy as np
 
 from .dgp import DGP_Base
-from .kernels import RBF, ArcCosine, ConvKernel, AdditivePatchKernel, PatchInducingFeatures
+from .kernels import RBF, ArcCosine, ConvKernel, AdditivePatchKernel, PatchInducingFeatures, InducingPoints
 from .layers import ConvLayer, SVGP_Layer
 from .likelihoods import MultiClass
 from .views import FullView
@@ -29,6 +29,11 @@ def build_layers_from_spec(spec):
         layers.append(layer)
     h = spec["head"]
     view = FullView((h["H"], h["W"], h["C"]), h["f"], h["C"], h["s"])
+    if h.get("kernel", "conv") == "rbf":   # dense RBF-ARD head (--last-kernel rbf)
+        layers.append(SVGP_Layer(kern=RBF(h["Z"].shape[1], h["variance"], h["ls_ard"], ARD=True), num_outputs=h["R"],
+                                 feature=InducingPoints(h["Z"]), mean_function=None, white=h["white"], q_mu=h["q_mu"],
+                                 q_sqrt=h["q_sqrt"]))
+        return layers
     cls = AdditivePatchKernel if h.get("kernel", "conv") == "add" else ConvKernel
     kern = cls(RBF(view.patch_length, h["variance"], h["ls"]), view, patch_weights=h["w"])
     layers.append(SVGP_Layer(kern=kern, num_outputs=h["R"], feature=PatchInducingFeatures(h["Z"]),
@@ -131,7 +136,17 @@ class ModelBuilder(object):
                 print("filter_size {} != {} for last layer. Resetting parameters.".format(filter_size, saved))
                 Z = q_mu = q_sqrt = None
         if self.flags.last_kernel == 'rbf':
-            raise NotImplementedError("RBF-ARD head is not on the accelerated path yet (SURVEY.md 8 f-4)")
+            # dense head on the flattened features: RBF with one lengthscale per dimension, k-means inducing points
+            # (conv_gp/models.py:160-168, select_initial_inducing_points :24-27)
+            flat = H_X.reshape(H_X.shape[0], -1)
+            kernel = RBF(flat.shape[1], variance=float(layer_params.get('variance', 5.0)),
+                         lengthscales=layer_params.get('lengthscales', 5.0), ARD=True)
+            Z = layer_params.get('Z')
+            if Z is None:
+                from sklearn import cluster
+                Z = cluster.KMeans(n_clusters=M, init='k-means++', n_init=1).fit(flat).cluster_centers_
+            return SVGP_Layer(kern=kernel, num_outputs=10, feature=InducingPoints(Z), mean_function=None,
+                              white=self.flags.white, q_mu=q_mu, q_sqrt=q_sqrt)
         variance = float(layer_params.get('base_kernel/variance', 5.0))
         lengthscales = float(layer_params.get('base_kernel/lengthscales', 5.0))
         input_dim = filter_size ** 2 * NHWC[3]

@@ -90,7 +90,7 @@ def _acos0(A, B, variance, wv, bv):
 
 
 def make_spec(hwc, convs, head, M, S=10, num_data=60000, seed=0, white=False, q_mu_random=True,
-              conv_q_sqrt_scale=1e-5, head_q_sqrt_scale=1.0, head_outputs=10, variance=5.0, ls=5.0, base_kernel="rbf"):
+              conv_q_sqrt_scale=1e-5, head_q_sqrt_scale=1.0, head_outputs=10, variance=5.0, ls=5.0, base_kernel="rbf", head_kernel="conv"):
     """Build a model spec (see module docstring) with seeded synthetic parameters."""
     rng = np.random.default_rng(seed)
     H, W, C = hwc
@@ -112,6 +112,21 @@ def make_spec(hwc, convs, head, M, S=10, num_data=60000, seed=0, white=False, q_
         spec["convs"].append(layer)
         init_imgs = _identity_conv(init_imgs, f, R, s)
         h, w, c = init_imgs.shape[1:]
+    f, s = head
+    if head_kernel == "rbf":   # dense RBF-ARD head on the flattened features (--last-kernel rbf, conv_gp/models.py:160-168)
+        flat = init_imgs.reshape(init_imgs.shape[0], -1)
+        D = flat.shape[1]
+        Z = flat[rng.integers(0, flat.shape[0], M)] + 0.05 * rng.standard_normal((M, D))
+        ls_ard = ls * (0.8 + 0.4 * rng.random(D))
+        Zs = Z / ls_ard
+        Ku = _rbf(Zs, Zs, variance, 1.0) + JITTER * np.eye(M)
+        spec["head"] = dict(H=h, W=w, C=c, f=f, s=s, M=M, R=head_outputs, Z=Z, variance=variance, ls=ls, ls_ard=ls_ard,
+                            kernel="rbf", w=np.ones(1),
+                            q_mu=(rng.standard_normal((M, head_outputs)) if q_mu_random else np.zeros((M, head_outputs))),
+                            q_sqrt=(np.tile(np.eye(M)[None], [head_outputs, 1, 1]) if white
+                                    else np.tile(np.linalg.cholesky(Ku)[None], [head_outputs, 1, 1]) * head_q_sqrt_scale),
+                            white=bool(white))
+        return spec
     f, s = head
     Z = _cut_patches(rng, init_imgs, M, f)
     Ku = _rbf(Z, Z, variance, ls) + JITTER * np.eye(M)

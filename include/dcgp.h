@@ -167,7 +167,9 @@ int dcgp_model_set_head(dcgp_model* model, int H, int W, int C, int f, int strid
 int dcgp_model_set_keep_outputs(dcgp_model* model, int on);
 /* Push a changed parameter: which = "Z", "Z0", "q_mu", "q_sqrt", "w", "variance", "lengthscale", or
  * "base_kernel" = {type, variance, p1, p2}: type 0 RBF (p1 = lengthscale), type 1 ArcCosine order 0 (p1 = weight
- * variance, p2 = bias variance; conv layers only, conv_gp/models.py:113-121).                        */
+ * variance, p2 = bias variance; conv layers only, conv_gp/models.py:113-121), or "ard_lengthscales" = one lengthscale
+ * per input dimension for a single-patch head (H = W = f = 1, C = D): gpflow RBF(D, ARD=True) on the flattened
+ * features, the dense head of --last-kernel rbf (conv_gp/models.py:160-168).                          */
 int dcgp_model_set_param(dcgp_model* model, int layer, const char* which, const double* value_host,
                          size_t count);
 

@@ -15,16 +15,22 @@ FLOAT = np.float64
 
 
 class RBF:
-    """gpflow.kernels.RBF(input_dim, variance, lengthscales) with scalar lengthscale.
+    """gpflow.kernels.RBF(input_dim, variance, lengthscales, ARD=False).
 
-    Call sites: conv_gp/layers.py:20,29,40,49; conv_gp/kernels.py:114,123,136;
-    construction conv_gp/models.py:114-117 (variance=5, lengthscales=5).
+    Call sites: conv_gp/layers.py:20,29,40,49; conv_gp/kernels.py:114,123,136; construction
+    conv_gp/models.py:114-117 (variance=5, lengthscales=5, scalar) and :163-164 (ARD=True on the flattened features
+    of the dense head: one lengthscale per input dimension, initialised to the scalar).
     """
 
-    def __init__(self, input_dim, variance=1.0, lengthscales=1.0):
+    def __init__(self, input_dim, variance=1.0, lengthscales=1.0, ARD=False):
         self.input_dim = int(input_dim)
         self.variance = float(variance)
-        self.lengthscales = float(lengthscales)
+        self.ARD = bool(ARD)
+        if self.ARD:
+            ls = np.asarray(lengthscales, FLOAT)
+            self.lengthscales = np.full(self.input_dim, float(ls)) if ls.ndim == 0 else ls.reshape(self.input_dim).copy()
+        else:
+            self.lengthscales = float(lengthscales)
 
     def square_dist(self, X, X2=None):
         # GPflow 1.2 Stationary.square_dist: scale, then |x|^2 + |x'|^2 - 2 x.x' (no clamp).
@@ -41,6 +47,14 @@ class RBF:
 
     def Kdiag(self, X):
         return np.full(np.shape(X)[0], self.variance, FLOAT)
+
+    # gpflow.features.InducingPoints dispatch (Kuu = K(Z) + jitter I, Kuf = K(Z, X)) in the Kzz / Kzx vocabulary of
+    # conv_gp/kernels.py:172-178, so that the dense head goes through the same SVGP_Layer code
+    def Kzz(self, Z):
+        return self.K(Z)
+
+    def Kzx(self, Z, X):
+        return self.K(Z, X)
 
 
 class ArcCosine:

@@ -18,6 +18,10 @@ def oracle_layers(spec):
         layer.Z0 = np.array(c["Z0"], np.float64)
         layers.append(layer)
     h = spec["head"]
+    if h.get("kernel", "conv") == "rbf":   # dense RBF-ARD head: gpflow InducingPoints + RBF(ARD=True)
+        layers.append(SVGP_Layer(RBF(h["Z"].shape[1], h["variance"], h["ls_ard"], ARD=True), h["R"], h["Z"], None,
+                                 white=h["white"], q_mu=h["q_mu"], q_sqrt=h["q_sqrt"]))
+        return layers
     view = FullView((h["H"], h["W"], h["C"]), h["f"], h["C"], h["s"])
     kern = ConvKernel(RBF(view.patch_length, h["variance"], h["ls"]), view, patch_weights=h["w"])
     layers.append(SVGP_Layer(kern, h["R"], h["Z"], None, white=h["white"], q_mu=h["q_mu"], q_sqrt=h["q_sqrt"]))

@@ -284,3 +284,32 @@ def test_elbo_acos_base_kernel(ctx):
     e2 = model.compute_log_likelihood(X, Y, zs=zs)
     assert abs(e2 - ref.compute_log_likelihood(X, Y, zs=zs)) <= 1e-8 * abs(e2) and e2 != e
     model.close()
+
+
+@pytest.mark.parametrize("white", [False, True])
+def test_elbo_dense_rbf_ard_head(ctx, white):
+    """--last-kernel rbf (conv_gp/models.py:160-168): conv layer + dense RBF(ARD=True) head on the flattened 12 x 12 x 10
+    features (D = 1440), one lengthscale per dimension, through the fused model path."""
+    hwc = (28, 28, 1)
+    spec = syn.make_spec(hwc, [(5, 2, 10)], (5, 1), M=40, S=2, num_data=60000, seed=33, head_kernel="rbf", white=white,
+                         conv_q_sqrt_scale=0.2, ls=5.0)
+    spec["head"]["ls_ard"] = spec["head"]["ls_ard"] * 6.0      # sqrt(D)-ish scale so that the head kernel is not ~delta
+    X, Y = syn.make_batch(hwc, 4, seed=33)
+    zs = syn.make_noise(spec, 4, seed=33)
+    ref, model = oracle_model(spec, X, Y), build_from_spec(spec, X, Y)
+    e, dt, kl = model.compute_log_likelihood(X, Y, zs=zs, return_parts=True)
+    assert abs(dt - ref.data_term(X, Y, zs=zs)) <= RTOL * abs(dt)
+    assert abs(kl - ref.KL()) <= RTOL * max(abs(kl), 1.0)
+    assert abs(e - ref.compute_log_likelihood(X, Y, zs=zs)) <= RTOL * abs(e)
+    pm, pv = model.predict_y(X, 2, zs=zs)
+    om, ov = ref.predict_y(X, 2, zs=zs)
+    assert rel(pm, om) < RTOL and rel(pv, ov) < RTOL
+    # the lengthscales are parameters: change them on both sides, push, compare again
+    new_ls = spec["head"]["ls_ard"] * 1.3
+    model.layers[-1].kern.lengthscales = new_ls.copy()
+    ref.layers[-1].kern.lengthscales = new_ls.copy()
+    model.sync_parameters()
+    e2 = model.compute_log_likelihood(X, Y, zs=zs)
+    assert abs(e2 - ref.compute_log_likelihood(X, Y, zs=zs)) <= RTOL * abs(e2) and e2 != e
+    assert [p.pathname for p in model.parameters if "/layers/1/kern" in p.pathname] == ["DGP/layers/1/kern/variance", "DGP/layers/1/kern/lengthscales"]
+    model.close()

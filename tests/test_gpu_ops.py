@@ -290,3 +290,27 @@ def test_acos_conv_layer(ctx, white):
     close(m, om, 1e-8, "mean")
     close(var, ovar, 1e-8, "var")
     close(layer.KL(), olayer.KL(), 1e-8, "KL")
+
+
+# ---- dense RBF-ARD head (--last-kernel rbf, conv_gp/models.py:160-168): gpflow RBF(D, ARD=True) + InducingPoints ----
+@pytest.mark.parametrize("white", [False, True])
+@pytest.mark.parametrize("D,M,N", [(20, 7, 5), (360, 24, 9), (1440, 48, 6)])
+def test_rbf_ard_dense_head(ctx, white, D, M, N):
+    from deepcgp_amd.kernels import RBF, InducingPoints
+    from deepcgp_amd.layers import SVGP_Layer
+    rng = np.random.default_rng(D + M)
+    R = 10
+    X = rng.standard_normal((N, D))
+    Z = rng.standard_normal((M, D))
+    ls = 3.0 * np.sqrt(D / 20.0) * (0.8 + 0.4 * rng.random(D))
+    _, q_mu, q_sqrt = rand_spd_inputs(rng, M, R, D, 0.2)
+    k, ok = RBF(D, 2.5, ls, ARD=True), ORBF(D, 2.5, ls, ARD=True)
+    close(k.K(Z), ok.K(Z), 1e-10, "K(Z)")
+    close(k.K(Z, X), ok.K(Z, X), 1e-10, "K(Z, X)")
+    layer = SVGP_Layer(k, R, InducingPoints(Z), None, white=white, q_mu=q_mu, q_sqrt=q_sqrt)
+    olayer = OSVGP(ok, R, Z, None, white=white, q_mu=q_mu, q_sqrt=q_sqrt)
+    m, v = layer.conditional_ND(X)
+    om, ov = olayer.conditional_ND(X)
+    close(m, om, 1e-9, "mean")
+    close(v, ov, 1e-9, "var")
+    close(layer.KL(), olayer.KL(), 1e-9, "KL")
