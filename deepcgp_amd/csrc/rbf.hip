@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256, 4) void patch_rbf_kernel(PatchRbfArgs a) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) rsum[x][v] = 0.0;
 
+  const bool one_chunk = a.Lp <= PR_BK;
   for (int pt = pt_lo; pt < pt_hi; ++pt) {
     const int p0 = pt * PR_BP + wn * 32;
     int pb[2];
@@ -168,17 +169,21 @@ __global__ __launch_bounds__(256, 4) void patch_rbf_kernel(PatchRbfArgs a) {
     double xn[2] = {0.0, 0.0};
 
     for (int k0 = 0; k0 < a.Lp; k0 += PR_BK) {
-      __syncthreads();   // previous chunk fully consumed
-      // stage ZT[k0 .. k0+BK) x [m0 .. m0+64): 32 rows x 32 double2 chunks = 1024 chunks / 256 threads
+      // stage ZT[k0 .. k0+BK) x [m0 .. m0+64): 32 rows x 32 double2 chunks = 1024 chunks / 256 threads.  A patch
+      // length of one chunk (L <= 32: every first layer) is staged once for all the patch tiles of the workgroup --
+      // the reduce mode walks all of them, and re-staging cost two barriers and an L2 round trip per tile.
+      if (!(one_chunk && pt > pt_lo)) {
+        __syncthreads();   // previous chunk fully consumed
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        int ch = tid + c * 256;
-        int row = ch >> 5, col = (ch & 31) * 2;
-        double2 v = double2{0.0, 0.0};
-        if (k0 + row < a.Lp && m0 + col < a.Mp) v = *reinterpret_cast<const double2*>(a.ZT + (long)(k0 + row) * a.Mp + m0 + col);
-        *reinterpret_cast<double2*>(zt + row * PR_LDZ + col) = v;
+        for (int c = 0; c < 4; ++c) {
+          int ch = tid + c * 256;
+          int row = ch >> 5, col = (ch & 31) * 2;
+          double2 v = double2{0.0, 0.0};
+          if (k0 + row < a.Lp && m0 + col < a.Mp) v = *reinterpret_cast<const double2*>(a.ZT + (long)(k0 + row) * a.Mp + m0 + col);
+          *reinterpret_cast<double2*>(zt + row * PR_LDZ + col) = v;
+        }
+        __syncthreads();
       }
-      __syncthreads();
       const int kmax = min(PR_BK, a.Lp - k0);
       for (int kk = 0; kk < kmax; kk += 4) {
         const int k = k0 + kk + lrow;
