@@ -1,14 +1,15 @@
 // cond.hip -- the doubly-stochastic SVGP conditional (conv_gp/conditionals.py:6-67) and the scalar
 // terms around it (gauss_kl, RobustMax variational expectations, reparameterisation).
 //
-// With Lm = chol(Kmm) and Linv = inv(Lm) the reference's per-patch triangular solves become three
-// k-major matrix-core products on the [M x (P*N)] Kuf matrix (gemm.hip):
-//     A1 = Linv  Kuf            lower-triangular W      -> s1[j]   = sum_m A1[m,j]^2        (:31-33,:40)
-//     A  = Linv' A1             upper-triangular W                                           (:44-47)
-//     T_r= Lq_r' A  (no store)  upper-triangular W, x R -> s2[r,j] = sum_m T_r[m,j]^2        (:55-65)
-//     mu[r,j] = sum_m q_mu[m,r] A[m,j]                                                       (:50)
+// With Lm = chol(Kmm) and Linv = inv(Lm) the reference's per-patch triangular solves become k-major matrix-core
+// products on the [M x (P*N)] Kuf matrix (gemm.hip); the second solve (A = Linv' A1, :44-47) is folded into the small
+// operands G_r = Linv Lq_r and alpha = Linv q_mu (cond_prep / prep_solve_kernel), so the big matrix is passed twice:
+//     A1 = Linv Kuf              lower-triangular W      -> s1[j]   = sum_m A1[m,j]^2        (:31-33,:40)
+//     T_r = G_r' A1 (no store)   upper-triangular W, x R -> s2[r,j] = sum_m T_r[m,j]^2        (:55-65)
+//     mu[r,j] = sum_m alpha[m,r] A1[m,j]                                                      (:50)
 // and a fused epilogue forms var = Knn - s1 + s2, the N x (P*R) output layout of
-// conv_gp/layers.py:128-131 and the sample mean + z*sqrt(var + jitter).
+// conv_gp/layers.py:128-131 and the sample mean + z*sqrt(var + jitter).  (A few-column problem -- the head -- takes
+// the one-launch route of head_cond.hip instead.)
 #include "layer_impl.h"
 
 namespace {

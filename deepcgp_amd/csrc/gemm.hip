@@ -4,16 +4,16 @@
 //
 // Both operands are k-major so that every LDS fill is a plain row copy and every MFMA operand read
 // is a 16-double contiguous ds_read_b64 group.  W may be lower/upper triangular (the triangular
-// solves of the reference are applied as products with the inverted factor, and L_r^T A is an
+// solves of the reference are applied as products with the inverted factor, and G_r^T A1 is an
 // upper-triangular product): k tiles that are structurally zero are skipped per workgroup AND per
-// wave.  The epilogue optionally stores C and/or reduces sum_i C[i][j]^2 per column (the
+// 16-row fragment.  The epilogue optionally stores C and/or reduces sum_i C[i][j]^2 per column (the
 // reduce_sum(square(A), 1) / reduce_sum(square(LTA), 1) of conditionals.py:40,65) so the
 // R x M x (P*N) intermediate of the reference is never materialised.
 //
 // Tile: BM x BN output per workgroup, BK = 16; waves in a WAVES_M x WAVES_N grid, each owning
-// FM x FN 16x16 accumulator fragments (4 f64 per lane each).  Register-staged double buffering:
-// the global loads of k-tile t+1 are issued before the MFMAs of k-tile t and written to the other
-// LDS buffer afterwards -- one barrier per k-tile.
+// FM x FN 16x16 accumulator fragments (4 f64 per lane each).  Double-buffered LDS, one barrier per k-tile: the
+// 128 x 128 tile of 16 waves fills the other buffer with LDS-DMA loads issued before the MFMAs of the current
+// k-tile; the smaller tiles stage through registers.
 #include <cstdlib>
 
 #include "common.h"

@@ -2,13 +2,13 @@
 // _build_likelihood of doubly_stochastic_dgp; ConvLayer.conditional_ND of conv_gp/layers.py:96-135;
 // SVGP_Layer.conditional_ND with the ConvKernel head of conv_gp/kernels.py:79-136).
 //
-// Per forward step, on ONE stream, nothing cached across steps:
-//   1. every layer: Kuu(Z) (+ prior Kuu(Z0)), padded q_sqrt / q_mu, Z^T and |z|^2
-//   2. ONE batched Cholesky + ONE batched triangular inverse for all M x M matrices of the model
-//   3. KL terms (one GEMM + one small kernel per layer)
-//   4. conv layers: patch-RBF sweep -> 3 conditional GEMMs -> mean -> finalize (+ sample)
-//   5. head: Kzx (patch sweep reduced over patches), Kdiag, conditional, RobustMax expectations
-//   6. (multi-GPU) all-reduce of the data term, ELBO assembly, one 32-byte read-back.
+// Per forward step, nothing cached across steps (main stream = the data path, side stream = the replicated M x M work):
+//   1. main: every layer's Kuu(Z) (+ prior Kuu(Z0)), padded q_sqrt / q_mu, Z^T and |z|^2 -- one launch (prep.hip)
+//   2. side: ONE batched Cholesky + inverse chain for all M x M matrices of the model (chol_fused.hip), then G / alpha of
+//      every layer in one launch (head_cond.hip), then the KL terms; main meanwhile: the first layer's patch sweep
+//   3. main, per conv layer: patch sweep -> stage-1 GEMM -> stage-3 GEMM -> mean -> finalize (+ sample)
+//   4. main: head Kzx sweep (Kdiag beside it on the side stream), fused head conditional, RobustMax expectations
+//   5. (multi-GPU) all-reduce of the data term, ELBO assembly, one 32-byte read-back, one host sync.
 #include <cstdlib>
 #include <cstring>
 #include <memory>
