@@ -104,6 +104,33 @@ struct GemmArgs {
 int gemm_tn(dcgp_ctx* ctx, const GemmArgs& a, int* n_row_blocks_out);
 int gemm_row_block(int Mi, int Kc, int batch);   // BM the dispatcher picks (callers size partial-sum buffers with it)
 
+// exp() for the kernel sweeps.  The device library's exp is the same range reduction + degree-13 polynomial, but hipcc
+// turns every Horner step into v_fmac with the coefficient re-materialised into a fresh VGPR pair (two v_mov each):
+// ~45 VALU instructions per value where 19 do the work, and the sweeps' epilogues are VALU-bound on it.  Here each
+// step is a v_fma_f64 whose addend is the coefficient in an SGPR pair (one scalar operand per VOP3 is free).
+__device__ __forceinline__ double exp_sweep(double x) {
+  const double kf = rint(x * 1.4426950408889634074);          // x / ln 2
+  double r = fma(-kf, 6.93147180369123816490e-01, x);        // Cody-Waite: ln 2 in two pieces
+  r = fma(-kf, 1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;                          // 1/13!  (|r| <= ln2/2: remainder r^14/14! < 5e-18)
+#define DCGP_EXP_STEP(c) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(r), "s"((double)(c)))
+  DCGP_EXP_STEP(2.08767569878681e-09);      // 1/12!
+  DCGP_EXP_STEP(2.505210838544172e-08);     // 1/11!
+  DCGP_EXP_STEP(2.755731922398589e-07);     // 1/10!
+  DCGP_EXP_STEP(2.7557319223985893e-06);    // 1/9!
+  DCGP_EXP_STEP(2.48015873015873e-05);      // 1/8!
+  DCGP_EXP_STEP(1.984126984126984e-04);     // 1/7!
+  DCGP_EXP_STEP(1.388888888888889e-03);     // 1/6!
+  DCGP_EXP_STEP(8.333333333333333e-03);     // 1/5!
+  DCGP_EXP_STEP(4.1666666666666664e-02);    // 1/4!
+  DCGP_EXP_STEP(1.6666666666666666e-01);    // 1/3!
+  DCGP_EXP_STEP(0.5);
+  DCGP_EXP_STEP(1.0);
+  DCGP_EXP_STEP(1.0);
+#undef DCGP_EXP_STEP
+  return ldexp(p, (int)kf);   // exact scaling; underflows to 0 below ~ -745, NaN stays NaN
+}
+
 // The base kernel of a layer, evaluated from (x.z, |x|^2, |z|^2):
 //   type 0  gpflow RBF:           variance * exp(-(|x|^2 + |z|^2 - 2 x.z) / (2 l^2))     p1 = 1 / l^2 (square_dist form, no clamp)
 //   type 1  gpflow ArcCosine(0):  variance * (pi - theta) / pi,  theta = acos(1e-15 + (1 - 2e-15) cos),
@@ -113,14 +140,14 @@ struct BaseKernel {
   int type = 0;
   double variance = 1.0, p1 = 1.0, p2 = 0.0;
   template <int T>   // the hot sweeps are instantiated per type: the acos code must not cost the RBF path registers
-  __host__ __device__ __forceinline__ double eval_as(double dot, double n1, double n2) const {
-    if (T == 0) return variance * exp(-0.5 * (n1 + n2 - 2.0 * dot) * p1);
+  __device__ __forceinline__ double eval_as(double dot, double n1, double n2) const {
+    if (T == 0) return variance * exp_sweep(-0.5 * (n1 + n2 - 2.0 * dot) * p1);
     const double c = (p1 * dot + p2) / sqrt((p1 * n1 + p2) * (p1 * n2 + p2));
     // fmin: on a diagonal entry cos can round a few ulp above 1 (dot and norms are accumulated in different orders)
     // and overshoot the reference's 1e-15 guard -- acos() would return NaN there, as the reference formula does
     return variance * (1.0 - acos(fmin(1e-15 + (1.0 - 2e-15) * c, 1.0)) * 0.31830988618379067154);
   }
-  __host__ __device__ __forceinline__ double eval(double dot, double n1, double n2) const {
+  __device__ __forceinline__ double eval(double dot, double n1, double n2) const {
     return type == 0 ? eval_as<0>(dot, n1, n2) : eval_as<1>(dot, n1, n2);
   }
 };
