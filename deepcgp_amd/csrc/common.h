@@ -128,7 +128,8 @@ __device__ __forceinline__ double exp_sweep(double x) {
   DCGP_EXP_STEP(1.0);
   DCGP_EXP_STEP(1.0);
 #undef DCGP_EXP_STEP
-  return ldexp(p, (int)kf);   // exact scaling; underflows to 0 below ~ -745, NaN stays NaN
+  // exact scaling; underflows gradually to 0 below ~ -745 (the guard covers -inf, where r would be NaN); NaN stays NaN
+  return x < -746.0 ? 0.0 : ldexp(p, (int)kf);
 }
 
 // The base kernel of a layer, evaluated from (x.z, |x|^2, |z|^2):
