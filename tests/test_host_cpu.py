@@ -99,3 +99,38 @@ def test_two_rank_gloo_elbo_allreduce():
     vals = [float(o.strip().splitlines()[-1].split()[-1]) for o in outs]
     assert vals[0] == vals[1]
     assert "OK" in outs[0]
+
+
+def test_kernel_host_classes_validate_without_a_device():
+    """Constructor-level behaviour of the gpflow stand-ins that needs no GPU: parameter validation, ARD expansion,
+    the {type, variance, p1, p2} description pushed to the device model, InducingPoints length."""
+    from deepcgp_amd.kernels import RBF, ArcCosine, InducingPoints
+    k = RBF(4, variance=2.0, lengthscales=3.0)
+    assert k._describe() == [0.0, 2.0, 3.0, 0.0] and not k.ARD
+    ka = RBF(3, variance=1.5, lengthscales=5.0, ARD=True)            # scalar initial value -> one lengthscale per dimension
+    assert ka.lengthscales.shape == (3,) and np.all(ka.lengthscales == 5.0) and ka._describe() == [0.0, 1.5, 1.0, 0.0]
+    assert np.allclose(RBF(2, lengthscales=[1.0, 4.0], ARD=True)._scaled(np.array([[2.0, 2.0]])), [[2.0, 0.5]])
+    with pytest.raises(ValueError):
+        RBF(2, variance=-1.0)
+    with pytest.raises(ValueError):
+        RBF(2, lengthscales=[1.0, 0.0], ARD=True)
+    with pytest.raises(ValueError):
+        ka._scaled(np.zeros((2, 5)))                                  # wrong input length
+    a = ArcCosine(7, order=0)                                         # gpflow defaults (conv_gp/models.py:119)
+    assert a._describe() == [1.0, 1.0, 1.0, 1.0] and np.all(a.Kdiag(np.zeros((3, 7))) == 1.0)
+    with pytest.raises(NotImplementedError):
+        ArcCosine(7, order=1)
+    with pytest.raises(ValueError):
+        ArcCosine(7, weight_variances=0.0)
+    assert len(InducingPoints(np.zeros((5, 2)))) == 5
+
+
+def test_synthetic_spec_variants():
+    """make_spec's kernel variants: acos conv layers carry base = 'acos', the dense head carries per-dimension lengthscales."""
+    from deepcgp_amd import synthetic as syn
+    s1 = syn.make_spec((12, 12, 1), [(3, 1, 2)], (3, 1), M=6, S=2, base_kernel="acos")
+    assert s1["convs"][0]["base"] == "acos" and s1["head"].get("kernel", "conv") == "conv"
+    s2 = syn.make_spec((12, 12, 1), [(3, 2, 2)], (3, 1), M=6, S=2, head_kernel="rbf")
+    h = s2["head"]
+    assert h["kernel"] == "rbf" and h["Z"].shape == (6, 5 * 5 * 2) and h["ls_ard"].shape == (50,) and h["w"].shape == (1,)
+    assert syn.layer_output_dims(s2) == [5 * 5 * 2, 10]
