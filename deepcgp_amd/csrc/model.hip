@@ -20,6 +20,7 @@ struct dcgp_model {
   dcgp_ctx* ctx = nullptr;
   int S = 1;
   double jitter = 1e-3;
+  double eps = 1e-3;   // RobustMax epsilon (conv_gp/models.py:67 keeps gpflow's default)
   std::vector<std::unique_ptr<LayerState>> layers;   // conv layers..., head last (once set)
   bool has_head = false;
   bool keep_outputs = false;
@@ -308,6 +309,11 @@ int dcgp_model_set_head(dcgp_model* model, int H, int W, int C, int f, int strid
 int dcgp_model_set_param(dcgp_model* model, int layer, const char* which, const double* value_host, size_t count) {
   if (!model || !which || !value_host) return DCGP_ERR_ARG;
   dcgp_ctx* ctx = model->ctx;
+  if (!strcmp(which, "likelihood_epsilon")) {   // model-wide, `layer` is ignored
+    if (count != 1 || !(value_host[0] > 0 && value_host[0] < 1)) return ctx_fail(ctx, DCGP_ERR_ARG, "set_param(likelihood_epsilon): one value in (0, 1)");
+    model->eps = value_host[0];
+    return DCGP_OK;
+  }
   if (layer < 0 || layer >= (int)model->layers.size()) return ctx_fail(ctx, DCGP_ERR_ARG, "set_param: no layer %d", layer);
   LayerState& L = *model->layers[layer];
   auto expect = [&](size_t n) { return count == n ? DCGP_OK : ctx_fail(ctx, DCGP_ERR_ARG, "set_param(%s): expected %zu values, got %zu", which, n, count); };
@@ -365,7 +371,7 @@ int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int 
   LayerState& H = *model->layers[nl - 1];
   auto& o = model->outs[nl - 1];
   DCGP_TRY(ensure(ctx, &model->d_ve, &model->ve_cap, (size_t)rows));
-  DCGP_TRY(varexp_rows(ctx, o.mean, o.var, y, rows, N, H.R, 1e-3, model->d_ve, 0));
+  DCGP_TRY(varexp_rows(ctx, o.mean, o.var, y, rows, N, H.R, model->eps, model->d_ve, 0));
   // rows == S*N normally; a head-only model under dedup has rows == N with S identical copies
   const double inv_s = (rows == S * N) ? 1.0 / S : 1.0;
   DCGP_TRY(reduce_sum(ctx, model->d_ve, rows, inv_s, model->d_scal));
@@ -405,6 +411,44 @@ int dcgp_model_propagate(dcgp_model* model, const double* X, int N, int S, const
   size_t n = (size_t)rows * o.width;
   if (out_fmean) HIP_TRY(ctx, hipMemcpyAsync(out_fmean, o.mean, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   if (out_fvar) HIP_TRY(ctx, hipMemcpyAsync(out_fvar, o.var, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return read_info(model, info_host);
+}
+
+namespace {
+// mean over the S samples of the class probabilities: p_bar[n][k] = 1/S sum_s p[s*N + n][k]
+__global__ void sample_mean_kernel(const double* __restrict__ p, int S, long NK, double* __restrict__ out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NK) return;
+  double acc = 0.0;
+  for (int s = 0; s < S; ++s) acc += p[(long)s * NK + i];
+  out[i] = acc / (double)S;
+}
+}  // namespace
+
+int dcgp_model_predict_y(dcgp_model* model, const double* X, int N, int S, const double* const* z_per_layer_host,
+                         uint64_t seed, double* out_p, double* out_p_mean, int* info_host) {
+  if (!model || !X || N <= 0 || S <= 0 || (!out_p && !out_p_mean))
+    return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "predict_y: bad args") : DCGP_ERR_ARG;
+  dcgp_ctx* ctx = model->ctx;
+  if (info_host) *info_host = 0;
+  int rows = 0;
+  DCGP_TRY(forward_all(model, X, N, S, z_per_layer_host, seed, 0, false, &rows));
+  const int nl = (int)model->layers.size();
+  auto& o = model->outs[nl - 1];
+  const int K = o.width;
+  if (K < 2) return ctx_fail(ctx, DCGP_ERR_ARG, "predict_y: the last layer has %d outputs, RobustMax needs >= 2", K);
+  double* p = out_p;
+  if (!p) {
+    p = (double*)ws_get(ctx, "predict_p", (size_t)rows * K * sizeof(double));
+    if (!p) return DCGP_ERR_ALLOC;
+  }
+  DCGP_TRY(varexp_rows(ctx, o.mean, o.var, nullptr, rows, 1, K, model->eps, p, 1));
+  if (out_p_mean) {
+    long NK = (long)N * K;
+    hipLaunchKernelGGL(sample_mean_kernel, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, ctx->stream, p, S, NK, out_p_mean);
+    LAUNCH_CHECK(ctx);
+  }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return read_info(model, info_host);
 }

@@ -85,6 +85,8 @@ class DGP_Base:
         if getattr(base, "ARD", False):
             ls = np.ascontiguousarray(base.lengthscales, np.float64)
             ctx._check(L.dcgp_model_set_param(self._model, len(self.layers) - 1, b"ard_lengthscales", ls.ctypes.data, ls.size))
+        eps = np.array([float(getattr(self.likelihood, "epsilon", 1e-3))])
+        ctx._check(L.dcgp_model_set_param(self._model, 0, b"likelihood_epsilon", eps.ctypes.data, 1))
 
     def sync_parameters(self):
         """Push the current Python-side parameter values to the device copy."""
@@ -108,6 +110,7 @@ class DGP_Base:
                     push(li, "w", l.kern.patch_weights)
             else:
                 push(li, "Z0", l.Z_prior)
+        push(0, "likelihood_epsilon", float(getattr(self.likelihood, "epsilon", 1e-3)))
 
     @property
     def parameters(self):
@@ -199,12 +202,36 @@ class DGP_Base:
             L.dcgp_model_set_keep_outputs(self._model, 0)
         return Fs, Fm, Fv
 
+    def _predict(self, X, S, zs, seed, want_samples, want_mean):
+        self._build()
+        ctx, L = self._ctx, dev.lib()
+        X = np.ascontiguousarray(np.reshape(X, (np.shape(X)[0], -1)), np.float64)
+        N, K = X.shape[0], self.layers[-1].num_outputs
+        dX = ctx.to_device(X)
+        arr, keep = self._z_table(zs, N, S)
+        p = ctx.empty((S * N, K)) if want_samples else None
+        pm = ctx.empty((N, K)) if want_mean else None
+        info = C.c_int(0)
+        rc = L.dcgp_model_predict_y(self._model, dX.ptr, N, int(S), arr, int(seed), p.ptr if p else None,
+                                    pm.ptr if pm else None, C.byref(info))
+        ctx._check(rc, info)
+        return (p.numpy().reshape(S, N, K) if p else None), (pm.numpy() if pm else None)
+
     def predict_y(self, X, S, zs=None, seed=0):
-        """(mean, var) of p(y*) per sample: S x N x num_classes (used at conv_gp/utils/log.py:62-66)."""
-        _, Fm, Fv = self.propagate(X, S=S, zs=zs, seed=seed)
-        Sn, N, D = Fm[-1].shape
-        m, v = self.likelihood.predict_mean_and_var(Fm[-1].reshape(Sn * N, D), Fv[-1].reshape(Sn * N, D))
-        return m.reshape(Sn, N, -1), v.reshape(Sn, N, -1)
+        """(mean, var) of p(y*) per sample: S x N x num_classes (used at conv_gp/utils/log.py:62-66).
+        One device call: forward pass and RobustMax quadrature, only the probabilities come back."""
+        if np.shape(X)[0] == 0:
+            K = self.layers[-1].num_outputs
+            return np.zeros((S, 0, K)), np.zeros((S, 0, K))
+        ps, _ = self._predict(X, S, zs, seed, True, False)
+        return ps, ps - np.square(ps)
+
+    def predict_proba(self, X, S, zs=None, seed=0):
+        """Class probabilities averaged over the S samples, N x num_classes (the quantity AccuracyLogger
+        arg-maxes, conv_gp/utils/log.py:62-67); the sample mean is taken on the device."""
+        if np.shape(X)[0] == 0:
+            return np.zeros((0, self.layers[-1].num_outputs))
+        return self._predict(X, S, zs, seed, False, True)[1]
 
     def KL(self):
         return float(sum(l.KL() for l in self.layers))

@@ -57,6 +57,25 @@ def save_model_parameters(model, path, global_step=0):
     return params
 
 
+class AccuracyLogger(object):
+    """Test accuracy the way the reference's training log computes it (conv_gp/utils/log.py:50-67): batches of 32,
+    five samples per image, arg-max of the sample-mean class probabilities.  Each batch is one device call
+    (``predict_proba``); only N x num_classes probabilities cross the bus."""
+    title = 'test_accuracy'
+
+    def __init__(self, X_test, Y_test, batch_size=32, num_samples=5):
+        self.X_test, self.Y_test = X_test, np.reshape(Y_test, (-1,))
+        self.batch_size, self.num_samples = int(batch_size), int(num_samples)
+
+    def __call__(self, model, seed=0):
+        correct = 0
+        for i, lo in enumerate(range(0, len(self.Y_test), self.batch_size)):
+            sl = slice(lo, lo + self.batch_size)
+            p = model.predict_proba(self.X_test[sl], self.num_samples, seed=seed + i)
+            correct += int((p.argmax(axis=1) == self.Y_test[sl]).sum())
+        return correct / max(self.Y_test.size, 1)
+
+
 def identity_conv(NHWC_X, filter_size, feature_maps_in, feature_maps_out, stride, count=1000):
     """Propagate random images through IdentityConv2dMean to initialise the next layer
     (conv_gp/models.py:29-33, conv_gp/mean_functions.py:6-26)."""

@@ -169,7 +169,8 @@ int dcgp_model_set_keep_outputs(dcgp_model* model, int on);
  * "base_kernel" = {type, variance, p1, p2}: type 0 RBF (p1 = lengthscale), type 1 ArcCosine order 0 (p1 = weight
  * variance, p2 = bias variance; conv layers only, conv_gp/models.py:113-121), or "ard_lengthscales" = one lengthscale
  * per input dimension for a single-patch head (H = W = f = 1, C = D): gpflow RBF(D, ARD=True) on the flattened
- * features, the dense head of --last-kernel rbf (conv_gp/models.py:160-168).                          */
+ * features, the dense head of --last-kernel rbf (conv_gp/models.py:160-168).  "likelihood_epsilon" (one value in
+ * (0, 1), `layer` ignored) is the RobustMax epsilon of the ELBO / predict_y entry points (default 1e-3).  */
 int dcgp_model_set_param(dcgp_model* model, int layer, const char* which, const double* value_host,
                          size_t count);
 
@@ -188,6 +189,13 @@ int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int 
 int dcgp_model_propagate(dcgp_model* model, const double* X, int N, int S,
                          const double* const* z_per_layer_host, uint64_t seed,
                          double* out_fmean, double* out_fvar, int* info_host);
+/* DGP_Base.predict_y(X, S) with the RobustMax likelihood, device end to end (doubly_stochastic_dgp
+ * predict_y -> likelihood.predict_mean_and_var; caller at conv_gp/utils/log.py:62-66): out_p [S*N, K]
+ * class probabilities per sample (the predictive variance is p - p^2), out_p_mean [N, K] their mean over
+ * the S samples (what AccuracyLogger arg-maxes).  Either output may be NULL, not both.  Device buffers. */
+int dcgp_model_predict_y(dcgp_model* model, const double* X, int N, int S,
+                         const double* const* z_per_layer_host, uint64_t seed,
+                         double* out_p, double* out_p_mean, int* info_host);
 /* Output of layer `layer` from the most recent forward: sample/mean/var [rows, D_l] device->device copy. */
 int dcgp_model_layer_output(dcgp_model* model, int layer, double* out_sample, double* out_mean,
                             double* out_var, int* rows, int* width);

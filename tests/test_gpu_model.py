@@ -69,6 +69,41 @@ def test_elbo_vs_oracle_midsize(ctx, case, white):
     pm, pv = model.predict_y(X, S, zs=zs)
     om, ov = ref.predict_y(X, S, zs=zs)
     assert rel(pm, om) < RTOL and rel(pv, ov) < RTOL
+    pbar = model.predict_proba(X, S, zs=zs)
+    assert pbar.shape == (N, 10) and rel(pbar, om.mean(axis=0)) < RTOL
+    model.close()
+
+
+def test_predict_y_epsilon_and_accuracy_logger(ctx):
+    """predict_y is one device call (forward + RobustMax quadrature); a non-default RobustMax epsilon reaches
+    both it and the ELBO; AccuracyLogger (conv_gp/utils/log.py:50-67) over ragged batches equals the
+    arg-max of the oracle's sample-mean probabilities."""
+    from deepcgp_amd.models import AccuracyLogger
+    hwc, N, S = (28, 28, 1), 7, 5
+    spec = syn.make_spec(hwc, [(5, 2, 10)], (5, 1), 32, S=S, num_data=1000, seed=5, conv_q_sqrt_scale=0.2)
+    X, Y = syn.make_batch(hwc, N, seed=5)
+    ref = oracle_model(spec, X, Y)
+    model = build_from_spec(spec, X, Y)
+    for eps in (1e-3, 0.05):
+        ref.likelihood.epsilon = eps
+        ref.likelihood.eps_k1 = eps / (ref.likelihood.num_classes - 1.0)
+        model.likelihood.epsilon = eps
+        model.sync_parameters()
+        zs = syn.make_noise(spec, N, seed=6)
+        pm, pv = model.predict_y(X, S, zs=zs)
+        om, ov = ref.predict_y(X, S, zs=zs)
+        assert rel(pm, om) < RTOL and rel(pv, ov) < RTOL
+        e = model.compute_log_likelihood(X, Y, zs=zs)
+        assert abs(e - ref.compute_log_likelihood(X, Y, zs=zs)) <= RTOL * abs(e)
+    # device RNG path: the logger's answer must equal the arg-max of its own probabilities, batch by batch
+    logger = AccuracyLogger(X, Y, batch_size=3, num_samples=S)
+    acc = logger(model, seed=11)
+    want = 0
+    for i, lo in enumerate(range(0, N, 3)):
+        p, _ = model.predict_y(X[lo:lo + 3], S, seed=11 + i)
+        want += int((p.mean(axis=0).argmax(axis=1) == Y.reshape(-1)[lo:lo + 3]).sum())
+    assert acc == want / N
+    assert model.predict_y(X[:0], S)[0].shape == (S, 0, 10)
     model.close()
 
 
