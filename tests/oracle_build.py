@@ -30,3 +30,21 @@ def oracle_layers(spec):
 
 def oracle_model(spec, X, Y):
     return DGP_Base(X, Y, MultiClass(10), oracle_layers(spec), num_samples=spec["S"], num_data=spec["num_data"])
+
+
+def oracle_param_handles(model):
+    """[(layer index, gradient name, getter, setter)] of every trainable value of an oracle model with RBF base
+    kernels -- the names oracle.grad.elbo_and_grad and dcgp_model_get_grad use."""
+    out, nl = [], len(model.layers)
+    for li, l in enumerate(model.layers):
+        head = li == nl - 1
+        kern = l.kern.base_kernel if head else l.base_kernel
+        out.append((li, "Z", lambda l=l: l.Z, lambda v, l=l: setattr(l, "Z", v)))
+        out.append((li, "q_mu", lambda l=l: l.q_mu, lambda v, l=l: setattr(l, "q_mu", v)))
+        out.append((li, "q_sqrt", lambda l=l: l.q_sqrt, lambda v, l=l: setattr(l, "q_sqrt", v)))
+        out.append((li, "variance", lambda k=kern: np.array(k.variance), lambda v, k=kern: setattr(k, "variance", float(v))))
+        out.append((li, "lengthscales", lambda k=kern: np.array(k.lengthscales),
+                    lambda v, k=kern: setattr(k, "lengthscales", float(v))))
+        if head:
+            out.append((li, "patch_weights", lambda l=l: l.kern.patch_weights, lambda v, l=l: setattr(l.kern, "patch_weights", v)))
+    return out

@@ -203,3 +203,39 @@ def test_arccosine_order0_known_answers():
     c = (0.5 * 0.0 + 2.0) / np.sqrt((0.5 * 5.0 + 2.0) * (0.5 * 1.25 + 2.0))
     assert abs(kb.K(x, z)[0, 0] - (1.0 - np.arccos(1e-15 + (1 - 2e-15) * c) / np.pi)) < 1e-15
     assert np.allclose(kb.K(x, z), kb.K(z, x).T)
+
+
+@pytest.mark.parametrize("white,additive", [(False, False), (False, True), (True, False), (True, True)])
+def test_hand_written_gradient_against_finite_differences(white, additive):
+    """oracle/grad.py (the checker of the device backward pass) against central differences of the oracle ELBO
+    along random directions of every parameter group; three layers so that the sample path between layers,
+    overlapping-patch scatter and both head kernels are exercised."""
+    from oracle.grad import elbo_and_grad
+    from oracle_build import oracle_param_handles
+    hwc, seed = (10, 10, 1), 3
+    spec = syn.make_spec(hwc, [(3, 1, 2), (3, 2, 2)], (2, 1), 6, S=2, num_data=100, seed=seed, white=white,
+                         conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5)
+    rng = np.random.default_rng(seed)
+    spec["head"]["w"] = 0.5 + rng.random(spec["head"]["w"].shape)
+    X, Y = syn.make_batch(hwc, 3, seed=seed)
+    zs = syn.make_noise(spec, 3, seed=seed)
+    m = oracle_model(spec, X, Y)
+    if additive:
+        k = m.layers[-1].kern
+        m.layers[-1].kern = AdditivePatchKernel(k.base_kernel, k.view, k.patch_weights)
+    e, grads = elbo_and_grad(m, X, Y, zs)
+    assert abs(e - m.compute_log_likelihood(X, Y, zs=zs)) <= 1e-12 * abs(e)
+    for li, name, get, set_ in oracle_param_handles(m):
+        v0 = np.array(get(), np.float64)
+        g = np.asarray(grads[li][name])
+        assert g.shape == v0.shape
+        for _ in range(2):
+            d = rng.standard_normal(v0.shape)
+            if name == "q_sqrt":
+                d = np.tril(d)
+            h = 1e-5
+            set_(v0 + h * d); ep = m.compute_log_likelihood(X, Y, zs=zs)
+            set_(v0 - h * d); em = m.compute_log_likelihood(X, Y, zs=zs)
+            set_(v0)
+            fd, an = (ep - em) / (2 * h), float(np.sum(g * d))
+            assert abs(fd - an) <= 1e-4 * max(abs(fd), abs(an), 1e-3), (li, name, fd, an)
