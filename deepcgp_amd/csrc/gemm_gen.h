@@ -1,0 +1,18 @@
+// Internal: general strided fp64 GEMM (gemm_gen.hip), the workhorse of the backward pass.
+#pragma once
+#include "common.h"
+
+// C_b(i, j) (+)= alpha * colscale_b[j] * sum_k A_b(i, k) B_b(k, j)
+//   A_b(i, k) = A[b * a_bs + i * a_rs + k * a_cs],  B_b(k, j) = B[b * b_bs + k * b_rs + j * b_cs],
+//   C_b(i, j) = C[b * c_bs + i * c_rs + j],         colscale_b[j] = colscale[b * cs_bs + j * cs_s] (optional)
+struct GenGemm {
+  const double* A = nullptr; long a_rs = 0, a_cs = 0, a_bs = 0;
+  const double* B = nullptr; long b_rs = 0, b_cs = 0, b_bs = 0;
+  double* C = nullptr; long c_rs = 0, c_bs = 0;
+  int M = 0, N = 0, K = 0, batch = 1;
+  double alpha = 1.0;
+  int accumulate = 0;      // C += ... instead of C = ...
+  const double* colscale = nullptr; long cs_s = 0, cs_bs = 0;
+  int lower_only = 0;      // entries with j > i are written as 0 (before accumulation)
+};
+int gemm_gen(dcgp_ctx* ctx, const GenGemm& g);

@@ -1,0 +1,808 @@
+// grad.hip -- reverse pass of the ELBO (the reference gets it from TensorFlow autodiff of the graph it
+// builds at conv_gp/experiment.py:84-108).  Runs over the state the forward pass (model.hip) left on the device:
+// every layer's K_uf and A1 = inv(L) K_uf, the factors and their inverses, G_r / alpha, and the per-layer
+// (sample, mean, var).  Per layer, given d ELBO / d(mean, var) of its outputs:
+//
+//   conditional   mean = alpha^T A1,  var = Knn - sum_m A1^2 + sum_m (G_r^T A1)^2   (the forward's re-association)
+//     dT_r = 2 (G_r^T A1) o dvar_r                      d alpha = A1 dmean          dG_r = tril(A1 dT_r^T)
+//     dA1  = alpha dmean^T - 2 A1 o sum_r dvar_r + sum_r G_r dT_r
+//     unwhitened: dq_mu = inv(L)^T d alpha, dq_sqrt_r = tril(inv(L)^T dG_r), dL -= tril(dq_mu alpha^T + sum_r (inv(L)^T dG_r) G_r^T)
+//     dKuf = inv(L)^T dA1,  dL -= tril(dKuf A1^T)
+//   Cholesky      S = inv(L)^T Phi(L^T dL) inv(L)   (Phi: lower triangle, diagonal halved; Murray 2016), used unsymmetrised
+//   kernels       E = dK o K:  dvariance = sum E / variance, dlengthscale = sum E d^2 / l^3,
+//                 dZ = (E X - rowsum(E) o Z) / l^2,  dX = (E^T Z - colsum(E) o X) / l^2  on im2col'd patches, col2im gather
+//   KL            closed form in inv(K) (no second Cholesky adjoint), sample: dmean += dF, dvar += dF (F - mean) / (2 (var + jitter))
+//
+// All products go through gemm_gen (strided MFMA GEMM, deterministic split-k); the rest are elementwise / reduction kernels.
+// Everything is ordered on the main stream.  The oracle for this file is oracle/grad.py.
+#include "model_state.h"
+#include "gemm_gen.h"
+
+namespace {
+
+constexpr int VAR_SLOT = 0, LS_SLOT = 16;   // gslots: [0, 16) variance contributions, [16, 32) lengthscale contributions
+
+inline unsigned blocks_for(long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+__device__ __forceinline__ double block_sum_256(double v, double* red) {
+  const int t = threadIdx.x;
+  red[t] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) red[t] += red[t + s];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// ---- likelihood ------------------------------------------------------------------------------------------------
+// d sum_rows weight * ve(row) / d(mu, var): one thread per (row, class).  Same quadrature as varexp_kernel (cond.hip):
+// 20 Gauss-Hermite nodes, cdf = (1 - 2e-4) Phi + 1e-4, clips at 1e-10.
+__global__ void robustmax_grad_kernel(const double* __restrict__ mu, const double* __restrict__ var, const int32_t* __restrict__ y,
+                                      int rows, int n_labels, int K, double eps, const double* __restrict__ gh, double weight,
+                                      double* __restrict__ gm, double* __restrict__ gv) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * K) return;
+  const int row = (int)(idx / K), k = (int)(idx % K);
+  const int lab = y[row % n_labels];
+  const double* m = mu + (long)row * K;
+  const double* v = var + (long)row * K;
+  const double muy = m[lab], vy = v[lab];
+  const bool live_y = 2.0 * vy > 1e-10;
+  const double sy = sqrt(fmax(2.0 * vy, 1e-10));
+  const double c = log(1.0 - eps) - log(eps / (K - 1.0));
+  const double inv_sqrt_pi = 0.56418958354775628695, inv_sqrt_2pi = 0.39894228040143267794;
+  double acc_mu = 0.0, acc_var = 0.0;
+  for (int g = 0; g < 20; ++g) {
+    const double xg = gh[g], wg = gh[20 + g] * inv_sqrt_pi;
+    const double X = muy + xg * sy;
+    double prod = 1.0;
+    for (int kk = 0; kk < K; ++kk) {
+      if (kk == lab) continue;
+      const double d = (X - m[kk]) / sqrt(fmax(v[kk], 1e-10));
+      prod *= 0.5 * (1.0 + erf(d * 0.70710678118654752440)) * (1.0 - 2e-4) + 1e-4;
+    }
+    if (k != lab) {
+      const double sig = sqrt(fmax(v[k], 1e-10));
+      const double d = (X - m[k]) / sig;
+      const double cdf = 0.5 * (1.0 + erf(d * 0.70710678118654752440)) * (1.0 - 2e-4) + 1e-4;
+      const double q = wg * prod / cdf * exp(-0.5 * d * d) * inv_sqrt_2pi * (1.0 - 2e-4);
+      acc_mu -= q / sig;
+      if (v[k] > 1e-10) acc_var -= q * d / (2.0 * v[k]);
+    } else {
+      double qs = 0.0;
+      for (int kk = 0; kk < K; ++kk) {
+        if (kk == lab) continue;
+        const double sig = sqrt(fmax(v[kk], 1e-10));
+        const double d = (X - m[kk]) / sig;
+        const double cdf = 0.5 * (1.0 + erf(d * 0.70710678118654752440)) * (1.0 - 2e-4) + 1e-4;
+        qs += wg * prod / cdf * exp(-0.5 * d * d) * inv_sqrt_2pi * (1.0 - 2e-4) / sig;
+      }
+      acc_mu += qs;
+      if (live_y) acc_var += qs * xg / sy;
+    }
+  }
+  gm[idx] = c * weight * acc_mu;
+  gv[idx] = c * weight * acc_var;
+}
+
+// previous layer's (dmean, dvar) from d sample:  sample = mean + z sqrt(var + jitter),  z = (sample - mean) / sqrt(var + jitter)
+__global__ void sample_backward_kernel(const double* __restrict__ dF, const double* __restrict__ sample, const double* __restrict__ mean,
+                                       const double* __restrict__ var, double jitter, long n, double* __restrict__ gm,
+                                       double* __restrict__ gv) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double d = dF[i];
+  gm[i] = d;
+  gv[i] = d * (sample[i] - mean[i]) / (2.0 * (var[i] + jitter));
+}
+
+// ---- conditional -----------------------------------------------------------------------------------------------
+__global__ void rowsum_small_kernel(const double* __restrict__ a, long n, int R, double* __restrict__ out) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  double s = 0.0;
+  for (int r = 0; r < R; ++r) s += a[c * R + r];
+  out[c] = s;
+}
+
+// dA1[m][c] -= 2 A1[m][c] gvs[c]
+__global__ void dA1_fix_kernel(double* __restrict__ dA1, const double* __restrict__ A1, const double* __restrict__ gvs, int M, long Kc,
+                               long ld) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = blockIdx.y;
+  if (c >= Kc || m >= M) return;
+  dA1[m * ld + c] -= 2.0 * A1[m * ld + c] * gvs[c];
+}
+
+// dst_b[i][j] (+)= alpha * (j <= i ? src_b[i][j] : 0)
+__global__ void mask_lower_kernel(const double* __restrict__ src, long lds, long sbs, double* __restrict__ dst, long ldd, long dbs, int M,
+                                  double alpha, int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
+  if (j >= M) return;
+  const double v = j <= i ? alpha * src[b * sbs + i * lds + j] : 0.0;
+  double* d = dst + b * dbs + i * ldd + j;
+  *d = accumulate ? *d + v : v;
+}
+
+// dst[i][j] (+)= alpha * src[i][j]   (rectangular copy between leading dimensions)
+__global__ void copy2d_kernel(const double* __restrict__ src, long lds, double* __restrict__ dst, long ldd, int rows, int cols, double alpha,
+                              int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= cols || i >= rows) return;
+  const double v = alpha * src[i * lds + j];
+  double* d = dst + i * ldd + j;
+  *d = accumulate ? *d + v : v;
+}
+
+// Phi: keep the lower triangle, halve the diagonal (in place)
+__global__ void phi_kernel(double* __restrict__ P, long ld, int M) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= M) return;
+  double v = P[i * ld + j];
+  P[i * ld + j] = j < i ? v : (j == i ? 0.5 * v : 0.0);
+}
+
+// gq_sqrt[r][i][i] += 1 / Lq[r][i][i]   (- d/dLq of -1/2 log det(Lq Lq^T))
+__global__ void kl_diag_kernel(double* __restrict__ gq, const double* __restrict__ Lq, int M, int Mp, int R) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * R) return;
+  const int r = idx / M, i = idx % M;
+  gq[((long)r * M + i) * M + i] += 1.0 / Lq[((long)r * Mp + i) * Mp + i];
+}
+
+// ---- RBF Gram backward ------------------------------------------------------------------------------------------
+// One block per row i.  S = d ELBO / dK (not symmetrised).  Writes Es[i][j] = (S_ij + S_ji) k_ij (or nothing if Es is
+// null), rs[i] = sum_j Es[i][j], and the per-row partial sums pv[i] = sum_j S_ij k_ij / variance, pl[i] = sum_j S_ij k_ij d_ij^2 / l^3.
+__global__ __launch_bounds__(256) void kuu_backward_kernel(const double* __restrict__ Z, int M, int L, const double* __restrict__ S, long lds,
+                                                           double variance, double inv_l2, double inv_l3, double* __restrict__ Es, long lde,
+                                                           double* __restrict__ rs, double* __restrict__ pv, double* __restrict__ pl) {
+  __shared__ double red[256];
+  const int i = blockIdx.x, t = threadIdx.x;
+  double srow = 0.0, sv = 0.0, sl = 0.0;
+  for (int j = t; j < M; j += 256) {
+    double d2 = 0.0;
+    for (int l = 0; l < L; ++l) {
+      const double d = Z[(long)i * L + l] - Z[(long)j * L + l];
+      d2 += d * d;
+    }
+    const double k = variance * exp(-0.5 * d2 * inv_l2);
+    const double e = S[i * lds + j] * k;
+    sv += e;
+    sl += e * d2;
+    if (Es) {
+      const double es = e + S[j * lds + i] * k;
+      Es[i * lde + j] = es;
+      srow += es;
+    }
+  }
+  const double a = block_sum_256(srow, red), b = block_sum_256(sv, red), c = block_sum_256(sl, red);
+  if (t == 0) {
+    if (rs) rs[i] = a;
+    pv[i] = b / variance;
+    pl[i] = c * inv_l3;
+  }
+}
+
+// ---- patch kernels backward -------------------------------------------------------------------------------------
+// Xcol[c][l], c = n * P + p, l = (kh * f + kw) * C + ch  (FullView.extract_patches, conv_gp/views.py:46-54)
+__global__ void im2col_kernel(const double* __restrict__ X, int n_mod, int H, int W, int C, int f, int s, int Wo, int P, int L, long Kc,
+                              double* __restrict__ Xcol) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Kc * L) return;
+  const long c = idx / L;
+  const int l = (int)(idx % L);
+  const int n = (int)(c / P), p = (int)(c % P);
+  const int oh = p / Wo, ow = p % Wo, ch = l % C, kw = (l / C) % f, kh = l / (C * f);
+  Xcol[idx] = X[(((long)(n % n_mod) * H + oh * s + kh) * W + ow * s + kw) * C + ch];
+}
+
+// dX[n][h][w][ch] = sum over the patches that contain the pixel (adjoint of extract_patches; gather, no atomics)
+__global__ void col2im_kernel(const double* __restrict__ dXcol, int N, int H, int W, int C, int f, int s, int Ho, int Wo, int L,
+                              double* __restrict__ dX) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)N * H * W * C) return;
+  const int ch = (int)(idx % C);
+  const int w = (int)((idx / C) % W), h = (int)((idx / ((long)C * W)) % H);
+  const int n = (int)(idx / ((long)C * W * H));
+  const int P = Ho * Wo;
+  double acc = 0.0;
+  for (int kh = 0; kh < f; ++kh) {
+    const int hh = h - kh;
+    if (hh < 0 || hh % s) continue;
+    const int oh = hh / s;
+    if (oh >= Ho) continue;
+    for (int kw = 0; kw < f; ++kw) {
+      const int ww = w - kw;
+      if (ww < 0 || ww % s) continue;
+      const int ow = ww / s;
+      if (ow >= Wo) continue;
+      acc += dXcol[((long)n * P + oh * Wo + ow) * L + (kh * f + kw) * C + ch];
+    }
+  }
+  dX[idx] = acc;
+}
+
+// One thread per column c, loop over the M rows:  E[m][c] = dK[m][c / pdiv] * (w ? w[c % pdiv] * wscale : 1) * K[m][c]
+// (written over dKE when pdiv == 1, else into E), cs[c] = sum_m E, raw[c] = sum_m dK K (head: for d patch_weights),
+// per-block partials pv[block] = sum E, pl[block] = sum E d^2 with d^2 = -2 l^2 log(K / variance).
+__global__ __launch_bounds__(256) void e_form_kernel(const double* __restrict__ dK, long lddk, int pdiv, const double* __restrict__ w,
+                                                     double wscale, const double* __restrict__ K, long ldk, double* __restrict__ E, long lde,
+                                                     int M, long Kc, double inv_var, double two_l2, double* __restrict__ cs,
+                                                     double* __restrict__ raw, double* __restrict__ pv, double* __restrict__ pl) {
+  __shared__ double red[256];
+  const long c = (long)blockIdx.x * 256 + threadIdx.x;
+  double sc = 0.0, sr = 0.0, sd = 0.0;
+  if (c < Kc) {
+    const long cd = c / pdiv;
+    const double f = w ? w[c % pdiv] * wscale : 1.0;
+    for (int m = 0; m < M; ++m) {
+      const double k = K[m * ldk + c];
+      const double r = dK[m * lddk + cd] * k;
+      const double e = r * f;
+      E[m * lde + c] = e;
+      sr += r;
+      sc += e;
+      if (k > 0.0) sd -= e * two_l2 * log(k * inv_var);
+    }
+    cs[c] = sc;
+    if (raw) raw[c] = sr;
+  }
+  const double a = block_sum_256(sc, red), b = block_sum_256(sd, red);
+  if (threadIdx.x == 0) { pv[blockIdx.x] = a; pl[blockIdx.x] = b; }
+}
+
+// out[m] = sum_c A[m][c]: one block per row
+__global__ __launch_bounds__(256) void rowsum_big_kernel(const double* __restrict__ A, long ld, long Kc, double* __restrict__ out) {
+  __shared__ double red[256];
+  const int m = blockIdx.x;
+  double s = 0.0;
+  for (long c = threadIdx.x; c < Kc; c += 256) s += A[m * ld + c];
+  const double r = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[m] = r;
+}
+
+// dst[i][l] (+)= alpha * (P[i][l] - v[i] * X[i][l])
+__global__ void axmy_kernel(const double* __restrict__ Pm, const double* __restrict__ v, const double* __restrict__ X, long rows, int L,
+                            double alpha, int accumulate, double* __restrict__ dst) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * L) return;
+  const long i = idx / L;
+  const double val = alpha * (Pm[idx] - v[i] * X[idx]);
+  dst[idx] = accumulate ? dst[idx] + val : val;
+}
+
+// out[p] (+)= scale * sum_n raw[n * P + p]
+__global__ void strided_sum_kernel(const double* __restrict__ raw, int N, int P, double scale, int accumulate, double* __restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  double s = 0.0;
+  for (int n = 0; n < N; ++n) s += raw[(long)n * P + p];
+  out[p] = accumulate ? out[p] + scale * s : scale * s;
+}
+
+// ConvKernel.Kdiag backward (conv_gp/kernels.py:106-115): block per (image n, patch p), thread per p'.
+// Gm[n][p][p'] = x_p . x_p' in, E[n][p][p'] = g_n w_p w_p' k_pp' / P^2 out (over Gm; the squared norms come from the
+// copy `norms`, because other blocks overwrite the diagonal they would otherwise be read from).
+__global__ __launch_bounds__(256) void kdiag_backward_kernel(double* __restrict__ Gm, const double* __restrict__ norms, const double* __restrict__ gkd,
+                                                             const double* __restrict__ w, int P, double variance, double inv_l2,
+                                                             double* __restrict__ dwn, double* __restrict__ pv, double* __restrict__ pl) {
+  __shared__ double red[256];
+  const int n = blockIdx.y, p = blockIdx.x;
+  double* G = Gm + (long)n * P * P;
+  const double gpp = norms[(long)n * P + p];
+  const double coef = gkd[n] / ((double)P * P);
+  double se = 0.0, sd = 0.0, sw = 0.0;
+  for (int q = threadIdx.x; q < P; q += 256) {
+    const double d2 = gpp + norms[(long)n * P + q] - 2.0 * G[(long)p * P + q];
+    const double k = variance * exp(-0.5 * d2 * inv_l2);
+    const double e = coef * w[p] * w[q] * k;
+    sw += k * w[q];
+    se += e;
+    sd += e * d2;
+    G[(long)p * P + q] = e;
+  }
+  const double a = block_sum_256(se, red), b = block_sum_256(sd, red), c = block_sum_256(sw, red);
+  if (threadIdx.x == 0) {
+    const long o = (long)n * P + p;
+    pv[o] = a;          // sum E over the row (also the row sum the patch gradient needs)
+    pl[o] = b;
+    dwn[o] = 2.0 * coef * c;
+  }
+}
+// AdditivePatchKernel.Kdiag = variance * mean(w):  t[0] = sum_n g_n, t[1] = mean(w)
+__global__ void additive_kdiag_backward_kernel(const double* __restrict__ t, int P, double variance, double* __restrict__ gw,
+                                               double* __restrict__ var_slot) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < P) gw[p] += t[0] * variance / P;
+  if (p == 0) *var_slot = t[0] * t[1];
+}
+__global__ void kdiag_norms_kernel(const double* __restrict__ Gm, int P, long n_img, double* __restrict__ norms) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_img * P) return;
+  const long n = idx / P;
+  const int p = (int)(idx % P);
+  norms[idx] = Gm[(n * P + p) * P + p];
+}
+
+__global__ void fill_kernel(double* __restrict__ p, long n, double v) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__global__ void scal_finish_kernel(const double* __restrict__ slots, double* __restrict__ gscal) {
+  if (threadIdx.x || blockIdx.x) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < 16; ++i) { a += slots[VAR_SLOT + i]; b += slots[LS_SLOT + i]; }
+  gscal[0] = a;
+  gscal[1] = b;
+}
+
+// ---- host helpers ------------------------------------------------------------------------------------------------
+struct Bk {   // per-backward bookkeeping
+  dcgp_model* m;
+  dcgp_ctx* ctx;
+  std::string pfx;   // workspace prefix of the layer being processed
+  int slot_v = 0, slot_l = 0;
+  double* ws(const char* name, size_t n_doubles) { return (double*)ws_get(ctx, pfx + "g_" + name, (n_doubles ? n_doubles : 1) * sizeof(double)); }
+};
+
+GenGemm mk(const double* A, long ars, long acs, const double* B, long brs, long bcs, double* C, long crs, int M, int N, int K) {
+  GenGemm g;
+  g.A = A; g.a_rs = ars; g.a_cs = acs; g.B = B; g.b_rs = brs; g.b_cs = bcs; g.C = C; g.c_rs = crs; g.M = M; g.N = N; g.K = K;
+  return g;
+}
+
+#define NEED(p) do { if (!(p)) return DCGP_ERR_ALLOC; } while (0)
+
+// add scale * sum(part[0..n)) to the next variance / lengthscale slot of the layer
+int add_scalar(Bk& bk, LayerState& L, bool lengthscale, const double* part, long n, double scale) {
+  int& s = lengthscale ? bk.slot_l : bk.slot_v;
+  if (s >= 16) return ctx_fail(bk.ctx, DCGP_ERR_ARG, "grad: out of scalar slots");
+  DCGP_TRY(reduce_sum(bk.ctx, part, n, scale, L.gslots + (lengthscale ? LS_SLOT : VAR_SLOT) + s));
+  ++s;
+  return DCGP_OK;
+}
+
+// RBF Gram backward from S = d ELBO / dK (unsymmetrised).  dZ accumulates into L.gZ when Zsrc is the live Z (want_dz).
+int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, long lds, bool want_dz) {
+  dcgp_ctx* ctx = bk.ctx;
+  const int M = L.M, Ld = L.v.L;
+  const double inv_l2 = 1.0 / (L.ls * L.ls), inv_l3 = inv_l2 / L.ls;
+  double *Es = nullptr, *rs = nullptr;
+  double* pv = bk.ws("kuu_pv", M);
+  double* pl = bk.ws("kuu_pl", M);
+  NEED(pv); NEED(pl);
+  if (want_dz) { Es = bk.ws("kuu_Es", (size_t)M * M); rs = bk.ws("kuu_rs", M); NEED(Es); NEED(rs); }
+  hipLaunchKernelGGL(kuu_backward_kernel, dim3(M), dim3(256), 0, ctx->stream, Zsrc, M, Ld, S, lds, L.variance, inv_l2, inv_l3, Es, (long)M, rs, pv, pl);
+  LAUNCH_CHECK(ctx);
+  DCGP_TRY(add_scalar(bk, L, false, pv, M, 1.0));
+  DCGP_TRY(add_scalar(bk, L, true, pl, M, 1.0));
+  if (want_dz) {
+    double* EX = bk.ws("kuu_EX", (size_t)M * Ld);
+    NEED(EX);
+    DCGP_TRY(gemm_gen(ctx, mk(Es, M, 1, Zsrc, Ld, 1, EX, Ld, M, Ld, M)));
+    hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for((long)M * Ld)), dim3(256), 0, ctx->stream, EX, rs, Zsrc, (long)M, Ld, inv_l2, 1, L.gZ);
+    LAUNCH_CHECK(ctx);
+  }
+  return DCGP_OK;
+}
+
+// Patch-kernel backward: E [M x Kc] (ld) = d ELBO / dKfull o Kfull is ready, cs = its column sums.
+// dZ += (E Xcol - rowsum(E) o Z) / l^2;  dXcol (=|+=) (E^T Z - cs o Xcol) / l^2 when requested.
+int patch_backward(Bk& bk, LayerState& L, const double* E, long ld, long Kc, const double* cs, const double* Xcol, double* dXcol,
+                   int dx_accumulate) {
+  dcgp_ctx* ctx = bk.ctx;
+  const int M = L.M, Ld = L.v.L;
+  const double inv_l2 = 1.0 / (L.ls * L.ls);
+  double* rs = bk.ws("pb_rs", M);
+  double* EX = bk.ws("pb_EX", (size_t)M * Ld);
+  NEED(rs); NEED(EX);
+  hipLaunchKernelGGL(rowsum_big_kernel, dim3(M), dim3(256), 0, ctx->stream, E, ld, Kc, rs);
+  LAUNCH_CHECK(ctx);
+  DCGP_TRY(gemm_gen(ctx, mk(E, ld, 1, Xcol, Ld, 1, EX, Ld, M, Ld, (int)Kc)));
+  hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for((long)M * Ld)), dim3(256), 0, ctx->stream, EX, rs, L.Z, (long)M, Ld, inv_l2, 1, L.gZ);
+  LAUNCH_CHECK(ctx);
+  if (dXcol) {
+    double* EtZ = bk.ws("pb_EtZ", (size_t)Kc * Ld);
+    NEED(EtZ);
+    DCGP_TRY(gemm_gen(ctx, mk(E, 1, ld, L.Z, Ld, 1, EtZ, Ld, (int)Kc, Ld, M)));
+    hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for(Kc * Ld)), dim3(256), 0, ctx->stream, EtZ, cs, Xcol, Kc, Ld, inv_l2, dx_accumulate, dXcol);
+    LAUNCH_CHECK(ctx);
+  }
+  return DCGP_OK;
+}
+
+// KL backward of one layer (ELBO = ... - KL).  Returns with -dKL/dK_prior ADDED to Sacc [M x M, ld Mp] when Sacc != null
+// (head: the prior shares the live Z), otherwise pushed through the Gram backward on the frozen Z0 (conv layers).
+int kl_backward(Bk& bk, LayerState& L, double* Sacc) {
+  dcgp_ctx* ctx = bk.ctx;
+  const int M = L.M, Mp = L.Mp, R = L.R, Rp = L.g.Rp;
+  const long mm = (long)Mp * Mp;
+  if (L.white) {
+    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(R), M), dim3(256), 0, ctx->stream, L.q_mu, (long)R, L.gq_mu, (long)R, M, R, -1.0, 1);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, L.g.Lq, (long)Mp, mm, L.gq_sqrt, (long)M,
+                       (long)M * M, M, -1.0, 1);
+    LAUNCH_CHECK(ctx);
+  } else {
+    const double* Lpinv = L.g.Kp ? L.g.Lpinv : L.g.Linv;
+    double* a1 = bk.ws("kl_a1", (size_t)Mp * Rp);
+    double* Kimu = bk.ws("kl_Kimu", (size_t)Mp * Rp);
+    double* Wm = bk.ws("kl_W", (size_t)R * mm);
+    double* KiL = bk.ws("kl_KiL", (size_t)R * mm);
+    NEED(a1); NEED(Kimu); NEED(Wm); NEED(KiL);
+    DCGP_TRY(gemm_gen(ctx, mk(Lpinv, Mp, 1, L.q_mu, R, 1, a1, Rp, M, R, M)));
+    DCGP_TRY(gemm_gen(ctx, mk(Lpinv, 1, Mp, a1, Rp, 1, Kimu, Rp, M, R, M)));
+    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(R), M), dim3(256), 0, ctx->stream, Kimu, (long)Rp, L.gq_mu, (long)R, M, R, -1.0, 1);
+    LAUNCH_CHECK(ctx);
+    GenGemm g1 = mk(Lpinv, Mp, 1, L.g.Lq, Mp, 1, Wm, Mp, M, M, M);
+    g1.batch = R; g1.b_bs = mm; g1.c_bs = mm;
+    DCGP_TRY(gemm_gen(ctx, g1));
+    GenGemm g2 = mk(Lpinv, 1, Mp, Wm, Mp, 1, KiL, Mp, M, M, M);
+    g2.batch = R; g2.b_bs = mm; g2.c_bs = mm;
+    DCGP_TRY(gemm_gen(ctx, g2));
+    hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, KiL, (long)Mp, mm, L.gq_sqrt, (long)M,
+                       (long)M * M, M, -1.0, 1);
+    LAUNCH_CHECK(ctx);
+    // -dKL/dK = -1/2 [R inv(K) - (inv(K) q_mu)(inv(K) q_mu)^T - sum_r (inv(K) Lq_r)(inv(K) Lq_r)^T]
+    double* Sk = Sacc;
+    int acc = 1;
+    if (!Sk) { Sk = bk.ws("kl_S", (size_t)mm); NEED(Sk); acc = 0; }
+    GenGemm g3 = mk(Lpinv, 1, Mp, Lpinv, Mp, 1, Sk, Mp, M, M, M);
+    g3.alpha = -0.5 * R; g3.accumulate = acc;
+    DCGP_TRY(gemm_gen(ctx, g3));
+    GenGemm g4 = mk(Kimu, Rp, 1, Kimu, 1, Rp, Sk, Mp, M, M, R);
+    g4.alpha = 0.5; g4.accumulate = 1;
+    DCGP_TRY(gemm_gen(ctx, g4));
+    for (int r = 0; r < R; ++r) {
+      GenGemm g5 = mk(KiL + r * mm, Mp, 1, KiL + r * mm, 1, Mp, Sk, Mp, M, M, M);
+      g5.alpha = 0.5; g5.accumulate = 1;
+      DCGP_TRY(gemm_gen(ctx, g5));
+    }
+    if (!Sacc) DCGP_TRY(kuu_backward(bk, L, L.Z0, Sk, Mp, false));   // frozen Z0: hyper-parameters only
+  }
+  hipLaunchKernelGGL(kl_diag_kernel, dim3(blocks_for((long)M * R)), dim3(256), 0, ctx->stream, L.gq_sqrt, L.g.Lq, M, Mp, R);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
+// The conditional's backward shared by conv layers and the head.  Kuf, A1: [Mp x ld] with Kc live columns;
+// gm, gv: [Kc][R].  Leaves dKuf in `dKuf` [M x ld], writes L.gq_mu / L.gq_sqrt (overwrites), and S = d ELBO / dKuu
+// (data part) in `S` [M x M, ld Mp]; gvs [Kc] = sum_r gv (= d ELBO / d Knn).
+int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, const double* gm, const double* gv, double* dKuf, double* S,
+                  double* gvs) {
+  dcgp_ctx* ctx = bk.ctx;
+  const int M = L.M, Mp = L.Mp, R = L.R, Rp = L.g.Rp;
+  const long mm = (long)Mp * Mp;
+  const GpMats& g = L.g;
+  hipLaunchKernelGGL(rowsum_small_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, gv, Kc, R, gvs);
+  LAUNCH_CHECK(ctx);
+  double* dA1 = bk.ws("dA1", (size_t)Mp * ld);
+  double* dalpha = bk.ws("dalpha", (size_t)Mp * Rp);
+  double* dG = bk.ws("dG", (size_t)R * mm);
+  double* dL = bk.ws("dL", (size_t)mm);
+  NEED(dA1); NEED(dalpha); NEED(dG); NEED(dL);
+  // dA1 = alpha gm^T - 2 A1 o gvs
+  DCGP_TRY(gemm_gen(ctx, mk(g.alpha, Rp, 1, gm, 1, R, dA1, ld, M, (int)Kc, R)));
+  hipLaunchKernelGGL(dA1_fix_kernel, dim3(blocks_for(Kc), M), dim3(256), 0, ctx->stream, dA1, A1, gvs, M, Kc, ld);
+  LAUNCH_CHECK(ctx);
+  // d alpha = A1 gm
+  DCGP_TRY(gemm_gen(ctx, mk(A1, ld, 1, gm, R, 1, dalpha, Rp, M, R, (int)Kc)));
+  if (L.has_qsqrt) {
+    double* dT = bk.ws("dT", (size_t)R * Mp * ld);
+    NEED(dT);
+    GenGemm t = mk(g.G, 1, Mp, A1, ld, 1, dT, ld, M, (int)Kc, M);   // dT_r = 2 (G_r^T A1) o gv_r
+    t.batch = R; t.a_bs = mm; t.c_bs = (long)Mp * ld; t.alpha = 2.0; t.colscale = gv; t.cs_s = R; t.cs_bs = 1;
+    DCGP_TRY(gemm_gen(ctx, t));
+    for (int r = 0; r < R; ++r) {                                    // dA1 += G_r dT_r
+      GenGemm a = mk(g.G + r * mm, Mp, 1, dT + (long)r * Mp * ld, ld, 1, dA1, ld, M, (int)Kc, M);
+      a.accumulate = 1;
+      DCGP_TRY(gemm_gen(ctx, a));
+    }
+    GenGemm d = mk(A1, ld, 1, dT, 1, ld, dG, Mp, M, M, (int)Kc);     // dG_r = tril(A1 dT_r^T)
+    d.batch = R; d.b_bs = (long)Mp * ld; d.c_bs = mm; d.lower_only = 1;
+    DCGP_TRY(gemm_gen(ctx, d));
+  }
+  if (L.white) {
+    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(R), M), dim3(256), 0, ctx->stream, dalpha, (long)Rp, L.gq_mu, (long)R, M, R, 1.0, 0);
+    LAUNCH_CHECK(ctx);
+    if (L.has_qsqrt) {
+      hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, dG, (long)Mp, mm, L.gq_sqrt, (long)M,
+                         (long)M * M, M, 1.0, 0);
+      LAUNCH_CHECK(ctx);
+    }
+    HIP_TRY(ctx, hipMemsetAsync(dL, 0, mm * sizeof(double), ctx->stream));
+  } else {
+    // dq_mu = inv(L)^T d alpha;  dL = -tril(dq_mu alpha^T)
+    DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dalpha, Rp, 1, L.gq_mu, R, M, R, M)));
+    GenGemm l1 = mk(L.gq_mu, R, 1, g.alpha, 1, Rp, dL, Mp, M, M, R);
+    l1.alpha = -1.0; l1.lower_only = 1;
+    DCGP_TRY(gemm_gen(ctx, l1));
+    if (L.has_qsqrt) {
+      double* Bm = bk.ws("Bm", (size_t)R * mm);
+      NEED(Bm);
+      GenGemm b = mk(g.Linv, 1, Mp, dG, Mp, 1, Bm, Mp, M, M, M);     // B_r = inv(L)^T dG_r
+      b.batch = R; b.b_bs = mm; b.c_bs = mm;
+      DCGP_TRY(gemm_gen(ctx, b));
+      hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Bm, (long)Mp, mm, L.gq_sqrt, (long)M,
+                         (long)M * M, M, 1.0, 0);
+      LAUNCH_CHECK(ctx);
+      for (int r = 0; r < R; ++r) {                                  // dL -= tril(B_r G_r^T)
+        GenGemm l2 = mk(Bm + r * mm, Mp, 1, g.G + r * mm, 1, Mp, dL, Mp, M, M, M);
+        l2.alpha = -1.0; l2.lower_only = 1; l2.accumulate = 1;
+        DCGP_TRY(gemm_gen(ctx, l2));
+      }
+    }
+  }
+  // dKuf = inv(L)^T dA1;  dL -= tril(dKuf A1^T)
+  DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dA1, ld, 1, dKuf, ld, M, (int)Kc, M)));
+  GenGemm l3 = mk(dKuf, ld, 1, A1, 1, ld, dL, Mp, M, M, (int)Kc);
+  l3.alpha = -1.0; l3.lower_only = 1; l3.accumulate = 1;
+  DCGP_TRY(gemm_gen(ctx, l3));
+  // Cholesky adjoint: S = inv(L)^T Phi(L^T dL) inv(L)
+  double* Lc = bk.ws("Lc", (size_t)mm);
+  double* Pm = bk.ws("Pm", (size_t)mm);
+  double* S1 = bk.ws("S1", (size_t)mm);
+  NEED(Lc); NEED(Pm); NEED(S1);
+  hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, 1), dim3(256), 0, ctx->stream, g.K, (long)Mp, 0L, Lc, (long)Mp, 0L, M, 1.0, 0);
+  LAUNCH_CHECK(ctx);
+  DCGP_TRY(gemm_gen(ctx, mk(Lc, 1, Mp, dL, Mp, 1, Pm, Mp, M, M, M)));
+  hipLaunchKernelGGL(phi_kernel, dim3(blocks_for(M), M), dim3(256), 0, ctx->stream, Pm, (long)Mp, M);
+  LAUNCH_CHECK(ctx);
+  DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, Pm, Mp, 1, S1, Mp, M, M, M)));
+  DCGP_TRY(gemm_gen(ctx, mk(S1, Mp, 1, g.Linv, Mp, 1, S, Mp, M, M, M)));
+  return DCGP_OK;
+}
+
+int e_form(Bk& bk, LayerState& L, const double* dK, long lddk, int pdiv, const double* w, double wscale, const double* K, long ldk,
+           double* E, long lde, long Kc, double* cs, double* raw) {
+  dcgp_ctx* ctx = bk.ctx;
+  const unsigned nb = blocks_for(Kc);
+  double* pv = bk.ws("ef_pv", nb);
+  double* pl = bk.ws("ef_pl", nb);
+  NEED(pv); NEED(pl);
+  hipLaunchKernelGGL(e_form_kernel, dim3(nb), dim3(256), 0, ctx->stream, dK, lddk, pdiv, w, wscale, K, ldk, E, lde, L.M, Kc, 1.0 / L.variance,
+                     2.0 * L.ls * L.ls, cs, raw, pv, pl);
+  LAUNCH_CHECK(ctx);
+  DCGP_TRY(add_scalar(bk, L, false, pv, nb, 1.0 / L.variance));
+  DCGP_TRY(add_scalar(bk, L, true, pl, nb, 1.0 / (L.ls * L.ls * L.ls)));
+  return DCGP_OK;
+}
+
+int begin_layer(Bk& bk, LayerState& L) {
+  DCGP_TRY(L.ensure_grads());
+  bk.slot_v = bk.slot_l = 0;
+  HIP_TRY(bk.ctx, hipMemsetAsync(L.gslots, 0, 32 * sizeof(double), bk.ctx->stream));
+  HIP_TRY(bk.ctx, hipMemsetAsync(L.gZ, 0, (size_t)L.M * L.v.L * sizeof(double), bk.ctx->stream));
+  HIP_TRY(bk.ctx, hipMemsetAsync(L.gw, 0, (size_t)L.v.P * sizeof(double), bk.ctx->stream));
+  if (!L.has_qsqrt) HIP_TRY(bk.ctx, hipMemsetAsync(L.gq_sqrt, 0, (size_t)L.R * L.M * L.M * sizeof(double), bk.ctx->stream));
+  return DCGP_OK;
+}
+int end_layer(Bk& bk, LayerState& L) {
+  hipLaunchKernelGGL(scal_finish_kernel, dim3(1), dim3(64), 0, bk.ctx->stream, L.gslots, L.gscal);
+  LAUNCH_CHECK(bk.ctx);
+  return DCGP_OK;
+}
+
+// ConvLayer backward.  Xin: the layer's input images ([n_mod, H, W, C], row n reads image n % n_mod); gm / gv [rows * P][R].
+int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod, const double* gm, const double* gv, double* dXin) {
+  dcgp_ctx* ctx = bk.ctx;
+  const int M = L.M, Mp = L.Mp, P = L.v.P, Ld = L.v.L;
+  const long Kc = (long)rows * P, ld = round_up_l(Kc, 128);
+  DCGP_TRY(begin_layer(bk, L));
+  // forward leftovers (conv_forward / cond_core workspaces)
+  auto itB = ctx->ws.find(bk.pfx + "Kuf"), itA = ctx->ws.find(bk.pfx + "A1");
+  if (itB == ctx->ws.end() || itA == ctx->ws.end() || itA->second.second < (size_t)Mp * ld * sizeof(double))
+    return ctx_fail(ctx, DCGP_ERR_ARG, "grad: the forward pass left no K_uf / A1 for this layer");
+  const double* Kuf = (const double*)itB->second.first;
+  const double* A1 = (const double*)itA->second.first;
+  double* dKuf = bk.ws("dKuf", (size_t)Mp * ld);
+  double* S = bk.ws("S", (size_t)Mp * Mp);
+  double* gvs = bk.ws("gvs", Kc);
+  double* cs = bk.ws("cs", Kc);
+  double* Xcol = bk.ws("Xcol", (size_t)Kc * Ld);
+  NEED(dKuf); NEED(S); NEED(gvs); NEED(cs); NEED(Xcol);
+  DCGP_TRY(cond_backward(bk, L, A1, ld, Kc, gm, gv, dKuf, S, gvs));
+  DCGP_TRY(add_scalar(bk, L, false, gvs, Kc, 1.0));                  // Knn = variance on every column
+  DCGP_TRY(kuu_backward(bk, L, L.Z, S, Mp, true));
+  hipLaunchKernelGGL(im2col_kernel, dim3(blocks_for(Kc * Ld)), dim3(256), 0, ctx->stream, Xin, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s,
+                     L.v.Wo, P, Ld, Kc, Xcol);
+  LAUNCH_CHECK(ctx);
+  DCGP_TRY(e_form(bk, L, dKuf, ld, 1, nullptr, 1.0, Kuf, ld, dKuf, ld, Kc, cs, nullptr));   // E over dKuf
+  double* dXcol = nullptr;
+  if (dXin) { dXcol = bk.ws("dXcol", (size_t)Kc * Ld); NEED(dXcol); }
+  DCGP_TRY(patch_backward(bk, L, dKuf, ld, Kc, cs, Xcol, dXcol, 0));
+  if (dXin) {
+    const long n = (long)rows * L.v.H * L.v.W * L.v.C;
+    hipLaunchKernelGGL(col2im_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, dXcol, rows, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s, L.v.Ho,
+                       L.v.Wo, Ld, dXin);
+    LAUNCH_CHECK(ctx);
+  }
+  DCGP_TRY(kl_backward(bk, L, nullptr));
+  return end_layer(bk, L);
+}
+
+// SVGP head backward (ConvKernel / AdditivePatchKernel, conv_gp/kernels.py:15-136).  gm / gv [rows][R].
+int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod, const double* gm, const double* gv, double* dXin) {
+  dcgp_ctx* ctx = bk.ctx;
+  const int M = L.M, Mp = L.Mp, P = L.v.P, Ld = L.v.L;
+  const long ld = round_up_l(rows, 128), Kc = (long)rows * P, ldf = round_up_l(Kc, 128);
+  if (L.in_scale) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: the dense ARD head has no backward pass yet");
+  DCGP_TRY(begin_layer(bk, L));
+  auto itB = ctx->ws.find(bk.pfx + "Kzx");
+  if (itB == ctx->ws.end()) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: the forward pass left no K_zx for the head");
+  const double* Kzx = (const double*)itB->second.first;
+  double* A1 = bk.ws("A1h", (size_t)Mp * ld);
+  double* dKzx = bk.ws("dKzx", (size_t)Mp * ld);
+  double* S = bk.ws("S", (size_t)Mp * Mp);
+  double* gkd = bk.ws("gkd", rows);
+  double* Kfull = bk.ws("Kfull", (size_t)Mp * ldf);
+  double* E = bk.ws("E", (size_t)Mp * ldf);
+  double* cs = bk.ws("cs", Kc);
+  double* raw = bk.ws("raw", Kc);
+  double* Xcol = bk.ws("Xcol", (size_t)Kc * Ld);
+  double* dXcol = bk.ws("dXcol", (size_t)Kc * Ld);
+  NEED(A1); NEED(dKzx); NEED(S); NEED(gkd); NEED(Kfull); NEED(E); NEED(cs); NEED(raw); NEED(Xcol); NEED(dXcol);
+  DCGP_TRY(gemm_gen(ctx, mk(L.g.Linv, Mp, 1, Kzx, ld, 1, A1, ld, M, rows, M)));      // the fused forward keeps A1 on chip
+  DCGP_TRY(cond_backward(bk, L, A1, ld, rows, gm, gv, dKzx, S, gkd));
+  if (!L.white) DCGP_TRY(kl_backward(bk, L, S)); else DCGP_TRY(kl_backward(bk, L, nullptr));
+  DCGP_TRY(kuu_backward(bk, L, L.Z, S, Mp, true));
+  // every patch response again: Kfull[m][n * P + p] = k(Z_m, x_np)
+  PatchRbfArgs a;
+  a.X = Xin; a.N = rows; a.n_mod = n_mod;
+  a.H = L.v.H; a.W = L.v.W; a.C = L.v.C; a.f = L.v.f; a.s = L.v.s; a.Ho = L.v.Ho; a.Wo = L.v.Wo; a.P = P; a.L = Ld;
+  a.ZT = L.ZT; a.zn = L.zn; a.M = M; a.Mp = Mp; a.Lp = L.Lp;
+  a.bk = L.base();
+  a.out = Kfull; a.sM = ldf; a.sN = P; a.sP = 1;
+  DCGP_TRY(patch_rbf(ctx, a, "grad_head_kfull"));
+  hipLaunchKernelGGL(im2col_kernel, dim3(blocks_for(Kc * Ld)), dim3(256), 0, ctx->stream, Xin, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s,
+                     L.v.Wo, P, Ld, Kc, Xcol);
+  LAUNCH_CHECK(ctx);
+  // Kzx[m][n] = 1/P sum_p w_p k(Z_m, x_np)
+  DCGP_TRY(e_form(bk, L, dKzx, ld, P, L.w, 1.0 / P, Kfull, ldf, E, ldf, Kc, cs, raw));
+  hipLaunchKernelGGL(strided_sum_kernel, dim3(blocks_for(P)), dim3(256), 0, ctx->stream, raw, rows, P, 1.0 / P, 1, L.gw);
+  LAUNCH_CHECK(ctx);
+  DCGP_TRY(patch_backward(bk, L, E, ldf, Kc, cs, Xcol, dXin ? dXcol : nullptr, 0));
+  // Kdiag
+  if (L.kernel_type == 0) {
+    const double inv_l2 = 1.0 / (L.ls * L.ls);
+    double* Gm = bk.ws("kd_G", (size_t)rows * P * P);
+    double* norms = bk.ws("kd_norms", (size_t)rows * P);
+    double* dwn = bk.ws("kd_dwn", (size_t)rows * P);
+    double* pv = bk.ws("kd_pv", (size_t)rows * P);
+    double* pl = bk.ws("kd_pl", (size_t)rows * P);
+    double* EXn = bk.ws("kd_EX", (size_t)Kc * Ld);
+    NEED(Gm); NEED(norms); NEED(dwn); NEED(pv); NEED(pl); NEED(EXn);
+    GenGemm gg = mk(Xcol, Ld, 1, Xcol, 1, Ld, Gm, P, P, P, Ld);     // per image: X_n X_n^T
+    gg.batch = rows; gg.a_bs = (long)P * Ld; gg.b_bs = (long)P * Ld; gg.c_bs = (long)P * P;
+    DCGP_TRY(gemm_gen(ctx, gg));
+    hipLaunchKernelGGL(kdiag_norms_kernel, dim3(blocks_for((long)rows * P)), dim3(256), 0, ctx->stream, Gm, P, (long)rows, norms);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(kdiag_backward_kernel, dim3(P, rows), dim3(256), 0, ctx->stream, Gm, norms, gkd, L.w, P, L.variance, inv_l2, dwn, pv, pl);
+    LAUNCH_CHECK(ctx);
+    DCGP_TRY(add_scalar(bk, L, false, pv, (long)rows * P, 1.0 / L.variance));
+    DCGP_TRY(add_scalar(bk, L, true, pl, (long)rows * P, inv_l2 / L.ls));
+    hipLaunchKernelGGL(strided_sum_kernel, dim3(blocks_for(P)), dim3(256), 0, ctx->stream, dwn, rows, P, 1.0, 1, L.gw);
+    LAUNCH_CHECK(ctx);
+    if (dXin) {
+      GenGemm ge = mk(Gm, P, 1, Xcol, Ld, 1, EXn, Ld, P, Ld, P);    // E_n X_n
+      ge.batch = rows; ge.a_bs = (long)P * P; ge.b_bs = (long)P * Ld; ge.c_bs = (long)P * Ld;
+      DCGP_TRY(gemm_gen(ctx, ge));
+      // d x_p += 2 (E X - rowsum(E) o X)_p / l^2   (E symmetric)
+      hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for(Kc * Ld)), dim3(256), 0, ctx->stream, EXn, pv, Xcol, Kc, Ld, 2.0 * inv_l2, 1, dXcol);
+      LAUNCH_CHECK(ctx);
+    }
+  } else {
+    // AdditivePatchKernel.Kdiag = mean_p w_p variance (conv_gp/kernels.py:53-61)
+    double* tmp = bk.ws("kd_tmp", 2);
+    NEED(tmp);
+    DCGP_TRY(reduce_sum(ctx, gkd, rows, 1.0, tmp));                  // sum_n gkd
+    DCGP_TRY(reduce_sum(ctx, L.w, P, 1.0 / P, tmp + 1));             // mean(w)
+    hipLaunchKernelGGL(additive_kdiag_backward_kernel, dim3(blocks_for(P)), dim3(256), 0, ctx->stream, tmp, P, L.variance, L.gw,
+                       L.gslots + VAR_SLOT + bk.slot_v);
+    LAUNCH_CHECK(ctx);
+    ++bk.slot_v;
+  }
+  if (dXin) {
+    const long n = (long)rows * L.v.H * L.v.W * L.v.C;
+    hipLaunchKernelGGL(col2im_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, dXcol, rows, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s, L.v.Ho,
+                       L.v.Wo, Ld, dXin);
+    LAUNCH_CHECK(ctx);
+  }
+  return end_layer(bk, L);
+}
+
+}  // namespace
+
+int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, double scale) {
+  dcgp_ctx* ctx = m->ctx;
+  const int nl = (int)m->layers.size(), S = m->S;
+  if (!m->keep_outputs) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: the forward pass must keep the layer outputs");
+  for (auto& l : m->layers) {
+    if (l->base_type != 0) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: only RBF base kernels have a backward pass");
+    if (l->identity_mean) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: Conv2dMean layers have no backward pass yet");
+  }
+  const double* gh = gauss_hermite_table(ctx);
+  if (!gh) return DCGP_ERR_ALLOC;
+  Bk bk;
+  bk.m = m; bk.ctx = ctx;
+  const std::string mp = "m" + std::to_string(m->id) + "_";
+  LayerState& H = *m->layers[nl - 1];
+  auto& oh = m->outs[nl - 1];
+  const int rows = oh.rows;
+  const double weight = scale * ((rows == S * N) ? 1.0 / S : 1.0);
+  double* gm = (double*)ws_get(ctx, mp + "g_gm_head", (size_t)rows * H.R * sizeof(double));
+  double* gv = (double*)ws_get(ctx, mp + "g_gv_head", (size_t)rows * H.R * sizeof(double));
+  NEED(gm); NEED(gv);
+  hipLaunchKernelGGL(robustmax_grad_kernel, dim3(blocks_for((long)rows * H.R)), dim3(256), 0, ctx->stream, oh.mean, oh.var, y, rows, N, H.R,
+                     m->eps, gh, weight, gm, gv);
+  LAUNCH_CHECK(ctx);
+  for (int li = nl - 1; li >= 0; --li) {
+    LayerState& L = *m->layers[li];
+    bk.pfx = mp + std::to_string(li) + "_";
+    const double* Xin = li == 0 ? X : m->outs[li - 1].sample;
+    const int rows_l = m->outs[li].rows;            // rows entering == rows leaving (no dedup on this path)
+    const int n_mod = li == 0 ? N : rows_l;
+    double* dXin = nullptr;
+    if (li > 0) {
+      dXin = (double*)ws_get(ctx, bk.pfx + "g_dXin", (size_t)rows_l * L.v.H * L.v.W * L.v.C * sizeof(double));
+      NEED(dXin);
+    }
+    if (L.is_head) DCGP_TRY(head_backward(bk, L, Xin, rows_l, n_mod, gm, gv, dXin));
+    else DCGP_TRY(conv_backward(bk, L, Xin, rows_l, n_mod, gm, gv, dXin));
+    if (li > 0) {
+      auto& o = m->outs[li - 1];
+      const long n = (long)o.rows * o.width;
+      gm = (double*)ws_get(ctx, mp + std::to_string(li - 1) + "_g_gm", (size_t)n * sizeof(double));
+      gv = (double*)ws_get(ctx, mp + std::to_string(li - 1) + "_g_gv", (size_t)n * sizeof(double));
+      NEED(gm); NEED(gv);
+      hipLaunchKernelGGL(sample_backward_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, dXin, o.sample, o.mean, o.var, m->jitter, n, gm, gv);
+      LAUNCH_CHECK(ctx);
+    }
+  }
+  return DCGP_OK;
+}
+
+extern "C" {
+
+int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, double scale, const double* const* z_per_layer_host,
+                   uint64_t seed, double* out_host, int* info_host) {
+  if (!model || !X || !y || N <= 0 || !out_host) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "elbo_grad: bad args") : DCGP_ERR_ARG;
+  dcgp_ctx* ctx = model->ctx;
+  const bool keep = model->keep_outputs;
+  model->keep_outputs = true;   // the reverse pass reads every layer's (sample, mean, var)
+  int rc = elbo_forward_impl(model, X, y, N, scale, z_per_layer_host, seed, 0, out_host, info_host);
+  if (rc == DCGP_OK) rc = model_backward(model, X, y, N, scale);
+  model->keep_outputs = keep;
+  DCGP_TRY(rc);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}
+
+int dcgp_model_get_grad(dcgp_model* model, int layer, const char* which, double* out_host, size_t count) {
+  if (!model || !which || !out_host) return DCGP_ERR_ARG;
+  dcgp_ctx* ctx = model->ctx;
+  if (layer < 0 || layer >= (int)model->layers.size()) return ctx_fail(ctx, DCGP_ERR_ARG, "get_grad: no layer %d", layer);
+  LayerState& L = *model->layers[layer];
+  if (!L.gZ) return ctx_fail(ctx, DCGP_ERR_ARG, "get_grad: call dcgp_elbo_grad first");
+  const double* src = nullptr;
+  size_t n = 0;
+  if (!strcmp(which, "Z")) { src = L.gZ; n = (size_t)L.M * L.v.L; }
+  else if (!strcmp(which, "q_mu")) { src = L.gq_mu; n = (size_t)L.M * L.R; }
+  else if (!strcmp(which, "q_sqrt")) { src = L.gq_sqrt; n = (size_t)L.R * L.M * L.M; }
+  else if (!strcmp(which, "variance")) { src = L.gscal; n = 1; }
+  else if (!strcmp(which, "lengthscale")) { src = L.gscal + 1; n = 1; }
+  else if (!strcmp(which, "w")) {
+    if (!L.is_head) return ctx_fail(ctx, DCGP_ERR_ARG, "get_grad: only the head has patch weights");
+    src = L.gw; n = (size_t)L.v.P;
+  } else return ctx_fail(ctx, DCGP_ERR_ARG, "get_grad: unknown parameter '%s'", which);
+  if (count != n) return ctx_fail(ctx, DCGP_ERR_ARG, "get_grad(%s): expected %zu values, got %zu", which, n, count);
+  HIP_TRY(ctx, hipMemcpyAsync(out_host, src, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}
+
+}  // extern "C"

@@ -35,6 +35,9 @@ struct LayerState {
   // derived every step
   GpMats g;
   double *ZT = nullptr, *zn = nullptr;
+  // gradients of the ELBO with respect to the (constrained) parameter values, caller's layouts (grad.hip); allocated on
+  // first use.  gscal = {d variance, d lengthscale}; gslots = per-contribution partial sums of those two (16 + 16).
+  double *gZ = nullptr, *gq_mu = nullptr, *gq_sqrt = nullptr, *gw = nullptr, *gscal = nullptr, *gslots = nullptr;
   std::vector<void*> owned;
 
   ~LayerState() {
@@ -73,6 +76,13 @@ struct LayerState {
     zn = dalloc(Mp);
     for (void* p : owned)
       if (!p) return ctx_fail(c, DCGP_ERR_ALLOC, "layer: device allocation failed");
+    return DCGP_OK;
+  }
+  int ensure_grads() {
+    if (gZ) return DCGP_OK;
+    gZ = dalloc((size_t)M * v.L); gq_mu = dalloc((size_t)M * R); gq_sqrt = dalloc((size_t)R * M * M);
+    gw = dalloc(v.P); gscal = dalloc(2); gslots = dalloc(32);
+    if (!gZ || !gq_mu || !gq_sqrt || !gw || !gscal || !gslots) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: gradient allocation failed");
     return DCGP_OK;
   }
   int upload(double* dst, const double* src_host, size_t n) {

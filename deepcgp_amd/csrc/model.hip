@@ -13,33 +13,9 @@
 #include <cstring>
 #include <memory>
 
-#include "layer_impl.h"
+#include "model_state.h"
 #include <chrono>
 
-struct dcgp_model {
-  dcgp_ctx* ctx = nullptr;
-  int S = 1;
-  double jitter = 1e-3;
-  double eps = 1e-3;   // RobustMax epsilon (conv_gp/models.py:67 keeps gpflow's default)
-  std::vector<std::unique_ptr<LayerState>> layers;   // conv layers..., head last (once set)
-  bool has_head = false;
-  bool keep_outputs = false;
-  std::vector<FactorGroup> groups;
-  bool groups_built = false;
-  // per-layer outputs of the most recent forward
-  struct Out { double *sample = nullptr, *mean = nullptr, *var = nullptr; int rows = 0, width = 0; size_t cap = 0; };
-  std::vector<Out> outs;
-  double* d_scal = nullptr;   // [0]=data, [4 + 4l ..] 4 KL pieces of layer l, [40..43] ELBO, data term, KL, potrf status
-  double* d_ve = nullptr; size_t ve_cap = 0;
-  double* d_kd = nullptr; size_t kd_cap = 0;
-  int id = 0;
-
-  ~dcgp_model() {
-    for (auto& gr : groups) gr.release();
-    for (auto& o : outs) { hipFree(o.sample); hipFree(o.mean); hipFree(o.var); }
-    hipFree(d_scal); hipFree(d_ve); hipFree(d_kd);
-  }
-};
 
 namespace {
 
@@ -360,6 +336,14 @@ int dcgp_model_set_param(dcgp_model* model, int layer, const char* which, const 
 int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
                       const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, double* out_host,
                       int* info_host) {
+  return elbo_forward_impl(model, X, y, N, scale, z_per_layer_host, seed, dedup_layer0, out_host, info_host);
+}
+
+}  // extern "C"
+
+int elbo_forward_impl(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
+                      const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, double* out_host,
+                      int* info_host) {
   if (!model || !X || !y || N <= 0 || !out_host) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "elbo_forward: bad args") : DCGP_ERR_ARG;
   dcgp_ctx* ctx = model->ctx;
   if (info_host) *info_host = 0;
@@ -398,6 +382,8 @@ int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int 
   if (bad) return ctx_fail(ctx, DCGP_ERR_NOT_PD, "Cholesky: matrix not positive definite at column %d", bad);
   return DCGP_OK;
 }
+
+extern "C" {
 
 int dcgp_model_propagate(dcgp_model* model, const double* X, int N, int S, const double* const* z_per_layer_host,
                          uint64_t seed, double* out_fmean, double* out_fvar, int* info_host) {

@@ -1,0 +1,36 @@
+// Internal: the device-resident model (layers + per-step outputs), shared by model.hip (forward) and grad.hip (backward).
+#pragma once
+#include "layer_impl.h"
+
+struct dcgp_model {
+  dcgp_ctx* ctx = nullptr;
+  int S = 1;
+  double jitter = 1e-3;
+  double eps = 1e-3;   // RobustMax epsilon (conv_gp/models.py:67 keeps gpflow's default)
+  std::vector<std::unique_ptr<LayerState>> layers;   // conv layers..., head last (once set)
+  bool has_head = false;
+  bool keep_outputs = false;
+  std::vector<FactorGroup> groups;
+  bool groups_built = false;
+  // per-layer outputs of the most recent forward
+  struct Out { double *sample = nullptr, *mean = nullptr, *var = nullptr; int rows = 0, width = 0; size_t cap = 0; };
+  std::vector<Out> outs;
+  double* d_scal = nullptr;   // [0]=data, [4 + 4l ..] 4 KL pieces of layer l, [40..43] ELBO, data term, KL, potrf status
+  double* d_ve = nullptr; size_t ve_cap = 0;
+  double* d_kd = nullptr; size_t kd_cap = 0;
+  int id = 0;
+
+  ~dcgp_model() {
+    for (auto& gr : groups) gr.release();
+    for (auto& o : outs) { hipFree(o.sample); hipFree(o.mean); hipFree(o.var); }
+    hipFree(d_scal); hipFree(d_ve); hipFree(d_kd);
+  }
+};
+
+// model.hip: the forward ELBO of a minibatch; leaves every layer's outputs in model->outs (keep_outputs) and the
+// factorisations / conditional operands in the layers' GpMats.  out_host[0..2] = ELBO, data term, KL.
+int elbo_forward_impl(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
+                      const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, double* out_host,
+                      int* info_host);
+// grad.hip: reverse pass over the state the forward left behind; fills every layer's gradient buffers
+int model_backward(dcgp_model* model, const double* X, const int32_t* y, int N, double scale);

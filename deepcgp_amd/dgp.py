@@ -174,6 +174,37 @@ class DGP_Base:
             return out[0], out[1], out[2]
         return out[0]
 
+    def compute_gradients(self, X, Y, zs=None, seed=0, scale=None):
+        """(ELBO, [per-layer dict]) -- the value and gradient TensorFlow hands the optimiser at
+        conv_gp/experiment.py:84-108, from the hand-written reverse pass (csrc/grad.hip).  Keys: ``Z``,
+        ``q_mu``, ``q_sqrt`` (lower triangle), ``variance``, ``lengthscales`` and, for the head,
+        ``patch_weights``; all with respect to the constrained values."""
+        self._build()
+        ctx, L = self._ctx, dev.lib()
+        dX = ctx.as_device(np.reshape(X, (np.shape(X)[0], -1)) if not isinstance(X, dev.DeviceArray) else X)
+        dY = ctx.as_device(np.reshape(Y, (-1,)) if not isinstance(Y, dev.DeviceArray) else Y, np.int32)
+        N = dX.shape[0]
+        if scale is None:
+            scale = float(self.num_data) / float(N)
+        arr, keep = self._z_table(zs, N, self.num_samples)
+        out = (C.c_double * 3)()
+        info = C.c_int(0)
+        ctx._check(L.dcgp_elbo_grad(self._model, dX.ptr, dY.ptr, N, float(scale), arr, int(seed), out, C.byref(info)), info)
+        grads = []
+        for li, l in enumerate(self.layers):
+            head = li == len(self.layers) - 1
+            M, R = l.num_inducing, (l.num_outputs if head else l.gp_count)
+            shapes = {"Z": (M, np.shape(l.feature.Z)[1]), "q_mu": (M, R), "q_sqrt": (R, M, M), "variance": (), "lengthscale": ()}
+            if head and hasattr(l.kern, "patch_weights"):
+                shapes["w"] = (np.size(l.kern.patch_weights),)
+            g = {}
+            for which, shp in shapes.items():
+                buf = np.empty(shp, np.float64)
+                ctx._check(L.dcgp_model_get_grad(self._model, li, which.encode(), buf.ctypes.data, buf.size))
+                g[{"lengthscale": "lengthscales", "w": "patch_weights"}.get(which, which)] = buf
+            grads.append(g)
+        return out[0], grads
+
     def propagate(self, X, full_cov=False, S=1, zs=None, seed=0):
         """(Fs, Fmeans, Fvars): per layer S x N x D_l arrays (doubly_stochastic_dgp DGP_Base.propagate)."""
         if full_cov:

@@ -185,6 +185,14 @@ int dcgp_model_set_param(dcgp_model* model, int layer, const char* which, const 
 int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
                       const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0,
                       double* out_host, int* info_host);
+/* The ELBO of dcgp_elbo_forward AND its gradient with respect to every trainable value (what TensorFlow autodiff
+ * hands the optimiser at conv_gp/experiment.py:84-108): Z, q_mu, q_sqrt (lower triangle), base-kernel variance and
+ * lengthscale of every layer, patch_weights of the head -- constrained values, not gpflow's unconstrained ones.
+ * RBF base kernels, no Conv2dMean.  The gradients stay on the device; read them with dcgp_model_get_grad. */
+int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
+                   const double* const* z_per_layer_host, uint64_t seed, double* out_host, int* info_host);
+/* which = "Z" [M, L], "q_mu" [M, R], "q_sqrt" [R, M, M], "variance" [1], "lengthscale" [1], "w" [P] (head). */
+int dcgp_model_get_grad(dcgp_model* model, int layer, const char* which, double* out_host, size_t count);
 /* DGP_Base.propagate(X, S) -> last layer's Fmean, Fvar [S*N, R] (device buffers owned by caller) */
 int dcgp_model_propagate(dcgp_model* model, const double* X, int N, int S,
                          const double* const* z_per_layer_host, uint64_t seed,

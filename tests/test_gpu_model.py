@@ -348,3 +348,34 @@ def test_elbo_dense_rbf_ard_head(ctx, white):
     assert abs(e2 - ref.compute_log_likelihood(X, Y, zs=zs)) <= RTOL * abs(e2) and e2 != e
     assert [p.pathname for p in model.parameters if "/layers/1/kern" in p.pathname] == ["DGP/layers/1/kern/variance", "DGP/layers/1/kern/lengthscales"]
     model.close()
+
+
+@pytest.mark.parametrize("white,additive", [(False, False), (True, False), (False, True)])
+def test_gradients_match_oracle(ctx, white, additive):
+    """dcgp_elbo_grad (csrc/grad.hip) against oracle/grad.py -- itself pinned by finite differences on CPU -- on a
+    three-layer model: every parameter group of every layer."""
+    from oracle.grad import elbo_and_grad
+    hwc, N, S = (14, 14, 1), 3, 2
+    spec = syn.make_spec(hwc, [(3, 1, 3), (4, 2, 2)], (3, 1), 20, S=S, num_data=500, seed=9, white=white,
+                         conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5)
+    rng = np.random.default_rng(9)
+    spec["head"]["w"] = 0.5 + rng.random(spec["head"]["w"].shape)
+    if additive:
+        spec["head"]["kernel"] = "add"
+    X, Y = syn.make_batch(hwc, N, seed=9)
+    zs = syn.make_noise(spec, N, seed=9)
+    ref = oracle_model(spec, X, Y)
+    if additive:
+        from oracle.kernels import AdditivePatchKernel
+        k = ref.layers[-1].kern
+        ref.layers[-1].kern = AdditivePatchKernel(k.base_kernel, k.view, k.patch_weights)
+    model = build_from_spec(spec, X, Y)
+    e, grads = model.compute_gradients(X, Y, zs=zs)
+    eo, go = elbo_and_grad(ref, X, Y, zs)
+    assert abs(e - eo) <= RTOL * abs(eo)
+    for li, (g, o) in enumerate(zip(grads, go)):
+        for name, val in o.items():
+            # relative to the largest entry, or 1e-8 absolute where data and KL parts cancel to a tiny net gradient
+            err = np.abs(g[name] - val).max()
+            assert err < 1e-7 * np.abs(val).max() or err < 1e-8, (li, name, err, np.abs(val).max())
+    model.close()
