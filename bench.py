@@ -86,6 +86,7 @@ def main():
                     help="evaluate layer 0 on the distinct images only (exact; off by default so that the step does "
                          "the same work as the reference, which tiles the batch S times)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grad-leg", action="store_true", help="skip the informational value-and-gradient timing")
     ap.add_argument("--profile", action="store_true",
                     help="for rocprofv3 runs: exactly --warmup + --steps steps, none of the extra regions, no CPU baseline")
     ap.add_argument("--comm", type=str, default="rccl", choices=["rccl", "gloo"],
@@ -212,6 +213,20 @@ def main():
     barrier()
     timing_all = ctx.timing()
     ctx.timing_enable(0)
+    # ... and the same step followed by its reverse pass (dcgp_elbo_grad: value and gradient with respect to every
+    # trainable parameter -- what the reference's training step differentiates, experiment.py:84-108).  Informational,
+    # single-rank only (the gradient all-reduce is not wired up yet); never part of `value`.
+    dt_grad, grad_timing = None, {}
+    if world == 1 and not args.profile and not args.no_grad_leg:
+        n_g = max(3, min(args.steps, 20))
+        for i in range(2):
+            model.compute_gradients(dX, dY, seed=i, scale=scale, fetch=False)
+        barrier()
+        t3 = time.perf_counter()
+        for i in range(n_g):
+            model.compute_gradients(dX, dY, seed=args.warmup + i, scale=scale, fetch=False)
+        barrier()
+        dt_grad = (time.perf_counter() - t3) / n_g
     if td is not None:
         t = torch.tensor([dt, dt_plain, dt_dedup or 0.0], dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -236,6 +251,8 @@ def main():
             "elbo": elbo,
             "ms_per_step_without_event_timing": 1e3 * dt_plain / args.steps,
             "steps_per_s_with_exact_layer0_dedup": (units_per_step * args.steps / dt_dedup) if dt_dedup else None,
+            "value_and_grad_steps_per_s": (1.0 / dt_grad) if dt_grad else None,
+            "value_and_grad_ms": (1e3 * dt_grad) if dt_grad else None,
         }
         # ---- roofline of the dominant kernel: the R-batched L_q^T A product with fused square-reduce ----
         rows0 = per_rank_batch if (args.dedup_layer0 and cfg["convs"]) else per_rank_batch * S

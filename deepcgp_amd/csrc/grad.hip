@@ -340,6 +340,28 @@ __global__ void scal_finish_kernel(const double* __restrict__ slots, double* __r
   gscal[1] = b;
 }
 
+// ---- optimiser ---------------------------------------------------------------------------------------------------
+// tf.train.AdamOptimizer on gpflow's unconstrained variables, ascending the ELBO.  transform 0: identity;
+// 1: gpflow transforms.positive (x = softplus(u) + 1e-6): the parameter is held constrained, moved through u.
+__global__ void adam_kernel(double* __restrict__ p, const double* __restrict__ g, double* __restrict__ m, double* __restrict__ v, long n,
+                            double lr_t, double b1, double b2, double eps, int transform) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double x = p[i], gr = -g[i];                       // minimise -ELBO
+  double u = x;
+  if (transform == 1) {
+    const double y = x - 1e-6;
+    u = y > 35.0 ? y : log(expm1(y));               // softplus^-1
+    gr *= -expm1(-y);                                // dx/du = sigmoid(u) = 1 - exp(-y)
+  }
+  const double mi = b1 * m[i] + (1.0 - b1) * gr;
+  const double vi = b2 * v[i] + (1.0 - b2) * gr * gr;
+  m[i] = mi;
+  v[i] = vi;
+  u -= lr_t * mi / (sqrt(vi) + eps);
+  p[i] = transform == 1 ? (u > 35.0 ? u : log1p(exp(u))) + 1e-6 : u;
+}
+
 // ---- host helpers ------------------------------------------------------------------------------------------------
 struct Bk {   // per-backward bookkeeping
   dcgp_model* m;
@@ -800,6 +822,69 @@ int dcgp_model_get_grad(dcgp_model* model, int layer, const char* which, double*
     src = L.gw; n = (size_t)L.v.P;
   } else return ctx_fail(ctx, DCGP_ERR_ARG, "get_grad: unknown parameter '%s'", which);
   if (count != n) return ctx_fail(ctx, DCGP_ERR_ARG, "get_grad(%s): expected %zu values, got %zu", which, n, count);
+  HIP_TRY(ctx, hipMemcpyAsync(out_host, src, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta2, double eps, int t) {
+  if (!model || t < 1 || !(lr > 0) || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1) || !(eps > 0))
+    return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "adam_step: bad arguments") : DCGP_ERR_ARG;
+  dcgp_ctx* ctx = model->ctx;
+  const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
+  auto run = [&](double* p, const double* g, double* const* mv, long n, int transform) -> int {
+    if (n <= 0) return DCGP_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, p, g, mv[0], mv[1], n, lr_t, beta1, beta2, eps, transform);
+    LAUNCH_CHECK(ctx);
+    return DCGP_OK;
+  };
+  const int nl = (int)model->layers.size();
+  double* h = ctx->h_scratch;   // 64 pinned doubles: {variance, lengthscale} per layer
+  for (int li = 0; li < nl; ++li) {
+    LayerState& L = *model->layers[li];
+    if (!L.gZ) return ctx_fail(ctx, DCGP_ERR_ARG, "adam_step: call dcgp_elbo_grad first");
+    DCGP_TRY(L.ensure_adam());
+    h[2 * li] = L.variance; h[2 * li + 1] = L.ls;
+    HIP_TRY(ctx, hipMemcpyAsync(L.hyp, h + 2 * li, 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    DCGP_TRY(run(L.Z, L.gZ, L.aZ, (long)L.M * L.v.L, 0));
+    DCGP_TRY(run(L.q_mu, L.gq_mu, L.aq_mu, (long)L.M * L.R, 0));
+    if (L.has_qsqrt) DCGP_TRY(run(L.q_sqrt, L.gq_sqrt, L.aq_sqrt, (long)L.R * L.M * L.M, 0));   // upper triangle: zero gradient, zero step
+    if (L.is_head && L.w) DCGP_TRY(run(L.w, L.gw, L.aw, (long)L.v.P, 0));
+    DCGP_TRY(run(L.hyp, L.gscal, L.ahyp, 2, 1));
+    HIP_TRY(ctx, hipMemcpyAsync(h + 2 * li, L.hyp, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int li = 0; li < nl; ++li) {
+    model->layers[li]->variance = h[2 * li];
+    model->layers[li]->ls = h[2 * li + 1];
+  }
+  return DCGP_OK;
+}
+
+int dcgp_model_get_param(dcgp_model* model, int layer, const char* which, double* out_host, size_t count) {
+  if (!model || !which || !out_host) return DCGP_ERR_ARG;
+  dcgp_ctx* ctx = model->ctx;
+  if (layer < 0 || layer >= (int)model->layers.size()) return ctx_fail(ctx, DCGP_ERR_ARG, "get_param: no layer %d", layer);
+  LayerState& L = *model->layers[layer];
+  const double* src = nullptr;
+  size_t n = 0;
+  if (!strcmp(which, "variance") || !strcmp(which, "lengthscale")) {
+    if (count != 1) return ctx_fail(ctx, DCGP_ERR_ARG, "get_param(%s): expected 1 value", which);
+    out_host[0] = which[0] == 'v' ? L.variance : L.ls;
+    return DCGP_OK;
+  }
+  if (!strcmp(which, "Z")) { src = L.Z; n = (size_t)L.M * L.v.L; }
+  else if (!strcmp(which, "q_mu")) { src = L.q_mu; n = (size_t)L.M * L.R; }
+  else if (!strcmp(which, "q_sqrt")) { src = L.q_sqrt; n = (size_t)L.R * L.M * L.M; }
+  else if (!strcmp(which, "w")) {
+    if (!L.w) return ctx_fail(ctx, DCGP_ERR_ARG, "get_param: only the head has patch weights");
+    src = L.w; n = (size_t)L.v.P;
+  } else return ctx_fail(ctx, DCGP_ERR_ARG, "get_param: unknown parameter '%s'", which);
+  if (count != n) return ctx_fail(ctx, DCGP_ERR_ARG, "get_param(%s): expected %zu values, got %zu", which, n, count);
   HIP_TRY(ctx, hipMemcpyAsync(out_host, src, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return DCGP_OK;

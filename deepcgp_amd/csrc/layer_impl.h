@@ -38,6 +38,8 @@ struct LayerState {
   // gradients of the ELBO with respect to the (constrained) parameter values, caller's layouts (grad.hip); allocated on
   // first use.  gscal = {d variance, d lengthscale}; gslots = per-contribution partial sums of those two (16 + 16).
   double *gZ = nullptr, *gq_mu = nullptr, *gq_sqrt = nullptr, *gw = nullptr, *gscal = nullptr, *gslots = nullptr;
+  // Adam moments, same layouts (allocated zeroed on the first optimiser step); hyp = {variance, lengthscale} device copy
+  double *aZ[2] = {}, *aq_mu[2] = {}, *aq_sqrt[2] = {}, *aw[2] = {}, *ahyp[2] = {}, *hyp = nullptr;
   std::vector<void*> owned;
 
   ~LayerState() {
@@ -83,6 +85,22 @@ struct LayerState {
     gZ = dalloc((size_t)M * v.L); gq_mu = dalloc((size_t)M * R); gq_sqrt = dalloc((size_t)R * M * M);
     gw = dalloc(v.P); gscal = dalloc(2); gslots = dalloc(32);
     if (!gZ || !gq_mu || !gq_sqrt || !gw || !gscal || !gslots) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: gradient allocation failed");
+    return DCGP_OK;
+  }
+  int ensure_adam() {
+    if (hyp) return DCGP_OK;
+    const size_t nz = (size_t)M * v.L, nm = (size_t)M * R, nq = (size_t)R * M * M, nw = (size_t)v.P;
+    for (int k = 0; k < 2; ++k) {
+      aZ[k] = dalloc(nz); aq_mu[k] = dalloc(nm); aq_sqrt[k] = dalloc(nq); aw[k] = dalloc(nw); ahyp[k] = dalloc(2);
+      if (!aZ[k] || !aq_mu[k] || !aq_sqrt[k] || !aw[k] || !ahyp[k]) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: optimiser state allocation failed");
+      HIP_TRY(ctx, hipMemsetAsync(aZ[k], 0, nz * sizeof(double), ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync(aq_mu[k], 0, nm * sizeof(double), ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync(aq_sqrt[k], 0, nq * sizeof(double), ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync(aw[k], 0, (nw ? nw : 2) * sizeof(double), ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync(ahyp[k], 0, 2 * sizeof(double), ctx->stream));
+    }
+    hyp = dalloc(2);
+    if (!hyp) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: optimiser state allocation failed");
     return DCGP_OK;
   }
   int upload(double* dst, const double* src_host, size_t n) {

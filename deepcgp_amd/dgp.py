@@ -174,7 +174,7 @@ class DGP_Base:
             return out[0], out[1], out[2]
         return out[0]
 
-    def compute_gradients(self, X, Y, zs=None, seed=0, scale=None):
+    def compute_gradients(self, X, Y, zs=None, seed=0, scale=None, fetch=True):
         """(ELBO, [per-layer dict]) -- the value and gradient TensorFlow hands the optimiser at
         conv_gp/experiment.py:84-108, from the hand-written reverse pass (csrc/grad.hip).  Keys: ``Z``,
         ``q_mu``, ``q_sqrt`` (lower triangle), ``variance``, ``lengthscales`` and, for the head,
@@ -190,6 +190,8 @@ class DGP_Base:
         out = (C.c_double * 3)()
         info = C.c_int(0)
         ctx._check(L.dcgp_elbo_grad(self._model, dX.ptr, dY.ptr, N, float(scale), arr, int(seed), out, C.byref(info)), info)
+        if not fetch:            # the gradients stay on the device (dcgp_model_get_grad / the optimiser step read them there)
+            return out[0], None
         grads = []
         for li, l in enumerate(self.layers):
             head = li == len(self.layers) - 1
@@ -204,6 +206,34 @@ class DGP_Base:
                 g[{"lengthscale": "lengthscales", "w": "patch_weights"}.get(which, which)] = buf
             grads.append(g)
         return out[0], grads
+
+    def adam_step(self, lr, t, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        """One Adam step (tf.train.AdamOptimizer defaults, gpflow.train.AdamOptimizer at
+        conv_gp/experiment.py:104-107) on the gradients the last ``compute_gradients`` left on the device,
+        in gpflow's unconstrained space.  ``t`` is the 1-based step count.  The device copy of the parameters
+        moves; ``pull_parameters`` refreshes the Python-side values."""
+        self._ctx._check(dev.lib().dcgp_model_adam_step(self._model, float(lr), float(beta1), float(beta2), float(epsilon), int(t)))
+
+    def pull_parameters(self):
+        """Read the device copy of every trainable value back into the layer / kernel objects."""
+        self._build()
+        L, ctx = dev.lib(), self._ctx
+
+        def pull(li, which, shape):
+            buf = np.empty(shape, np.float64)
+            ctx._check(L.dcgp_model_get_param(self._model, li, which.encode(), buf.ctypes.data, buf.size))
+            return buf
+        for li, l in enumerate(self.layers):
+            head = li == len(self.layers) - 1
+            kern = (l.kern.base_kernel if hasattr(l.kern, "base_kernel") else l.kern) if head else l.base_kernel
+            l.feature.Z = pull(li, "Z", np.shape(l.feature.Z))
+            l.q_mu = pull(li, "q_mu", np.shape(l.q_mu))
+            l.q_sqrt = pull(li, "q_sqrt", np.shape(l.q_sqrt))
+            kern.variance = float(pull(li, "variance", ()))
+            if not getattr(kern, "ARD", False) and hasattr(kern, "lengthscales"):
+                kern.lengthscales = float(pull(li, "lengthscale", ()))
+            if head and hasattr(l.kern, "patch_weights"):
+                l.kern.patch_weights = pull(li, "w", np.shape(l.kern.patch_weights))
 
     def propagate(self, X, full_cov=False, S=1, zs=None, seed=0):
         """(Fs, Fmeans, Fvars): per layer S x N x D_l arrays (doubly_stochastic_dgp DGP_Base.propagate)."""

@@ -57,6 +57,31 @@ def save_model_parameters(model, path, global_step=0):
     return params
 
 
+def learning_rate(lr, global_step, lr_decay_steps, decay_rate=0.1):
+    """tf.train.exponential_decay(..., staircase=True) of conv_gp/experiment.py:71-73."""
+    return float(lr) * decay_rate ** (int(global_step) // int(lr_decay_steps))
+
+
+def train(model, steps, lr=0.01, lr_decay_steps=50000, global_step=0, seed=0, callback=None):
+    """The Adam branch of the reference's optimisation loop (conv_gp/experiment.py:84-108 + gpflow.actions.Loop
+    at :44): every step draws a minibatch, evaluates the ELBO and its gradient on the device
+    (``compute_gradients``) and applies one Adam step there.  Returns the list of ELBO values; the Python-side
+    parameter objects are refreshed at the end (``pull_parameters``)."""
+    rng = np.random.default_rng(seed)
+    n = model.X.shape[0]
+    bs = min(model.minibatch_size or n, n)
+    history = []
+    for i in range(int(steps)):
+        idx = rng.choice(n, size=bs, replace=False)
+        elbo, _ = model.compute_gradients(model.X[idx], model.Y[idx], seed=seed + global_step + i, fetch=False)
+        model.adam_step(learning_rate(lr, global_step + i, lr_decay_steps), global_step + i + 1)
+        history.append(elbo)
+        if callback is not None:
+            callback(global_step + i + 1, elbo)
+    model.pull_parameters()
+    return history
+
+
 class AccuracyLogger(object):
     """Test accuracy the way the reference's training log computes it (conv_gp/utils/log.py:50-67): batches of 32,
     five samples per image, arg-max of the sample-mean class probabilities.  Each batch is one device call

@@ -193,6 +193,14 @@ int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, 
                    const double* const* z_per_layer_host, uint64_t seed, double* out_host, int* info_host);
 /* which = "Z" [M, L], "q_mu" [M, R], "q_sqrt" [R, M, M], "variance" [1], "lengthscale" [1], "w" [P] (head). */
 int dcgp_model_get_grad(dcgp_model* model, int layer, const char* which, double* out_host, size_t count);
+/* One optimiser step on the gradients dcgp_elbo_grad left on the device: tf.train.AdamOptimizer semantics
+ * (lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t); theta -= lr_t m / (sqrt(v) + eps); t = 1, 2, ...) ascending the
+ * ELBO in gpflow's unconstrained space -- variance / lengthscale through transforms.positive (softplus + 1e-6),
+ * q_sqrt on its lower triangle, Z / q_mu / patch_weights as they are (gpflow.train.AdamOptimizer at
+ * conv_gp/experiment.py:104-107; the learning-rate schedule :71-73 stays with the caller). */
+int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta2, double eps, int t);
+/* current (constrained) value of a parameter, names as dcgp_model_get_grad; the inverse of dcgp_model_set_param */
+int dcgp_model_get_param(dcgp_model* model, int layer, const char* which, double* out_host, size_t count);
 /* DGP_Base.propagate(X, S) -> last layer's Fmean, Fvar [S*N, R] (device buffers owned by caller) */
 int dcgp_model_propagate(dcgp_model* model, const double* X, int N, int S,
                          const double* const* z_per_layer_host, uint64_t seed,
