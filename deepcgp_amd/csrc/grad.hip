@@ -146,11 +146,11 @@ __global__ void phi_kernel(double* __restrict__ P, long ld, int M) {
 }
 
 // gq_sqrt[r][i][i] += 1 / Lq[r][i][i]   (- d/dLq of -1/2 log det(Lq Lq^T))
-__global__ void kl_diag_kernel(double* __restrict__ gq, const double* __restrict__ Lq, int M, int Mp, int R) {
+__global__ void kl_diag_kernel(double* __restrict__ gq, const double* __restrict__ Lq, int M, int Mp, int R, double kw) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= M * R) return;
   const int r = idx / M, i = idx % M;
-  gq[((long)r * M + i) * M + i] += 1.0 / Lq[((long)r * Mp + i) * Mp + i];
+  gq[((long)r * M + i) * M + i] += kw / Lq[((long)r * Mp + i) * Mp + i];
 }
 
 // ---- RBF Gram backward ------------------------------------------------------------------------------------------
@@ -368,6 +368,7 @@ struct Bk {   // per-backward bookkeeping
   dcgp_ctx* ctx;
   std::string pfx;   // workspace prefix of the layer being processed
   int slot_v = 0, slot_l = 0;
+  double klw = 1.0;   // weight of the (replicated) KL term on this rank: 1 / number of batch shards
   double* ws(const char* name, size_t n_doubles) { return (double*)ws_get(ctx, pfx + "g_" + name, (n_doubles ? n_doubles : 1) * sizeof(double)); }
 };
 
@@ -443,11 +444,12 @@ int kl_backward(Bk& bk, LayerState& L, double* Sacc) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Mp = L.Mp, R = L.R, Rp = L.g.Rp;
   const long mm = (long)Mp * Mp;
+  const double kw = bk.klw;
   if (L.white) {
-    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(R), M), dim3(256), 0, ctx->stream, L.q_mu, (long)R, L.gq_mu, (long)R, M, R, -1.0, 1);
+    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(R), M), dim3(256), 0, ctx->stream, L.q_mu, (long)R, L.gq_mu, (long)R, M, R, -kw, 1);
     LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, L.g.Lq, (long)Mp, mm, L.gq_sqrt, (long)M,
-                       (long)M * M, M, -1.0, 1);
+                       (long)M * M, M, -kw, 1);
     LAUNCH_CHECK(ctx);
   } else {
     const double* Lpinv = L.g.Kp ? L.g.Lpinv : L.g.Linv;
@@ -458,7 +460,7 @@ int kl_backward(Bk& bk, LayerState& L, double* Sacc) {
     NEED(a1); NEED(Kimu); NEED(Wm); NEED(KiL);
     DCGP_TRY(gemm_gen(ctx, mk(Lpinv, Mp, 1, L.q_mu, R, 1, a1, Rp, M, R, M)));
     DCGP_TRY(gemm_gen(ctx, mk(Lpinv, 1, Mp, a1, Rp, 1, Kimu, Rp, M, R, M)));
-    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(R), M), dim3(256), 0, ctx->stream, Kimu, (long)Rp, L.gq_mu, (long)R, M, R, -1.0, 1);
+    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(R), M), dim3(256), 0, ctx->stream, Kimu, (long)Rp, L.gq_mu, (long)R, M, R, -kw, 1);
     LAUNCH_CHECK(ctx);
     GenGemm g1 = mk(Lpinv, Mp, 1, L.g.Lq, Mp, 1, Wm, Mp, M, M, M);
     g1.batch = R; g1.b_bs = mm; g1.c_bs = mm;
@@ -467,26 +469,26 @@ int kl_backward(Bk& bk, LayerState& L, double* Sacc) {
     g2.batch = R; g2.b_bs = mm; g2.c_bs = mm;
     DCGP_TRY(gemm_gen(ctx, g2));
     hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, KiL, (long)Mp, mm, L.gq_sqrt, (long)M,
-                       (long)M * M, M, -1.0, 1);
+                       (long)M * M, M, -kw, 1);
     LAUNCH_CHECK(ctx);
     // -dKL/dK = -1/2 [R inv(K) - (inv(K) q_mu)(inv(K) q_mu)^T - sum_r (inv(K) Lq_r)(inv(K) Lq_r)^T]
     double* Sk = Sacc;
     int acc = 1;
     if (!Sk) { Sk = bk.ws("kl_S", (size_t)mm); NEED(Sk); acc = 0; }
     GenGemm g3 = mk(Lpinv, 1, Mp, Lpinv, Mp, 1, Sk, Mp, M, M, M);
-    g3.alpha = -0.5 * R; g3.accumulate = acc;
+    g3.alpha = -0.5 * R * kw; g3.accumulate = acc;
     DCGP_TRY(gemm_gen(ctx, g3));
     GenGemm g4 = mk(Kimu, Rp, 1, Kimu, 1, Rp, Sk, Mp, M, M, R);
-    g4.alpha = 0.5; g4.accumulate = 1;
+    g4.alpha = 0.5 * kw; g4.accumulate = 1;
     DCGP_TRY(gemm_gen(ctx, g4));
     for (int r = 0; r < R; ++r) {
       GenGemm g5 = mk(KiL + r * mm, Mp, 1, KiL + r * mm, 1, Mp, Sk, Mp, M, M, M);
-      g5.alpha = 0.5; g5.accumulate = 1;
+      g5.alpha = 0.5 * kw; g5.accumulate = 1;
       DCGP_TRY(gemm_gen(ctx, g5));
     }
     if (!Sacc) DCGP_TRY(kuu_backward(bk, L, L.Z0, Sk, Mp, false));   // frozen Z0: hyper-parameters only
   }
-  hipLaunchKernelGGL(kl_diag_kernel, dim3(blocks_for((long)M * R)), dim3(256), 0, ctx->stream, L.gq_sqrt, L.g.Lq, M, Mp, R);
+  hipLaunchKernelGGL(kl_diag_kernel, dim3(blocks_for((long)M * R)), dim3(256), 0, ctx->stream, L.gq_sqrt, L.g.Lq, M, Mp, R, kw);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }
@@ -751,6 +753,9 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
   if (!gh) return DCGP_ERR_ALLOC;
   Bk bk;
   bk.m = m; bk.ctx = ctx;
+  // the data term is summed over the batch shards (ranks); the KL term is replicated, so each shard carries 1 / shards of it
+  const int shards = m->grad_shards > 0 ? m->grad_shards : (ctx->comm ? ctx->nranks : 1);
+  bk.klw = 1.0 / shards;
   const std::string mp = "m" + std::to_string(m->id) + "_";
   LayerState& H = *m->layers[nl - 1];
   auto& oh = m->outs[nl - 1];
@@ -785,6 +790,12 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
       LAUNCH_CHECK(ctx);
     }
   }
+  if (ctx->comm)   // one in-stream all-reduce per layer over its contiguous gradient block (RCCL over xGMI)
+    for (auto& l : m->layers) {
+      const size_t n = l->grad_block_count();
+      if (n > 0x7fffffffUL) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: gradient block too large for one all-reduce");
+      DCGP_TRY(allreduce_sum_f64_async(ctx, l->gZ, (int)n));
+    }
   return DCGP_OK;
 }
 
@@ -830,6 +841,22 @@ int dcgp_model_get_grad(dcgp_model* model, int layer, const char* which, double*
 }  // extern "C"
 
 extern "C" {
+
+int dcgp_model_set_grad_shards(dcgp_model* model, int shards) {
+  if (!model || shards < 0) return DCGP_ERR_ARG;
+  model->grad_shards = shards;
+  return DCGP_OK;
+}
+
+int dcgp_model_grad_block(dcgp_model* model, int layer, double** block_dev, size_t* count) {
+  if (!model || !block_dev || !count) return DCGP_ERR_ARG;
+  if (layer < 0 || layer >= (int)model->layers.size()) return ctx_fail(model->ctx, DCGP_ERR_ARG, "grad_block: no layer %d", layer);
+  LayerState& L = *model->layers[layer];
+  DCGP_TRY(L.ensure_grads());
+  *block_dev = L.gZ;
+  *count = L.grad_block_count();
+  return DCGP_OK;
+}
 
 int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta2, double eps, int t) {
   if (!model || t < 1 || !(lr > 0) || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1) || !(eps > 0))

@@ -80,11 +80,14 @@ struct LayerState {
       if (!p) return ctx_fail(c, DCGP_ERR_ALLOC, "layer: device allocation failed");
     return DCGP_OK;
   }
+  // one contiguous block per layer [gZ | gq_mu | gq_sqrt | gw | gscal] so that a single all-reduce covers the layer
+  size_t grad_block_count() const { return (size_t)M * v.L + (size_t)M * R + (size_t)R * M * M + (size_t)v.P + 2; }
   int ensure_grads() {
     if (gZ) return DCGP_OK;
-    gZ = dalloc((size_t)M * v.L); gq_mu = dalloc((size_t)M * R); gq_sqrt = dalloc((size_t)R * M * M);
-    gw = dalloc(v.P); gscal = dalloc(2); gslots = dalloc(32);
-    if (!gZ || !gq_mu || !gq_sqrt || !gw || !gscal || !gslots) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: gradient allocation failed");
+    double* blk = dalloc(grad_block_count());
+    gslots = dalloc(32);
+    if (!blk || !gslots) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: gradient allocation failed");
+    gZ = blk; gq_mu = gZ + (size_t)M * v.L; gq_sqrt = gq_mu + (size_t)M * R; gw = gq_sqrt + (size_t)R * M * M; gscal = gw + v.P;
     return DCGP_OK;
   }
   int ensure_adam() {

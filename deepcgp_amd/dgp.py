@@ -174,7 +174,7 @@ class DGP_Base:
             return out[0], out[1], out[2]
         return out[0]
 
-    def compute_gradients(self, X, Y, zs=None, seed=0, scale=None, fetch=True):
+    def compute_gradients(self, X, Y, zs=None, seed=0, scale=None, fetch=True, shards=None):
         """(ELBO, [per-layer dict]) -- the value and gradient TensorFlow hands the optimiser at
         conv_gp/experiment.py:84-108, from the hand-written reverse pass (csrc/grad.hip).  Keys: ``Z``,
         ``q_mu``, ``q_sqrt`` (lower triangle), ``variance``, ``lengthscales`` and, for the head,
@@ -189,6 +189,8 @@ class DGP_Base:
         arr, keep = self._z_table(zs, N, self.num_samples)
         out = (C.c_double * 3)()
         info = C.c_int(0)
+        if shards is not None:   # this call handles one of `shards` batch shards: the replicated KL term is weighted 1 / shards
+            ctx._check(L.dcgp_model_set_grad_shards(self._model, int(shards)))
         ctx._check(L.dcgp_elbo_grad(self._model, dX.ptr, dY.ptr, N, float(scale), arr, int(seed), out, C.byref(info)), info)
         if not fetch:            # the gradients stay on the device (dcgp_model_get_grad / the optimiser step read them there)
             return out[0], None

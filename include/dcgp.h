@@ -193,6 +193,15 @@ int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, 
                    const double* const* z_per_layer_host, uint64_t seed, double* out_host, int* info_host);
 /* which = "Z" [M, L], "q_mu" [M, R], "q_sqrt" [R, M, M], "variance" [1], "lengthscale" [1], "w" [P] (head). */
 int dcgp_model_get_grad(dcgp_model* model, int layer, const char* which, double* out_host, size_t count);
+/* Data parallelism of the gradient: every rank holds a shard of the batch and the full parameters.  The data part of
+ * the gradient is a sum over shards, the KL part is replicated, so each rank computes scale * data_grad(shard) -
+ * KL_grad / shards and the sum over ranks is the full gradient.  With a communicator on the ctx
+ * (dcgp_comm_init_rank) dcgp_elbo_grad does that sum itself: one in-stream ncclAllReduce per layer over the layer's
+ * contiguous gradient block.  Without one (host-side reduction, tests) set the shard count explicitly and reduce
+ * the blocks yourself: block = [Z | q_mu | q_sqrt | w | variance, lengthscale], device pointer.  shards = 0
+ * restores the default (ranks of the communicator, else 1). */
+int dcgp_model_set_grad_shards(dcgp_model* model, int shards);
+int dcgp_model_grad_block(dcgp_model* model, int layer, double** block_dev, size_t* count);
 /* One optimiser step on the gradients dcgp_elbo_grad left on the device: tf.train.AdamOptimizer semantics
  * (lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t); theta -= lr_t m / (sqrt(v) + eps); t = 1, 2, ...) ascending the
  * ELBO in gpflow's unconstrained space -- variance / lengthscale through transforms.positive (softplus + 1e-6),

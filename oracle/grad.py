@@ -267,18 +267,21 @@ def head_kl_backward(layer):
 # ---------------------------------------------------------------------------------------------------
 # model
 # ---------------------------------------------------------------------------------------------------
-def elbo_and_grad(model, X, Y, zs):
-    """(ELBO, [dict per layer]) of oracle DGP_Base.compute_log_likelihood(X, Y, zs) with explicit noise."""
+def elbo_and_grad(model, X, Y, zs, scale=None, kl_weight=1.0):
+    """(ELBO, [dict per layer]) of oracle DGP_Base.compute_log_likelihood(X, Y, zs) with explicit noise.
+    ``scale`` / ``kl_weight`` restate one shard of a data-parallel step: scale * data_term(shard) - kl_weight * KL
+    (scale = num_data / GLOBAL batch, kl_weight = 1 / shards), whose sum over the shards is the full-batch value."""
     X = np.asarray(X, np.float64)
     N, S = X.shape[0], model.num_samples
     Fs, Fm, Fv = model.propagate(X, S=S, zs=zs)
     nl = len(model.layers)
-    scale = float(model.num_data) / float(N)
+    if scale is None:
+        scale = float(model.num_data) / float(N)
     D = Fm[-1].shape[2]
     Yt = np.tile(np.asarray(Y).reshape(1, N), [S, 1]).reshape(S * N)
     mu, var = Fm[-1].reshape(S * N, D), Fv[-1].reshape(S * N, D)
     ve = model.likelihood.variational_expectations(mu, var, Yt)
-    elbo = scale * ve.sum() / S - model.KL()
+    elbo = scale * ve.sum() / S - kl_weight * model.KL()
     gm, gv = robustmax_backward(model.likelihood, mu, var, Yt)
     gm *= scale / S
     gv *= scale / S
@@ -294,7 +297,7 @@ def elbo_and_grad(model, X, Y, zs):
             dX, g = conv_layer_backward(layer, Xin, gm, gv)
             kl = conv_layer_kl_backward(layer)
         for k_, val in kl.items():
-            g[k_] = g[k_] - val
+            g[k_] = g[k_] - kl_weight * val
         grads[li] = g
         if li > 0:
             # sample = mean + z sqrt(var + jitter) of the layer below

@@ -434,3 +434,24 @@ def test_adam_steps_match_numpy_on_oracle_gradients(ctx):
     hist = train(model, 20, lr=0.02, seed=1)
     assert len(hist) == 20 and np.mean(hist[-5:]) > np.mean(hist[:5])
     model.close()
+
+
+def test_gradient_of_batch_shards_sums_to_full_batch(ctx):
+    """Data parallelism of the training step: with the KL term weighted 1 / shards on every shard, the shard
+    gradients add up to the full-batch gradient (what the per-layer all-reduce in dcgp_elbo_grad computes)."""
+    hwc, N, S = (12, 12, 1), 4, 2
+    spec = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), 12, S=S, num_data=200, seed=6, conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5)
+    X, Y = syn.make_batch(hwc, N, seed=6)
+    zs = syn.make_noise(spec, N, seed=6)
+    model = build_from_spec(spec, X, Y)
+    scale = 200.0 / N
+    e_full, g_full = model.compute_gradients(X, Y, zs=zs, scale=scale, shards=1)
+    parts = []
+    for lo, hi in ((0, 1), (1, 4)):                      # ragged shards
+        parts.append(model.compute_gradients(X[lo:hi], Y[lo:hi], zs=[z[:, lo:hi] for z in zs], scale=scale, shards=2))
+    for li, g in enumerate(g_full):
+        for name, val in g.items():
+            tot = parts[0][1][li][name] + parts[1][1][li][name]
+            err = np.abs(tot - val).max()
+            assert err < 1e-9 * max(np.abs(val).max(), 1.0), (li, name, err)
+    model.close()

@@ -239,3 +239,25 @@ def test_hand_written_gradient_against_finite_differences(white, additive):
             set_(v0)
             fd, an = (ep - em) / (2 * h), float(np.sum(g * d))
             assert abs(fd - an) <= 1e-4 * max(abs(fd), abs(an), 1e-3), (li, name, fd, an)
+
+
+def test_shard_gradients_sum_to_full_batch_gradient():
+    """The decomposition the multi-GPU training step relies on, on the oracle: sum over batch shards of
+    grad[scale * data(shard) - KL / shards] == grad of the full-batch ELBO (scale = num_data / global batch)."""
+    from oracle.grad import elbo_and_grad
+    hwc, N = (10, 10, 1), 4
+    spec = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), 6, S=2, num_data=100, seed=5, conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5)
+    X, Y = syn.make_batch(hwc, N, seed=5)
+    zs = syn.make_noise(spec, N, seed=5)
+    m = oracle_model(spec, X, Y)
+    e, g = elbo_and_grad(m, X, Y, zs)
+    scale = 100.0 / N
+    tot_e, tot = 0.0, None
+    for lo, hi in ((0, 1), (1, 4)):
+        es, gs = elbo_and_grad(m, X[lo:hi], Y[lo:hi], [z[:, lo:hi] for z in zs], scale=scale, kl_weight=0.5)
+        tot_e += es
+        tot = gs if tot is None else [{k: a[k] + b[k] for k in a} for a, b in zip(tot, gs)]
+    assert abs(tot_e - e) <= 1e-12 * abs(e)
+    for a, b in zip(tot, g):
+        for k in b:
+            assert np.abs(a[k] - b[k]).max() <= 1e-10 * max(np.abs(b[k]).max(), 1.0), k
