@@ -95,6 +95,7 @@ struct GemmArgs {
   const double* B = nullptr;  long bBatch = 0; int ldb = 0;
   double* C = nullptr;        long cBatch = 0; int ldc = 0;
   double* colsq = nullptr;    long sBatch = 0; long sRowBlk = 0;   // colsq[batch*sBatch + rb*sRowBlk + j]
+  const double* cscale = nullptr; long csCol = 0, csBatch = 0; double calpha = 1.0;   // stored C[i][j] *= calpha * cscale[batch*csBatch + j*csCol] (backward pass)
   int Mi = 0, Mk = 0, Kc = 0;  // rows of C, contraction length, columns
   int nW = 1, nB = 1;          // batch = nW * nB, bz -> (iw = bz / nB, ib = bz % nB)
   int tri = 0;                 // 0 dense, 1: W lower (k <= i), 2: W upper (k >= i)

@@ -242,10 +242,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
 #pragma unroll
       for (int y = 0; y < FN; ++y) {
         int j = j0 + wn * WNC + y * 16 + lcol;
+        const double cs = (a.cscale && j < a.Kc) ? a.calpha * a.cscale[(long)bzl * a.csBatch + (long)j * a.csCol] : 1.0;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           int i = i0 + frag_off(x) + lrow + 4 * v;
-          if (i < a.Mi && j < a.Kc) C[(long)i * a.ldc + j] = acc[x][y][v];
+          if (i < a.Mi && j < a.Kc) C[(long)i * a.ldc + j] = acc[x][y][v] * cs;
         }
       }
   }

@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 
-// C_b(i, j) (+)= alpha * colscale_b[j] * sum_k A_b(i, k) B_b(k, j)
+// C_b(i, j) (+)= alpha * colscale_b[j] * sum_k A_b(i, k) kscale_b[k] B_b(k, j)
 //   A_b(i, k) = A[b * a_bs + i * a_rs + k * a_cs],  B_b(k, j) = B[b * b_bs + k * b_rs + j * b_cs],
 //   C_b(i, j) = C[b * c_bs + i * c_rs + j],         colscale_b[j] = colscale[b * cs_bs + j * cs_s] (optional)
 struct GenGemm {
@@ -13,6 +13,7 @@ struct GenGemm {
   double alpha = 1.0;
   int accumulate = 0;      // C += ... instead of C = ...
   const double* colscale = nullptr; long cs_s = 0, cs_bs = 0;
+  const double* kscale = nullptr; long ks_s = 0, ks_bs = 0;   // B_b(k, j) is read as B_b(k, j) * kscale[b * ks_bs + k * ks_s]
   int lower_only = 0;      // entries with j > i are written as 0 (before accumulation)
 };
 int gemm_gen(dcgp_ctx* ctx, const GenGemm& g);

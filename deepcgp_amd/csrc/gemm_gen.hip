@@ -10,30 +10,68 @@ namespace {
 
 constexpr int GT = 64, GK = 16, GLD = 80;   // GLD: 64 + 16 -> the two 16-lane halves of a ds_read_b64 hit disjoint banks
 
-__device__ __forceinline__ double ld_or_zero(const double* p, bool ok) { return ok ? *p : 0.0; }
-
+// AKF / BKF: the operand's contraction index is the contiguous one (fetch 4 consecutive k per thread), otherwise 4
+// consecutive rows (columns) per thread.  VEC: every 4-element group is 16-byte aligned and contiguous (two b128 loads).
+template <bool AKF, bool BKF, bool VEC>
 __global__ __launch_bounds__(256) void gemm_gen_kernel(GenGemm g, int kchunk, double* part) {
   __shared__ double As[GK][GLD];
   __shared__ double Bs[GK][GLD];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int bz = blockIdx.z, b = bz % g.batch, sp = bz / g.batch;
   const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+  const bool split = part != nullptr;
+  double* C = split ? part + ((long)sp * g.batch + b) * (long)g.M * g.N : g.C + (long)b * g.c_bs;
+  const long c_rs = split ? g.N : g.c_rs;
+  if (g.lower_only && j0 > i0 + GT - 1) {   // tile strictly above the diagonal: nothing to compute
+    if (!split && !g.accumulate)
+      for (int e = t; e < GT * GT; e += 256) {
+        const int i = i0 + e / GT, j = j0 + e % GT;
+        if (i < g.M && j < g.N) C[(long)i * c_rs + j] = 0.0;
+      }
+    return;
+  }
   const int kbeg = sp * kchunk, kend = min(g.K, kbeg + kchunk);
-  const double* A = g.A + (long)b * g.a_bs;
-  const double* B = g.B + (long)b * g.b_bs;
-  // operand fetch: 4 elements per thread per tile, along whichever index is contiguous in memory
-  const bool a_kfast = g.a_cs == 1, b_kfast = g.b_rs == 1;
-  const int a_m = a_kfast ? (t >> 2) : ((t & 15) * 4), a_k = a_kfast ? ((t & 3) * 4) : (t >> 4);
-  const int b_n = b_kfast ? (t >> 2) : ((t & 15) * 4), b_k = b_kfast ? ((t & 3) * 4) : (t >> 4);
+  const int a_m = AKF ? (t >> 2) : ((t & 15) * 4), a_k = AKF ? ((t & 3) * 4) : (t >> 4);
+  const int b_n = BKF ? (t >> 2) : ((t & 15) * 4), b_k = BKF ? ((t & 3) * 4) : (t >> 4);
+  // per-thread fetch pointers, advanced by one k tile per iteration; row / column validity is loop invariant
+  const double* pa = g.A + (long)b * g.a_bs + (long)(i0 + a_m) * g.a_rs + (long)(kbeg + a_k) * g.a_cs;
+  const double* pb = g.B + (long)b * g.b_bs + (long)(j0 + b_n) * g.b_cs + (long)(kbeg + b_k) * g.b_rs;
+  const long a_step = (long)GK * g.a_cs, b_step = (long)GK * g.b_rs;
+  const long a_u = AKF ? g.a_cs : g.a_rs, b_u = BKF ? g.b_rs : g.b_cs;   // stride between the thread's 4 elements
+  bool va[4], vb[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    va[u] = (i0 + a_m + (AKF ? 0 : u)) < g.M;
+    vb[u] = (j0 + b_n + (BKF ? 0 : u)) < g.N;
+  }
+  const bool a_all = va[0] && va[3], b_all = vb[0] && vb[3];
   double ra[4], rb[4];
   auto fetch = [&](int k0) {
+    const bool full = k0 + GK <= kend;
+    if (VEC && full && a_all) {
+      const double2 x = *(const double2*)pa, y = *(const double2*)(pa + 2);
+      ra[0] = x.x; ra[1] = x.y; ra[2] = y.x; ra[3] = y.y;
+    } else {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int mi = i0 + a_m + (a_kfast ? 0 : u), ki = k0 + a_k + (a_kfast ? u : 0);
-      ra[u] = ld_or_zero(A + (long)mi * g.a_rs + (long)ki * g.a_cs, mi < g.M && ki < kend);
-      const int nj = j0 + b_n + (b_kfast ? 0 : u), kj = k0 + b_k + (b_kfast ? u : 0);
-      rb[u] = ld_or_zero(B + (long)kj * g.b_rs + (long)nj * g.b_cs, nj < g.N && kj < kend);
+      for (int u = 0; u < 4; ++u) ra[u] = (va[u] && (full || k0 + a_k + (AKF ? u : 0) < kend)) ? pa[u * a_u] : 0.0;
     }
+    if (VEC && full && b_all) {
+      const double2 x = *(const double2*)pb, y = *(const double2*)(pb + 2);
+      rb[0] = x.x; rb[1] = x.y; rb[2] = y.x; rb[3] = y.y;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rb[u] = (vb[u] && (full || k0 + b_k + (BKF ? u : 0) < kend)) ? pb[u * b_u] : 0.0;
+    }
+    if (g.kscale) {
+      const double* ks = g.kscale + (long)b * g.ks_bs;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kq = k0 + b_k + (BKF ? u : 0);
+        rb[u] *= kq < kend ? ks[(long)kq * g.ks_s] : 0.0;
+      }
+    }
+    pa += a_step;
+    pb += b_step;
   };
   d4 acc[2][2];
 #pragma unroll
@@ -46,8 +84,8 @@ __global__ __launch_bounds__(256) void gemm_gen_kernel(GenGemm g, int kchunk, do
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      As[a_k + (a_kfast ? u : 0)][a_m + (a_kfast ? 0 : u)] = ra[u];
-      Bs[b_k + (b_kfast ? u : 0)][b_n + (b_kfast ? 0 : u)] = rb[u];
+      As[a_k + (AKF ? u : 0)][a_m + (AKF ? 0 : u)] = ra[u];
+      Bs[b_k + (BKF ? u : 0)][b_n + (BKF ? 0 : u)] = rb[u];
     }
     __syncthreads();
     if (k0 + GK < kend) fetch(k0 + GK);
@@ -62,9 +100,6 @@ __global__ __launch_bounds__(256) void gemm_gen_kernel(GenGemm g, int kchunk, do
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
   }
-  const bool split = part != nullptr;
-  double* C = split ? part + ((long)sp * g.batch + b) * (long)g.M * g.N : g.C + (long)b * g.c_bs;
-  const long c_rs = split ? g.N : g.c_rs;
 #pragma unroll
   for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
@@ -106,11 +141,12 @@ __global__ void splitk_reduce_kernel(GenGemm g, int ksplit, const double* part) 
 int gemm_gen(dcgp_ctx* ctx, const GenGemm& g) {
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return DCGP_OK;
   if (!g.A || !g.B || !g.C || g.K < 0) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_gen: bad arguments");
-  const int tiles = ((g.M + GT - 1) / GT) * ((g.N + GT - 1) / GT) * g.batch;
+  int tiles = ((g.M + GT - 1) / GT) * ((g.N + GT - 1) / GT) * g.batch;
+  if (g.lower_only) tiles = tiles * 5 / 8 + 1;   // tiles above the diagonal exit at once
   // split long contractions until the launch covers the chip a few times over
   int ksplit = 1;
-  if (g.K >= 2048 && tiles < 1024) {
-    ksplit = (1024 + tiles - 1) / tiles;
+  if (g.K >= 2048 && tiles < 1536) {
+    ksplit = (1536 + tiles - 1) / tiles;
     const int max_split = g.K / 512;
     if (ksplit > max_split) ksplit = max_split;
     if (ksplit < 1) ksplit = 1;
@@ -125,7 +161,18 @@ int gemm_gen(dcgp_ctx* ctx, const GenGemm& g) {
   }
   if ((long)g.batch * ksplit > 65535) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_gen: batch %d x split %d too large", g.batch, ksplit);
   dim3 grid((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, g.batch * ksplit);
-  hipLaunchKernelGGL(gemm_gen_kernel, grid, dim3(256), 0, ctx->stream, g, kchunk, part);
+  const bool akf = g.a_cs == 1, bkf = g.b_rs == 1;
+  // 16-byte loads: the contiguous stride is 1 and every other stride, the base and the k origin of a split keep 16-byte alignment
+  auto even = [](long x) { return (x & 1) == 0; };
+  const bool a_vec = (akf ? even(g.a_rs) : (g.a_rs == 1 && even(g.a_cs))) && even(g.a_bs) && ((uintptr_t)g.A % 16 == 0);
+  const bool b_vec = (bkf ? even(g.b_cs) : (g.b_cs == 1 && even(g.b_rs))) && even(g.b_bs) && ((uintptr_t)g.B % 16 == 0);
+  const bool vec = a_vec && b_vec;
+#define GG_LAUNCH(AK, BKK, V) hipLaunchKernelGGL((gemm_gen_kernel<AK, BKK, V>), grid, dim3(256), 0, ctx->stream, g, kchunk, part)
+  if (akf && bkf) { if (vec) GG_LAUNCH(true, true, true); else GG_LAUNCH(true, true, false); }
+  else if (akf) { if (vec) GG_LAUNCH(true, false, true); else GG_LAUNCH(true, false, false); }
+  else if (bkf) { if (vec) GG_LAUNCH(false, true, true); else GG_LAUNCH(false, true, false); }
+  else { if (vec) GG_LAUNCH(false, false, true); else GG_LAUNCH(false, false, false); }
+#undef GG_LAUNCH
   LAUNCH_CHECK(ctx);
   if (part) {
     const long total = (long)g.M * g.N * g.batch;

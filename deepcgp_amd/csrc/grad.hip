@@ -38,54 +38,66 @@ __device__ __forceinline__ double block_sum_256(double v, double* red) {
 }
 
 // ---- likelihood ------------------------------------------------------------------------------------------------
-// d sum_rows weight * ve(row) / d(mu, var): one thread per (row, class).  Same quadrature as varexp_kernel (cond.hip):
-// 20 Gauss-Hermite nodes, cdf = (1 - 2e-4) Phi + 1e-4, clips at 1e-10.
-__global__ void robustmax_grad_kernel(const double* __restrict__ mu, const double* __restrict__ var, const int32_t* __restrict__ y,
-                                      int rows, int n_labels, int K, double eps, const double* __restrict__ gh, double weight,
-                                      double* __restrict__ gm, double* __restrict__ gv) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)rows * K) return;
-  const int row = (int)(idx / K), k = (int)(idx % K);
-  const int lab = y[row % n_labels];
-  const double* m = mu + (long)row * K;
-  const double* v = var + (long)row * K;
-  const double muy = m[lab], vy = v[lab];
-  const bool live_y = 2.0 * vy > 1e-10;
-  const double sy = sqrt(fmax(2.0 * vy, 1e-10));
-  const double c = log(1.0 - eps) - log(eps / (K - 1.0));
+// d sum_rows weight * ve(row) / d(mu, var).  Same quadrature as varexp_kernel (cond.hip): 20 Gauss-Hermite nodes,
+// cdf = (1 - 2e-4) Phi + 1e-4, clips at 1e-10.  One thread per (row, node) evaluates the node's terms for every class
+// into LDS; one thread per (row, class) then adds the 20 nodes in a fixed order.  RM_ROWS rows per 256-thread block.
+constexpr int RM_ROWS = 12, RM_KMAX = 16;
+__global__ __launch_bounds__(256) void robustmax_grad_kernel(const double* __restrict__ mu, const double* __restrict__ var, const int32_t* __restrict__ y,
+                                                             int rows, int n_labels, int K, double eps, const double* __restrict__ gh, double weight,
+                                                             double* __restrict__ gm, double* __restrict__ gv) {
+  __shared__ double tm[RM_ROWS][20][RM_KMAX], tv[RM_ROWS][20][RM_KMAX];
+  const int t = threadIdx.x, lr = t / 20, g = t % 20;
+  const int row = blockIdx.x * RM_ROWS + lr;
   const double inv_sqrt_pi = 0.56418958354775628695, inv_sqrt_2pi = 0.39894228040143267794;
-  double acc_mu = 0.0, acc_var = 0.0;
-  for (int g = 0; g < 20; ++g) {
+  if (lr < RM_ROWS && row < rows) {
+    const int lab = y[row % n_labels];
+    const double* m = mu + (long)row * K;
+    const double* v = var + (long)row * K;
+    const double vy = v[lab];
+    const bool live_y = 2.0 * vy > 1e-10;
+    const double sy = sqrt(fmax(2.0 * vy, 1e-10));
     const double xg = gh[g], wg = gh[20 + g] * inv_sqrt_pi;
-    const double X = muy + xg * sy;
+    const double X = m[lab] + xg * sy;
     double prod = 1.0;
-    for (int kk = 0; kk < K; ++kk) {
-      if (kk == lab) continue;
-      const double d = (X - m[kk]) / sqrt(fmax(v[kk], 1e-10));
+    for (int k = 0; k < K; ++k) {
+      if (k == lab) continue;
+      const double d = (X - m[k]) / sqrt(fmax(v[k], 1e-10));
       prod *= 0.5 * (1.0 + erf(d * 0.70710678118654752440)) * (1.0 - 2e-4) + 1e-4;
     }
-    if (k != lab) {
+    double qs = 0.0;
+    for (int k = 0; k < K; ++k) {
+      if (k == lab) continue;
       const double sig = sqrt(fmax(v[k], 1e-10));
       const double d = (X - m[k]) / sig;
       const double cdf = 0.5 * (1.0 + erf(d * 0.70710678118654752440)) * (1.0 - 2e-4) + 1e-4;
       const double q = wg * prod / cdf * exp(-0.5 * d * d) * inv_sqrt_2pi * (1.0 - 2e-4);
-      acc_mu -= q / sig;
-      if (v[k] > 1e-10) acc_var -= q * d / (2.0 * v[k]);
-    } else {
-      double qs = 0.0;
-      for (int kk = 0; kk < K; ++kk) {
-        if (kk == lab) continue;
-        const double sig = sqrt(fmax(v[kk], 1e-10));
-        const double d = (X - m[kk]) / sig;
-        const double cdf = 0.5 * (1.0 + erf(d * 0.70710678118654752440)) * (1.0 - 2e-4) + 1e-4;
-        qs += wg * prod / cdf * exp(-0.5 * d * d) * inv_sqrt_2pi * (1.0 - 2e-4) / sig;
-      }
-      acc_mu += qs;
-      if (live_y) acc_var += qs * xg / sy;
+      tm[lr][g][k] = -q / sig;
+      tv[lr][g][k] = v[k] > 1e-10 ? -q * d / (2.0 * v[k]) : 0.0;
+      qs += q / sig;
     }
+    tm[lr][g][lab] = qs;
+    tv[lr][g][lab] = live_y ? qs * xg / sy : 0.0;
   }
-  gm[idx] = c * weight * acc_mu;
-  gv[idx] = c * weight * acc_var;
+  __syncthreads();
+  const double c = log(1.0 - eps) - log(eps / (K - 1.0));
+  for (int idx = t; idx < RM_ROWS * K; idx += 256) {
+    const int r2 = idx / K, k = idx % K, row2 = blockIdx.x * RM_ROWS + r2;
+    if (row2 >= rows) continue;
+    double a = 0.0, b = 0.0;
+    for (int gg = 0; gg < 20; ++gg) { a += tm[r2][gg][k]; b += tv[r2][gg][k]; }
+    gm[(long)row2 * K + k] = c * weight * a;
+    gv[(long)row2 * K + k] = c * weight * b;
+  }
+}
+
+// GT[(r * Mp + k) * Mp + i] = G[r][i][k]: the R transposes stacked along k (pads included)
+__global__ void restack_transpose_kernel(const double* __restrict__ G, int Mp, int R, double* __restrict__ GT) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long mm = (long)Mp * Mp;
+  if (idx >= mm * R) return;
+  const int r = (int)(idx / mm);
+  const int k = (int)((idx % mm) / Mp), i = (int)(idx % Mp);
+  GT[idx] = G[r * mm + (long)i * Mp + k];
 }
 
 // previous layer's (dmean, dvar) from d sample:  sample = mean + z sqrt(var + jitter),  z = (sample - mean) / sqrt(var + jitter)
@@ -135,6 +147,22 @@ __global__ void copy2d_kernel(const double* __restrict__ src, long lds, double* 
   const double v = alpha * src[i * lds + j];
   double* d = dst + i * ldd + j;
   *d = accumulate ? *d + v : v;
+}
+
+// out[r][c] = in[c][r]   (in [n][R])
+__global__ void transpose_small_kernel(const double* __restrict__ in, long n, int R, double* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * R) return;
+  const long c = idx / R;
+  const int r = (int)(idx % R);
+  out[r * n + c] = in[idx];
+}
+
+// A_b[i][j] = A_b[j][i] for j > i
+__global__ void mirror_lower_kernel(double* __restrict__ A, long ld, long bs, int M) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
+  if (j >= M || j <= i) return;
+  A[b * bs + i * ld + j] = A[b * bs + j * ld + i];
 }
 
 // Phi: keep the lower triangle, halve the diagonal (in place)
@@ -274,13 +302,15 @@ __global__ void axmy_kernel(const double* __restrict__ Pm, const double* __restr
   dst[idx] = accumulate ? dst[idx] + val : val;
 }
 
-// out[p] (+)= scale * sum_n raw[n * P + p]
-__global__ void strided_sum_kernel(const double* __restrict__ raw, int N, int P, double scale, int accumulate, double* __restrict__ out) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
+// out[p] (+)= scale * sum_n raw[n * P + p]: one block per p
+__global__ __launch_bounds__(256) void strided_sum_kernel(const double* __restrict__ raw, int N, int P, double scale, int accumulate,
+                                                          double* __restrict__ out) {
+  __shared__ double red[256];
+  const int p = blockIdx.x;
   double s = 0.0;
-  for (int n = 0; n < N; ++n) s += raw[(long)n * P + p];
-  out[p] = accumulate ? out[p] + scale * s : scale * s;
+  for (int n = threadIdx.x; n < N; n += 256) s += raw[(long)n * P + p];
+  const double r = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[p] = accumulate ? out[p] + scale * r : scale * r;
 }
 
 // ConvKernel.Kdiag backward (conv_gp/kernels.py:106-115): block per (image n, patch p), thread per p'.
@@ -465,10 +495,12 @@ int kl_backward(Bk& bk, LayerState& L, double* Sacc) {
     GenGemm g1 = mk(Lpinv, Mp, 1, L.g.Lq, Mp, 1, Wm, Mp, M, M, M);
     g1.batch = R; g1.b_bs = mm; g1.c_bs = mm;
     DCGP_TRY(gemm_gen(ctx, g1));
-    GenGemm g2 = mk(Lpinv, 1, Mp, Wm, Mp, 1, KiL, Mp, M, M, M);
-    g2.batch = R; g2.b_bs = mm; g2.c_bs = mm;
+    const long Rm = (long)R * Mp;
+    HIP_TRY(ctx, hipMemsetAsync(KiL, 0, (size_t)R * mm * sizeof(double), ctx->stream));
+    GenGemm g2 = mk(Lpinv, 1, Mp, Wm, Mp, 1, KiL, Rm, M, M, M);        // inv(K) Lq_r, stored [i][r][k]
+    g2.batch = R; g2.b_bs = mm; g2.c_bs = Mp;
     DCGP_TRY(gemm_gen(ctx, g2));
-    hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, KiL, (long)Mp, mm, L.gq_sqrt, (long)M,
+    hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, KiL, Rm, (long)Mp, L.gq_sqrt, (long)M,
                        (long)M * M, M, -kw, 1);
     LAUNCH_CHECK(ctx);
     // -dKL/dK = -1/2 [R inv(K) - (inv(K) q_mu)(inv(K) q_mu)^T - sum_r (inv(K) Lq_r)(inv(K) Lq_r)^T]
@@ -481,11 +513,9 @@ int kl_backward(Bk& bk, LayerState& L, double* Sacc) {
     GenGemm g4 = mk(Kimu, Rp, 1, Kimu, 1, Rp, Sk, Mp, M, M, R);
     g4.alpha = 0.5 * kw; g4.accumulate = 1;
     DCGP_TRY(gemm_gen(ctx, g4));
-    for (int r = 0; r < R; ++r) {
-      GenGemm g5 = mk(KiL + r * mm, Mp, 1, KiL + r * mm, 1, Mp, Sk, Mp, M, M, M);
-      g5.alpha = 0.5 * kw; g5.accumulate = 1;
-      DCGP_TRY(gemm_gen(ctx, g5));
-    }
+    GenGemm g5 = mk(KiL, Rm, 1, KiL, 1, Rm, Sk, Mp, M, M, (int)Rm);     // all r at once, stacked along k
+    g5.alpha = 0.5 * kw; g5.accumulate = 1;
+    DCGP_TRY(gemm_gen(ctx, g5));
     if (!Sacc) DCGP_TRY(kuu_backward(bk, L, L.Z0, Sk, Mp, false));   // frozen Z0: hyper-parameters only
   }
   hipLaunchKernelGGL(kl_diag_kernel, dim3(blocks_for((long)M * R)), dim3(256), 0, ctx->stream, L.gq_sqrt, L.g.Lq, M, Mp, R, kw);
@@ -509,27 +539,72 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   double* dG = bk.ws("dG", (size_t)R * mm);
   double* dL = bk.ws("dL", (size_t)mm);
   NEED(dA1); NEED(dalpha); NEED(dG); NEED(dL);
-  // dA1 = alpha gm^T - 2 A1 o gvs
-  DCGP_TRY(gemm_gen(ctx, mk(g.alpha, Rp, 1, gm, 1, R, dA1, ld, M, (int)Kc, R)));
-  hipLaunchKernelGGL(dA1_fix_kernel, dim3(blocks_for(Kc), M), dim3(256), 0, ctx->stream, dA1, A1, gvs, M, Kc, ld);
-  LAUNCH_CHECK(ctx);
+  const long Rm = (long)R * Mp;
+  double* GT = nullptr;
+  if (L.has_qsqrt) {
+    GT = bk.ws("GT", (size_t)R * mm);
+    NEED(GT);
+    hipLaunchKernelGGL(restack_transpose_kernel, dim3(blocks_for(R * mm)), dim3(256), 0, ctx->stream, g.G, Mp, R, GT);
+    LAUNCH_CHECK(ctx);
+  }
   // d alpha = A1 gm
   DCGP_TRY(gemm_gen(ctx, mk(A1, ld, 1, gm, R, 1, dalpha, Rp, M, R, (int)Kc)));
+  int dA1_acc = 0;
+  if (!L.has_qsqrt && Mp > M) HIP_TRY(ctx, hipMemsetAsync(dA1 + (size_t)M * ld, 0, (size_t)(Mp - M) * ld * sizeof(double), ctx->stream));
   if (L.has_qsqrt) {
     double* dT = bk.ws("dT", (size_t)R * Mp * ld);
     NEED(dT);
-    GenGemm t = mk(g.G, 1, Mp, A1, ld, 1, dT, ld, M, (int)Kc, M);   // dT_r = 2 (G_r^T A1) o gv_r
-    t.batch = R; t.a_bs = mm; t.c_bs = (long)Mp * ld; t.alpha = 2.0; t.colscale = gv; t.cs_s = R; t.cs_bs = 1;
-    DCGP_TRY(gemm_gen(ctx, t));
-    for (int r = 0; r < R; ++r) {                                    // dA1 += G_r dT_r
-      GenGemm a = mk(g.G + r * mm, Mp, 1, dT + (long)r * Mp * ld, ld, 1, dA1, ld, M, (int)Kc, M);
-      a.accumulate = 1;
-      DCGP_TRY(gemm_gen(ctx, a));
+    const bool tn_ok = (long)Mp * ld * 8 < (1L << 31);
+    if (tn_ok) {   // dT_r = 2 (G_r^T A1) o gv_r: the forward's stage-3 product, stored, columns scaled in the epilogue
+      GemmArgs a;
+      a.Wt = g.G; a.ldw = Mp; a.wBatch = mm; a.nW = R;
+      a.B = A1; a.ldb = (int)ld;
+      a.C = dT; a.ldc = (int)ld; a.cBatch = (long)Mp * ld;
+      a.cscale = gv; a.csCol = R; a.csBatch = 1; a.calpha = 2.0;
+      a.Mi = Mp; a.Mk = Mp; a.Kc = (int)Kc; a.tri = 2;
+      DCGP_TRY(gemm_tn(ctx, a, nullptr));
+    } else {
+      GenGemm t = mk(g.G, 1, Mp, A1, ld, 1, dT, ld, Mp, (int)Kc, Mp);
+      t.batch = R; t.a_bs = mm; t.c_bs = (long)Mp * ld; t.alpha = 2.0; t.colscale = gv; t.cs_s = R; t.cs_bs = 1;
+      DCGP_TRY(gemm_gen(ctx, t));
     }
-    GenGemm d = mk(A1, ld, 1, dT, 1, ld, dG, Mp, M, M, (int)Kc);     // dG_r = tril(A1 dT_r^T)
-    d.batch = R; d.b_bs = (long)Mp * ld; d.c_bs = mm; d.lower_only = 1;
+    // dA1 = sum_r G_r dT_r: ONE product with the R blocks stacked along k (GT [R Mp x Mp], dT [R Mp x ld])
+    if (Rm * ld * 8 < (1L << 31)) {
+      GemmArgs a;
+      a.Wt = GT; a.ldw = Mp;
+      a.B = dT; a.ldb = (int)ld;
+      a.C = dA1; a.ldc = (int)ld;
+      a.Mi = Mp; a.Mk = (int)Rm; a.Kc = (int)Kc; a.tri = 0;
+      DCGP_TRY(gemm_tn(ctx, a, nullptr));
+    } else {
+      DCGP_TRY(gemm_gen(ctx, mk(GT, 1, Mp, dT, ld, 1, dA1, ld, M, (int)Kc, (int)Rm)));
+    }
+    dA1_acc = 1;
+    // dG_r = tril(A1 dT_r^T) = tril(W_r G_r),  W_r = 2 A1 diag(gv_r) A1^T (symmetric).  Both operands of the long
+    // contraction are then A1 itself (94 MB at the headline size: it stays in the 256 MB Infinity Cache across the R
+    // batches, where the R x larger dT would stream from HBM); lower tiles only, mirrored afterwards.
+    double* gvT = bk.ws("gvT", (size_t)R * Kc);
+    double* Wr = bk.ws("Wr", (size_t)R * mm);
+    NEED(gvT); NEED(Wr);
+    hipLaunchKernelGGL(transpose_small_kernel, dim3(blocks_for(Kc * R)), dim3(256), 0, ctx->stream, gv, Kc, R, gvT);
+    LAUNCH_CHECK(ctx);
+    GenGemm w = mk(A1, ld, 1, A1, 1, ld, Wr, Mp, M, M, (int)Kc);
+    w.batch = R; w.c_bs = mm; w.lower_only = 1; w.alpha = 2.0; w.kscale = gvT; w.ks_s = 1; w.ks_bs = Kc;
+    DCGP_TRY(gemm_gen(ctx, w));
+    hipLaunchKernelGGL(mirror_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Wr, (long)Mp, mm, M);
+    LAUNCH_CHECK(ctx);
+    GenGemm d = mk(Wr, Mp, 1, g.G, Mp, 1, dG, Mp, M, M, M);
+    d.batch = R; d.a_bs = mm; d.b_bs = mm; d.c_bs = mm; d.lower_only = 1;
     DCGP_TRY(gemm_gen(ctx, d));
   }
+  // dA1 (+)= alpha gm^T - 2 A1 o gvs
+  {
+    GenGemm a = mk(g.alpha, Rp, 1, gm, 1, R, dA1, ld, M, (int)Kc, R);
+    a.accumulate = dA1_acc;
+    DCGP_TRY(gemm_gen(ctx, a));
+  }
+  hipLaunchKernelGGL(dA1_fix_kernel, dim3(blocks_for(Kc), M), dim3(256), 0, ctx->stream, dA1, A1, gvs, M, Kc, ld);
+  LAUNCH_CHECK(ctx);
   if (L.white) {
     hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(R), M), dim3(256), 0, ctx->stream, dalpha, (long)Rp, L.gq_mu, (long)R, M, R, 1.0, 0);
     LAUNCH_CHECK(ctx);
@@ -546,23 +621,31 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
     l1.alpha = -1.0; l1.lower_only = 1;
     DCGP_TRY(gemm_gen(ctx, l1));
     if (L.has_qsqrt) {
-      double* Bm = bk.ws("Bm", (size_t)R * mm);
+      double* Bm = bk.ws("Bm", (size_t)R * mm);                      // B_r = inv(L)^T dG_r, stored [i][r][k]
       NEED(Bm);
-      GenGemm b = mk(g.Linv, 1, Mp, dG, Mp, 1, Bm, Mp, M, M, M);     // B_r = inv(L)^T dG_r
-      b.batch = R; b.b_bs = mm; b.c_bs = mm;
+      HIP_TRY(ctx, hipMemsetAsync(Bm, 0, (size_t)R * mm * sizeof(double), ctx->stream));
+      GenGemm b = mk(g.Linv, 1, Mp, dG, Mp, 1, Bm, Rm, M, M, M);
+      b.batch = R; b.b_bs = mm; b.c_bs = Mp;
       DCGP_TRY(gemm_gen(ctx, b));
-      hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Bm, (long)Mp, mm, L.gq_sqrt, (long)M,
+      hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Bm, Rm, (long)Mp, L.gq_sqrt, (long)M,
                          (long)M * M, M, 1.0, 0);
       LAUNCH_CHECK(ctx);
-      for (int r = 0; r < R; ++r) {                                  // dL -= tril(B_r G_r^T)
-        GenGemm l2 = mk(Bm + r * mm, Mp, 1, g.G + r * mm, 1, Mp, dL, Mp, M, M, M);
-        l2.alpha = -1.0; l2.lower_only = 1; l2.accumulate = 1;
-        DCGP_TRY(gemm_gen(ctx, l2));
-      }
+      GenGemm l2 = mk(Bm, Rm, 1, GT, Mp, 1, dL, Mp, M, M, (int)Rm);   // dL -= tril(sum_r B_r G_r^T), stacked along k
+      l2.alpha = -1.0; l2.lower_only = 1; l2.accumulate = 1;
+      DCGP_TRY(gemm_gen(ctx, l2));
     }
   }
   // dKuf = inv(L)^T dA1;  dL -= tril(dKuf A1^T)
-  DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dA1, ld, 1, dKuf, ld, M, (int)Kc, M)));
+  if ((long)Mp * ld * 8 < (1L << 31)) {   // inv(L) row-major IS the k-major operand of inv(L)^T; upper-triangular product
+    GemmArgs a;
+    a.Wt = g.Linv; a.ldw = Mp;
+    a.B = dA1; a.ldb = (int)ld;
+    a.C = dKuf; a.ldc = (int)ld;
+    a.Mi = Mp; a.Mk = Mp; a.Kc = (int)Kc; a.tri = 2;
+    DCGP_TRY(gemm_tn(ctx, a, nullptr));
+  } else {
+    DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dA1, ld, 1, dKuf, ld, M, (int)Kc, M)));
+  }
   GenGemm l3 = mk(dKuf, ld, 1, A1, 1, ld, dL, Mp, M, M, (int)Kc);
   l3.alpha = -1.0; l3.lower_only = 1; l3.accumulate = 1;
   DCGP_TRY(gemm_gen(ctx, l3));
@@ -687,7 +770,7 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   LAUNCH_CHECK(ctx);
   // Kzx[m][n] = 1/P sum_p w_p k(Z_m, x_np)
   DCGP_TRY(e_form(bk, L, dKzx, ld, P, L.w, 1.0 / P, Kfull, ldf, E, ldf, Kc, cs, raw));
-  hipLaunchKernelGGL(strided_sum_kernel, dim3(blocks_for(P)), dim3(256), 0, ctx->stream, raw, rows, P, 1.0 / P, 1, L.gw);
+  hipLaunchKernelGGL(strided_sum_kernel, dim3(P), dim3(256), 0, ctx->stream, raw, rows, P, 1.0 / P, 1, L.gw);
   LAUNCH_CHECK(ctx);
   DCGP_TRY(patch_backward(bk, L, E, ldf, Kc, cs, Xcol, dXin ? dXcol : nullptr, 0));
   // Kdiag
@@ -709,7 +792,7 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
     LAUNCH_CHECK(ctx);
     DCGP_TRY(add_scalar(bk, L, false, pv, (long)rows * P, 1.0 / L.variance));
     DCGP_TRY(add_scalar(bk, L, true, pl, (long)rows * P, inv_l2 / L.ls));
-    hipLaunchKernelGGL(strided_sum_kernel, dim3(blocks_for(P)), dim3(256), 0, ctx->stream, dwn, rows, P, 1.0, 1, L.gw);
+    hipLaunchKernelGGL(strided_sum_kernel, dim3(P), dim3(256), 0, ctx->stream, dwn, rows, P, 1.0, 1, L.gw);
     LAUNCH_CHECK(ctx);
     if (dXin) {
       GenGemm ge = mk(Gm, P, 1, Xcol, Ld, 1, EXn, Ld, P, Ld, P);    // E_n X_n
@@ -764,7 +847,8 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
   double* gm = (double*)ws_get(ctx, mp + "g_gm_head", (size_t)rows * H.R * sizeof(double));
   double* gv = (double*)ws_get(ctx, mp + "g_gv_head", (size_t)rows * H.R * sizeof(double));
   NEED(gm); NEED(gv);
-  hipLaunchKernelGGL(robustmax_grad_kernel, dim3(blocks_for((long)rows * H.R)), dim3(256), 0, ctx->stream, oh.mean, oh.var, y, rows, N, H.R,
+  if (H.R > RM_KMAX) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: at most %d classes", RM_KMAX);
+  hipLaunchKernelGGL(robustmax_grad_kernel, dim3((rows + RM_ROWS - 1) / RM_ROWS), dim3(256), 0, ctx->stream, oh.mean, oh.var, y, rows, N, H.R,
                      m->eps, gh, weight, gm, gv);
   LAUNCH_CHECK(ctx);
   for (int li = nl - 1; li >= 0; --li) {
