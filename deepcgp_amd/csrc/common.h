@@ -13,6 +13,10 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline long round_up_l(long x, long m) { return (x + m - 1) / m * m; }
+// Leading dimension of the [M x columns] matrices (K_uf, A1, dT, ...): a multiple of 128 columns plus a skew.  Without
+// the skew the row stride is a multiple of 4 KB at the bench sizes and every row of a k tile lands on the same HBM
+// channel (the backward products read 128 B of each of 128 rows per step).
+long col_ld(long columns);
 
 struct TimingAcc {
   int launches = 0;

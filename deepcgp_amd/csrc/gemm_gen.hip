@@ -1,21 +1,35 @@
 // General strided fp64 GEMM on v_mfma_f64_16x16x4_f64 for the backward pass (grad.hip): every operand is addressed
 // through (row stride, column stride, batch stride), so transposes and the [Kc][R] <-> [R][Kc] views of the
-// backward products need no copies.  64 x 64 output tile per 256-thread workgroup (4 waves, 32 x 32 each), BK = 16,
-// register prefetch of the next k tile.  Long contractions with a small output (d alpha, d G_r, d L: K = number of
+// backward products need no copies.  64 x 64 (or 128 x 128) output tile, 32 x 32 per wave, BK = 16, register prefetch of
+// the next k tile, double-buffered LDS (one barrier per k tile).  Long contractions with a small output (d alpha, d G_r, d L: K = number of
 // patch columns) are split along k into a partial buffer and summed in a fixed order -- no atomics, so gradients are
 // reproducible run to run.  The forward path's tuned kernel is gemm.hip; this one trades peak rate for generality.
 #include "gemm_gen.h"
 
 namespace {
 
-constexpr int GT = 64, GK = 16, GLD = 80;   // GLD: 64 + 16 -> the two 16-lane halves of a ds_read_b64 hit disjoint banks
+constexpr int GK = 16;
+// LDS tile layouts.  An operand whose rows (columns) are contiguous in memory is staged [k][m] with row stride GT + 16
+// (the two 16-lane halves of a ds_read_b64 hit disjoint banks); one whose contraction index is contiguous is staged
+// [m][k] with row stride LDK = 17, so that each thread's consecutive k land next to each other and the fragment reads
+// (16 rows x 4 k per wave) still spread over all banks.  Two buffers per operand: one barrier per k tile.
+constexpr int LDK = 17;
 
-// AKF / BKF: the operand's contraction index is the contiguous one (fetch 4 consecutive k per thread), otherwise 4
-// consecutive rows (columns) per thread.  VEC: every 4-element group is 16-byte aligned and contiguous (two b128 loads).
-template <bool AKF, bool BKF, bool VEC>
-__global__ __launch_bounds__(256) void gemm_gen_kernel(GenGemm g, int kchunk, double* part) {
-  __shared__ double As[GK][GLD];
-  __shared__ double Bs[GK][GLD];
+// GT x GT output tile on NT threads (NT / 64 waves, 32 x 32 per wave); each thread fetches EPT = GT * GK / NT elements of
+// either operand per k tile.  <64, 256> is the general configuration; <128, 1024> halves the operand traffic per flop
+// for the long contractions whose operands stream from the Infinity Cache / HBM (8 -> 16 flop per byte).
+// AKF / BKF: the operand's contraction index is the contiguous one (fetch EPT consecutive k per thread), otherwise EPT
+// consecutive rows (columns) per thread.  VEC: every EPT-element group is 16-byte aligned and contiguous (b128 loads).
+template <int GT, int NT, bool AKF, bool BKF, bool VEC>
+__global__ __launch_bounds__(NT, NT == 1024 ? 8 : 4) void gemm_gen_kernel(GenGemm g, int kchunk, double* part) {
+  constexpr int EPT = GT * GK / NT, LDM = GT + 16;
+  constexpr int TILE = (GK * LDM > GT * LDK) ? GK * LDM : GT * LDK;
+  constexpr int TPR = GK / EPT, TPK = GT / EPT, WAVES_N = GT / 32;
+  static_assert(EPT == 2 || EPT == 4, "fetch width");
+  auto lds_a = [](int m, int k) { return AKF ? m * LDK + k : k * LDM + m; };
+  auto lds_b = [](int m, int k) { return BKF ? m * LDK + k : k * LDM + m; };
+  __shared__ __attribute__((aligned(16))) double As[2][TILE];
+  __shared__ __attribute__((aligned(16))) double Bs[2][TILE];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int bz = blockIdx.z, b = bz % g.batch, sp = bz / g.batch;
   const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
@@ -24,48 +38,54 @@ __global__ __launch_bounds__(256) void gemm_gen_kernel(GenGemm g, int kchunk, do
   const long c_rs = split ? g.N : g.c_rs;
   if (g.lower_only && j0 > i0 + GT - 1) {   // tile strictly above the diagonal: nothing to compute
     if (!split && !g.accumulate)
-      for (int e = t; e < GT * GT; e += 256) {
+      for (int e = t; e < GT * GT; e += NT) {
         const int i = i0 + e / GT, j = j0 + e % GT;
         if (i < g.M && j < g.N) C[(long)i * c_rs + j] = 0.0;
       }
     return;
   }
   const int kbeg = sp * kchunk, kend = min(g.K, kbeg + kchunk);
-  const int a_m = AKF ? (t >> 2) : ((t & 15) * 4), a_k = AKF ? ((t & 3) * 4) : (t >> 4);
-  const int b_n = BKF ? (t >> 2) : ((t & 15) * 4), b_k = BKF ? ((t & 3) * 4) : (t >> 4);
-  // per-thread fetch pointers, advanced by one k tile per iteration; row / column validity is loop invariant
+  const int a_m = AKF ? (t / TPR) : ((t % TPK) * EPT), a_k = AKF ? ((t % TPR) * EPT) : (t / TPK);
+  const int b_n = BKF ? (t / TPR) : ((t % TPK) * EPT), b_k = BKF ? ((t % TPR) * EPT) : (t / TPK);
+  // per-thread fetch pointers, advanced by one k tile per fetch; row / column validity is loop invariant
   const double* pa = g.A + (long)b * g.a_bs + (long)(i0 + a_m) * g.a_rs + (long)(kbeg + a_k) * g.a_cs;
   const double* pb = g.B + (long)b * g.b_bs + (long)(j0 + b_n) * g.b_cs + (long)(kbeg + b_k) * g.b_rs;
   const long a_step = (long)GK * g.a_cs, b_step = (long)GK * g.b_rs;
-  const long a_u = AKF ? g.a_cs : g.a_rs, b_u = BKF ? g.b_rs : g.b_cs;   // stride between the thread's 4 elements
-  bool va[4], vb[4];
+  const long a_u = AKF ? g.a_cs : g.a_rs, b_u = BKF ? g.b_rs : g.b_cs;   // stride between the thread's elements
+  bool va[EPT], vb[EPT];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < EPT; ++u) {
     va[u] = (i0 + a_m + (AKF ? 0 : u)) < g.M;
     vb[u] = (j0 + b_n + (BKF ? 0 : u)) < g.N;
   }
-  const bool a_all = va[0] && va[3], b_all = vb[0] && vb[3];
-  double ra[4], rb[4];
+  const bool a_all = va[0] && va[EPT - 1], b_all = vb[0] && vb[EPT - 1];
+  double ra[EPT], rb[EPT];
   auto fetch = [&](int k0) {
     const bool full = k0 + GK <= kend;
     if (VEC && full && a_all) {
-      const double2 x = *(const double2*)pa, y = *(const double2*)(pa + 2);
-      ra[0] = x.x; ra[1] = x.y; ra[2] = y.x; ra[3] = y.y;
+#pragma unroll
+      for (int u = 0; u < EPT; u += 2) {
+        const double2 x = *(const double2*)(pa + u);
+        ra[u] = x.x; ra[u + 1] = x.y;
+      }
     } else {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) ra[u] = (va[u] && (full || k0 + a_k + (AKF ? u : 0) < kend)) ? pa[u * a_u] : 0.0;
+      for (int u = 0; u < EPT; ++u) ra[u] = (va[u] && (full || k0 + a_k + (AKF ? u : 0) < kend)) ? pa[u * a_u] : 0.0;
     }
     if (VEC && full && b_all) {
-      const double2 x = *(const double2*)pb, y = *(const double2*)(pb + 2);
-      rb[0] = x.x; rb[1] = x.y; rb[2] = y.x; rb[3] = y.y;
+#pragma unroll
+      for (int u = 0; u < EPT; u += 2) {
+        const double2 x = *(const double2*)(pb + u);
+        rb[u] = x.x; rb[u + 1] = x.y;
+      }
     } else {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) rb[u] = (vb[u] && (full || k0 + b_k + (BKF ? u : 0) < kend)) ? pb[u * b_u] : 0.0;
+      for (int u = 0; u < EPT; ++u) rb[u] = (vb[u] && (full || k0 + b_k + (BKF ? u : 0) < kend)) ? pb[u * b_u] : 0.0;
     }
     if (g.kscale) {
       const double* ks = g.kscale + (long)b * g.ks_bs;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < EPT; ++u) {
         const int kq = k0 + b_k + (BKF ? u : 0);
         rb[u] *= kq < kend ? ks[(long)kq * g.ks_s] : 0.0;
       }
@@ -73,32 +93,41 @@ __global__ __launch_bounds__(256) void gemm_gen_kernel(GenGemm g, int kchunk, do
     pa += a_step;
     pb += b_step;
   };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+      As[buf][lds_a(a_m + (AKF ? 0 : u), a_k + (AKF ? u : 0))] = ra[u];
+      Bs[buf][lds_b(b_n + (BKF ? 0 : u), b_k + (BKF ? u : 0))] = rb[u];
+    }
+  };
   d4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  if (kbeg < kend) fetch(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += GK) {
+  const int wm = (wave / WAVES_N) * 32, wn = (wave % WAVES_N) * 32;
+  const int nk = (kend - kbeg + GK - 1) / GK;
+  if (nk > 0) {
+    fetch(kbeg);
+    stage(0);
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      As[a_k + (AKF ? u : 0)][a_m + (AKF ? 0 : u)] = ra[u];
-      Bs[b_k + (BKF ? u : 0)][b_n + (BKF ? 0 : u)] = rb[u];
-    }
-    __syncthreads();
-    if (k0 + GK < kend) fetch(k0 + GK);
+    if (nk > 1) fetch(kbeg + GK);
+  }
+  for (int it = 0; it < nk; ++it) {
+    const int cur = it & 1;
 #pragma unroll
     for (int kk = 0; kk < GK; kk += 4) {
       const int kr = kk + (lane >> 4), c = lane & 15;
-      const double a0 = As[kr][wm + c], a1 = As[kr][wm + 16 + c];
-      const double b0 = Bs[kr][wn + c], b1 = Bs[kr][wn + 16 + c];
+      const double a0 = As[cur][lds_a(wm + c, kr)], a1 = As[cur][lds_a(wm + 16 + c, kr)];
+      const double b0 = Bs[cur][lds_b(wn + c, kr)], b1 = Bs[cur][lds_b(wn + 16 + c, kr)];
       acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
+    if (it + 1 < nk) stage(cur ^ 1);     // the other buffer was last read before the previous barrier
+    __syncthreads();
+    if (it + 2 < nk) fetch(kbeg + (it + 2) * GK);
   }
 #pragma unroll
   for (int fi = 0; fi < 2; ++fi)
@@ -138,15 +167,20 @@ __global__ void splitk_reduce_kernel(GenGemm g, int ksplit, const double* part) 
 
 }  // namespace
 
-int gemm_gen(dcgp_ctx* ctx, const GenGemm& g) {
-  if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return DCGP_OK;
-  if (!g.A || !g.B || !g.C || g.K < 0) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_gen: bad arguments");
-  int tiles = ((g.M + GT - 1) / GT) * ((g.N + GT - 1) / GT) * g.batch;
-  if (g.lower_only) tiles = tiles * 5 / 8 + 1;   // tiles above the diagonal exit at once
-  // split long contractions until the launch covers the chip a few times over
+template <int GT, int NT>
+static int gemm_gen_launch(dcgp_ctx* ctx, const GenGemm& g, int slots_per_round) {
+  const int nt_m = (g.M + GT - 1) / GT, nt_n = (g.N + GT - 1) / GT;
+  long tiles = (long)nt_m * nt_n * g.batch;
+  if (g.lower_only) {                 // tiles above the diagonal exit at once
+    long live = 0;
+    for (int bi = 0; bi < nt_m; ++bi) live += (bi + 1 < nt_n ? bi + 1 : nt_n);
+    tiles = live * g.batch;
+  }
+  // split long contractions so that the launch fills the chip: a whole number of rounds of co-resident workgroups
   int ksplit = 1;
-  if (g.K >= 2048 && tiles < 1536) {
-    ksplit = (1536 + tiles - 1) / tiles;
+  if (g.K >= 2048 && tiles < slots_per_round) {
+    ksplit = (int)((slots_per_round + tiles - 1) / tiles);
+    if (tiles * ksplit > slots_per_round && ksplit > 1) --ksplit;   // stay within one round rather than spill a few workgroups into a second
     const int max_split = g.K / 512;
     if (ksplit > max_split) ksplit = max_split;
     if (ksplit < 1) ksplit = 1;
@@ -160,14 +194,14 @@ int gemm_gen(dcgp_ctx* ctx, const GenGemm& g) {
     if (!part) return DCGP_ERR_ALLOC;
   }
   if ((long)g.batch * ksplit > 65535) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_gen: batch %d x split %d too large", g.batch, ksplit);
-  dim3 grid((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, g.batch * ksplit);
+  dim3 grid(nt_n, nt_m, g.batch * ksplit);
   const bool akf = g.a_cs == 1, bkf = g.b_rs == 1;
   // 16-byte loads: the contiguous stride is 1 and every other stride, the base and the k origin of a split keep 16-byte alignment
   auto even = [](long x) { return (x & 1) == 0; };
   const bool a_vec = (akf ? even(g.a_rs) : (g.a_rs == 1 && even(g.a_cs))) && even(g.a_bs) && ((uintptr_t)g.A % 16 == 0);
   const bool b_vec = (bkf ? even(g.b_cs) : (g.b_cs == 1 && even(g.b_rs))) && even(g.b_bs) && ((uintptr_t)g.B % 16 == 0);
   const bool vec = a_vec && b_vec;
-#define GG_LAUNCH(AK, BKK, V) hipLaunchKernelGGL((gemm_gen_kernel<AK, BKK, V>), grid, dim3(256), 0, ctx->stream, g, kchunk, part)
+#define GG_LAUNCH(AK, BKK, V) hipLaunchKernelGGL((gemm_gen_kernel<GT, NT, AK, BKK, V>), grid, dim3(NT), 0, ctx->stream, g, kchunk, part)
   if (akf && bkf) { if (vec) GG_LAUNCH(true, true, true); else GG_LAUNCH(true, true, false); }
   else if (akf) { if (vec) GG_LAUNCH(true, false, true); else GG_LAUNCH(true, false, false); }
   else if (bkf) { if (vec) GG_LAUNCH(false, true, true); else GG_LAUNCH(false, true, false); }
@@ -180,4 +214,12 @@ int gemm_gen(dcgp_ctx* ctx, const GenGemm& g) {
     LAUNCH_CHECK(ctx);
   }
   return DCGP_OK;
+}
+
+int gemm_gen(dcgp_ctx* ctx, const GenGemm& g) {
+  if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return DCGP_OK;
+  if (!g.A || !g.B || !g.C || g.K < 0) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_gen: bad arguments");
+  // 256 CUs; 4 co-resident 64-tile workgroups per CU (40 KB LDS each), 2 of the 128-tile ones (72 KB, 1024 threads)
+  if (g.M >= 128 && g.N >= 128 && g.K >= 4096) return gemm_gen_launch<128, 1024>(ctx, g, 512);
+  return gemm_gen_launch<64, 256>(ctx, g, 1024);
 }

@@ -698,7 +698,7 @@ int end_layer(Bk& bk, LayerState& L) {
 int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod, const double* gm, const double* gv, double* dXin) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Mp = L.Mp, P = L.v.P, Ld = L.v.L;
-  const long Kc = (long)rows * P, ld = round_up_l(Kc, 128);
+  const long Kc = (long)rows * P, ld = col_ld(Kc);
   DCGP_TRY(begin_layer(bk, L));
   // forward leftovers (conv_forward / cond_core workspaces)
   auto itB = ctx->ws.find(bk.pfx + "Kuf"), itA = ctx->ws.find(bk.pfx + "A1");
@@ -736,7 +736,7 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
 int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod, const double* gm, const double* gv, double* dXin) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Mp = L.Mp, P = L.v.P, Ld = L.v.L;
-  const long ld = round_up_l(rows, 128), Kc = (long)rows * P, ldf = round_up_l(Kc, 128);
+  const long ld = col_ld(rows), Kc = (long)rows * P, ldf = col_ld(Kc);
   if (L.in_scale) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: the dense ARD head has no backward pass yet");
   DCGP_TRY(begin_layer(bk, L));
   auto itB = ctx->ws.find(bk.pfx + "Kzx");

@@ -182,7 +182,7 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   const int Mp = L.Mp, P = L.v.P;
   const long Kc = (long)rows * P;
   if (Kc > 0x7fffff00L) return ctx_fail(ctx, DCGP_ERR_ARG, "conv layer: %ld patch columns exceed the 32-bit tile index", Kc);
-  const long ldb = round_up_l(Kc, 128);
+  const long ldb = col_ld(Kc);
   double* B = (double*)ws_get(ctx, pfx + "Kuf", (size_t)Mp * ldb * sizeof(double));
   if (!B) return DCGP_ERR_ALLOC;
   if ((phase & 1) && Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));
@@ -215,7 +215,7 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
                  double* out_var, const std::string& pfx, hipEvent_t factor_done = nullptr,
                                hipEvent_t prep_done = nullptr, int phase = 3) {
   const int Mp = L.Mp;
-  const long ldb = round_up_l(rows, 128);
+  const long ldb = col_ld(rows);
   double* B = (double*)ws_get(ctx, pfx + "Kzx", (size_t)Mp * ldb * sizeof(double));
   if (!B) return DCGP_ERR_ALLOC;
   if ((phase & 1) && Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));
