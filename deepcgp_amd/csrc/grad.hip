@@ -253,6 +253,17 @@ __global__ void col2im_kernel(const double* __restrict__ dXcol, int N, int H, in
   dX[idx] = acc;
 }
 
+// Conv2dMean adjoint (conv_gp/mean_functions.py:28-41): map 0 of patch p copied the centre pixel of channel 0, so
+// dX[n][oh s + f/2][ow s + f/2][0] += gm[(n P + p) R + 0]; distinct patches have distinct centres (no conflicts)
+__global__ void idmean_backward_kernel(const double* __restrict__ gm, long Kc, int R, int P, int Wo, int H, int W, int C, int f, int s,
+                                       double* __restrict__ dX) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Kc) return;
+  const long n = c / P;
+  const int p = (int)(c % P), oh = p / Wo, ow = p % Wo;
+  dX[((n * H + oh * s + f / 2) * W + ow * s + f / 2) * C] += gm[c * R];
+}
+
 // One thread per column c, loop over the M rows:  E[m][c] = dK[m][c / pdiv] * (w ? w[c % pdiv] * wscale : 1) * K[m][c]
 // (written over dKE when pdiv == 1, else into E), cs[c] = sum_m E, raw[c] = sum_m dK K (head: for d patch_weights),
 // per-block partials pv[block] = sum E, pl[block] = sum E d^2 with d^2 = -2 l^2 log(K / variance).
@@ -727,6 +738,11 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
     hipLaunchKernelGGL(col2im_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, dXcol, rows, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s, L.v.Ho,
                        L.v.Wo, Ld, dXin);
     LAUNCH_CHECK(ctx);
+    if (L.identity_mean) {
+      hipLaunchKernelGGL(idmean_backward_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, gm, Kc, L.R, P, L.v.Wo, L.v.H, L.v.W, L.v.C,
+                         L.v.f, L.v.s, dXin);
+      LAUNCH_CHECK(ctx);
+    }
   }
   DCGP_TRY(kl_backward(bk, L, nullptr));
   return end_layer(bk, L);
@@ -830,7 +846,6 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
   if (!m->keep_outputs) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: the forward pass must keep the layer outputs");
   for (auto& l : m->layers) {
     if (l->base_type != 0) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: only RBF base kernels have a backward pass");
-    if (l->identity_mean) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: Conv2dMean layers have no backward pass yet");
   }
   const double* gh = gauss_hermite_table(ctx);
   if (!gh) return DCGP_ERR_ALLOC;

@@ -8,7 +8,7 @@ file differentiates the oracle's forward pass (`oracle/layers.py`, `oracle/condi
 differences of `DGP_Base.compute_log_likelihood` (tests/test_oracle_cpu.py).  PARITY UNPINNED in the same
 sense as the rest of the oracle.
 
-Scope: RBF base kernels with one lengthscale, `mean_function=None`, `ConvLayer`s followed by an
+Scope: RBF base kernels with one lengthscale, `ConvLayer`s (mean function None or the fixed `Conv2dMean`) followed by an
 `SVGP_Layer` whose kernel is `ConvKernel` or `AdditivePatchKernel`; whitened or not.  Gradients are taken
 with respect to the constrained values (variance, lengthscales, Z, q_mu, q_sqrt (lower triangle),
 patch_weights); the frozen prior inducing patches `Z0` of a ConvLayer receive none.
@@ -155,8 +155,6 @@ def _patch_scatter(view, dPatches_NPL, N):
 
 def conv_layer_backward(layer, X, gmean, gvar):
     """ConvLayer.conditional_ND backward.  X [Nt, D]; gmean / gvar [Nt, P*R].  Returns dX and a dict."""
-    if layer.mean_function is not None:
-        raise NotImplementedError("gradients: mean_function must be None")
     v, kern = layer.view, layer.base_kernel
     Nt, P, R, M = X.shape[0], layer.patch_count, layer.gp_count, layer.num_inducing
     NHWC = X.reshape(Nt, v.input_size[0], v.input_size[1], layer.feature_maps_in)
@@ -178,6 +176,8 @@ def conv_layer_backward(layer, X, gmean, gvar):
     dvar += dKnn.sum()                                                      # Knn = variance for every column
     dZ2, dvar2, dls2 = _kuu_backward(kern, layer.Z, _chol_backward(L, dL))
     dX = _patch_scatter(v, np.transpose(dXc.reshape(P, Nt, -1), (1, 0, 2)), Nt).reshape(Nt, -1)
+    if layer.mean_function is not None:          # Conv2dMean (fixed filter): mean += centre pixel of channel 0 on map 0
+        dX = dX + layer.mean_function.backward(NHWC, gmean).reshape(Nt, -1)
     return dX, {"Z": dZ + dZ2, "variance": dvar + dvar2, "lengthscales": dls + dls2, "q_mu": dq_mu, "q_sqrt": dq_sqrt}
 
 

@@ -13,7 +13,11 @@ def oracle_layers(spec):
     for c in spec["convs"]:
         view = FullView((c["H"], c["W"]), c["f"], c["C"], c["s"])
         rbf = ArcCosine(view.patch_length, order=0) if c.get("base", "rbf") == "acos" else RBF(view.patch_length, c["variance"], c["ls"])
-        layer = ConvLayer(rbf, None, c["Z"], view, white=c["white"], gp_count=c["R"],
+        mean = None
+        if c.get("mean_function") == "conv2d":   # Conv2dMean, conv_gp/models.py:97-100
+            from oracle.mean_functions import Conv2dMean
+            mean = Conv2dMean(c["f"], c["C"], c["R"], c["s"])
+        layer = ConvLayer(rbf, mean, c["Z"], view, white=c["white"], gp_count=c["R"],
                           q_mu=c["q_mu"], q_sqrt=c["q_sqrt"])
         layer.Z0 = np.array(c["Z0"], np.float64)
         layers.append(layer)

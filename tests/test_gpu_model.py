@@ -350,18 +350,22 @@ def test_elbo_dense_rbf_ard_head(ctx, white):
     model.close()
 
 
-@pytest.mark.parametrize("white,additive", [(False, False), (True, False), (False, True)])
-def test_gradients_match_oracle(ctx, white, additive):
+@pytest.mark.parametrize("white,additive,idmean", [(False, False, False), (True, False, False), (False, True, False), (False, False, True)])
+def test_gradients_match_oracle(ctx, white, additive, idmean):
     """dcgp_elbo_grad (csrc/grad.hip) against oracle/grad.py -- itself pinned by finite differences on CPU -- on a
     three-layer model: every parameter group of every layer."""
     from oracle.grad import elbo_and_grad
     hwc, N, S = (14, 14, 1), 3, 2
-    spec = syn.make_spec(hwc, [(3, 1, 3), (4, 2, 2)], (3, 1), 20, S=S, num_data=500, seed=9, white=white,
+    convs = [(3, 1, 3), (3, 2, 2)] if idmean else [(3, 1, 3), (4, 2, 2)]      # Conv2dMean needs odd filters
+    spec = syn.make_spec(hwc, convs, (3, 1), 20, S=S, num_data=500, seed=9, white=white,
                          conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5)
     rng = np.random.default_rng(9)
     spec["head"]["w"] = 0.5 + rng.random(spec["head"]["w"].shape)
     if additive:
         spec["head"]["kernel"] = "add"
+    if idmean:
+        for c in spec["convs"]:
+            c["mean_function"] = "conv2d"
     X, Y = syn.make_batch(hwc, N, seed=9)
     zs = syn.make_noise(spec, N, seed=9)
     ref = oracle_model(spec, X, Y)

@@ -205,8 +205,9 @@ def test_arccosine_order0_known_answers():
     assert np.allclose(kb.K(x, z), kb.K(z, x).T)
 
 
-@pytest.mark.parametrize("white,additive", [(False, False), (False, True), (True, False), (True, True)])
-def test_hand_written_gradient_against_finite_differences(white, additive):
+@pytest.mark.parametrize("white,additive,idmean", [(False, False, False), (False, True, False), (True, False, False),
+                                                   (True, True, False), (False, False, True)])
+def test_hand_written_gradient_against_finite_differences(white, additive, idmean):
     """oracle/grad.py (the checker of the device backward pass) against central differences of the oracle ELBO
     along random directions of every parameter group; three layers so that the sample path between layers,
     overlapping-patch scatter and both head kernels are exercised."""
@@ -217,6 +218,9 @@ def test_hand_written_gradient_against_finite_differences(white, additive):
                          conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5)
     rng = np.random.default_rng(seed)
     spec["head"]["w"] = 0.5 + rng.random(spec["head"]["w"].shape)
+    if idmean:                                   # Conv2dMean on every conv layer (--identity-mean)
+        for c in spec["convs"]:
+            c["mean_function"] = "conv2d"
     X, Y = syn.make_batch(hwc, 3, seed=seed)
     zs = syn.make_noise(spec, 3, seed=seed)
     m = oracle_model(spec, X, Y)
