@@ -15,6 +15,8 @@
 //
 // All products go through gemm_gen (strided MFMA GEMM, deterministic split-k); the rest are elementwise / reduction kernels.
 // Everything is ordered on the main stream.  The oracle for this file is oracle/grad.py.
+#include <algorithm>
+
 #include "model_state.h"
 #include "gemm_gen.h"
 
@@ -264,20 +266,23 @@ __global__ void idmean_backward_kernel(const double* __restrict__ gm, long Kc, i
   dX[((n * H + oh * s + f / 2) * W + ow * s + f / 2) * C] += gm[c * R];
 }
 
-// One thread per column c, loop over the M rows:  E[m][c] = dK[m][c / pdiv] * (w ? w[c % pdiv] * wscale : 1) * K[m][c]
-// (written over dKE when pdiv == 1, else into E), cs[c] = sum_m E, raw[c] = sum_m dK K (head: for d patch_weights),
-// per-block partials pv[block] = sum E, pl[block] = sum E d^2 with d^2 = -2 l^2 log(K / variance).
+// One thread per column c and row chunk (blockIdx.y), loop over the chunk's rows:
+//   E[m][c] = dK[m][c / pdiv] * (w ? w[c % pdiv] * wscale : 1) * K[m][c]   (written over dK when pdiv == 1, else into E),
+//   csp[chunk][c] = sum_m E, rawp[chunk][c] = sum_m dK K (head: for d patch_weights), per-block partials
+//   pv = sum E, pl = sum E d^2 with d^2 = -2 l^2 log(K / variance).
 __global__ __launch_bounds__(256) void e_form_kernel(const double* __restrict__ dK, long lddk, int pdiv, const double* __restrict__ w,
                                                      double wscale, const double* __restrict__ K, long ldk, double* __restrict__ E, long lde,
-                                                     int M, long Kc, double inv_var, double two_l2, double* __restrict__ cs,
-                                                     double* __restrict__ raw, double* __restrict__ pv, double* __restrict__ pl) {
+                                                     int M, int rows_per_chunk, long Kc, double inv_var, double two_l2,
+                                                     double* __restrict__ csp, double* __restrict__ rawp, double* __restrict__ pv,
+                                                     double* __restrict__ pl) {
   __shared__ double red[256];
   const long c = (long)blockIdx.x * 256 + threadIdx.x;
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
   double sc = 0.0, sr = 0.0, sd = 0.0;
   if (c < Kc) {
     const long cd = c / pdiv;
     const double f = w ? w[c % pdiv] * wscale : 1.0;
-    for (int m = 0; m < M; ++m) {
+    for (int m = m0; m < m1; ++m) {
       const double k = K[m * ldk + c];
       const double r = dK[m * lddk + cd] * k;
       const double e = r * f;
@@ -286,21 +291,35 @@ __global__ __launch_bounds__(256) void e_form_kernel(const double* __restrict__ 
       sc += e;
       if (k > 0.0) sd -= e * two_l2 * log(k * inv_var);
     }
-    cs[c] = sc;
-    if (raw) raw[c] = sr;
+    csp[(long)blockIdx.y * Kc + c] = sc;
+    if (rawp) rawp[(long)blockIdx.y * Kc + c] = sr;
   }
   const double a = block_sum_256(sc, red), b = block_sum_256(sd, red);
-  if (threadIdx.x == 0) { pv[blockIdx.x] = a; pl[blockIdx.x] = b; }
+  if (threadIdx.x == 0) {
+    pv[(long)blockIdx.y * gridDim.x + blockIdx.x] = a;
+    pl[(long)blockIdx.y * gridDim.x + blockIdx.x] = b;
+  }
 }
 
-// out[m] = sum_c A[m][c]: one block per row
-__global__ __launch_bounds__(256) void rowsum_big_kernel(const double* __restrict__ A, long ld, long Kc, double* __restrict__ out) {
+// out[i] = sum_ch part[ch][i]
+__global__ void sum_chunks_kernel(const double* __restrict__ part, int chunks, long n, double* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int ch = 0; ch < chunks; ++ch) s += part[(long)ch * n + i];
+  out[i] = s;
+}
+
+// part[chunk][m] = sum over the chunk's columns of A[m][c]: block (m, chunk); sum_chunks_kernel finishes
+__global__ __launch_bounds__(256) void rowsum_big_kernel(const double* __restrict__ A, long ld, long Kc, long cols_per_chunk, int M,
+                                                         double* __restrict__ part) {
   __shared__ double red[256];
   const int m = blockIdx.x;
+  const long c0 = (long)blockIdx.y * cols_per_chunk, c1 = min(Kc, c0 + cols_per_chunk);
   double s = 0.0;
-  for (long c = threadIdx.x; c < Kc; c += 256) s += A[m * ld + c];
+  for (long c = c0 + threadIdx.x; c < c1; c += 256) s += A[m * ld + c];
   const double r = block_sum_256(s, red);
-  if (threadIdx.x == 0) out[m] = r;
+  if (threadIdx.x == 0) part[(long)blockIdx.y * M + m] = r;
 }
 
 // dst[i][l] (+)= alpha * (P[i][l] - v[i] * X[i][l])
@@ -464,8 +483,16 @@ int patch_backward(Bk& bk, LayerState& L, const double* E, long ld, long Kc, con
   double* rs = bk.ws("pb_rs", M);
   double* EX = bk.ws("pb_EX", (size_t)M * Ld);
   NEED(rs); NEED(EX);
-  hipLaunchKernelGGL(rowsum_big_kernel, dim3(M), dim3(256), 0, ctx->stream, E, ld, Kc, rs);
-  LAUNCH_CHECK(ctx);
+  {
+    const int chunks = (int)std::min<long>(32, (Kc + 4095) / 4096);
+    const long cpc = round_up_l((Kc + chunks - 1) / chunks, 256);
+    double* rsp = bk.ws("pb_rsp", (size_t)chunks * M);
+    NEED(rsp);
+    hipLaunchKernelGGL(rowsum_big_kernel, dim3(M, chunks), dim3(256), 0, ctx->stream, E, ld, Kc, cpc, M, rsp);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks_for(M)), dim3(256), 0, ctx->stream, rsp, chunks, (long)M, rs);
+    LAUNCH_CHECK(ctx);
+  }
   DCGP_TRY(gemm_gen(ctx, mk(E, ld, 1, Xcol, Ld, 1, EX, Ld, M, Ld, (int)Kc)));
   hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for((long)M * Ld)), dim3(256), 0, ctx->stream, EX, rs, L.Z, (long)M, Ld, inv_l2, 1, L.gZ);
   LAUNCH_CHECK(ctx);
@@ -679,14 +706,30 @@ int e_form(Bk& bk, LayerState& L, const double* dK, long lddk, int pdiv, const d
            double* E, long lde, long Kc, double* cs, double* raw) {
   dcgp_ctx* ctx = bk.ctx;
   const unsigned nb = blocks_for(Kc);
-  double* pv = bk.ws("ef_pv", nb);
-  double* pl = bk.ws("ef_pl", nb);
-  NEED(pv); NEED(pl);
-  hipLaunchKernelGGL(e_form_kernel, dim3(nb), dim3(256), 0, ctx->stream, dK, lddk, pdiv, w, wscale, K, ldk, E, lde, L.M, Kc, 1.0 / L.variance,
-                     2.0 * L.ls * L.ls, cs, raw, pv, pl);
+  // enough row chunks to put a few thousand blocks on the chip
+  int chunks = (int)std::min<long>(16, std::max<long>(1, 2048 / nb));
+  chunks = std::min(chunks, (L.M + 15) / 16);
+  const int rpc = (L.M + chunks - 1) / chunks;
+  chunks = (L.M + rpc - 1) / rpc;
+  double* pv = bk.ws("ef_pv", (size_t)nb * chunks);
+  double* pl = bk.ws("ef_pl", (size_t)nb * chunks);
+  double* csp = chunks > 1 ? bk.ws("ef_csp", (size_t)chunks * Kc) : cs;
+  double* rawp = raw ? (chunks > 1 ? bk.ws("ef_rawp", (size_t)chunks * Kc) : raw) : nullptr;
+  NEED(pv); NEED(pl); NEED(csp);
+  if (raw) NEED(rawp);
+  hipLaunchKernelGGL(e_form_kernel, dim3(nb, chunks), dim3(256), 0, ctx->stream, dK, lddk, pdiv, w, wscale, K, ldk, E, lde, L.M, rpc, Kc,
+                     1.0 / L.variance, 2.0 * L.ls * L.ls, csp, rawp, pv, pl);
   LAUNCH_CHECK(ctx);
-  DCGP_TRY(add_scalar(bk, L, false, pv, nb, 1.0 / L.variance));
-  DCGP_TRY(add_scalar(bk, L, true, pl, nb, 1.0 / (L.ls * L.ls * L.ls)));
+  if (chunks > 1) {
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, csp, chunks, Kc, cs);
+    LAUNCH_CHECK(ctx);
+    if (raw) {
+      hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, rawp, chunks, Kc, raw);
+      LAUNCH_CHECK(ctx);
+    }
+  }
+  DCGP_TRY(add_scalar(bk, L, false, pv, (long)nb * chunks, 1.0 / L.variance));
+  DCGP_TRY(add_scalar(bk, L, true, pl, (long)nb * chunks, 1.0 / (L.ls * L.ls * L.ls)));
   return DCGP_OK;
 }
 

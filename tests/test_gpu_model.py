@@ -459,3 +459,24 @@ def test_gradient_of_batch_shards_sums_to_full_batch(ctx):
             err = np.abs(tot - val).max()
             assert err < 1e-9 * max(np.abs(val).max(), 1.0), (li, name, err)
     model.close()
+
+
+def test_gradients_match_oracle_mnist_geometry(ctx):
+    """The headline geometry (28 x 28, 5 x 5 stride-2 conv layer with 10 maps, conv head) at M = 136 -- not a
+    multiple of 16 or 128 -- and 4320 patch columns: the 128 x 128 split-k products, the stacked-k launches and
+    the padded rows of the gemm_tn paths are all live."""
+    from oracle.grad import elbo_and_grad
+    hwc, N, S = (28, 28, 1), 15, 2
+    spec = syn.make_spec(hwc, [(5, 2, 10)], (5, 1), 136, S=S, num_data=60000, seed=21, conv_q_sqrt_scale=0.2)
+    X, Y = syn.make_batch(hwc, N, seed=21)
+    zs = syn.make_noise(spec, N, seed=21)
+    ref = oracle_model(spec, X, Y)
+    model = build_from_spec(spec, X, Y)
+    e, grads = model.compute_gradients(X, Y, zs=zs)
+    eo, go = elbo_and_grad(ref, X, Y, zs)
+    assert abs(e - eo) <= RTOL * abs(eo)
+    for li, (g, o) in enumerate(zip(grads, go)):
+        for name, val in o.items():
+            err = np.abs(g[name] - val).max()
+            assert err < 1e-7 * np.abs(val).max() or err < 1e-8, (li, name, err, np.abs(val).max())
+    model.close()
