@@ -346,30 +346,37 @@ __global__ __launch_bounds__(256) void strided_sum_kernel(const double* __restri
 // ConvKernel.Kdiag backward (conv_gp/kernels.py:106-115): block per (image n, patch p), thread per p'.
 // Gm[n][p][p'] = x_p . x_p' in, E[n][p][p'] = g_n w_p w_p' k_pp' / P^2 out (over Gm; the squared norms come from the
 // copy `norms`, because other blocks overwrite the diagonal they would otherwise be read from).
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// one wave per (image n, patch p): 4 rows per 256-thread block, lanes stride over p'
 __global__ __launch_bounds__(256) void kdiag_backward_kernel(double* __restrict__ Gm, const double* __restrict__ norms, const double* __restrict__ gkd,
                                                              const double* __restrict__ w, int P, double variance, double inv_l2,
                                                              double* __restrict__ dwn, double* __restrict__ pv, double* __restrict__ pl) {
-  __shared__ double red[256];
-  const int n = blockIdx.y, p = blockIdx.x;
-  double* G = Gm + (long)n * P * P;
-  const double gpp = norms[(long)n * P + p];
+  const int n = blockIdx.y, p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= P) return;
+  double* G = Gm + ((long)n * P + p) * P;
+  const double* nr = norms + (long)n * P;
+  const double gpp = nr[p], wp = w[p];
   const double coef = gkd[n] / ((double)P * P);
   double se = 0.0, sd = 0.0, sw = 0.0;
-  for (int q = threadIdx.x; q < P; q += 256) {
-    const double d2 = gpp + norms[(long)n * P + q] - 2.0 * G[(long)p * P + q];
+  for (int q = lane; q < P; q += 64) {
+    const double d2 = gpp + nr[q] - 2.0 * G[q];
     const double k = variance * exp(-0.5 * d2 * inv_l2);
-    const double e = coef * w[p] * w[q] * k;
+    const double e = coef * wp * w[q] * k;
     sw += k * w[q];
     se += e;
     sd += e * d2;
-    G[(long)p * P + q] = e;
+    G[q] = e;
   }
-  const double a = block_sum_256(se, red), b = block_sum_256(sd, red), c = block_sum_256(sw, red);
-  if (threadIdx.x == 0) {
+  se = wave_sum(se); sd = wave_sum(sd); sw = wave_sum(sw);
+  if (lane == 0) {
     const long o = (long)n * P + p;
-    pv[o] = a;          // sum E over the row (also the row sum the patch gradient needs)
-    pl[o] = b;
-    dwn[o] = 2.0 * coef * c;
+    pv[o] = se;          // sum E over the row (also the row sum the patch gradient needs)
+    pl[o] = sd;
+    dwn[o] = 2.0 * coef * sw;
   }
 }
 // AdditivePatchKernel.Kdiag = variance * mean(w):  t[0] = sum_n g_n, t[1] = mean(w)
@@ -847,7 +854,7 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
     DCGP_TRY(gemm_gen(ctx, gg));
     hipLaunchKernelGGL(kdiag_norms_kernel, dim3(blocks_for((long)rows * P)), dim3(256), 0, ctx->stream, Gm, P, (long)rows, norms);
     LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(kdiag_backward_kernel, dim3(P, rows), dim3(256), 0, ctx->stream, Gm, norms, gkd, L.w, P, L.variance, inv_l2, dwn, pv, pl);
+    hipLaunchKernelGGL(kdiag_backward_kernel, dim3((P + 3) / 4, rows), dim3(256), 0, ctx->stream, Gm, norms, gkd, L.w, P, L.variance, inv_l2, dwn, pv, pl);
     LAUNCH_CHECK(ctx);
     DCGP_TRY(add_scalar(bk, L, false, pv, (long)rows * P, 1.0 / L.variance));
     DCGP_TRY(add_scalar(bk, L, true, pl, (long)rows * P, inv_l2 / L.ls));
