@@ -190,7 +190,9 @@ static int gemm_gen_launch(dcgp_ctx* ctx, const GenGemm& g, int slots_per_round)
   if (ksplit > 1) {
     kchunk = round_up((g.K + ksplit - 1) / ksplit, GK);
     ksplit = (g.K + kchunk - 1) / kchunk;
-    part = (double*)ws_get(ctx, "gemm_gen_part", (size_t)ksplit * g.batch * g.M * g.N * sizeof(double));
+    // one partial buffer per stream: the backward pass runs two chains concurrently
+    part = (double*)ws_get(ctx, ctx->stream == ctx->stream2 ? "gemm_gen_part_side" : "gemm_gen_part",
+                           (size_t)ksplit * g.batch * g.M * g.N * sizeof(double));
     if (!part) return DCGP_ERR_ALLOC;
   }
   if ((long)g.batch * ksplit > 65535) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_gen: batch %d x split %d too large", g.batch, ksplit);

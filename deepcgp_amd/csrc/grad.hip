@@ -592,8 +592,76 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
     hipLaunchKernelGGL(restack_transpose_kernel, dim3(blocks_for(R * mm)), dim3(256), 0, ctx->stream, g.G, Mp, R, GT);
     LAUNCH_CHECK(ctx);
   }
-  // d alpha = A1 gm
-  DCGP_TRY(gemm_gen(ctx, mk(A1, ld, 1, gm, R, 1, dalpha, Rp, M, R, (int)Kc)));
+  // Two independent chains from here.  Side stream: everything that ends in an M x M result (d alpha, W_r -> dG_r ->
+  // dq_sqrt, the first two dL terms) -- long split-k contractions at ~40 % MFMA utilisation.  Main stream: dT, dA1, dK_uf
+  // on the tuned kernel.  They share only read-only inputs; the join is in front of the third dL term.
+  hipStream_t main_s = ctx->stream;
+  const bool fork = !ctx->no_side && ctx->stream2 && ctx->stream2 != main_s;
+  if (fork) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, main_s));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_aux, 0));
+    ctx->stream = ctx->stream2;
+  }
+  auto side_chain = [&]() -> int {
+    // d alpha = A1 gm
+    DCGP_TRY(gemm_gen(ctx, mk(A1, ld, 1, gm, R, 1, dalpha, Rp, M, R, (int)Kc)));
+    if (L.has_qsqrt) {
+      // dG_r = tril(A1 dT_r^T) = tril(W_r G_r),  W_r = 2 A1 diag(gv_r) A1^T (symmetric).  Both operands of the long
+      // contraction are then A1 itself (94 MB at the headline size: it stays in the 256 MB Infinity Cache across the R
+      // batches, where the R x larger dT would stream from HBM); lower tiles only, mirrored afterwards.
+      double* gvT = bk.ws("gvT", (size_t)R * Kc);
+      double* Wr = bk.ws("Wr", (size_t)R * mm);
+      NEED(gvT); NEED(Wr);
+      hipLaunchKernelGGL(transpose_small_kernel, dim3(blocks_for(Kc * R)), dim3(256), 0, ctx->stream, gv, Kc, R, gvT);
+      LAUNCH_CHECK(ctx);
+      GenGemm w = mk(A1, ld, 1, A1, 1, ld, Wr, Mp, M, M, (int)Kc);
+      w.batch = R; w.c_bs = mm; w.lower_only = 1; w.alpha = 2.0; w.kscale = gvT; w.ks_s = 1; w.ks_bs = Kc;
+      DCGP_TRY(gemm_gen(ctx, w));
+      hipLaunchKernelGGL(mirror_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Wr, (long)Mp, mm, M);
+      LAUNCH_CHECK(ctx);
+      GenGemm d = mk(Wr, Mp, 1, g.G, Mp, 1, dG, Mp, M, M, M);
+      d.batch = R; d.a_bs = mm; d.b_bs = mm; d.c_bs = mm; d.lower_only = 1;
+      DCGP_TRY(gemm_gen(ctx, d));
+    }
+    if (L.white) {
+      hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(R), M), dim3(256), 0, ctx->stream, dalpha, (long)Rp, L.gq_mu, (long)R, M, R, 1.0, 0);
+      LAUNCH_CHECK(ctx);
+      if (L.has_qsqrt) {
+        hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, dG, (long)Mp, mm, L.gq_sqrt, (long)M,
+                           (long)M * M, M, 1.0, 0);
+        LAUNCH_CHECK(ctx);
+      }
+      HIP_TRY(ctx, hipMemsetAsync(dL, 0, mm * sizeof(double), ctx->stream));
+    } else {
+      // dq_mu = inv(L)^T d alpha;  dL = -tril(dq_mu alpha^T)
+      DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dalpha, Rp, 1, L.gq_mu, R, M, R, M)));
+      GenGemm l1 = mk(L.gq_mu, R, 1, g.alpha, 1, Rp, dL, Mp, M, M, R);
+      l1.alpha = -1.0; l1.lower_only = 1;
+      DCGP_TRY(gemm_gen(ctx, l1));
+      if (L.has_qsqrt) {
+        double* Bm = bk.ws("Bm", (size_t)R * mm);                      // B_r = inv(L)^T dG_r, stored [i][r][k]
+        NEED(Bm);
+        HIP_TRY(ctx, hipMemsetAsync(Bm, 0, (size_t)R * mm * sizeof(double), ctx->stream));
+        GenGemm b = mk(g.Linv, 1, Mp, dG, Mp, 1, Bm, Rm, M, M, M);
+        b.batch = R; b.b_bs = mm; b.c_bs = Mp;
+        DCGP_TRY(gemm_gen(ctx, b));
+        hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Bm, Rm, (long)Mp, L.gq_sqrt, (long)M,
+                           (long)M * M, M, 1.0, 0);
+        LAUNCH_CHECK(ctx);
+        GenGemm l2 = mk(Bm, Rm, 1, GT, Mp, 1, dL, Mp, M, M, (int)Rm);   // dL -= tril(sum_r B_r G_r^T), stacked along k
+        l2.alpha = -1.0; l2.lower_only = 1; l2.accumulate = 1;
+        DCGP_TRY(gemm_gen(ctx, l2));
+      }
+    }
+    return DCGP_OK;
+  };
+  int rc_side = side_chain();
+  if (fork) {
+    if (rc_side == DCGP_OK && hipEventRecord(ctx->ev_aux2, ctx->stream2) != hipSuccess) rc_side = DCGP_ERR_HIP;
+    ctx->stream = main_s;
+  }
+  if (rc_side != DCGP_OK) { if (fork) hipStreamSynchronize(ctx->stream2); return rc_side; }
+  // main chain
   int dA1_acc = 0;
   if (!L.has_qsqrt && Mp > M) HIP_TRY(ctx, hipMemsetAsync(dA1 + (size_t)M * ld, 0, (size_t)(Mp - M) * ld * sizeof(double), ctx->stream));
   if (L.has_qsqrt) {
@@ -625,22 +693,6 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
       DCGP_TRY(gemm_gen(ctx, mk(GT, 1, Mp, dT, ld, 1, dA1, ld, M, (int)Kc, (int)Rm)));
     }
     dA1_acc = 1;
-    // dG_r = tril(A1 dT_r^T) = tril(W_r G_r),  W_r = 2 A1 diag(gv_r) A1^T (symmetric).  Both operands of the long
-    // contraction are then A1 itself (94 MB at the headline size: it stays in the 256 MB Infinity Cache across the R
-    // batches, where the R x larger dT would stream from HBM); lower tiles only, mirrored afterwards.
-    double* gvT = bk.ws("gvT", (size_t)R * Kc);
-    double* Wr = bk.ws("Wr", (size_t)R * mm);
-    NEED(gvT); NEED(Wr);
-    hipLaunchKernelGGL(transpose_small_kernel, dim3(blocks_for(Kc * R)), dim3(256), 0, ctx->stream, gv, Kc, R, gvT);
-    LAUNCH_CHECK(ctx);
-    GenGemm w = mk(A1, ld, 1, A1, 1, ld, Wr, Mp, M, M, (int)Kc);
-    w.batch = R; w.c_bs = mm; w.lower_only = 1; w.alpha = 2.0; w.kscale = gvT; w.ks_s = 1; w.ks_bs = Kc;
-    DCGP_TRY(gemm_gen(ctx, w));
-    hipLaunchKernelGGL(mirror_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Wr, (long)Mp, mm, M);
-    LAUNCH_CHECK(ctx);
-    GenGemm d = mk(Wr, Mp, 1, g.G, Mp, 1, dG, Mp, M, M, M);
-    d.batch = R; d.a_bs = mm; d.b_bs = mm; d.c_bs = mm; d.lower_only = 1;
-    DCGP_TRY(gemm_gen(ctx, d));
   }
   // dA1 (+)= alpha gm^T - 2 A1 o gvs
   {
@@ -650,36 +702,6 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   }
   hipLaunchKernelGGL(dA1_fix_kernel, dim3(blocks_for(Kc), M), dim3(256), 0, ctx->stream, dA1, A1, gvs, M, Kc, ld);
   LAUNCH_CHECK(ctx);
-  if (L.white) {
-    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(R), M), dim3(256), 0, ctx->stream, dalpha, (long)Rp, L.gq_mu, (long)R, M, R, 1.0, 0);
-    LAUNCH_CHECK(ctx);
-    if (L.has_qsqrt) {
-      hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, dG, (long)Mp, mm, L.gq_sqrt, (long)M,
-                         (long)M * M, M, 1.0, 0);
-      LAUNCH_CHECK(ctx);
-    }
-    HIP_TRY(ctx, hipMemsetAsync(dL, 0, mm * sizeof(double), ctx->stream));
-  } else {
-    // dq_mu = inv(L)^T d alpha;  dL = -tril(dq_mu alpha^T)
-    DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dalpha, Rp, 1, L.gq_mu, R, M, R, M)));
-    GenGemm l1 = mk(L.gq_mu, R, 1, g.alpha, 1, Rp, dL, Mp, M, M, R);
-    l1.alpha = -1.0; l1.lower_only = 1;
-    DCGP_TRY(gemm_gen(ctx, l1));
-    if (L.has_qsqrt) {
-      double* Bm = bk.ws("Bm", (size_t)R * mm);                      // B_r = inv(L)^T dG_r, stored [i][r][k]
-      NEED(Bm);
-      HIP_TRY(ctx, hipMemsetAsync(Bm, 0, (size_t)R * mm * sizeof(double), ctx->stream));
-      GenGemm b = mk(g.Linv, 1, Mp, dG, Mp, 1, Bm, Rm, M, M, M);
-      b.batch = R; b.b_bs = mm; b.c_bs = Mp;
-      DCGP_TRY(gemm_gen(ctx, b));
-      hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Bm, Rm, (long)Mp, L.gq_sqrt, (long)M,
-                         (long)M * M, M, 1.0, 0);
-      LAUNCH_CHECK(ctx);
-      GenGemm l2 = mk(Bm, Rm, 1, GT, Mp, 1, dL, Mp, M, M, (int)Rm);   // dL -= tril(sum_r B_r G_r^T), stacked along k
-      l2.alpha = -1.0; l2.lower_only = 1; l2.accumulate = 1;
-      DCGP_TRY(gemm_gen(ctx, l2));
-    }
-  }
   // dKuf = inv(L)^T dA1;  dL -= tril(dKuf A1^T)
   if ((long)Mp * ld * 8 < (1L << 31)) {   // inv(L) row-major IS the k-major operand of inv(L)^T; upper-triangular product
     GemmArgs a;
@@ -691,6 +713,7 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   } else {
     DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dA1, ld, 1, dKuf, ld, M, (int)Kc, M)));
   }
+  if (fork) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux2, 0));   // join: dL's first terms, dq_mu, dq_sqrt are done
   GenGemm l3 = mk(dKuf, ld, 1, A1, 1, ld, dL, Mp, M, M, (int)Kc);
   l3.alpha = -1.0; l3.lower_only = 1; l3.accumulate = 1;
   DCGP_TRY(gemm_gen(ctx, l3));
