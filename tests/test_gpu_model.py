@@ -480,3 +480,32 @@ def test_gradients_match_oracle_mnist_geometry(ctx):
             err = np.abs(g[name] - val).max()
             assert err < 1e-7 * np.abs(val).max() or err < 1e-8, (li, name, err, np.abs(val).max())
     model.close()
+
+
+def test_training_entry_points_fail_loudly(ctx):
+    """Error behaviour of the training-step C-ABI: no silent fallbacks."""
+    from deepcgp_amd import device as dev
+    hwc, N = (12, 12, 1), 2
+    spec = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), 8, S=2, num_data=100, seed=2, conv_q_sqrt_scale=0.3)
+    X, Y = syn.make_batch(hwc, N, seed=2)
+    model = build_from_spec(spec, X, Y)
+    with pytest.raises(dev.DcgpError):            # optimiser step before any gradient exists
+        model._build(); model.adam_step(0.01, 1)
+    model.compute_gradients(X, Y, fetch=False)
+    with pytest.raises(dev.DcgpError):            # t is 1-based
+        model.adam_step(0.01, 0)
+    with pytest.raises(dev.DcgpError):            # learning rate must be positive
+        model.adam_step(-1.0, 1)
+    L = dev.lib()
+    buf = np.zeros(3)
+    assert L.dcgp_model_get_grad(model._model, 0, b"nope", buf.ctypes.data, 3) != 0
+    assert L.dcgp_model_get_grad(model._model, 0, b"q_mu", buf.ctypes.data, 3) != 0      # wrong count
+    assert L.dcgp_model_get_grad(model._model, 0, b"w", buf.ctypes.data, 3) != 0         # conv layers have no patch weights
+    assert L.dcgp_model_get_param(model._model, 7, b"Z", buf.ctypes.data, 3) != 0        # no such layer
+    model.close()
+    # a base kernel without a reverse pass is rejected, not differentiated wrongly
+    spec2 = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), 8, S=2, num_data=100, seed=2, base_kernel="acos")
+    m2 = build_from_spec(spec2, X, Y)
+    with pytest.raises(dev.DcgpError):
+        m2.compute_gradients(X, Y)
+    m2.close()
