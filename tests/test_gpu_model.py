@@ -509,3 +509,50 @@ def test_training_entry_points_fail_loudly(ctx):
     with pytest.raises(dev.DcgpError):
         m2.compute_gradients(X, Y)
     m2.close()
+
+
+def test_gradient_properties_at_full_baseline_size(ctx):
+    """BASELINE configs[1] at full size (M = 256, batch 32, S = 10: 46080 patch columns), where the oracle is too slow to
+    be the checker: (1) the shard gradients of a 2-way batch split add up to the full-batch gradient, (2) the gradient
+    agrees with central differences of the DEVICE forward ELBO along a random direction of every parameter group."""
+    cfg = syn.CONFIGS["cfg2_mnist_CH_M256"]
+    S, N = 10, cfg["batch"]
+    spec = syn.make_spec(cfg["hwc"], cfg["convs"], cfg["head"], cfg["M"], S=S, num_data=cfg["num_data"], seed=31, conv_q_sqrt_scale=0.1)
+    X, Y = syn.make_batch(cfg["hwc"], N, seed=31)
+    zs = syn.make_noise(spec, N, seed=31)
+    model = build_from_spec(spec, X, Y)
+    scale = cfg["num_data"] / N
+    e, g = model.compute_gradients(X, Y, zs=zs, scale=scale, shards=1)
+    assert abs(e - model.compute_log_likelihood(X, Y, zs=zs, scale=scale)) <= 1e-10 * abs(e)
+    h = N // 2
+    parts = [model.compute_gradients(X[lo:hi], Y[lo:hi], zs=[z[:, lo:hi] for z in zs], scale=scale, shards=2)
+             for lo, hi in ((0, h), (h, N))]
+    for li, gl in enumerate(g):
+        for name, val in gl.items():
+            tot = parts[0][1][li][name] + parts[1][1][li][name]
+            assert np.abs(tot - val).max() <= 1e-8 * max(np.abs(val).max(), 1.0), (li, name)
+    model.compute_gradients(X, Y, zs=zs, scale=scale, shards=1, fetch=False)     # restore the 1-shard KL weight
+    rng = np.random.default_rng(0)
+    for li, l in enumerate(model.layers):
+        head = li == len(model.layers) - 1
+        kern = l.kern.base_kernel if head else l.base_kernel
+        for name in ("q_mu", "Z", "variance", "lengthscales"):
+            if name == "q_mu":
+                v0 = np.array(l.q_mu); set_ = lambda v, l=l: setattr(l, "q_mu", v)
+            elif name == "Z":
+                v0 = np.array(l.feature.Z); set_ = lambda v, l=l: setattr(l.feature, "Z", v)
+            else:
+                v0 = np.array(getattr(kern, name), np.float64); set_ = lambda v, k=kern, n=name: setattr(k, n, float(v))
+            d = rng.standard_normal(v0.shape)
+            hstep = 1e-6 * max(np.abs(v0).max(), 1.0)
+            vals = []
+            for sgn in (1.0, -1.0):
+                set_(v0 + sgn * hstep * d)
+                model.sync_parameters()
+                vals.append(model.compute_log_likelihood(X, Y, zs=zs, scale=scale))
+            set_(v0)
+            model.sync_parameters()
+            fd = (vals[0] - vals[1]) / (2 * hstep)
+            an = float(np.sum(g[li][name] * d))
+            assert abs(fd - an) <= 2e-4 * max(abs(fd), abs(an), 1.0), (li, name, fd, an)
+    model.close()
