@@ -15,5 +15,6 @@ struct GenGemm {
   const double* colscale = nullptr; long cs_s = 0, cs_bs = 0;
   const double* kscale = nullptr; long ks_s = 0, ks_bs = 0;   // B_b(k, j) is read as B_b(k, j) * kscale[b * ks_bs + k * ks_s]
   int lower_only = 0;      // entries with j > i are written as 0 (before accumulation)
+  int lower_compact = 0;   // set by the launcher: the grid enumerates the tiles on / below the diagonal only
 };
 int gemm_gen(dcgp_ctx* ctx, const GenGemm& g);

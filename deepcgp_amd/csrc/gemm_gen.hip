@@ -32,16 +32,25 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 4) void gemm_gen_kernel(GenGem
   __shared__ __attribute__((aligned(16))) double Bs[2][TILE];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int bz = blockIdx.z, b = bz % g.batch, sp = bz / g.batch;
-  const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+  // lower_only launches enumerate the tiles on and below the diagonal only (blockIdx.x = bi (bi + 1) / 2 + bj): a
+  // rectangular grid with early-exit tiles above the diagonal starves whole XCDs -- workgroups go to XCD (id mod 8),
+  // and with 2 x 2 tiles every dead workgroup has id = 1 mod 4, i.e. XCDs 1 and 5 would receive nothing else
+  int bi = blockIdx.y, bj = blockIdx.x;
+  if (g.lower_compact) {
+    bi = (int)((sqrtf(8.0f * blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+    while ((bi + 1) * (bi + 2) / 2 <= (int)blockIdx.x) ++bi;
+    while (bi * (bi + 1) / 2 > (int)blockIdx.x) --bi;
+    bj = blockIdx.x - bi * (bi + 1) / 2;
+  }
+  const int i0 = bi * GT, j0 = bj * GT;
   const bool split = part != nullptr;
   double* C = split ? part + ((long)sp * g.batch + b) * (long)g.M * g.N : g.C + (long)b * g.c_bs;
   const long c_rs = split ? g.N : g.c_rs;
-  if (g.lower_only && j0 > i0 + GT - 1) {   // tile strictly above the diagonal: nothing to compute
-    if (!split && !g.accumulate)
-      for (int e = t; e < GT * GT; e += NT) {
-        const int i = i0 + e / GT, j = j0 + e % GT;
-        if (i < g.M && j < g.N) C[(long)i * c_rs + j] = 0.0;
-      }
+  if (g.lower_only && j0 > i0 + GT - 1) {   // rectangular grid (direct store): the tile above the diagonal is defined as zero
+    for (int e = t; e < GT * GT; e += NT) {
+      const int i = i0 + e / GT, j = j0 + e % GT;
+      if (i < g.M && j < g.N) C[(long)i * c_rs + j] = 0.0;
+    }
     return;
   }
   const int kbeg = sp * kchunk, kend = min(g.K, kbeg + kchunk);
@@ -197,13 +206,19 @@ static int gemm_gen_launch(dcgp_ctx* ctx, const GenGemm& g, int slots_per_round)
   }
   if ((long)g.batch * ksplit > 65535) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_gen: batch %d x split %d too large", g.batch, ksplit);
   dim3 grid(nt_n, nt_m, g.batch * ksplit);
+  GenGemm gk = g;
+  if (g.lower_only && (part || g.accumulate)) {   // nothing has to be written above the diagonal: visit the live tiles only
+    if (g.M != g.N) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_gen: lower_only needs a square output");
+    gk.lower_compact = 1;
+    grid = dim3((unsigned)(tiles / g.batch), 1, g.batch * ksplit);
+  }
   const bool akf = g.a_cs == 1, bkf = g.b_rs == 1;
   // 16-byte loads: the contiguous stride is 1 and every other stride, the base and the k origin of a split keep 16-byte alignment
   auto even = [](long x) { return (x & 1) == 0; };
   const bool a_vec = (akf ? even(g.a_rs) : (g.a_rs == 1 && even(g.a_cs))) && even(g.a_bs) && ((uintptr_t)g.A % 16 == 0);
   const bool b_vec = (bkf ? even(g.b_cs) : (g.b_cs == 1 && even(g.b_rs))) && even(g.b_bs) && ((uintptr_t)g.B % 16 == 0);
   const bool vec = a_vec && b_vec;
-#define GG_LAUNCH(AK, BKK, V) hipLaunchKernelGGL((gemm_gen_kernel<GT, NT, AK, BKK, V>), grid, dim3(NT), 0, ctx->stream, g, kchunk, part)
+#define GG_LAUNCH(AK, BKK, V) hipLaunchKernelGGL((gemm_gen_kernel<GT, NT, AK, BKK, V>), grid, dim3(NT), 0, ctx->stream, gk, kchunk, part)
   if (akf && bkf) { if (vec) GG_LAUNCH(true, true, true); else GG_LAUNCH(true, true, false); }
   else if (akf) { if (vec) GG_LAUNCH(true, false, true); else GG_LAUNCH(true, false, false); }
   else if (bkf) { if (vec) GG_LAUNCH(false, true, true); else GG_LAUNCH(false, true, false); }
