@@ -186,7 +186,8 @@ __global__ void kl_diag_kernel(double* __restrict__ gq, const double* __restrict
 // ---- RBF Gram backward ------------------------------------------------------------------------------------------
 // One block per row i.  S = d ELBO / dK (not symmetrised).  Writes Es[i][j] = (S_ij + S_ji) k_ij (or nothing if Es is
 // null), rs[i] = sum_j Es[i][j], and the per-row partial sums pv[i] = sum_j S_ij k_ij / variance, pl[i] = sum_j S_ij k_ij d_ij^2 / l^3.
-__global__ __launch_bounds__(256) void kuu_backward_kernel(const double* __restrict__ Z, int M, int L, const double* __restrict__ S, long lds,
+__global__ __launch_bounds__(256) void kuu_backward_kernel(const double* __restrict__ Z, const double* __restrict__ ZT, int ldzt, int M, int L,
+                                                           const double* __restrict__ S, long lds,
                                                            double variance, double inv_l2, double inv_l3, double* __restrict__ Es, long lde,
                                                            double* __restrict__ rs, double* __restrict__ pv, double* __restrict__ pl) {
   __shared__ double red[256];
@@ -194,9 +195,16 @@ __global__ __launch_bounds__(256) void kuu_backward_kernel(const double* __restr
   double srow = 0.0, sv = 0.0, sl = 0.0;
   for (int j = t; j < M; j += 256) {
     double d2 = 0.0;
-    for (int l = 0; l < L; ++l) {
-      const double d = Z[(long)i * L + l] - Z[(long)j * L + l];
-      d2 += d * d;
+    if (ZT) {   // k-major copy of Z (prepare_all): neighbouring threads read neighbouring j
+      for (int l = 0; l < L; ++l) {
+        const double d = Z[(long)i * L + l] - ZT[(long)l * ldzt + j];
+        d2 += d * d;
+      }
+    } else {
+      for (int l = 0; l < L; ++l) {
+        const double d = Z[(long)i * L + l] - Z[(long)j * L + l];
+        d2 += d * d;
+      }
     }
     const double k = variance * exp(-0.5 * d2 * inv_l2);
     const double e = S[i * lds + j] * k;
@@ -466,7 +474,8 @@ int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, lon
   double* pl = bk.ws("kuu_pl", M);
   NEED(pv); NEED(pl);
   if (want_dz) { Es = bk.ws("kuu_Es", (size_t)M * M); rs = bk.ws("kuu_rs", M); NEED(Es); NEED(rs); }
-  hipLaunchKernelGGL(kuu_backward_kernel, dim3(M), dim3(256), 0, ctx->stream, Zsrc, M, Ld, S, lds, L.variance, inv_l2, inv_l3, Es, (long)M, rs, pv, pl);
+  hipLaunchKernelGGL(kuu_backward_kernel, dim3(M), dim3(256), 0, ctx->stream, Zsrc, Zsrc == L.Z ? L.ZT : nullptr, L.Mp, M, Ld, S, lds, L.variance,
+                     inv_l2, inv_l3, Es, (long)M, rs, pv, pl);
   LAUNCH_CHECK(ctx);
   DCGP_TRY(add_scalar(bk, L, false, pv, M, 1.0));
   DCGP_TRY(add_scalar(bk, L, true, pl, M, 1.0));
@@ -596,7 +605,8 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   // dq_sqrt, the first two dL terms) -- long split-k contractions at ~40 % MFMA utilisation.  Main stream: dT, dA1, dK_uf
   // on the tuned kernel.  They share only read-only inputs; the join is in front of the third dL term.
   hipStream_t main_s = ctx->stream;
-  const bool fork = !ctx->no_side && ctx->stream2 && ctx->stream2 != main_s;
+  static const bool nofork = getenv("DCGP_GRAD_NOFORK") != nullptr;   // A/B switch
+  const bool fork = !nofork && !ctx->no_side && ctx->stream2 && ctx->stream2 != main_s;
   if (fork) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, main_s));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_aux, 0));
