@@ -4,7 +4,7 @@
 // (sample, mean, var).  Per layer, given d ELBO / d(mean, var) of its outputs:
 //
 //   conditional   mean = alpha^T A1,  var = Knn - sum_m A1^2 + sum_m (G_r^T A1)^2   (the forward's re-association)
-//     dT_r = 2 (G_r^T A1) o dvar_r                      d alpha = A1 dmean          dG_r = tril(A1 dT_r^T)
+//     dT_r = 2 (G_r^T A1) o dvar_r        d alpha = A1 dmean        dG_r = tril(A1 dT_r^T) = tril(2 A1 diag(dvar_r) A1^T G_r)
 //     dA1  = alpha dmean^T - 2 A1 o sum_r dvar_r + sum_r G_r dT_r
 //     unwhitened: dq_mu = inv(L)^T d alpha, dq_sqrt_r = tril(inv(L)^T dG_r), dL -= tril(dq_mu alpha^T + sum_r (inv(L)^T dG_r) G_r^T)
 //     dKuf = inv(L)^T dA1,  dL -= tril(dKuf A1^T)
@@ -13,8 +13,11 @@
 //                 dZ = (E X - rowsum(E) o Z) / l^2,  dX = (E^T Z - colsum(E) o X) / l^2  on im2col'd patches, col2im gather
 //   KL            closed form in inv(K) (no second Cholesky adjoint), sample: dmean += dF, dvar += dF (F - mean) / (2 (var + jitter))
 //
-// All products go through gemm_gen (strided MFMA GEMM, deterministic split-k); the rest are elementwise / reduction kernels.
-// Everything is ordered on the main stream.  The oracle for this file is oracle/grad.py.
+// The R M^2 K products that fit the forward's tuned kernel run on it (gemm.hip: dT with a column-scaled store, dA1 as one
+// launch with the R blocks stacked along k, dK_uf); everything else goes through gemm_gen (strided MFMA GEMM, deterministic
+// split-k) and elementwise / reduction kernels.  Main stream = the data path; the M x M-result chain of each conditional
+// (d alpha, W_r -> dG_r -> dq_sqrt, first dL terms) runs on the side stream (cond_backward).  No atomics anywhere: the
+// gradients are reproducible run to run.  The oracle for this file is oracle/grad.py.
 #include <algorithm>
 
 #include "model_state.h"
