@@ -440,6 +440,21 @@ __global__ void adam_kernel(double* __restrict__ p, const double* __restrict__ g
   p[i] = transform == 1 ? (u > 35.0 ? u : log1p(exp(u))) + 1e-6 : u;
 }
 
+// plain gradient ascent on the ELBO in the unconstrained space (tf.train.GradientDescentOptimizer on -ELBO)
+__global__ void sgd_kernel(double* __restrict__ p, const double* __restrict__ g, long n, double lr, int transform) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double x = p[i], gr = g[i];
+  if (transform == 1) {
+    const double y = x - 1e-6;
+    double u = y > 35.0 ? y : log(expm1(y));
+    u += lr * gr * -expm1(-y);
+    p[i] = (u > 35.0 ? u : log1p(exp(u))) + 1e-6;
+  } else {
+    p[i] = x + lr * gr;
+  }
+}
+
 // ---- host helpers ------------------------------------------------------------------------------------------------
 struct Bk {   // per-backward bookkeeping
   dcgp_model* m;
@@ -1062,11 +1077,11 @@ int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta
     DCGP_TRY(L.ensure_adam());
     h[2 * li] = L.variance; h[2 * li + 1] = L.ls;
     HIP_TRY(ctx, hipMemcpyAsync(L.hyp, h + 2 * li, 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    DCGP_TRY(run(L.Z, L.gZ, L.aZ, (long)L.M * L.v.L, 0));
-    DCGP_TRY(run(L.q_mu, L.gq_mu, L.aq_mu, (long)L.M * L.R, 0));
-    if (L.has_qsqrt) DCGP_TRY(run(L.q_sqrt, L.gq_sqrt, L.aq_sqrt, (long)L.R * L.M * L.M, 0));   // upper triangle: zero gradient, zero step
-    if (L.is_head && L.w) DCGP_TRY(run(L.w, L.gw, L.aw, (long)L.v.P, 0));
-    DCGP_TRY(run(L.hyp, L.gscal, L.ahyp, 2, 1));
+    if (!(L.frozen & 1u)) DCGP_TRY(run(L.Z, L.gZ, L.aZ, (long)L.M * L.v.L, 0));
+    if (!(L.frozen & 2u)) DCGP_TRY(run(L.q_mu, L.gq_mu, L.aq_mu, (long)L.M * L.R, 0));
+    if (L.has_qsqrt && !(L.frozen & 4u)) DCGP_TRY(run(L.q_sqrt, L.gq_sqrt, L.aq_sqrt, (long)L.R * L.M * L.M, 0));   // upper triangle: zero gradient, zero step
+    if (L.is_head && L.w && !(L.frozen & 8u)) DCGP_TRY(run(L.w, L.gw, L.aw, (long)L.v.P, 0));
+    if (!(L.frozen & 16u)) DCGP_TRY(run(L.hyp, L.gscal, L.ahyp, 2, 1));
     HIP_TRY(ctx, hipMemcpyAsync(h + 2 * li, L.hyp, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1074,6 +1089,53 @@ int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta
     model->layers[li]->variance = h[2 * li];
     model->layers[li]->ls = h[2 * li + 1];
   }
+  return DCGP_OK;
+}
+
+int dcgp_model_sgd_step(dcgp_model* model, double lr) {
+  if (!model || !(lr > 0)) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "sgd_step: bad arguments") : DCGP_ERR_ARG;
+  dcgp_ctx* ctx = model->ctx;
+  auto run = [&](double* p, const double* g, long n, int transform) -> int {
+    if (n <= 0) return DCGP_OK;
+    hipLaunchKernelGGL(sgd_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, p, g, n, lr, transform);
+    LAUNCH_CHECK(ctx);
+    return DCGP_OK;
+  };
+  const int nl = (int)model->layers.size();
+  double* h = ctx->h_scratch;
+  for (int li = 0; li < nl; ++li) {
+    LayerState& L = *model->layers[li];
+    if (!L.gZ) return ctx_fail(ctx, DCGP_ERR_ARG, "sgd_step: call dcgp_elbo_grad first");
+    DCGP_TRY(L.ensure_adam());   // for the device copy of the hyper-parameters
+    h[2 * li] = L.variance; h[2 * li + 1] = L.ls;
+    HIP_TRY(ctx, hipMemcpyAsync(L.hyp, h + 2 * li, 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (!(L.frozen & 1u)) DCGP_TRY(run(L.Z, L.gZ, (long)L.M * L.v.L, 0));
+    if (!(L.frozen & 2u)) DCGP_TRY(run(L.q_mu, L.gq_mu, (long)L.M * L.R, 0));
+    if (L.has_qsqrt && !(L.frozen & 4u)) DCGP_TRY(run(L.q_sqrt, L.gq_sqrt, (long)L.R * L.M * L.M, 0));
+    if (L.is_head && L.w && !(L.frozen & 8u)) DCGP_TRY(run(L.w, L.gw, (long)L.v.P, 0));
+    if (!(L.frozen & 16u)) DCGP_TRY(run(L.hyp, L.gscal, 2, 1));
+    HIP_TRY(ctx, hipMemcpyAsync(h + 2 * li, L.hyp, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int li = 0; li < nl; ++li) {
+    model->layers[li]->variance = h[2 * li];
+    model->layers[li]->ls = h[2 * li + 1];
+  }
+  return DCGP_OK;
+}
+
+int dcgp_model_set_trainable(dcgp_model* model, int layer, const char* which, int on) {
+  if (!model || !which) return DCGP_ERR_ARG;
+  if (layer < 0 || layer >= (int)model->layers.size()) return ctx_fail(model->ctx, DCGP_ERR_ARG, "set_trainable: no layer %d", layer);
+  LayerState& L = *model->layers[layer];
+  unsigned bit = 0;
+  if (!strcmp(which, "Z")) bit = 1u;
+  else if (!strcmp(which, "q_mu")) bit = 2u;
+  else if (!strcmp(which, "q_sqrt")) bit = 4u;
+  else if (!strcmp(which, "w")) bit = 8u;
+  else if (!strcmp(which, "variance") || !strcmp(which, "lengthscale") || !strcmp(which, "hyper")) bit = 16u;
+  else return ctx_fail(model->ctx, DCGP_ERR_ARG, "set_trainable: unknown parameter '%s'", which);
+  if (on) L.frozen &= ~bit; else L.frozen |= bit;
   return DCGP_OK;
 }
 

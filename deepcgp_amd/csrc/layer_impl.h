@@ -40,6 +40,8 @@ struct LayerState {
   double *gZ = nullptr, *gq_mu = nullptr, *gq_sqrt = nullptr, *gw = nullptr, *gscal = nullptr, *gslots = nullptr;
   // Adam moments, same layouts (allocated zeroed on the first optimiser step); hyp = {variance, lengthscale} device copy
   double *aZ[2] = {}, *aq_mu[2] = {}, *aq_sqrt[2] = {}, *aw[2] = {}, *ahyp[2] = {}, *hyp = nullptr;
+  // optimiser: parameters excluded from dcgp_model_adam_step / dcgp_model_sgd_step (bit 0 Z, 1 q_mu, 2 q_sqrt, 3 w, 4 hyper-parameters)
+  unsigned frozen = 0;
   std::vector<void*> owned;
 
   ~LayerState() {

@@ -62,22 +62,57 @@ def learning_rate(lr, global_step, lr_decay_steps, decay_rate=0.1):
     return float(lr) * decay_rate ** (int(global_step) // int(lr_decay_steps))
 
 
-def train(model, steps, lr=0.01, lr_decay_steps=50000, global_step=0, seed=0, callback=None):
-    """The Adam branch of the reference's optimisation loop (conv_gp/experiment.py:84-108 + gpflow.actions.Loop
-    at :44): every step draws a minibatch, evaluates the ELBO and its gradient on the device
-    (``compute_gradients``) and applies one Adam step there.  Returns the list of ELBO values; the Python-side
-    parameter objects are refreshed at the end (``pull_parameters``)."""
+def natgrad_gamma(global_step, gamma0=0.001, steps_back=0, gamma_step=1e-3, back_step=0.2, gamma_max=1.0):
+    """The NatGrad step-size schedule of conv_gp/experiment.py:74-81."""
+    t = float(global_step) / 100.0
+    return min((t * gamma_step + gamma0) * back_step ** steps_back, gamma_max)
+
+
+def train(model, steps, lr=0.01, lr_decay_steps=50000, global_step=0, seed=0, callback=None, optimizer="Adam", gamma=0.001,
+          max_retries=5):
+    """The reference's optimisation loop (conv_gp/experiment.py:84-108 + gpflow.actions.Loop at :44).  Every step draws a
+    minibatch and evaluates the ELBO and its gradient on the device (``compute_gradients``), then
+      "Adam":    one device Adam step on every parameter;
+      "SGD":     one plain gradient step;
+      "NatGrad": a natural-gradient step on every layer's (q_mu, q_sqrt) (``DGP_Base.natgrad_step``, step size from
+                 ``natgrad_gamma``), then -- as the reference's loop does, with the variational parameters switched to
+                 non-trainable -- a fresh gradient and an Adam step on everything else.
+    Returns the list of ELBO values; the Python-side parameter objects are refreshed at the end (``pull_parameters``)."""
+    if optimizer not in ("Adam", "NatGrad", "SGD"):
+        raise ValueError("Not a supported optimizer. Try Adam or NatGrad.")     # experiment.py:109-110
     rng = np.random.default_rng(seed)
     n = model.X.shape[0]
     bs = min(model.minibatch_size or n, n)
     history = []
+    steps_back = 0
+    model._build()
+    nl = len(model.layers)
+    for li in range(nl):
+        for which in ("q_mu", "q_sqrt"):
+            model.set_trainable(li, which, optimizer != "NatGrad")
     for i in range(int(steps)):
         idx = rng.choice(n, size=bs, replace=False)
-        elbo, _ = model.compute_gradients(model.X[idx], model.Y[idx], seed=seed + global_step + i, fetch=False)
-        model.adam_step(learning_rate(lr, global_step + i, lr_decay_steps), global_step + i + 1)
+        step = global_step + i
+        elbo, _ = model.compute_gradients(model.X[idx], model.Y[idx], seed=seed + step, fetch=False)
+        if optimizer == "NatGrad":
+            # a step that leaves the positive-definite cone is retried with gamma scaled by 0.2, at most max_retries
+            # times over the run -- the InvalidArgumentError / step_back_gamma handling of experiment.py:36-49
+            while True:
+                try:
+                    model.natgrad_step(natgrad_gamma(step, gamma, steps_back))
+                    break
+                except np.linalg.LinAlgError:
+                    steps_back += 1
+                    if steps_back > max_retries:
+                        raise
+            model.compute_gradients(model.X[idx], model.Y[idx], seed=seed + step, fetch=False)
+        if optimizer == "SGD":
+            model.sgd_step(learning_rate(lr, step, lr_decay_steps))
+        else:
+            model.adam_step(learning_rate(lr, step, lr_decay_steps), step + 1)
         history.append(elbo)
         if callback is not None:
-            callback(global_step + i + 1, elbo)
+            callback(step + 1, elbo)
     model.pull_parameters()
     return history
 

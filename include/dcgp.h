@@ -208,6 +208,12 @@ int dcgp_model_grad_block(dcgp_model* model, int layer, double** block_dev, size
  * q_sqrt on its lower triangle, Z / q_mu / patch_weights as they are (gpflow.train.AdamOptimizer at
  * conv_gp/experiment.py:104-107; the learning-rate schedule :71-73 stays with the caller). */
 int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta2, double eps, int t);
+/* Plain gradient ascent in the same unconstrained space (gpflow.train.GradientDescentOptimizer, the "SGD" branch
+ * at conv_gp/experiment.py:100-103). */
+int dcgp_model_sgd_step(dcgp_model* model, double lr);
+/* param.set_trainable(False / True) (conv_gp/experiment.py:93-95, models.py:100): parameters switched off are left
+ * alone by the Adam / SGD steps.  which = "Z", "q_mu", "q_sqrt", "w", or "hyper" (variance and lengthscale). */
+int dcgp_model_set_trainable(dcgp_model* model, int layer, const char* which, int on);
 /* current (constrained) value of a parameter, names as dcgp_model_get_grad; the inverse of dcgp_model_set_param */
 int dcgp_model_get_param(dcgp_model* model, int layer, const char* which, double* out_host, size_t count);
 /* DGP_Base.propagate(X, S) -> last layer's Fmean, Fvar [S*N, R] (device buffers owned by caller) */

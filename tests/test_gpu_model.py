@@ -556,3 +556,56 @@ def test_gradient_properties_at_full_baseline_size(ctx):
             an = float(np.sum(g[li][name] * d))
             assert abs(fd - an) <= 2e-4 * max(abs(fd), abs(an), 1.0), (li, name, fd, an)
     model.close()
+
+
+def test_sgd_natgrad_and_trainable_flags(ctx):
+    """(1) One SGD step equals theta + lr * (oracle gradient) in the unconstrained space.  (2) set_trainable(False)
+    parameters are left alone by the device steps.  (3) Natural gradients: with the data term switched off (scale = 0)
+    the objective is -KL[q || prior], conjugate in q, so ONE natural-gradient step with gamma = 1 must land on the prior
+    (q_mu = 0, q_sqrt q_sqrt^T = K_uu(Z0) / K_uu(Z) / I) whatever q was -- the property that pins the step without gpflow.
+    (4) The NatGrad + Adam loop of experiment.py:90-107 runs and improves the bound."""
+    from oracle.grad import elbo_and_grad
+    from deepcgp_amd.models import train
+    hwc, N, S = (12, 12, 1), 3, 2
+    spec = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), 10, S=S, num_data=300, seed=8, conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5)
+    X, Y = syn.make_batch(hwc, N, seed=8)
+    zs = syn.make_noise(spec, N, seed=8)
+    ref = oracle_model(spec, X, Y)
+    model = build_from_spec(spec, X, Y)
+    # (1) + (2)
+    model.set_trainable(0, "Z", False)
+    model.compute_gradients(X, Y, zs=zs, fetch=False)
+    model.sgd_step(1e-3)
+    _, go = elbo_and_grad(ref, X, Y, zs)
+    Z0_before = np.array(model.layers[0].feature.Z)
+    qmu_before = [np.array(l.q_mu) for l in model.layers]
+    var_before = model.layers[0].base_kernel.variance
+    model.pull_parameters()
+    assert np.array_equal(model.layers[0].feature.Z, Z0_before)                       # frozen
+    for li, l in enumerate(model.layers):
+        assert rel(l.q_mu, qmu_before[li] + 1e-3 * go[li]["q_mu"]) < 1e-9
+    u = np.log(np.expm1(var_before - 1e-6)) + 1e-3 * go[0]["variance"] * (1.0 - np.exp(-(var_before - 1e-6)))
+    assert abs(model.layers[0].base_kernel.variance - (np.log1p(np.exp(u)) + 1e-6)) < 1e-9
+    model.set_trainable(0, "Z", True)
+    # (3)
+    model.compute_gradients(X, Y, zs=zs, scale=0.0, fetch=False)
+    model.natgrad_step(1.0)
+    for li, l in enumerate(model.layers):
+        o = ref.layers[li]
+        head = li == len(model.layers) - 1
+        K = (o.kern.base_kernel.K(l.feature.Z) if head else o.base_kernel.K(np.asarray(spec["convs"][li]["Z0"]))) + 1e-3 * np.eye(l.num_inducing)
+        # hyper-parameters moved in step (1): evaluate the prior with the model's current values
+        kern = l.kern.base_kernel if head else l.base_kernel
+        Zp = l.feature.Z if head else np.asarray(spec["convs"][li]["Z0"])
+        d2 = ((Zp[:, None, :] - Zp[None, :, :]) ** 2).sum(-1)
+        K = kern.variance * np.exp(-0.5 * d2 / kern.lengthscales ** 2) + 1e-3 * np.eye(l.num_inducing)
+        assert np.abs(l.q_mu).max() < 1e-6
+        for r in range(l.q_sqrt.shape[0]):
+            assert rel(l.q_sqrt[r] @ l.q_sqrt[r].T, K) < 1e-6
+    # (4)
+    model.minibatch_size = N
+    hist = train(model, 15, lr=0.01, optimizer="NatGrad", gamma=0.05, seed=3)
+    assert len(hist) == 15 and np.mean(hist[-4:]) > np.mean(hist[:4])
+    with pytest.raises(ValueError):
+        train(model, 1, optimizer="LBFGS")
+    model.close()
