@@ -222,7 +222,8 @@ def test_full_size_cfg2_vs_oracle(ctx):
 
 def test_rccl_single_rank_allreduce_path(ctx):
     """The N>1 code path on one GPU: a 1-rank RCCL communicator, the in-stream all-reduce inside
-    dcgp_elbo_forward and the explicit dcgp_allreduce_sum_f64 entry point."""
+    dcgp_elbo_forward, the per-layer gradient all-reduce inside dcgp_elbo_grad and the explicit
+    dcgp_allreduce_sum_f64 entry point."""
     from deepcgp_amd import device as dev
     hwc = (12, 12, 1)
     spec = syn.make_spec(hwc, [(3, 2, 4)], (3, 1), M=10, S=2, num_data=500, seed=5, conv_q_sqrt_scale=0.3)
@@ -230,9 +231,16 @@ def test_rccl_single_rank_allreduce_path(ctx):
     zs = syn.make_noise(spec, 4, seed=5)
     model = build_from_spec(spec, X, Y)
     e0 = model.compute_log_likelihood(X, Y, zs=zs)
+    _, g0 = model.compute_gradients(X, Y, zs=zs)
     ctx.comm_init(1, 0, dev.comm_unique_id())
     try:
         assert model.compute_log_likelihood(X, Y, zs=zs) == e0
+        # training step: one in-stream all-reduce per layer over its contiguous gradient block (identity with one rank)
+        e1, g1 = model.compute_gradients(X, Y, zs=zs)
+        assert e1 == e0
+        for a, b in zip(g0, g1):
+            for name in a:
+                np.testing.assert_array_equal(a[name], b[name])
         buf = ctx.to_device(np.array([1.5, -2.0, 3.25]))
         ctx.allreduce_sum(buf)
         np.testing.assert_array_equal(buf.numpy(), [1.5, -2.0, 3.25])
