@@ -418,6 +418,42 @@ __global__ void scal_finish_kernel(const double* __restrict__ slots, double* __r
   gscal[1] = b;
 }
 
+// ---- dense RBF(ARD) head (--last-kernel rbf) --------------------------------------------------------------------------
+// out[i][d] = in[(i % n_mod)][d] * s[d]
+__global__ void scale_rows_kernel(const double* __restrict__ in, int n_mod, long rows, int D, const double* __restrict__ s, double* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * D) return;
+  const long i = idx / D;
+  const int d = (int)(idx % D);
+  out[idx] = in[(i % n_mod) * D + d] * s[d];
+}
+// chain rule back through x / l, z / l: gZ = dZs o s, dX = dXs o s (if wanted), and one block per input dimension d:
+// gard[d] = -s_d (sum_m dZs[m][d] Zs[m][d] + sum_n dXs[n][d] Xs[n][d])
+__global__ __launch_bounds__(256) void ard_finish_kernel(const double* __restrict__ dZs, const double* __restrict__ Zs, int M, const double* __restrict__ dXs,
+                                                         const double* __restrict__ Xs, long N, int D, const double* __restrict__ s,
+                                                         double* __restrict__ gZ, double* __restrict__ dX, double* __restrict__ gard) {
+  __shared__ double red[256];
+  const int d = blockIdx.x, t = threadIdx.x;
+  const double sd = s[d];
+  double acc = 0.0;
+  for (int m = t; m < M; m += 256) {
+    const double g = dZs[(long)m * D + d];
+    acc += g * Zs[(long)m * D + d];
+    gZ[(long)m * D + d] = g * sd;
+  }
+  for (long n = t; n < N; n += 256) {
+    const double g = dXs[n * D + d];
+    acc += g * Xs[n * D + d];
+    if (dX) dX[n * D + d] = g * sd;
+  }
+  const double r = block_sum_256(acc, red);
+  if (t == 0) gard[d] = -sd * r;
+}
+__global__ void reciprocal_kernel(const double* __restrict__ in, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = 1.0 / in[i];
+}
+
 // ---- optimiser ---------------------------------------------------------------------------------------------------
 // tf.train.AdamOptimizer on gpflow's unconstrained variables, ascending the ELBO.  transform 0: identity;
 // 1: gpflow transforms.positive (x = softplus(u) + 1e-6): the parameter is held constrained, moved through u.
@@ -483,7 +519,7 @@ int add_scalar(Bk& bk, LayerState& L, bool lengthscale, const double* part, long
 }
 
 // RBF Gram backward from S = d ELBO / dK (unsymmetrised).  dZ accumulates into L.gZ when Zsrc is the live Z (want_dz).
-int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, long lds, bool want_dz) {
+int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, long lds, bool want_dz, double* dz_out = nullptr) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Ld = L.v.L;
   const double inv_l2 = 1.0 / (L.ls * L.ls), inv_l3 = inv_l2 / L.ls;
@@ -501,7 +537,8 @@ int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, lon
     double* EX = bk.ws("kuu_EX", (size_t)M * Ld);
     NEED(EX);
     DCGP_TRY(gemm_gen(ctx, mk(Es, M, 1, Zsrc, Ld, 1, EX, Ld, M, Ld, M)));
-    hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for((long)M * Ld)), dim3(256), 0, ctx->stream, EX, rs, Zsrc, (long)M, Ld, inv_l2, 1, L.gZ);
+    hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for((long)M * Ld)), dim3(256), 0, ctx->stream, EX, rs, Zsrc, (long)M, Ld, inv_l2, 1,
+                       dz_out ? dz_out : L.gZ);
     LAUNCH_CHECK(ctx);
   }
   return DCGP_OK;
@@ -510,7 +547,7 @@ int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, lon
 // Patch-kernel backward: E [M x Kc] (ld) = d ELBO / dKfull o Kfull is ready, cs = its column sums.
 // dZ += (E Xcol - rowsum(E) o Z) / l^2;  dXcol (=|+=) (E^T Z - cs o Xcol) / l^2 when requested.
 int patch_backward(Bk& bk, LayerState& L, const double* E, long ld, long Kc, const double* cs, const double* Xcol, double* dXcol,
-                   int dx_accumulate) {
+                   int dx_accumulate, const double* Zuse = nullptr, double* dz_out = nullptr) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Ld = L.v.L;
   const double inv_l2 = 1.0 / (L.ls * L.ls);
@@ -528,12 +565,14 @@ int patch_backward(Bk& bk, LayerState& L, const double* E, long ld, long Kc, con
     LAUNCH_CHECK(ctx);
   }
   DCGP_TRY(gemm_gen(ctx, mk(E, ld, 1, Xcol, Ld, 1, EX, Ld, M, Ld, (int)Kc)));
-  hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for((long)M * Ld)), dim3(256), 0, ctx->stream, EX, rs, L.Z, (long)M, Ld, inv_l2, 1, L.gZ);
+  const double* Zp = Zuse ? Zuse : L.Z;
+  hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for((long)M * Ld)), dim3(256), 0, ctx->stream, EX, rs, Zp, (long)M, Ld, inv_l2, 1,
+                     dz_out ? dz_out : L.gZ);
   LAUNCH_CHECK(ctx);
   if (dXcol) {
     double* EtZ = bk.ws("pb_EtZ", (size_t)Kc * Ld);
     NEED(EtZ);
-    DCGP_TRY(gemm_gen(ctx, mk(E, 1, ld, L.Z, Ld, 1, EtZ, Ld, (int)Kc, Ld, M)));
+    DCGP_TRY(gemm_gen(ctx, mk(E, 1, ld, Zp, Ld, 1, EtZ, Ld, (int)Kc, Ld, M)));
     hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for(Kc * Ld)), dim3(256), 0, ctx->stream, EtZ, cs, Xcol, Kc, Ld, inv_l2, dx_accumulate, dXcol);
     LAUNCH_CHECK(ctx);
   }
@@ -796,7 +835,7 @@ int begin_layer(Bk& bk, LayerState& L) {
   bk.slot_v = bk.slot_l = 0;
   HIP_TRY(bk.ctx, hipMemsetAsync(L.gslots, 0, 32 * sizeof(double), bk.ctx->stream));
   HIP_TRY(bk.ctx, hipMemsetAsync(L.gZ, 0, (size_t)L.M * L.v.L * sizeof(double), bk.ctx->stream));
-  HIP_TRY(bk.ctx, hipMemsetAsync(L.gw, 0, (size_t)L.v.P * sizeof(double), bk.ctx->stream));
+  HIP_TRY(bk.ctx, hipMemsetAsync(L.gw, 0, ((size_t)L.v.P + 2 + (L.is_head ? (size_t)L.v.L : 0)) * sizeof(double), bk.ctx->stream));   // gw, gscal, gard
   if (!L.has_qsqrt) HIP_TRY(bk.ctx, hipMemsetAsync(L.gq_sqrt, 0, (size_t)L.R * L.M * L.M * sizeof(double), bk.ctx->stream));
   return DCGP_OK;
 }
@@ -849,12 +888,55 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   return end_layer(bk, L);
 }
 
+// Dense head backward: gpflow RBF(D, ARD=True) on the flattened features (--last-kernel rbf, conv_gp/models.py:160-168).
+// The forward divides x and Z by the lengthscales while staging (in_scale) and runs the unit-lengthscale kernel
+// (L.ls == 1), so every kernel adjoint below is the generic one on the scaled copies Xs = X o s, Zs = Z o s; the chain
+// rule back through the scaling gives dZ, dX and the per-dimension lengthscale gradient (ard_finish_kernel).
+int dense_head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod, const double* gm, const double* gv, double* dXin) {
+  dcgp_ctx* ctx = bk.ctx;
+  const int M = L.M, Mp = L.Mp, D = L.v.L;
+  const long ld = col_ld(rows);
+  if (L.v.P != 1 || L.kernel_type != 0) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: ARD lengthscales need the single-patch head");
+  DCGP_TRY(begin_layer(bk, L));
+  auto itB = ctx->ws.find(bk.pfx + "Kzx");
+  if (itB == ctx->ws.end()) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: the forward pass left no K_zx for the head");
+  const double* Kzx = (const double*)itB->second.first;
+  double* A1 = bk.ws("A1h", (size_t)Mp * ld);
+  double* dKzx = bk.ws("dKzx", (size_t)Mp * ld);
+  double* S = bk.ws("S", (size_t)Mp * Mp);
+  double* gkd = bk.ws("gkd", rows);
+  double* cs = bk.ws("cs", rows);
+  double* Zs = bk.ws("Zs", (size_t)M * D);
+  double* Xs = bk.ws("Xs", (size_t)rows * D);
+  double* dZs = bk.ws("dZs", (size_t)M * D);
+  double* dXs = bk.ws("dXs", (size_t)rows * D);
+  NEED(A1); NEED(dKzx); NEED(S); NEED(gkd); NEED(cs); NEED(Zs); NEED(Xs); NEED(dZs); NEED(dXs);
+  DCGP_TRY(gemm_gen(ctx, mk(L.g.Linv, Mp, 1, Kzx, ld, 1, A1, ld, M, rows, M)));
+  DCGP_TRY(cond_backward(bk, L, A1, ld, rows, gm, gv, dKzx, S, gkd));
+  DCGP_TRY(kl_backward(bk, L, L.white ? nullptr : S));
+  DCGP_TRY(add_scalar(bk, L, false, gkd, rows, 1.0));             // Kdiag = variance
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks_for((long)M * D)), dim3(256), 0, ctx->stream, L.Z, M, (long)M, D, L.in_scale, Zs);
+  LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks_for((long)rows * D)), dim3(256), 0, ctx->stream, Xin, n_mod, (long)rows, D, L.in_scale, Xs);
+  LAUNCH_CHECK(ctx);
+  HIP_TRY(ctx, hipMemsetAsync(dZs, 0, (size_t)M * D * sizeof(double), ctx->stream));
+  DCGP_TRY(kuu_backward(bk, L, Zs, S, Mp, true, dZs));
+  DCGP_TRY(e_form(bk, L, dKzx, ld, 1, nullptr, 1.0, Kzx, ld, dKzx, ld, rows, cs, nullptr));   // E over dKzx (P == 1: K_zx is the full response)
+  DCGP_TRY(patch_backward(bk, L, dKzx, ld, rows, cs, Xs, dXs, 0, Zs, dZs));
+  hipLaunchKernelGGL(ard_finish_kernel, dim3(D), dim3(256), 0, ctx->stream, dZs, Zs, M, dXs, Xs, (long)rows, D, L.in_scale, L.gZ, dXin, L.gard);
+  LAUNCH_CHECK(ctx);
+  DCGP_TRY(end_layer(bk, L));
+  // the scalar "lengthscale" slot collected d / d(unit lengthscale): meaningless here, and L.ls must stay 1
+  HIP_TRY(ctx, hipMemsetAsync(L.gscal + 1, 0, sizeof(double), ctx->stream));
+  return DCGP_OK;
+}
+
 // SVGP head backward (ConvKernel / AdditivePatchKernel, conv_gp/kernels.py:15-136).  gm / gv [rows][R].
 int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod, const double* gm, const double* gv, double* dXin) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Mp = L.Mp, P = L.v.P, Ld = L.v.L;
   const long ld = col_ld(rows), Kc = (long)rows * P, ldf = col_ld(Kc);
-  if (L.in_scale) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: the dense ARD head has no backward pass yet");
+  if (L.in_scale) return dense_head_backward(bk, L, Xin, rows, n_mod, gm, gv, dXin);
   DCGP_TRY(begin_layer(bk, L));
   auto itB = ctx->ws.find(bk.pfx + "Kzx");
   if (itB == ctx->ws.end()) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: the forward pass left no K_zx for the head");
@@ -1031,6 +1113,9 @@ int dcgp_model_get_grad(dcgp_model* model, int layer, const char* which, double*
   else if (!strcmp(which, "w")) {
     if (!L.is_head) return ctx_fail(ctx, DCGP_ERR_ARG, "get_grad: only the head has patch weights");
     src = L.gw; n = (size_t)L.v.P;
+  } else if (!strcmp(which, "ard_lengthscales")) {
+    if (!L.ard || !L.gard) return ctx_fail(ctx, DCGP_ERR_ARG, "get_grad: this layer has no ARD lengthscales");
+    src = L.gard; n = (size_t)L.v.L;
   } else return ctx_fail(ctx, DCGP_ERR_ARG, "get_grad: unknown parameter '%s'", which);
   if (count != n) return ctx_fail(ctx, DCGP_ERR_ARG, "get_grad(%s): expected %zu values, got %zu", which, n, count);
   HIP_TRY(ctx, hipMemcpyAsync(out_host, src, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1082,6 +1167,11 @@ int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta
     if (L.has_qsqrt && !(L.frozen & 4u)) DCGP_TRY(run(L.q_sqrt, L.gq_sqrt, L.aq_sqrt, (long)L.R * L.M * L.M, 0));   // upper triangle: zero gradient, zero step
     if (L.is_head && L.w && !(L.frozen & 8u)) DCGP_TRY(run(L.w, L.gw, L.aw, (long)L.v.P, 0));
     if (!(L.frozen & 16u)) DCGP_TRY(run(L.hyp, L.gscal, L.ahyp, 2, 1));
+    if (L.ard && !(L.frozen & 16u)) {   // dense head: per-dimension lengthscales, then refresh the staging scale 1 / l
+      DCGP_TRY(run(L.ard, L.gard, L.aard, (long)L.v.L, 1));
+      hipLaunchKernelGGL(reciprocal_kernel, dim3(blocks_for(L.v.L)), dim3(256), 0, ctx->stream, L.ard, L.v.L, L.in_scale);
+      LAUNCH_CHECK(ctx);
+    }
     HIP_TRY(ctx, hipMemcpyAsync(h + 2 * li, L.hyp, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1114,6 +1204,11 @@ int dcgp_model_sgd_step(dcgp_model* model, double lr) {
     if (L.has_qsqrt && !(L.frozen & 4u)) DCGP_TRY(run(L.q_sqrt, L.gq_sqrt, (long)L.R * L.M * L.M, 0));
     if (L.is_head && L.w && !(L.frozen & 8u)) DCGP_TRY(run(L.w, L.gw, (long)L.v.P, 0));
     if (!(L.frozen & 16u)) DCGP_TRY(run(L.hyp, L.gscal, 2, 1));
+    if (L.ard && !(L.frozen & 16u)) {
+      DCGP_TRY(run(L.ard, L.gard, (long)L.v.L, 1));
+      hipLaunchKernelGGL(reciprocal_kernel, dim3(blocks_for(L.v.L)), dim3(256), 0, ctx->stream, L.ard, L.v.L, L.in_scale);
+      LAUNCH_CHECK(ctx);
+    }
     HIP_TRY(ctx, hipMemcpyAsync(h + 2 * li, L.hyp, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1157,6 +1252,9 @@ int dcgp_model_get_param(dcgp_model* model, int layer, const char* which, double
   else if (!strcmp(which, "w")) {
     if (!L.w) return ctx_fail(ctx, DCGP_ERR_ARG, "get_param: only the head has patch weights");
     src = L.w; n = (size_t)L.v.P;
+  } else if (!strcmp(which, "ard_lengthscales")) {
+    if (!L.ard) return ctx_fail(ctx, DCGP_ERR_ARG, "get_param: this layer has no ARD lengthscales");
+    src = L.ard; n = (size_t)L.v.L;
   } else return ctx_fail(ctx, DCGP_ERR_ARG, "get_param: unknown parameter '%s'", which);
   if (count != n) return ctx_fail(ctx, DCGP_ERR_ARG, "get_param(%s): expected %zu values, got %zu", which, n, count);
   HIP_TRY(ctx, hipMemcpyAsync(out_host, src, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -32,6 +32,8 @@ struct LayerState {
   // parameters in the caller's layout (device)
   double *Z = nullptr, *Z0 = nullptr, *q_mu = nullptr, *q_sqrt = nullptr, *w = nullptr;
   double* in_scale = nullptr;   // [L] 1 / ARD lengthscale per input dimension, or nullptr (set_param "ard_lengthscales"; single-patch head only)
+  double* ard = nullptr;        // [L] the ARD lengthscales themselves (optimiser state; in_scale is refreshed from it)
+  double *gard = nullptr, *aard[2] = {};   // their gradient (inside the gradient block) and Adam moments
   // derived every step
   GpMats g;
   double *ZT = nullptr, *zn = nullptr;
@@ -83,13 +85,14 @@ struct LayerState {
     return DCGP_OK;
   }
   // one contiguous block per layer [gZ | gq_mu | gq_sqrt | gw | gscal] so that a single all-reduce covers the layer
-  size_t grad_block_count() const { return (size_t)M * v.L + (size_t)M * R + (size_t)R * M * M + (size_t)v.P + 2; }
+  size_t grad_block_count() const { return (size_t)M * v.L + (size_t)M * R + (size_t)R * M * M + (size_t)v.P + 2 + (is_head ? (size_t)v.L : 0); }
   int ensure_grads() {
     if (gZ) return DCGP_OK;
     double* blk = dalloc(grad_block_count());
     gslots = dalloc(32);
     if (!blk || !gslots) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: gradient allocation failed");
     gZ = blk; gq_mu = gZ + (size_t)M * v.L; gq_sqrt = gq_mu + (size_t)M * R; gw = gq_sqrt + (size_t)R * M * M; gscal = gw + v.P;
+    gard = is_head ? gscal + 2 : nullptr;   // [L] d / d ARD lengthscales (dense head), zero otherwise
     return DCGP_OK;
   }
   int ensure_adam() {
@@ -106,6 +109,11 @@ struct LayerState {
     }
     hyp = dalloc(2);
     if (!hyp) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: optimiser state allocation failed");
+    if (ard)
+      for (int k = 0; k < 2; ++k) {
+        if (!(aard[k] = dalloc(v.L))) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: optimiser state allocation failed");
+        HIP_TRY(ctx, hipMemsetAsync(aard[k], 0, (size_t)v.L * sizeof(double), ctx->stream));
+      }
     return DCGP_OK;
   }
   int upload(double* dst, const double* src_host, size_t n) {

@@ -317,7 +317,9 @@ int dcgp_model_set_param(dcgp_model* model, int layer, const char* which, const 
       inv[i] = 1.0 / value_host[i];
     }
     if (!L.in_scale && !(L.in_scale = L.dalloc(count))) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: device allocation failed");
+    if (!L.ard && !(L.ard = L.dalloc(count))) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: device allocation failed");
     L.ls = 1.0;
+    DCGP_TRY(L.upload(L.ard, value_host, count));
     return L.upload(L.in_scale, inv.data(), count);
   }
   if (!strcmp(which, "base_kernel")) {   // {type, variance, p1, p2}: 0 = RBF (p1 = lengthscale), 1 = ArcCosine order 0 (p1 = weight, p2 = bias variance)

@@ -201,11 +201,14 @@ class DGP_Base:
             shapes = {"Z": (M, np.shape(l.feature.Z)[1]), "q_mu": (M, R), "q_sqrt": (R, M, M), "variance": (), "lengthscale": ()}
             if head and hasattr(l.kern, "patch_weights"):
                 shapes["w"] = (np.size(l.kern.patch_weights),)
+            if head and getattr(l.kern, "ARD", False):       # dense RBF(ARD) head: one lengthscale per input dimension
+                del shapes["lengthscale"]
+                shapes["ard_lengthscales"] = (np.size(l.kern.lengthscales),)
             g = {}
             for which, shp in shapes.items():
                 buf = np.empty(shp, np.float64)
                 ctx._check(L.dcgp_model_get_grad(self._model, li, which.encode(), buf.ctypes.data, buf.size))
-                g[{"lengthscale": "lengthscales", "w": "patch_weights"}.get(which, which)] = buf
+                g[{"lengthscale": "lengthscales", "ard_lengthscales": "lengthscales", "w": "patch_weights"}.get(which, which)] = buf
             grads.append(g)
         return out[0], grads
 
@@ -289,7 +292,9 @@ class DGP_Base:
             l.q_mu = pull(li, "q_mu", np.shape(l.q_mu))
             l.q_sqrt = pull(li, "q_sqrt", np.shape(l.q_sqrt))
             kern.variance = float(pull(li, "variance", ()))
-            if not getattr(kern, "ARD", False) and hasattr(kern, "lengthscales"):
+            if getattr(kern, "ARD", False):
+                kern.lengthscales = pull(li, "ard_lengthscales", (np.size(kern.lengthscales),))
+            elif hasattr(kern, "lengthscales"):
                 kern.lengthscales = float(pull(li, "lengthscale", ()))
             if head and hasattr(l.kern, "patch_weights"):
                 l.kern.patch_weights = pull(li, "w", np.shape(l.kern.patch_weights))

@@ -9,7 +9,8 @@ differences of `DGP_Base.compute_log_likelihood` (tests/test_oracle_cpu.py).  PA
 sense as the rest of the oracle.
 
 Scope: RBF base kernels with one lengthscale, `ConvLayer`s (mean function None or the fixed `Conv2dMean`) followed by an
-`SVGP_Layer` whose kernel is `ConvKernel` or `AdditivePatchKernel`; whitened or not.  Gradients are taken
+`SVGP_Layer` whose kernel is `ConvKernel`, `AdditivePatchKernel` or the dense `RBF(ARD=True)` of `--last-kernel rbf`;
+whitened or not.  Gradients are taken
 with respect to the constrained values (variance, lengthscales, Z, q_mu, q_sqrt (lower triangle),
 patch_weights); the frozen prior inducing patches `Z0` of a ConvLayer receive none.
 """
@@ -239,6 +240,67 @@ def head_backward(layer, X, gmean, gvar):
                 "q_sqrt": dq_sqrt, "patch_weights": dw}
 
 
+class _UnitRBF:
+    """view of an ARD RBF kernel on inputs already divided by the lengthscales"""
+    def __init__(self, variance):
+        self.variance, self.lengthscales = variance, 1.0
+
+
+def dense_head_backward(layer, X, gmean, gvar):
+    """SVGP_Layer.conditional_ND backward with gpflow RBF(D, ARD=True) on the flattened features (the dense head of
+    --last-kernel rbf, conv_gp/models.py:160-168).  X [Nt, D]; gmean / gvar [Nt, R].  ``lengthscales`` gets a [D] gradient."""
+    if layer.mean_function is not None:
+        raise NotImplementedError("gradients: mean_function must be None")
+    kern = layer.kern
+    ls = np.asarray(kern.lengthscales, np.float64)
+    unit = _UnitRBF(kern.variance)
+    M, R = layer.num_inducing, layer.num_outputs
+    Zs, Xs = layer.Z / ls, np.asarray(X, np.float64) / ls
+    Kzx, d2 = _rbf(unit, Zs, Xs)
+    Ku = _rbf(unit, Zs, Zs)[0] + np.eye(M) * JITTER
+    L = np.linalg.cholesky(Ku)
+    A1 = solve_triangular(L, Kzx, lower=True)
+    Lq = layer.q_sqrt
+    if layer.white:
+        alpha, G = layer.q_mu, Lq
+    else:
+        alpha = solve_triangular(L, layer.q_mu, lower=True)
+        G = np.stack([solve_triangular(L, Lq[r], lower=True) for r in range(R)])
+    dKzx, dL, dq_mu, dq_sqrt, dkd = _cond_backward(L, A1, alpha, G, gmean, gvar, layer.white, layer.q_mu, Lq)
+    dZs, dXs, dvar, _ = _rbf_cross_backward(unit, Zs, Xs, Kzx, d2, dKzx)
+    dvar += dkd.sum()                                            # Kdiag = variance
+    S = _chol_backward(L, dL)
+    kl = {}
+    if layer.white:
+        d = np.tril(Lq)
+        for r in range(R):
+            d[r] -= np.diag(1.0 / np.diag(Lq[r]))
+        kl = {"q_mu": layer.q_mu.copy(), "q_sqrt": d}
+    else:
+        Kinv_mu = _lsolve_T(L, solve_triangular(L, layer.q_mu, lower=True))
+        Kinv = _lsolve_T(L, solve_triangular(L, np.eye(M), lower=True))
+        dK = 0.5 * (R * Kinv - Kinv_mu @ Kinv_mu.T)
+        dLq = np.zeros_like(Lq)
+        for r in range(R):
+            KiL = _lsolve_T(L, solve_triangular(L, Lq[r], lower=True))
+            dLq[r] = np.tril(KiL) - np.diag(1.0 / np.diag(Lq[r]))
+            dK -= 0.5 * KiL @ KiL.T
+        kl = {"q_mu": Kinv_mu, "q_sqrt": dLq, "dK": dK}
+    return dKzx, (dZs, dXs, dvar, S, dq_mu, dq_sqrt, kl, Zs, Xs, ls, unit)
+
+
+def dense_head_finish(parts, kl_weight):
+    dZs, dXs, dvar, S, dq_mu, dq_sqrt, kl, Zs, Xs, ls, unit = parts
+    if "dK" in kl:
+        S = S - kl_weight * kl["dK"]
+    dZs2, dvar2, _ = _kuu_backward(unit, Zs, S)
+    dZs = dZs + dZs2
+    g = {"Z": dZs / ls, "variance": dvar + dvar2,
+         "lengthscales": -(np.sum(dZs * Zs, 0) + np.sum(dXs * Xs, 0)) / ls,
+         "q_mu": dq_mu - kl_weight * kl["q_mu"], "q_sqrt": dq_sqrt - kl_weight * kl["q_sqrt"]}
+    return dXs / ls, g
+
+
 def head_kl_backward(layer):
     """SVGP_Layer.KL backward (live Z in the prior)."""
     Lq = layer.q_sqrt
@@ -290,7 +352,11 @@ def elbo_and_grad(model, X, Y, zs, scale=None, kl_weight=1.0):
     for li in range(nl - 1, -1, -1):
         layer = model.layers[li]
         Xin = inputs[li].reshape(S * N, -1)
-        if li == nl - 1:
+        if li == nl - 1 and not hasattr(layer.kern, "base_kernel"):      # dense RBF(ARD) head
+            _, parts = dense_head_backward(layer, Xin, gm, gv)
+            dX, g = dense_head_finish(parts, kl_weight)
+            kl = {}
+        elif li == nl - 1:
             dX, g = head_backward(layer, Xin, gm, gv)
             kl = head_kl_backward(layer)
         else:

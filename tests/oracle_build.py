@@ -42,13 +42,13 @@ def oracle_param_handles(model):
     out, nl = [], len(model.layers)
     for li, l in enumerate(model.layers):
         head = li == nl - 1
-        kern = l.kern.base_kernel if head else l.base_kernel
+        kern = (l.kern.base_kernel if hasattr(l.kern, "base_kernel") else l.kern) if head else l.base_kernel
         out.append((li, "Z", lambda l=l: l.Z, lambda v, l=l: setattr(l, "Z", v)))
         out.append((li, "q_mu", lambda l=l: l.q_mu, lambda v, l=l: setattr(l, "q_mu", v)))
         out.append((li, "q_sqrt", lambda l=l: l.q_sqrt, lambda v, l=l: setattr(l, "q_sqrt", v)))
         out.append((li, "variance", lambda k=kern: np.array(k.variance), lambda v, k=kern: setattr(k, "variance", float(v))))
         out.append((li, "lengthscales", lambda k=kern: np.array(k.lengthscales),
-                    lambda v, k=kern: setattr(k, "lengthscales", float(v))))
-        if head:
+                    lambda v, k=kern: setattr(k, "lengthscales", np.array(v, np.float64) if np.ndim(v) else float(v))))
+        if head and hasattr(l.kern, "patch_weights"):
             out.append((li, "patch_weights", lambda l=l: l.kern.patch_weights, lambda v, l=l: setattr(l.kern, "patch_weights", v)))
     return out

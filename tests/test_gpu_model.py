@@ -358,15 +358,18 @@ def test_elbo_dense_rbf_ard_head(ctx, white):
     model.close()
 
 
-@pytest.mark.parametrize("white,additive,idmean", [(False, False, False), (True, False, False), (False, True, False), (False, False, True)])
+@pytest.mark.parametrize("white,additive,idmean", [(False, False, False), (True, False, False), (False, True, False), (False, False, True),
+                                                   (False, "dense", False), (True, "dense", False)])
 def test_gradients_match_oracle(ctx, white, additive, idmean):
     """dcgp_elbo_grad (csrc/grad.hip) against oracle/grad.py -- itself pinned by finite differences on CPU -- on a
     three-layer model: every parameter group of every layer."""
     from oracle.grad import elbo_and_grad
     hwc, N, S = (14, 14, 1), 3, 2
     convs = [(3, 1, 3), (3, 2, 2)] if idmean else [(3, 1, 3), (4, 2, 2)]      # Conv2dMean needs odd filters
+    dense = additive == "dense"               # RBF(ARD=True) head on the flattened features (--last-kernel rbf)
+    additive = additive is True
     spec = syn.make_spec(hwc, convs, (3, 1), 20, S=S, num_data=500, seed=9, white=white,
-                         conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5)
+                         conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5, head_kernel="rbf" if dense else "conv")
     rng = np.random.default_rng(9)
     spec["head"]["w"] = 0.5 + rng.random(spec["head"]["w"].shape)
     if additive:
@@ -397,13 +400,15 @@ def _softplus_inv(x):
     return np.log(np.expm1(x - 1e-6))
 
 
-def test_adam_steps_match_numpy_on_oracle_gradients(ctx):
+@pytest.mark.parametrize("head_kernel", ["conv", "rbf"])
+def test_adam_steps_match_numpy_on_oracle_gradients(ctx, head_kernel):
     """Three device Adam steps (dcgp_model_adam_step) against tf.train.AdamOptimizer's update written out in numpy
     on the ORACLE's gradients, in gpflow's unconstrained space (softplus + 1e-6 for variance / lengthscales)."""
     from oracle.grad import elbo_and_grad
     from oracle_build import oracle_param_handles
     hwc, N, S, lr = (12, 12, 1), 3, 2, 0.05
-    spec = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), 12, S=S, num_data=200, seed=4, conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5)
+    spec = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), 12, S=S, num_data=200, seed=4, conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5,
+                         head_kernel=head_kernel)
     X, Y = syn.make_batch(hwc, N, seed=4)
     ref = oracle_model(spec, X, Y)
     model = build_from_spec(spec, X, Y)
@@ -434,11 +439,12 @@ def test_adam_steps_match_numpy_on_oracle_gradients(ctx):
     for li, l in enumerate(model.layers):
         o = ref.layers[li]
         head = li == len(model.layers) - 1
-        kern, okern = (l.kern.base_kernel, o.kern.base_kernel) if head else (l.base_kernel, o.base_kernel)
+        dense = head and head_kernel == "rbf"
+        kern, okern = ((l.kern, o.kern) if dense else (l.kern.base_kernel, o.kern.base_kernel)) if head else (l.base_kernel, o.base_kernel)
         assert rel(l.feature.Z, o.Z) < 1e-7 and rel(l.q_mu, o.q_mu) < 1e-7 and rel(l.q_sqrt, o.q_sqrt) < 1e-7
         assert abs(kern.variance - okern.variance) < 1e-8 * okern.variance
-        assert abs(kern.lengthscales - okern.lengthscales) < 1e-8 * okern.lengthscales
-        if head:
+        assert np.all(np.abs(np.asarray(kern.lengthscales) - np.asarray(okern.lengthscales)) < 1e-8 * np.asarray(okern.lengthscales))
+        if head and not dense:
             assert rel(l.kern.patch_weights, o.kern.patch_weights) < 1e-7
     # and the training loop mirror runs and improves the bound on a fixed batch
     from deepcgp_amd.models import train

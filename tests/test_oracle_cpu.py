@@ -206,7 +206,8 @@ def test_arccosine_order0_known_answers():
 
 
 @pytest.mark.parametrize("white,additive,idmean", [(False, False, False), (False, True, False), (True, False, False),
-                                                   (True, True, False), (False, False, True)])
+                                                   (True, True, False), (False, False, True), (False, "dense", False),
+                                                   (True, "dense", False)])
 def test_hand_written_gradient_against_finite_differences(white, additive, idmean):
     """oracle/grad.py (the checker of the device backward pass) against central differences of the oracle ELBO
     along random directions of every parameter group; three layers so that the sample path between layers,
@@ -214,8 +215,10 @@ def test_hand_written_gradient_against_finite_differences(white, additive, idmea
     from oracle.grad import elbo_and_grad
     from oracle_build import oracle_param_handles
     hwc, seed = (10, 10, 1), 3
+    dense = additive == "dense"                  # RBF(ARD=True) head on the flattened features (--last-kernel rbf)
+    additive = additive is True
     spec = syn.make_spec(hwc, [(3, 1, 2), (3, 2, 2)], (2, 1), 6, S=2, num_data=100, seed=seed, white=white,
-                         conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5)
+                         conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5, head_kernel="rbf" if dense else "conv")
     rng = np.random.default_rng(seed)
     spec["head"]["w"] = 0.5 + rng.random(spec["head"]["w"].shape)
     if idmean:                                   # Conv2dMean on every conv layer (--identity-mean)
