@@ -216,7 +216,7 @@ def main():
     # ... and the same step followed by its reverse pass (dcgp_elbo_grad: value and gradient with respect to every
     # trainable parameter -- what the reference's training step differentiates, experiment.py:84-108).  Informational,
     # single-rank only (the gradient all-reduce is not wired up yet); never part of `value`.
-    dt_grad, dt_train = None, None
+    dt_grad, dt_train, dt_train_dedup = None, None, None
     if world == 1 and not args.profile and not args.no_grad_leg:
         n_g = max(3, min(args.steps, 20))
         for i in range(2):
@@ -236,6 +236,21 @@ def main():
             model.adam_step(1e-9, i + 1)
         barrier()
         dt_train = (time.perf_counter() - t4) / n_g
+        # ... and the same optimisation step with the exact layer-0 de-duplication (forward and reverse pass of the first
+        # layer on the N distinct images; identical gradients, tests/test_gpu_model.py)
+        dt_train_dedup = None
+        if cfg["convs"] and not args.dedup_layer0:
+            model.dedup_layer0 = True
+            for i in range(2):
+                model.compute_gradients(dX, dY, seed=i, scale=scale, fetch=False)
+            barrier()
+            t5 = time.perf_counter()
+            for i in range(n_g):
+                model.compute_gradients(dX, dY, seed=args.warmup + i, scale=scale, fetch=False)
+                model.adam_step(1e-9, n_g + i + 1)
+            barrier()
+            dt_train_dedup = (time.perf_counter() - t5) / n_g
+            model.dedup_layer0 = False
     if td is not None:
         t = torch.tensor([dt, dt_plain, dt_dedup or 0.0], dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -263,6 +278,7 @@ def main():
             "value_and_grad_steps_per_s": (1.0 / dt_grad) if dt_grad else None,
             "value_and_grad_ms": (1e3 * dt_grad) if dt_grad else None,
             "train_step_ms_value_grad_adam": (1e3 * dt_train) if dt_train else None,
+            "train_step_ms_with_exact_layer0_dedup": (1e3 * dt_train_dedup) if dt_train_dedup else None,
         }
         # ---- roofline of the dominant kernel: the R-batched L_q^T A product with fused square-reduce ----
         rows0 = per_rank_batch if (args.dedup_layer0 and cfg["convs"]) else per_rank_batch * S

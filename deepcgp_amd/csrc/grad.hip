@@ -116,6 +116,17 @@ __global__ void sample_backward_kernel(const double* __restrict__ dF, const doub
   gv[i] = d * (sample[i] - mean[i]) / (2.0 * (var[i] + jitter));
 }
 
+// out[i] = sum_s in[s * n + i]: the S samples of a de-duplicated first layer share one conditional
+__global__ void reduce_replicas_kernel(const double* __restrict__ a, const double* __restrict__ b, int S, long n, double* __restrict__ oa,
+                                       double* __restrict__ ob) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double sa = 0.0, sb = 0.0;
+  for (int s = 0; s < S; ++s) { sa += a[(long)s * n + i]; sb += b[(long)s * n + i]; }
+  oa[i] = sa;
+  ob[i] = sb;
+}
+
 // ---- conditional -----------------------------------------------------------------------------------------------
 __global__ void rowsum_small_kernel(const double* __restrict__ a, long n, int R, double* __restrict__ out) {
   const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1023,7 +1034,7 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
 
 }  // namespace
 
-int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, double scale) {
+int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, double scale, int dedup_layer0) {
   dcgp_ctx* ctx = m->ctx;
   const int nl = (int)m->layers.size(), S = m->S;
   if (!m->keep_outputs) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: the forward pass must keep the layer outputs");
@@ -1053,7 +1064,20 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
     LayerState& L = *m->layers[li];
     bk.pfx = mp + std::to_string(li) + "_";
     const double* Xin = li == 0 ? X : m->outs[li - 1].sample;
-    const int rows_l = m->outs[li].rows;            // rows entering == rows leaving (no dedup on this path)
+    int rows_l = m->outs[li].rows;                  // rows entering == rows leaving ...
+    // ... except for a de-duplicated first conv layer: propagate() tiles the batch S times, so layer 0 saw S identical
+    // copies; the forward evaluated its conditional on the N distinct images and drew S samples from it.  The S
+    // gradients arriving per image add up, and the conditional's reverse pass runs on N rows instead of S N (exact).
+    if (li == 0 && dedup_layer0 && !L.is_head && rows_l == S * N && S > 1) {
+      const long n = (long)N * L.v.P * L.R;
+      double* gm0 = (double*)ws_get(ctx, bk.pfx + "g_gm_dedup", (size_t)n * sizeof(double));
+      double* gv0 = (double*)ws_get(ctx, bk.pfx + "g_gv_dedup", (size_t)n * sizeof(double));
+      NEED(gm0); NEED(gv0);
+      hipLaunchKernelGGL(reduce_replicas_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, gm, gv, S, n, gm0, gv0);
+      LAUNCH_CHECK(ctx);
+      gm = gm0; gv = gv0;
+      rows_l = N;
+    }
     const int n_mod = li == 0 ? N : rows_l;
     double* dXin = nullptr;
     if (li > 0) {
@@ -1084,13 +1108,13 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
 extern "C" {
 
 int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, double scale, const double* const* z_per_layer_host,
-                   uint64_t seed, double* out_host, int* info_host) {
+                   uint64_t seed, int dedup_layer0, double* out_host, int* info_host) {
   if (!model || !X || !y || N <= 0 || !out_host) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "elbo_grad: bad args") : DCGP_ERR_ARG;
   dcgp_ctx* ctx = model->ctx;
   const bool keep = model->keep_outputs;
   model->keep_outputs = true;   // the reverse pass reads every layer's (sample, mean, var)
-  int rc = elbo_forward_impl(model, X, y, N, scale, z_per_layer_host, seed, 0, out_host, info_host);
-  if (rc == DCGP_OK) rc = model_backward(model, X, y, N, scale);
+  int rc = elbo_forward_impl(model, X, y, N, scale, z_per_layer_host, seed, dedup_layer0, out_host, info_host);
+  if (rc == DCGP_OK) rc = model_backward(model, X, y, N, scale, dedup_layer0);
   model->keep_outputs = keep;
   DCGP_TRY(rc);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -34,4 +34,4 @@ int elbo_forward_impl(dcgp_model* model, const double* X, const int32_t* y, int 
                       const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, double* out_host,
                       int* info_host);
 // grad.hip: reverse pass over the state the forward left behind; fills every layer's gradient buffers
-int model_backward(dcgp_model* model, const double* X, const int32_t* y, int N, double scale);
+int model_backward(dcgp_model* model, const double* X, const int32_t* y, int N, double scale, int dedup_layer0);

@@ -82,7 +82,7 @@ _SIGS = {
     "dcgp_model_set_param": [_vp, _i, C.c_char_p, _vp, _sz],
     "dcgp_elbo_forward": [_vp, _vp, _vp, _i, _d, C.POINTER(_vp), _u64, _i, _dp, _ip],
     "dcgp_model_propagate": [_vp, _vp, _i, _i, C.POINTER(_vp), _u64, _vp, _vp, _ip],
-    "dcgp_elbo_grad": [_vp, _vp, _vp, _i, _d, C.POINTER(_vp), _u64, C.POINTER(_d), _ip],
+    "dcgp_elbo_grad": [_vp, _vp, _vp, _i, _d, C.POINTER(_vp), _u64, _i, C.POINTER(_d), _ip],
     "dcgp_model_get_grad": [_vp, _i, C.c_char_p, _vp, C.c_size_t],
     "dcgp_model_adam_step": [_vp, _d, _d, _d, _d, _i],
     "dcgp_model_get_param": [_vp, _i, C.c_char_p, _vp, C.c_size_t],

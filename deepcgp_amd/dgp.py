@@ -191,7 +191,8 @@ class DGP_Base:
         info = C.c_int(0)
         if shards is not None:   # this call handles one of `shards` batch shards: the replicated KL term is weighted 1 / shards
             ctx._check(L.dcgp_model_set_grad_shards(self._model, int(shards)))
-        ctx._check(L.dcgp_elbo_grad(self._model, dX.ptr, dY.ptr, N, float(scale), arr, int(seed), out, C.byref(info)), info)
+        ctx._check(L.dcgp_elbo_grad(self._model, dX.ptr, dY.ptr, N, float(scale), arr, int(seed), int(self.dedup_layer0), out,
+                                    C.byref(info)), info)
         if not fetch:            # the gradients stay on the device (dcgp_model_get_grad / the optimiser step read them there)
             return out[0], None
         grads = []

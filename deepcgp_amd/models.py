@@ -69,7 +69,7 @@ def natgrad_gamma(global_step, gamma0=0.001, steps_back=0, gamma_step=1e-3, back
 
 
 def train(model, steps, lr=0.01, lr_decay_steps=50000, global_step=0, seed=0, callback=None, optimizer="Adam", gamma=0.001,
-          max_retries=5):
+          max_retries=5, dedup_layer0=True):
     """The reference's optimisation loop (conv_gp/experiment.py:84-108 + gpflow.actions.Loop at :44).  Every step draws a
     minibatch and evaluates the ELBO and its gradient on the device (``compute_gradients``), then
       "Adam":    one device Adam step on every parameter;
@@ -77,6 +77,9 @@ def train(model, steps, lr=0.01, lr_decay_steps=50000, global_step=0, seed=0, ca
       "NatGrad": a natural-gradient step on every layer's (q_mu, q_sqrt) (``DGP_Base.natgrad_step``, step size from
                  ``natgrad_gamma``), then -- as the reference's loop does, with the variational parameters switched to
                  non-trainable -- a fresh gradient and an Adam step on everything else.
+    ``dedup_layer0`` (default on): propagate() tiles the minibatch S times, so the first layer sees S identical copies;
+    its conditional and reverse pass are evaluated on the distinct images only -- same ELBO, same gradients, about half the
+    step time at the headline configuration.
     Returns the list of ELBO values; the Python-side parameter objects are refreshed at the end (``pull_parameters``)."""
     if optimizer not in ("Adam", "NatGrad", "SGD"):
         raise ValueError("Not a supported optimizer. Try Adam or NatGrad.")     # experiment.py:109-110
@@ -86,6 +89,7 @@ def train(model, steps, lr=0.01, lr_decay_steps=50000, global_step=0, seed=0, ca
     history = []
     steps_back = 0
     model._build()
+    dedup_before, model.dedup_layer0 = model.dedup_layer0, bool(dedup_layer0)
     nl = len(model.layers)
     for li in range(nl):
         for which in ("q_mu", "q_sqrt"):
@@ -113,6 +117,7 @@ def train(model, steps, lr=0.01, lr_decay_steps=50000, global_step=0, seed=0, ca
         history.append(elbo)
         if callback is not None:
             callback(step + 1, elbo)
+    model.dedup_layer0 = dedup_before
     model.pull_parameters()
     return history
 

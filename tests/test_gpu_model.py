@@ -643,3 +643,22 @@ def test_gradient_with_device_rng_matches_explicit_noise(ctx):
             err = np.abs(a[name] - b[name]).max()
             assert err <= 1e-7 * max(np.abs(a[name]).max(), 1.0), (name, err)
     model.close()
+
+
+def test_gradient_with_layer0_dedup_is_identical(ctx):
+    """dedup_layer0 in the training step: the first layer's conditional and its reverse pass on the N distinct images
+    (the S per-sample gradients of an image added first) give the gradients of the tiled evaluation."""
+    hwc, N, S = (14, 14, 1), 4, 3
+    spec = syn.make_spec(hwc, [(3, 1, 3), (4, 2, 2)], (3, 1), 20, S=S, num_data=500, seed=14, conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5)
+    X, Y = syn.make_batch(hwc, N, seed=14)
+    zs = syn.make_noise(spec, N, seed=14)
+    model = build_from_spec(spec, X, Y)
+    e0, g0 = model.compute_gradients(X, Y, zs=zs)
+    model.dedup_layer0 = True
+    e1, g1 = model.compute_gradients(X, Y, zs=zs)
+    assert abs(e0 - e1) <= 1e-12 * abs(e0)
+    for a, b in zip(g0, g1):
+        for name in a:
+            err = np.abs(a[name] - b[name]).max()
+            assert err <= 1e-9 * max(np.abs(a[name]).max(), 1.0), (name, err)
+    model.close()
