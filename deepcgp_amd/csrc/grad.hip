@@ -512,6 +512,30 @@ struct Bk {   // per-backward bookkeeping
   double* ws(const char* name, size_t n_doubles) { return (double*)ws_get(ctx, pfx + "g_" + name, (n_doubles ? n_doubles : 1) * sizeof(double)); }
 };
 
+// Runs the launches issued in its lifetime on the side stream, ordered behind what the main stream holds at construction;
+// done() records `done_ev` (wait for it on the main stream to join).  Restores ctx->stream on every exit path.
+struct SideScope {
+  dcgp_ctx* ctx;
+  hipStream_t main_s;
+  bool active;
+  SideScope(dcgp_ctx* c, hipEvent_t fork_ev) : ctx(c), main_s(c->stream) {
+    static const bool nofork = getenv("DCGP_GRAD_NOFORK") != nullptr;   // A/B switch
+    active = !nofork && !c->no_side && c->stream2 && c->stream2 != c->stream;
+    if (active) {
+      if (hipEventRecord(fork_ev, main_s) != hipSuccess || hipStreamWaitEvent(c->stream2, fork_ev, 0) != hipSuccess) active = false;
+      else c->stream = c->stream2;
+    }
+  }
+  int done(hipEvent_t done_ev) {
+    if (!active) return DCGP_OK;
+    const hipError_t e = hipEventRecord(done_ev, ctx->stream2);
+    ctx->stream = main_s;
+    active = false;
+    return e == hipSuccess ? DCGP_OK : ctx_fail(ctx, DCGP_ERR_HIP, "grad: event record failed");
+  }
+  ~SideScope() { if (active) { hipStreamSynchronize(ctx->stream2); ctx->stream = main_s; } }
+};
+
 GenGemm mk(const double* A, long ars, long acs, const double* B, long brs, long bcs, double* C, long crs, int M, int N, int K) {
   GenGemm g;
   g.A = A; g.a_rs = ars; g.a_cs = acs; g.B = B; g.b_rs = brs; g.b_cs = bcs; g.C = C; g.c_rs = crs; g.M = M; g.N = N; g.K = K;
@@ -760,7 +784,8 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
       DCGP_TRY(gemm_gen(ctx, t));
     }
     // dA1 = sum_r G_r dT_r: ONE product with the R blocks stacked along k (GT [R Mp x Mp], dT [R Mp x ld])
-    if (Rm * ld * 8 < (1L << 31)) {
+    // (few columns -- a de-duplicated first layer, the head: the 72-workgroup launch would be one long k chain; gemm_gen splits k)
+    if (Rm * ld * 8 < (1L << 31) && Kc >= 16384) {
       GemmArgs a;
       a.Wt = GT; a.ldw = Mp;
       a.B = dT; a.ldb = (int)ld;
@@ -875,15 +900,27 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   double* Xcol = bk.ws("Xcol", (size_t)Kc * Ld);
   NEED(dKuf); NEED(S); NEED(gvs); NEED(cs); NEED(Xcol);
   DCGP_TRY(cond_backward(bk, L, A1, ld, Kc, gm, gv, dKuf, S, gvs));
-  DCGP_TRY(add_scalar(bk, L, false, gvs, Kc, 1.0));                  // Knn = variance on every column
-  DCGP_TRY(kuu_backward(bk, L, L.Z, S, Mp, true));
+  // two independent tails: the M x M one (Gram adjoint of K_uu, KL adjoint: ~25 small launches) on the side stream, the
+  // patch-kernel adjoint on the main stream; both add into dZ, so the main one collects its part in a scratch first
+  double* dzp = bk.ws("dz_patch", (size_t)M * Ld);
+  NEED(dzp);
+  bool forked;
+  {
+    SideScope side(ctx, ctx->ev_fork);
+    forked = side.active;
+    DCGP_TRY(add_scalar(bk, L, false, gvs, Kc, 1.0));                  // Knn = variance on every column
+    DCGP_TRY(kuu_backward(bk, L, L.Z, S, Mp, true));
+    DCGP_TRY(kl_backward(bk, L, nullptr));
+    DCGP_TRY(side.done(ctx->ev_kl));
+  }
+  HIP_TRY(ctx, hipMemsetAsync(dzp, 0, (size_t)M * Ld * sizeof(double), ctx->stream));
   hipLaunchKernelGGL(im2col_kernel, dim3(blocks_for(Kc * Ld)), dim3(256), 0, ctx->stream, Xin, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s,
                      L.v.Wo, P, Ld, Kc, Xcol);
   LAUNCH_CHECK(ctx);
   DCGP_TRY(e_form(bk, L, dKuf, ld, 1, nullptr, 1.0, Kuf, ld, dKuf, ld, Kc, cs, nullptr));   // E over dKuf
   double* dXcol = nullptr;
   if (dXin) { dXcol = bk.ws("dXcol", (size_t)Kc * Ld); NEED(dXcol); }
-  DCGP_TRY(patch_backward(bk, L, dKuf, ld, Kc, cs, Xcol, dXcol, 0));
+  DCGP_TRY(patch_backward(bk, L, dKuf, ld, Kc, cs, Xcol, dXcol, 0, nullptr, dzp));
   if (dXin) {
     const long n = (long)rows * L.v.H * L.v.W * L.v.C;
     hipLaunchKernelGGL(col2im_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, dXcol, rows, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s, L.v.Ho,
@@ -895,7 +932,9 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
       LAUNCH_CHECK(ctx);
     }
   }
-  DCGP_TRY(kl_backward(bk, L, nullptr));
+  if (forked) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_kl, 0));   // join
+  hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(Ld), M), dim3(256), 0, ctx->stream, dzp, (long)Ld, L.gZ, (long)Ld, M, Ld, 1.0, 1);
+  LAUNCH_CHECK(ctx);
   return end_layer(bk, L);
 }
 
@@ -965,8 +1004,18 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   NEED(A1); NEED(dKzx); NEED(S); NEED(gkd); NEED(Kfull); NEED(E); NEED(cs); NEED(raw); NEED(Xcol); NEED(dXcol);
   DCGP_TRY(gemm_gen(ctx, mk(L.g.Linv, Mp, 1, Kzx, ld, 1, A1, ld, M, rows, M)));      // the fused forward keeps A1 on chip
   DCGP_TRY(cond_backward(bk, L, A1, ld, rows, gm, gv, dKzx, S, gkd));
-  if (!L.white) DCGP_TRY(kl_backward(bk, L, S)); else DCGP_TRY(kl_backward(bk, L, nullptr));
-  DCGP_TRY(kuu_backward(bk, L, L.Z, S, Mp, true));
+  // as in conv_backward: KL + Gram adjoints on the side stream, the patch-kernel adjoints (K_zx, K_diag) on the main one
+  double* dzp = bk.ws("dz_patch", (size_t)M * Ld);
+  NEED(dzp);
+  bool forked;
+  {
+    SideScope side(ctx, ctx->ev_fork);
+    forked = side.active;
+    if (!L.white) DCGP_TRY(kl_backward(bk, L, S)); else DCGP_TRY(kl_backward(bk, L, nullptr));
+    DCGP_TRY(kuu_backward(bk, L, L.Z, S, Mp, true));
+    DCGP_TRY(side.done(ctx->ev_kl));
+  }
+  HIP_TRY(ctx, hipMemsetAsync(dzp, 0, (size_t)M * Ld * sizeof(double), ctx->stream));
   // every patch response again: Kfull[m][n * P + p] = k(Z_m, x_np)
   PatchRbfArgs a;
   a.X = Xin; a.N = rows; a.n_mod = n_mod;
@@ -982,7 +1031,7 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   DCGP_TRY(e_form(bk, L, dKzx, ld, P, L.w, 1.0 / P, Kfull, ldf, E, ldf, Kc, cs, raw));
   hipLaunchKernelGGL(strided_sum_kernel, dim3(P), dim3(256), 0, ctx->stream, raw, rows, P, 1.0 / P, 1, L.gw);
   LAUNCH_CHECK(ctx);
-  DCGP_TRY(patch_backward(bk, L, E, ldf, Kc, cs, Xcol, dXin ? dXcol : nullptr, 0));
+  DCGP_TRY(patch_backward(bk, L, E, ldf, Kc, cs, Xcol, dXin ? dXcol : nullptr, 0, nullptr, dzp));
   // Kdiag
   if (L.kernel_type == 0) {
     const double inv_l2 = 1.0 / (L.ls * L.ls);
@@ -1029,6 +1078,9 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
                        L.v.Wo, Ld, dXin);
     LAUNCH_CHECK(ctx);
   }
+  if (forked) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_kl, 0));   // join
+  hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(Ld), M), dim3(256), 0, ctx->stream, dzp, (long)Ld, L.gZ, (long)Ld, M, Ld, 1.0, 1);
+  LAUNCH_CHECK(ctx);
   return end_layer(bk, L);
 }
 

@@ -13,6 +13,7 @@ S = cfg.get("S", 10)
 spec = syn.make_spec(cfg["hwc"], cfg["convs"], cfg["head"], cfg["M"], S=S, num_data=cfg["num_data"], seed=1)
 X, Y = syn.make_batch(cfg["hwc"], cfg["batch"], seed=1)
 model = build_from_spec(spec, X, Y)
+model.dedup_layer0 = bool(int(os.environ.get("DCGP_DEDUP", "0")))   # exact layer-0 de-duplication (training default)
 ctx = dev.get_context()
 dX, dY = ctx.to_device(X), ctx.to_device(Y, np.int32)
 for i in range(2):
