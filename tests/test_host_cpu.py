@@ -134,3 +134,17 @@ def test_synthetic_spec_variants():
     h = s2["head"]
     assert h["kernel"] == "rbf" and h["Z"].shape == (6, 5 * 5 * 2) and h["ls_ard"].shape == (50,) and h["w"].shape == (1,)
     assert syn.layer_output_dims(s2) == [5 * 5 * 2, 10]
+
+
+def test_optimiser_schedules_match_the_reference_formulas():
+    """learning_rate = tf.train.exponential_decay(lr, step, decay_steps, 0.1, staircase=True) and the NatGrad gamma
+    schedule min((step / 100 * 1e-3 + gamma0) * 0.2 ** steps_back, 1) of conv_gp/experiment.py:71-81."""
+    from deepcgp_amd.models import learning_rate, natgrad_gamma
+    assert learning_rate(0.01, 0, 50000) == 0.01
+    assert learning_rate(0.01, 49999, 50000) == 0.01
+    assert abs(learning_rate(0.01, 50000, 50000) - 0.001) < 1e-18
+    assert abs(learning_rate(0.01, 125000, 50000) - 0.0001) < 1e-18
+    assert natgrad_gamma(0) == 0.001
+    assert abs(natgrad_gamma(5000, 0.001) - (50 * 1e-3 + 0.001)) < 1e-15
+    assert abs(natgrad_gamma(5000, 0.001, steps_back=2) - (50 * 1e-3 + 0.001) * 0.04) < 1e-15
+    assert natgrad_gamma(10 ** 9) == 1.0
