@@ -293,6 +293,16 @@ def test_model_builder_from_flags(ctx):
         assert p1.pathname == p2.pathname and np.array_equal(np.asarray(p1.value), np.asarray(p2.value)), p1.pathname
     e2 = m2.compute_log_likelihood(X[:8].reshape(8, -1), Y[:8], seed=1)
     assert e2 == e1 and e1 != e
+    # the reference's loop on the rebuilt model: a few optimisation steps from the flags' batch size, accuracy logger,
+    # checkpoint of the trained values (the README snippet)
+    from deepcgp_amd.models import train, AccuracyLogger
+    hist = train(m2, 4, lr=0.01, seed=2)
+    assert len(hist) == 4 and all(np.isfinite(hist))
+    acc = AccuracyLogger(X[:20], Y[:20])(m2)
+    assert 0.0 <= acc <= 1.0
+    with tempfile.TemporaryDirectory() as tmp:
+        saved2 = save_model_parameters(m2, os.path.join(tmp, 't2.npy'), global_step=127)
+    assert not np.array_equal(saved2['DGP/layers/1/q_mu'], saved['DGP/layers/1/q_mu'])      # the parameters moved
     m2.close()
     with pytest.raises(AssertionError):
         flags.feature_maps = '3,3'
