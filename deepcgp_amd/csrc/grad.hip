@@ -25,7 +25,7 @@
 
 namespace {
 
-constexpr int VAR_SLOT = 0, LS_SLOT = 16;   // gslots: [0, 16) variance contributions, [16, 32) lengthscale contributions
+constexpr int VAR_SLOT = 0, LS_SLOT = 16, P2_SLOT = 32;   // gslots: [0,16) variance, [16,32) lengthscale | acos weight variance, [32,48) acos bias variance
 
 inline unsigned blocks_for(long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
 
@@ -423,10 +423,106 @@ __global__ void fill_kernel(double* __restrict__ p, long n, double v) {
 
 __global__ void scal_finish_kernel(const double* __restrict__ slots, double* __restrict__ gscal) {
   if (threadIdx.x || blockIdx.x) return;
-  double a = 0.0, b = 0.0;
-  for (int i = 0; i < 16; ++i) { a += slots[VAR_SLOT + i]; b += slots[LS_SLOT + i]; }
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int i = 0; i < 16; ++i) { a += slots[VAR_SLOT + i]; b += slots[LS_SLOT + i]; c += slots[P2_SLOT + i]; }
   gscal[0] = a;
   gscal[1] = b;
+  gscal[2] = c;
+}
+
+// ---- ArcCosine(order 0) base kernel (--base-kernel acos, conv layers) ------------------------------------------------
+// K = variance (pi - theta) / pi, theta = acos(c'), c' = 1e-15 + (1 - 2e-15) c, c = (w x.z + b) / sqrt(Q A), Q = w |z|^2 + b,
+// A = w |x|^2 + b.  With F = dLoss/dc = dK variance (1 - 2e-15) / (pi sin theta), F1 = F / sqrt(Q A), F2 = F c:
+//   dZ = w (F1 X - (rowsum(F2) / Q) o Z),  dX = w (F1^T Z - (colsum(F2) / A) o X)     -- the RBF adjoint's shape with
+//   E -> F1, rowsum(E) -> rowsum(F2) / Q, colsum(E) -> colsum(F2) / A, 1 / l^2 -> w, so patch_backward / kuu GEMMs are shared;
+//   dw = sum F1 s - F2 (a / A + q / Q) / 2,  db = sum F1 - F2 (1 / A + 1 / Q) / 2   (s = x.z, a = |x|^2, q = |z|^2).
+// theta and c are recovered from the stored K (theta = pi (1 - K / variance)).  Coincident points (sin theta ~ 0) carry no
+// gradient except through the variance: c == 1 there identically in z, w and b (oracle/grad.py _acos_backward).
+__global__ void rownorm_kernel(const double* __restrict__ X, long rows, int L, double* __restrict__ out) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= rows) return;
+  double s = 0.0;
+  for (int l = 0; l < L; ++l) { const double v = X[c * L + l]; s += v * v; }
+  out[c] = s;
+}
+// one thread per column c and row chunk (blockIdx.y): F1 over dK (in place), F2, csp[chunk][c] = sum_m F2 / A_c, block partials
+__global__ __launch_bounds__(256) void acos_e_form_kernel(double* __restrict__ dKF1, long ld, const double* __restrict__ K, double* __restrict__ F2,
+                                                          int M, int rows_per_chunk, long Kc, double variance, double w, double b,
+                                                          const double* __restrict__ zn, const double* __restrict__ xn, double* __restrict__ csp,
+                                                          double* __restrict__ pv, double* __restrict__ pw, double* __restrict__ pb) {
+  __shared__ double red[256];
+  const long c = (long)blockIdx.x * 256 + threadIdx.x;
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  double sv = 0.0, sw = 0.0, sb = 0.0, sc = 0.0;
+  if (c < Kc) {
+    const double a2 = xn[c], A = w * a2 + b;
+    for (int m = m0; m < m1; ++m) {
+      const double k = K[m * ld + c], dk = dKF1[m * ld + c];
+      const double theta = 3.14159265358979323846 * (1.0 - k / variance);
+      const double sn = sin(theta), cc = (cos(theta) - 1e-15) / (1.0 - 2e-15);
+      const double F = sn > 1e-12 ? dk * variance * 0.31830988618379067154 * (1.0 - 2e-15) / sn : 0.0;
+      const double q2 = zn[m], Q = w * q2 + b, rt = sqrt(Q * A);
+      const double f1 = F / rt, f2 = F * cc;
+      dKF1[m * ld + c] = f1;
+      F2[m * ld + c] = f2;
+      sv += dk * k;
+      sw += f1 * (cc * rt - b) / w - 0.5 * f2 * (a2 / A + q2 / Q);
+      sb += f1 - 0.5 * f2 * (1.0 / A + 1.0 / Q);
+      sc += f2;
+    }
+    csp[(long)blockIdx.y * Kc + c] = sc / A;
+  }
+  const double a = block_sum_256(sv, red), bb = block_sum_256(sw, red), cc2 = block_sum_256(sb, red);
+  if (threadIdx.x == 0) {
+    const long o = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    pv[o] = a; pw[o] = bb; pb[o] = cc2;
+  }
+}
+// v[i] /= (w * n[i] + b)
+__global__ void acos_divide_kernel(double* __restrict__ v, const double* __restrict__ n, int M, double w, double b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M) v[i] /= (w * n[i] + b);
+}
+// Gram adjoint, one block per row i (both arguments are Z; the diagonal is skipped): Es[i][j] = (F_ij + F_ji) / sqrt(Q_i Q_j),
+// rs[i] = sum_j (F_ij + F_ji) c_ij / Q_i, partials pv (variance), pw, pb
+__global__ __launch_bounds__(256) void acos_kuu_backward_kernel(const double* __restrict__ Z, const double* __restrict__ zn, int M, int L,
+                                                                const double* __restrict__ S, long lds, double variance, double w, double b,
+                                                                double* __restrict__ Es, long lde, double* __restrict__ rs,
+                                                                double* __restrict__ pv, double* __restrict__ pw, double* __restrict__ pb) {
+  __shared__ double red[256];
+  const int i = blockIdx.x, t = threadIdx.x;
+  const double qi = zn[i], Qi = w * qi + b;
+  double srow = 0.0, sv = 0.0, sw = 0.0, sb = 0.0;
+  for (int j = t; j < M; j += 256) {
+    double s = 0.0;
+    for (int l = 0; l < L; ++l) s += Z[(long)i * L + l] * Z[(long)j * L + l];
+    const double qj = zn[j], Qj = w * qj + b, rt = sqrt(Qi * Qj);
+    const double c = (w * s + b) / rt;
+    const double cp = fmin(1e-15 + (1.0 - 2e-15) * c, 1.0);
+    const double theta = acos(cp);
+    const double k = variance * (1.0 - theta * 0.31830988618379067154);
+    const double Sij = S[i * lds + j];
+    sv += Sij * k;
+    double es = 0.0;
+    if (j != i) {
+      const double sn = sin(theta);
+      const double g = sn > 1e-12 ? variance * 0.31830988618379067154 * (1.0 - 2e-15) / sn : 0.0;
+      const double Fij = Sij * g, Fji = S[j * lds + i] * g;
+      const double f1 = Fij / rt;
+      sw += f1 * s - 0.5 * Fij * c * (qi / Qi + qj / Qj);
+      sb += f1 - 0.5 * Fij * c * (1.0 / Qi + 1.0 / Qj);
+      es = (Fij + Fji) / rt;
+      srow += (Fij + Fji) * c;
+    }
+    if (Es) Es[i * lde + j] = es;
+  }
+  const double a = block_sum_256(srow, red), bv = block_sum_256(sv, red), cw = block_sum_256(sw, red), db = block_sum_256(sb, red);
+  if (t == 0) {
+    if (rs) rs[i] = a / Qi;
+    pv[i] = bv / variance;
+    pw[i] = cw;
+    pb[i] = db;
+  }
 }
 
 // ---- dense RBF(ARD) head (--last-kernel rbf) --------------------------------------------------------------------------
@@ -507,7 +603,7 @@ struct Bk {   // per-backward bookkeeping
   dcgp_model* m;
   dcgp_ctx* ctx;
   std::string pfx;   // workspace prefix of the layer being processed
-  int slot_v = 0, slot_l = 0;
+  int slot_v = 0, slot_l = 0, slot_b = 0;
   double klw = 1.0;   // weight of the (replicated) KL term on this rank: 1 / number of batch shards
   double* ws(const char* name, size_t n_doubles) { return (double*)ws_get(ctx, pfx + "g_" + name, (n_doubles ? n_doubles : 1) * sizeof(double)); }
 };
@@ -544,11 +640,11 @@ GenGemm mk(const double* A, long ars, long acs, const double* B, long brs, long 
 
 #define NEED(p) do { if (!(p)) return DCGP_ERR_ALLOC; } while (0)
 
-// add scale * sum(part[0..n)) to the next variance / lengthscale slot of the layer
-int add_scalar(Bk& bk, LayerState& L, bool lengthscale, const double* part, long n, double scale) {
-  int& s = lengthscale ? bk.slot_l : bk.slot_v;
+// add scale * sum(part[0..n)) to the next slot of the layer: which = 0 variance, 1 lengthscale | acos weight variance, 2 acos bias variance
+int add_scalar(Bk& bk, LayerState& L, int which, const double* part, long n, double scale) {
+  int& s = which == 0 ? bk.slot_v : (which == 1 ? bk.slot_l : bk.slot_b);
   if (s >= 16) return ctx_fail(bk.ctx, DCGP_ERR_ARG, "grad: out of scalar slots");
-  DCGP_TRY(reduce_sum(bk.ctx, part, n, scale, L.gslots + (lengthscale ? LS_SLOT : VAR_SLOT) + s));
+  DCGP_TRY(reduce_sum(bk.ctx, part, n, scale, L.gslots + (which == 0 ? VAR_SLOT : (which == 1 ? LS_SLOT : P2_SLOT)) + s));
   ++s;
   return DCGP_OK;
 }
@@ -563,16 +659,30 @@ int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, lon
   double* pl = bk.ws("kuu_pl", M);
   NEED(pv); NEED(pl);
   if (want_dz) { Es = bk.ws("kuu_Es", (size_t)M * M); rs = bk.ws("kuu_rs", M); NEED(Es); NEED(rs); }
-  hipLaunchKernelGGL(kuu_backward_kernel, dim3(M), dim3(256), 0, ctx->stream, Zsrc, Zsrc == L.Z ? L.ZT : nullptr, L.Mp, M, Ld, S, lds, L.variance,
-                     inv_l2, inv_l3, Es, (long)M, rs, pv, pl);
-  LAUNCH_CHECK(ctx);
-  DCGP_TRY(add_scalar(bk, L, false, pv, M, 1.0));
-  DCGP_TRY(add_scalar(bk, L, true, pl, M, 1.0));
+  double cz = inv_l2;      // factor of the dZ combination: 1 / l^2 (RBF) or the weight variance (ArcCosine)
+  if (L.base_type == 1) {
+    double* pb = bk.ws("kuu_pb", M);
+    double* znv = bk.ws("kuu_zn", M);
+    NEED(pb); NEED(znv);
+    hipLaunchKernelGGL(rownorm_kernel, dim3(blocks_for(M)), dim3(256), 0, ctx->stream, Zsrc, (long)M, Ld, znv);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(acos_kuu_backward_kernel, dim3(M), dim3(256), 0, ctx->stream, Zsrc, znv, M, Ld, S, lds, L.variance, L.acos_w, L.acos_b,
+                       Es, (long)M, rs, pv, pl, pb);
+    LAUNCH_CHECK(ctx);
+    DCGP_TRY(add_scalar(bk, L, 2, pb, M, 1.0));
+    cz = L.acos_w;
+  } else {
+    hipLaunchKernelGGL(kuu_backward_kernel, dim3(M), dim3(256), 0, ctx->stream, Zsrc, Zsrc == L.Z ? L.ZT : nullptr, L.Mp, M, Ld, S, lds, L.variance,
+                       inv_l2, inv_l3, Es, (long)M, rs, pv, pl);
+    LAUNCH_CHECK(ctx);
+  }
+  DCGP_TRY(add_scalar(bk, L, 0, pv, M, 1.0));
+  DCGP_TRY(add_scalar(bk, L, 1, pl, M, 1.0));
   if (want_dz) {
     double* EX = bk.ws("kuu_EX", (size_t)M * Ld);
     NEED(EX);
     DCGP_TRY(gemm_gen(ctx, mk(Es, M, 1, Zsrc, Ld, 1, EX, Ld, M, Ld, M)));
-    hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for((long)M * Ld)), dim3(256), 0, ctx->stream, EX, rs, Zsrc, (long)M, Ld, inv_l2, 1,
+    hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for((long)M * Ld)), dim3(256), 0, ctx->stream, EX, rs, Zsrc, (long)M, Ld, cz, 1,
                        dz_out ? dz_out : L.gZ);
     LAUNCH_CHECK(ctx);
   }
@@ -582,14 +692,14 @@ int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, lon
 // Patch-kernel backward: E [M x Kc] (ld) = d ELBO / dKfull o Kfull is ready, cs = its column sums.
 // dZ += (E Xcol - rowsum(E) o Z) / l^2;  dXcol (=|+=) (E^T Z - cs o Xcol) / l^2 when requested.
 int patch_backward(Bk& bk, LayerState& L, const double* E, long ld, long Kc, const double* cs, const double* Xcol, double* dXcol,
-                   int dx_accumulate, const double* Zuse = nullptr, double* dz_out = nullptr) {
+                   int dx_accumulate, const double* Zuse = nullptr, double* dz_out = nullptr, const double* rs_in = nullptr, double cz = 0.0) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Ld = L.v.L;
-  const double inv_l2 = 1.0 / (L.ls * L.ls);
-  double* rs = bk.ws("pb_rs", M);
+  const double inv_l2 = cz != 0.0 ? cz : 1.0 / (L.ls * L.ls);   // cz: the ArcCosine adjoint passes its weight variance (and its own row vector)
+  double* rs = rs_in ? const_cast<double*>(rs_in) : bk.ws("pb_rs", M);
   double* EX = bk.ws("pb_EX", (size_t)M * Ld);
   NEED(rs); NEED(EX);
-  {
+  if (!rs_in) {
     const int chunks = (int)std::min<long>(32, (Kc + 4095) / 4096);
     const long cpc = round_up_l((Kc + chunks - 1) / chunks, 256);
     double* rsp = bk.ws("pb_rsp", (size_t)chunks * M);
@@ -861,17 +971,17 @@ int e_form(Bk& bk, LayerState& L, const double* dK, long lddk, int pdiv, const d
       LAUNCH_CHECK(ctx);
     }
   }
-  DCGP_TRY(add_scalar(bk, L, false, pv, (long)nb * chunks, 1.0 / L.variance));
-  DCGP_TRY(add_scalar(bk, L, true, pl, (long)nb * chunks, 1.0 / (L.ls * L.ls * L.ls)));
+  DCGP_TRY(add_scalar(bk, L, 0, pv, (long)nb * chunks, 1.0 / L.variance));
+  DCGP_TRY(add_scalar(bk, L, 1, pl, (long)nb * chunks, 1.0 / (L.ls * L.ls * L.ls)));
   return DCGP_OK;
 }
 
 int begin_layer(Bk& bk, LayerState& L) {
   DCGP_TRY(L.ensure_grads());
-  bk.slot_v = bk.slot_l = 0;
-  HIP_TRY(bk.ctx, hipMemsetAsync(L.gslots, 0, 32 * sizeof(double), bk.ctx->stream));
+  bk.slot_v = bk.slot_l = bk.slot_b = 0;
+  HIP_TRY(bk.ctx, hipMemsetAsync(L.gslots, 0, 48 * sizeof(double), bk.ctx->stream));
   HIP_TRY(bk.ctx, hipMemsetAsync(L.gZ, 0, (size_t)L.M * L.v.L * sizeof(double), bk.ctx->stream));
-  HIP_TRY(bk.ctx, hipMemsetAsync(L.gw, 0, ((size_t)L.v.P + 2 + (L.is_head ? (size_t)L.v.L : 0)) * sizeof(double), bk.ctx->stream));   // gw, gscal, gard
+  HIP_TRY(bk.ctx, hipMemsetAsync(L.gw, 0, ((size_t)L.v.P + 3 + (L.is_head ? (size_t)L.v.L : 0)) * sizeof(double), bk.ctx->stream));   // gw, gscal, gard
   if (!L.has_qsqrt) HIP_TRY(bk.ctx, hipMemsetAsync(L.gq_sqrt, 0, (size_t)L.R * L.M * L.M * sizeof(double), bk.ctx->stream));
   return DCGP_OK;
 }
@@ -908,7 +1018,7 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   {
     SideScope side(ctx, ctx->ev_fork);
     forked = side.active;
-    DCGP_TRY(add_scalar(bk, L, false, gvs, Kc, 1.0));                  // Knn = variance on every column
+    DCGP_TRY(add_scalar(bk, L, 0, gvs, Kc, 1.0));                  // Knn = variance on every column
     DCGP_TRY(kuu_backward(bk, L, L.Z, S, Mp, true));
     DCGP_TRY(kl_backward(bk, L, nullptr));
     DCGP_TRY(side.done(ctx->ev_kl));
@@ -917,10 +1027,48 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   hipLaunchKernelGGL(im2col_kernel, dim3(blocks_for(Kc * Ld)), dim3(256), 0, ctx->stream, Xin, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s,
                      L.v.Wo, P, Ld, Kc, Xcol);
   LAUNCH_CHECK(ctx);
-  DCGP_TRY(e_form(bk, L, dKuf, ld, 1, nullptr, 1.0, Kuf, ld, dKuf, ld, Kc, cs, nullptr));   // E over dKuf
   double* dXcol = nullptr;
   if (dXin) { dXcol = bk.ws("dXcol", (size_t)Kc * Ld); NEED(dXcol); }
-  DCGP_TRY(patch_backward(bk, L, dKuf, ld, Kc, cs, Xcol, dXcol, 0, nullptr, dzp));
+  if (L.base_type == 1) {   // ArcCosine(order 0): F1 over dKuf, F2 beside it, the RBF machinery on (F1, rowsum(F2) / Q, colsum(F2) / A, w)
+    const unsigned nb = blocks_for(Kc);
+    int chunks = (int)std::min<long>(16, std::max<long>(1, 2048 / nb));
+    chunks = std::min(chunks, (M + 15) / 16);
+    const int rpc = (M + chunks - 1) / chunks;
+    chunks = (M + rpc - 1) / rpc;
+    double* F2 = bk.ws("acos_F2", (size_t)Mp * ld);
+    double* xn = bk.ws("acos_xn", Kc);
+    double* csp = bk.ws("ef_csp", (size_t)chunks * Kc);
+    double* pv = bk.ws("ef_pv", (size_t)nb * chunks);
+    double* pw = bk.ws("ef_pl", (size_t)nb * chunks);
+    double* pb = bk.ws("ef_pb", (size_t)nb * chunks);
+    double* rs2 = bk.ws("acos_rs", M);
+    double* rsp = bk.ws("pb_rsp", (size_t)32 * M);
+    NEED(F2); NEED(xn); NEED(csp); NEED(pv); NEED(pw); NEED(pb); NEED(rs2); NEED(rsp);
+    hipLaunchKernelGGL(rownorm_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, Xcol, Kc, Ld, xn);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(acos_e_form_kernel, dim3(nb, chunks), dim3(256), 0, ctx->stream, dKuf, ld, Kuf, F2, M, rpc, Kc, L.variance, L.acos_w, L.acos_b,
+                       L.zn, xn, csp, pv, pw, pb);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, csp, chunks, Kc, cs);
+    LAUNCH_CHECK(ctx);
+    DCGP_TRY(add_scalar(bk, L, 0, pv, (long)nb * chunks, 1.0 / L.variance));
+    DCGP_TRY(add_scalar(bk, L, 1, pw, (long)nb * chunks, 1.0));
+    DCGP_TRY(add_scalar(bk, L, 2, pb, (long)nb * chunks, 1.0));
+    {   // rowsum(F2) / Q
+      const int rch = (int)std::min<long>(32, (Kc + 4095) / 4096);
+      const long cpc = round_up_l((Kc + rch - 1) / rch, 256);
+      hipLaunchKernelGGL(rowsum_big_kernel, dim3(M, rch), dim3(256), 0, ctx->stream, F2, ld, Kc, cpc, M, rsp);
+      LAUNCH_CHECK(ctx);
+      hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks_for(M)), dim3(256), 0, ctx->stream, rsp, rch, (long)M, rs2);
+      LAUNCH_CHECK(ctx);
+      hipLaunchKernelGGL(acos_divide_kernel, dim3(blocks_for(M)), dim3(256), 0, ctx->stream, rs2, L.zn, M, L.acos_w, L.acos_b);
+      LAUNCH_CHECK(ctx);
+    }
+    DCGP_TRY(patch_backward(bk, L, dKuf, ld, Kc, cs, Xcol, dXcol, 0, nullptr, dzp, rs2, L.acos_w));
+  } else {
+    DCGP_TRY(e_form(bk, L, dKuf, ld, 1, nullptr, 1.0, Kuf, ld, dKuf, ld, Kc, cs, nullptr));   // E over dKuf
+    DCGP_TRY(patch_backward(bk, L, dKuf, ld, Kc, cs, Xcol, dXcol, 0, nullptr, dzp));
+  }
   if (dXin) {
     const long n = (long)rows * L.v.H * L.v.W * L.v.C;
     hipLaunchKernelGGL(col2im_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, dXcol, rows, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s, L.v.Ho,
@@ -964,7 +1112,7 @@ int dense_head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int 
   DCGP_TRY(gemm_gen(ctx, mk(L.g.Linv, Mp, 1, Kzx, ld, 1, A1, ld, M, rows, M)));
   DCGP_TRY(cond_backward(bk, L, A1, ld, rows, gm, gv, dKzx, S, gkd));
   DCGP_TRY(kl_backward(bk, L, L.white ? nullptr : S));
-  DCGP_TRY(add_scalar(bk, L, false, gkd, rows, 1.0));             // Kdiag = variance
+  DCGP_TRY(add_scalar(bk, L, 0, gkd, rows, 1.0));             // Kdiag = variance
   hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks_for((long)M * D)), dim3(256), 0, ctx->stream, L.Z, M, (long)M, D, L.in_scale, Zs);
   LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks_for((long)rows * D)), dim3(256), 0, ctx->stream, Xin, n_mod, (long)rows, D, L.in_scale, Xs);
@@ -1049,8 +1197,8 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
     LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(kdiag_backward_kernel, dim3((P + 3) / 4, rows), dim3(256), 0, ctx->stream, Gm, norms, gkd, L.w, P, L.variance, inv_l2, dwn, pv, pl);
     LAUNCH_CHECK(ctx);
-    DCGP_TRY(add_scalar(bk, L, false, pv, (long)rows * P, 1.0 / L.variance));
-    DCGP_TRY(add_scalar(bk, L, true, pl, (long)rows * P, inv_l2 / L.ls));
+    DCGP_TRY(add_scalar(bk, L, 0, pv, (long)rows * P, 1.0 / L.variance));
+    DCGP_TRY(add_scalar(bk, L, 1, pl, (long)rows * P, inv_l2 / L.ls));
     hipLaunchKernelGGL(strided_sum_kernel, dim3(P), dim3(256), 0, ctx->stream, dwn, rows, P, 1.0, 1, L.gw);
     LAUNCH_CHECK(ctx);
     if (dXin) {
@@ -1091,7 +1239,7 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
   const int nl = (int)m->layers.size(), S = m->S;
   if (!m->keep_outputs) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: the forward pass must keep the layer outputs");
   for (auto& l : m->layers) {
-    if (l->base_type != 0) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: only RBF base kernels have a backward pass");
+    if (l->base_type != 0 && l->is_head) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: the head kernels are RBF-based");
   }
   const double* gh = gauss_hermite_table(ctx);
   if (!gh) return DCGP_ERR_ALLOC;
@@ -1185,7 +1333,8 @@ int dcgp_model_get_grad(dcgp_model* model, int layer, const char* which, double*
   else if (!strcmp(which, "q_mu")) { src = L.gq_mu; n = (size_t)L.M * L.R; }
   else if (!strcmp(which, "q_sqrt")) { src = L.gq_sqrt; n = (size_t)L.R * L.M * L.M; }
   else if (!strcmp(which, "variance")) { src = L.gscal; n = 1; }
-  else if (!strcmp(which, "lengthscale")) { src = L.gscal + 1; n = 1; }
+  else if (!strcmp(which, "lengthscale") || !strcmp(which, "weight_variances")) { src = L.gscal + 1; n = 1; }
+  else if (!strcmp(which, "bias_variance")) { src = L.gscal + 2; n = 1; }
   else if (!strcmp(which, "w")) {
     if (!L.is_head) return ctx_fail(ctx, DCGP_ERR_ARG, "get_grad: only the head has patch weights");
     src = L.gw; n = (size_t)L.v.P;
@@ -1231,29 +1380,30 @@ int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta
     return DCGP_OK;
   };
   const int nl = (int)model->layers.size();
-  double* h = ctx->h_scratch;   // 64 pinned doubles: {variance, lengthscale} per layer
+  double* h = ctx->h_scratch;   // 64 pinned doubles: {variance, p1, p2} per layer (at most 8 layers)
   for (int li = 0; li < nl; ++li) {
     LayerState& L = *model->layers[li];
     if (!L.gZ) return ctx_fail(ctx, DCGP_ERR_ARG, "adam_step: call dcgp_elbo_grad first");
     DCGP_TRY(L.ensure_adam());
-    h[2 * li] = L.variance; h[2 * li + 1] = L.ls;
-    HIP_TRY(ctx, hipMemcpyAsync(L.hyp, h + 2 * li, 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    h[3 * li] = L.variance; h[3 * li + 1] = L.base_type == 1 ? L.acos_w : L.ls; h[3 * li + 2] = L.base_type == 1 ? L.acos_b : 1.0;
+    HIP_TRY(ctx, hipMemcpyAsync(L.hyp, h + 3 * li, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (!(L.frozen & 1u)) DCGP_TRY(run(L.Z, L.gZ, L.aZ, (long)L.M * L.v.L, 0));
     if (!(L.frozen & 2u)) DCGP_TRY(run(L.q_mu, L.gq_mu, L.aq_mu, (long)L.M * L.R, 0));
     if (L.has_qsqrt && !(L.frozen & 4u)) DCGP_TRY(run(L.q_sqrt, L.gq_sqrt, L.aq_sqrt, (long)L.R * L.M * L.M, 0));   // upper triangle: zero gradient, zero step
     if (L.is_head && L.w && !(L.frozen & 8u)) DCGP_TRY(run(L.w, L.gw, L.aw, (long)L.v.P, 0));
-    if (!(L.frozen & 16u)) DCGP_TRY(run(L.hyp, L.gscal, L.ahyp, 2, 1));
+    if (!(L.frozen & 16u)) DCGP_TRY(run(L.hyp, L.gscal, L.ahyp, 3, 1));
     if (L.ard && !(L.frozen & 16u)) {   // dense head: per-dimension lengthscales, then refresh the staging scale 1 / l
       DCGP_TRY(run(L.ard, L.gard, L.aard, (long)L.v.L, 1));
       hipLaunchKernelGGL(reciprocal_kernel, dim3(blocks_for(L.v.L)), dim3(256), 0, ctx->stream, L.ard, L.v.L, L.in_scale);
       LAUNCH_CHECK(ctx);
     }
-    HIP_TRY(ctx, hipMemcpyAsync(h + 2 * li, L.hyp, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + 3 * li, L.hyp, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   for (int li = 0; li < nl; ++li) {
-    model->layers[li]->variance = h[2 * li];
-    model->layers[li]->ls = h[2 * li + 1];
+    LayerState& L = *model->layers[li];
+    L.variance = h[3 * li];
+    if (L.base_type == 1) { L.acos_w = h[3 * li + 1]; L.acos_b = h[3 * li + 2]; } else L.ls = h[3 * li + 1];
   }
   return DCGP_OK;
 }
@@ -1273,24 +1423,25 @@ int dcgp_model_sgd_step(dcgp_model* model, double lr) {
     LayerState& L = *model->layers[li];
     if (!L.gZ) return ctx_fail(ctx, DCGP_ERR_ARG, "sgd_step: call dcgp_elbo_grad first");
     DCGP_TRY(L.ensure_adam());   // for the device copy of the hyper-parameters
-    h[2 * li] = L.variance; h[2 * li + 1] = L.ls;
-    HIP_TRY(ctx, hipMemcpyAsync(L.hyp, h + 2 * li, 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    h[3 * li] = L.variance; h[3 * li + 1] = L.base_type == 1 ? L.acos_w : L.ls; h[3 * li + 2] = L.base_type == 1 ? L.acos_b : 1.0;
+    HIP_TRY(ctx, hipMemcpyAsync(L.hyp, h + 3 * li, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (!(L.frozen & 1u)) DCGP_TRY(run(L.Z, L.gZ, (long)L.M * L.v.L, 0));
     if (!(L.frozen & 2u)) DCGP_TRY(run(L.q_mu, L.gq_mu, (long)L.M * L.R, 0));
     if (L.has_qsqrt && !(L.frozen & 4u)) DCGP_TRY(run(L.q_sqrt, L.gq_sqrt, (long)L.R * L.M * L.M, 0));
     if (L.is_head && L.w && !(L.frozen & 8u)) DCGP_TRY(run(L.w, L.gw, (long)L.v.P, 0));
-    if (!(L.frozen & 16u)) DCGP_TRY(run(L.hyp, L.gscal, 2, 1));
+    if (!(L.frozen & 16u)) DCGP_TRY(run(L.hyp, L.gscal, 3, 1));
     if (L.ard && !(L.frozen & 16u)) {
       DCGP_TRY(run(L.ard, L.gard, (long)L.v.L, 1));
       hipLaunchKernelGGL(reciprocal_kernel, dim3(blocks_for(L.v.L)), dim3(256), 0, ctx->stream, L.ard, L.v.L, L.in_scale);
       LAUNCH_CHECK(ctx);
     }
-    HIP_TRY(ctx, hipMemcpyAsync(h + 2 * li, L.hyp, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + 3 * li, L.hyp, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   for (int li = 0; li < nl; ++li) {
-    model->layers[li]->variance = h[2 * li];
-    model->layers[li]->ls = h[2 * li + 1];
+    LayerState& L = *model->layers[li];
+    L.variance = h[3 * li];
+    if (L.base_type == 1) { L.acos_w = h[3 * li + 1]; L.acos_b = h[3 * li + 2]; } else L.ls = h[3 * li + 1];
   }
   return DCGP_OK;
 }
@@ -1317,9 +1468,9 @@ int dcgp_model_get_param(dcgp_model* model, int layer, const char* which, double
   LayerState& L = *model->layers[layer];
   const double* src = nullptr;
   size_t n = 0;
-  if (!strcmp(which, "variance") || !strcmp(which, "lengthscale")) {
+  if (!strcmp(which, "variance") || !strcmp(which, "lengthscale") || !strcmp(which, "weight_variances") || !strcmp(which, "bias_variance")) {
     if (count != 1) return ctx_fail(ctx, DCGP_ERR_ARG, "get_param(%s): expected 1 value", which);
-    out_host[0] = which[0] == 'v' ? L.variance : L.ls;
+    out_host[0] = which[0] == 'v' ? L.variance : (which[0] == 'l' ? L.ls : (which[0] == 'w' ? L.acos_w : L.acos_b));
     return DCGP_OK;
   }
   if (!strcmp(which, "Z")) { src = L.Z; n = (size_t)L.M * L.v.L; }

@@ -38,9 +38,10 @@ struct LayerState {
   GpMats g;
   double *ZT = nullptr, *zn = nullptr;
   // gradients of the ELBO with respect to the (constrained) parameter values, caller's layouts (grad.hip); allocated on
-  // first use.  gscal = {d variance, d lengthscale}; gslots = per-contribution partial sums of those two (16 + 16).
+  // first use.  gscal = {d variance, d p1, d p2} (p1 = lengthscale | ArcCosine weight variance, p2 = ArcCosine bias variance);
+  // gslots = per-contribution partial sums of those three (3 x 16).
   double *gZ = nullptr, *gq_mu = nullptr, *gq_sqrt = nullptr, *gw = nullptr, *gscal = nullptr, *gslots = nullptr;
-  // Adam moments, same layouts (allocated zeroed on the first optimiser step); hyp = {variance, lengthscale} device copy
+  // Adam moments, same layouts (allocated zeroed on the first optimiser step); hyp = {variance, p1, p2} device copy
   double *aZ[2] = {}, *aq_mu[2] = {}, *aq_sqrt[2] = {}, *aw[2] = {}, *ahyp[2] = {}, *hyp = nullptr;
   // optimiser: parameters excluded from dcgp_model_adam_step / dcgp_model_sgd_step (bit 0 Z, 1 q_mu, 2 q_sqrt, 3 w, 4 hyper-parameters)
   unsigned frozen = 0;
@@ -85,29 +86,29 @@ struct LayerState {
     return DCGP_OK;
   }
   // one contiguous block per layer [gZ | gq_mu | gq_sqrt | gw | gscal] so that a single all-reduce covers the layer
-  size_t grad_block_count() const { return (size_t)M * v.L + (size_t)M * R + (size_t)R * M * M + (size_t)v.P + 2 + (is_head ? (size_t)v.L : 0); }
+  size_t grad_block_count() const { return (size_t)M * v.L + (size_t)M * R + (size_t)R * M * M + (size_t)v.P + 3 + (is_head ? (size_t)v.L : 0); }
   int ensure_grads() {
     if (gZ) return DCGP_OK;
     double* blk = dalloc(grad_block_count());
-    gslots = dalloc(32);
+    gslots = dalloc(48);
     if (!blk || !gslots) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: gradient allocation failed");
     gZ = blk; gq_mu = gZ + (size_t)M * v.L; gq_sqrt = gq_mu + (size_t)M * R; gw = gq_sqrt + (size_t)R * M * M; gscal = gw + v.P;
-    gard = is_head ? gscal + 2 : nullptr;   // [L] d / d ARD lengthscales (dense head), zero otherwise
+    gard = is_head ? gscal + 3 : nullptr;   // [L] d / d ARD lengthscales (dense head), zero otherwise
     return DCGP_OK;
   }
   int ensure_adam() {
     if (hyp) return DCGP_OK;
     const size_t nz = (size_t)M * v.L, nm = (size_t)M * R, nq = (size_t)R * M * M, nw = (size_t)v.P;
     for (int k = 0; k < 2; ++k) {
-      aZ[k] = dalloc(nz); aq_mu[k] = dalloc(nm); aq_sqrt[k] = dalloc(nq); aw[k] = dalloc(nw); ahyp[k] = dalloc(2);
+      aZ[k] = dalloc(nz); aq_mu[k] = dalloc(nm); aq_sqrt[k] = dalloc(nq); aw[k] = dalloc(nw); ahyp[k] = dalloc(3);
       if (!aZ[k] || !aq_mu[k] || !aq_sqrt[k] || !aw[k] || !ahyp[k]) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: optimiser state allocation failed");
       HIP_TRY(ctx, hipMemsetAsync(aZ[k], 0, nz * sizeof(double), ctx->stream));
       HIP_TRY(ctx, hipMemsetAsync(aq_mu[k], 0, nm * sizeof(double), ctx->stream));
       HIP_TRY(ctx, hipMemsetAsync(aq_sqrt[k], 0, nq * sizeof(double), ctx->stream));
       HIP_TRY(ctx, hipMemsetAsync(aw[k], 0, (nw ? nw : 2) * sizeof(double), ctx->stream));
-      HIP_TRY(ctx, hipMemsetAsync(ahyp[k], 0, 2 * sizeof(double), ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync(ahyp[k], 0, 3 * sizeof(double), ctx->stream));
     }
-    hyp = dalloc(2);
+    hyp = dalloc(3);
     if (!hyp) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: optimiser state allocation failed");
     if (ard)
       for (int k = 0; k < 2; ++k) {

@@ -205,6 +205,9 @@ class DGP_Base:
             if head and getattr(l.kern, "ARD", False):       # dense RBF(ARD) head: one lengthscale per input dimension
                 del shapes["lengthscale"]
                 shapes["ard_lengthscales"] = (np.size(l.kern.lengthscales),)
+            if not head and not hasattr(l.base_kernel, "lengthscales"):   # ArcCosine(order 0) base kernel
+                del shapes["lengthscale"]
+                shapes["weight_variances"], shapes["bias_variance"] = (), ()
             g = {}
             for which, shp in shapes.items():
                 buf = np.empty(shp, np.float64)
@@ -297,6 +300,9 @@ class DGP_Base:
                 kern.lengthscales = pull(li, "ard_lengthscales", (np.size(kern.lengthscales),))
             elif hasattr(kern, "lengthscales"):
                 kern.lengthscales = float(pull(li, "lengthscale", ()))
+            else:                                             # ArcCosine(order 0)
+                kern.weight_variances = float(pull(li, "weight_variances", ()))
+                kern.bias_variance = float(pull(li, "bias_variance", ()))
             if head and hasattr(l.kern, "patch_weights"):
                 l.kern.patch_weights = pull(li, "w", np.shape(l.kern.patch_weights))
 

@@ -188,13 +188,14 @@ int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int 
 /* The ELBO of dcgp_elbo_forward AND its gradient with respect to every trainable value (what TensorFlow autodiff
  * hands the optimiser at conv_gp/experiment.py:84-108): Z, q_mu, q_sqrt (lower triangle), base-kernel variance and
  * lengthscale of every layer, patch_weights of the head -- constrained values, not gpflow's unconstrained ones.
- * RBF base kernels (ArcCosine models are rejected).  dedup_layer0 as in dcgp_elbo_forward: the first layer's conditional
+ * dedup_layer0 as in dcgp_elbo_forward: the first layer's conditional
  * and its reverse pass run on the N distinct images (the S gradients per image are added first) -- same values.
  * The gradients stay on the device; read them with dcgp_model_get_grad. */
 int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
                    const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, double* out_host,
                    int* info_host);
-/* which = "Z" [M, L], "q_mu" [M, R], "q_sqrt" [R, M, M], "variance" [1], "lengthscale" [1], "w" [P] (head),
+/* which = "Z" [M, L], "q_mu" [M, R], "q_sqrt" [R, M, M], "variance" [1], "lengthscale" [1] (RBF) or "weight_variances" [1] and
+ * "bias_variance" [1] (ArcCosine conv layers), "w" [P] (head),
  * "ard_lengthscales" [D] (dense RBF(ARD) head; its scalar "lengthscale" gradient is 0). */
 int dcgp_model_get_grad(dcgp_model* model, int layer, const char* which, double* out_host, size_t count);
 /* Data parallelism of the gradient: every rank holds a shard of the batch and the full parameters.  The data part of

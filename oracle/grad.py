@@ -8,7 +8,8 @@ file differentiates the oracle's forward pass (`oracle/layers.py`, `oracle/condi
 differences of `DGP_Base.compute_log_likelihood` (tests/test_oracle_cpu.py).  PARITY UNPINNED in the same
 sense as the rest of the oracle.
 
-Scope: RBF base kernels with one lengthscale, `ConvLayer`s (mean function None or the fixed `Conv2dMean`) followed by an
+Scope: RBF base kernels with one lengthscale -- or ArcCosine(order 0) on the conv layers, pinned at kernel level only
+(finite differences of the ELBO cannot see past the rounding noise of acos(1 - 1e-15) on the K_uu diagonal) --, `ConvLayer`s (mean function None or the fixed `Conv2dMean`) followed by an
 `SVGP_Layer` whose kernel is `ConvKernel`, `AdditivePatchKernel` or the dense `RBF(ARD=True)` of `--last-kernel rbf`;
 whitened or not.  Gradients are taken
 with respect to the constrained values (variance, lengthscales, Z, q_mu, q_sqrt (lower triangle),
@@ -109,6 +110,41 @@ def _kuu_backward(kern, Z, dK):
     return dZ, E.sum() / kern.variance, np.sum(E * d2) / kern.lengthscales ** 3
 
 
+def _acos_backward(kern, Zm, Xc, dK, skip_diag=False):
+    """ArcCosine(order 0) adjoint (oracle/gpflow_ref.py ArcCosine.K): K = variance (pi - theta) / pi, theta = acos(c'),
+    c' = 1e-15 + (1 - 2e-15) c, c = (w x.z + b) / sqrt((w |x|^2 + b)(w |z|^2 + b)).  dK = dLoss/dK [M x N].
+    Returns dZ, dX, dvariance, dweight_variances, dbias_variance.  ``skip_diag`` (K_uu: both arguments are Z): on the
+    diagonal c == 1 identically in z, w and b, so those entries carry no gradient except through ``variance`` -- while
+    dK/dc = variance / (pi sin(theta)) is ~2e7 there and would multiply rounding noise."""
+    w, b, var = kern.weight_variances, kern.bias_variance, kern.variance
+    A = w * np.sum(Xc * Xc, 1) + b                      # [N]
+    Q = w * np.sum(Zm * Zm, 1) + b                      # [M]
+    s = Zm @ Xc.T
+    rt = np.sqrt(Q[:, None] * A[None, :])
+    c = (w * s + b) / rt
+    cp = np.minimum(1e-15 + (1.0 - 2e-15) * c, 1.0)
+    theta = np.arccos(cp)
+    K = var * (np.pi - theta) / np.pi
+    with np.errstate(divide="ignore", invalid="ignore"):
+        F = dK * var / np.pi * (1.0 - 2e-15) / np.sin(theta)           # dLoss/dc
+    if skip_diag:
+        F[np.diag_indices(min(F.shape))] = 0.0
+    F1 = F / rt
+    F2 = F * c
+    dZ = w * (F1 @ Xc - (F2.sum(1) / Q)[:, None] * Zm)
+    dX = w * (F1.T @ Zm - (F2.sum(0) / A)[:, None] * Xc)
+    a2, q2 = (A - b) / w, (Q - b) / w                  # |x|^2, |z|^2
+    dw = np.sum(F1 * s) - 0.5 * np.sum(F2 * (a2[None, :] / A[None, :] + q2[:, None] / Q[:, None]))
+    db = np.sum(F1) - 0.5 * np.sum(F2 * (1.0 / A[None, :] + 1.0 / Q[:, None]))
+    return dZ, dX, np.sum(dK * K) / var, dw, db
+
+
+def _acos_kuu_backward(kern, Z, dK):
+    """K = acos(Z, Z) (+ jitter I) with dLoss/dK any matrix: both arguments are Z."""
+    dZa, dZb, dvar, dw, db = _acos_backward(kern, Z, Z, dK, skip_diag=True)
+    return dZa + dZb, dvar, dw, db
+
+
 def robustmax_backward(lik, Fmu, Fvar, Y):
     """d sum_n ve_n / d(Fmu, Fvar) for MultiClass.variational_expectations (oracle/gpflow_ref.py)."""
     gh_x, gh_w = np.polynomial.hermite.hermgauss(lik.num_gauss_hermite_points)
@@ -160,7 +196,8 @@ def conv_layer_backward(layer, X, gmean, gvar):
     Nt, P, R, M = X.shape[0], layer.patch_count, layer.gp_count, layer.num_inducing
     NHWC = X.reshape(Nt, v.input_size[0], v.input_size[1], layer.feature_maps_in)
     Xc = v.extract_patches_PNL(NHWC).reshape(P * Nt, v.patch_length)        # column c = p * Nt + n
-    Kuf, d2 = _rbf(kern, layer.Z, Xc)
+    acos = not hasattr(kern, "lengthscales")             # ArcCosine(order 0) base kernel (--base-kernel acos)
+    Kuf, d2 = (kern.K(layer.Z, Xc), None) if acos else _rbf(kern, layer.Z, Xc)
     Kuu = layer.conv_kernel.Kuu(layer.Z)
     L = np.linalg.cholesky(Kuu)
     A1 = solve_triangular(L, Kuf, lower=True)
@@ -173,13 +210,21 @@ def conv_layer_backward(layer, X, gmean, gvar):
     gm = np.transpose(gmean.reshape(Nt, P, R), (1, 0, 2)).reshape(P * Nt, R)
     gv = np.transpose(gvar.reshape(Nt, P, R), (1, 0, 2)).reshape(P * Nt, R)
     dKuf, dL, dq_mu, dq_sqrt, dKnn = _cond_backward(L, A1, alpha, G, gm, gv, layer.white, layer.q_mu, Lq)
-    dZ, dXc, dvar, dls = _rbf_cross_backward(kern, layer.Z, Xc, Kuf, d2, dKuf)
+    if acos:
+        dZ, dXc, dvar, dw, db = _acos_backward(kern, layer.Z, Xc, dKuf)
+        dZ2, dvar2, dw2, db2 = _acos_kuu_backward(kern, layer.Z, _chol_backward(L, dL))
+        hyper = {"weight_variances": dw + dw2, "bias_variance": db + db2}
+    else:
+        dZ, dXc, dvar, dls = _rbf_cross_backward(kern, layer.Z, Xc, Kuf, d2, dKuf)
+        dZ2, dvar2, dls2 = _kuu_backward(kern, layer.Z, _chol_backward(L, dL))
+        hyper = {"lengthscales": dls + dls2}
     dvar += dKnn.sum()                                                      # Knn = variance for every column
-    dZ2, dvar2, dls2 = _kuu_backward(kern, layer.Z, _chol_backward(L, dL))
     dX = _patch_scatter(v, np.transpose(dXc.reshape(P, Nt, -1), (1, 0, 2)), Nt).reshape(Nt, -1)
     if layer.mean_function is not None:          # Conv2dMean (fixed filter): mean += centre pixel of channel 0 on map 0
         dX = dX + layer.mean_function.backward(NHWC, gmean).reshape(Nt, -1)
-    return dX, {"Z": dZ + dZ2, "variance": dvar + dvar2, "lengthscales": dls + dls2, "q_mu": dq_mu, "q_sqrt": dq_sqrt}
+    g = {"Z": dZ + dZ2, "variance": dvar + dvar2, "q_mu": dq_mu, "q_sqrt": dq_sqrt}
+    g.update(hyper)
+    return dX, g
 
 
 def conv_layer_kl_backward(layer):
@@ -189,6 +234,9 @@ def conv_layer_kl_backward(layer):
         return {"q_mu": dq_mu, "q_sqrt": dLq}
     Lp = np.linalg.cholesky(layer.conv_kernel.Kuu(layer.Z0))
     dq_mu, dLq, dK = _kl_backward(layer.q_mu, Lq, Lp)
+    if not hasattr(layer.base_kernel, "lengthscales"):
+        _, dvar, dw, db = _acos_kuu_backward(layer.base_kernel, layer.Z0, dK)     # Z0 is frozen
+        return {"q_mu": dq_mu, "q_sqrt": dLq, "variance": dvar, "weight_variances": dw, "bias_variance": db}
     _, dvar, dls = _kuu_backward(layer.base_kernel, layer.Z0, dK)          # Z0 is frozen
     return {"q_mu": dq_mu, "q_sqrt": dLq, "variance": dvar, "lengthscales": dls}
 

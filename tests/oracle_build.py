@@ -47,8 +47,12 @@ def oracle_param_handles(model):
         out.append((li, "q_mu", lambda l=l: l.q_mu, lambda v, l=l: setattr(l, "q_mu", v)))
         out.append((li, "q_sqrt", lambda l=l: l.q_sqrt, lambda v, l=l: setattr(l, "q_sqrt", v)))
         out.append((li, "variance", lambda k=kern: np.array(k.variance), lambda v, k=kern: setattr(k, "variance", float(v))))
-        out.append((li, "lengthscales", lambda k=kern: np.array(k.lengthscales),
-                    lambda v, k=kern: setattr(k, "lengthscales", np.array(v, np.float64) if np.ndim(v) else float(v))))
+        if hasattr(kern, "lengthscales"):
+            out.append((li, "lengthscales", lambda k=kern: np.array(k.lengthscales),
+                        lambda v, k=kern: setattr(k, "lengthscales", np.array(v, np.float64) if np.ndim(v) else float(v))))
+        else:                                         # ArcCosine(order 0)
+            for pname in ("weight_variances", "bias_variance"):
+                out.append((li, pname, lambda k=kern, n=pname: np.array(getattr(k, n)), lambda v, k=kern, n=pname: setattr(k, n, float(v))))
         if head and hasattr(l.kern, "patch_weights"):
             out.append((li, "patch_weights", lambda l=l: l.kern.patch_weights, lambda v, l=l: setattr(l.kern, "patch_weights", v)))
     return out

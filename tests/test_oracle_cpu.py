@@ -268,3 +268,41 @@ def test_shard_gradients_sum_to_full_batch_gradient():
     for a, b in zip(tot, g):
         for k in b:
             assert np.abs(a[k] - b[k]).max() <= 1e-10 * max(np.abs(b[k]).max(), 1.0), k
+
+
+def test_arccosine_adjoint_against_finite_differences():
+    """oracle/grad.py _acos_backward (checker of the device ArcCosine reverse pass) at kernel level: sum(dK o K) with respect
+    to Z, X, variance, weight_variances, bias_variance -- cross-covariance, and K_uu with its diagonal excluded (there
+    c == 1 identically and acos(1 - 1e-15 +- rounding) makes any finite difference meaningless)."""
+    from oracle.gpflow_ref import ArcCosine
+    from oracle.grad import _acos_backward, _acos_kuu_backward
+    rng = np.random.default_rng(0)
+    k = ArcCosine(9, order=0, variance=1.7, weight_variances=0.8, bias_variance=1.3)
+    Z, X = rng.standard_normal((5, 9)), rng.standard_normal((7, 9))
+
+    def check(f, grads, arrays):
+        for name, g in grads.items():
+            if name in arrays:
+                a = arrays[name]
+                d = rng.standard_normal(a.shape)
+                a0 = a.copy()
+                a[...] = a0 + 1e-6 * d; fp = f()
+                a[...] = a0 - 1e-6 * d; fm = f()
+                a[...] = a0
+                fd, an = (fp - fm) / 2e-6, float(np.sum(g * d))
+            else:
+                v0 = getattr(k, name)
+                setattr(k, name, v0 + 1e-6); fp = f()
+                setattr(k, name, v0 - 1e-6); fm = f()
+                setattr(k, name, v0)
+                fd, an = (fp - fm) / 2e-6, float(g)
+            assert abs(fd - an) <= 1e-6 * max(abs(fd), abs(an), 1.0), (name, fd, an)
+
+    dK = rng.standard_normal((5, 7))
+    dZ, dX, dv, dw, db = _acos_backward(k, Z, X, dK)
+    check(lambda: float(np.sum(dK * k.K(Z, X))), {"Z": dZ, "X": dX, "variance": dv, "weight_variances": dw, "bias_variance": db},
+          {"Z": Z, "X": X})
+    dK2 = rng.standard_normal((5, 5))
+    np.fill_diagonal(dK2, 0.0)
+    dZ2, dv2, dw2, db2 = _acos_kuu_backward(k, Z, dK2)
+    check(lambda: float(np.sum(dK2 * k.K(Z))), {"Z": dZ2, "variance": dv2, "weight_variances": dw2, "bias_variance": db2}, {"Z": Z})
