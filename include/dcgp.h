@@ -186,10 +186,11 @@ int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int 
                       const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0,
                       double* out_host, int* info_host);
 /* The ELBO of dcgp_elbo_forward AND its gradient with respect to every trainable value (what TensorFlow autodiff
- * hands the optimiser at conv_gp/experiment.py:84-108): Z, q_mu, q_sqrt (lower triangle), base-kernel variance and
- * lengthscale of every layer, patch_weights of the head -- constrained values, not gpflow's unconstrained ones.
- * dedup_layer0 as in dcgp_elbo_forward: the first layer's conditional
- * and its reverse pass run on the N distinct images (the S gradients per image are added first) -- same values.
+ * hands the optimiser at conv_gp/experiment.py:84-108): Z, q_mu, q_sqrt (lower triangle), the base-kernel
+ * hyper-parameters of every layer (variance + lengthscale, ArcCosine: variance + weight / bias variances, dense head:
+ * variance + one lengthscale per input dimension), patch_weights of the head -- constrained values, not gpflow's
+ * unconstrained ones.  dedup_layer0 as in dcgp_elbo_forward: the first layer's conditional and its reverse pass run on
+ * the N distinct images (the S gradients per image are added first) -- same values.
  * The gradients stay on the device; read them with dcgp_model_get_grad. */
 int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
                    const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, double* out_host,
