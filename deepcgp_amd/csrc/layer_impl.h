@@ -45,6 +45,7 @@ struct LayerState {
   double *aZ[2] = {}, *aq_mu[2] = {}, *aq_sqrt[2] = {}, *aw[2] = {}, *ahyp[2] = {}, *hyp = nullptr;
   // optimiser: parameters excluded from dcgp_model_adam_step / dcgp_model_sgd_step (bit 0 Z, 1 q_mu, 2 q_sqrt, 3 w, 4 hyper-parameters)
   unsigned frozen = 0;
+  std::shared_ptr<void> natgrad_state;   // scratch of dcgp_model_natgrad_step (natgrad.hip), created on first use
   std::vector<void*> owned;
 
   ~LayerState() {

@@ -90,6 +90,7 @@ _SIGS = {
     "dcgp_model_grad_block": [_vp, _i, C.POINTER(_vp), C.POINTER(C.c_size_t)],
     "dcgp_model_sgd_step": [_vp, _d],
     "dcgp_model_set_trainable": [_vp, _i, C.c_char_p, _i],
+    "dcgp_model_natgrad_step": [_vp, _d, _ip],
     "dcgp_model_predict_y": [_vp, _vp, _i, _i, C.POINTER(_vp), _u64, _vp, _vp, _ip],
     "dcgp_model_layer_output": [_vp, _i, _vp, _vp, _vp, _ip, _ip],
     "dcgp_comm_unique_id": [C.c_char_p],

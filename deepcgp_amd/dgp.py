@@ -234,51 +234,15 @@ class DGP_Base:
 
     def natgrad_step(self, gamma):
         """One natural-gradient step of size ``gamma`` on every layer's (q_mu, q_sqrt) -- gpflow.train.NatGradOptimizer
-        on var_list=[(l.q_mu, l.q_sqrt)] as set up at conv_gp/experiment.py:90-99 (Salimbeni, Eleftheriadis & Hensman 2018;
-        restated from the published algorithm, gpflow itself is not in the reference tree).  With q = N(mu, S = L L^T):
-        natural parameters theta = (S^-1 mu, -S^-1 / 2), expectation parameters eta = (mu, S + mu mu^T) and
-        theta <- theta + gamma dELBO/d eta, where dELBO/d eta2 = dELBO/dS and dELBO/d eta1 = dELBO/dmu - 2 (dELBO/dS) mu.
-        Uses the gradients the last ``compute_gradients`` left on the device; the M x M algebra of this step is done on
-        the host in NumPy (R matrices of M x M per layer), the updated values are pushed back with dcgp_model_set_param."""
-        from scipy.linalg import solve_triangular
-        L_, ctx = dev.lib(), self._ctx
-        updates = []
-        for li, l in enumerate(self.layers):
-            head = li == len(self.layers) - 1
-            M, R = l.num_inducing, (l.num_outputs if head else l.gp_count)
-            bufs = {}
-            for which, shp in (("q_mu", (M, R)), ("q_sqrt", (R, M, M))):
-                g = np.empty(shp, np.float64)
-                ctx._check(L_.dcgp_model_get_grad(self._model, li, which.encode(), g.ctypes.data, g.size))
-                v = np.empty(shp, np.float64)
-                ctx._check(L_.dcgp_model_get_param(self._model, li, which.encode(), v.ctypes.data, v.size))
-                bufs[which] = (v, g)
-            (mu, g_mu), (Lq, g_L) = bufs["q_mu"], bufs["q_sqrt"]
-            new_mu, new_L = np.empty_like(mu), np.zeros_like(Lq)
-            I = np.eye(M)
-            for r in range(R):
-                Lr = np.tril(Lq[r])
-                # dELBO/dS from dELBO/dL for S = L L^T (Cholesky adjoint, symmetric form)
-                P = np.tril(Lr.T @ np.tril(g_L[r]))
-                P[np.diag_indices(M)] *= 0.5
-                Sbar = solve_triangular(Lr, solve_triangular(Lr, P.T, lower=True, trans='T').T, lower=True, trans='T')
-                Sbar = 0.5 * (Sbar + Sbar.T)
-                Linv = solve_triangular(Lr, I, lower=True)
-                Sinv = Linv.T @ Linv
-                m = mu[:, r]
-                theta1 = Sinv @ m + gamma * (g_mu[:, r] - 2.0 * Sbar @ m)
-                prec = Sinv - 2.0 * gamma * Sbar                   # -2 theta2'
-                Lp = np.linalg.cholesky(0.5 * (prec + prec.T))     # raises if the step leaves the positive-definite cone
-                Lpinv = solve_triangular(Lp, I, lower=True)
-                S_new = Lpinv.T @ Lpinv
-                new_mu[:, r] = S_new @ theta1
-                new_L[r] = np.linalg.cholesky(0.5 * (S_new + S_new.T))
-            updates.append((li, l, new_mu, new_L))
-        for li, l, new_mu, new_L in updates:          # nothing is pushed unless every layer's step stayed positive definite
-            for which, val in (("q_mu", new_mu), ("q_sqrt", new_L)):
-                a = np.ascontiguousarray(val, np.float64)
-                ctx._check(L_.dcgp_model_set_param(self._model, li, which.encode(), a.ctypes.data, a.size))
-            l.q_mu, l.q_sqrt = new_mu, new_L
+        on var_list=[(l.q_mu, l.q_sqrt)] as set up at conv_gp/experiment.py:90-99 -- from the gradients the last
+        ``compute_gradients`` left on the device (dcgp_model_natgrad_step, csrc/natgrad.hip: batched Cholesky chains and
+        GEMMs, nothing crosses the bus).  Raises ``numpy.linalg.LinAlgError`` and leaves the parameters untouched when
+        the step leaves the positive-definite cone (the reference's loop then scales gamma back, experiment.py:36-49)."""
+        info = C.c_int(0)
+        rc = dev.lib().dcgp_model_natgrad_step(self._model, float(gamma), C.byref(info))
+        if rc == dev.ERR_NOT_PD:
+            raise np.linalg.LinAlgError("natural-gradient step not positive definite (column %d); reduce gamma" % info.value)
+        self._ctx._check(rc, info)
 
     def pull_parameters(self):
         """Read the device copy of every trainable value back into the layer / kernel objects."""

@@ -217,6 +217,11 @@ int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta
 /* Plain gradient ascent in the same unconstrained space (gpflow.train.GradientDescentOptimizer, the "SGD" branch
  * at conv_gp/experiment.py:100-103). */
 int dcgp_model_sgd_step(dcgp_model* model, double lr);
+/* One natural-gradient step of size gamma on every layer's (q_mu, q_sqrt) from the gradients of the last dcgp_elbo_grad:
+ * gpflow.train.NatGradOptimizer(gamma) on var_list = [(l.q_mu, l.q_sqrt)] (conv_gp/experiment.py:90-99), natural-parameter
+ * form theta <- theta + gamma dELBO/d eta.  Returns DCGP_ERR_NOT_PD (nothing written, *info = failing column) when a new
+ * precision matrix is not positive definite: the reference's loop then scales gamma by 0.2 and retries (:36-49). */
+int dcgp_model_natgrad_step(dcgp_model* model, double gamma, int* info_host);
 /* param.set_trainable(False / True) (conv_gp/experiment.py:93-95, models.py:100): parameters switched off are left
  * alone by the Adam / SGD steps.  which = "Z", "q_mu", "q_sqrt", "w", or "hyper" (variance and lengthscale). */
 int dcgp_model_set_trainable(dcgp_model* model, int layer, const char* which, int on);

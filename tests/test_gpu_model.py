@@ -614,6 +614,7 @@ def test_sgd_natgrad_and_trainable_flags(ctx):
     # (3)
     model.compute_gradients(X, Y, zs=zs, scale=0.0, fetch=False)
     model.natgrad_step(1.0)
+    model.pull_parameters()
     for li, l in enumerate(model.layers):
         o = ref.layers[li]
         head = li == len(model.layers) - 1
@@ -626,6 +627,23 @@ def test_sgd_natgrad_and_trainable_flags(ctx):
         assert np.abs(l.q_mu).max() < 1e-6
         for r in range(l.q_sqrt.shape[0]):
             assert rel(l.q_sqrt[r] @ l.q_sqrt[r].T, K) < 1e-6
+    # (3b) a step on the real objective against the NumPy restatement of the algorithm (tests/natgrad_ref.py), and the
+    # positive-definiteness failure: a far too large gamma must raise and leave the parameters untouched
+    from natgrad_ref import natgrad_reference
+    _, g = model.compute_gradients(X, Y, zs=zs)
+    before = [(np.array(l.q_mu), np.array(l.q_sqrt)) for l in model.layers]
+    model.natgrad_step(0.01)
+    model.pull_parameters()
+    for (mu0, L0), gl, l in zip(before, g, model.layers):
+        mu1, L1 = natgrad_reference(mu0, L0, gl["q_mu"], gl["q_sqrt"], 0.01)
+        assert rel(l.q_mu, mu1) < 1e-8 and rel(l.q_sqrt, L1) < 1e-8
+    model.compute_gradients(X, Y, zs=zs, fetch=False)
+    kept = [(np.array(l.q_mu), np.array(l.q_sqrt)) for l in model.layers]
+    with pytest.raises(np.linalg.LinAlgError):
+        model.natgrad_step(1e6)
+    model.pull_parameters()
+    for (mu0, L0), l in zip(kept, model.layers):
+        assert np.array_equal(l.q_mu, mu0) and np.array_equal(l.q_sqrt, L0)
     # (4)
     model.minibatch_size = N
     hist = train(model, 15, lr=0.01, optimizer="NatGrad", gamma=0.05, seed=3)
