@@ -205,17 +205,32 @@ def _sample_patches(HW_image, N, patch_size, patch_length):
     return out
 
 
+def kmeans(points, k, max_iter=300, tol=1e-4, rng=None):
+    """Lloyd's k-means on the device (dcgp_kmeans): sklearn.cluster.KMeans(n_clusters=k, init='random', n_init=1) in
+    its own terms -- k random observations as the initial centres, ``tol`` relative to the mean feature variance,
+    stop when the summed squared centre shift falls below it.  Returns the [k, d] centres."""
+    import ctypes as C
+    from . import device as dev
+    ctx = dev.get_context()
+    P = np.ascontiguousarray(points, np.float64)
+    n, d = P.shape
+    rows = np.ascontiguousarray((rng or np.random).choice(n, size=k, replace=False), np.int32)
+    dP, dC = ctx.to_device(P), ctx.empty((k, d))
+    iters = C.c_int(0)
+    ctx._check(dev.lib().dcgp_kmeans(ctx.handle, dP.ptr, n, d, k, rows.ctypes.data, int(max_iter), float(tol * np.mean(np.var(P, axis=0))),
+                                     dC.ptr, C.byref(iters)))
+    return dC.numpy()
+
+
 def _cluster_patches(NHWC_X, M, patch_size):
-    """k-means of 100*M random patches (conv_gp/kernels.py:147-164): one-off host-side init."""
-    from sklearn import cluster
+    """k-means of 100*M random patches (conv_gp/kernels.py:147-164); the patches are drawn on the host as the
+    reference draws them, the clustering runs on the device."""
     NHWC = NHWC_X.shape
     patch_length = patch_size ** 2 * NHWC[3]
     patches = np.zeros((M * 100, patch_length))
     for i in range(M * 100):
         patches[i] = _sample_patches(_sample(NHWC_X, 1)[0], 1, patch_size, patch_length)
-    k_means = cluster.KMeans(n_clusters=M, init='random', n_init=1)
-    k_means.fit(patches)
-    return k_means.cluster_centers_
+    return kmeans(patches, M)
 
 
 class InducingPoints:

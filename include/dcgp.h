@@ -242,6 +242,14 @@ int dcgp_model_predict_y(dcgp_model* model, const double* X, int N, int S,
 int dcgp_model_layer_output(dcgp_model* model, int layer, double* out_sample, double* out_mean,
                             double* out_var, int* rows, int* width);
 
+/* ---- initialisation ---------------------------------------------------------------------------------------------- */
+/* Lloyd's k-means of n points [n, d] (device) into k centres [k, d] (device): the inducing-patch initialisation of
+ * PatchInducingFeatures.from_images (conv_gp/kernels.py:147-164: sklearn KMeans(n_clusters=M, init='random')).
+ * init_rows_host: k row indices, the 'random' initial centres (drawn by the caller); stops after max_iter iterations or
+ * when the summed squared centre shift is <= tol.  Deterministic for given initial rows. */
+int dcgp_kmeans(dcgp_ctx* ctx, const double* X, long n, int d, int k, const int32_t* init_rows_host, int max_iter,
+                double tol, double* centers, int* iters_out);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------ */
 int dcgp_comm_unique_id(unsigned char* out_128bytes);
 int dcgp_comm_init_rank(dcgp_ctx* ctx, int nranks, int rank, const unsigned char* id_128bytes);

@@ -314,3 +314,38 @@ def test_rbf_ard_dense_head(ctx, white, D, M, N):
     close(m, om, 1e-9, "mean")
     close(v, ov, 1e-9, "var")
     close(layer.KL(), olayer.KL(), 1e-9, "KL")
+
+
+def test_kmeans_matches_numpy_lloyd(ctx):
+    """dcgp_kmeans (the inducing-patch initialisation, conv_gp/kernels.py:147-164) against Lloyd's algorithm in NumPy
+    from the same initial rows with the same stopping rule: same centres; and it is deterministic."""
+    from deepcgp_amd import kernels as K
+    rng = np.random.default_rng(0)
+    n, d, k = 3000, 9, 17
+    P = np.concatenate([rng.standard_normal((n // 3, d)) + c for c in (0.0, 3.0, -2.5)])
+    n = P.shape[0]
+
+    class FixedRng:
+        def __init__(self):
+            self.rows = np.random.default_rng(5).choice(n, size=k, replace=False)
+
+        def choice(self, n_, size, replace):
+            return self.rows
+    fr = FixedRng()
+    C1 = K.kmeans(P, k, rng=fr)
+    C2 = K.kmeans(P, k, rng=fr)
+    assert np.array_equal(C1, C2)
+    C = P[fr.rows].copy()
+    tol = 1e-4 * np.mean(np.var(P, axis=0))
+    for _ in range(300):
+        dist = (C * C).sum(1)[None, :] - 2.0 * P @ C.T
+        a = dist.argmin(1)
+        newC = C.copy()
+        for j in range(k):
+            if np.any(a == j):
+                newC[j] = P[a == j].mean(0)
+        shift = ((newC - C) ** 2).sum()
+        C = newC
+        if shift <= tol:
+            break
+    assert np.abs(C1 - C).max() < 1e-9
