@@ -58,9 +58,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
   if (a.rb_major) wgid = orig;   // ids stay interleaved over the XCDs: each XCD gets its share of the heavy blocks
   int ct, bz, rb;
   if (a.rb_major) {
-    // Launches of at most ~2 rounds: ALL heavy row blocks first, then the lighter ones -- the light blocks fill the
-    // tail while the heavy ones run, so the launch lasts one heavy block (mixed orders end with a heavy block that
-    // started late).  No fixed-stride heavy/light alternation either.
+    // ALL heavy row blocks first, then the lighter ones (longest-processing-time order): the light blocks fill the tail
+    // while the last heavy ones run, where mixed orders end with a heavy block that started late.  No fixed-stride
+    // heavy/light alternation either.  First used for launches of at most ~2 rounds; on the 14-round stage-3 launch it
+    // beats the Thue-Morse mixing below by 5 % as well (535 -> 509 us), so it is the order of every triangular launch.
     const int per = n_col_tiles * batch;
     const int rbk = (int)(wgid / per), rem = (int)(wgid % per);
     ct = rem / batch;
@@ -287,7 +288,8 @@ int launch(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
   size_t red = (size_t)WAVES_M * BN * sizeof(double);
   if (red > lds) lds = red;
   GemmArgs k = a;
-  k.rb_major = a.tri != 0 && nwg <= 1024;
+  static const bool mixed = getenv("DCGP_RB_MIXED") != nullptr;   // A/B switch: Thue-Morse mixed order for launches of many rounds
+  k.rb_major = a.tri != 0 && (nwg <= 1024 || !mixed);
   hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WAVES_M, WAVES_N, ABL>), dim3((unsigned)nwg), dim3(NT), lds, ctx->stream,
                      k, nct, nrb);
   LAUNCH_CHECK(ctx);
