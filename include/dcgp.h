@@ -225,7 +225,8 @@ int dcgp_model_natgrad_step(dcgp_model* model, double gamma, int* info_host);
 /* param.set_trainable(False / True) (conv_gp/experiment.py:93-95, models.py:100): parameters switched off are left
  * alone by the Adam / SGD steps.  which = "Z", "q_mu", "q_sqrt", "w", or "hyper" (variance and lengthscale). */
 int dcgp_model_set_trainable(dcgp_model* model, int layer, const char* which, int on);
-/* current (constrained) value of a parameter, names as dcgp_model_get_grad; the inverse of dcgp_model_set_param */
+/* current (constrained) value of a parameter, names as dcgp_model_get_grad; the inverse of dcgp_model_set_param -- what
+ * sess.run(param.constrained_tensor) returns when the reference writes its checkpoint (conv_gp/experiment.py:56-64) */
 int dcgp_model_get_param(dcgp_model* model, int layer, const char* which, double* out_host, size_t count);
 /* DGP_Base.propagate(X, S) -> last layer's Fmean, Fvar [S*N, R] (device buffers owned by caller) */
 int dcgp_model_propagate(dcgp_model* model, const double* X, int N, int S,
