@@ -83,6 +83,14 @@ def main():
             out["z%d" % i] = z
         for i in range(len(Fs)):
             out["Fs%d" % i], out["Fmean%d" % i], out["Fvar%d" % i] = Fs[i], Fm[i], Fv[i]
+        # the training step: gradient of that ELBO with respect to every parameter group (oracle/grad.py, itself pinned by
+        # finite differences in tests/test_oracle_cpu.py)
+        from oracle.grad import elbo_and_grad
+        eg, grads = elbo_and_grad(model, X, Y, zs)
+        assert abs(eg - elbo) <= 1e-12 * abs(elbo), name
+        for li, g in enumerate(grads):
+            for gname, val in g.items():
+                out["grad%d_%s" % (li, gname)] = np.asarray(val)
         np.savez_compressed(os.path.join(here, name + ".npz"), **out)
         print(name, "elbo", elbo, "bytes", os.path.getsize(os.path.join(here, name + ".npz")))
 

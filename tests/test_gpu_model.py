@@ -45,6 +45,16 @@ def test_golden_vectors(ctx, path):
     assert e_d == elbo if spec["convs"] else abs(e_d - elbo) <= 1e-13 * abs(elbo)
     # per-layer KL through the operator API agrees with the fused path
     assert abs(model.KL() - kl) <= 1e-10 * abs(kl)
+    # the training step against the committed gradient fixtures (tiled and de-duplicated first layer)
+    for dedup in (False, True):
+        model.dedup_layer0 = dedup
+        e_g, grads = model.compute_gradients(d["X"], d["Y"], zs=zs)
+        assert abs(e_g - float(d["elbo"])) <= RTOL * abs(float(d["elbo"]))
+        for li, g in enumerate(grads):
+            for name, val in g.items():
+                want = d["grad%d_%s" % (li, name)]
+                err = np.abs(val - want).max()
+                assert err < 1e-7 * np.abs(want).max() or err < 1e-8, (dedup, li, name, err)
     model.close()
 
 

@@ -167,6 +167,13 @@ def test_golden_vectors_pin_the_oracle(path):
     np.testing.assert_allclose(model.compute_log_likelihood(d["X"], d["Y"], zs=zs), float(d["elbo"]), rtol=1e-12)
     e2, d2, k2 = alt.elbo(spec, d["X"], d["Y"], zs, spec["num_data"])
     np.testing.assert_allclose([e2, d2, k2], [float(d["elbo"]), float(d["data_term"]), float(d["kl"])], rtol=1e-10)
+    # the training step's fixtures: gradient of that ELBO with respect to every parameter group
+    from oracle.grad import elbo_and_grad
+    _, grads = elbo_and_grad(model, d["X"], d["Y"], zs)
+    for li, g in enumerate(grads):
+        for name, val in g.items():
+            want = d["grad%d_%s" % (li, name)]
+            np.testing.assert_allclose(val, want, rtol=1e-9, atol=1e-9 * max(np.abs(want).max(), 1.0))
 
 
 def test_shard_sum_equals_full_batch():
