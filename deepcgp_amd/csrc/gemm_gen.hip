@@ -240,3 +240,20 @@ int gemm_gen(dcgp_ctx* ctx, const GenGemm& g) {
   if (g.M >= 128 && g.N >= 128 && g.K >= 4096) return gemm_gen_launch<128, 1024>(ctx, g, 512);
   return gemm_gen_launch<64, 256>(ctx, g, 1024);
 }
+
+// C-ABI view of the same kernel (tests drive every layout / edge case through it)
+extern "C" int dcgp_gemm_strided(dcgp_ctx* ctx, const double* A, long a_rs, long a_cs, long a_bs, const double* B, long b_rs, long b_cs,
+                                 long b_bs, double* C, long c_rs, long c_bs, int M, int N, int K, int batch, double alpha, int accumulate,
+                                 const double* colscale, long cs_s, long cs_bs, const double* kscale, long ks_s, long ks_bs, int lower_only) {
+  if (!ctx) return DCGP_ERR_ARG;
+  if (!A || !B || !C || M < 0 || N < 0 || K < 0 || batch < 0 || c_rs < N) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_strided: bad arguments");
+  GenGemm g;
+  g.A = A; g.a_rs = a_rs; g.a_cs = a_cs; g.a_bs = a_bs;
+  g.B = B; g.b_rs = b_rs; g.b_cs = b_cs; g.b_bs = b_bs;
+  g.C = C; g.c_rs = c_rs; g.c_bs = c_bs;
+  g.M = M; g.N = N; g.K = K; g.batch = batch; g.alpha = alpha; g.accumulate = accumulate;
+  g.colscale = colscale; g.cs_s = cs_s; g.cs_bs = cs_bs; g.kscale = kscale; g.ks_s = ks_s; g.ks_bs = ks_bs; g.lower_only = lower_only;
+  DCGP_TRY(gemm_gen(ctx, g));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}

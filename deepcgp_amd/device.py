@@ -93,6 +93,8 @@ _SIGS = {
     "dcgp_model_natgrad_step": [_vp, _d, _ip],
     "dcgp_model_predict_y": [_vp, _vp, _i, _i, C.POINTER(_vp), _u64, _vp, _vp, _ip],
     "dcgp_model_layer_output": [_vp, _i, _vp, _vp, _vp, _ip, _ip],
+    "dcgp_gemm_strided": [_vp, _vp, C.c_long, C.c_long, C.c_long, _vp, C.c_long, C.c_long, C.c_long, _vp, C.c_long, C.c_long,
+                          _i, _i, _i, _i, _d, _i, _vp, C.c_long, C.c_long, _vp, C.c_long, C.c_long, _i],
     "dcgp_kmeans": [_vp, _vp, C.c_long, _i, _i, _vp, _i, _d, _vp, _ip],
     "dcgp_comm_unique_id": [C.c_char_p],
     "dcgp_comm_init_rank": [_vp, _i, _i, C.c_char_p],

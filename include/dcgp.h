@@ -243,6 +243,16 @@ int dcgp_model_predict_y(dcgp_model* model, const double* X, int N, int S,
 int dcgp_model_layer_output(dcgp_model* model, int layer, double* out_sample, double* out_mean,
                             double* out_var, int* rows, int* width);
 
+/* The strided fp64 GEMM of the training step, as an operator (every tf.matmul / tf.tensordot of the reverse pass, e.g.
+ * the adjoints of conv_gp/conditionals.py:50,58, runs on it):
+ *   C_b(i, j) (+)= alpha * colscale_b[j] * sum_k A_b(i, k) * kscale_b[k] * B_b(k, j),   b = 0 .. batch-1,
+ *   A_b(i, k) = A[b a_bs + i a_rs + k a_cs],  B_b(k, j) = B[b b_bs + k b_rs + j b_cs],  C_b(i, j) = C[b c_bs + i c_rs + j];
+ * colscale / kscale may be NULL; lower_only writes 0 above the diagonal of a square result.  Device pointers. */
+int dcgp_gemm_strided(dcgp_ctx* ctx, const double* A, long a_rs, long a_cs, long a_bs, const double* B, long b_rs,
+                      long b_cs, long b_bs, double* C, long c_rs, long c_bs, int M, int N, int K, int batch,
+                      double alpha, int accumulate, const double* colscale, long cs_s, long cs_bs,
+                      const double* kscale, long ks_s, long ks_bs, int lower_only);
+
 /* ---- initialisation ---------------------------------------------------------------------------------------------- */
 /* Lloyd's k-means of n points [n, d] (device) into k centres [k, d] (device): the inducing-patch initialisation of
  * PatchInducingFeatures.from_images (conv_gp/kernels.py:147-164: sklearn KMeans(n_clusters=M, init='random')).

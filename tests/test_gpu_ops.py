@@ -349,3 +349,53 @@ def test_kmeans_matches_numpy_lloyd(ctx):
         if shift <= tol:
             break
     assert np.abs(C1 - C).max() < 1e-9
+
+
+@pytest.mark.parametrize("mode", ["nn", "tn", "nt", "tt"])
+def test_strided_gemm_layouts_edges_and_epilogues(ctx, mode):
+    """dcgp_gemm_strided (csrc/gemm_gen.hip, every product of the reverse pass): all four operand layouts, sizes off the
+    tile grid, batches, accumulation, column / k scaling, lower-triangular output, long contractions through the
+    deterministic split-k path (64- and 128-tile kernels) -- against NumPy."""
+    from deepcgp_amd import device as dev
+    L = dev.lib()
+    rng = np.random.default_rng(1)
+
+    def run(M, N, K, batch=1, alpha=1.0, accumulate=False, colscale=False, kscale=False, lower=False):
+        A = rng.standard_normal((batch, K, M) if mode[0] == "t" else (batch, M, K))
+        B = rng.standard_normal((batch, N, K) if mode[1] == "t" else (batch, K, N))
+        C0 = rng.standard_normal((batch, M, N + 3))                # c_rs > N: a view into a wider buffer
+        cs = rng.standard_normal((batch, N)) if colscale else None
+        ks = rng.standard_normal((batch, K)) if kscale else None
+        dA, dB, dC = ctx.to_device(A), ctx.to_device(B), ctx.to_device(C0)
+        dcs = ctx.to_device(cs) if colscale else None
+        dks = ctx.to_device(ks) if kscale else None
+        a_rs, a_cs = (1, M) if mode[0] == "t" else (K, 1)
+        b_rs, b_cs = (1, K) if mode[1] == "t" else (N, 1)
+        ctx._check(L.dcgp_gemm_strided(ctx.handle, dA.ptr, a_rs, a_cs, M * K, dB.ptr, b_rs, b_cs, K * N, dC.ptr, N + 3, M * (N + 3),
+                                       M, N, K, batch, alpha, int(accumulate), dcs.ptr if colscale else None, 1, N,
+                                       dks.ptr if kscale else None, 1, K, int(lower)))
+        out = dC.numpy()
+        for b in range(batch):
+            a = A[b].T if mode[0] == "t" else A[b]
+            bb = B[b].T if mode[1] == "t" else B[b]
+            if kscale:
+                bb = bb * ks[b][:, None]
+            want = alpha * (a @ bb)
+            if colscale:
+                want = want * cs[b][None, :]
+            if lower:
+                want = np.tril(want)
+            if accumulate:
+                want = want + C0[b][:, :N]
+            err = np.abs(out[b][:, :N] - want).max()
+            assert err <= 1e-11 * max(np.abs(want).max(), 1.0) * max(K, 1) ** 0.5, (M, N, K, batch, err)
+            assert np.array_equal(out[b][:, N:], C0[b][:, N:])      # nothing written beside the result
+    run(1, 1, 1)
+    run(37, 53, 19, batch=3, alpha=-0.5)
+    run(64, 64, 16, accumulate=True)
+    run(65, 129, 33, colscale=True, kscale=True)
+    run(96, 96, 40, batch=2, lower=True)                        # rectangular grid, zeros above the diagonal
+    run(96, 96, 40, batch=2, lower=True, accumulate=True)       # compact lower-tile grid
+    run(20, 7, 5000, kscale=True)                               # split-k, 64-tile kernel
+    run(130, 130, 4100, batch=2, lower=True, alpha=2.0)         # split-k, 128-tile kernel, compact grid
+    run(256, 25, 9000, accumulate=True)                         # tall contraction into a narrow result
