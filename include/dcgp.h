@@ -204,7 +204,8 @@ int dcgp_model_get_grad(dcgp_model* model, int layer, const char* which, double*
  * KL_grad / shards and the sum over ranks is the full gradient.  With a communicator on the ctx
  * (dcgp_comm_init_rank) dcgp_elbo_grad does that sum itself: one in-stream ncclAllReduce per layer over the layer's
  * contiguous gradient block.  Without one (host-side reduction, tests) set the shard count explicitly and reduce
- * the blocks yourself: block = [Z | q_mu | q_sqrt | w | variance, lengthscale], device pointer.  shards = 0
+ * the blocks yourself: block = [Z | q_mu | q_sqrt | w | variance, p1, p2 | ARD lengthscales (head)], device pointer
+ * (p1 = lengthscale or ArcCosine weight variance, p2 = ArcCosine bias variance).  shards = 0
  * restores the default (ranks of the communicator, else 1). */
 int dcgp_model_set_grad_shards(dcgp_model* model, int shards);
 int dcgp_model_grad_block(dcgp_model* model, int layer, double** block_dev, size_t* count);
