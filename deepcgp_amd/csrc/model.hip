@@ -234,7 +234,19 @@ int dcgp_model_create(dcgp_ctx* ctx, int num_samples, double jitter, dcgp_model*
 
 int dcgp_model_destroy(dcgp_model* model) {
   if (!model) return DCGP_ERR_ARG;
-  hipStreamSynchronize(model->ctx->stream);
+  dcgp_ctx* ctx = model->ctx;
+  hipDeviceSynchronize();   // both streams: the model's workspaces may still be in use
+  // the per-model workspaces of the forward / reverse pass live in the ctx under "m<id>_..." (the training step's are large:
+  // R x M x columns doubles per conv layer); they go with the model
+  const std::string pfx = "m" + std::to_string(model->id) + "_";
+  for (auto it = ctx->ws.begin(); it != ctx->ws.end();) {
+    if (it->first.compare(0, pfx.size(), pfx) == 0) {
+      hipFree(it->second.first);
+      it = ctx->ws.erase(it);
+    } else {
+      ++it;
+    }
+  }
   delete model;
   return DCGP_OK;
 }

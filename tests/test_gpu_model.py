@@ -722,3 +722,30 @@ def test_gradients_are_bitwise_reproducible_at_full_size(ctx):
     assert abs(first[True][0] - first[False][0]) <= 1e-10 * abs(first[False][0])
     assert np.abs(first[True][1] - first[False][1]).max() <= 1e-8 * max(np.abs(first[False][1]).max(), 1.0)
     model.close()
+
+
+def test_model_destroy_releases_its_workspaces(ctx):
+    """The forward / reverse-pass workspaces of a model live in the ctx under the model's prefix; destroying the model frees
+    them (the training step's are large), so building models in a loop does not grow device memory."""
+    from deepcgp_amd import device as dev
+    import ctypes as C
+    hwc, N = (28, 28, 1), 8
+    spec = syn.make_spec(hwc, [(5, 2, 10)], (5, 1), 64, S=4, num_data=1000, seed=3, conv_q_sqrt_scale=0.3)
+    X, Y = syn.make_batch(hwc, N, seed=3)
+
+    def free_bytes():
+        import subprocess  # noqa: F401  (hipMemGetInfo through the runtime the library already loaded)
+        hip = C.CDLL("libamdhip64.so")
+        free, total = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+    build_from_spec(spec, X, Y).close()             # first-use allocations of the ctx itself (shared scratch) happen here
+    m = build_from_spec(spec, X, Y)
+    m.compute_gradients(X, Y, fetch=False)
+    m.close()
+    base = free_bytes()
+    for _ in range(3):
+        m = build_from_spec(spec, X, Y)
+        m.compute_gradients(X, Y, fetch=False)
+        m.close()
+    assert base - free_bytes() < 8 * 1024 * 1024, (base, free_bytes())
