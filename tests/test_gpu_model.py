@@ -749,3 +749,27 @@ def test_model_destroy_releases_its_workspaces(ctx):
         m.compute_gradients(X, Y, fetch=False)
         m.close()
     assert base - free_bytes() < 8 * 1024 * 1024, (base, free_bytes())
+
+
+def test_gradients_match_oracle_odd_shapes(ctx):
+    """Padding paths of the reverse pass: M = 33 (Mp = 48), 17 feature maps (R padded to 32), two input channels,
+    stride 3, a 2 x 2 head filter, 5 images x 3 samples."""
+    from oracle.grad import elbo_and_grad
+    hwc, N, S = (13, 13, 2), 5, 3
+    spec = syn.make_spec(hwc, [(4, 3, 17)], (2, 1), 33, S=S, num_data=777, seed=41, conv_q_sqrt_scale=0.3, variance=1.3, ls=2.1)
+    rng = np.random.default_rng(41)
+    spec["head"]["w"] = 0.5 + rng.random(spec["head"]["w"].shape)
+    X, Y = syn.make_batch(hwc, N, seed=41)
+    zs = syn.make_noise(spec, N, seed=41)
+    ref = oracle_model(spec, X, Y)
+    model = build_from_spec(spec, X, Y)
+    eo, go = elbo_and_grad(ref, X, Y, zs)
+    for dedup in (False, True):
+        model.dedup_layer0 = dedup
+        e, grads = model.compute_gradients(X, Y, zs=zs)
+        assert abs(e - eo) <= RTOL * abs(eo)
+        for li, (g, o) in enumerate(zip(grads, go)):
+            for name, val in o.items():
+                err = np.abs(g[name] - val).max()
+                assert err < 1e-7 * np.abs(val).max() or err < 1e-8, (dedup, li, name, err, np.abs(val).max())
+    model.close()
