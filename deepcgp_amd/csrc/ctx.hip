@@ -1,5 +1,6 @@
 // Context, memory, error and HIP-event timing plumbing of libdcgp.so.
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -29,6 +30,14 @@ void* ws_get(dcgp_ctx* ctx, const std::string& name, size_t bytes) {
   if (hipMalloc(&p, cap) != hipSuccess) {
     ctx_fail(ctx, DCGP_ERR_ALLOC, "workspace '%s': hipMalloc(%zu) failed", name.c_str(), cap);
     return nullptr;
+  }
+  // debugging aid: fresh workspaces filled with NaNs (all-ones bit pattern) so that any read of memory a kernel was
+  // supposed to have written first shows up in the results (the GPU suite is run this way once per change of the reverse pass)
+  static const bool poison = getenv("DCGP_POISON_WS") != nullptr;
+  static const char* only = getenv("DCGP_POISON_ONLY");   // restrict to workspaces whose name contains this string
+  if (poison && (!only || name.find(only) != std::string::npos)) {
+    hipMemset(p, 0xFF, cap);
+    hipDeviceSynchronize();   // the ctx streams are non-blocking: the fill must have landed before any kernel writes the buffer
   }
   ctx->ws[name] = {p, cap};
   return p;

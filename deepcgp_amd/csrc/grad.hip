@@ -875,7 +875,9 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   if (rc_side != DCGP_OK) { if (fork) hipStreamSynchronize(ctx->stream2); return rc_side; }
   // main chain
   int dA1_acc = 0;
-  if (!L.has_qsqrt && Mp > M) HIP_TRY(ctx, hipMemsetAsync(dA1 + (size_t)M * ld, 0, (size_t)(Mp - M) * ld * sizeof(double), ctx->stream));
+  // the padded rows M..Mp-1 of dA1 are operands of the gemm_tn launch that forms dK_uf (times zeros of inv(L)'s padding):
+  // they must be finite whichever path writes the live rows
+  if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(dA1 + (size_t)M * ld, 0, (size_t)(Mp - M) * ld * sizeof(double), ctx->stream));
   if (L.has_qsqrt) {
     double* dT = bk.ws("dT", (size_t)R * Mp * ld);
     NEED(dT);
@@ -1109,6 +1111,7 @@ int dense_head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int 
   double* dZs = bk.ws("dZs", (size_t)M * D);
   double* dXs = bk.ws("dXs", (size_t)rows * D);
   NEED(A1); NEED(dKzx); NEED(S); NEED(gkd); NEED(cs); NEED(Zs); NEED(Xs); NEED(dZs); NEED(dXs);
+  if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(A1 + (size_t)M * ld, 0, (size_t)(Mp - M) * ld * sizeof(double), ctx->stream));
   DCGP_TRY(gemm_gen(ctx, mk(L.g.Linv, Mp, 1, Kzx, ld, 1, A1, ld, M, rows, M)));
   DCGP_TRY(cond_backward(bk, L, A1, ld, rows, gm, gv, dKzx, S, gkd));
   DCGP_TRY(kl_backward(bk, L, L.white ? nullptr : S));
@@ -1150,6 +1153,7 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   double* Xcol = bk.ws("Xcol", (size_t)Kc * Ld);
   double* dXcol = bk.ws("dXcol", (size_t)Kc * Ld);
   NEED(A1); NEED(dKzx); NEED(S); NEED(gkd); NEED(Kfull); NEED(E); NEED(cs); NEED(raw); NEED(Xcol); NEED(dXcol);
+  if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(A1 + (size_t)M * ld, 0, (size_t)(Mp - M) * ld * sizeof(double), ctx->stream));   // padded rows: operands of gemm_tn
   DCGP_TRY(gemm_gen(ctx, mk(L.g.Linv, Mp, 1, Kzx, ld, 1, A1, ld, M, rows, M)));      // the fused forward keeps A1 on chip
   DCGP_TRY(cond_backward(bk, L, A1, ld, rows, gm, gv, dKzx, S, gkd));
   // as in conv_backward: KL + Gram adjoints on the side stream, the patch-kernel adjoints (K_zx, K_diag) on the main one

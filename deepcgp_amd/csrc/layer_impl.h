@@ -54,6 +54,8 @@ struct LayerState {
   double* dalloc(size_t n_doubles) {
     void* p = nullptr;
     if (hipMalloc(&p, (n_doubles ? n_doubles : 2) * sizeof(double)) != hipSuccess) return nullptr;
+    static const bool poison = getenv("DCGP_POISON_WS") != nullptr;   // debugging aid, see ws_get (ctx.hip)
+    if (poison) { hipMemset(p, 0xFF, (n_doubles ? n_doubles : 2) * sizeof(double)); hipDeviceSynchronize(); }
     owned.push_back(p);
     return (double*)p;
   }

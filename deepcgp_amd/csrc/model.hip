@@ -44,6 +44,7 @@ int ensure(dcgp_ctx* ctx, double** p, size_t* cap, size_t n) {
   if (*cap >= n && *p) return DCGP_OK;
   if (*p) { hipStreamSynchronize(ctx->stream); hipFree(*p); *p = nullptr; }
   if (hipMalloc((void**)p, (n ? n : 2) * sizeof(double)) != hipSuccess) return ctx_fail(ctx, DCGP_ERR_ALLOC, "model: allocation failed");
+  if (getenv("DCGP_POISON_WS")) { hipMemset(*p, 0xFF, (n ? n : 2) * sizeof(double)); hipDeviceSynchronize(); }   // debugging aid, see ws_get
   *cap = n;
   return DCGP_OK;
 }
@@ -58,6 +59,10 @@ int ensure_out(dcgp_model* m, int li, int rows, int width, bool need_mv) {
     if (hipMalloc((void**)&o.sample, n * sizeof(double)) != hipSuccess || hipMalloc((void**)&o.mean, n * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&o.var, n * sizeof(double)) != hipSuccess)
       return ctx_fail(m->ctx, DCGP_ERR_ALLOC, "model: output allocation failed");
+    if (getenv("DCGP_POISON_WS")) {
+      hipMemset(o.sample, 0xFF, n * sizeof(double)); hipMemset(o.mean, 0xFF, n * sizeof(double)); hipMemset(o.var, 0xFF, n * sizeof(double));
+      hipDeviceSynchronize();
+    }
     o.cap = n;
   }
   (void)need_mv;

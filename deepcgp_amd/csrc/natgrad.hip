@@ -10,6 +10,7 @@
 // the parameters unless every precision matrix of every layer was positive definite (DCGP_ERR_NOT_PD otherwise: the
 // caller scales gamma back, conv_gp/experiment.py:36-49).
 #include <algorithm>
+#include <cstdlib>
 
 #include "model_state.h"
 #include "gemm_gen.h"
@@ -100,6 +101,7 @@ struct NatGradState {   // per layer: fixed buffers + the pointer tables of the 
   double* alloc(size_t n) {
     void* p = nullptr;
     if (hipMalloc(&p, n * sizeof(double)) != hipSuccess) return nullptr;
+    if (getenv("DCGP_POISON_WS")) { hipMemset(p, 0xFF, n * sizeof(double)); hipDeviceSynchronize(); }   // debugging aid, see ws_get
     owned.push_back(p);
     return (double*)p;
   }

@@ -773,3 +773,43 @@ def test_gradients_match_oracle_odd_shapes(ctx):
                 err = np.abs(g[name] - val).max()
                 assert err < 1e-7 * np.abs(val).max() or err < 1e-8, (dedup, li, name, err, np.abs(val).max())
     model.close()
+
+
+def test_no_read_of_unwritten_workspace_memory(ctx):
+    """DCGP_POISON_WS=1 fills every fresh workspace with NaNs (csrc/ctx.hip): a kernel that reads a padded row / column it was
+    supposed to receive initialised (M not a multiple of 16, ragged column counts) then poisons the result.  Run a forward
+    ELBO, a prediction and two training steps (tiled, de-duplicated) of such a model in a fresh process and compare with
+    this process's values."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from deepcgp_amd import synthetic as syn
+from deepcgp_amd.models import build_from_spec
+hwc, N, S = (13, 13, 2), 5, 3
+spec = syn.make_spec(hwc, [(4, 3, 7), (3, 1, 3)], (2, 1), 21, S=S, num_data=777, seed=43, conv_q_sqrt_scale=0.3, variance=1.3, ls=2.1)
+X, Y = syn.make_batch(hwc, N, seed=43)
+zs = syn.make_noise(spec, N, seed=43)
+model = build_from_spec(spec, X, Y)
+out = [model.compute_log_likelihood(X, Y, zs=zs)]
+out.append(float(np.sum(model.predict_y(X, S, zs=zs)[0])))
+for dedup in (False, True):
+    model.dedup_layer0 = dedup
+    e, g = model.compute_gradients(X, Y, zs=zs)
+    out.append(e)
+    out.append(float(sum(np.sum(np.abs(v)) for gl in g for v in gl.values())))
+print("RESULT", " ".join(repr(v) for v in out))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env_extra):
+        env = dict(os.environ)
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1]
+        return [float(v) for v in line.split()[1:]]
+    clean, poisoned = run({}), run({"DCGP_POISON_WS": "1"})
+    assert all(np.isfinite(poisoned)), poisoned
+    assert clean == poisoned, (clean, poisoned)
