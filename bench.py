@@ -159,6 +159,23 @@ def main():
             return float(t[0]) * scale - kl
         return model.compute_log_likelihood(dX, dY, seed=i, scale=scale)
 
+    def run_steps(first, n, depth):
+        """n steps; depth > 1 keeps that many steps queued (dcgp_elbo_forward_enqueue / _collect): every step's ELBO
+        still comes back to the host, the host just does not wait for step i before queueing step i + 1."""
+        if depth <= 1 or comm.startswith("gloo"):
+            v = None
+            for i in range(n):
+                v = step(first + i)
+            return v
+        tickets, v = [], None
+        for i in range(n):
+            tickets.append(model.enqueue_log_likelihood(dX, dY, seed=first + i, scale=scale))
+            if len(tickets) >= depth:
+                v = model.collect_log_likelihood(tickets.pop(0))
+        while tickets:
+            v = model.collect_log_likelihood(tickets.pop(0))
+        return v
+
     def barrier():
         ctx.sync()
         if td is not None:
@@ -184,6 +201,18 @@ def main():
     dt = time.perf_counter() - t0
     timing = ctx.timing()
     ctx.timing_enable(0)
+    # the same K steps with two steps in flight (throughput mode, same values) ...
+    dt_pipe = None
+    if not args.profile:
+        ctx.timing_enable(2)
+        run_steps(0, 4, 2)
+        barrier()
+        tp = time.perf_counter()
+        elbo_pipe = run_steps(args.warmup, args.steps, 2)
+        barrier()
+        dt_pipe = time.perf_counter() - tp
+        ctx.timing_enable(0)
+        assert elbo_pipe == elbo, (elbo_pipe, elbo)   # same seeds: bit-identical to the synchronous loop
     # the same K steps without any event bracket (what the instrumentation costs) ...
     barrier()
     t1 = time.perf_counter()
@@ -274,6 +303,8 @@ def main():
                        "dedup_layer0": bool(args.dedup_layer0), "parallelism": "image-sharded x%d, %s all-reduce of 1 f64" % (world, comm)},
             "elbo": elbo,
             "ms_per_step_without_event_timing": 1e3 * dt_plain / args.steps,
+            "ms_per_step_two_in_flight": None if dt_pipe is None else 1e3 * dt_pipe / args.steps,
+            "steps_per_s_two_in_flight": None if dt_pipe is None else args.steps / dt_pipe,
             "steps_per_s_with_exact_layer0_dedup": (units_per_step * args.steps / dt_dedup) if dt_dedup else None,
             "value_and_grad_steps_per_s": (1.0 / dt_grad) if dt_grad else None,
             "value_and_grad_ms": (1e3 * dt_grad) if dt_grad else None,

@@ -358,14 +358,28 @@ int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int 
   return elbo_forward_impl(model, X, y, N, scale, z_per_layer_host, seed, dedup_layer0, out_host, info_host);
 }
 
+int dcgp_elbo_forward_enqueue(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
+                              const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, uint64_t* ticket) {
+  return elbo_forward_enqueue_impl(model, X, y, N, scale, z_per_layer_host, seed, dedup_layer0, ticket);
+}
+
+int dcgp_elbo_forward_collect(dcgp_model* model, uint64_t ticket, double* out_host, int* info_host) {
+  return elbo_forward_collect_impl(model, ticket, out_host, info_host);
+}
+
 }  // extern "C"
 
-int elbo_forward_impl(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
-                      const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, double* out_host,
-                      int* info_host) {
-  if (!model || !X || !y || N <= 0 || !out_host) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "elbo_forward: bad args") : DCGP_ERR_ARG;
+int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
+                              const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, uint64_t* ticket) {
+  if (!model || !X || !y || N <= 0 || !ticket) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "elbo_forward: bad args") : DCGP_ERR_ARG;
   dcgp_ctx* ctx = model->ctx;
-  if (info_host) *info_host = 0;
+  if (model->enq_seq - model->col_seq >= (uint64_t)dcgp_model::RING)
+    return ctx_fail(ctx, DCGP_ERR_ARG, "elbo_forward_enqueue: %d steps in flight, collect the oldest first", dcgp_model::RING);
+  if (!model->h_ring) {
+    if (hipHostMalloc((void**)&model->h_ring, dcgp_model::RING * 4 * sizeof(double)) != hipSuccess)
+      return ctx_fail(ctx, DCGP_ERR_ALLOC, "elbo_forward: pinned result slots");
+    for (auto& e : model->ring_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   int rows = 0;
   const int S = model->S;
   const auto host_t0 = std::chrono::steady_clock::now();
@@ -387,19 +401,46 @@ int elbo_forward_impl(dcgp_model* model, const double* X, const int32_t* y, int 
   for (int g = 0; g < c.ngroups; ++g) { c.info[g] = model->groups[g].d_info; c.ninfo[g] = (int)model->groups[g].K.size(); }
   hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, ctx->stream, model->d_scal, model->d_scal + 40, c);
   LAUNCH_CHECK(ctx);
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scratch, model->d_scal + 40, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  const int slot = (int)(model->enq_seq % dcgp_model::RING);
+  HIP_TRY(ctx, hipMemcpyAsync(model->h_ring + 4 * slot, model->d_scal + 40, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(model->ring_ev[slot], ctx->stream));
   if (ctx->timing) {   // host time to enqueue one step (everything before the wait), reported beside the kernel timers
     auto& acc = ctx->tim["host_enqueue"];
     acc.launches += 1;
     acc.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  out_host[0] = ctx->h_scratch[0]; out_host[1] = ctx->h_scratch[1]; out_host[2] = ctx->h_scratch[2];
-  if (ctx->timing && ctx->pending.size() > 512) timing_flush(ctx);   // both streams are drained here; resolve lazily
-  const int bad = (int)ctx->h_scratch[3];
+  *ticket = model->enq_seq++;
+  return DCGP_OK;
+}
+
+int elbo_forward_collect_impl(dcgp_model* model, uint64_t ticket, double* out_host, int* info_host) {
+  if (!model || !out_host) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "elbo_forward_collect: bad args") : DCGP_ERR_ARG;
+  dcgp_ctx* ctx = model->ctx;
+  if (info_host) *info_host = 0;
+  if (ticket != model->col_seq || ticket >= model->enq_seq)
+    return ctx_fail(ctx, DCGP_ERR_ARG, "elbo_forward_collect: tickets are collected in the order they were handed out");
+  const int slot = (int)(ticket % dcgp_model::RING);
+  HIP_TRY(ctx, hipEventSynchronize(model->ring_ev[slot]));
+  ++model->col_seq;
+  const double* h = model->h_ring + 4 * slot;
+  out_host[0] = h[0]; out_host[1] = h[1]; out_host[2] = h[2];
+  // the timers resolve their events lazily, once nothing is in flight any more
+  if (ctx->timing && ctx->pending.size() > 512 && model->col_seq == model->enq_seq) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); timing_flush(ctx); }
+  const int bad = (int)h[3];
   if (info_host) *info_host = bad;
   if (bad) return ctx_fail(ctx, DCGP_ERR_NOT_PD, "Cholesky: matrix not positive definite at column %d", bad);
   return DCGP_OK;
+}
+
+int elbo_forward_impl(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
+                      const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, double* out_host,
+                      int* info_host) {
+  if (!model || !out_host) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "elbo_forward: bad args") : DCGP_ERR_ARG;
+  if (model->enq_seq != model->col_seq) return ctx_fail(model->ctx, DCGP_ERR_ARG, "elbo_forward: enqueued steps are still to be collected");
+  if (info_host) *info_host = 0;
+  uint64_t ticket = 0;
+  DCGP_TRY(elbo_forward_enqueue_impl(model, X, y, N, scale, z_per_layer_host, seed, dedup_layer0, &ticket));
+  return elbo_forward_collect_impl(model, ticket, out_host, info_host);
 }
 
 extern "C" {

@@ -20,8 +20,16 @@ struct dcgp_model {
   double* d_ve = nullptr; size_t ve_cap = 0;
   double* d_kd = nullptr; size_t kd_cap = 0;
   int id = 0;
+  // throughput mode of the forward (dcgp_elbo_forward_enqueue / _collect): results of up to RING steps in flight land in
+  // pinned host slots, one event per slot; tickets are handed out and collected in order
+  static constexpr int RING = 4;
+  double* h_ring = nullptr;            // RING x 4 pinned doubles: ELBO, data term, KL, potrf status
+  hipEvent_t ring_ev[RING] = {};
+  uint64_t enq_seq = 0, col_seq = 0;   // tickets handed out / collected
 
   ~dcgp_model() {
+    if (h_ring) hipHostFree(h_ring);
+    for (auto& e : ring_ev) if (e) hipEventDestroy(e);
     for (auto& gr : groups) gr.release();
     for (auto& o : outs) { hipFree(o.sample); hipFree(o.mean); hipFree(o.var); }
     hipFree(d_scal); hipFree(d_ve); hipFree(d_kd);
@@ -33,5 +41,9 @@ struct dcgp_model {
 int elbo_forward_impl(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
                       const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, double* out_host,
                       int* info_host);
+// the two halves of it: queue the step's launches and the copy of its result into a ring slot / wait for the oldest slot
+int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
+                              const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, uint64_t* ticket);
+int elbo_forward_collect_impl(dcgp_model* model, uint64_t ticket, double* out_host, int* info_host);
 // grad.hip: reverse pass over the state the forward left behind; fills every layer's gradient buffers
 int model_backward(dcgp_model* model, const double* X, const int32_t* y, int N, double scale, int dedup_layer0);

@@ -81,6 +81,8 @@ _SIGS = {
     "dcgp_model_set_keep_outputs": [_vp, _i],
     "dcgp_model_set_param": [_vp, _i, C.c_char_p, _vp, _sz],
     "dcgp_elbo_forward": [_vp, _vp, _vp, _i, _d, C.POINTER(_vp), _u64, _i, _dp, _ip],
+    "dcgp_elbo_forward_enqueue": [_vp, _vp, _vp, _i, _d, C.POINTER(_vp), _u64, _i, C.POINTER(_u64)],
+    "dcgp_elbo_forward_collect": [_vp, _u64, _dp, _ip],
     "dcgp_model_propagate": [_vp, _vp, _i, _i, C.POINTER(_vp), _u64, _vp, _vp, _ip],
     "dcgp_elbo_grad": [_vp, _vp, _vp, _i, _d, C.POINTER(_vp), _u64, _i, C.POINTER(_d), _ip],
     "dcgp_model_get_grad": [_vp, _i, C.c_char_p, _vp, C.c_size_t],

@@ -174,6 +174,40 @@ class DGP_Base:
             return out[0], out[1], out[2]
         return out[0]
 
+    def enqueue_log_likelihood(self, X, Y, zs=None, seed=0, scale=None):
+        """Throughput mode of ``compute_log_likelihood``: queue one ELBO step and return a ticket without waiting for
+        the device (``dcgp_elbo_forward_enqueue``); ``collect_log_likelihood(ticket)`` returns its value.  At most 4
+        tickets may be outstanding and they are collected in order.  The device buffers of the step are kept alive
+        with the ticket."""
+        self._build()
+        ctx, L = self._ctx, dev.lib()
+        dX = ctx.as_device(np.reshape(X, (np.shape(X)[0], -1)) if not isinstance(X, dev.DeviceArray) else X)
+        dY = ctx.as_device(np.reshape(Y, (-1,)) if not isinstance(Y, dev.DeviceArray) else Y, np.int32)
+        N = dX.shape[0]
+        if scale is None:
+            scale = float(self.num_data) / float(N)
+        arr, keep = self._z_table(zs, N, self.num_samples)
+        ticket = C.c_uint64(0)
+        ctx._check(L.dcgp_elbo_forward_enqueue(self._model, dX.ptr, dY.ptr, N, float(scale), arr, int(seed), int(self.dedup_layer0),
+                                               C.byref(ticket)))
+        if not hasattr(self, "_inflight"):
+            self._inflight = {}
+        self._inflight[ticket.value] = (dX, dY, arr, keep)
+        return ticket.value
+
+    def collect_log_likelihood(self, ticket, return_parts=False):
+        """Wait for an enqueued step and return its ELBO (same value and errors as ``compute_log_likelihood``)."""
+        ctx, L = self._ctx, dev.lib()
+        out = (C.c_double * 3)()
+        info = C.c_int(0)
+        rc = L.dcgp_elbo_forward_collect(self._model, int(ticket), out, C.byref(info))
+        if rc != dev.ERR_ARG:
+            getattr(self, "_inflight", {}).pop(int(ticket), None)
+        ctx._check(rc, info)
+        if return_parts:
+            return out[0], out[1], out[2]
+        return out[0]
+
     def compute_gradients(self, X, Y, zs=None, seed=0, scale=None, fetch=True, shards=None):
         """(ELBO, [per-layer dict]) -- the value and gradient TensorFlow hands the optimiser at
         conv_gp/experiment.py:84-108, from the hand-written reverse pass (csrc/grad.hip).  Keys: ``Z``,

@@ -185,6 +185,17 @@ int dcgp_model_set_param(dcgp_model* model, int layer, const char* which, const 
 int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
                       const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0,
                       double* out_host, int* info_host);
+/* Throughput mode of dcgp_elbo_forward for loops that do not need step i's value before step i + 1 is queued (an
+ * optimisation loop: session.run(train_op) at conv_gp/experiment.py:84-108 returns nothing; the logger reads the
+ * objective every test_every steps only).  _enqueue queues the same launches and returns a ticket without waiting;
+ * _collect waits for that step and hands back what dcgp_elbo_forward would have (same values, same error codes).
+ * Tickets are collected in the order they were handed out, at most 4 may be outstanding; X, y and the noise buffers of
+ * an enqueued step must stay untouched until it is collected.  The host then runs ahead of the device, which hides
+ * the launch latency at the head of a step and the wake-up after it. */
+int dcgp_elbo_forward_enqueue(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
+                              const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0,
+                              uint64_t* ticket);
+int dcgp_elbo_forward_collect(dcgp_model* model, uint64_t ticket, double* out_host, int* info_host);
 /* The ELBO of dcgp_elbo_forward AND its gradient with respect to every trainable value (what TensorFlow autodiff
  * hands the optimiser at conv_gp/experiment.py:84-108): Z, q_mu, q_sqrt (lower triangle), the base-kernel
  * hyper-parameters of every layer (variance + lengthscale, ArcCosine: variance + weight / bias variances, dense head:

@@ -176,6 +176,52 @@ def test_device_rng_path(ctx):
     model.close()
 
 
+def test_enqueued_steps_match_the_synchronous_forward(ctx):
+    """dcgp_elbo_forward_enqueue / _collect: several steps in flight (different minibatches, explicit noise or the
+    device RNG) hand back bit-identical values to dcgp_elbo_forward, in order; misuse is refused."""
+    from deepcgp_amd.device import DcgpError
+    hwc = (14, 14, 1)
+    spec = syn.make_spec(hwc, [(3, 2, 5)], (3, 1), M=20, S=4, num_data=700, seed=21, conv_q_sqrt_scale=0.5)
+    model = build_from_spec(spec, *syn.make_batch(hwc, 6, seed=21))
+    batches = [syn.make_batch(hwc, n, seed=30 + n) for n in (6, 3, 8, 5)]
+    noise = [syn.make_noise(spec, 6, seed=1), None, syn.make_noise(spec, 8, seed=2), None]
+    want = [model.compute_log_likelihood(X, Y, zs=z, seed=7 + i, return_parts=True) for i, ((X, Y), z) in enumerate(zip(batches, noise))]
+    for _ in range(3):       # the ring of result slots wraps around
+        tickets = [model.enqueue_log_likelihood(X, Y, zs=z, seed=7 + i) for i, ((X, Y), z) in enumerate(zip(batches, noise))]
+        with pytest.raises(DcgpError):   # a fifth step in flight
+            model.enqueue_log_likelihood(*batches[0])
+        with pytest.raises(DcgpError):   # out of order
+            model.collect_log_likelihood(tickets[1])
+        with pytest.raises(DcgpError):   # the synchronous call while steps are outstanding
+            model.compute_log_likelihood(*batches[0])
+        got = [model.collect_log_likelihood(t, return_parts=True) for t in tickets]
+        assert got == want
+        with pytest.raises(DcgpError):   # nothing left to collect
+            model.collect_log_likelihood(tickets[-1] + 1)
+    assert model.compute_log_likelihood(*batches[1], seed=8) == want[1][0]
+    model.close()
+
+
+def test_enqueued_step_reports_failed_factorisation(ctx):
+    hwc = (12, 12, 1)
+    spec = syn.make_spec(hwc, [(3, 2, 4)], (3, 1), M=10, S=2, num_data=500, seed=5)
+    X, Y = syn.make_batch(hwc, 4, seed=5)
+    model = build_from_spec(spec, X, Y)
+    good = model.compute_log_likelihood(X, Y, seed=1)
+    Z = model.layers[0].feature.Z.copy()
+    model.layers[0].feature.Z = np.full_like(Z, np.nan)
+    model.sync_parameters()
+    t = model.enqueue_log_likelihood(X, Y, seed=1)
+    from deepcgp_amd.device import NotPositiveDefinite
+    with pytest.raises(NotPositiveDefinite):
+        model.collect_log_likelihood(t)
+    model.layers[0].feature.Z = Z
+    model.sync_parameters()
+    t = model.enqueue_log_likelihood(X, Y, seed=1)
+    assert model.collect_log_likelihood(t) == good
+    model.close()
+
+
 def test_shards_sum_to_full_batch_on_gpu(ctx):
     hwc = (28, 28, 1)
     spec = syn.make_spec(hwc, [(5, 2, 10)], (5, 1), M=32, S=3, num_data=60000, seed=9, conv_q_sqrt_scale=0.2)
