@@ -4,6 +4,8 @@
 // the next k tile, double-buffered LDS (one barrier per k tile).  Long contractions with a small output (d alpha, d G_r, d L: K = number of
 // patch columns) are split along k into a partial buffer and summed in a fixed order -- no atomics, so gradients are
 // reproducible run to run.  The forward path's tuned kernel is gemm.hip; this one trades peak rate for generality.
+#include <cstdlib>
+
 #include "gemm_gen.h"
 
 namespace {
@@ -13,18 +15,18 @@ constexpr int GK = 16;
 // (the two 16-lane halves of a ds_read_b64 hit disjoint banks); one whose contraction index is contiguous is staged
 // [m][k] with row stride LDK = 17, so that each thread's consecutive k land next to each other and the fragment reads
 // (16 rows x 4 k per wave) still spread over all banks.  Two buffers per operand: one barrier per k tile.
-constexpr int LDK = 17;
 
 // GT x GT output tile on NT threads (NT / 64 waves, 32 x 32 per wave); each thread fetches EPT = GT * GK / NT elements of
 // either operand per k tile.  <64, 256> is the general configuration; <128, 1024> halves the operand traffic per flop
 // for the long contractions whose operands stream from the Infinity Cache / HBM (8 -> 16 flop per byte).
 // AKF / BKF: the operand's contraction index is the contiguous one (fetch EPT consecutive k per thread), otherwise EPT
 // consecutive rows (columns) per thread.  VEC: every EPT-element group is 16-byte aligned and contiguous (b128 loads).
-template <int GT, int NT, bool AKF, bool BKF, bool VEC>
+template <int GT, int NT, int WT, bool AKF, bool BKF, bool VEC>
 __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 4) void gemm_gen_kernel(GenGemm g, int kchunk, double* part) {
-  constexpr int EPT = GT * GK / NT, LDM = GT + 16;
+  constexpr int LDK = GK + 1, EPT = GT * GK / NT, LDM = GT + 16, WF = WT / 16;
   constexpr int TILE = (GK * LDM > GT * LDK) ? GK * LDM : GT * LDK;
-  constexpr int TPR = GK / EPT, TPK = GT / EPT, WAVES_N = GT / 32;
+  constexpr int TPR = GK / EPT, TPK = GT / EPT, WAVES_N = GT / WT;
+  static_assert(NT == WAVES_N * WAVES_N * 64, "one wave per WT x WT block of the tile");
   static_assert(EPT == 2 || EPT == 4, "fetch width");
   auto lds_a = [](int m, int k) { return AKF ? m * LDK + k : k * LDM + m; };
   auto lds_b = [](int m, int k) { return BKF ? m * LDK + k : k * LDM + m; };
@@ -109,12 +111,12 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 4) void gemm_gen_kernel(GenGem
       Bs[buf][lds_b(b_n + (BKF ? 0 : u), b_k + (BKF ? u : 0))] = rb[u];
     }
   };
-  d4 acc[2][2];
+  d4 acc[WF][WF];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WF; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-  const int wm = (wave / WAVES_N) * 32, wn = (wave % WAVES_N) * 32;
+    for (int j = 0; j < WF; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  const int wm = (wave / WAVES_N) * WT, wn = (wave % WAVES_N) * WT;
   const int nk = (kend - kbeg + GK - 1) / GK;
   if (nk > 0) {
     fetch(kbeg);
@@ -127,21 +129,25 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 4) void gemm_gen_kernel(GenGem
 #pragma unroll
     for (int kk = 0; kk < GK; kk += 4) {
       const int kr = kk + (lane >> 4), c = lane & 15;
-      const double a0 = As[cur][lds_a(wm + c, kr)], a1 = As[cur][lds_a(wm + 16 + c, kr)];
-      const double b0 = Bs[cur][lds_b(wn + c, kr)], b1 = Bs[cur][lds_b(wn + 16 + c, kr)];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      double af[WF], bf[WF];
+#pragma unroll
+      for (int f = 0; f < WF; ++f) {
+        af[f] = As[cur][lds_a(wm + 16 * f + c, kr)];
+        bf[f] = Bs[cur][lds_b(wn + 16 * f + c, kr)];
+      }
+#pragma unroll
+      for (int fi = 0; fi < WF; ++fi)
+#pragma unroll
+        for (int fj = 0; fj < WF; ++fj) acc[fi][fj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[fi], bf[fj], acc[fi][fj], 0, 0, 0);
     }
     if (it + 1 < nk) stage(cur ^ 1);     // the other buffer was last read before the previous barrier
     __syncthreads();
     if (it + 2 < nk) fetch(kbeg + (it + 2) * GK);
   }
 #pragma unroll
-  for (int fi = 0; fi < 2; ++fi)
+  for (int fi = 0; fi < WF; ++fi)
 #pragma unroll
-    for (int fj = 0; fj < 2; ++fj)
+    for (int fj = 0; fj < WF; ++fj)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = i0 + wm + fi * 16 + (lane >> 4) + 4 * q, j = j0 + wn + fj * 16 + (lane & 15);
@@ -176,7 +182,7 @@ __global__ void splitk_reduce_kernel(GenGemm g, int ksplit, const double* part) 
 
 }  // namespace
 
-template <int GT, int NT>
+template <int GT, int NT, int WT>
 static int gemm_gen_launch(dcgp_ctx* ctx, const GenGemm& g, int slots_per_round) {
   const int nt_m = (g.M + GT - 1) / GT, nt_n = (g.N + GT - 1) / GT;
   long tiles = (long)nt_m * nt_n * g.batch;
@@ -218,7 +224,7 @@ static int gemm_gen_launch(dcgp_ctx* ctx, const GenGemm& g, int slots_per_round)
   const bool a_vec = (akf ? even(g.a_rs) : (g.a_rs == 1 && even(g.a_cs))) && even(g.a_bs) && ((uintptr_t)g.A % 16 == 0);
   const bool b_vec = (bkf ? even(g.b_cs) : (g.b_cs == 1 && even(g.b_rs))) && even(g.b_bs) && ((uintptr_t)g.B % 16 == 0);
   const bool vec = a_vec && b_vec;
-#define GG_LAUNCH(AK, BKK, V) hipLaunchKernelGGL((gemm_gen_kernel<GT, NT, AK, BKK, V>), grid, dim3(NT), 0, ctx->stream, gk, kchunk, part)
+#define GG_LAUNCH(AK, BKK, V) hipLaunchKernelGGL((gemm_gen_kernel<GT, NT, WT, AK, BKK, V>), grid, dim3(NT), 0, ctx->stream, gk, kchunk, part)
   if (akf && bkf) { if (vec) GG_LAUNCH(true, true, true); else GG_LAUNCH(true, true, false); }
   else if (akf) { if (vec) GG_LAUNCH(true, false, true); else GG_LAUNCH(true, false, false); }
   else if (bkf) { if (vec) GG_LAUNCH(false, true, true); else GG_LAUNCH(false, true, false); }
@@ -237,8 +243,14 @@ int gemm_gen(dcgp_ctx* ctx, const GenGemm& g) {
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return DCGP_OK;
   if (!g.A || !g.B || !g.C || g.K < 0) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_gen: bad arguments");
   // 256 CUs; 4 co-resident 64-tile workgroups per CU (40 KB LDS each), 2 of the 128-tile ones (72 KB, 1024 threads)
-  if (g.M >= 128 && g.N >= 128 && g.K >= 4096) return gemm_gen_launch<128, 1024>(ctx, g, 512);
-  return gemm_gen_launch<64, 256>(ctx, g, 1024);
+  if (g.M >= 128 && g.N >= 128 && g.K >= 4096) return gemm_gen_launch<128, 1024, 32>(ctx, g, 512);
+  // the M x M x M products of the Cholesky / KL adjoint chains would launch a few dozen 64-tile workgroups on 256 CUs and
+  // take as long as one wave needs for its 32 x 32 x K block (K x 64 cycles of fp64 MFMA); 32-tiles with a 16 x 16 block per
+  // wave put four times as many CUs to work on a quarter of that each
+  static const long small_wgs = getenv("DCGP_GEMM_SMALL_WGS") ? atol(getenv("DCGP_GEMM_SMALL_WGS")) : 256;
+  const long wgs = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.batch / (g.lower_only ? 2 : 1);
+  if (g.K < 2048 && wgs <= small_wgs) return gemm_gen_launch<32, 256, 16>(ctx, g, 1024);
+  return gemm_gen_launch<64, 256, 32>(ctx, g, 1024);
 }
 
 // C-ABI view of the same kernel (tests drive every layout / edge case through it)
