@@ -178,6 +178,23 @@ __global__ __launch_bounds__(1024) void reduce_sum_kernel(const double* __restri
   if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 
+// up to four independent sums in one launch (one workgroup each; the same summation order as reduce_sum_kernel)
+__global__ __launch_bounds__(1024) void reduce_sum_multi_kernel(ReduceJobs j) {
+  __shared__ double red[1024];
+  const int k = blockIdx.x;
+  const double* __restrict__ in = j.in[k];
+  const long n = j.n[k];
+  double s = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) s += in[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) j.out[k][0] = red[0] * j.scale[k];
+}
+
 __global__ void reparam_kernel(const double* __restrict__ mean, const double* __restrict__ var,
                                const double* __restrict__ z, size_t n, double jitter, double* __restrict__ out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -237,6 +254,14 @@ const double* gauss_hermite_table(dcgp_ctx* ctx) {
 
 int reduce_sum(dcgp_ctx* ctx, const double* in, long n, double scale, double* out) {
   hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, in, n, scale, out);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
+int reduce_sum_multi(dcgp_ctx* ctx, const ReduceJobs& jobs, int count) {
+  if (count <= 0) return DCGP_OK;
+  if (count > 4) return ctx_fail(ctx, DCGP_ERR_ARG, "reduce_sum_multi: at most 4 sums per launch");
+  hipLaunchKernelGGL(reduce_sum_multi_kernel, dim3(count), dim3(1024), 0, ctx->stream, jobs);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }

@@ -19,6 +19,7 @@
 // (d alpha, W_r -> dG_r -> dq_sqrt, first dL terms) runs on the side stream (cond_backward).  No atomics anywhere: the
 // gradients are reproducible run to run.  The oracle for this file is oracle/grad.py.
 #include <algorithm>
+#include <initializer_list>
 
 #include "model_state.h"
 #include "gemm_gen.h"
@@ -649,6 +650,21 @@ int add_scalar(Bk& bk, LayerState& L, int which, const double* part, long n, dou
   return DCGP_OK;
 }
 
+// several hyper-parameter partial sums in one launch
+struct ScalarPart { int which; const double* part; long n; double scale; };
+int add_scalars(Bk& bk, LayerState& L, std::initializer_list<ScalarPart> parts) {
+  ReduceJobs j{};
+  int k = 0;
+  for (const ScalarPart& p : parts) {
+    int& s = p.which == 0 ? bk.slot_v : (p.which == 1 ? bk.slot_l : bk.slot_b);
+    if (s >= 16 || k >= 4) return ctx_fail(bk.ctx, DCGP_ERR_ARG, "grad: out of scalar slots");
+    j.in[k] = p.part; j.n[k] = p.n; j.scale[k] = p.scale;
+    j.out[k] = L.gslots + (p.which == 0 ? VAR_SLOT : (p.which == 1 ? LS_SLOT : P2_SLOT)) + s;
+    ++s; ++k;
+  }
+  return reduce_sum_multi(bk.ctx, j, k);
+}
+
 // RBF Gram backward from S = d ELBO / dK (unsymmetrised).  dZ accumulates into L.gZ when Zsrc is the live Z (want_dz).
 int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, long lds, bool want_dz, double* dz_out = nullptr) {
   dcgp_ctx* ctx = bk.ctx;
@@ -676,8 +692,7 @@ int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, lon
                        inv_l2, inv_l3, Es, (long)M, rs, pv, pl);
     LAUNCH_CHECK(ctx);
   }
-  DCGP_TRY(add_scalar(bk, L, 0, pv, M, 1.0));
-  DCGP_TRY(add_scalar(bk, L, 1, pl, M, 1.0));
+  DCGP_TRY(add_scalars(bk, L, {{0, pv, M, 1.0}, {1, pl, M, 1.0}}));
   if (want_dz) {
     double* EX = bk.ws("kuu_EX", (size_t)M * Ld);
     NEED(EX);
@@ -973,8 +988,7 @@ int e_form(Bk& bk, LayerState& L, const double* dK, long lddk, int pdiv, const d
       LAUNCH_CHECK(ctx);
     }
   }
-  DCGP_TRY(add_scalar(bk, L, 0, pv, (long)nb * chunks, 1.0 / L.variance));
-  DCGP_TRY(add_scalar(bk, L, 1, pl, (long)nb * chunks, 1.0 / (L.ls * L.ls * L.ls)));
+  DCGP_TRY(add_scalars(bk, L, {{0, pv, (long)nb * chunks, 1.0 / L.variance}, {1, pl, (long)nb * chunks, 1.0 / (L.ls * L.ls * L.ls)}}));
   return DCGP_OK;
 }
 
@@ -982,6 +996,10 @@ int begin_layer(Bk& bk, LayerState& L) {
   DCGP_TRY(L.ensure_grads());
   bk.slot_v = bk.slot_l = bk.slot_b = 0;
   HIP_TRY(bk.ctx, hipMemsetAsync(L.gslots, 0, 48 * sizeof(double), bk.ctx->stream));
+  if (L.grad_block_count() * sizeof(double) <= (8u << 20)) {   // a small block ([Z | q_mu | q_sqrt | w | gscal | gard], contiguous): one fill
+    HIP_TRY(bk.ctx, hipMemsetAsync(L.gZ, 0, L.grad_block_count() * sizeof(double), bk.ctx->stream));
+    return DCGP_OK;
+  }
   HIP_TRY(bk.ctx, hipMemsetAsync(L.gZ, 0, (size_t)L.M * L.v.L * sizeof(double), bk.ctx->stream));
   HIP_TRY(bk.ctx, hipMemsetAsync(L.gw, 0, ((size_t)L.v.P + 3 + (L.is_head ? (size_t)L.v.L : 0)) * sizeof(double), bk.ctx->stream));   // gw, gscal, gard
   if (!L.has_qsqrt) HIP_TRY(bk.ctx, hipMemsetAsync(L.gq_sqrt, 0, (size_t)L.R * L.M * L.M * sizeof(double), bk.ctx->stream));
@@ -1053,9 +1071,7 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
     LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, csp, chunks, Kc, cs);
     LAUNCH_CHECK(ctx);
-    DCGP_TRY(add_scalar(bk, L, 0, pv, (long)nb * chunks, 1.0 / L.variance));
-    DCGP_TRY(add_scalar(bk, L, 1, pw, (long)nb * chunks, 1.0));
-    DCGP_TRY(add_scalar(bk, L, 2, pb, (long)nb * chunks, 1.0));
+    DCGP_TRY(add_scalars(bk, L, {{0, pv, (long)nb * chunks, 1.0 / L.variance}, {1, pw, (long)nb * chunks, 1.0}, {2, pb, (long)nb * chunks, 1.0}}));
     {   // rowsum(F2) / Q
       const int rch = (int)std::min<long>(32, (Kc + 4095) / 4096);
       const long cpc = round_up_l((Kc + rch - 1) / rch, 256);
@@ -1201,8 +1217,7 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
     LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(kdiag_backward_kernel, dim3((P + 3) / 4, rows), dim3(256), 0, ctx->stream, Gm, norms, gkd, L.w, P, L.variance, inv_l2, dwn, pv, pl);
     LAUNCH_CHECK(ctx);
-    DCGP_TRY(add_scalar(bk, L, 0, pv, (long)rows * P, 1.0 / L.variance));
-    DCGP_TRY(add_scalar(bk, L, 1, pl, (long)rows * P, inv_l2 / L.ls));
+    DCGP_TRY(add_scalars(bk, L, {{0, pv, (long)rows * P, 1.0 / L.variance}, {1, pl, (long)rows * P, inv_l2 / L.ls}}));
     hipLaunchKernelGGL(strided_sum_kernel, dim3(P), dim3(256), 0, ctx->stream, dwn, rows, P, 1.0, 1, L.gw);
     LAUNCH_CHECK(ctx);
     if (dXin) {

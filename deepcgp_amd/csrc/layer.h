@@ -89,3 +89,5 @@ const double* gauss_hermite_table(dcgp_ctx* ctx);   // [40]: 20 nodes then 20 we
 
 // deterministic single-block sum of n doubles, scaled: out[0] = scale * sum
 int reduce_sum(dcgp_ctx* ctx, const double* in, long n, double scale, double* out);
+struct ReduceJobs { const double* in[4]; long n[4]; double scale[4]; double* out[4]; };
+int reduce_sum_multi(dcgp_ctx* ctx, const ReduceJobs& jobs, int count);   // out[k][0] = scale[k] * sum(in[k][0..n[k])), one launch
