@@ -192,11 +192,13 @@ static int gemm_gen_launch(dcgp_ctx* ctx, const GenGemm& g, int slots_per_round)
     tiles = live * g.batch;
   }
   // split long contractions so that the launch fills the chip: a whole number of rounds of co-resident workgroups
+  // (the 32-tile configuration serves launches that cannot fill the chip: it splits earlier and finer)
+  constexpr int SPLIT_MIN_K = GT == 32 ? 1024 : 2048, SPLIT_CHUNK = GT == 32 ? 128 : 512;
   int ksplit = 1;
-  if (g.K >= 2048 && tiles < slots_per_round) {
+  if (g.K >= SPLIT_MIN_K && tiles < slots_per_round) {
     ksplit = (int)((slots_per_round + tiles - 1) / tiles);
     if (tiles * ksplit > slots_per_round && ksplit > 1) --ksplit;   // stay within one round rather than spill a few workgroups into a second
-    const int max_split = g.K / 512;
+    const int max_split = g.K / SPLIT_CHUNK;
     if (ksplit > max_split) ksplit = max_split;
     if (ksplit < 1) ksplit = 1;
   }
@@ -246,10 +248,12 @@ int gemm_gen(dcgp_ctx* ctx, const GenGemm& g) {
   if (g.M >= 128 && g.N >= 128 && g.K >= 4096) return gemm_gen_launch<128, 1024, 32>(ctx, g, 512);
   // the M x M x M products of the Cholesky / KL adjoint chains would launch a few dozen 64-tile workgroups on 256 CUs and
   // take as long as one wave needs for its 32 x 32 x K block (K x 64 cycles of fp64 MFMA); 32-tiles with a 16 x 16 block per
-  // wave put four times as many CUs to work on a quarter of that each
+  // wave put four times as many CUs to work on a quarter of that each.  Likewise the long contractions with a narrow
+  // output (d alpha = A1 gm: M x R): a handful of tiles, split into 128-deep chunks instead of 512-deep ones
   static const long small_wgs = getenv("DCGP_GEMM_SMALL_WGS") ? atol(getenv("DCGP_GEMM_SMALL_WGS")) : 256;
   const long wgs = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.batch / (g.lower_only ? 2 : 1);
-  if (g.K < 2048 && wgs <= small_wgs) return gemm_gen_launch<32, 256, 16>(ctx, g, 1024);
+  const long max_wgs = wgs * (g.K >= 2048 ? g.K / 512 : 1);   // what the 64-tile configuration could launch, split included
+  if (max_wgs <= small_wgs) return gemm_gen_launch<32, 256, 16>(ctx, g, 1024);
   return gemm_gen_launch<64, 256, 32>(ctx, g, 1024);
 }
 
