@@ -245,10 +245,12 @@ int gemm_gen(dcgp_ctx* ctx, const GenGemm& g) {
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return DCGP_OK;
   if (!g.A || !g.B || !g.C || g.K < 0) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_gen: bad arguments");
   // 256 CUs; 4 co-resident 64-tile workgroups per CU (40 KB LDS each), 2 of the 128-tile ones (72 KB, 1024 threads)
-  // the 1024-thread 128-tile pays off on the tiled batch's contractions (K = 46080 columns at the headline size); at a few
-  // thousand columns (de-duplicated first layer) its ~270 workgroups lose to ~900 64-tiles (training step 2.05 -> 1.93 ms)
-  static const long big_k = getenv("DCGP_GEMM_BIG_K") ? atol(getenv("DCGP_GEMM_BIG_K")) : 16384;
-  if (g.M >= 128 && g.N >= 128 && g.K >= big_k) return gemm_gen_launch<128, 1024, 32>(ctx, g, 512);
+  // the 1024-thread 128-tile (twice the flop per operand byte) pays off where it can fill its 512 slots, split included:
+  // the tiled batch's contractions (K = 46080 columns at the headline size), M = 1024.  With a few thousand columns and
+  // M = 256 (de-duplicated first layer) its ~270 workgroups lose to ~900 64-tiles (training step 2.05 -> 1.93 ms)
+  static const long big_fill = getenv("DCGP_GEMM_BIG_FILL") ? atol(getenv("DCGP_GEMM_BIG_FILL")) : 512;
+  const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch / (g.lower_only ? 2 : 1);
+  if (g.M >= 128 && g.N >= 128 && g.K >= 4096 && tiles128 * (g.K / 512) >= big_fill) return gemm_gen_launch<128, 1024, 32>(ctx, g, 512);
   // the M x M x M products of the Cholesky / KL adjoint chains would launch a few dozen 64-tile workgroups on 256 CUs and
   // take as long as one wave needs for its 32 x 32 x K block (K x 64 cycles of fp64 MFMA); 32-tiles with a 16 x 16 block per
   // wave put four times as many CUs to work on a quarter of that each.  Likewise the long contractions with a narrow
