@@ -291,6 +291,8 @@ def test_rccl_single_rank_allreduce_path(ctx):
     ctx.comm_init(1, 0, dev.comm_unique_id())
     try:
         assert model.compute_log_likelihood(X, Y, zs=zs) == e0
+        tickets = [model.enqueue_log_likelihood(X, Y, zs=zs) for _ in range(3)]    # steps in flight, each with its all-reduce
+        assert [model.collect_log_likelihood(t) for t in tickets] == [e0] * 3
         # training step: one in-stream all-reduce per layer over its contiguous gradient block (identity with one rank)
         e1, g1 = model.compute_gradients(X, Y, zs=zs)
         assert e1 == e0
