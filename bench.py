@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- forward ELBO steps/sec of the conv-GP hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME]
 
 One "step" = one forward ELBO evaluation of a synthetic minibatch (compute_log_likelihood semantics:
 S = 10 samples, all layers, data term + all KLs, scalar read back to the host), inputs already resident
@@ -9,11 +9,16 @@ in HBM, nothing cached across steps.  At N = 1 the workload is BASELINE.json con
 M = 256, batch 32) in its conv-layer + head form (K_uf + Cholesky + conditional); noise comes from the
 counter-based device RNG, as the reference draws it inside its graph.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the minibatch images are sharded over the
-ranks; every rank runs the same step on its shard and ONE RCCL all-reduce (1 x fp64) of the data term per
-step joins them.  --scaling weak (default): 32 images per GPU (global batch 32*N), value counts
-batch-32-equivalent steps (images/s / 32); --scaling strong: global batch fixed at 32.
-Rank 0 prints ONE JSON line.  torch is used only as host plumbing (gloo barrier / broadcast / max).
+N > 1: one process per GPU.  Launched by a process launcher (RANK / WORLD_SIZE in the environment, e.g.
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) each process is one rank; launched
+plainly (`python bench.py --gpus N`) this process starts the N ranks itself.  The ranks find each other over a
+small TCP host group (deepcgp_amd.dist.HostGroup -- no torch anywhere), rank 0's RCCL id is handed round, and
+from then on the only exchange per step is ONE in-stream ncclAllReduce (1 x fp64) of the data term.  The
+minibatch images are sharded over the ranks:
+  * `value` is STRONG scaling -- the global batch stays the configuration's (32 at cfg2), which is what
+    north_star's ">= 6x at 8 GPUs over 1 GPU" and SURVEY 8(e) define;
+  * `weak` (config batch per GPU, value = batch-equivalent steps/s) is reported beside it in the same line.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import gc
@@ -27,10 +32,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from deepcgp_amd import device as dev                    # noqa: E402
-from deepcgp_amd import synthetic as syn                 # noqa: E402
-from deepcgp_amd.dist import shard_range, init_rccl      # noqa: E402
-from deepcgp_amd.models import build_from_spec           # noqa: E402
+from deepcgp_amd import device as dev                                   # noqa: E402
+from deepcgp_amd import synthetic as syn                                # noqa: E402
+from deepcgp_amd.dist import HostGroup, shard_range, init_rccl, spawn_ranks   # noqa: E402
+from deepcgp_amd.models import build_from_spec                          # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix peak (datasheet; the guide lists no fp64 row): 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
@@ -74,264 +79,323 @@ def cpu_baseline(name, S, batch, budget_s=30.0):
                       "oracle in the reference's operation order; median %.2f s/step; not TensorFlow" % (len(times), batch, S, med)}
 
 
+class Leg:
+    """One sharded workload on this rank: the model, its device-resident shard and the step function."""
+
+    def __init__(self, ctx, grp, comm, cfg_name, S, global_batch, lo, hi, dedup):
+        cfg = syn.CONFIGS[cfg_name]
+        self.ctx, self.grp, self.comm = ctx, grp, comm
+        self.global_batch, self.local_batch = global_batch, hi - lo
+        seed = 1234 + list(syn.CONFIGS).index(cfg_name)
+        self.spec = syn.make_spec(cfg["hwc"], cfg["convs"], cfg["head"], cfg["M"], S=S, num_data=cfg["num_data"], seed=seed)
+        Xg, Yg = syn.make_batch(cfg["hwc"], global_batch, seed=seed)
+        self.Xh, self.Yh = Xg[lo:hi], Yg[lo:hi]
+        self.model = build_from_spec(self.spec, self.Xh, self.Yh)
+        self.model.dedup_layer0 = bool(dedup)
+        self.model.global_batch = global_batch
+        self.dX, self.dY = ctx.to_device(self.Xh), ctx.to_device(self.Yh, np.int32)
+        self.scale = float(self.spec["num_data"]) / float(global_batch)
+
+    def step(self, i):
+        if self.comm == "host":
+            # fallback join (RCCL could not initialise, e.g. two ranks on one device): the local data term comes back,
+            # is summed over the ranks by the host group, and the ELBO is assembled here
+            _, data, kl = self.model.compute_log_likelihood(self.dX, self.dY, seed=i, scale=self.scale, return_parts=True)
+            return float(self.grp.allreduce([data], "sum")[0]) * self.scale - kl
+        return self.model.compute_log_likelihood(self.dX, self.dY, seed=i, scale=self.scale)
+
+    def run_pipelined(self, first, n, depth):
+        """n steps with `depth` steps queued (dcgp_elbo_forward_enqueue / _collect): every step's ELBO still comes back
+        to the host, the host just does not wait for step i before queueing step i + 1."""
+        tickets, v = [], None
+        for i in range(n):
+            tickets.append(self.model.enqueue_log_likelihood(self.dX, self.dY, seed=first + i, scale=self.scale))
+            if len(tickets) >= depth:
+                v = self.model.collect_log_likelihood(tickets.pop(0))
+        while tickets:
+            v = self.model.collect_log_likelihood(tickets.pop(0))
+        return v
+
+    def barrier(self):
+        self.ctx.sync()
+        self.grp.barrier()
+        self.ctx.sync()
+
+    def timed(self, first, n, fn=None):
+        """Wall time of n steps between two (device sync + rank barrier) brackets, max over the ranks."""
+        fn = fn or self.step
+        self.barrier()
+        t0 = time.perf_counter()
+        v = None
+        for i in range(n):
+            v = fn(first + i)
+        self.barrier()
+        dt = time.perf_counter() - t0
+        return float(self.grp.allreduce([dt], "max")[0]), v
+
+
+def shard_sweep(leg, steps, warmup):
+    """Strong-scaling preview on ONE GPU: the step on the shard a rank would hold at G = 1, 2, 4, 8 (same parameters, same
+    num_data / global-batch scale).  t(b) = replicated + b * per_image fitted through the end points gives the Amdahl
+    fraction of the step that does not shrink with the shard (factorisation chain, KL, launch + host latency)."""
+    out = {}
+    B = leg.local_batch
+    for G in (1, 2, 4, 8):
+        b = max(1, -(-B // G))
+        dX, dY = leg.ctx.to_device(leg.Xh[:b]), leg.ctx.to_device(leg.Yh[:b], np.int32)
+        for i in range(5):
+            leg.model.compute_log_likelihood(dX, dY, seed=i, scale=leg.scale)
+        leg.ctx.sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            leg.model.compute_log_likelihood(dX, dY, seed=warmup + i, scale=leg.scale)
+        leg.ctx.sync()
+        out[G] = (b, 1e3 * (time.perf_counter() - t0) / steps)
+    (b1, t1), (b8, t8) = out[1], out[8]
+    per_image = (t1 - t8) / max(b1 - b8, 1)
+    replicated = t1 - per_image * b1
+    return {"per_rank_batch_ms": {str(G): {"images": b, "ms_per_step": round(t, 4)} for G, (b, t) in out.items()},
+            "replicated_ms": replicated, "replicated_fraction": replicated / t1,
+            "predicted_strong_speedup_excluding_allreduce": {str(G): round(t1 / t, 3) for G, (b, t) in out.items()}}
+
+
+def head_only_leg(ctx, grp, S, steps):
+    """The reference's literal "1-layer M=256" (results/N60000_M256/options.toml:3: scalar M = SVGP head with the ConvKernel,
+    no ConvLayer): forward ELBO steps/s and the roofline of its largest term, ConvKernel.Kdiag (kernels.py:106-115)."""
+    leg = Leg(ctx, grp, "none", "cfg2_mnist_H_M256", S, 32, 0, 32, False)
+    for i in range(20):
+        leg.step(i)
+    dt, _ = leg.timed(20, steps)
+    ctx.timing_enable(1)
+    ctx.timing_reset()
+    for i in range(10):
+        leg.step(i)
+    ctx.sync()
+    tim = ctx.timing()
+    ctx.timing_enable(0)
+    h = leg.spec["head"]
+    P, L, _ = conv_geometry(h, 1)
+    rows = 32 * S
+    flops = float(rows) * P * P * (2 * L + 4)
+    us = 1e3 * tim["head_kdiag"][1] / max(tim["head_kdiag"][0], 1)
+    ach = flops / (us * 1e-6) / 1e12
+    out = {"head_only_steps_per_s": steps / dt, "head_only_ms_per_step": 1e3 * dt / steps,
+           "roofline_head": {"kernel": "head_kdiag_kernel (ConvKernel.Kdiag, all patch pairs of an image; upper-triangular tile pairs only)",
+                             "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                             "traffic": None, "algorithmic_flops_per_launch": flops, "avg_us": us,
+                             "note": "full-count N'*P^2*(2L+4) (SURVEY 8(d)); the kernel evaluates the upper triangle of tile pairs only"},
+           "head_only_kernel_times_us": {k: round(1e3 * v[1] / max(v[0], 1), 2) for k, v in sorted(tim.items())}}
+    leg.model.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=str, default="cfg2_mnist_CH_M256", choices=sorted(syn.CONFIGS))
-    ap.add_argument("--scaling", type=str, default="weak", choices=["weak", "strong"])
     ap.add_argument("--samples", type=int, default=10)
     ap.add_argument("--dedup-layer0", action="store_true",
                     help="evaluate layer 0 on the distinct images only (exact; off by default so that the step does "
                          "the same work as the reference, which tiles the batch S times)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grad-leg", action="store_true", help="skip the informational value-and-gradient timing")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the head-only and shard-sweep legs")
     ap.add_argument("--profile", action="store_true",
                     help="for rocprofv3 runs: exactly --warmup + --steps steps, none of the extra regions, no CPU baseline")
-    ap.add_argument("--comm", type=str, default="rccl", choices=["rccl", "gloo"],
-                    help="N > 1: rccl = in-stream ncclAllReduce inside dcgp_elbo_forward (default); gloo = host "
+    ap.add_argument("--comm", type=str, default="rccl", choices=["rccl", "host"],
+                    help="N > 1: rccl = in-stream ncclAllReduce inside dcgp_elbo_forward (default); host = host-group "
                          "all-reduce of the per-rank data term (debug / fallback when RCCL cannot initialise)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process is the launcher -- one child per rank, rank 0 prints the line
+        raise SystemExit(spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
-    td = None
-    if world > 1:
-        import torch
-        import torch.distributed as td
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("gloo", rank=rank, world_size=world)
-
-    ctx = dev.Context(local_rank if dev.device_count() > local_rank else 0)
+    grp = HostGroup(rank, world)
+    n_dev = dev.device_count()
+    ctx = dev.Context(local_rank if n_dev > local_rank else local_rank % max(n_dev, 1))
     dev._default_ctx = ctx
+    comm, rccl_ranks = "none", 0
     if world > 1:
-        def bcast(b):
-            t = torch.tensor(list(b), dtype=torch.uint8)
-            td.broadcast(t, src=0)
-            return bytes(t.tolist())
         comm = args.comm
         if comm == "rccl":
             ok = 1
             try:
-                init_rccl(ctx, rank, world, bcast)
+                init_rccl(ctx, rank, world, grp.broadcast_bytes)
             except Exception as exc:          # noqa: BLE001 -- any failure must reach the collective vote below
                 ok = 0
                 print("rank %d: RCCL init failed (%s); falling back to the host all-reduce" % (rank, exc), file=sys.stderr)
-            vote = torch.tensor([ok], dtype=torch.int32)
-            td.all_reduce(vote, op=td.ReduceOp.MIN)
-            if int(vote[0]) == 0:
-                dev.lib().dcgp_comm_destroy(ctx.handle)
-                comm = "gloo(fallback)"
-    else:
-        comm = "none"
+            if int(grp.allreduce([ok], "min")[0]) == 0:
+                ctx.comm_destroy()
+                comm = "host"
+            else:
+                rccl_ranks = ctx.comm_count()
 
     cfg = syn.CONFIGS[args.config]
     S = args.samples
-    per_rank_batch = cfg["batch"]
-    if args.scaling == "weak":
-        global_batch = cfg["batch"] * world
-        lo, hi = rank * cfg["batch"], (rank + 1) * cfg["batch"]
-    else:
-        global_batch = cfg["batch"]
-        lo, hi = shard_range(global_batch, rank, world)
-        per_rank_batch = hi - lo
-    seed = 1234 + list(syn.CONFIGS).index(args.config)
-    spec = syn.make_spec(cfg["hwc"], cfg["convs"], cfg["head"], cfg["M"], S=S, num_data=cfg["num_data"], seed=seed)
-    Xg, Yg = syn.make_batch(cfg["hwc"], global_batch, seed=seed)
-    model = build_from_spec(spec, Xg[lo:hi], Yg[lo:hi])
-    model.dedup_layer0 = bool(args.dedup_layer0)
-    dX, dY = ctx.to_device(Xg[lo:hi]), ctx.to_device(Yg[lo:hi], np.int32)
-    scale = float(spec["num_data"]) / float(global_batch)
-
-    def step(i):
-        if comm.startswith("gloo"):
-            # host-side join: the local data term comes back, is summed over ranks with gloo, ELBO assembled here
-            _, data, kl = model.compute_log_likelihood(dX, dY, seed=i, scale=scale, return_parts=True)
-            t = torch.tensor([data], dtype=torch.float64)
-            td.all_reduce(t, op=td.ReduceOp.SUM)
-            return float(t[0]) * scale - kl
-        return model.compute_log_likelihood(dX, dY, seed=i, scale=scale)
-
-    def run_steps(first, n, depth):
-        """n steps; depth > 1 keeps that many steps queued (dcgp_elbo_forward_enqueue / _collect): every step's ELBO
-        still comes back to the host, the host just does not wait for step i before queueing step i + 1."""
-        if depth <= 1 or comm.startswith("gloo"):
-            v = None
-            for i in range(n):
-                v = step(first + i)
-            return v
-        tickets, v = [], None
-        for i in range(n):
-            tickets.append(model.enqueue_log_likelihood(dX, dY, seed=first + i, scale=scale))
-            if len(tickets) >= depth:
-                v = model.collect_log_likelihood(tickets.pop(0))
-        while tickets:
-            v = model.collect_log_likelihood(tickets.pop(0))
-        return v
-
-    def barrier():
-        ctx.sync()
-        if td is not None:
-            td.barrier()
-        ctx.sync()
+    # strong scaling (value): the configuration's batch, sharded; weak: the configuration's batch on every rank
+    lo, hi = shard_range(cfg["batch"], rank, world)
+    if int(grp.allreduce([hi - lo], "min")[0]) == 0:
+        raise SystemExit("--gpus %d leaves a rank without an image at batch %d" % (world, cfg["batch"]))
+    leg = Leg(ctx, grp, comm, args.config, S, cfg["batch"], lo, hi, args.dedup_layer0)
+    model, spec = leg.model, leg.spec
 
     # HIP events bracket only the two roofline kernels (gemm_cond_s3, kuf) on their launch stream; the mode is
     # switched on before the warm-up so that every lazy first-use cost of the event path is paid outside the timed region
     ctx.timing_enable(2)
-    elbo = None
     # The HIP runtime has a one-off ~50 ms hiccup somewhere in the first few dozen steps of a process (seen in 1 run
     # out of 4 when only a handful of warm-up steps were run); warm-up is untimed, so run at least 50 of them.
     for i in range(args.warmup if args.profile else max(args.warmup, 50)):
-        elbo = step(i)
+        leg.step(i)
     ctx.timing_reset()
     gc.collect()
     gc.disable()       # a generation-2 collection inside the timed loop showed up as a ~50 ms hiccup in 1 run out of 4
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        elbo = step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, elbo = leg.timed(args.warmup, args.steps)
     timing = ctx.timing()
     ctx.timing_enable(0)
-    # the same K steps with two steps in flight (throughput mode, same values) ...
-    dt_pipe, pipe_matches = None, None
-    if not args.profile and world == 1:   # informational leg, single GPU only (like the training-step legs)
+    extra = {}
+
+    def informational(name, fn):
+        """An informational leg can never cost the bench line."""
+        if args.profile:
+            return None
         try:
-            ctx.timing_enable(2)
-            run_steps(0, 4, 2)
-            barrier()
-            tp = time.perf_counter()
-            elbo_pipe = run_steps(args.warmup, args.steps, 2)
-            barrier()
-            dt_pipe = time.perf_counter() - tp
-            pipe_matches = bool(elbo_pipe == elbo)   # same seeds: bit-identical to the synchronous loop
-        except Exception as e:                        # never let an informational leg cost the bench line
-            print("two-in-flight leg skipped: %r" % (e,), file=sys.stderr)
-            dt_pipe = None
-        finally:
-            ctx.timing_enable(0)
-    # the same K steps without any event bracket (what the instrumentation costs) ...
-    barrier()
-    t1 = time.perf_counter()
-    for i in range(0 if args.profile else args.steps):
-        step(args.warmup + i)
-    barrier()
-    dt_plain = time.perf_counter() - t1
-    # ... with layer-0 de-duplication (propagate() tiles the batch S times, so layer 0 sees S identical copies;
-    # evaluating the distinct images once is exact -- bit-identical ELBO) as an additional, separately labelled number
+            return fn()
+        except Exception as e:                # noqa: BLE001
+            print("%s leg skipped: %r" % (name, e), file=sys.stderr)
+            return None
+
+    # the same K steps with two steps in flight (throughput mode, same values)
+    def pipelined():
+        leg.run_pipelined(0, 4, 2)
+        d, v = leg.timed(args.warmup, 1, lambda first: leg.run_pipelined(first, args.steps, 2))
+        return d, bool(v == elbo)   # same seeds: bit-identical to the synchronous loop
+    pipe = informational("two-in-flight", pipelined) if comm != "host" else None
+    # the same K steps without any event bracket (what the instrumentation costs)
+    dt_plain = None if args.profile else leg.timed(args.warmup, args.steps)[0]
+
+    # weak scaling beside it: the configuration's batch on every rank
+    weak = None
+    if world > 1 and not args.profile:
+        def weak_leg():
+            wl = Leg(ctx, grp, comm, args.config, S, cfg["batch"] * world, rank * cfg["batch"], (rank + 1) * cfg["batch"], args.dedup_layer0)
+            for i in range(20):
+                wl.step(i)
+            d, _ = wl.timed(args.warmup, args.steps)
+            wl.model.close()
+            return {"value": world * args.steps / d, "unit": "batch-%d-equivalent ELBO steps/s" % cfg["batch"], "ms_per_step": 1e3 * d / args.steps,
+                    "global_batch": cfg["batch"] * world, "per_gpu_batch": cfg["batch"]}
+        weak = informational("weak-scaling", weak_leg)
+
+    # exact layer-0 de-duplication (propagate() tiles the batch S times, so layer 0 sees S identical copies; evaluating the
+    # distinct images once is exact -- bit-identical ELBO): an additional, separately labelled number
     dt_dedup = None
-    if cfg["convs"] and not args.dedup_layer0 and not args.profile:
-        model.dedup_layer0 = True
-        for i in range(2):
-            step(i)
-        barrier()
-        t2 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        barrier()
-        dt_dedup = time.perf_counter() - t2
-        model.dedup_layer0 = False
-    # ... and once more with every kernel family bracketed, for the informational per-kernel table only
-    ctx.timing_enable(1)
-    ctx.timing_reset()
-    for i in range(0 if args.profile else min(args.steps, 10)):
-        step(args.warmup + i)
-    barrier()
-    timing_all = ctx.timing()
-    ctx.timing_enable(0)
-    # ... and the same step followed by its reverse pass (dcgp_elbo_grad: value and gradient with respect to every
-    # trainable parameter -- what the reference's training step differentiates, experiment.py:84-108).  Informational,
-    # single-rank only (the gradient all-reduce is not wired up yet); never part of `value`.
-    dt_grad, dt_train, dt_train_dedup = None, None, None
-    if world == 1 and not args.profile and not args.no_grad_leg:
-        n_g = max(3, min(args.steps, 20))
-        for i in range(2):
-            model.compute_gradients(dX, dY, seed=i, scale=scale, fetch=False)
-        barrier()
-        t3 = time.perf_counter()
-        for i in range(n_g):
-            model.compute_gradients(dX, dY, seed=args.warmup + i, scale=scale, fetch=False)
-        barrier()
-        dt_grad = (time.perf_counter() - t3) / n_g
-        # ... and a full optimisation step: value + gradient + the device Adam update (tf.train.AdamOptimizer semantics,
-        # lr small enough to leave the benchmark state essentially where it was)
-        barrier()
-        t4 = time.perf_counter()
-        for i in range(n_g):
-            model.compute_gradients(dX, dY, seed=args.warmup + i, scale=scale, fetch=False)
-            model.adam_step(1e-9, i + 1)
-        barrier()
-        dt_train = (time.perf_counter() - t4) / n_g
-        # ... and the same optimisation step with the exact layer-0 de-duplication (forward and reverse pass of the first
-        # layer on the N distinct images; identical gradients, tests/test_gpu_model.py)
-        dt_train_dedup = None
-        if cfg["convs"] and not args.dedup_layer0:
+    if cfg["convs"] and not args.dedup_layer0:
+        def dedup():
             model.dedup_layer0 = True
+            try:
+                for i in range(2):
+                    leg.step(i)
+                return leg.timed(args.warmup, args.steps)[0]
+            finally:
+                model.dedup_layer0 = False
+        dt_dedup = informational("dedup", dedup)
+
+    # once more with every kernel family bracketed, for the informational per-kernel table only
+    timing_all = {}
+    if not args.profile:
+        ctx.timing_enable(1)
+        ctx.timing_reset()
+        for i in range(min(args.steps, 10)):
+            leg.step(args.warmup + i)
+        leg.barrier()
+        timing_all = ctx.timing()
+        ctx.timing_enable(0)
+
+    # the same step followed by its reverse pass (dcgp_elbo_grad: value and gradient with respect to every trainable
+    # parameter -- what the reference's training step differentiates, experiment.py:84-108).  Informational, single-rank.
+    grad = {}
+    if world == 1 and not args.no_grad_leg:
+        def grad_leg():
+            g = {}
+            n_g = max(3, min(args.steps, 20))
+            cg = lambda i: model.compute_gradients(leg.dX, leg.dY, seed=i, scale=leg.scale, fetch=False)   # noqa: E731
             for i in range(2):
-                model.compute_gradients(dX, dY, seed=i, scale=scale, fetch=False)
-            barrier()
-            t5 = time.perf_counter()
-            for i in range(n_g):
-                model.compute_gradients(dX, dY, seed=args.warmup + i, scale=scale, fetch=False)
-                model.adam_step(1e-9, n_g + i + 1)
-            barrier()
-            dt_train_dedup = (time.perf_counter() - t5) / n_g
-            model.dedup_layer0 = False
-    if td is not None:
-        t = torch.tensor([dt, dt_plain, dt_dedup or 0.0], dtype=torch.float64)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt, dt_plain = float(t[0]), float(t[1])
-        dt_dedup = float(t[2]) if dt_dedup is not None else None
+                cg(i)
+            g["value_and_grad_ms"] = 1e3 * leg.timed(args.warmup, n_g, cg)[0] / n_g
+
+            def train_step(i):
+                cg(i)
+                model.adam_step(1e-9)     # lr small enough to leave the benchmark state essentially where it was
+            g["train_step_ms_value_grad_adam"] = 1e3 * leg.timed(args.warmup, n_g, train_step)[0] / n_g
+            if cfg["convs"] and not args.dedup_layer0:
+                model.dedup_layer0 = True
+                try:
+                    for i in range(2):
+                        cg(i)
+                    g["train_step_ms_with_exact_layer0_dedup"] = 1e3 * leg.timed(args.warmup, n_g, train_step)[0] / n_g
+                finally:
+                    model.dedup_layer0 = False
+            return g
+        grad = informational("gradient", grad_leg) or {}
+
+    if world == 1 and not args.no_extra_legs:
+        extra.update(informational("shard-sweep", lambda: {"strong_scaling_preview": shard_sweep(leg, min(args.steps, 100), args.warmup)}) or {})
+        if args.config.startswith("cfg2"):
+            extra.update(informational("head-only", lambda: head_only_leg(ctx, grp, S, min(args.steps, 100))) or {})
 
     if rank == 0:
-        units_per_step = global_batch / float(cfg["batch"])        # batch-32-equivalent ELBO steps per step
-        value = units_per_step * args.steps / dt
+        value = args.steps / dt
+        per_rank_batch = hi - lo
         out = {
-            # BASELINE.json's metric string for its configs[1]; `value` is the steps/sec part (forward ELBO evaluations,
-            # batch-32-equivalent when sharded), the K_uf HBM GB/s part is `kuf_hbm_gbs` / `roofline_kuf`
+            # BASELINE.json's metric string for its configs[1]; `value` is the steps/sec part (forward ELBO evaluations of the
+            # configuration's minibatch, sharded over the ranks), the K_uf HBM GB/s part is `kuf_hbm_gbs` / `roofline_kuf`
             "metric": "ELBO steps/sec (batch=%d) + achieved HBM GB/s on K_uf, MNIST M=256 1-layer" % cfg["batch"]
                       if args.config.startswith("cfg2") else "ELBO steps/sec (batch=%d) + achieved HBM GB/s on K_uf" % cfg["batch"],
             "value": value, "unit": "ELBO steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.config, "variant": "conv layer + head" if cfg["convs"] else "head only",
-                       "M": cfg["M"], "per_gpu_batch": per_rank_batch, "global_batch": global_batch, "num_samples": S,
+                       "M": cfg["M"], "per_gpu_batch": per_rank_batch, "global_batch": cfg["batch"], "num_samples": S,
                        "image": list(cfg["hwc"]), "layers": len(cfg["convs"]) + 1, "noise": "device Philox RNG",
-                       "dedup_layer0": bool(args.dedup_layer0), "parallelism": "image-sharded x%d, %s all-reduce of 1 f64" % (world, comm)},
+                       "dedup_layer0": bool(args.dedup_layer0),
+                       "parallelism": "image-sharded x%d, %s" % (world, {"none": "no collective", "rccl": "in-stream ncclAllReduce of 1 f64",
+                                                                          "host": "host-group all-reduce of 1 f64 (RCCL fallback)"}[comm])},
+            "ranks_seen_by_rccl": rccl_ranks,
+            "weak": weak if world > 1 else {"value": value, "unit": "batch-%d-equivalent ELBO steps/s" % cfg["batch"], "ms_per_step": 1e3 * dt / args.steps,
+                                            "global_batch": cfg["batch"], "per_gpu_batch": cfg["batch"]},
             "elbo": elbo,
-            "ms_per_step_without_event_timing": 1e3 * dt_plain / args.steps,
-            "ms_per_step_two_in_flight": None if dt_pipe is None else 1e3 * dt_pipe / args.steps,
-            "steps_per_s_two_in_flight": None if dt_pipe is None else args.steps / dt_pipe,
-            "two_in_flight_elbo_identical": pipe_matches,
-            "steps_per_s_with_exact_layer0_dedup": (units_per_step * args.steps / dt_dedup) if dt_dedup else None,
-            "value_and_grad_steps_per_s": (1.0 / dt_grad) if dt_grad else None,
-            "value_and_grad_ms": (1e3 * dt_grad) if dt_grad else None,
-            "train_step_ms_value_grad_adam": (1e3 * dt_train) if dt_train else None,
-            "train_step_ms_with_exact_layer0_dedup": (1e3 * dt_train_dedup) if dt_train_dedup else None,
+            "ms_per_step_without_event_timing": None if dt_plain is None else 1e3 * dt_plain / args.steps,
+            "ms_per_step_two_in_flight": None if pipe is None else 1e3 * pipe[0] / args.steps,
+            "steps_per_s_two_in_flight": None if pipe is None else args.steps / pipe[0],
+            "two_in_flight_elbo_identical": None if pipe is None else pipe[1],
+            "steps_per_s_with_exact_layer0_dedup": (args.steps / dt_dedup) if dt_dedup else None,
+            "value_and_grad_steps_per_s": (1e3 / grad["value_and_grad_ms"]) if grad.get("value_and_grad_ms") else None,
+            "value_and_grad_ms": grad.get("value_and_grad_ms"),
+            "train_step_ms_value_grad_adam": grad.get("train_step_ms_value_grad_adam"),
+            "train_step_ms_with_exact_layer0_dedup": grad.get("train_step_ms_with_exact_layer0_dedup"),
         }
-        # ---- roofline of the dominant kernel: the R-batched L_q^T A product with fused square-reduce ----
+        out.update(extra)
+        # ---- roofline of the dominant kernel -------------------------------------------------------------------------
         rows0 = per_rank_batch if (args.dedup_layer0 and cfg["convs"]) else per_rank_batch * S
         kern = {k: {"launches": v[0], "avg_us": 1e3 * v[1] / max(v[0], 1)} for k, v in timing_all.items()}
         out["kernel_times_us"] = {k: round(v["avg_us"], 2) for k, v in sorted(kern.items())}
         if cfg["convs"]:
             c = spec["convs"][0]
             P, L, Kc = conv_geometry(c, rows0)
-            M, R = c["M"], c["R"]
-            nl = len(cfg["convs"]) + 1
-            # gemm_cond_s3 is launched once per layer; layer 0 dominates -- use its algorithmic flops only when it
-            # is the only conv layer, else report the sum over layers per step
+            M = c["M"]
+            # the stage-3 product is launched once per conv layer: algorithmic flops = sum over layers of R*M^2*K
             flops_s3 = 0.0
-            rows = rows0
             for ci, cc in enumerate(spec["convs"]):
-                Pc, Lc, Kcc = conv_geometry(cc, rows if ci == 0 else per_rank_batch * S)
+                Pc, Lc, Kcc = conv_geometry(cc, rows0 if ci == 0 else per_rank_batch * S)
                 flops_s3 += float(cc["R"]) * cc["M"] ** 2 * Kcc
             n_conv = len(cfg["convs"])
             t_s3 = timing.get("gemm_cond_s3", (0, 0.0))
@@ -351,17 +415,16 @@ def main():
                 us = 1e3 * t_kuf[1] / t_kuf[0]
                 gbs = bytes_kuf / (us * 1e-6) / 1e9
                 out["kuf_hbm_gbs"] = gbs
-                out["roofline_kuf"] = {"kernel": "patch_rbf_kernel (K_uf sweep, layer 0; held to 2 workgroups/CU while it overlaps the factorisation chain)", "bound": "hbm", "achieved": gbs,
+                out["roofline_kuf"] = {"kernel": "patch_rbf_kernel (K_uf sweep, layer 0)", "bound": "hbm", "achieved": gbs,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                        "traffic": pmc_traffic("kuf", args.config),
                                        "algorithmic_bytes_per_launch": bytes_kuf, "avg_us": us}
         if not args.no_cpu_baseline and not args.profile and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, S, cfg["batch"])
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if td is not None:
-        td.barrier()
-        td.destroy_process_group()
+        sys.stdout.flush()
+    grp.barrier()
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -15,6 +15,7 @@ typedef int (*fn_comm_init_rank)(void** comm, int nranks, UniqueId id, int rank)
 typedef int (*fn_comm_destroy)(void* comm);
 typedef int (*fn_all_reduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t s);
 typedef const char* (*fn_get_error_string)(int);
+typedef int (*fn_comm_count)(void* comm, int* count);
 
 struct Rccl {
   void* h = nullptr;
@@ -23,6 +24,7 @@ struct Rccl {
   fn_comm_destroy comm_destroy = nullptr;
   fn_all_reduce all_reduce = nullptr;
   fn_get_error_string get_error_string = nullptr;
+  fn_comm_count comm_count = nullptr;
 };
 Rccl g_rccl;
 
@@ -40,6 +42,7 @@ bool rccl_load() {
   g_rccl.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
   g_rccl.all_reduce = (fn_all_reduce)dlsym(h, "ncclAllReduce");
   g_rccl.get_error_string = (fn_get_error_string)dlsym(h, "ncclGetErrorString");
+  g_rccl.comm_count = (fn_comm_count)dlsym(h, "ncclCommCount");
   if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce) {
     dlclose(h);
     return false;
@@ -101,6 +104,14 @@ int dcgp_comm_destroy(dcgp_ctx* ctx) {
   ctx->comm = nullptr;
   ctx->nranks = 1;
   ctx->rank = 0;
+  return DCGP_OK;
+}
+
+int dcgp_comm_count(dcgp_ctx* ctx, int* out_ranks) {
+  if (!ctx || !out_ranks) return ctx ? ctx_fail(ctx, DCGP_ERR_ARG, "comm_count: bad args") : DCGP_ERR_ARG;
+  *out_ranks = 0;
+  if (!ctx->comm) return DCGP_OK;
+  if (!g_rccl.comm_count || g_rccl.comm_count(ctx->comm, out_ranks) != 0) return ctx_fail(ctx, DCGP_ERR_RCCL, "ncclCommCount failed");
   return DCGP_OK;
 }
 

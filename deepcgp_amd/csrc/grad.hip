@@ -1388,9 +1388,12 @@ int dcgp_model_grad_block(dcgp_model* model, int layer, double** block_dev, size
 }
 
 int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta2, double eps, int t) {
-  if (!model || t < 1 || !(lr > 0) || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1) || !(eps > 0))
+  if (!model || t < 0 || !(lr > 0) || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1) || !(eps > 0))
     return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "adam_step: bad arguments") : DCGP_ERR_ARG;
   dcgp_ctx* ctx = model->ctx;
+  // t == 0: the model's own count of Adam steps since its moment buffers were created (they start at zero with it) --
+  // what tf.train.AdamOptimizer's beta powers do for a freshly built optimiser, whatever global_step a checkpoint carried
+  if (t == 0) t = ++model->adam_t; else model->adam_t = t;
   const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
   auto run = [&](double* p, const double* g, double* const* mv, long n, int transform) -> int {
     if (n <= 0) return DCGP_OK;

@@ -101,6 +101,7 @@ _SIGS = {
     "dcgp_comm_unique_id": [C.c_char_p],
     "dcgp_comm_init_rank": [_vp, _i, _i, C.c_char_p],
     "dcgp_comm_destroy": [_vp],
+    "dcgp_comm_count": [_vp, _ip],
     "dcgp_allreduce_sum_f64": [_vp, _vp, _i],
 }
 _RESTYPE = {"dcgp_last_error": C.c_char_p}
@@ -190,6 +191,7 @@ class Context:
             raise DcgpError(rc, "dcgp_ctx_create(device=%d) failed" % device)
         self.handle = h.value
         self.device = int(device)
+        self.nranks, self.rank = 1, 0     # RCCL communicator of this ctx (comm_init)
 
     def _check(self, rc, info=None):
         if rc == DCGP_OK:
@@ -236,6 +238,17 @@ class Context:
     # multi-GPU ---------------------------------------------------------------------------------
     def comm_init(self, nranks, rank, unique_id):
         self._check(lib().dcgp_comm_init_rank(self.handle, int(nranks), int(rank), bytes(unique_id)))
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def comm_count(self):
+        """Ranks RCCL reports for this ctx's communicator (0 without one)."""
+        n = C.c_int(0)
+        self._check(lib().dcgp_comm_count(self.handle, C.byref(n)))
+        return n.value
+
+    def comm_destroy(self):
+        self._check(lib().dcgp_comm_destroy(self.handle))
+        self.nranks, self.rank = 1, 0
 
     def allreduce_sum(self, dev_array):
         self._check(lib().dcgp_allreduce_sum_f64(self.handle, dev_array.ptr, dev_array.size))

@@ -37,6 +37,7 @@ class DGP_Base:
         self.minibatch_size = minibatch_size
         self.name = name
         self.num_data = int(num_data if num_data is not None else self.X.shape[0])
+        self.global_batch = None      # multi-rank runs: the minibatch size summed over the ranks (see _default_scale)
         self.dedup_layer0 = False     # exact optimisation: layer 0 sees S identical copies of the batch
         self._ctx = None
         self._model = None
@@ -46,6 +47,16 @@ class DGP_Base:
         for l in self.layers[:-1]:
             if not isinstance(l, ConvLayer):
                 raise ValueError("hidden layers must be ConvLayer instances")
+
+    def _default_scale(self, n_local):
+        """num_data / minibatch size.  With an RCCL communicator on the ctx the data term is summed over the ranks inside
+        the device call, so the minibatch is the GLOBAL one: set ``global_batch`` (or pass ``scale``) -- the local shard
+        size would make the ELBO too large by the rank count."""
+        if getattr(self._ctx, "nranks", 1) > 1:
+            if getattr(self, "global_batch", None) is None:
+                raise ValueError("an RCCL communicator is attached: pass scale=num_data/global_batch or set model.global_batch")
+            return float(self.num_data) / float(self.global_batch)
+        return float(self.num_data) / float(n_local)
 
     # ---- device model -----------------------------------------------------------------------------
     def _ptr(self, a):
@@ -164,7 +175,7 @@ class DGP_Base:
         dY = ctx.as_device(np.reshape(Y, (-1,)) if not isinstance(Y, dev.DeviceArray) else Y, np.int32)
         N = dX.shape[0]
         if scale is None:
-            scale = float(self.num_data) / float(N)
+            scale = self._default_scale(N)
         arr, keep = self._z_table(zs, N, self.num_samples)
         out = (C.c_double * 3)()
         info = C.c_int(0)
@@ -185,7 +196,7 @@ class DGP_Base:
         dY = ctx.as_device(np.reshape(Y, (-1,)) if not isinstance(Y, dev.DeviceArray) else Y, np.int32)
         N = dX.shape[0]
         if scale is None:
-            scale = float(self.num_data) / float(N)
+            scale = self._default_scale(N)
         arr, keep = self._z_table(zs, N, self.num_samples)
         ticket = C.c_uint64(0)
         ctx._check(L.dcgp_elbo_forward_enqueue(self._model, dX.ptr, dY.ptr, N, float(scale), arr, int(seed), int(self.dedup_layer0),
@@ -219,12 +230,13 @@ class DGP_Base:
         dY = ctx.as_device(np.reshape(Y, (-1,)) if not isinstance(Y, dev.DeviceArray) else Y, np.int32)
         N = dX.shape[0]
         if scale is None:
-            scale = float(self.num_data) / float(N)
+            scale = self._default_scale(N)
         arr, keep = self._z_table(zs, N, self.num_samples)
         out = (C.c_double * 3)()
         info = C.c_int(0)
-        if shards is not None:   # this call handles one of `shards` batch shards: the replicated KL term is weighted 1 / shards
-            ctx._check(L.dcgp_model_set_grad_shards(self._model, int(shards)))
+        # this call handles one of `shards` batch shards: the replicated KL term is weighted 1 / shards; None = the rank
+        # count of the ctx's communicator (1 without one).  Always passed, so that it never sticks from an earlier call.
+        ctx._check(L.dcgp_model_set_grad_shards(self._model, int(shards or 0)))
         ctx._check(L.dcgp_elbo_grad(self._model, dX.ptr, dY.ptr, N, float(scale), arr, int(seed), int(self.dedup_layer0), out,
                                     C.byref(info)), info)
         if not fetch:            # the gradients stay on the device (dcgp_model_get_grad / the optimiser step read them there)
@@ -250,12 +262,14 @@ class DGP_Base:
             grads.append(g)
         return out[0], grads
 
-    def adam_step(self, lr, t, beta1=0.9, beta2=0.999, epsilon=1e-8):
+    def adam_step(self, lr, t=None, beta1=0.9, beta2=0.999, epsilon=1e-8):
         """One Adam step (tf.train.AdamOptimizer defaults, gpflow.train.AdamOptimizer at
         conv_gp/experiment.py:104-107) on the gradients the last ``compute_gradients`` left on the device,
-        in gpflow's unconstrained space.  ``t`` is the 1-based step count.  The device copy of the parameters
+        in gpflow's unconstrained space.  ``t`` is the 1-based step count of the bias correction; None (default) = the
+        device model's own count of steps since its moment buffers were created (independent of any global_step a
+        checkpoint carried, like a freshly built tf optimiser).  The device copy of the parameters
         moves; ``pull_parameters`` refreshes the Python-side values."""
-        self._ctx._check(dev.lib().dcgp_model_adam_step(self._model, float(lr), float(beta1), float(beta2), float(epsilon), int(t)))
+        self._ctx._check(dev.lib().dcgp_model_adam_step(self._model, float(lr), float(beta1), float(beta2), float(epsilon), int(t or 0)))
 
     def sgd_step(self, lr):
         """Plain gradient ascent step in the unconstrained space (the "SGD" branch, conv_gp/experiment.py:100-103)."""

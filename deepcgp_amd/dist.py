@@ -3,11 +3,23 @@
 The data term of the ELBO is a sum over minibatch images and every layer's conditional is independent
 per image, so the N images of a minibatch (each with all S samples and all P patches) are partitioned
 contiguously over the ranks.  Parameters, Kuu, the Choleskys and the KL terms are replicated.  The only
-exchange per step is a sum all-reduce of ONE float64 (the per-rank data term): on GPUs it is an RCCL
-``ncclAllReduce`` issued on the ctx stream inside ``dcgp_elbo_forward``; the same assembly logic runs
-over ``torch.distributed`` (gloo) in the CPU tests.
+exchange per step is a sum all-reduce of ONE float64 (the per-rank data term): an RCCL ``ncclAllReduce``
+issued on the ctx stream inside ``dcgp_elbo_forward``.
+
+Host-side plumbing (who am I, hand the 128-byte RCCL id to the other ranks, start/stop the clock together)
+needs no framework: ``HostGroup`` is a few dozen lines of TCP on the loopback/cluster interface -- rank 0
+listens, the others connect, every exchange is gather-to-0 + broadcast.  It is used for set-up and for the
+timing barriers only, never on the data path.  ``spawn_ranks`` starts one process per GPU when the caller was
+not already launched by a process launcher (RANK / WORLD_SIZE in the environment).
 """
+import json
 import os
+import socket
+import struct
+import subprocess
+import sys
+import tempfile
+import time
 
 import numpy as np
 
@@ -38,18 +50,167 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def allreduce_sum_host(value, group=None):
-    """Sum a Python float over the ranks of an initialised torch.distributed group (gloo on CPU)."""
-    import torch
-    import torch.distributed as td
-    t = torch.tensor([float(value)], dtype=torch.float64)
-    td.all_reduce(t, op=td.ReduceOp.SUM, group=group)
-    return float(t[0])
+# ---------------------------------------------------------------------------------------------------
+# host-side process group over TCP
+# ---------------------------------------------------------------------------------------------------
+def _send_msg(sock, payload):
+    sock.sendall(struct.pack("!I", len(payload)) + payload)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed the rendezvous socket")
+        buf.extend(chunk)
+    return bytes(buf)
+
+
+def _recv_msg(sock):
+    (n,) = struct.unpack("!I", _recv_exact(sock, 4))
+    return _recv_exact(sock, n)
+
+
+def rendezvous_file():
+    """Where rank 0 publishes the port it listens on.  ``spawn_ranks`` hands every rank a fresh path in
+    DCGP_RDZV_FILE; under an external launcher (torch.distributed.run, mpirun, ...) the ranks of one job share the
+    launcher as parent process and the MASTER_PORT it chose, which names the file.  (MASTER_PORT itself belongs to
+    the launcher's own store, so the group listens on an ephemeral port instead.)"""
+    path = os.environ.get("DCGP_RDZV_FILE")
+    if path:
+        return path
+    tag = "%s_%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "x"))
+    return os.path.join(tempfile.gettempdir(), "dcgp_rdzv_" + "".join(c if c.isalnum() else "_" for c in tag))
+
+
+class HostGroup:
+    """Star-topology host process group: ``broadcast_bytes``, ``allreduce`` (small float vectors), ``barrier``."""
+
+    def __init__(self, rank, world, addr=None, path=None, timeout=120.0):
+        self.rank, self.world = int(rank), int(world)
+        self._peers, self._sock, self._path = [], None, None
+        if self.world <= 1:
+            return
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        path = path or rendezvous_file()
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind(("", 0))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            token = os.urandom(8).hex()
+            tmp = path + ".%d.tmp" % os.getpid()
+            with open(tmp, "w") as fh:
+                json.dump({"port": srv.getsockname()[1], "token": token}, fh)
+            os.replace(tmp, path)          # atomic: a reader sees the old file or the new one, never half of it
+            self._path = path
+            peers = {}
+            while len(peers) < self.world - 1:
+                conn, _ = srv.accept()
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                conn.settimeout(timeout)
+                hello = json.loads(_recv_msg(conn).decode())
+                if hello.get("token") != token or not (0 < hello.get("rank", -1) < self.world) or hello["rank"] in peers:
+                    conn.close()           # a stray process, or a rank of an earlier job that read a stale file
+                    continue
+                peers[hello["rank"]] = conn
+                _send_msg(conn, b"ok")
+            srv.close()
+            self._peers = [peers[r] for r in range(1, self.world)]
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    with open(path) as fh:
+                        info = json.load(fh)
+                    s = socket.create_connection((addr, int(info["port"])), timeout=5.0)
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    s.settimeout(timeout)
+                    _send_msg(s, json.dumps({"rank": self.rank, "token": info["token"]}).encode())
+                    if _recv_msg(s) == b"ok":
+                        self._sock = s
+                        break
+                    s.close()
+                except (OSError, ValueError, KeyError, ConnectionError):
+                    pass                   # file not there yet / stale file of an earlier job: look again
+                if time.time() > deadline:
+                    raise TimeoutError("rank %d: no rendezvous with rank 0 through %s" % (self.rank, path))
+                time.sleep(0.05)
+
+    # every collective = gather to rank 0, combine there, send the result back
+    def _exchange(self, payload, combine):
+        if self.world <= 1:
+            return combine([payload])
+        if self.rank == 0:
+            parts = [payload] + [_recv_msg(c) for c in self._peers]
+            out = combine(parts)
+            for c in self._peers:
+                _send_msg(c, out)
+            return out
+        _send_msg(self._sock, payload)
+        return _recv_msg(self._sock)
+
+    def broadcast_bytes(self, b, src=0):
+        if src != 0:
+            raise ValueError("HostGroup broadcasts from rank 0")
+        return self._exchange(bytes(b) if self.rank == 0 else b"", lambda parts: parts[0])
+
+    def allreduce(self, values, op="sum"):
+        """Elementwise sum / max / min of a short float vector over the ranks (fixed rank order: reproducible)."""
+        fn = {"sum": np.sum, "max": np.max, "min": np.min}[op]
+        v = np.ascontiguousarray(np.atleast_1d(values), np.float64)
+
+        def combine(parts):
+            return np.ascontiguousarray(fn(np.stack([np.frombuffer(p, np.float64) for p in parts]), axis=0)).tobytes()
+        return np.frombuffer(self._exchange(v.tobytes(), combine), np.float64).copy()
+
+    def barrier(self):
+        self._exchange(b"", lambda parts: b"")
+
+    def close(self):
+        for c in self._peers:
+            c.close()
+        if self._sock is not None:
+            self._sock.close()
+        if self._path:
+            try:
+                os.unlink(self._path)
+            except OSError:
+                pass
+        self._peers, self._sock, self._path = [], None, None
+
+
+def spawn_ranks(n, argv=None, env=None):
+    """Start ``n`` copies of this program, one per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR and a fresh
+    DCGP_RDZV_FILE in their environment), wait for all of them and return the worst exit status.  Rank 0's stdout
+    is this process's stdout."""
+    argv = list(argv if argv is not None else sys.argv)
+    fd, path = tempfile.mkstemp(prefix="dcgp_rdzv_")
+    os.close(fd)
+    os.unlink(path)
+    procs = []
+    for r in range(n):
+        e = dict(os.environ if env is None else env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), DCGP_RDZV_FILE=path)
+        e.setdefault("MASTER_ADDR", "127.0.0.1")
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs across processes on this driver
+        procs.append(subprocess.Popen([sys.executable] + argv, env=e, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
+    return rc
 
 
 def init_rccl(ctx, rank, world, broadcast_bytes):
-    """Create the RCCL communicator of ``ctx``: rank 0 draws the unique id, ``broadcast_bytes(b, src=0)``
-    (any host-side broadcast, e.g. torch.distributed gloo) ships the 128 bytes to the other ranks."""
+    """Create the RCCL communicator of ``ctx``: rank 0 draws the unique id, ``broadcast_bytes(b)``
+    (``HostGroup.broadcast_bytes``) ships the 128 bytes to the other ranks."""
     from . import device as dev
     uid = dev.comm_unique_id() if rank == 0 else bytes(128)
     uid = broadcast_bytes(uid)

@@ -89,6 +89,9 @@ def train(model, steps, lr=0.01, lr_decay_steps=50000, global_step=0, seed=0, ca
     history = []
     steps_back = 0
     model._build()
+    if getattr(model._ctx, "nranks", 1) > 1:
+        # every rank would draw the same minibatch and the all-reduced gradients would count it once per rank
+        raise NotImplementedError("train() drives one GPU; shard the minibatch per rank and call compute_gradients / adam_step yourself")
     dedup_before, model.dedup_layer0 = model.dedup_layer0, bool(dedup_layer0)
     nl = len(model.layers)
     for li in range(nl):
@@ -113,7 +116,7 @@ def train(model, steps, lr=0.01, lr_decay_steps=50000, global_step=0, seed=0, ca
         if optimizer == "SGD":
             model.sgd_step(learning_rate(lr, step, lr_decay_steps))
         else:
-            model.adam_step(learning_rate(lr, step, lr_decay_steps), step + 1)
+            model.adam_step(learning_rate(lr, step, lr_decay_steps))   # bias correction: the model's own step count
         history.append(elbo)
         if callback is not None:
             callback(step + 1, elbo)

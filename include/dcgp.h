@@ -224,7 +224,9 @@ int dcgp_model_grad_block(dcgp_model* model, int layer, double** block_dev, size
  * (lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t); theta -= lr_t m / (sqrt(v) + eps); t = 1, 2, ...) ascending the
  * ELBO in gpflow's unconstrained space -- variance / lengthscale through transforms.positive (softplus + 1e-6),
  * q_sqrt on its lower triangle, Z / q_mu / patch_weights as they are (gpflow.train.AdamOptimizer at
- * conv_gp/experiment.py:104-107; the learning-rate schedule :71-73 stays with the caller). */
+ * conv_gp/experiment.py:104-107; the learning-rate schedule :71-73 stays with the caller).  t = 0: use the model's
+ * own count of steps taken since its (zero-initialised) moment buffers were created -- a freshly built optimiser
+ * restarts its beta powers whatever global_step a loaded checkpoint carries (experiment.py:84-89). */
 int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta2, double eps, int t);
 /* Plain gradient ascent in the same unconstrained space (gpflow.train.GradientDescentOptimizer, the "SGD" branch
  * at conv_gp/experiment.py:100-103). */
@@ -277,6 +279,8 @@ int dcgp_kmeans(dcgp_ctx* ctx, const double* X, long n, int d, int k, const int3
 int dcgp_comm_unique_id(unsigned char* out_128bytes);
 int dcgp_comm_init_rank(dcgp_ctx* ctx, int nranks, int rank, const unsigned char* id_128bytes);
 int dcgp_comm_destroy(dcgp_ctx* ctx);
+/* ranks RCCL itself reports for the ctx's communicator (ncclCommCount); 0 without one */
+int dcgp_comm_count(dcgp_ctx* ctx, int* out_ranks);
 int dcgp_allreduce_sum_f64(dcgp_ctx* ctx, double* buf_dev, int n);
 
 #ifdef __cplusplus

@@ -276,6 +276,76 @@ def test_full_size_cfg2_vs_oracle(ctx):
     model.close()
 
 
+BIG = ["cfg3_mnist_3layer_M256", "cfg4_cifar_3layer_M384", "cfg5_mnist_H_M1024", "cfg5_mnist_CH_M1024"]
+
+
+@pytest.mark.parametrize("name", BIG)
+def test_baseline_configs_3_to_5_vs_oracle(ctx, name):
+    """BASELINE.json configs[2..4] against the oracle at FULL M (256 x 3 layers / 384 / 1024) on a reduced batch (2 images,
+    S = 2): every layer's sample / mean / variance and the three ELBO parts.  M = 384 / 1024 take other code than cfg2 (the
+    generic GEMMs instead of the fused head conditional, 12- / 32-panel factorisation chains, other tile configurations)."""
+    spec, X, Y = syn.make_config(name, S=2)
+    X, Y = X[:2], Y[:2]
+    zs = syn.make_noise(spec, 2, seed=3)
+    model, ref = build_from_spec(spec, X, Y), oracle_model(spec, X, Y)
+    oFs, oFm, oFv = ref.propagate(X, S=2, zs=zs)
+    Fs, Fm, Fv = model.propagate(X, S=2, zs=zs)
+    for i in range(len(Fs)):
+        assert rel(Fm[i], oFm[i]) < 1e-8, ("Fmean", i, rel(Fm[i], oFm[i]))
+        assert rel(Fv[i], oFv[i]) < 1e-8, ("Fvar", i, rel(Fv[i], oFv[i]))
+        assert rel(Fs[i], oFs[i]) < 1e-8, ("Fs", i)
+    e, data, kl = model.compute_log_likelihood(X, Y, zs=zs, return_parts=True)
+    assert abs(data - ref.data_term(X, Y, zs=zs)) <= 1e-8 * abs(data)
+    assert abs(kl - ref.KL()) <= 1e-8 * abs(kl)
+    assert abs(e - ref.compute_log_likelihood(X, Y, zs=zs)) <= 1e-8 * abs(e)
+    model.dedup_layer0 = True
+    e_d = model.compute_log_likelihood(X, Y, zs=zs)
+    assert abs(e_d - e) <= 1e-13 * abs(e)
+    model.close()
+
+
+@pytest.mark.parametrize("name", BIG)
+def test_baseline_configs_3_to_5_full_size_properties(ctx, name):
+    """The same configurations at their full batch (64 / 32 / 128 images, S = 10) through properties that need no oracle run:
+    ELBO assembly, exact layer-0 de-duplication, image-order invariance, shard additivity (the multi-GPU decomposition), and
+    agreement of the synchronous and the enqueued step."""
+    spec, X, Y = syn.make_config(name)
+    N = X.shape[0]
+    zs = syn.make_noise(spec, N, seed=1)
+    model = build_from_spec(spec, X, Y)
+    e, data, kl = model.compute_log_likelihood(X, Y, zs=zs, return_parts=True)
+    assert np.isfinite([e, data, kl]).all() and kl > 0 and data < 0
+    assert abs(e - (data * spec["num_data"] / N - kl)) <= 1e-12 * abs(e)
+    model.dedup_layer0 = True
+    e_d = model.compute_log_likelihood(X, Y, zs=zs)
+    assert (e_d == e) if spec["convs"] else abs(e_d - e) <= 1e-13 * abs(e)
+    model.dedup_layer0 = False
+    perm = np.random.default_rng(0).permutation(N)
+    e_p = model.compute_log_likelihood(X[perm], Y[perm], zs=[z[:, perm] for z in zs])
+    assert abs(e_p - e) <= 1e-11 * abs(e)
+    cut = N // 4 + 1                                                            # ragged shards
+    lo = model.compute_log_likelihood(X[:cut], Y[:cut], zs=[z[:, :cut] for z in zs], return_parts=True)[1]
+    hi = model.compute_log_likelihood(X[cut:], Y[cut:], zs=[z[:, cut:] for z in zs], return_parts=True)[1]
+    assert abs((lo + hi) - data) <= 1e-11 * abs(data)
+    t = model.enqueue_log_likelihood(X, Y, zs=zs)
+    assert model.collect_log_likelihood(t) == e
+    model.close()
+
+
+def test_oversized_operand_slab_is_refused(ctx):
+    """gemm_tn fetches whole k-tiles through 32-bit-offset buffer descriptors: an [M x columns] operand of 2 GiB or more is
+    refused with DCGP_ERR_ARG and a message naming the limit -- never silently wrapped."""
+    from deepcgp_amd import device as dev
+    spec, X, Y = syn.make_config("cfg5_mnist_CH_M1024", S=10)
+    X = np.tile(X, (2, 1))[:200]                    # 200 images x 10 samples x 144 patches = 288 000 columns x 1024 rows x 8 B = 2.36 GB
+    Y = np.tile(Y, 2)[:200]
+    model = build_from_spec(spec, X, Y)
+    with pytest.raises(dev.DcgpError) as ei:
+        model.compute_log_likelihood(X, Y, seed=0)
+    assert ei.value.code == dev.ERR_ARG and "2 GiB" in str(ei.value)
+    model.close()
+
+
 def test_rccl_single_rank_allreduce_path(ctx):
     """The N>1 code path on one GPU: a 1-rank RCCL communicator, the in-stream all-reduce inside
     dcgp_elbo_forward, the per-layer gradient all-reduce inside dcgp_elbo_grad and the explicit

@@ -101,6 +101,34 @@ def test_two_rank_gloo_elbo_allreduce():
     assert "OK" in outs[0]
 
 
+def test_two_rank_hostgroup_elbo(tmp_path):
+    """The same world_size-2 assembly over the product's own host group (TCP rendezvous through a file, no torch): id
+    broadcast, sum / max all-reduce, barrier; both ranks arrive at the full-batch ELBO."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", DCGP_RDZV_FILE=str(tmp_path / "rdzv"),
+               PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
+    worker = os.path.join(ROOT, "tests", "hostgroup_worker.py")
+    for world in (2, 3):
+        procs = [subprocess.Popen([sys.executable, worker], env=dict(env, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        outs = [p.communicate(timeout=300)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
+        vals = [float(o.strip().splitlines()[-1].split()[-1]) for o in outs]
+        assert len(set(vals)) == 1 and all("OK" in o for o in outs)
+
+
+def test_spawn_ranks_sets_the_rank_environment(tmp_path):
+    """spawn_ranks: one child per rank with RANK / LOCAL_RANK / WORLD_SIZE and a shared rendezvous file; worst exit code."""
+    from deepcgp_amd.dist import spawn_ranks
+    script = tmp_path / "child.py"
+    script.write_text("import os, sys\n"
+                      "open(os.path.join(%r, 'r' + os.environ['RANK']), 'w').write(os.environ['WORLD_SIZE'] + ' ' + os.environ['DCGP_RDZV_FILE'])\n"
+                      "sys.exit(3 if os.environ['RANK'] == '1' and len(sys.argv) > 1 else 0)\n" % str(tmp_path))
+    assert spawn_ranks(2, [str(script)]) == 0
+    got = [(tmp_path / ("r%d" % r)).read_text().split() for r in range(2)]
+    assert got[0][0] == got[1][0] == "2" and got[0][1] == got[1][1]
+    assert spawn_ranks(2, [str(script), "fail"]) == 3
+
+
 def test_kernel_host_classes_validate_without_a_device():
     """Constructor-level behaviour of the gpflow stand-ins that needs no GPU: parameter validation, ARD expansion,
     the {type, variance, p1, p2} description pushed to the device model, InducingPoints length."""
