@@ -421,7 +421,7 @@ def main():
                                        "algorithmic_bytes_per_launch": bytes_kuf, "avg_us": us}
         if not args.no_cpu_baseline and not args.profile and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, S, cfg["batch"])
-        print(json.dumps(out))
+        print("\n" + json.dumps(out))      # on a line of its own whatever a library (RCCL's banner) left on stdout before it
         sys.stdout.flush()
     grp.barrier()
     grp.close()

@@ -640,6 +640,24 @@ def test_gradients_match_oracle_mnist_geometry(ctx):
     model.close()
 
 
+def test_adam_bias_correction_uses_the_models_own_step_count(ctx):
+    """adam_step() without t counts the steps taken on this model's (zero-initialised) moment buffers: identical to explicit
+    t = 1, 2, ... and independent of whatever global_step a resumed run carries (a fresh tf optimiser restarts its beta powers)."""
+    hwc, N = (12, 12, 1), 3
+    spec = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), 8, S=2, num_data=100, seed=4, conv_q_sqrt_scale=0.3)
+    X, Y = syn.make_batch(hwc, N, seed=4)
+    zs = syn.make_noise(spec, N, seed=4)
+    a, b = build_from_spec(spec, X, Y), build_from_spec(spec, X, Y)
+    for t in (1, 2, 3):
+        a.compute_gradients(X, Y, zs=zs, fetch=False); a.adam_step(0.01, t)
+        b.compute_gradients(X, Y, zs=zs, fetch=False); b.adam_step(0.01)
+    a.pull_parameters(); b.pull_parameters()
+    for la, lb in zip(a.layers, b.layers):
+        np.testing.assert_array_equal(la.q_mu, lb.q_mu)
+        np.testing.assert_array_equal(la.feature.Z, lb.feature.Z)
+    a.close(); b.close()
+
+
 def test_training_entry_points_fail_loudly(ctx):
     """Error behaviour of the training-step C-ABI: no silent fallbacks."""
     from deepcgp_amd import device as dev
@@ -650,8 +668,8 @@ def test_training_entry_points_fail_loudly(ctx):
     with pytest.raises(dev.DcgpError):            # optimiser step before any gradient exists
         model._build(); model.adam_step(0.01, 1)
     model.compute_gradients(X, Y, fetch=False)
-    with pytest.raises(dev.DcgpError):            # t is 1-based
-        model.adam_step(0.01, 0)
+    with pytest.raises(dev.DcgpError):            # t is 1-based (None / 0 = the model's own step count)
+        model.adam_step(0.01, -1)
     with pytest.raises(dev.DcgpError):            # learning rate must be positive
         model.adam_step(-1.0, 1)
     L = dev.lib()
