@@ -11,32 +11,9 @@
 // conv_gp/layers.py:128-131 and the sample mean + z*sqrt(var + jitter).  (A few-column problem -- the head -- takes
 // the one-launch route of head_cond.hip instead.)
 #include "layer_impl.h"
+#include "rng.h"
 
 namespace {
-
-// ---- counter-based RNG (Philox4x32-10) + Box-Muller, one normal per element -------------------
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-  uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-  uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-  uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
-  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-__device__ __forceinline__ double philox_normal(uint64_t seed, uint32_t stream, uint64_t idx) {
-  uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), stream, 0x5eed5eedu};
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    philox_round(c, k0, k1);
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  // 53-bit uniform in (0,1] and a 32-bit angle
-  uint64_t bits = ((uint64_t)c[0] << 21) ^ (uint64_t)(c[1] >> 11);
-  double u1 = ((double)(bits & ((1ull << 53) - 1)) + 1.0) * (1.0 / 9007199254740992.0);
-  double u2 = ((double)c[2] + 0.5) * (1.0 / 4294967296.0);
-  return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
-}
 
 // 64 columns x R per block: phase 1 gathers the per-row-block partial sums (column-contiguous reads),
 // phase 2 writes the (column, r) pairs r-fastest == the N x (P*R) layout (contiguous writes).

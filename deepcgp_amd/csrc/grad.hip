@@ -1332,9 +1332,11 @@ int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, 
   dcgp_ctx* ctx = model->ctx;
   const bool keep = model->keep_outputs;
   model->keep_outputs = true;   // the reverse pass reads every layer's (sample, mean, var)
+  model->keep_state = true;     // ... and K_uf / A1 of every conv layer
   int rc = elbo_forward_impl(model, X, y, N, scale, z_per_layer_host, seed, dedup_layer0, out_host, info_host);
   if (rc == DCGP_OK) rc = model_backward(model, X, y, N, scale, dedup_layer0);
   model->keep_outputs = keep;
+  model->keep_state = false;
   DCGP_TRY(rc);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return DCGP_OK;

@@ -79,6 +79,28 @@ struct FinalizeArgs {
 };
 int finalize_layer(dcgp_ctx* ctx, const FinalizeArgs& a);
 
+// conv_fused.hip: the whole conv layer (patch sweep, both triangular products, mean, var, sample) of a column strip in one
+// workgroup; K_uf and A1 never leave the chip unless the training step asks for them
+struct ConvFusedArgs {
+  const double* X = nullptr; int n_mod = 0;               // [n_mod, H, W, C]; image of row n is X[n % n_mod]
+  int H = 0, W = 0, C = 0, f = 0, s = 0, Wo = 0, P = 0, L = 0, Lp = 0, HWC = 0;
+  const double* ZT = nullptr; const double* zn = nullptr; int M = 0, Mp = 0;
+  BaseKernel bk;
+  const double* LinvT = nullptr;                           // [Mp][Mp]
+  const double* G = nullptr;                               // [R][Mp][Mp] or nullptr (no q_sqrt term)
+  const double* alpha = nullptr; int R = 0, Rp = 0;        // [Mp][Rp]
+  int Kc = 0;                                              // columns = rows * P
+  double knn = 0.0;
+  int rep = 1; long rep_stride = 0;
+  const double* z = nullptr; uint64_t seed = 0; uint32_t stream_id = 0; double jitter = 0.0;
+  double *out_sample = nullptr, *out_mean = nullptr, *out_var = nullptr;
+  int idm = 0;
+  double *Kuf_out = nullptr, *A1_out = nullptr; long ldk = 0;   // training step: k-major [Mp][ldk] copies for the reverse pass
+  int lds_main = 0, lds_img = 0;                           // set by the launcher
+};
+bool conv_fused_ok(const ConvFusedArgs& a);
+int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a);
+
 // KL pieces of one layer -> kl4[0..3] = {mahalanobis, logdet_q, logdet_p, trace} (device)
 int kl_layer(dcgp_ctx* ctx, const GpMats& g, const double* Lp, const double* LpinvT, int white, const char* ws_prefix,
              double* kl4);

@@ -189,14 +189,40 @@ struct FactorGroup {
 static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, int rows, int n_mod, int rep, long rep_stride,
                  const double* z, uint64_t seed, uint32_t stream_id, double jitter, double* out_sample, double* out_mean,
                  double* out_var, const std::string& pfx, hipEvent_t factor_done = nullptr,
-                               hipEvent_t prep_done = nullptr, int phase = 3) {
+                               hipEvent_t prep_done = nullptr, int phase = 3, bool keep_state = true) {
   // phase bit 0: the K_uf sweep (needs only Z); bit 1: conditional + finalize (needs the factorisation).  The model
   // path enqueues bit 0 of its first layer BEFORE the long side-stream sequence so that the sweep is not held up
   // by the host still enqueueing the factorisation chain.
+  // keep_state: K_uf and A1 are left in the "<pfx>Kuf" / "<pfx>A1" workspaces (the reverse pass reads them there).
   const int Mp = L.Mp, P = L.v.P;
   const long Kc = (long)rows * P;
   if (Kc > 0x7fffff00L) return ctx_fail(ctx, DCGP_ERR_ARG, "conv layer: %ld patch columns exceed the 32-bit tile index", Kc);
   const long ldb = col_ld(Kc);
+  {
+    // one launch for the whole layer where the shape allows (conv_fused.hip): the strip of K_uf / A1 a workgroup owns
+    // stays in LDS from the patch gather to the sample
+    ConvFusedArgs fa;
+    fa.X = X; fa.n_mod = n_mod;
+    fa.H = L.v.H; fa.W = L.v.W; fa.C = L.v.C; fa.f = L.v.f; fa.s = L.v.s; fa.Wo = L.v.Wo; fa.P = P; fa.L = L.v.L; fa.Lp = L.Lp;
+    fa.HWC = L.v.H * L.v.W * L.v.C;
+    fa.ZT = L.ZT; fa.zn = L.zn; fa.M = L.M; fa.Mp = Mp; fa.bk = L.base();
+    fa.LinvT = L.g.LinvT; fa.G = L.has_qsqrt ? L.g.G : nullptr; fa.alpha = L.g.alpha; fa.R = L.R; fa.Rp = L.g.Rp;
+    fa.Kc = (int)Kc; fa.knn = L.variance;
+    fa.rep = rep; fa.rep_stride = rep_stride; fa.z = z; fa.seed = seed; fa.stream_id = stream_id; fa.jitter = jitter;
+    fa.out_sample = out_sample; fa.out_mean = out_mean; fa.out_var = out_var; fa.idm = L.identity_mean;
+    if (conv_fused_ok(fa)) {
+      if (!(phase & 2)) return DCGP_OK;   // nothing to run ahead of the factorisation: the sweep is part of the one launch
+      if (keep_state) {
+        fa.Kuf_out = (double*)ws_get(ctx, pfx + "Kuf", (size_t)Mp * ldb * sizeof(double));
+        fa.A1_out = (double*)ws_get(ctx, pfx + "A1", (size_t)Mp * ldb * sizeof(double));
+        if (!fa.Kuf_out || !fa.A1_out) return DCGP_ERR_ALLOC;
+        fa.ldk = ldb;
+      }
+      if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
+      if (prep_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, prep_done, 0));
+      return conv_fused(ctx, fa);
+    }
+  }
   double* B = (double*)ws_get(ctx, pfx + "Kuf", (size_t)Mp * ldb * sizeof(double));
   if (!B) return DCGP_ERR_ALLOC;
   if ((phase & 1) && Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));

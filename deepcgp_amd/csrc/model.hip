@@ -147,7 +147,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       auto& o = m->outs[li];
       DCGP_TRY(conv_forward(ctx, L, F, rows, n_mod, expand ? S : 1, (long)N * width, z, seed, (uint32_t)(li + 1 + 64 * ctx->rank),
                             m->jitter, o.sample, m->keep_outputs ? o.mean : nullptr, m->keep_outputs ? o.var : nullptr, pfx,
-                            fdone, ctx->ev_prep[li], phase));
+                            fdone, ctx->ev_prep[li], phase, m->keep_state));
       *out_rows_p = out_rows;
     } else {
       DCGP_TRY(ensure_out(m, li, rows, L.R, true));

@@ -10,6 +10,7 @@ struct dcgp_model {
   std::vector<std::unique_ptr<LayerState>> layers;   // conv layers..., head last (once set)
   bool has_head = false;
   bool keep_outputs = false;
+  bool keep_state = false;   // the forward leaves K_uf / A1 of every conv layer in HBM (set around the forward of dcgp_elbo_grad)
   int adam_t = 0;        // Adam steps taken on this model's moment buffers (bias correction; dcgp_model_adam_step with t = 0)
   int grad_shards = 0;   // KL gradient weight 1 / shards; 0 = number of ranks of the ctx's communicator (1 without one)
   std::vector<FactorGroup> groups;

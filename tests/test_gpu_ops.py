@@ -218,6 +218,49 @@ def test_conv_layer(ctx, white, H, W, C, f, s, M, R):
         assert abs(l0.KL()) < 1e-7
 
 
+@pytest.mark.parametrize("white", [False, True])
+@pytest.mark.parametrize("H,W,C,f,s,M,R,N", [
+    (28, 28, 1, 5, 2, 256, 10, 5),     # cfg2 conv0: 64-column strips, 8 waves x 2 row fragments, strips straddling two images
+    (13, 13, 10, 5, 1, 256, 10, 3),    # cfg3 conv1: L = 250, big images
+    (28, 28, 1, 4, 2, 200, 10, 3),     # Mp = 208: 13 row fragments (odd), padded rows
+    (32, 32, 3, 4, 2, 384, 10, 2),     # cfg4 conv0: 32-column strips, 12 waves
+    (15, 15, 10, 5, 1, 384, 10, 2),    # cfg4 conv1
+    (28, 28, 1, 5, 2, 500, 7, 2),      # Mp = 512: 16 waves x 2 fragments
+    (28, 28, 1, 5, 2, 1024, 10, 2),    # cfg5 conv0: 16-column strips, 16 waves x 4 row fragments
+    (9, 7, 3, 4, 2, 5, 3, 4),          # P = 6: many images per strip, a single (padded) row fragment
+    (12, 12, 2, 3, 1, 37, 16, 3),      # R = 16
+])
+def test_fused_conv_layer_matches_the_unfused_route_and_the_oracle(ctx, white, H, W, C, f, s, M, R, N):
+    """conv_fused.hip (the whole layer of a column strip in one workgroup) against the sweep + GEMM route it replaces
+    (DCGP_NO_FUSED_LAYER) and against the oracle, over every tile shape the launcher picks."""
+    import os
+    from deepcgp_amd.kernels import RBF, PatchInducingFeatures
+    from deepcgp_amd.layers import ConvLayer
+    from deepcgp_amd.views import FullView
+    rng = np.random.default_rng(1000 * M + R)
+    X = rng.standard_normal((N, H * W * C))
+    v, ov = FullView((H, W), f, C, s), OFullView((H, W), f, C, s)
+    Z, q_mu, q_sqrt = rand_spd_inputs(rng, M, R, v.patch_length, scale=0.05)
+    Z *= 1.5
+    layer = ConvLayer(RBF(v.patch_length, 5.0, 5.0), None, PatchInducingFeatures(Z), v, white=white, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
+    z = rng.standard_normal((N, layer.num_outputs))
+    assert "DCGP_NO_FUSED_LAYER" not in os.environ
+    smp, mean, var = layer._forward(X, z)
+    os.environ["DCGP_NO_FUSED_LAYER"] = "1"
+    try:
+        smp_u, mean_u, var_u = layer._forward(X, z)
+    finally:
+        del os.environ["DCGP_NO_FUSED_LAYER"]
+    close(mean, mean_u, 1e-11, "mean vs unfused")
+    close(var, var_u, 1e-10, "var vs unfused")
+    close(smp, smp_u, 1e-10, "sample vs unfused")
+    if M <= 512:
+        olayer = OConvLayer(ORBF(v.patch_length, 5.0, 5.0), None, Z, ov, white=white, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
+        om, ovar = olayer.conditional_ND(X)
+        close(mean, om, 1e-9, "mean vs oracle")
+        close(var, ovar, 1e-9, "var vs oracle")
+
+
 def test_conv_layer_identity_mean(ctx):
     from deepcgp_amd.kernels import RBF, PatchInducingFeatures
     from deepcgp_amd.layers import ConvLayer
