@@ -24,30 +24,49 @@
 namespace {
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-constexpr int CF_D = 3;   // A-operand k-tiles in flight per wave beside the one being multiplied
+constexpr int CF_D_DEFAULT = 3;   // A-operand k-tiles in flight per wave beside the one being multiplied
 
 __device__ __forceinline__ int frag_of(int w, int W, int c) { return (c >> 1) * 2 * W + ((c & 1) ? 2 * W - 1 - w : w); }
 
-template <int FN, int MAXF, int NT, int BT>
+// phase timestamps for tools/fused_trace.py: [workgroup][wave][16] shader-clock ticks, first 8 workgroups of every 90th
+#define CF_TR(k)                                                                                              \
+  if (a.trace && lane == 0 && blockIdx.x % 90 == 0 && blockIdx.x / 90 < 8)                                   \
+    a.trace[((blockIdx.x / 90) * 16 + wave) * 16 + (k)] = (long long)__builtin_readcyclecounter();
+
+// FN: 16-column fragments per strip.  NS: the W = NT/64 waves form NS teams of TW = W/NS; the row fragments are dealt to the
+// TW members of a team (boustrophedon), and the teams split the rest of the work: the columns of the strip in the sweep and in
+// the first product (FN/NS fragments each), the outputs r = team, team + NS, ... in the R-batched second product (all FN
+// column fragments, so that an A tile is still fetched by exactly one wave).  NS = 2 puts 16 waves = 4 per SIMD on a
+// 64-column strip: the fp64 MFMA pipe reaches 92 % of its rate from two waves per SIMD and 98 % from four.
+// MAXF: row fragments per wave at most.  ABL: timing experiments only (wrong results): 1 = second product without its
+// A-operand loads, 2 = without the LDS reads of the B operand, 4 = two more A tiles in flight.
+template <int FN, int NS, int MAXF, int NT, int BT, int ABL = 0>
 __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
-  constexpr int BN = FN * 16;
+  constexpr int BN = FN * 16, W = NT / 64, TW = W / NS, FNS = FN / NS, KG = W / FN;
+  static_assert(FN % NS == 0 && W % NS == 0 && W % FN == 0, "team split");
+  constexpr int CF_D = ((ABL & 4) ? 2 : 0) + (NT >= 1024 ? 2 : CF_D_DEFAULT);   // 128-register budget at 16 waves: two tiles ahead
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int Mp = a.Mp, nf = Mp >> 4, R = a.R;
   const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
-  const int W = NT / 64;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % TW, sp = NS == 1 ? 0 : wave / TW;   // member index within the team, team
   double* strip = smem;                                  // [Mp][BN], 16-column groups XOR-swizzled by (row & (FN-1))
-  double* aux = smem + a.lds_main;                       // images of the strip; dead after phase 1
+  double* aux = smem + a.lds_main;                       // images of the strip; after phase 1: [TW][BN] partial sums of A1^2
   double* xn = aux + a.lds_img;                          // [BN] |x_p|^2
   int* koff = reinterpret_cast<int*>(xn + BN);           // [Lp]
   const int j0 = blockIdx.x * BN;
   const int jmax = a.Kc - 1;
+  CF_TR(0)
+  if (a.trace && lane == 0 && blockIdx.x % 90 == 0 && blockIdx.x / 90 < 8) a.trace[((blockIdx.x / 90) * 16 + wave) * 16 + 10] = (long long)wall_clock64();
 
-  // fragments of this wave
+  // row fragments of this wave: frag_of(wm, TW, c), c < nfw
   int nfw = 0;
 #pragma unroll
-  for (int c = 0; c < MAXF; ++c) nfw += frag_of(wave, W, c) < nf ? 1 : 0;
+  for (int c = 0; c < MAXF; ++c) nfw += frag_of(wm, TW, c) < nf ? 1 : 0;
   nfw = __builtin_amdgcn_readfirstlane(nfw);
+  int fr[MAXF];   // fragments beyond the matrix repeat the first one (their loads stay in range, their results are dropped)
+#pragma unroll
+  for (int c = 0; c < MAXF; ++c) fr[c] = c < nfw ? frag_of(wm, TW, c) : min(wm, nf - 1);
 
   // ---- phase 0: images of the strip -> LDS, patch-element offsets, |x|^2 per column -----------------------------
   const int n_first = j0 / a.P;
@@ -82,6 +101,12 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
     const int oh = p / a.Wo, ow = p - oh * a.Wo;
     return (n - n_first) * a.HWC + (oh * a.s * a.W + ow * a.s) * a.C;
   };
+  // |z_m|^2 of this lane's accumulator rows: fetched here, needed after the sweep
+  double znv[MAXF][4];
+#pragma unroll
+  for (int c = 0; c < MAXF; ++c)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) znv[c][v] = a.zn[16 * fr[c] + lrow + 4 * v];
   __syncthreads();
   if (tid < 8 * BN) {   // 8 threads per column
     const int c = tid >> 3, sub = tid & 7;
@@ -97,62 +122,82 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
     if (sub == 0) xn[c] = s;
   }
   __syncthreads();
+  CF_TR(1)
 
   // per-lane constants of the strip accesses: element (row k, column y*16 + lcol) with k & 3 == lrow lives at
   // k * BN + ((y ^ (lrow & (FN-1))) * 16 + lcol)
   int bsw[FN];
 #pragma unroll
   for (int y = 0; y < FN; ++y) bsw[y] = ((y ^ (lrow & (FN - 1))) << 4) + lcol;
-
-  d4 acc[FN];
-  auto zero_acc = [&]() {
+  int bsw_s[FNS];   // the same for this team's column fragments sp*FNS + y
 #pragma unroll
-    for (int y = 0; y < FN; ++y) acc[y] = d4{0.0, 0.0, 0.0, 0.0};
-  };
+  for (int y = 0; y < FNS; ++y) bsw_s[y] = (((sp * FNS + y) ^ (lrow & (FN - 1))) << 4) + lcol;
 
-  // ---- phase 1: K_uf[:, strip] -> strip -------------------------------------------------------------------------
+  // ---- phase 1: K_uf[:, strip] -> strip: this wave's row fragments x its team's FNS column fragments ----------------
   {
-    int pb[FN];
+    int pb[FNS];
 #pragma unroll
-    for (int y = 0; y < FN; ++y) pb[y] = patch_off(y * 16 + lcol);
+    for (int y = 0; y < FNS; ++y) pb[y] = patch_off((sp * FNS + y) * 16 + lcol);
     const int nk4 = a.Lp >> 2;
-    for (int c = 0; c < nfw; ++c) {
-      const int f = frag_of(wave, W, c);
-      const double* __restrict__ zt = a.ZT + 16 * f + lcol;
-      zero_acc();
-      constexpr int D4 = 4;
-      double ring[D4 + 1];
+    d4 kacc[MAXF][FNS];
 #pragma unroll
-      for (int u = 0; u < D4; ++u) ring[u] = zt[(long)(4 * min(u, nk4 - 1) + lrow) * Mp];
-      for (int t = 0; t < nk4; t += D4 + 1) {
+    for (int c = 0; c < MAXF; ++c)
 #pragma unroll
-        for (int u = 0; u <= D4; ++u) {
-          if (t + u < nk4) {
-            ring[(u + D4) % (D4 + 1)] = zt[(long)(4 * min(t + u + D4, nk4 - 1) + lrow) * Mp];
-            const int k = 4 * (t + u) + lrow;
-            const int ko = koff[k];
-            const bool kin = k < a.L;
+      for (int y = 0; y < FNS; ++y) kacc[c][y] = d4{0.0, 0.0, 0.0, 0.0};
+    const double* __restrict__ zt = a.ZT + lcol;
+    constexpr int D4 = 4;
+    double ring[D4 + 1][MAXF];
+    auto ldz = [&](int k4, double (&dst)[MAXF]) {
 #pragma unroll
-            for (int y = 0; y < FN; ++y) {
-              const double v = aux[pb[y] + ko];
-              acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[u], kin ? v : 0.0, acc[y], 0, 0, 0);
-            }
-          }
-        }
+      for (int c = 0; c < MAXF; ++c) dst[c] = zt[(long)(4 * k4 + lrow) * Mp + 16 * fr[c]];
+    };
+    auto kstep = [&](int k4, const double (&w)[MAXF]) {
+      const int k = 4 * k4 + lrow;
+      const int ko = koff[k];
+      const bool kin = k < a.L;
+      double bv[FNS];
+#pragma unroll
+      for (int y = 0; y < FNS; ++y) {
+        const double v = aux[pb[y] + ko];
+        bv[y] = kin ? v : 0.0;
       }
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int m = 16 * f + lrow + 4 * v;
-        const double znm = a.zn[m];
+      for (int c = 0; c < MAXF; ++c)
 #pragma unroll
-        for (int y = 0; y < FN; ++y) {
-          const double kv = a.bk.template eval_as<BT>(acc[y][v], xn[y * 16 + lcol], znm);
-          strip[m * BN + bsw[y]] = (m < a.M) ? kv : 0.0;
+        for (int y = 0; y < FNS; ++y) kacc[c][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[c], bv[y], kacc[c][y], 0, 0, 0);
+    };
+#pragma unroll
+    for (int u = 0; u < D4; ++u) ldz(min(u, nk4 - 1), ring[u]);
+    int t = 0;
+    for (; t + D4 + 1 <= nk4; t += D4 + 1) {
+#pragma unroll
+      for (int u = 0; u <= D4; ++u) {
+        ldz(min(t + u + D4, nk4 - 1), ring[(u + D4) % (D4 + 1)]);
+        kstep(t + u, ring[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < D4; ++u)
+      if (t + u < nk4) kstep(t + u, ring[u]);
+#pragma unroll
+    for (int c = 0; c < MAXF; ++c) {
+      if (c < nfw) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int m = 16 * fr[c] + lrow + 4 * v;
+#pragma unroll
+          for (int y = 0; y < FNS; ++y) {
+            const int yy = sp * FNS + y;
+            const double kv = a.bk.template eval_as<BT>(kacc[c][y][v], xn[yy * 16 + lcol], znv[c][v]);
+            strip[m * BN + bsw_s[y]] = (m < a.M) ? kv : 0.0;
+          }
         }
       }
     }
   }
+  CF_TR(2)
   __syncthreads();
+  CF_TR(3)
   // training step: the reverse pass reads K_uf and A1 from HBM (k-major [Mp][ldk], column j)
   auto store_strip = [&](double* __restrict__ out) {
     for (int idx = tid; idx < Mp * BN; idx += NT) {
@@ -166,7 +211,6 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
   // ---- the A-operand stream ---------------------------------------------------------------------------------------
   // lane (lrow, lcol) of k-substep q of k-tile kt needs Wt[kt*16 + 4q + lrow][16 f + lcol]: per-lane byte offset voff[q],
   // everything else (matrix r, k-tile, fragment) is a scalar byte offset
-  constexpr unsigned OOB = 0x80000000u;
   unsigned voff[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) voff[q] = (unsigned)(((4 * q + lrow) * Mp + lcol) * 8);
@@ -177,84 +221,141 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
       __builtin_memcpy(&dst[q], &v, 8);
     }
   };
-  auto mfma_tile = [&](int kt, const double (&w)[4]) {
-    const double* b = strip + kt * 16 * BN;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int y = 0; y < FN; ++y)
-        acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[q], b[(4 * q + lrow) * BN + bsw[y]], acc[y], 0, 0, 0);
-  };
-  (void)OOB;
 
-  // ---- phase 2: A1 = inv(L) K_uf (lower-triangular W: fragment f needs k-tiles 0 .. f) --------------------------------
+  // ---- phase 2: A1 = inv(L) K_uf (lower-triangular W: fragment f needs k-tiles 0 .. f), FNS column fragments per wave ----
   const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.LinvT), 0, Mp * Mp * 8, 0x00020000);
-  d4 a1[MAXF][FN];
-  double s1acc[FN];
+  d4 a1[MAXF][FNS];
+  {
+    double s1acc[FNS];
 #pragma unroll
-  for (int y = 0; y < FN; ++y) s1acc[y] = 0.0;
+    for (int y = 0; y < FNS; ++y) s1acc[y] = 0.0;
+    d4 acc[FNS];
+    auto ldb = [&](int kt, int q, double (&dst)[FNS]) {
+      const double* b = strip + (kt * 16 + 4 * q + lrow) * BN;
 #pragma unroll
-  for (int c = 0; c < MAXF; ++c) {
-    if (c < nfw) {
-      const int f = frag_of(wave, W, c);
-      const int fo = 16 * f * 8;
-      zero_acc();
-      double ring[CF_D + 1][4];
+      for (int y = 0; y < FNS; ++y) dst[y] = b[bsw_s[y]];
+    };
+    auto mf = [&](double w, const double (&b)[FNS]) {
 #pragma unroll
-      for (int u = 0; u < CF_D; ++u) ldw(lrs, fo + min(u, f) * 16 * Mp * 8, ring[u]);
-      for (int kt = 0; kt <= f; kt += CF_D + 1) {
+      for (int y = 0; y < FNS; ++y) acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, b[y], acc[y], 0, 0, 0);
+    };
+    auto tile = [&](int kt, int kt_next, const double (&w)[4], double (&b0)[FNS]) {
+      double b1[FNS], b2[FNS], b3[FNS];
+      ldb(kt, 1, b1);
+      mf(w[0], b0);
+      ldb(kt, 2, b2);
+      mf(w[1], b1);
+      ldb(kt, 3, b3);
+      mf(w[2], b2);
+      ldb(kt_next, 0, b0);
+      mf(w[3], b3);
+    };
 #pragma unroll
-        for (int u = 0; u <= CF_D; ++u) {
-          if (kt + u <= f) {
+    for (int c = 0; c < MAXF; ++c) {
+      if (c < nfw) {
+        const int f = fr[c];
+        const int fo = 16 * f * 8;
+        const int n1 = f + 1;   // tiles 0 .. f
+#pragma unroll
+        for (int y = 0; y < FNS; ++y) acc[y] = d4{0.0, 0.0, 0.0, 0.0};
+        double ring[CF_D + 1][4], b0[FNS];
+#pragma unroll
+        for (int u = 0; u < CF_D; ++u) ldw(lrs, fo + min(u, f) * 16 * Mp * 8, ring[u]);
+        ldb(0, 0, b0);
+        int kt = 0;
+        for (; kt + CF_D + 1 <= n1; kt += CF_D + 1) {   // full groups: no conditionals, the load counters stay exact
+#pragma unroll
+          for (int u = 0; u <= CF_D; ++u) {
             ldw(lrs, fo + min(kt + u + CF_D, f) * 16 * Mp * 8, ring[(u + CF_D) % (CF_D + 1)]);
-            mfma_tile(kt + u, ring[u]);
+            tile(kt + u, min(kt + u + 1, f), ring[u], b0);
           }
         }
-      }
 #pragma unroll
-      for (int y = 0; y < FN; ++y) {
-        a1[c][y] = acc[y];
+        for (int u = 0; u < CF_D; ++u) {
+          if (kt + u < n1) tile(kt + u, min(kt + u + 1, f), ring[u], b0);
+        }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) s1acc[y] = fma(acc[y][v], acc[y][v], s1acc[y]);
+        for (int y = 0; y < FNS; ++y) {
+          a1[c][y] = acc[y];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) s1acc[y] = fma(acc[y][v], acc[y][v], s1acc[y]);
+        }
       }
     }
+    CF_TR(4)
+    __syncthreads();   // every wave is done reading K_uf (and the images)
+#pragma unroll
+    for (int y = 0; y < FNS; ++y) {   // sum over this wave's rows of A1^2, per column: joined over the team in phase 4
+      double s = s1acc[y];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lrow == 0) aux[wm * BN + (sp * FNS + y) * 16 + lcol] = s;
+    }
   }
-  __syncthreads();   // every wave is done reading K_uf
 #pragma unroll
   for (int c = 0; c < MAXF; ++c) {
     if (c < nfw) {
-      const int f = frag_of(wave, W, c);
 #pragma unroll
-      for (int y = 0; y < FN; ++y)
+      for (int y = 0; y < FNS; ++y)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) strip[(16 * f + lrow + 4 * v) * BN + bsw[y]] = a1[c][y][v];
+        for (int v = 0; v < 4; ++v) strip[(16 * fr[c] + lrow + 4 * v) * BN + bsw_s[y]] = a1[c][y][v];
     }
   }
   __syncthreads();   // A1 published
+  CF_TR(5)
   if (a.A1_out) store_strip(a.A1_out);
 
-  // ---- phase 3: T_r = G_r^T A1 for every r (upper-triangular W: fragment f needs k-tiles f .. nf-1), one flat stream ----
-  // s2 of output r is parked in the lanes with lrow == (r & 3) of keep[r >> 2][.]
-  double keep[4][FN];
+  // ---- phase 3: T_r = G_r^T A1 for r = sp, sp + NS, ... (upper-triangular W: fragment f needs k-tiles f .. nf-1): one flat
+  // stream over (r, fragment, k-tile), all FN column fragments.  s2 of this wave's i-th output is parked in the lanes with
+  // lrow == (i & 3) of keep[i >> 2][.]
+  constexpr int KEEP = (16 / NS + 3) / 4;
+  double keep[KEEP][FN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < KEEP; ++i)
 #pragma unroll
     for (int y = 0; y < FN; ++y) keep[i][y] = 0.0;
-  if (a.G && nfw > 0) {
+  d4 acc[FN];
+#pragma unroll
+  for (int y = 0; y < FN; ++y) acc[y] = d4{0.0, 0.0, 0.0, 0.0};
+  auto ldb = [&](int kt, int q, double (&dst)[FN]) {
+    const double* b = strip + (kt * 16 + 4 * q + lrow) * BN;
+#pragma unroll
+    for (int y = 0; y < FN; ++y) dst[y] = (ABL & 2) ? (double)(lane + y + q) : b[bsw[y]];
+  };
+  auto mf = [&](double w, const double (&b)[FN]) {
+#pragma unroll
+    for (int y = 0; y < FN; ++y) acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, b[y], acc[y], 0, 0, 0);
+  };
+  // one k-tile: b0 holds sub-step 0 of tile kt on entry and of tile kt_next on exit -- the LDS reads of every sub-step are
+  // issued one sub-step ahead of the MFMAs that consume them, across the scalar bookkeeping between two tiles as well
+  auto tile = [&](int kt, int kt_next, const double (&w)[4], double (&b0)[FN]) {
+    double b1[FN];
+    ldb(kt, 1, b1);
+    mf(w[0], b0);
+    ldb(kt, 2, b0);
+    mf(w[1], b1);
+    ldb(kt, 3, b1);
+    mf(w[2], b0);
+    ldb(kt_next, 0, b0);
+    mf(w[3], b1);
+  };
+  const int nr = (R - sp + NS - 1) / NS;   // outputs of this team
+  if (a.G && nfw > 0 && nr > 0) {
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.G), 0, R * Mp * Mp * 8, 0x00020000);
     int steps_per_r = 0;
-    for (int c = 0; c < nfw; ++c) steps_per_r += nf - frag_of(wave, W, c);
-    const int total = R * steps_per_r;
-    // load cursor / compute cursor: (r, c, kt) with f = frag_of(c)
-    int lr = 0, lc = 0, lf = frag_of(wave, W, 0), lk = lf, lleft = total - 1;   // lleft: advances still allowed (clamp at the last tile)
-    int cr = 0, cc = 0, cf = lf, ck = lf;
+    for (int c = 0; c < nfw; ++c) steps_per_r += nf - frag_of(wm, TW, c);
+    const int total = nr * steps_per_r;
+    // load cursor / compute cursor over the flat sequence of (r, fragment c, k-tile); the load cursor stops on the last tile
+    const int f0 = frag_of(wm, TW, 0);
+    int lr = sp, lc = 0, lf = f0, lk = f0, lleft = total - 1;
+    int ci = 0, cc = 0, ck = f0, cleft = total - 1;
     auto lsoff = [&]() { return ((lr * Mp + lk * 16) * Mp + 16 * lf) * 8; };
     auto ladv = [&]() {
       if (lleft > 0) {
         --lleft;
         if (++lk >= nf) {
-          if (++lc == nfw) { lc = 0; ++lr; }
-          lf = frag_of(wave, W, lc);
+          if (++lc == nfw) { lc = 0; lr += NS; }
+          lf = frag_of(wm, TW, lc);
           lk = lf;
         }
       }
@@ -262,91 +363,112 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
     double s2acc[FN];
 #pragma unroll
     for (int y = 0; y < FN; ++y) s2acc[y] = 0.0;
-    zero_acc();
-    double ring[CF_D + 1][4];
+    double ring[CF_D + 1][4], b0[FN];
 #pragma unroll
     for (int u = 0; u < CF_D; ++u) { ldw(grs, lsoff(), ring[u]); ladv(); }
-    for (int t = 0; t < total; t += CF_D + 1) {
+    ldb(ck, 0, b0);
+    auto step = [&](const double (&w)[4]) {
+      const int kcur = ck;
+      const bool frag_end = kcur == nf - 1;
+      bool r_end = false;
+      if (cleft > 0) {   // advance the compute cursor first: the next tile's first B sub-step is fetched under this tile's MFMAs
+        --cleft;
+        if (frag_end) {
+          if (++cc == nfw) { cc = 0; r_end = true; }
+          ck = frag_of(wm, TW, cc);
+        } else {
+          ++ck;
+        }
+      } else {
+        r_end = true;
+      }
+      tile(kcur, ck, w, b0);
+      if (frag_end) {   // fragment done: fold its rows into the column sums of squares
 #pragma unroll
-      for (int u = 0; u <= CF_D; ++u) {
-        if (t + u < total) {
-          ldw(grs, lsoff(), ring[(u + CF_D) % (CF_D + 1)]);
-          ladv();
-          mfma_tile(ck, ring[u]);
-          if (++ck >= nf) {   // fragment done: fold its rows into the column sums of squares
+        for (int y = 0; y < FN; ++y) {
 #pragma unroll
-            for (int y = 0; y < FN; ++y) {
+          for (int v = 0; v < 4; ++v) s2acc[y] = fma(acc[y][v], acc[y][v], s2acc[y]);
+          acc[y] = d4{0.0, 0.0, 0.0, 0.0};
+        }
+        if (r_end) {   // output done
 #pragma unroll
-              for (int v = 0; v < 4; ++v) s2acc[y] = fma(acc[y][v], acc[y][v], s2acc[y]);
-              acc[y] = d4{0.0, 0.0, 0.0, 0.0};
-            }
-            if (++cc == nfw) {   // output r done
+          for (int y = 0; y < FN; ++y) {
+            double s = s2acc[y];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
 #pragma unroll
-              for (int y = 0; y < FN; ++y) {
-                double s = s2acc[y];
-                s += __shfl_xor(s, 16);
-                s += __shfl_xor(s, 32);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) keep[i][y] = ((cr >> 2) == i && (cr & 3) == lrow) ? s : keep[i][y];
-                s2acc[y] = 0.0;
-              }
-              cc = 0;
-              ++cr;
-            }
-            cf = frag_of(wave, W, cc);
-            ck = cf;
+            for (int i = 0; i < KEEP; ++i) keep[i][y] = ((ci >> 2) == i && (ci & 3) == lrow) ? s : keep[i][y];
+            s2acc[y] = 0.0;
           }
+          ++ci;
         }
       }
+    };
+    int t = 0;
+    for (; t + CF_D + 1 <= total; t += CF_D + 1) {   // full groups: no conditionals around the loads
+#pragma unroll
+      for (int u = 0; u <= CF_D; ++u) {
+        if (!(ABL & 1)) ldw(grs, lsoff(), ring[(u + CF_D) % (CF_D + 1)]);
+        ladv();
+        step(ring[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CF_D; ++u) {
+      if (t + u < total) step(ring[u]);
     }
   }
+  CF_TR(6)
 
-  // ---- mean = alpha^T A1: k-tiles dealt round-robin to the waves, partial sums joined in the final reduction ----------
-  zero_acc();
+  // ---- mean = alpha^T A1: wave (y, g) = (wave % FN, wave / FN) takes column fragment y and the k-tiles g, g + KG, ... -------
+  d4 macc = d4{0.0, 0.0, 0.0, 0.0};
   {
+    const int y = wave % FN, g = wave / FN;
     const double* __restrict__ al = a.alpha + lcol;
-    for (int kt = wave; kt < nf; kt += W) {
-      double w[4];
+    for (int kt = g; kt < nf; kt += KG) {
+      double w[4], b[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) w[q] = al[(long)(kt * 16 + 4 * q + lrow) * a.Rp];
-      mfma_tile(kt, w);
+      for (int q = 0; q < 4; ++q) {
+        w[q] = al[(long)(kt * 16 + 4 * q + lrow) * a.Rp];
+        b[q] = strip[(kt * 16 + 4 * q + lrow) * BN + ((y ^ (lrow & (FN - 1))) << 4) + lcol];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) macc = __builtin_amdgcn_mfma_f64_16x16x4f64(w[q], b[q], macc, 0, 0, 0);
     }
   }
-  // per-column sums over this wave's rows
-#pragma unroll
-  for (int y = 0; y < FN; ++y) {
-    s1acc[y] += __shfl_xor(s1acc[y], 16);
-    s1acc[y] += __shfl_xor(s1acc[y], 32);
-  }
-  __syncthreads();   // the strip is dead: reuse it as [W][BN] s1 | [W][R][BN] s2 | [W][16][BN] mean partials
-  double* s1p = smem;
-  double* s2p = s1p + W * BN;
-  double* mup = s2p + W * R * BN;
+  CF_TR(7)
+  __syncthreads();   // the strip is dead: reuse it as [TW][R][BN] s2 | [KG][16][BN] mean partials
+  double* s1p = aux;
+  double* s2p = smem;
+  double* mup = s2p + TW * R * BN;
 #pragma unroll
   for (int y = 0; y < FN; ++y) {
     const int c = y * 16 + lcol;
-    if (lrow == 0) s1p[wave * BN + c] = s1acc[y];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = 4 * i + lrow;
-      if (r < R) s2p[(wave * R + r) * BN + c] = keep[i][y];
+    for (int i = 0; i < KEEP; ++i) {
+      const int r = sp + NS * (4 * i + lrow);
+      if (r < R) s2p[(wm * R + r) * BN + c] = keep[i][y];
     }
+  }
+  {
+    const int y = wave % FN, g = wave / FN;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) mup[(wave * 16 + lrow + 4 * v) * BN + c] = acc[y][v];
+    for (int v = 0; v < 4; ++v) mup[(g * 16 + lrow + 4 * v) * BN + y * 16 + lcol] = macc[v];
   }
   __syncthreads();
 
+  CF_TR(8)
   // ---- phase 4: var, mean, sample in the N x (P*R) layout (column j, output r at j*R + r) ----------------------------
   for (int idx = tid; idx < BN * R; idx += NT) {
     const int c = idx / R, r = idx - c * R;
     const int j = j0 + c;
     if (j > jmax) continue;
     double s1 = 0.0, s2 = 0.0, m = 0.0;
-    for (int w = 0; w < W; ++w) {
+    for (int w = 0; w < TW; ++w) {
       s1 += s1p[w * BN + c];
       s2 += s2p[(w * R + r) * BN + c];
-      m += mup[(w * 16 + r) * BN + c];
     }
+    for (int g = 0; g < KG; ++g) m += mup[(g * 16 + r) * BN + c];
     const double v = (a.knn - s1) + s2;
     if (a.idm && r == 0) {   // Conv2dMean (conv_gp/mean_functions.py:28-41): centre pixel of channel 0 onto map 0
       const int n = j / a.P, p = j - n * a.P;
@@ -364,48 +486,70 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
       }
     }
   }
+  CF_TR(9)
+  if (a.trace && lane == 0 && blockIdx.x % 90 == 0 && blockIdx.x / 90 < 8) a.trace[((blockIdx.x / 90) * 16 + wave) * 16 + 11] = (long long)wall_clock64();
 }
 
-template <int FN, int MAXF, int NT>
+// the instantiated shapes: <FN, NS, MAXF, NT>
+//   0: <4,2,2,1024>  Mp <= 256, 64-column strips, 16 waves in two teams       1: <4,1,2,512>  the same on 8 waves
+//   2: <2,1,2,512>   Mp <= 256, 32-column strips (large images)               3: <1,1,2,512>  16-column strips
+//   4: <2,1,2,768>   Mp <= 384 (12 waves)     5: <2,1,2,1024>  Mp <= 512      6: <1,1,4,1024>  Mp <= 1024
+struct FusedShape { int FN, NS, MAXF, NT, max_nf; };
+constexpr FusedShape kShapes[] = {{4, 2, 2, 1024, 16}, {4, 1, 2, 512, 16}, {2, 1, 2, 512, 16}, {1, 1, 2, 512, 16},
+                                  {2, 1, 2, 768, 24},  {2, 1, 2, 1024, 32}, {1, 1, 4, 1024, 64}};
+constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
+
+template <int FN, int NS, int MAXF, int NT>
 int launch_fused(dcgp_ctx* ctx, const ConvFusedArgs& a, size_t lds) {
   const int BN = FN * 16;
   const unsigned grid = (unsigned)((a.Kc + BN - 1) / BN);
-  if (a.bk.type == 0) hipLaunchKernelGGL((conv_fused_kernel<FN, MAXF, NT, 0>), dim3(grid), dim3(NT), lds, ctx->stream, a);
-  else hipLaunchKernelGGL((conv_fused_kernel<FN, MAXF, NT, 1>), dim3(grid), dim3(NT), lds, ctx->stream, a);
+  static bool attr_done = false;
+  if (!attr_done) {   // more than 64 KB of dynamic LDS needs the opt-in
+    hipFuncSetAttribute((const void*)conv_fused_kernel<FN, NS, MAXF, NT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)conv_fused_kernel<FN, NS, MAXF, NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  if (a.bk.type == 0) hipLaunchKernelGGL((conv_fused_kernel<FN, NS, MAXF, NT, 0>), dim3(grid), dim3(NT), lds, ctx->stream, a);
+  else hipLaunchKernelGGL((conv_fused_kernel<FN, NS, MAXF, NT, 1>), dim3(grid), dim3(NT), lds, ctx->stream, a);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }
 
-struct FusedPlan { int FN, W, MAXF; size_t lds; int lds_main, lds_img; };
+struct FusedPlan { int shape; size_t lds; int lds_main, lds_img; };
 
-// tile shape for a layer: the widest strip whose LDS footprint fits, waves = half the row fragments (one early + one late
-// fragment each) up to 16
+// the first instantiated shape (widest strip, most waves) that covers Mp and whose LDS footprint fits
 bool plan_fused(const ConvFusedArgs& a, FusedPlan* p) {
-  static const int force_fn = getenv("DCGP_FUSED_FN") ? atoi(getenv("DCGP_FUSED_FN")) : 0;
+  const int force = getenv("DCGP_FUSED_SHAPE") ? atoi(getenv("DCGP_FUSED_SHAPE")) : -1;   // A/B experiments
   const int nf = a.Mp / 16;
-  if (a.Rp != 16 || a.R > 16 || a.Mp > 1024) return false;
-  for (int FN = 4; FN >= 1; FN >>= 1) {
-    if (force_fn && FN != force_fn) continue;
-    const int BN = FN * 16;
-    int W, MAXF;
-    if (nf <= 16) { W = 8; MAXF = 2; }
-    else if (nf <= 24) { W = 12; MAXF = 2; }
-    else if (nf <= 32) { W = 16; MAXF = 2; }
-    else { W = 16; MAXF = 4; }
-    if (MAXF == 4 && FN != 1) continue;            // instantiated shapes: <4,2,512> <2,2,512|768|1024> <1,2,512> <1,4,1024>
-    if (MAXF == 2 && W != 8 && FN != 2) continue;
+  if (a.Rp != 16 || a.R > 16 || a.Mp > 1024 || a.Mp % 16) return false;
+  for (int i = 0; i < kNumShapes; ++i) {
+    const FusedShape& sh = kShapes[i];
+    if (force >= 0 && i != force) continue;
+    if (nf > sh.max_nf) continue;
+    if (sh.max_nf > 16 && nf <= 16 && force < 0) continue;   // the many-wave shapes are for the large matrices
+    const int BN = sh.FN * 16, W = sh.NT / 64, TW = W / sh.NS, KG = W / sh.FN;
     const int nimg = (BN - 1) / a.P + 2;           // images a strip can touch
-    const long main_d = (long)a.Mp * BN > (long)(W + W * a.R + W * 16) * BN ? (long)a.Mp * BN : (long)(W + W * a.R + W * 16) * BN;
-    const long img_d = ((long)nimg * a.HWC + 1) & ~1L;
+    const long fin = (long)(TW * a.R + KG * 16) * BN;
+    const long main_d = (long)a.Mp * BN > fin ? (long)a.Mp * BN : fin;
+    long img_d = ((long)nimg * a.HWC + 1) & ~1L;
+    if (img_d < (long)TW * BN) img_d = (long)TW * BN;
     const long bytes = (main_d + img_d + BN) * 8 + (long)a.Lp * 4;
     if (bytes > 160 * 1024) continue;
-    p->FN = FN; p->W = W; p->MAXF = MAXF; p->lds = (size_t)bytes; p->lds_main = (int)main_d; p->lds_img = (int)img_d;
+    p->shape = i; p->lds = (size_t)bytes; p->lds_main = (int)main_d; p->lds_img = (int)img_d;
     return true;
   }
   return false;
 }
 
 }  // namespace
+
+static long long* g_cf_trace = nullptr;
+// debugging aid (tools/fused_trace.py): device buffer of 8 x 16 x 16 int64 that the fused layer kernel stamps its phases into
+extern "C" int dcgp_debug_set_fused_trace(dcgp_ctx* ctx, long long* buf_dev) {
+  (void)ctx;
+  g_cf_trace = buf_dev;
+  return DCGP_OK;
+}
 
 bool conv_fused_ok(const ConvFusedArgs& a) {
   const bool off = getenv("DCGP_NO_FUSED_LAYER") != nullptr;   // A/B switch (read per call: tests flip it): the unfused sweep + GEMM route
@@ -420,20 +564,28 @@ int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a_in) {
   if ((long)a_in.R * a_in.Mp * a_in.Mp * 8 >= (1L << 31)) return ctx_fail(ctx, DCGP_ERR_ARG, "conv_fused: G exceeds 2 GiB");
   ConvFusedArgs a = a_in;
   a.lds_main = p.lds_main; a.lds_img = p.lds_img;
-  static bool attr_done = false;
-  if (!attr_done) {   // more than 64 KB of dynamic LDS needs the opt-in
-#define CF_ATTR(FN, MF, NT)                                                                                                           \
-  hipFuncSetAttribute((const void*)conv_fused_kernel<FN, MF, NT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-  hipFuncSetAttribute((const void*)conv_fused_kernel<FN, MF, NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    CF_ATTR(4, 2, 512) CF_ATTR(2, 2, 512) CF_ATTR(1, 2, 512) CF_ATTR(2, 2, 768) CF_ATTR(2, 2, 1024) CF_ATTR(1, 4, 1024)
-#undef CF_ATTR
-    attr_done = true;
-  }
+  a.trace = g_cf_trace;
   ScopedTimer t(ctx, "conv_fused");
-  if (p.MAXF == 4) return launch_fused<1, 4, 1024>(ctx, a, p.lds);
-  if (p.W == 16) return launch_fused<2, 2, 1024>(ctx, a, p.lds);
-  if (p.W == 12) return launch_fused<2, 2, 768>(ctx, a, p.lds);
-  if (p.FN == 4) return launch_fused<4, 2, 512>(ctx, a, p.lds);
-  if (p.FN == 2) return launch_fused<2, 2, 512>(ctx, a, p.lds);
-  return launch_fused<1, 2, 512>(ctx, a, p.lds);
+  const int abl = getenv("DCGP_FUSED_ABL") ? atoi(getenv("DCGP_FUSED_ABL")) : 0;   // timing experiments (wrong results)
+  if (abl && p.shape == 0 && a.bk.type == 0) {
+    const unsigned grid = (unsigned)((a.Kc + 63) / 64);
+#define CF_ABL(X)                                                                                                                       \
+  case X:                                                                                                                               \
+    hipFuncSetAttribute((const void*)conv_fused_kernel<4, 2, 2, 1024, 0, X>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((conv_fused_kernel<4, 2, 2, 1024, 0, X>), dim3(grid), dim3(1024), p.lds, ctx->stream, a);                        \
+    break;
+    switch (abl) { CF_ABL(1) CF_ABL(2) CF_ABL(3) CF_ABL(4) default: break; }
+#undef CF_ABL
+    LAUNCH_CHECK(ctx);
+    return DCGP_OK;
+  }
+  switch (p.shape) {
+    case 0: return launch_fused<4, 2, 2, 1024>(ctx, a, p.lds);
+    case 1: return launch_fused<4, 1, 2, 512>(ctx, a, p.lds);
+    case 2: return launch_fused<2, 1, 2, 512>(ctx, a, p.lds);
+    case 3: return launch_fused<1, 1, 2, 512>(ctx, a, p.lds);
+    case 4: return launch_fused<2, 1, 2, 768>(ctx, a, p.lds);
+    case 5: return launch_fused<2, 1, 2, 1024>(ctx, a, p.lds);
+    default: return launch_fused<1, 1, 4, 1024>(ctx, a, p.lds);
+  }
 }

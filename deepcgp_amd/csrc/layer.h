@@ -97,6 +97,7 @@ struct ConvFusedArgs {
   int idm = 0;
   double *Kuf_out = nullptr, *A1_out = nullptr; long ldk = 0;   // training step: k-major [Mp][ldk] copies for the reverse pass
   int lds_main = 0, lds_img = 0;                           // set by the launcher
+  long long* trace = nullptr;                              // debugging aid: phase timestamps (dcgp_debug_set_fused_trace)
 };
 bool conv_fused_ok(const ConvFusedArgs& a);
 int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a);

@@ -283,6 +283,11 @@ int dcgp_comm_destroy(dcgp_ctx* ctx);
 int dcgp_comm_count(dcgp_ctx* ctx, int* out_ranks);
 int dcgp_allreduce_sum_f64(dcgp_ctx* ctx, double* buf_dev, int n);
 
+/* ---- debugging aid ----------------------------------------------------------------------------------------------- */
+/* Device buffer of 8 x 16 x 16 int64 into which the one-launch conv layer kernel (csrc/conv_fused.hip) stamps the shader
+ * clock at its phase boundaries (8 sampled workgroups x 16 waves x 16 stamps); NULL switches it off (tools/fused_trace.py). */
+int dcgp_debug_set_fused_trace(dcgp_ctx* ctx, long long* buf_dev);
+
 #ifdef __cplusplus
 }
 #endif

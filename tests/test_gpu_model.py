@@ -332,16 +332,25 @@ def test_baseline_configs_3_to_5_full_size_properties(ctx, name):
     model.close()
 
 
-def test_oversized_operand_slab_is_refused(ctx):
-    """gemm_tn fetches whole k-tiles through 32-bit-offset buffer descriptors: an [M x columns] operand of 2 GiB or more is
-    refused with DCGP_ERR_ARG and a message naming the limit -- never silently wrapped."""
+def test_oversized_operand_slab(ctx):
+    """[M x columns] = 1024 x 288 000 doubles = 2.36 GB.  The one-launch layer (conv_fused.hip) never materialises it and
+    takes the size in its stride; the sweep + GEMM route fetches whole k-tiles through 32-bit-offset buffer descriptors and
+    must REFUSE an operand of 2 GiB or more with DCGP_ERR_ARG and a message naming the limit -- never wrap silently."""
+    import os
     from deepcgp_amd import device as dev
     spec, X, Y = syn.make_config("cfg5_mnist_CH_M1024", S=10)
-    X = np.tile(X, (2, 1))[:200]                    # 200 images x 10 samples x 144 patches = 288 000 columns x 1024 rows x 8 B = 2.36 GB
+    X = np.tile(X, (2, 1))[:200]                    # 200 images x 10 samples x 144 patches
     Y = np.tile(Y, 2)[:200]
     model = build_from_spec(spec, X, Y)
-    with pytest.raises(dev.DcgpError) as ei:
-        model.compute_log_likelihood(X, Y, seed=0)
+    e, data, kl = model.compute_log_likelihood(X, Y, seed=0, return_parts=True)
+    lo = model.compute_log_likelihood(X[:100], Y[:100], seed=0, return_parts=True)[1]
+    assert np.isfinite([e, data, kl]).all() and data < lo < 0
+    os.environ["DCGP_NO_FUSED_LAYER"] = "1"
+    try:
+        with pytest.raises(dev.DcgpError) as ei:
+            model.compute_log_likelihood(X, Y, seed=0)
+    finally:
+        del os.environ["DCGP_NO_FUSED_LAYER"]
     assert ei.value.code == dev.ERR_ARG and "2 GiB" in str(ei.value)
     model.close()
 
