@@ -31,6 +31,14 @@ struct dcgp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;    // the stream launches go to (temporarily swapped to stream2 for the side branch)
   hipStream_t stream2 = nullptr;   // side stream: factorisation chain + KL terms
+  // CU partition for steps in flight (dcgp_elbo_forward_enqueue): the data path of step i on 30 CUs of every XCD, the
+  // parameter-only chain of step i + 1 on the other 2 (hipExtStreamCreateWithCUMask; nullptr when the device is not 8 x 32 CUs)
+  hipStream_t stream2b = nullptr;  // second side stream: the chain of a step enqueued while the previous one is in flight (bank 1)
+  hipStream_t stream_aux = nullptr;   // short excursions beside the main stream inside a layer (the head's Kdiag)
+  hipStream_t stream_m = nullptr, stream2_m = nullptr;
+  hipStream_t last_main = nullptr;             // main stream of the most recent forward step ...
+  hipEvent_t ev_last = nullptr;                // ... and the event marking the end of that step on it (not owned; a step on the other main stream waits for it)
+  bool ev_last_valid = false;
   hipEvent_t ev_fork = nullptr, ev_factor = nullptr, ev_kl = nullptr;
   hipEvent_t ev_prep[8] = {};   // per layer: G / alpha of layer l are ready (side stream)
   bool no_side = false;            // DCGP_NO_SIDE_STREAM: everything on the main stream (A/B switch; counter-collection runs, where
@@ -137,6 +145,42 @@ __device__ __forceinline__ double exp_sweep(double x) {
   return x < -746.0 ? 0.0 : ldexp(p, (int)kf);
 }
 
+// N of them at once.  One exp is a chain of ~25 DEPENDENT double-precision operations (~350 cycles of latency for ~100 of issue):
+// a wave that evaluates its accumulator values one after the other leaves the hiding to the other waves on its SIMD (the sweep
+// epilogues measured 350 cycles per wave-level exp).  Here every Horner step is issued for all N values before the next one.
+template <int N>
+__device__ __forceinline__ void exp_sweep_n(double (&x)[N]) {
+  double kf[N], r[N], p[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    kf[i] = rint(x[i] * 1.4426950408889634074);
+    r[i] = fma(-kf[i], 6.93147180369123816490e-01, x[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    r[i] = fma(-kf[i], 1.90821492927058770002e-10, r[i]);
+    p[i] = 1.6059043836821613e-10;
+  }
+#define DCGP_EXP_STEP_N(c)      \
+  _Pragma("unroll") for (int i = 0; i < N; ++i) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p[i]) : "v"(p[i]), "v"(r[i]), "s"((double)(c)))
+  DCGP_EXP_STEP_N(2.08767569878681e-09);
+  DCGP_EXP_STEP_N(2.505210838544172e-08);
+  DCGP_EXP_STEP_N(2.755731922398589e-07);
+  DCGP_EXP_STEP_N(2.7557319223985893e-06);
+  DCGP_EXP_STEP_N(2.48015873015873e-05);
+  DCGP_EXP_STEP_N(1.984126984126984e-04);
+  DCGP_EXP_STEP_N(1.388888888888889e-03);
+  DCGP_EXP_STEP_N(8.333333333333333e-03);
+  DCGP_EXP_STEP_N(4.1666666666666664e-02);
+  DCGP_EXP_STEP_N(1.6666666666666666e-01);
+  DCGP_EXP_STEP_N(0.5);
+  DCGP_EXP_STEP_N(1.0);
+  DCGP_EXP_STEP_N(1.0);
+#undef DCGP_EXP_STEP_N
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = x[i] < -746.0 ? 0.0 : ldexp(p[i], (int)kf[i]);   // same arithmetic as exp_sweep, element by element
+}
+
 // The base kernel of a layer, evaluated from (x.z, |x|^2, |z|^2):
 //   type 0  gpflow RBF:           variance * exp(-(|x|^2 + |z|^2 - 2 x.z) / (2 l^2))     p1 = 1 / l^2 (square_dist form, no clamp)
 //   type 1  gpflow ArcCosine(0):  variance * (pi - theta) / pi,  theta = acos(1e-15 + (1 - 2e-15) cos),
@@ -152,6 +196,20 @@ struct BaseKernel {
     // fmin: on a diagonal entry cos can round a few ulp above 1 (dot and norms are accumulated in different orders)
     // and overshoot the reference's 1e-15 guard -- acos() would return NaN there, as the reference formula does
     return variance * (1.0 - acos(fmin(1e-15 + (1.0 - 2e-15) * c, 1.0)) * 0.31830988618379067154);
+  }
+  // N values at once (io: x.z in, kernel value out): the RBF's exps interleaved (exp_sweep_n); bit-identical to eval_as
+  template <int T, int N>
+  __device__ __forceinline__ void eval_n(double (&io)[N], const double (&n1)[N], const double (&n2)[N]) const {
+    if (T == 0) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) io[i] = -0.5 * (n1[i] + n2[i] - 2.0 * io[i]) * p1;
+      exp_sweep_n<N>(io);
+#pragma unroll
+      for (int i = 0; i < N; ++i) io[i] *= variance;
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) io[i] = eval_as<1>(io[i], n1[i], n2[i]);
+    }
   }
   __device__ __forceinline__ double eval(double dot, double n1, double n2) const {
     return type == 0 ? eval_as<0>(dot, n1, n2) : eval_as<1>(dot, n1, n2);
@@ -176,6 +234,7 @@ struct PatchRbfArgs {
   int share_cu = 0;
 };
 int patch_rbf(dcgp_ctx* ctx, const PatchRbfArgs& a, const char* timer_name);
+int head_sweep(dcgp_ctx* ctx, const PatchRbfArgs& a, const double* w, const double** kd_partial, int* n_pairs, double* kd_scale);
 int head_kdiag(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, int C, int f, int s, BaseKernel bk,
                const double* w, double* out_N);
 

@@ -141,6 +141,77 @@ __global__ __launch_bounds__(256) void varexp_kernel(const double* __restrict__ 
   }
 }
 
+// ---- the ELBO tail in one launch: RobustMax expectations of every row (as varexp_kernel), their sum by the LAST block to
+// arrive (fixed order: reproducible), and -- with fin.nl > 0 -- the assembly  data * scale - sum_l KL_l  with the status words of
+// the factorisations.  Three dependent launches and their gaps otherwise, at the very end of the step where nothing hides them.
+__global__ __launch_bounds__(256) void elbo_tail_kernel(const double* __restrict__ mu, const double* __restrict__ var,
+                                                        const int32_t* __restrict__ y, int n_rows, int n_labels, int K, double eps,
+                                                        const double* __restrict__ gh, double* __restrict__ ve, double inv_s,
+                                                        unsigned* __restrict__ ticket, double* __restrict__ scal, ElboFinish fin) {
+  __shared__ double red[256];
+  __shared__ unsigned last;
+  const int tid = threadIdx.x, g = tid & 31;
+  const int row = blockIdx.x * 8 + (tid >> 5);
+  const bool live = row < n_rows;
+  double contrib = 0.0;
+  if (live && g < 20) {
+    const int yi = y[row % n_labels];
+    const double* m = mu + (long)row * K;
+    const double* v = var + (long)row * K;
+    double t = m[yi] + gh[g] * sqrt(fmax(2.0 * v[yi], 1e-10));
+    double prod = 1.0;
+    for (int k = 0; k < K; ++k) {
+      if (k == yi) continue;
+      double dist = (t - m[k]) / sqrt(fmax(v[k], 1e-10));
+      double cdf = 0.5 * (1.0 + erf(dist * 0.70710678118654752440));
+      prod *= cdf * (1.0 - 2e-4) + 1e-4;
+    }
+    contrib = prod * gh[20 + g] * 0.56418958354775628695;   // w / sqrt(pi)
+  }
+  for (int o = 1; o < 32; o <<= 1) contrib += __shfl_xor(contrib, o);
+  if (live && g == 0) ve[row] = contrib * log(1.0 - eps) + (1.0 - contrib) * log(eps / (K - 1.0));
+  // publish this block's rows, take a ticket (agent scope: the blocks sit on different XCDs, whose L2s are not coherent)
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!last) return;
+  double s = 0.0;
+  for (int i = tid; i < n_rows; i += 256) s += __hip_atomic_load(ve + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double data = red[0] * inv_s;
+    scal[0] = data;
+    *ticket = 0u;   // the next launch on this stream starts from zero
+    if (fin.nl > 0) {
+      double kl = 0.0;
+      for (int l = 0; l < fin.nl; ++l) {
+        const double* k4 = scal + 4 + 4 * l;
+        double two = k4[0] - (double)fin.M[l] * fin.R[l] - k4[1] + k4[3];
+        if (!fin.white[l]) two += (double)fin.R[l] * k4[2];
+        kl += 0.5 * two;
+      }
+      int bad = 0;   // first non-positive pivot of any factorisation: rides back with the result (one D2H, one sync)
+      for (int q = 0; q < fin.ngroups; ++q)
+        for (int i = 0; i < fin.ninfo[q]; ++i)
+          if (fin.info[q][i] && !bad) bad = fin.info[q][i];
+      scal[40] = data * fin.scale - kl;
+      scal[41] = data;
+      scal[42] = kl;
+      scal[43] = (double)bad;
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void reduce_sum_kernel(const double* __restrict__ in, long n, double scale,
                                                           double* __restrict__ out) {
   __shared__ double red[1024];
@@ -227,6 +298,24 @@ const double* gauss_hermite_table(dcgp_ctx* ctx) {
   hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream);
   hipStreamSynchronize(ctx->stream);
   return d;
+}
+
+int elbo_tail(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t* y, int n_rows, int n_labels, int K, double eps,
+              double* ve_rows, double inv_s, double* scal, const ElboFinish& fin) {
+  const double* gh = gauss_hermite_table(ctx);
+  if (!gh) return DCGP_ERR_ALLOC;
+  auto it = ctx->ws.find("elbo_ticket");
+  unsigned* ticket = it != ctx->ws.end() ? (unsigned*)it->second.first : nullptr;
+  if (!ticket) {
+    ticket = (unsigned*)ws_get(ctx, "elbo_ticket", 256);
+    if (!ticket) return DCGP_ERR_ALLOC;
+    HIP_TRY(ctx, hipMemsetAsync(ticket, 0, 256, ctx->stream));   // (a poisoned workspace must not leave a wrong count)
+  }
+  ScopedTimer t(ctx, "elbo_tail");
+  hipLaunchKernelGGL(elbo_tail_kernel, dim3((unsigned)((n_rows + 7) / 8)), dim3(256), 0, ctx->stream, mu, var, y, n_rows, n_labels, K,
+                     eps, gh, ve_rows, inv_s, ticket, scal, fin);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
 }
 
 int reduce_sum(dcgp_ctx* ctx, const double* in, long n, double scale, double* out) {

@@ -179,18 +179,23 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
 #pragma unroll
     for (int u = 0; u < D4; ++u)
       if (t + u < nk4) kstep(t + u, ring[u]);
+    double xnv[FNS];
+#pragma unroll
+    for (int y = 0; y < FNS; ++y) xnv[y] = xn[(sp * FNS + y) * 16 + lcol];
 #pragma unroll
     for (int c = 0; c < MAXF; ++c) {
       if (c < nfw) {
+        double kv[FNS * 4], n1[FNS * 4], n2[FNS * 4];   // this fragment's accumulator values: their exps interleaved
+#pragma unroll
+        for (int y = 0; y < FNS; ++y)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) { kv[y * 4 + v] = kacc[c][y][v]; n1[y * 4 + v] = xnv[y]; n2[y * 4 + v] = znv[c][v]; }
+        a.bk.template eval_n<BT, FNS * 4>(kv, n1, n2);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int m = 16 * fr[c] + lrow + 4 * v;
 #pragma unroll
-          for (int y = 0; y < FNS; ++y) {
-            const int yy = sp * FNS + y;
-            const double kv = a.bk.template eval_as<BT>(kacc[c][y][v], xn[yy * 16 + lcol], znv[c][v]);
-            strip[m * BN + bsw_s[y]] = (m < a.M) ? kv : 0.0;
-          }
+          for (int y = 0; y < FNS; ++y) strip[m * BN + bsw_s[y]] = (m < a.M) ? kv[y * 4 + v] : 0.0;
         }
       }
     }
@@ -522,6 +527,9 @@ bool plan_fused(const ConvFusedArgs& a, FusedPlan* p) {
   const int force = getenv("DCGP_FUSED_SHAPE") ? atoi(getenv("DCGP_FUSED_SHAPE")) : -1;   // A/B experiments
   const int nf = a.Mp / 16;
   if (a.Rp != 16 || a.R > 16 || a.Mp > 1024 || a.Mp % 16) return false;
+  // M > 256: the 32- / 16-column strips LDS leaves room for re-fetch the A operands 2 - 4 x as often per MFMA and measure
+  // 2 % (M = 384) to 16 % (M = 1024) behind the sweep + 128 x 128-tile GEMM route (87 % of the MFMA peak there); opt-in
+  if (nf > 16 && force < 0 && !getenv("DCGP_FUSED_LARGE")) return false;
   for (int i = 0; i < kNumShapes; ++i) {
     const FusedShape& sh = kShapes[i];
     if (force >= 0 && i != force) continue;

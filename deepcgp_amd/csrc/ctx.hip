@@ -44,7 +44,7 @@ void* ws_get(dcgp_ctx* ctx, const std::string& name, size_t bytes) {
 }
 
 ScopedTimer::ScopedTimer(dcgp_ctx* c, const char* name) : ctx(c), on(c->timing) {
-  if (on && c->timing_mode == 2 && strcmp(name, "gemm_cond_s3") != 0 && strcmp(name, "kuf") != 0) on = false;
+  if (on && c->timing_mode == 2 && strcmp(name, "gemm_cond_s3") != 0 && strcmp(name, "kuf") != 0 && strcmp(name, "conv_fused") != 0) on = false;
   if (!on) return;
   pe.name = name;
   auto take = [&](hipEvent_t& e) {
@@ -69,6 +69,10 @@ void timing_flush(dcgp_ctx* ctx) {
   if (ctx->pending.empty()) return;
   hipStreamSynchronize(ctx->stream);
   hipStreamSynchronize(ctx->stream2);
+  hipStreamSynchronize(ctx->stream2b);
+  hipStreamSynchronize(ctx->stream_aux);
+  if (ctx->stream_m) hipStreamSynchronize(ctx->stream_m);
+  if (ctx->stream2_m) hipStreamSynchronize(ctx->stream2_m);
   for (auto& pe : ctx->pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
@@ -110,7 +114,8 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
   c->device = device;
   c->no_side = getenv("DCGP_NO_SIDE_STREAM") != nullptr;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      side_stream_create(&c->stream2) != hipSuccess ||
+      side_stream_create(&c->stream2) != hipSuccess || side_stream_create(&c->stream2b) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_factor, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming) != hipSuccess ||
@@ -124,6 +129,24 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
       delete c;
       return DCGP_ERR_HIP;
     }
+  {
+    // CU-mask bit i lands on XCD i % 8, CU i / 8 (tools/cu_mask_census.hip): bits [0, 240) = 30 CUs of every XCD, [240, 256) = the
+    // other two.  OPT-IN (DCGP_CU_PARTITION=1), measured and NOT faster: workgroups are dealt to the four shader engines of an XCD
+    // in turn whatever their CU count, so the two engines left with 7 CUs need a fourth round for the 720 strips of the headline
+    // layer (800 us instead of 635) -- more than the undisturbed chain buys.  Without it the chain of step i + 1 finds its CUs in
+    // the partial last round and the head of step i (1107 vs 994 steps/s).
+    hipDeviceProp_t prop;
+    if (getenv("DCGP_CU_PARTITION") && !c->no_side && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount == 256) {
+      uint32_t big[8], small[8];
+      for (int w = 0; w < 8; ++w) { big[w] = 0xffffffffu; small[w] = 0u; }
+      big[7] = 0x0000ffffu; small[7] = 0xffff0000u;
+      if (hipExtStreamCreateWithCUMask(&c->stream_m, 8, big) != hipSuccess) c->stream_m = nullptr;
+      if (c->stream_m && hipExtStreamCreateWithCUMask(&c->stream2_m, 8, small) != hipSuccess) {
+        hipStreamDestroy(c->stream_m);
+        c->stream_m = c->stream2_m = nullptr;
+      }
+    }
+  }
   if (hipHostMalloc((void**)&c->h_scratch, 64 * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&c->h_info, 16 * sizeof(int)) != hipSuccess) {
     hipStreamDestroy(c->stream);
@@ -154,7 +177,11 @@ int dcgp_ctx_destroy(dcgp_ctx* ctx) {
   for (auto& e : ctx->ev_prep)
     if (e) hipEventDestroy(e);
   hipEventDestroy(ctx->ev_kl);
+  if (ctx->stream_m) hipStreamDestroy(ctx->stream_m);
+  if (ctx->stream2_m) hipStreamDestroy(ctx->stream2_m);
   hipStreamDestroy(ctx->stream2);
+  hipStreamDestroy(ctx->stream2b);
+  hipStreamDestroy(ctx->stream_aux);
   hipStreamDestroy(ctx->stream);
   delete ctx;
   return DCGP_OK;

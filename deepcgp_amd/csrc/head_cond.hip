@@ -28,7 +28,8 @@ struct HeadCondArgs {
   const double* LinvT;                     // [Mp][Mp]: Wt of stage 1 (lower-triangular W)
   const double* G;                         // [R][Mp][Mp]: Wt of stage 3 (upper-triangular W), nullptr: no q_sqrt term
   const double* alpha; int Rp;             // [Mp][Rp]
-  const double* kd;                        // Knn per column
+  const double* kd;                        // Knn per column: kd_scale * sum_i kd[j * kd_n + i]  (kd_n = 1, kd_scale = 1: plain vector)
+  int kd_n; double kd_scale;
   int Mp, R;
   double *out_mean, *out_var;              // [Kc][R]
 };
@@ -148,7 +149,9 @@ __global__ __launch_bounds__(1024, 4) void head_cond_kernel(HeadCondArgs a) {
     const int j = j0 + tid;
     if (j < a.Kc) {
       a.out_mean[(long)j * a.R + r] = tm;
-      a.out_var[(long)j * a.R + r] = a.kd[j] - t1 + t2;
+      double knn = 0.0;
+      for (int i = 0; i < a.kd_n; ++i) knn += a.kd[(long)j * a.kd_n + i];
+      a.out_var[(long)j * a.R + r] = knn * a.kd_scale - t1 + t2;
     }
   }
 }
@@ -239,7 +242,7 @@ bool head_cond_fused_ok(const GpMats& g) { return g.Mp <= HC_MP && g.Mp % HC_BK 
 
 // mean / var [Kc][R] of the conditional at Kc columns whose Kzx is B [Mp][ldb]; G / alpha from cond_prep
 int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, bool have_qsqrt, const double* kd,
-                    double* out_mean, double* out_var) {
+                    double* out_mean, double* out_var, int kd_n, double kd_scale) {
   if (Kc <= 0) return DCGP_OK;
   if (!head_cond_fused_ok(g) || (long)g.Mp * ldb * 8 >= (1L << 31))
     return ctx_fail(ctx, DCGP_ERR_ARG, "head_cond_fused: M = %d not supported", g.Mp);
@@ -247,7 +250,7 @@ int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, i
   HeadCondArgs a;
   a.B = B; a.ldb = ldb; a.Kc = Kc;
   a.LinvT = g.LinvT; a.G = have_qsqrt ? g.G : nullptr; a.alpha = g.alpha; a.Rp = g.Rp;
-  a.kd = kd; a.Mp = g.Mp; a.R = g.R;
+  a.kd = kd; a.kd_n = kd_n; a.kd_scale = kd_scale; a.Mp = g.Mp; a.R = g.R;
   a.out_mean = out_mean; a.out_var = out_var;
   hipLaunchKernelGGL(head_cond_kernel, dim3((Kc + HC_BN - 1) / HC_BN, g.R), dim3(1024), 0, ctx->stream, a);
   LAUNCH_CHECK(ctx);

@@ -56,7 +56,7 @@ int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc,
 // head_cond.hip: the whole conditional of a few-column problem in one launch (M <= 256): mean / var [Kc][R]
 bool head_cond_fused_ok(const GpMats& g);
 int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, bool have_qsqrt, const double* kd,
-                    double* out_mean, double* out_var);
+                    double* out_mean, double* out_var, int kd_n = 1, double kd_scale = 1.0);   // Knn[j] = kd_scale * sum_{i < kd_n} kd[j * kd_n + i]
 
 // head_cond.hip: G / alpha of every layer in one launch; done[i] = false where layer i still needs cond_prep
 int prep_solve_all(dcgp_ctx* ctx, GpMats* const* gs, const int* white, const bool* have_qsqrt, int nl, bool* done);
@@ -106,6 +106,19 @@ int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a);
 int kl_layer(dcgp_ctx* ctx, const GpMats& g, const double* Lp, const double* LpinvT, int white, const char* ws_prefix,
              double* kl4);
 
+// the ELBO assembly the tail kernel performs after the data term (nl == 0: data term only -> scal[0])
+struct ElboFinish {
+  int nl = 0;
+  int M[8], R[8], white[8];
+  double scale = 1.0;
+  const int* info[16];   // per factor group: potrf status words (0 or the 1-based failing column)
+  int ninfo[16];
+  int ngroups = 0;
+};
+// RobustMax expectations of every row -> ve_rows, scal[0] = inv_s * their sum, and (fin.nl > 0) scal[40..43] = ELBO, data term,
+// KL, potrf status from the KL pieces at scal[4 + 4 l ..]: one launch (cond.hip)
+int elbo_tail(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t* y, int n_rows, int n_labels, int K, double eps,
+              double* ve_rows, double inv_s, double* scal, const ElboFinish& fin);
 int varexp_rows(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t* y, int n_rows, int n_labels, int K,
                 double eps, double* out_rows, int predict);
 const double* gauss_hermite_table(dcgp_ctx* ctx);   // [40]: 20 nodes then 20 weights (device)

@@ -34,9 +34,14 @@ struct LayerState {
   double* in_scale = nullptr;   // [L] 1 / ARD lengthscale per input dimension, or nullptr (set_param "ard_lengthscales"; single-patch head only)
   double* ard = nullptr;        // [L] the ARD lengthscales themselves (optimiser state; in_scale is refreshed from it)
   double *gard = nullptr, *aard[2] = {};   // their gradient (inside the gradient block) and Adam moments
-  // derived every step
+  // derived every step.  Two banks of them: a step's parameter-only chain writes the bank of its parity, so that the chain of
+  // step i + 1 can run while the data path of step i still reads the other bank (dcgp_elbo_forward_enqueue).  g / ZT / zn are the
+  // bank in use (use_bank); bank 1 is allocated on first use.
   GpMats g;
   double *ZT = nullptr, *zn = nullptr;
+  GpMats gbank[2];
+  double *ZTb[2] = {}, *znb[2] = {};
+  bool need_prior_ = true;
   // gradients of the ELBO with respect to the (constrained) parameter values, caller's layouts (grad.hip); allocated on
   // first use.  gscal = {d variance, d p1, d p2} (p1 = lengthscale | ArcCosine weight variance, p2 = ArcCosine bias variance);
   // gslots = per-contribution partial sums of those three (3 x 16).
@@ -69,23 +74,39 @@ struct LayerState {
     M = M_; R = R_; white = white_; identity_mean = idm; kernel_type = ktype; variance = var; ls = ls_;
     Mp = round_up(M, 16);
     Lp = round_up(v.L, 4);
-    g.M = M; g.Mp = Mp; g.R = R; g.Rp = round_up(R, 16);
-    size_t mm = (size_t)Mp * Mp;
     Z = dalloc((size_t)M * v.L);
     Z0 = head ? nullptr : dalloc((size_t)M * v.L);
     q_mu = dalloc((size_t)M * R);
     q_sqrt = dalloc((size_t)R * M * M);
     w = head ? dalloc(v.P) : nullptr;
-    g.K = dalloc(mm); g.Linv = dalloc(mm); g.LinvT = dalloc(mm);
-    if (!head && !white && need_prior) { g.Kp = dalloc(mm); g.Lpinv = dalloc(mm); g.LpinvT = dalloc(mm); }
-    g.Lq = dalloc((size_t)R * mm);
-    g.qmu = dalloc((size_t)Mp * g.Rp);
-    if (white) { g.G = g.Lq; g.alpha = g.qmu; }
-    else { g.G = dalloc((size_t)R * mm); g.alpha = dalloc((size_t)Mp * g.Rp); }
-    ZT = dalloc((size_t)Lp * Mp);
-    zn = dalloc(Mp);
+    need_prior_ = need_prior;
+    alloc_bank(0);
+    use_bank(0);
     for (void* p : owned)
       if (!p) return ctx_fail(c, DCGP_ERR_ALLOC, "layer: device allocation failed");
+    return DCGP_OK;
+  }
+  void alloc_bank(int b) {
+    GpMats& q = gbank[b];
+    q.M = M; q.Mp = Mp; q.R = R; q.Rp = round_up(R, 16);
+    const size_t mm = (size_t)Mp * Mp;
+    q.K = dalloc(mm); q.Linv = dalloc(mm); q.LinvT = dalloc(mm);
+    if (!is_head && !white && need_prior_) { q.Kp = dalloc(mm); q.Lpinv = dalloc(mm); q.LpinvT = dalloc(mm); }
+    q.Lq = dalloc((size_t)R * mm);
+    q.qmu = dalloc((size_t)Mp * q.Rp);
+    if (white) { q.G = q.Lq; q.alpha = q.qmu; }
+    else { q.G = dalloc((size_t)R * mm); q.alpha = dalloc((size_t)Mp * q.Rp); }
+    ZTb[b] = dalloc((size_t)Lp * Mp);
+    znb[b] = dalloc(Mp);
+  }
+  int use_bank(int b) {
+    if (!gbank[b].K) {
+      const size_t before = owned.size();
+      alloc_bank(b);
+      for (size_t i = before; i < owned.size(); ++i)
+        if (!owned[i]) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: device allocation failed");
+    }
+    g = gbank[b]; ZT = ZTb[b]; zn = znb[b];
     return DCGP_OK;
   }
   // one contiguous block per layer [gZ | gq_mu | gq_sqrt | gw | gscal] so that a single all-reduce covers the layer
@@ -218,8 +239,9 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
         if (!fa.Kuf_out || !fa.A1_out) return DCGP_ERR_ALLOC;
         fa.ldk = ldb;
       }
-      if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
+      // G / alpha are recorded behind the factorisation on the chain's stream: one wait covers both
       if (prep_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, prep_done, 0));
+      else if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
       return conv_fused(ctx, fa);
     }
   }
@@ -268,16 +290,26 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   a.w = L.w; a.scale = 1.0 / (double)L.v.P; a.reduce = 1;
   a.in_scale = L.in_scale;
   a.share_cu = phase == 1;
+  static const bool unfused = getenv("DCGP_HEAD_UNFUSED") != nullptr;   // A/B switch
+  if (phase == 3 && L.kernel_type == 0 && a.bk.type == 0 && head_cond_fused_ok(L.g) && !unfused && !getenv("DCGP_HEAD_TWO_SWEEPS")) {
+    // ConvKernel head, M <= 256: Kzx and Kdiag in one launch, then the whole conditional in one launch that adds up the Kdiag
+    // tile-pair sums itself -- two launches on one stream for the layer
+    const double* kdp = nullptr; int kd_n = 1; double kd_scale = 1.0;
+    DCGP_TRY(head_sweep(ctx, a, L.w, &kdp, &kd_n, &kd_scale));
+    if (prep_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, prep_done, 0));
+    else if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
+    return head_cond_fused(ctx, L.g, B, ldb, rows, L.has_qsqrt, kdp, out_mean, out_var, kd_n, kd_scale);
+  }
   bool kd_on_side = false;
   if (phase & 1) {
     // Kdiag (all patch pairs of an image) is needed by finalize only: it runs on the side stream beside the
     // Kzx sweep and the conditional GEMMs instead of in front of them.
     hipStream_t main_s = ctx->stream;
-    kd_on_side = main_s != ctx->stream2 && !ctx->no_side;
+    kd_on_side = !ctx->no_side;
     if (kd_on_side) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, main_s));   // X is ready at this point of the main stream
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_aux, 0));
-      ctx->stream = ctx->stream2;
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->ev_aux, 0));
+      ctx->stream = ctx->stream_aux;
     }
     int rc;
     if (L.kernel_type == 0) {
@@ -286,7 +318,7 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
       rc = additive_kdiag_async(ctx, rows, L.v.P, L.variance, L.w, kd);
     }
     if (kd_on_side) {
-      if (rc == DCGP_OK && hipEventRecord(ctx->ev_aux2, ctx->stream2) != hipSuccess) rc = DCGP_ERR_HIP;
+      if (rc == DCGP_OK && hipEventRecord(ctx->ev_aux2, ctx->stream_aux) != hipSuccess) rc = DCGP_ERR_HIP;
       ctx->stream = main_s;
     }
     DCGP_TRY(rc);
@@ -294,17 +326,16 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   }
   if (!(phase & 2)) return DCGP_OK;
   if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
-  static const bool unfused = getenv("DCGP_HEAD_UNFUSED") != nullptr;   // A/B switch
   if (head_cond_fused_ok(L.g) && !unfused) {
     // few columns (one per image): both triangular products, the mean and mean / var in one launch (head_cond.hip)
     if (prep_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, prep_done, 0));
-    if (ctx->stream != ctx->stream2 && !ctx->no_side) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux2, 0));
+    if (!ctx->no_side) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux2, 0));
     return head_cond_fused(ctx, L.g, B, ldb, rows, L.has_qsqrt, kd, out_mean, out_var);
   }
   CondScratch sc;
   DCGP_TRY(cond_core(ctx, L.g, B, ldb, rows, L.white, L.has_qsqrt, pfx.c_str(), &sc, prep_done, true));
   // join: with phase == 2 the excursion was started by the earlier phase-1 call on the same stream pair
-  if (ctx->stream != ctx->stream2 && !ctx->no_side) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux2, 0));
+  if (!ctx->no_side) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux2, 0));
   FinalizeArgs fa;
   fa.s1p = sc.s1p; fa.nrb1 = sc.nrb1; fa.s2p = sc.s2p; fa.nrb3 = sc.nrb3; fa.mu = sc.mu; fa.ldk = ldb;
   fa.Kc = rows; fa.R = L.R; fa.knn_vec = kd;

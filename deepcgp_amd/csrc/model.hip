@@ -21,28 +21,42 @@ namespace {
 
 int g_model_counter = 0;
 
-int build_groups(dcgp_model* m) {
-  if (m->groups_built) return DCGP_OK;
-  for (auto& gr : m->groups) gr.release();
-  m->groups.clear();
+int build_groups(dcgp_model* m, int bank) {   // the layers must be on `bank` (use_bank)
+  if (m->groups_built[bank]) return DCGP_OK;
+  auto& groups = m->groups[bank];
+  for (auto& gr : groups) gr.release();
+  groups.clear();
   auto add = [&](int Mp, double* K, double* Linv, double* LinvT) {
-    for (auto& gr : m->groups)
+    for (auto& gr : groups)
       if (gr.Mp == Mp) { gr.K.push_back(K); gr.Linv.push_back(Linv); gr.LinvT.push_back(LinvT); return; }
     FactorGroup gr;
     gr.Mp = Mp; gr.K.push_back(K); gr.Linv.push_back(Linv); gr.LinvT.push_back(LinvT);
-    m->groups.push_back(gr);
+    groups.push_back(gr);
   };
   for (auto& l : m->layers) {
     add(l->Mp, l->g.K, l->g.Linv, l->g.LinvT);
     if (l->g.Kp) add(l->Mp, l->g.Kp, l->g.Lpinv, l->g.LpinvT);
   }
-  m->groups_built = true;
+  m->groups_built[bank] = true;
+  return DCGP_OK;
+}
+
+int ensure_events(dcgp_model* m) {
+  if (m->events_ok) return DCGP_OK;
+  dcgp_ctx* ctx = m->ctx;
+  for (int b = 0; b < 2; ++b) {
+    HIP_TRY(ctx, hipEventCreateWithFlags(&m->ev_sweep[b], hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&m->ev_factor[b], hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&m->ev_kl[b], hipEventDisableTiming));
+    for (auto& e : m->ev_prep[b]) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  m->events_ok = true;
   return DCGP_OK;
 }
 
 int ensure(dcgp_ctx* ctx, double** p, size_t* cap, size_t n) {
   if (*cap >= n && *p) return DCGP_OK;
-  if (*p) { hipStreamSynchronize(ctx->stream); hipFree(*p); *p = nullptr; }
+  if (*p) { hipDeviceSynchronize(); hipFree(*p); *p = nullptr; }   // steps in flight on any stream may still use it
   if (hipMalloc((void**)p, (n ? n : 2) * sizeof(double)) != hipSuccess) return ctx_fail(ctx, DCGP_ERR_ALLOC, "model: allocation failed");
   if (getenv("DCGP_POISON_WS")) { hipMemset(*p, 0xFF, (n ? n : 2) * sizeof(double)); hipDeviceSynchronize(); }   // debugging aid, see ws_get
   *cap = n;
@@ -53,7 +67,7 @@ int ensure_out(dcgp_model* m, int li, int rows, int width, bool need_mv) {
   auto& o = m->outs[li];
   size_t n = (size_t)rows * width;
   if (o.cap < n) {
-    hipStreamSynchronize(m->ctx->stream);
+    hipDeviceSynchronize();   // steps in flight on any stream may still use them
     hipFree(o.sample); hipFree(o.mean); hipFree(o.var);
     o.sample = o.mean = o.var = nullptr;
     if (hipMalloc((void**)&o.sample, n * sizeof(double)) != hipSuccess || hipMalloc((void**)&o.mean, n * sizeof(double)) != hipSuccess ||
@@ -101,7 +115,7 @@ __global__ void combine_kernel(const double* __restrict__ scal_in, double* __res
 int read_info(dcgp_model* m, int* info_host) {
   dcgp_ctx* ctx = m->ctx;
   int bad = 0;
-  for (auto& gr : m->groups) {
+  for (auto& gr : m->groups[m->bank]) {
     std::vector<int> h(gr.K.size());
     HIP_TRY(ctx, hipMemcpyAsync(h.data(), gr.d_info, h.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -113,32 +127,116 @@ int read_info(dcgp_model* m, int* info_host) {
   return DCGP_OK;
 }
 
-// layers 0..n-1 forward.  Returns device pointers of the last layer's mean/var and its row count.
+// Restores ctx->stream when a forward step returns, whichever way
+struct StreamGuard {
+  dcgp_ctx* ctx; hipStream_t saved;
+  explicit StreamGuard(dcgp_ctx* c) : ctx(c), saved(c->stream) {}
+  ~StreamGuard() { ctx->stream = saved; }
+};
+
+// layers 0..n-1 forward; leaves ctx->stream on the main stream the step runs on (the caller holds a StreamGuard).
+//   side stream: everything that depends on the parameters only, into the bank of this step's parity -- Kuu / prior Kuu /
+//                Z^T / padded q_sqrt, q_mu of every layer (one launch), ONE batched Cholesky + inverse chain for all M x M
+//                matrices, G / alpha of every layer (one launch), the KL terms;
+//   main stream: the data path (sweeps, conditionals, sampling), gated per layer by the side stream's events.
+// pipelined (dcgp_elbo_forward_enqueue): main = 30 CUs of every XCD, side = the other 2, so that the chain of step i + 1 runs
+// under the data path of step i without competing for its CUs; otherwise both streams see the whole chip.
 int forward_all(dcgp_model* m, const double* X, int N, int S, const double* const* zs, uint64_t seed, int dedup,
-                bool need_kl, int* rows_last) {
+                bool need_kl, bool pipelined, int* rows_last) {
   dcgp_ctx* ctx = m->ctx;
   if (!m->has_head) return ctx_fail(ctx, DCGP_ERR_ARG, "model has no head layer");
   const int nl = (int)m->layers.size();
   if (nl > 8) return ctx_fail(ctx, DCGP_ERR_ARG, "at most 8 layers supported");
-  DCGP_TRY(build_groups(m));
-  if (!m->d_scal && hipMalloc((void**)&m->d_scal, 64 * sizeof(double)) != hipSuccess)
+  DCGP_TRY(ensure_events(m));
+  const int bank = m->bank ^ 1;
+  m->bank = bank;
+  for (auto& l : m->layers) DCGP_TRY(l->use_bank(bank));
+  DCGP_TRY(build_groups(m, bank));
+  if (!m->d_scal && hipMalloc((void**)&m->d_scal, 128 * sizeof(double)) != hipSuccess)
     return ctx_fail(ctx, DCGP_ERR_ALLOC, "model: allocation failed");
+  double* scal = m->d_scal + 64 * bank;
   m->outs.resize(nl);
+  const std::string mp = "m" + std::to_string(m->id) + "_";
+  const int rows0 = dedup ? N : S * N;   // rows entering layer 0; it reads image (row % N): tile(X,[S,1,1]) is never formed
+
+  const bool no_side = ctx->no_side;   // A/B switch: everything on one stream
+  const bool part = pipelined && ctx->stream_m && !no_side;
+  const hipStream_t main_s = part ? ctx->stream_m : ctx->stream;
+  // Where the parameter-only chain runs.  A synchronous step has nothing else to do until the factorisation is there: the chain
+  // sits on the main stream itself (no cross-stream hand-off in front of the first layer, ~15 us each) and only the KL terms
+  // fork to the side stream.  A step enqueued beside others: the side stream of its bank, so that it overtakes the step in flight.
+  const hipStream_t kl_s = no_side ? main_s : (part ? ctx->stream2_m : (pipelined ? (bank ? ctx->stream2b : ctx->stream2) : ctx->stream2));
+  // (A first layer on the sweep + GEMM route keeps the side stream: its sweep needs Z only and runs beside the chain.)
+  bool first_fused = true;
+  if (!m->layers[0]->is_head) {
+    const LayerState& L0 = *m->layers[0];
+    ConvFusedArgs fa;
+    fa.Mp = L0.Mp; fa.M = L0.M; fa.R = L0.R; fa.Rp = L0.g.Rp; fa.P = L0.v.P; fa.HWC = L0.v.H * L0.v.W * L0.v.C; fa.Lp = L0.Lp;
+    first_fused = conv_fused_ok(fa);
+  }
+  const hipStream_t chain_s = (pipelined || !first_fused) ? kl_s : main_s;
+  // a step on the other main stream than the previous one starts behind it
+  if (ctx->ev_last_valid && ctx->last_main != main_s) HIP_TRY(ctx, hipStreamWaitEvent(main_s, ctx->ev_last, 0));
+  ctx->last_main = main_s;
+
+  // ---- the parameter-only chain ----
+  ctx->stream = chain_s;
+  if (chain_s != main_s) {
+    if (m->done_valid[bank]) HIP_TRY(ctx, hipStreamWaitEvent(chain_s, m->done_ev[bank], 0));   // the bank's previous reader
+    else if (ctx->ev_last_valid) HIP_TRY(ctx, hipStreamWaitEvent(chain_s, ctx->ev_last, 0));    // first use: behind whatever ran last
+  }
+  int rc = DCGP_OK;
   {
     PrepArgs pa;
     pa.nl = nl;
     for (int li = 0; li < nl; ++li) pa.l[li] = m->layers[li]->prep_args(m->jitter);
-    DCGP_TRY(prepare_all(ctx, pa));   // Kuu / prior Kuu / Z^T / padded q_sqrt, q_mu of every layer: one launch
+    rc = prepare_all(ctx, pa);
   }
-  const std::string mp = "m" + std::to_string(m->id) + "_";
-  const int rows0 = dedup ? N : S * N;   // rows entering layer 0; it reads image (row % N): tile(X,[S,1,1]) is never formed
+  // (events only where another stream waits for them: each record is a packet in front of the next launch)
+  const bool xs = chain_s != main_s;
+  if (rc == DCGP_OK && xs && !first_fused && hipEventRecord(m->ev_sweep[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;   // Z^T, |z|^2: what a sweep needs
+  for (auto& gr : m->groups[bank])
+    if (rc == DCGP_OK) rc = gr.run(ctx);
+  if (rc == DCGP_OK && xs && hipEventRecord(m->ev_factor[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
+  // G_r = inv(L) Lq_r and alpha = inv(L) q_mu of every layer (cond_prep): gate the second conditional GEMM
+  bool prep_done[8] = {};
+  if (rc == DCGP_OK) {   // every layer the one-launch route covers (unwhitened, M <= 256, <= 16 outputs): head_cond.hip
+    GpMats* gs[8]; int wh[8]; bool hq[8];
+    for (int li = 0; li < nl; ++li) { gs[li] = &m->layers[li]->g; wh[li] = m->layers[li]->white; hq[li] = m->layers[li]->has_qsqrt; }
+    rc = prep_solve_all(ctx, gs, wh, hq, nl, prep_done);
+  }
+  for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
+    if (!prep_done[li]) rc = cond_prep(ctx, m->layers[li]->g, m->layers[li]->white, m->layers[li]->has_qsqrt);   // generic GEMMs
+    if (rc == DCGP_OK && (xs || (li == nl - 1 && need_kl && kl_s != chain_s)) && hipEventRecord(m->ev_prep[bank][li], ctx->stream) != hipSuccess)
+      rc = DCGP_ERR_HIP;   // per layer: layer 0 does not wait for the others (same stream: only the fork of the KL terms needs one)
+  }
+  if (rc == DCGP_OK && need_kl) {
+    if (kl_s != chain_s) {   // fork: the KL terms need the factors only, the main stream goes on with the layers
+      if (hipStreamWaitEvent(kl_s, m->ev_prep[bank][nl - 1], 0) != hipSuccess) rc = DCGP_ERR_HIP;
+      ctx->stream = kl_s;
+    }
+    for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
+      LayerState& L = *m->layers[li];
+      const double* Lp = L.g.Kp ? L.g.Kp : L.g.K;
+      const double* LpinvT = L.g.Kp ? L.g.LpinvT : L.g.LinvT;
+      rc = kl_layer(ctx, L.g, Lp, LpinvT, L.white, (mp + std::to_string(li)).c_str(), scal + 4 + 4 * li);
+    }
+  }
+  if (rc == DCGP_OK && hipEventRecord(m->ev_kl[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
+  ctx->stream = main_s;
+  if (rc != DCGP_OK) {
+    hipStreamSynchronize(kl_s);
+    hipStreamSynchronize(chain_s);
+    return rc;
+  }
 
-  // One layer step.  phase 1 = the patch sweep(s) that need only Z, phase 2 = conditional + finalize, 3 = both.
-  auto layer_step = [&](int li, const double* F, int rows, int n_mod, int phase, int* out_rows_p) -> int {
+  // ---- main stream: propagate ----
+  auto layer_step = [&](int li, const double* F, int rows, int n_mod, int* out_rows_p) -> int {
     LayerState& L = *m->layers[li];
     const std::string pfx = mp + std::to_string(li) + "_";
     const double* z = zs ? zs[li] : nullptr;
-    hipEvent_t fdone = (li == 0) ? ctx->ev_factor : nullptr;   // later layers are stream-ordered behind layer 0
+    hipEvent_t fdone = (li == 0 && chain_s != main_s) ? m->ev_factor[bank] : nullptr;   // later layers are stream-ordered behind layer 0
+    hipEvent_t pdone = chain_s != main_s ? m->ev_prep[bank][li] : nullptr;
     if (!L.is_head) {
       const int width = L.v.P * L.R;
       const bool expand = dedup && li == 0;          // N distinct images -> S*N sampled rows
@@ -147,14 +245,14 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       auto& o = m->outs[li];
       DCGP_TRY(conv_forward(ctx, L, F, rows, n_mod, expand ? S : 1, (long)N * width, z, seed, (uint32_t)(li + 1 + 64 * ctx->rank),
                             m->jitter, o.sample, m->keep_outputs ? o.mean : nullptr, m->keep_outputs ? o.var : nullptr, pfx,
-                            fdone, ctx->ev_prep[li], phase, m->keep_state));
+                            fdone, pdone, 3, m->keep_state));
       *out_rows_p = out_rows;
     } else {
       DCGP_TRY(ensure_out(m, li, rows, L.R, true));
       auto& o = m->outs[li];
       DCGP_TRY(ensure(ctx, &m->d_kd, &m->kd_cap, (size_t)rows));
-      DCGP_TRY(head_forward(ctx, L, F, rows, n_mod, m->d_kd, o.mean, o.var, pfx, fdone, ctx->ev_prep[li], phase));
-      if ((phase & 2) && m->keep_outputs) {
+      DCGP_TRY(head_forward(ctx, L, F, rows, n_mod, m->d_kd, o.mean, o.var, pfx, fdone, pdone, 3));
+      if (m->keep_outputs) {
         // the head's sample is not needed by the ELBO; produce it only on request
         size_t n = (size_t)rows * L.R;
         if (z) {
@@ -167,61 +265,31 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     }
     return DCGP_OK;
   };
-
-  // The first layer's patch sweep needs only Z: enqueue it on the main stream BEFORE the long side-stream sequence,
-  // otherwise it sits behind the host still enqueueing the factorisation chain (~200 us of launch calls).
-  hipStream_t main_s = ctx->stream;
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_s));   // the side stream depends on prepare() only, not on the sweep
-  int r_tmp = 0;
-  DCGP_TRY(layer_step(0, X, rows0, N, 1, &r_tmp));
-
-  // The replicated M x M stage (batched Cholesky + inverse, the small operands of the conditional, then the KL
-  // terms) is a serial, few-CU chain: it runs on the side stream, overlapped with that sweep and with the
-  // conditional GEMMs.  ev_factor gates the first GEMM, ev_prep[l] the second of layer l, ev_kl the ELBO assembly.
-  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-  const bool no_side = ctx->no_side;   // A/B switch: everything on one stream
-  if (!no_side) ctx->stream = ctx->stream2;
-  int rc = DCGP_OK;
-  for (auto& gr : m->groups)
-    if ((rc = gr.run(ctx)) != DCGP_OK) break;
-  if (rc == DCGP_OK && hipEventRecord(ctx->ev_factor, ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
-  // G_r = inv(L) Lq_r and alpha = inv(L) q_mu of every layer (cond_prep): gate the second conditional GEMM
-  bool prep_done[8] = {};
-  if (rc == DCGP_OK) {   // every layer the one-launch route covers (unwhitened, M <= 256, <= 16 outputs): head_cond.hip
-    GpMats* gs[8]; int wh[8]; bool hq[8];
-    for (int li = 0; li < nl; ++li) { gs[li] = &m->layers[li]->g; wh[li] = m->layers[li]->white; hq[li] = m->layers[li]->has_qsqrt; }
-    rc = prep_solve_all(ctx, gs, wh, hq, nl, prep_done);
-  }
-  for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
-    if (!prep_done[li]) rc = cond_prep(ctx, m->layers[li]->g, m->layers[li]->white, m->layers[li]->has_qsqrt);   // generic GEMMs
-    if (rc == DCGP_OK && hipEventRecord(ctx->ev_prep[li], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;   // per layer: layer 0 does not wait for the others
-  }
-  if (rc == DCGP_OK && need_kl) {
-    for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
-      LayerState& L = *m->layers[li];
-      const double* Lp = L.g.Kp ? L.g.Kp : L.g.K;
-      const double* LpinvT = L.g.Kp ? L.g.LpinvT : L.g.LinvT;
-      rc = kl_layer(ctx, L.g, Lp, LpinvT, L.white, (mp + std::to_string(li)).c_str(), m->d_scal + 4 + 4 * li);
-    }
-  }
-  if (rc == DCGP_OK && hipEventRecord(ctx->ev_kl, ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
-  ctx->stream = main_s;
-  if (rc != DCGP_OK) {
-    hipStreamSynchronize(ctx->stream2);
-    return rc;
-  }
-  // propagate
+  // sweeps read Z^T / |z|^2 of this bank (a one-launch first layer waits for its G / alpha, recorded behind them on the same stream)
+  if (chain_s != main_s && !first_fused) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_sweep[bank], 0));
   const double* F = X;
   int rows = rows0, n_mod = N;
   for (int li = 0; li < nl; ++li) {
     int out_rows = 0;
-    DCGP_TRY(layer_step(li, F, rows, n_mod, li == 0 ? 2 : 3, &out_rows));
+    DCGP_TRY(layer_step(li, F, rows, n_mod, &out_rows));
     if (!m->layers[li]->is_head) F = m->outs[li].sample;
     rows = out_rows;
     n_mod = rows;
   }
-  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_kl, 0));   // join the side stream
+  if (kl_s != main_s) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_kl[bank], 0));   // join the side stream
   *rows_last = rows;
+  return DCGP_OK;
+}
+
+// The end of a step's data path on its main stream: `ev` (already recorded there, behind the step's last command) frees the
+// bank for its next writer and lets a step on the other main stream start.  ev == nullptr: the caller synchronises the stream
+// itself before anything else is enqueued.
+int forward_done(dcgp_model* m, hipEvent_t ev) {
+  dcgp_ctx* ctx = m->ctx;
+  m->done_ev[m->bank] = ev;
+  m->done_valid[m->bank] = ev != nullptr;
+  ctx->ev_last = ev;
+  ctx->ev_last_valid = ev != nullptr;
   return DCGP_OK;
 }
 
@@ -240,7 +308,9 @@ int dcgp_model_create(dcgp_ctx* ctx, int num_samples, double jitter, dcgp_model*
 int dcgp_model_destroy(dcgp_model* model) {
   if (!model) return DCGP_ERR_ARG;
   dcgp_ctx* ctx = model->ctx;
-  hipDeviceSynchronize();   // both streams: the model's workspaces may still be in use
+  hipDeviceSynchronize();   // every stream: the model's workspaces may still be in use
+  ctx->ev_last = nullptr;   // (it may be one of this model's result-ring events; nothing is in flight any more)
+  ctx->ev_last_valid = false;
   // the per-model workspaces of the forward / reverse pass live in the ctx under "m<id>_..." (the training step's are large:
   // R x M x columns doubles per conv layer); they go with the model
   const std::string pfx = "m" + std::to_string(model->id) + "_";
@@ -276,7 +346,7 @@ int dcgp_model_add_conv_layer(dcgp_model* model, int H, int W, int C, int f, int
   DCGP_TRY(L->upload(L->q_mu, q_mu_host, (size_t)M * R));
   DCGP_TRY(L->upload(L->q_sqrt, q_sqrt_host, (size_t)R * M * M));
   model->layers.push_back(std::move(L));
-  model->groups_built = false;
+  model->groups_built[0] = model->groups_built[1] = false;
   return DCGP_OK;
 }
 
@@ -295,7 +365,7 @@ int dcgp_model_set_head(dcgp_model* model, int H, int W, int C, int f, int strid
   DCGP_TRY(L->upload(L->q_sqrt, q_sqrt_host, (size_t)R * M * M));
   model->layers.push_back(std::move(L));
   model->has_head = true;
-  model->groups_built = false;
+  model->groups_built[0] = model->groups_built[1] = false;
   return DCGP_OK;
 }
 
@@ -360,7 +430,8 @@ int dcgp_elbo_forward(dcgp_model* model, const double* X, const int32_t* y, int 
 
 int dcgp_elbo_forward_enqueue(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
                               const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, uint64_t* ticket) {
-  return elbo_forward_enqueue_impl(model, X, y, N, scale, z_per_layer_host, seed, dedup_layer0, ticket);
+  // the caller means to keep steps in flight: data path and parameter-only chain on disjoint CUs (forward_all)
+  return elbo_forward_enqueue_impl(model, X, y, N, scale, z_per_layer_host, seed, dedup_layer0, ticket, true);
 }
 
 int dcgp_elbo_forward_collect(dcgp_model* model, uint64_t ticket, double* out_host, int* info_host) {
@@ -370,7 +441,8 @@ int dcgp_elbo_forward_collect(dcgp_model* model, uint64_t ticket, double* out_ho
 }  // extern "C"
 
 int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
-                              const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, uint64_t* ticket) {
+                              const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, uint64_t* ticket,
+                              bool pipelined) {
   if (!model || !X || !y || N <= 0 || !ticket) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "elbo_forward: bad args") : DCGP_ERR_ARG;
   dcgp_ctx* ctx = model->ctx;
   if (model->enq_seq - model->col_seq >= (uint64_t)dcgp_model::RING)
@@ -383,27 +455,42 @@ int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t*
   int rows = 0;
   const int S = model->S;
   const auto host_t0 = std::chrono::steady_clock::now();
-  DCGP_TRY(forward_all(model, X, N, S, z_per_layer_host, seed, dedup_layer0, true, &rows));
+  StreamGuard guard(ctx);   // forward_all leaves ctx->stream on the step's main stream
+  DCGP_TRY(forward_all(model, X, N, S, z_per_layer_host, seed, dedup_layer0, true, pipelined, &rows));
   const int nl = (int)model->layers.size();
   LayerState& H = *model->layers[nl - 1];
   auto& o = model->outs[nl - 1];
+  double* scal = model->d_scal + 64 * model->bank;
+  auto& groups = model->groups[model->bank];
   DCGP_TRY(ensure(ctx, &model->d_ve, &model->ve_cap, (size_t)rows));
-  DCGP_TRY(varexp_rows(ctx, o.mean, o.var, y, rows, N, H.R, model->eps, model->d_ve, 0));
   // rows == S*N normally; a head-only model under dedup has rows == N with S identical copies
   const double inv_s = (rows == S * N) ? 1.0 / S : 1.0;
-  DCGP_TRY(reduce_sum(ctx, model->d_ve, rows, inv_s, model->d_scal));
-  if (ctx->comm) DCGP_TRY(allreduce_sum_f64_async(ctx, model->d_scal, 1));
-  CombineArgs c;
-  c.nl = nl; c.scale = scale;
-  for (int l = 0; l < nl; ++l) { c.M[l] = model->layers[l]->M; c.R[l] = model->layers[l]->R; c.white[l] = model->layers[l]->white; }
-  if (model->groups.size() > 16) return ctx_fail(ctx, DCGP_ERR_ARG, "model: too many factor groups");
-  c.ngroups = (int)model->groups.size();
-  for (int g = 0; g < c.ngroups; ++g) { c.info[g] = model->groups[g].d_info; c.ninfo[g] = (int)model->groups[g].K.size(); }
-  hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, ctx->stream, model->d_scal, model->d_scal + 40, c);
-  LAUNCH_CHECK(ctx);
+  if (groups.size() > 16) return ctx_fail(ctx, DCGP_ERR_ARG, "model: too many factor groups");
+  ElboFinish fin;
+  fin.nl = nl; fin.scale = scale;
+  for (int l = 0; l < nl; ++l) { fin.M[l] = model->layers[l]->M; fin.R[l] = model->layers[l]->R; fin.white[l] = model->layers[l]->white; }
+  fin.ngroups = (int)groups.size();
+  for (int g = 0; g < fin.ngroups; ++g) { fin.info[g] = groups[g].d_info; fin.ninfo[g] = (int)groups[g].K.size(); }
+  if (!ctx->comm) {
+    // expectations, their sum and the ELBO assembly in one launch
+    DCGP_TRY(elbo_tail(ctx, o.mean, o.var, y, rows, N, H.R, model->eps, model->d_ve, inv_s, scal, fin));
+  } else {
+    // multi-GPU: the data term is summed over the ranks between the reduction and the assembly
+    ElboFinish none;
+    DCGP_TRY(elbo_tail(ctx, o.mean, o.var, y, rows, N, H.R, model->eps, model->d_ve, inv_s, scal, none));
+    DCGP_TRY(allreduce_sum_f64_async(ctx, scal, 1));
+    CombineArgs c;
+    c.nl = nl; c.scale = scale;
+    for (int l = 0; l < nl; ++l) { c.M[l] = fin.M[l]; c.R[l] = fin.R[l]; c.white[l] = fin.white[l]; }
+    c.ngroups = fin.ngroups;
+    for (int g = 0; g < c.ngroups; ++g) { c.info[g] = fin.info[g]; c.ninfo[g] = fin.ninfo[g]; }
+    hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, ctx->stream, scal, scal + 40, c);
+    LAUNCH_CHECK(ctx);
+  }
   const int slot = (int)(model->enq_seq % dcgp_model::RING);
-  HIP_TRY(ctx, hipMemcpyAsync(model->h_ring + 4 * slot, model->d_scal + 40, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(model->h_ring + 4 * slot, scal + 40, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(model->ring_ev[slot], ctx->stream));
+  DCGP_TRY(forward_done(model, model->ring_ev[slot]));
   if (ctx->timing) {   // host time to enqueue one step (everything before the wait), reported beside the kernel timers
     auto& acc = ctx->tim["host_enqueue"];
     acc.launches += 1;
@@ -425,7 +512,7 @@ int elbo_forward_collect_impl(dcgp_model* model, uint64_t ticket, double* out_ho
   const double* h = model->h_ring + 4 * slot;
   out_host[0] = h[0]; out_host[1] = h[1]; out_host[2] = h[2];
   // the timers resolve their events lazily, once nothing is in flight any more
-  if (ctx->timing && ctx->pending.size() > 512 && model->col_seq == model->enq_seq) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); timing_flush(ctx); }
+  if (ctx->timing && ctx->pending.size() > 512 && model->col_seq == model->enq_seq) timing_flush(ctx);   // synchronises every stream of the ctx
   const int bad = (int)h[3];
   if (info_host) *info_host = bad;
   if (bad) return ctx_fail(ctx, DCGP_ERR_NOT_PD, "Cholesky: matrix not positive definite at column %d", bad);
@@ -451,7 +538,9 @@ int dcgp_model_propagate(dcgp_model* model, const double* X, int N, int S, const
   dcgp_ctx* ctx = model->ctx;
   if (info_host) *info_host = 0;
   int rows = 0;
-  DCGP_TRY(forward_all(model, X, N, S, z_per_layer_host, seed, 0, false, &rows));
+  StreamGuard guard(ctx);
+  DCGP_TRY(forward_all(model, X, N, S, z_per_layer_host, seed, 0, false, false, &rows));
+  DCGP_TRY(forward_done(model, nullptr));   // this call synchronises the stream before it returns
   const int nl = (int)model->layers.size();
   auto& o = model->outs[nl - 1];
   size_t n = (size_t)rows * o.width;
@@ -479,7 +568,9 @@ int dcgp_model_predict_y(dcgp_model* model, const double* X, int N, int S, const
   dcgp_ctx* ctx = model->ctx;
   if (info_host) *info_host = 0;
   int rows = 0;
-  DCGP_TRY(forward_all(model, X, N, S, z_per_layer_host, seed, 0, false, &rows));
+  StreamGuard guard(ctx);
+  DCGP_TRY(forward_all(model, X, N, S, z_per_layer_host, seed, 0, false, false, &rows));
+  DCGP_TRY(forward_done(model, nullptr));   // this call synchronises the stream before it returns
   const int nl = (int)model->layers.size();
   auto& o = model->outs[nl - 1];
   const int K = o.width;

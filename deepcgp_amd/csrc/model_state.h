@@ -13,12 +13,18 @@ struct dcgp_model {
   bool keep_state = false;   // the forward leaves K_uf / A1 of every conv layer in HBM (set around the forward of dcgp_elbo_grad)
   int adam_t = 0;        // Adam steps taken on this model's moment buffers (bias correction; dcgp_model_adam_step with t = 0)
   int grad_shards = 0;   // KL gradient weight 1 / shards; 0 = number of ranks of the ctx's communicator (1 without one)
-  std::vector<FactorGroup> groups;
-  bool groups_built = false;
+  // two banks of parameter-only state (LayerState::use_bank): factor groups, events and ELBO scalars follow the bank
+  std::vector<FactorGroup> groups[2];
+  bool groups_built[2] = {false, false};
+  int bank = 0;                                  // bank of the most recent forward
+  hipEvent_t ev_sweep[2] = {}, ev_factor[2] = {}, ev_kl[2] = {}, ev_prep[2][8] = {};
+  hipEvent_t done_ev[2] = {};                    // not owned: the event that marks the end of the last step on the bank (a result-ring event)
+  bool done_valid[2] = {false, false};
+  bool events_ok = false;
   // per-layer outputs of the most recent forward
   struct Out { double *sample = nullptr, *mean = nullptr, *var = nullptr; int rows = 0, width = 0; size_t cap = 0; };
   std::vector<Out> outs;
-  double* d_scal = nullptr;   // [0]=data, [4 + 4l ..] 4 KL pieces of layer l, [40..43] ELBO, data term, KL, potrf status
+  double* d_scal = nullptr;   // per bank (64 doubles each): [0]=data, [4 + 4l ..] 4 KL pieces of layer l, [40..43] ELBO, data term, KL, potrf status
   double* d_ve = nullptr; size_t ve_cap = 0;
   double* d_kd = nullptr; size_t kd_cap = 0;
   int id = 0;
@@ -32,7 +38,13 @@ struct dcgp_model {
   ~dcgp_model() {
     if (h_ring) hipHostFree(h_ring);
     for (auto& e : ring_ev) if (e) hipEventDestroy(e);
-    for (auto& gr : groups) gr.release();
+    for (auto& gs : groups) for (auto& gr : gs) gr.release();
+    for (int b = 0; b < 2; ++b) {
+      if (ev_sweep[b]) hipEventDestroy(ev_sweep[b]);
+      if (ev_factor[b]) hipEventDestroy(ev_factor[b]);
+      if (ev_kl[b]) hipEventDestroy(ev_kl[b]);
+      for (auto& e : ev_prep[b]) if (e) hipEventDestroy(e);
+    }
     for (auto& o : outs) { hipFree(o.sample); hipFree(o.mean); hipFree(o.var); }
     hipFree(d_scal); hipFree(d_ve); hipFree(d_kd);
   }
@@ -45,7 +57,8 @@ int elbo_forward_impl(dcgp_model* model, const double* X, const int32_t* y, int 
                       int* info_host);
 // the two halves of it: queue the step's launches and the copy of its result into a ring slot / wait for the oldest slot
 int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
-                              const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, uint64_t* ticket);
+                              const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, uint64_t* ticket,
+                              bool pipelined = false);
 int elbo_forward_collect_impl(dcgp_model* model, uint64_t ticket, double* out_host, int* info_host);
 // grad.hip: reverse pass over the state the forward left behind; fills every layer's gradient buffers
 int model_backward(dcgp_model* model, const double* X, const int32_t* y, int N, double scale, int dedup_layer0);

@@ -97,8 +97,7 @@ __global__ __launch_bounds__(256) void z_transpose_kernel(const double* __restri
 // ---------------------------------------------------------------------------------------------
 constexpr int PR_BM = 64;    // inducing patches per workgroup
 constexpr int PR_BP = 64;    // image patches per tile
-constexpr int PR_BK = 32;    // k chunk of ZT staged in LDS
-constexpr int PR_LDZ = PR_BM + 16;
+constexpr int PR_D = 4;      // k sub-steps of Z^T in flight per wave beside the one being multiplied
 
 __device__ __forceinline__ int patch_base(int p, int P, int Wo, int s, int W, int C) {
   if (p >= P) p = 0;
@@ -106,20 +105,23 @@ __device__ __forceinline__ int patch_base(int p, int P, int Wo, int s, int W, in
   return (oh * s * W + ow * s) * C;
 }
 
-// grid: (p tiles [write mode] or 1 [reduce mode], Mp/64, N); block 256 = 4 waves as 2 (m) x 2 (p)
+// grid: (p tiles [write mode] or 1 [reduce mode], Mp/64, N); block 256 = 4 waves as 2 (m) x 2 (p).
+// The A operand (Z^T, k-major, L2-resident: every workgroup reads the same few hundred KB) goes from global memory straight
+// into MFMA registers, PR_D sub-steps ahead -- no LDS staging, no barrier in the k loop.  (Staged through LDS in chunks of 32
+// rows it cost two barriers and one exposed memory latency per chunk: 8 chunks at the head's L = 250, ~40 us per workgroup
+// where the MFMAs need 7.)
 template <int BT>
-__global__ __launch_bounds__(256, 4) void patch_rbf_kernel(PatchRbfArgs a) {
+__device__ __forceinline__ void patch_rbf_body(const PatchRbfArgs& a, const int bx, const int by, const int bz) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int HWC = a.H * a.W * a.C;
   double* img = smem;                                   // [HWC] (+pad to even)
-  double* zt = img + ((HWC + 1) & ~1);                  // [PR_BK][PR_LDZ]
-  double* red = zt + PR_BK * PR_LDZ;                    // [2][PR_BM] (reduce mode)
-  int* koff = reinterpret_cast<int*>(red + 2 * PR_BM);  // [Lp]
+  double* red = img + ((HWC + 1) & ~1);                 // [2][PR_BM] (reduce mode)
+  int* koff = reinterpret_cast<int*>(red + 3 * PR_BM);  // [Lp]  (red: [2][PR_BM] reduce scratch, then [PR_BM] |z|^2)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lrow = lane >> 4, lcol = lane & 15;
-  const int n = blockIdx.z, m0 = blockIdx.y * PR_BM;
+  const int n = bz, m0 = by * PR_BM;
 
   const double* __restrict__ Xn = a.X + (long)(n % a.n_mod) * HWC;
   // image -> LDS in batches of 8 loads per thread: a rolled loop waits one memory latency per iteration
@@ -143,10 +145,19 @@ __global__ __launch_bounds__(256, 4) void patch_rbf_kernel(PatchRbfArgs a) {
     int kw = t % a.f, kh = t / a.f;
     koff[l] = (kh * a.W + kw) * a.C + c;
   }
+  // this lane's A-operand columns: rows m0 + wm*32 + x*16 + lcol of Z (columns of Z^T); beyond Mp: re-read the last one, dropped later
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.ZT), 0, a.Lp * a.Mp * 8, 0x00020000);
+  unsigned zoff[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) zoff[x] = (unsigned)((lrow * a.Mp + min(m0 + wm * 32 + x * 16 + lcol, a.Mp - 1)) * 8);
+  double* znl = red + 2 * PR_BM;   // behind the reduce scratch: |z|^2 of the workgroup's 64 rows (koff follows)
+  if (tid < PR_BM) znl[tid] = (m0 + tid < a.Mp) ? a.zn[m0 + tid] : 0.0;
   __syncthreads();
 
   const int p_tiles = (a.P + PR_BP - 1) / PR_BP;
-  const int pt_lo = a.reduce ? 0 : blockIdx.x, pt_hi = a.reduce ? p_tiles : blockIdx.x + 1;
+  const int pt_lo = a.reduce ? 0 : bx, pt_hi = a.reduce ? p_tiles : bx + 1;
+  const int nk4 = a.Lp >> 2;
 
   double rsum[2][4];   // reduce mode: per (fm, v) running row sums
 #pragma unroll
@@ -154,7 +165,6 @@ __global__ __launch_bounds__(256, 4) void patch_rbf_kernel(PatchRbfArgs a) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) rsum[x][v] = 0.0;
 
-  const bool one_chunk = a.Lp <= PR_BK;
   for (int pt = pt_lo; pt < pt_hi; ++pt) {
     const int p0 = pt * PR_BP + wn * 32;
     int pb[2];
@@ -168,68 +178,72 @@ __global__ __launch_bounds__(256, 4) void patch_rbf_kernel(PatchRbfArgs a) {
       for (int y = 0; y < 2; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
     double xn[2] = {0.0, 0.0};
 
-    for (int k0 = 0; k0 < a.Lp; k0 += PR_BK) {
-      // stage ZT[k0 .. k0+BK) x [m0 .. m0+64): 32 rows x 32 double2 chunks = 1024 chunks / 256 threads.  A patch
-      // length of one chunk (L <= 32: every first layer) is staged once for all the patch tiles of the workgroup --
-      // the reduce mode walks all of them, and re-staging cost two barriers and an L2 round trip per tile.
-      if (!(one_chunk && pt > pt_lo)) {
-        __syncthreads();   // previous chunk fully consumed
+    double ring[PR_D + 1][2];
+    auto ldz = [&](int k4, double (&dst)[2]) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          int ch = tid + c * 256;
-          int row = ch >> 5, col = (ch & 31) * 2;
-          double2 v = double2{0.0, 0.0};
-          if (k0 + row < a.Lp && m0 + col < a.Mp) v = *reinterpret_cast<const double2*>(a.ZT + (long)(k0 + row) * a.Mp + m0 + col);
-          *reinterpret_cast<double2*>(zt + row * PR_LDZ + col) = v;
-        }
-        __syncthreads();
+      for (int x = 0; x < 2; ++x) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(zrs, (int)zoff[x], k4 * 4 * a.Mp * 8, 0);
+        __builtin_memcpy(&dst[x], &v, 8);
       }
-      const int kmax = min(PR_BK, a.Lp - k0);
-      for (int kk = 0; kk < kmax; kk += 4) {
-        const int k = k0 + kk + lrow;
-        const int ko = koff[k];
-        const bool kin = k < a.L;
-        double av[2], bv[2];
+    };
+    auto kstep = [&](int k4, const double (&w)[2]) {
+      const int k = 4 * k4 + lrow;
+      const int ko = koff[k];
+      const bool kin = k < a.L;
+      double bv[2];
 #pragma unroll
-        for (int x = 0; x < 2; ++x) av[x] = zt[(kk + lrow) * PR_LDZ + wm * 32 + x * 16 + lcol];
+      for (int y = 0; y < 2; ++y) {
+        const double v = img[pb[y] + ko];
+        bv[y] = kin ? v : 0.0;
+        xn[y] = fma(bv[y], bv[y], xn[y]);
+      }
 #pragma unroll
-        for (int y = 0; y < 2; ++y) {
-          double v = img[pb[y] + ko];
-          bv[y] = kin ? v : 0.0;
-          xn[y] += bv[y] * bv[y];
-        }
+      for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[x], bv[y], acc[x][y], 0, 0, 0);
+    };
 #pragma unroll
-          for (int y = 0; y < 2; ++y)
-            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
+    for (int u = 0; u < PR_D; ++u) ldz(min(u, nk4 - 1), ring[u]);
+    int t = 0;
+    for (; t + PR_D + 1 <= nk4; t += PR_D + 1) {   // full groups: no conditionals around the loads
+#pragma unroll
+      for (int u = 0; u <= PR_D; ++u) {
+        ldz(min(t + u + PR_D, nk4 - 1), ring[(u + PR_D) % (PR_D + 1)]);
+        kstep(t + u, ring[u]);
       }
     }
+#pragma unroll
+    for (int u = 0; u < PR_D; ++u)
+      if (t + u < nk4) kstep(t + u, ring[u]);
     // |x_p|^2 for column lcol of each fragment: combine the 4 k-groups
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
       xn[y] += __shfl_xor(xn[y], 16);
       xn[y] += __shfl_xor(xn[y], 32);
     }
-    // epilogue
+    // epilogue: the 4 accumulator values of a fragment together (their exps interleaved)
+    double wp[2];
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
+    for (int y = 0; y < 2; ++y) wp[y] = (a.reduce && p0 + y * 16 + lcol < a.P) ? a.w[p0 + y * 16 + lcol] : 0.0;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int m = m0 + wm * 32 + x * 16 + lrow + 4 * v;
-        const double znm = (m < a.Mp) ? a.zn[m] : 0.0;
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int y = 0; y < 2; ++y) {
-          const int p = p0 + y * 16 + lcol;
-          const double kv = a.bk.template eval_as<BT>(acc[x][y][v], xn[y], znm);
+      for (int y = 0; y < 2; ++y) {
+        const int p = p0 + y * 16 + lcol;
+        double kv[4], n1[4], n2[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { kv[v] = acc[x][y][v]; n1[v] = xn[y]; n2[v] = znl[wm * 32 + x * 16 + lrow + 4 * v]; }
+        a.bk.template eval_n<BT, 4>(kv, n1, n2);   // four dependent chains interleaved, times the four waves of the SIMD
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int m = m0 + wm * 32 + x * 16 + lrow + 4 * v;
           if (a.reduce) {
-            if (p < a.P) rsum[x][v] += a.w[p] * kv;
+            rsum[x][v] += wp[y] * kv[v];   // wp = 0 beyond the last patch
           } else if (m < a.M && p < a.P) {
-            a.out[(long)m * a.sM + (long)n * a.sN + (long)p * a.sP] = kv;
+            a.out[(long)m * a.sM + (long)n * a.sN + (long)p * a.sP] = kv[v];
           }
         }
       }
-    }
   }
 
   if (a.reduce) {
@@ -253,15 +267,25 @@ __global__ __launch_bounds__(256, 4) void patch_rbf_kernel(PatchRbfArgs a) {
   }
 }
 
+template <int BT>
+__global__ __launch_bounds__(256, BT == 0 ? 4 : 2) void patch_rbf_kernel(PatchRbfArgs a) {   // the acos epilogue needs the registers
+  patch_rbf_body<BT>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 // ---------------------------------------------------------------------------------------------
 // ConvKernel.Kdiag: per image sum_{p,p'} w_p w_p' k(x_p, x_p') / P^2, upper triangle of 64x64 patch
 // tile pairs (symmetry: off-diagonal pairs count twice).  grid (pairs, N); partial[n][pair].
 // ---------------------------------------------------------------------------------------------
+struct KdiagArgs {
+  const double* X; int n_mod, H, W, C, f, s, Ho, Wo, P, L; BaseKernel bk; const double* w; double* partial; int n_pairs, p_tiles;
+};
 template <int BT>
-__global__ __launch_bounds__(256, 4) void head_kdiag_kernel(const double* __restrict__ X, int n_mod, int H, int W, int C, int f,
-                                                          int s, int Ho, int Wo, int P, int L, BaseKernel bk,
-                                                          const double* __restrict__ w,
-                                                          double* __restrict__ partial, int n_pairs, int p_tiles) {
+__device__ __forceinline__ void head_kdiag_body(const KdiagArgs& k, const int bpair, const int n) {
+  const double* __restrict__ X = k.X;
+  const int n_mod = k.n_mod, H = k.H, W = k.W, C = k.C, f = k.f, s = k.s, Wo = k.Wo, P = k.P, L = k.L, n_pairs = k.n_pairs, p_tiles = k.p_tiles;
+  const BaseKernel& bk = k.bk;
+  const double* __restrict__ w = k.w;
+  double* __restrict__ partial = k.partial;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int HWC = H * W * C;
   const int Lp = (L + 3) & ~3;
@@ -272,9 +296,8 @@ __global__ __launch_bounds__(256, 4) void head_kdiag_kernel(const double* __rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lrow = lane >> 4, lcol = lane & 15;
-  const int n = blockIdx.y;
   // decode pair index -> (tr <= tc)
-  int pair = blockIdx.x, tr = 0;
+  int pair = bpair, tr = 0;
   while (pair >= p_tiles - tr) {
     pair -= p_tiles - tr;
     ++tr;
@@ -353,16 +376,24 @@ __global__ __launch_bounds__(256, 4) void head_kdiag_kernel(const double* __rest
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int ql = wm * 32 + x * 16 + lrow + 4 * v;
-      const int p = tr * 64 + ql;
+    for (int y = 0; y < 2; ++y) {
+      const int qc = wn * 32 + y * 16 + lcol;
+      const int pc = tc * 64 + qc;
+      const double wc = pc < P ? w[pc] : 0.0, nc = xn[64 + qc];
 #pragma unroll
-      for (int y = 0; y < 2; ++y) {
-        const int qc = wn * 32 + y * 16 + lcol;
-        const int pc = tc * 64 + qc;
-        if (p < P && pc < P) {
-          sum += w[p] * w[pc] * bk.template eval_as<BT>(acc[x][y][v], xn[ql], xn[64 + qc]);
+      for (int h = 0; h < 2; ++h) {   // two dependent exp chains interleaved, times the four waves of the SIMD
+        double kv[2], n1[2], n2[2], ww[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int v = 2 * h + e;
+          const int ql = wm * 32 + x * 16 + lrow + 4 * v;
+          const int p = tr * 64 + ql;
+          kv[e] = acc[x][y][v]; n1[e] = xn[ql]; n2[e] = nc;
+          ww[e] = p < P ? w[p] * wc : 0.0;
         }
+        bk.template eval_n<BT, 2>(kv, n1, n2);
+        sum += ww[0] * kv[0];
+        sum += ww[1] * kv[1];
       }
     }
 #pragma unroll
@@ -371,8 +402,22 @@ __global__ __launch_bounds__(256, 4) void head_kdiag_kernel(const double* __rest
   __syncthreads();
   if (tid == 0) {
     double t = (red[0] + red[1]) + (red[2] + red[3]);
-    partial[(long)n * n_pairs + blockIdx.x] = (tr == tc) ? t : 2.0 * t;
+    partial[(long)n * n_pairs + bpair] = (tr == tc) ? t : 2.0 * t;
   }
+}
+
+template <int BT>
+__global__ __launch_bounds__(256, 4) void head_kdiag_kernel(KdiagArgs k) {
+  head_kdiag_body<BT>(k, blockIdx.x, blockIdx.y);
+}
+
+// The head's two sweeps in ONE launch: per image, the Kdiag tile pairs first, then the 64-row blocks of Kzx (the image is
+// L2-warm for the second reader; no second stream, no cross-stream join in front of the head's conditional).
+__global__ __launch_bounds__(256, 4) void head_sweep_kernel(PatchRbfArgs a, KdiagArgs k, int ny) {
+  const int per_n = k.n_pairs + ny;
+  const int n = blockIdx.x / per_n, role = blockIdx.x - n * per_n;
+  if (role < k.n_pairs) head_kdiag_body<0>(k, role, n);
+  else patch_rbf_body<0>(a, 0, role - k.n_pairs, n);
 }
 
 __global__ void kdiag_reduce_kernel(const double* __restrict__ partial, int n_pairs, int N, double scale,
@@ -423,7 +468,8 @@ int patch_rbf(dcgp_ctx* ctx, const PatchRbfArgs& a, const char* timer_name) {
   if (a.n_mod <= 0) return ctx_fail(ctx, DCGP_ERR_ARG, "patch_rbf: n_mod must be positive");
   if (a.Mp % PR_BM != 0 && a.Mp % 16 != 0) return ctx_fail(ctx, DCGP_ERR_ARG, "patch_rbf: Mp must be a multiple of 16");
   const int HWC = a.H * a.W * a.C;
-  size_t lds = (size_t)(((HWC + 1) & ~1) + PR_BK * PR_LDZ + 2 * PR_BM) * sizeof(double) + (size_t)a.Lp * sizeof(int);
+  size_t lds = (size_t)(((HWC + 1) & ~1) + 3 * PR_BM) * sizeof(double) + (size_t)a.Lp * sizeof(int);
+  if ((long)a.Lp * a.Mp * 8 >= (1L << 31)) return ctx_fail(ctx, DCGP_ERR_ARG, "patch_rbf: Z^T exceeds 2 GiB");
   if (lds > 160 * 1024) return ctx_fail(ctx, DCGP_ERR_ARG, "patch_rbf: image of %d doubles does not fit LDS", HWC);
   // A sweep that overlaps the factorisation chain would otherwise starve it: its thousands of short 128-VGPR
   // workgroups refill every slot the moment it frees, and a chain workgroup (200 VGPRs, 50 KB LDS) never finds a
@@ -441,26 +487,55 @@ int patch_rbf(dcgp_ctx* ctx, const PatchRbfArgs& a, const char* timer_name) {
   return DCGP_OK;
 }
 
-int head_kdiag(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, int C, int f, int s, BaseKernel bk,
-               const double* w, double* out_N) {
+static int kdiag_args(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, int C, int f, int s, BaseKernel bk, const double* w,
+                      KdiagArgs* k, size_t* lds) {
   const int Ho = (H - f) / s + 1, Wo = (W - f) / s + 1, P = Ho * Wo, L = f * f * C;
   const int p_tiles = (P + 63) / 64, n_pairs = p_tiles * (p_tiles + 1) / 2;
   const int HWC = H * W * C, Lp = (L + 3) & ~3;
   double* partial = (double*)ws_get(ctx, "kdiag_partial", (size_t)N * n_pairs * sizeof(double));
   if (!partial) return DCGP_ERR_ALLOC;
-  size_t lds = (size_t)(((HWC + 1) & ~1) + 128 + 4) * sizeof(double) + (size_t)Lp * sizeof(int);
-  if (lds > 160 * 1024) return ctx_fail(ctx, DCGP_ERR_ARG, "head_kdiag: image does not fit LDS");
+  *lds = (size_t)(((HWC + 1) & ~1) + 128 + 4) * sizeof(double) + (size_t)Lp * sizeof(int);
+  if (*lds > 160 * 1024) return ctx_fail(ctx, DCGP_ERR_ARG, "head_kdiag: image does not fit LDS");
+  k->X = X; k->n_mod = n_mod; k->H = H; k->W = W; k->C = C; k->f = f; k->s = s; k->Ho = Ho; k->Wo = Wo; k->P = P; k->L = L;
+  k->bk = bk; k->w = w; k->partial = partial; k->n_pairs = n_pairs; k->p_tiles = p_tiles;
+  return DCGP_OK;
+}
+
+int head_kdiag(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, int C, int f, int s, BaseKernel bk,
+               const double* w, double* out_N) {
+  KdiagArgs k;
+  size_t lds = 0;
+  DCGP_TRY(kdiag_args(ctx, X, N, n_mod, H, W, C, f, s, bk, w, &k, &lds));
   ScopedTimer t(ctx, "head_kdiag");
-  if (bk.type == 0)
-    hipLaunchKernelGGL(head_kdiag_kernel<0>, dim3(n_pairs, N), dim3(256), lds, ctx->stream, X, n_mod, H, W, C, f, s, Ho, Wo, P, L,
-                       bk, w, partial, n_pairs, p_tiles);
-  else
-    hipLaunchKernelGGL(head_kdiag_kernel<1>, dim3(n_pairs, N), dim3(256), lds, ctx->stream, X, n_mod, H, W, C, f, s, Ho, Wo, P, L,
-                       bk, w, partial, n_pairs, p_tiles);
+  if (bk.type == 0) hipLaunchKernelGGL(head_kdiag_kernel<0>, dim3(k.n_pairs, N), dim3(256), lds, ctx->stream, k);
+  else hipLaunchKernelGGL(head_kdiag_kernel<1>, dim3(k.n_pairs, N), dim3(256), lds, ctx->stream, k);
   LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(kdiag_reduce_kernel, dim3((N + 127) / 128), dim3(128), 0, ctx->stream, partial, n_pairs, N,
-                     1.0 / ((double)P * (double)P), out_N);
+  hipLaunchKernelGGL(kdiag_reduce_kernel, dim3((N + 127) / 128), dim3(128), 0, ctx->stream, k.partial, k.n_pairs, N,
+                     1.0 / ((double)k.P * (double)k.P), out_N);
   LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
+// ConvKernel.Kzx (reduce-mode sweep `a`) and ConvKernel.Kdiag of the same images in one launch (RBF base kernel).  Kdiag is left
+// as per-image partial sums: Kdiag[n] = *kd_scale * sum_i (*kd_partial)[n * *n_pairs + i]  (the fused head conditional adds them up).
+int head_sweep(dcgp_ctx* ctx, const PatchRbfArgs& a, const double* w, const double** kd_partial, int* n_pairs, double* kd_scale) {
+  if (a.N <= 0) return DCGP_OK;
+  if (!a.reduce || a.bk.type != 0 || a.n_mod <= 0) return ctx_fail(ctx, DCGP_ERR_ARG, "head_sweep: reduce-mode RBF sweep expected");
+  KdiagArgs k;
+  size_t lds_k = 0;
+  DCGP_TRY(kdiag_args(ctx, a.X, a.N, a.n_mod, a.H, a.W, a.C, a.f, a.s, a.bk, w, &k, &lds_k));
+  const int HWC = a.H * a.W * a.C;
+  size_t lds = (size_t)(((HWC + 1) & ~1) + 3 * PR_BM) * sizeof(double) + (size_t)a.Lp * sizeof(int);
+  if (lds_k > lds) lds = lds_k;
+  if (lds > 160 * 1024) return ctx_fail(ctx, DCGP_ERR_ARG, "head_sweep: image of %d doubles does not fit LDS", HWC);
+  if ((long)a.Lp * a.Mp * 8 >= (1L << 31)) return ctx_fail(ctx, DCGP_ERR_ARG, "head_sweep: Z^T exceeds 2 GiB");
+  const int ny = (a.Mp + PR_BM - 1) / PR_BM;
+  const long nwg = (long)a.N * (k.n_pairs + ny);
+  if (nwg > 0x7fffffffL) return ctx_fail(ctx, DCGP_ERR_ARG, "head_sweep: too many workgroups");
+  ScopedTimer t(ctx, "head_sweep");
+  hipLaunchKernelGGL(head_sweep_kernel, dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a, k, ny);
+  LAUNCH_CHECK(ctx);
+  *kd_partial = k.partial; *n_pairs = k.n_pairs; *kd_scale = 1.0 / ((double)k.P * (double)k.P);
   return DCGP_OK;
 }
 

@@ -342,15 +342,15 @@ def test_oversized_operand_slab(ctx):
     X = np.tile(X, (2, 1))[:200]                    # 200 images x 10 samples x 144 patches
     Y = np.tile(Y, 2)[:200]
     model = build_from_spec(spec, X, Y)
-    e, data, kl = model.compute_log_likelihood(X, Y, seed=0, return_parts=True)
-    lo = model.compute_log_likelihood(X[:100], Y[:100], seed=0, return_parts=True)[1]
-    assert np.isfinite([e, data, kl]).all() and data < lo < 0
-    os.environ["DCGP_NO_FUSED_LAYER"] = "1"
+    os.environ["DCGP_FUSED_LARGE"] = "1"          # M > 256 takes the one-launch route on request only
     try:
-        with pytest.raises(dev.DcgpError) as ei:
-            model.compute_log_likelihood(X, Y, seed=0)
+        e, data, kl = model.compute_log_likelihood(X, Y, seed=0, return_parts=True)
+        lo = model.compute_log_likelihood(X[:100], Y[:100], seed=0, return_parts=True)[1]
     finally:
-        del os.environ["DCGP_NO_FUSED_LAYER"]
+        del os.environ["DCGP_FUSED_LARGE"]
+    assert np.isfinite([e, data, kl]).all() and data < lo < 0
+    with pytest.raises(dev.DcgpError) as ei:
+        model.compute_log_likelihood(X, Y, seed=0)
     assert ei.value.code == dev.ERR_ARG and "2 GiB" in str(ei.value)
     model.close()
 

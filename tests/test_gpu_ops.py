@@ -245,12 +245,14 @@ def test_fused_conv_layer_matches_the_unfused_route_and_the_oracle(ctx, white, H
     layer = ConvLayer(RBF(v.patch_length, 5.0, 5.0), None, PatchInducingFeatures(Z), v, white=white, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
     z = rng.standard_normal((N, layer.num_outputs))
     assert "DCGP_NO_FUSED_LAYER" not in os.environ
-    smp, mean, var = layer._forward(X, z)
-    os.environ["DCGP_NO_FUSED_LAYER"] = "1"
+    os.environ["DCGP_FUSED_LARGE"] = "1"        # M > 256 takes the one-launch route on request only
     try:
+        smp, mean, var = layer._forward(X, z)
+        os.environ["DCGP_NO_FUSED_LAYER"] = "1"
         smp_u, mean_u, var_u = layer._forward(X, z)
     finally:
-        del os.environ["DCGP_NO_FUSED_LAYER"]
+        os.environ.pop("DCGP_NO_FUSED_LAYER", None)
+        del os.environ["DCGP_FUSED_LARGE"]
     close(mean, mean_u, 1e-11, "mean vs unfused")
     close(var, var_u, 1e-10, "var vs unfused")
     close(smp, smp_u, 1e-10, "sample vs unfused")
