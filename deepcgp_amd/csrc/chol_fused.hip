@@ -329,12 +329,12 @@ __global__ void chol_finish_kernel(double* const* __restrict__ Ap, const double*
 
 // Cholesky factor in place (strict upper triangle zeroed) and, when d_Linv != nullptr, inv(L) (+ its transpose).
 int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_Linv, double* const* d_LinvT, int batch,
-                           int Mp, int ld, int* d_info) {
+                           int Mp, int ld, int* d_info, bool defer_finish) {
   if (batch <= 0) return DCGP_OK;
   ScopedTimer t(ctx, "factor_chain");
   const size_t mm = (size_t)Mp * ld;
-  double* Lout = (double*)ws_get(ctx, "chol_Lout", (size_t)batch * mm * sizeof(double));
-  double* Y = d_Linv ? (double*)ws_get(ctx, "chol_Y", (size_t)batch * mm * sizeof(double)) : nullptr;
+  double* Lout = (double*)ws_get(ctx, "chol_Lout" + ctx->ws_tag, (size_t)batch * mm * sizeof(double));
+  double* Y = d_Linv ? (double*)ws_get(ctx, "chol_Y" + ctx->ws_tag, (size_t)batch * mm * sizeof(double)) : nullptr;
   if (!Lout || (d_Linv && !Y)) return DCGP_ERR_ALLOC;
   for (int j = 0; j < Mp; j += NB) {
     RlArgs a;
@@ -349,7 +349,16 @@ int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_L
     hipLaunchKernelGGL(chol_rl_kernel, dim3(gx > 0 ? gx : 1, batch), dim3(256), 0, ctx->stream, a);
     LAUNCH_CHECK(ctx);
   }
-  hipLaunchKernelGGL(chol_finish_kernel, dim3(Mp, batch), dim3(128), 0, ctx->stream, d_A, (const double*)Lout, Mp, ld);
+  if (defer_finish) return DCGP_OK;   // inv(L) is complete; the caller copies the factor back (factor_finish_batched) off its critical path
+  return factor_finish_batched(ctx, d_A, batch, Mp, ld);
+}
+
+// final factor from the chain's scratch back over A (lower triangle; strict upper triangle zeroed)
+int factor_finish_batched(dcgp_ctx* ctx, double* const* d_A, int batch, int Mp, int ld) {
+  if (batch <= 0) return DCGP_OK;
+  auto it = ctx->ws.find("chol_Lout" + ctx->ws_tag);
+  if (it == ctx->ws.end()) return ctx_fail(ctx, DCGP_ERR_ARG, "factor_finish: no factorisation to finish");
+  hipLaunchKernelGGL(chol_finish_kernel, dim3(Mp, batch), dim3(128), 0, ctx->stream, d_A, (const double*)it->second.first, Mp, ld);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }

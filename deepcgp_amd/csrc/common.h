@@ -45,6 +45,7 @@ struct dcgp_ctx {
                                    // the profiler serialises dispatches and cross-stream waits can deadlock it)
   hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;  // fork / join of a short side-stream excursion inside a layer
   std::string err;
+  std::string ws_tag;   // suffix of the chain's / KL terms' scratch names: steps in flight on the two banks must not share them
   // named, grow-only device workspaces owned by the ctx
   std::map<std::string, std::pair<void*, size_t>> ws;
   // timing
@@ -248,6 +249,7 @@ int trtri_batched(dcgp_ctx* ctx, double* const* d_L, double* const* d_Linv, doub
                   int batch, int Mp, int ld);
 // left-looking fused Cholesky (+ inverse of the factor when d_Linv != nullptr): one launch per 32-wide panel
 int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_Linv, double* const* d_LinvT, int batch,
-                           int Mp, int ld, int* d_info);
+                           int Mp, int ld, int* d_info, bool defer_finish = false);
+int factor_finish_batched(dcgp_ctx* ctx, double* const* d_A, int batch, int Mp, int ld);
 int pad_copy(dcgp_ctx* ctx, const double* src, int rows, int cols, int lds, double* dst, int ldd, int rows_p,
              int cols_p, int mode, int batch, long src_batch, long dst_batch);   // mode 0 full, 1 lower-tri, 2: +I on pad diag

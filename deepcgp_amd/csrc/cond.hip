@@ -436,8 +436,8 @@ int kl_layer(dcgp_ctx* ctx, const GpMats& g, const double* Lp, const double* Lpi
     const int BMa = gemm_row_block(Mp, g.Rp, 1), nrba = (Mp + BMa - 1) / BMa;
     tp_count = (long)R * nrb * Mp;
     ap_count = (long)nrba * g.Rp;
-    tp = (double*)ws_get(ctx, std::string(pfx) + "kl_tp", (size_t)tp_count * sizeof(double));
-    ap = (double*)ws_get(ctx, std::string(pfx) + "kl_ap", (size_t)ap_count * sizeof(double));
+    tp = (double*)ws_get(ctx, std::string(pfx) + "kl_tp" + ctx->ws_tag, (size_t)tp_count * sizeof(double));
+    ap = (double*)ws_get(ctx, std::string(pfx) + "kl_ap" + ctx->ws_tag, (size_t)ap_count * sizeof(double));
     if (!tp || !ap) return DCGP_ERR_ALLOC;
     ScopedTimer t(ctx, "gemm_kl");
     GemmArgs a;   // || inv(Lp) Lq_r ||_F^2 for every r

@@ -193,16 +193,26 @@ struct FactorGroup {
     uploaded = true;
     return DCGP_OK;
   }
-  int run(dcgp_ctx* ctx) {
+  // defer_finish: inv(L) and its transpose are complete on return, the factor itself is copied back over K by finish() --
+  // only the KL terms (and the reverse pass) read it, so the copy need not sit in front of the first layer
+  bool deferred = false;
+  int run(dcgp_ctx* ctx, bool defer_finish = false) {
     DCGP_TRY(upload(ctx));
     static const bool legacy = getenv("DCGP_CHOL_LEGACY") != nullptr;   // A/B: right-looking potrf + recursive trtri
+    deferred = false;
     if (legacy) {
       DCGP_TRY(potrf_batched(ctx, dK, nullptr, (int)K.size(), Mp, Mp, d_info));
       DCGP_TRY(trtri_batched(ctx, dK, dLinv, dLinvT, (int)K.size(), Mp, Mp));
     } else {
-      DCGP_TRY(factor_inverse_batched(ctx, dK, dLinv, dLinvT, (int)K.size(), Mp, Mp, d_info));
+      DCGP_TRY(factor_inverse_batched(ctx, dK, dLinv, dLinvT, (int)K.size(), Mp, Mp, d_info, defer_finish));
+      deferred = defer_finish;
     }
     return DCGP_OK;
+  }
+  int finish(dcgp_ctx* ctx) {
+    if (!deferred) return DCGP_OK;
+    deferred = false;
+    return factor_finish_batched(ctx, dK, (int)K.size(), Mp, Mp);
   }
 };
 

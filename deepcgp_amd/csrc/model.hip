@@ -131,7 +131,7 @@ int read_info(dcgp_model* m, int* info_host) {
 struct StreamGuard {
   dcgp_ctx* ctx; hipStream_t saved;
   explicit StreamGuard(dcgp_ctx* c) : ctx(c), saved(c->stream) {}
-  ~StreamGuard() { ctx->stream = saved; }
+  ~StreamGuard() { ctx->stream = saved; ctx->ws_tag.clear(); }
 };
 
 // layers 0..n-1 forward; leaves ctx->stream on the main stream the step runs on (the caller holds a StreamGuard).
@@ -181,6 +181,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
 
   // ---- the parameter-only chain ----
   ctx->stream = chain_s;
+  ctx->ws_tag = bank ? "~b1" : "";   // its scratch per bank: the chains / KL terms of two steps in flight may overlap
   if (chain_s != main_s) {
     if (m->done_valid[bank]) HIP_TRY(ctx, hipStreamWaitEvent(chain_s, m->done_ev[bank], 0));   // the bank's previous reader
     else if (ctx->ev_last_valid) HIP_TRY(ctx, hipStreamWaitEvent(chain_s, ctx->ev_last, 0));    // first use: behind whatever ran last
@@ -195,8 +196,10 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   // (events only where another stream waits for them: each record is a packet in front of the next launch)
   const bool xs = chain_s != main_s;
   if (rc == DCGP_OK && xs && !first_fused && hipEventRecord(m->ev_sweep[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;   // Z^T, |z|^2: what a sweep needs
+  // with a single factor group its "chol_Lout" scratch stays untouched until the deferred copy runs on the KL stream
+  const bool defer = m->groups[bank].size() == 1 && need_kl && !m->keep_state;
   for (auto& gr : m->groups[bank])
-    if (rc == DCGP_OK) rc = gr.run(ctx);
+    if (rc == DCGP_OK) rc = gr.run(ctx, defer);
   if (rc == DCGP_OK && xs && hipEventRecord(m->ev_factor[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
   // G_r = inv(L) Lq_r and alpha = inv(L) q_mu of every layer (cond_prep): gate the second conditional GEMM
   bool prep_done[8] = {};
@@ -215,6 +218,8 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       if (hipStreamWaitEvent(kl_s, m->ev_prep[bank][nl - 1], 0) != hipSuccess) rc = DCGP_ERR_HIP;
       ctx->stream = kl_s;
     }
+    for (auto& gr : m->groups[bank])
+      if (rc == DCGP_OK) rc = gr.finish(ctx);   // the factor back over K (deferred copy): the KL terms read its diagonal
     for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
       LayerState& L = *m->layers[li];
       const double* Lp = L.g.Kp ? L.g.Kp : L.g.K;
@@ -224,6 +229,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   }
   if (rc == DCGP_OK && hipEventRecord(m->ev_kl[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
   ctx->stream = main_s;
+  ctx->ws_tag.clear();
   if (rc != DCGP_OK) {
     hipStreamSynchronize(kl_s);
     hipStreamSynchronize(chain_s);

@@ -236,6 +236,14 @@ class Context:
             out[name] = (n.value, ms.value)
         return out
 
+    # strided GEMM on device arrays ---------------------------------------------------------------
+    def gemm(self, A, a_strides, B, b_strides, C_out, c_rs, c_bs, M, N, K, batch=1, alpha=1.0, accumulate=False):
+        """C_b(i, j) (+)= alpha sum_k A_b(i, k) B_b(k, j) with A_b(i, k) = A[b a_bs + i a_rs + k a_cs] etc. (element strides:
+        ``a_strides = (a_rs, a_cs, a_bs)``); dcgp_gemm_strided, the MFMA fp64 GEMM of csrc/gemm_gen.hip."""
+        self._check(lib().dcgp_gemm_strided(self.handle, A.ptr, a_strides[0], a_strides[1], a_strides[2], B.ptr, b_strides[0],
+                                            b_strides[1], b_strides[2], C_out.ptr, c_rs, c_bs, M, N, K, batch, float(alpha),
+                                            int(bool(accumulate)), None, 0, 0, None, 0, 0, 0))
+
     # multi-GPU ---------------------------------------------------------------------------------
     def comm_init(self, nranks, rank, unique_id):
         self._check(lib().dcgp_comm_init_rank(self.handle, int(nranks), int(rank), bytes(unique_id)))

@@ -128,6 +128,9 @@ class DGP_Base:
         """Objects with ``pathname`` + ``value`` in the reference's checkpoint naming
         (DGP/layers/<i>/..., notebooks/Inspect.ipynb cell 6)."""
         out = []
+        if hasattr(self.likelihood, "epsilon"):     # RobustMax epsilon under the BroadcastingLikelihood wrapper's doubled path
+            out.append(Parameter("%s/likelihood/likelihood/invlink/epsilon" % self.name, lambda: np.array(self.likelihood.epsilon),
+                                 lambda v: setattr(self.likelihood, "epsilon", float(v))))
         for i, l in enumerate(self.layers):
             head = i == len(self.layers) - 1
             base = "%s/layers/%d" % (self.name, i)

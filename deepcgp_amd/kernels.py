@@ -191,21 +191,18 @@ class ConvKernel(AdditivePatchKernel):
         return out.numpy()
 
 
-def _sample(tensor, count):
-    return tensor[np.random.choice(np.arange(tensor.shape[0]), count)]
-
-
 def _sample_patches(HW_image, N, patch_size, patch_length):
-    """conv_gp/kernels.py:139-145 (imported by the reference's notebooks)."""
-    out = np.zeros((N, patch_length))
+    """N random patch_size x patch_size patches of ONE image, flattened -- the helper the reference's notebooks import from
+    conv_gp/kernels.py (:139-145); same draw order (row, then column, per patch)."""
+    rows = np.empty((N, patch_length))
+    hi_y, hi_x = HW_image.shape[0] - patch_size, HW_image.shape[1] - patch_size
     for i in range(N):
-        y = np.random.randint(0, HW_image.shape[0] - patch_size)
-        x = np.random.randint(0, HW_image.shape[1] - patch_size)
-        out[i] = HW_image[y:y + patch_size, x:x + patch_size].reshape(patch_length)
-    return out
+        top, left = np.random.randint(0, hi_y), np.random.randint(0, hi_x)
+        rows[i] = np.reshape(HW_image[top:top + patch_size, left:left + patch_size], patch_length)
+    return rows
 
 
-def kmeans(points, k, max_iter=300, tol=1e-4, rng=None):
+def kmeans(points, k, max_iter=300, tol=1e-4, rng=None, distinct_start=False):
     """Lloyd's k-means on the device (dcgp_kmeans): sklearn.cluster.KMeans(n_clusters=k, init='random', n_init=1) in
     its own terms -- k random observations as the initial centres, ``tol`` relative to the mean feature variance,
     stop when the summed squared centre shift falls below it.  Returns the [k, d] centres."""
@@ -214,7 +211,14 @@ def kmeans(points, k, max_iter=300, tol=1e-4, rng=None):
     ctx = dev.get_context()
     P = np.ascontiguousarray(points, np.float64)
     n, d = P.shape
-    rows = np.ascontiguousarray((rng or np.random).choice(n, size=k, replace=False), np.int32)
+    rng = rng or np.random
+    if distinct_start:
+        # start from k rows that differ in VALUE where the sample has that many (sklearn relocates empty clusters instead)
+        _, first = np.unique(P.round(12), axis=0, return_index=True)
+        pool = first if first.size >= k else np.arange(n)
+        rows = np.ascontiguousarray(rng.choice(pool, size=k, replace=False), np.int32)
+    else:
+        rows = np.ascontiguousarray(rng.choice(n, size=k, replace=False), np.int32)
     dP, dC = ctx.to_device(P), ctx.empty((k, d))
     iters = C.c_int(0)
     ctx._check(dev.lib().dcgp_kmeans(ctx.handle, dP.ptr, n, d, k, rows.ctypes.data, int(max_iter), float(tol * np.mean(np.var(P, axis=0))),
@@ -223,14 +227,13 @@ def kmeans(points, k, max_iter=300, tol=1e-4, rng=None):
 
 
 def _cluster_patches(NHWC_X, M, patch_size):
-    """k-means of 100*M random patches (conv_gp/kernels.py:147-164); the patches are drawn on the host as the
-    reference draws them, the clustering runs on the device."""
-    NHWC = NHWC_X.shape
-    patch_length = patch_size ** 2 * NHWC[3]
-    patches = np.zeros((M * 100, patch_length))
-    for i in range(M * 100):
-        patches[i] = _sample_patches(_sample(NHWC_X, 1)[0], 1, patch_size, patch_length)
-    return kmeans(patches, M)
+    """Inducing patches of PatchInducingFeatures.from_images (conv_gp/kernels.py:147-164): k-means centres of 100 * M patches cut at
+    random from random images.  The sample is one vectorised gather (deepcgp_amd.models.draw_patches); Lloyd's iterations run
+    on the device (``kmeans``), started from M DISTINCT patches -- on images with large constant regions (MNIST borders) a
+    plain random start picks many identical rows, whose clusters then stay empty and leave duplicate inducing patches."""
+    from .models import draw_patches
+    sample = draw_patches(np.asarray(NHWC_X, np.float64), 100 * M, patch_size)
+    return kmeans(sample, M, distinct_start=True)
 
 
 class InducingPoints:

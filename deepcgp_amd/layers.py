@@ -81,6 +81,11 @@ class MultiOutputConvKernel:
         self.base_kernel._kuf(ctx, dX, N, H, W, Cc, f, s, dZ, M, out, 0)
         return out.numpy()
 
+    def Kff(self, PNL_patches):
+        """P x N x N auto-covariance of the inputs, patch by patch (conv_gp/layers.py:34-41; full_cov=True only)."""
+        PNL = np.ascontiguousarray(PNL_patches, np.float64)
+        return np.stack([self.base_kernel._gram(PNL[p], 0.0) for p in range(PNL.shape[0])]) if PNL.shape[0] else np.zeros((0,) + PNL.shape[1:2] * 2)
+
     def Kdiag(self, PNL_patches):
         P, N = np.shape(PNL_patches)[:2]
         return np.full((P, N), self.base_kernel.variance)
@@ -154,8 +159,29 @@ class ConvLayer(Layer):
     def conditional_ND(self, ND_X, full_cov=False):
         """mean, var of q(f | m, S), each N x (patch_count * gp_count), HWC column order."""
         if full_cov:
-            raise NotImplementedError("full_cov=True is outside the accelerated hot path")
+            return self._conditional_full_cov(ND_X)
         return self._forward(ND_X, None)[1:]
+
+    def _conditional_full_cov(self, ND_X):
+        """conv_gp/layers.py:114-126 with full_cov=True: mean N x num_outputs, var N x N x num_outputs (per output = (patch, gp)
+        an N x N covariance over the inputs; conditionals._conditional_full_cov documents the per-patch reading).  Off the training
+        path (predict_f_full_cov-style calls): composed from the operator-level device calls."""
+        ND_X = np.ascontiguousarray(ND_X, np.float64)
+        N, v = ND_X.shape[0], self.view
+        X4 = ND_X.reshape(N, v.input_size[0], v.input_size[1], self.feature_maps_in)
+        PNL = v.extract_patches_PNL(X4)
+        mean, var = conditional(self.conv_kernel.Kuf(self.feature.Z, (X4, v)), self.conv_kernel.Kuu(self.feature.Z), self.conv_kernel.Kff(PNL),
+                                self.q_mu, full_cov=True, q_sqrt=self.q_sqrt, white=self.white)      # N x P x R, R x P x N x N
+        var = np.transpose(var, (2, 3, 1, 0)).reshape(N, N, self.num_outputs)
+        mean = mean.reshape(N, self.num_outputs)
+        if self.identity_mean:
+            f, st = v.filter_size, v.stride
+            Ho, Wo = (v.input_size[0] - f) // st + 1, (v.input_size[1] - f) // st + 1
+            c0 = f // 2
+            centre = X4[:, c0:c0 + (Ho - 1) * st + 1:st, c0:c0 + (Wo - 1) * st + 1:st, 0]
+            mean = mean.copy()
+            mean.reshape(N, v.patch_count, self.gp_count)[:, :, 0] += centre.reshape(N, v.patch_count)
+        return mean, var
 
     def _forward(self, ND_X, z):
         ctx = dev.get_context()

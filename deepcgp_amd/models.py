@@ -35,7 +35,7 @@ def build_layers_from_spec(spec):
                                  q_sqrt=h["q_sqrt"]))
         return layers
     cls = AdditivePatchKernel if h.get("kernel", "conv") == "add" else ConvKernel
-    kern = cls(RBF(view.patch_length, h["variance"], h["ls"]), view, patch_weights=h["w"])
+    kern = cls(RBF(view.patch_length, h["variance"], h["ls"]), view, patch_weights=h.get("w"))
     layers.append(SVGP_Layer(kern=kern, num_outputs=h["R"], feature=PatchInducingFeatures(h["Z"]),
                              mean_function=None, white=h["white"], q_mu=h["q_mu"], q_sqrt=h["q_sqrt"]))
     return layers
@@ -155,8 +155,60 @@ def identity_conv(NHWC_X, filter_size, feature_maps_in, feature_maps_out, stride
     return np.repeat(centre[..., None], feature_maps_out, axis=-1)
 
 
+# ---------------------------------------------------------------------------------------------------
+# flags -> architecture -> neutral model spec -> layers  (the job of conv_gp/models.py:35-247)
+# ---------------------------------------------------------------------------------------------------
+# Checkpoint keys are gpflow path names, "DGP/layers/<i>/<suffix>" (conv_gp/experiment.py:56-64, notebooks/Inspect.ipynb cell 6).
+# suffix -> field of the per-layer record the spec is filled from; the first matching row wins.
+CHECKPOINT_FIELDS = (
+    ("feature/Z", "Z"),
+    ("q_mu", "q_mu"),
+    ("q_sqrt", "q_sqrt"),
+    ("base_kernel/variance", "variance"),          # conv_kernel/base_kernel/... (conv layers), kern/base_kernel/... (patch heads)
+    ("base_kernel/lengthscales", "ls"),
+    ("kern/patch_weights", "w"),
+    ("kern/variance", "variance"),                 # dense RBF head (--last-kernel rbf): the kernel sits directly under kern/
+    ("kern/lengthscales", "ls"),
+)
+
+
+def read_checkpoint(path, n_layers):
+    """``{'global_step': int, layer index: {field: array}}`` from a ``np.save``d ``{pathname: value}`` dict.  A checkpoint with
+    fewer layers than the model being built keeps its conv layers in place and hands its LAST stored layer (the head it was
+    trained with) to the model's last layer (conv_gp/models.py:231-238)."""
+    raw = np.load(path, allow_pickle=True).item()
+    records = {}
+    for key, value in raw.items():
+        parts = key.split("/")
+        if len(parts) < 4 or parts[1] != "layers" or not parts[2].isdigit():
+            continue
+        suffix = "/".join(parts[3:])
+        field = next((f for tail, f in CHECKPOINT_FIELDS if suffix.endswith(tail)), None)
+        if field is not None:
+            records.setdefault(int(parts[2]), {})[field] = np.asarray(value)
+    stored = max(records) + 1 if records else 0
+    if stored > n_layers:
+        raise AssertionError("Can't load model if it has more layers than the one being built")
+    if records and stored != n_layers:
+        records[n_layers - 1] = records.pop(stored - 1)
+    return int(raw.get("global_step", 0)), records
+
+
+def draw_patches(NHWC_X, count, f, rng=np.random):
+    """``count`` f x f patches, each cut at a random position of a random image: [count, f*f*C] in the (kh, kw, c) element order of
+    FullView -- the sample PatchInducingFeatures.from_images clusters (conv_gp/kernels.py:139-164), drawn in one gather."""
+    n, H, W, C = NHWC_X.shape
+    img = rng.randint(0, n, size=count)
+    top, left = rng.randint(0, H - f, size=count), rng.randint(0, W - f, size=count)    # upper bound exclusive, as the reference draws them
+    dy, dx = np.arange(f)[None, :, None], np.arange(f)[None, None, :]
+    return NHWC_X[img[:, None, None], top[:, None, None] + dy, left[:, None, None] + dx, :].reshape(count, f * f * C)
+
+
 class ModelBuilder(object):
-    """Same flags and construction order as conv_gp/models.py:35-198 (checkpoint loading: :200-240)."""
+    """``ModelBuilder(flags, NHWC_X_train, Y_train, model_path).build() -> DGP_Base`` (the interface of conv_gp/models.py:35-70).
+    The flags are turned into a stage list, the stage list -- walking the initialisation images through the identity convolution,
+    clustering patches for the inducing inputs, filling in what a checkpoint holds -- into the neutral model spec of
+    ``deepcgp_amd.synthetic``, and the spec into layers by ``build_layers_from_spec``."""
 
     def __init__(self, flags, NHWC_X_train, Y_train, model_path=None):
         self.flags = flags
@@ -165,110 +217,78 @@ class ModelBuilder(object):
         self.model_path = model_path
         self.global_step = None
 
+    # ---- flags -> stages ---------------------------------------------------------------------------
+    def stages(self):
+        """[(M, filter, stride, feature maps)] per conv layer and (M, filter, stride) of the head.  The comma lists follow
+        conv_gp/arguments.py:27-31: one M / filter size / stride per GP layer (head included), one feature-map count per conv layer."""
+        fl = self.flags
+        M, fmaps = parse_ints(fl.M), parse_ints(fl.feature_maps)
+        filt, strd = parse_ints(fl.filter_sizes), parse_ints(fl.strides)
+        assert len(strd) == len(filt)
+        assert len(fmaps) == len(M) - 1
+        convs = [(M[i], filt[i], strd[i], fmaps[i]) for i in range(len(fmaps))]
+        return convs, (M[-1], filt[-1], strd[-1])
+
+    # ---- stages -> spec ----------------------------------------------------------------------------
+    def spec(self):
+        fl = self.flags
+        convs, (head_M, head_f, head_s) = self.stages()
+        n_layers = len(convs) + 1
+        stored = {}
+        if getattr(fl, "load_model", None) is not None:
+            self.global_step, stored = read_checkpoint(self.model_path, n_layers)
+        if fl.base_kernel not in ("rbf", "acos"):
+            raise ValueError("Not a valid base-kernel value")
+        if fl.last_kernel not in ("conv", "add", "rbf"):
+            raise ValueError("Invalid last layer kernel")
+        white = bool(fl.white)
+        spec = {"S": int(fl.num_samples), "num_data": int(self.X_train.shape[0]), "convs": []}
+        images = self.X_train                              # what the next layer is initialised on
+        for li, (M, f, s, R) in enumerate(convs):
+            have = stored.get(li, {})
+            _, H, W, C = images.shape
+            Z = have["Z"] if "Z" in have else PatchInducingFeatures.from_images(images, M, f).Z
+            spec["convs"].append(dict(
+                H=H, W=W, C=C, f=f, s=s, M=M, R=R, Z=Z, Z0=Z, white=white, base=fl.base_kernel,
+                variance=float(have.get("variance", 5.0)), ls=float(have.get("ls", 5.0)),     # models.py:114-117
+                q_mu=have.get("q_mu"), q_sqrt=have.get("q_sqrt"),
+                q_sqrt_scale=None if "q_sqrt" in have else 1e-5,                               # start with low variance (models.py:136-138)
+                mean_function="conv2d" if getattr(fl, "identity_mean", False) else None))
+            images = identity_conv(images, f, C, R, s)                                          # models.py:29-33,104
+        have = stored.get(n_layers - 1, {})
+        _, H, W, C = images.shape
+        if "Z" in have and fl.last_kernel != "rbf":
+            stored_f = int(round(np.sqrt(have["Z"].shape[1] / C)))
+            if stored_f != head_f:        # a head trained with another filter size starts afresh (models.py:152-158)
+                print("filter_size {} != {} for last layer. Resetting parameters.".format(head_f, stored_f))
+                have = {k: v for k, v in have.items() if k not in ("Z", "q_mu", "q_sqrt")}
+        head = dict(H=H, W=W, C=C, f=head_f, s=head_s, M=head_M, R=10, white=white, kernel=fl.last_kernel,
+                    variance=float(have.get("variance", 5.0)), q_mu=have.get("q_mu"), q_sqrt=have.get("q_sqrt"))
+        if fl.last_kernel == "rbf":
+            # dense head on the flattened features: one lengthscale per dimension, k-means++ inducing points (models.py:24-27,160-168)
+            flat = images.reshape(images.shape[0], -1)
+            head["ls_ard"] = np.broadcast_to(np.asarray(have.get("ls", 5.0), np.float64), (flat.shape[1],)).copy()
+            head["ls"] = 1.0
+            if "Z" in have:
+                head["Z"] = have["Z"]
+            else:
+                from sklearn import cluster
+                head["Z"] = cluster.KMeans(n_clusters=head_M, init="k-means++", n_init=1).fit(flat).cluster_centers_
+            head["w"] = np.ones(1)
+        else:
+            head["ls"] = float(have.get("ls", 5.0))
+            head["Z"] = have["Z"] if "Z" in have else PatchInducingFeatures.from_images(images, head_M, head_f).Z
+            head["w"] = have.get("w")
+        spec["head"] = head
+        return spec
+
+    # ---- spec -> model -----------------------------------------------------------------------------
     def build(self):
-        Ms = parse_ints(self.flags.M)
-        feature_maps = parse_ints(self.flags.feature_maps)
-        strides = parse_ints(self.flags.strides)
-        filter_sizes = parse_ints(self.flags.filter_sizes)
-        loaded = {}
-        if getattr(self.flags, "load_model", None) is not None:
-            self.global_step, loaded = self._load_layer_parameters(Ms)
-        assert len(strides) == len(filter_sizes)
-        assert len(feature_maps) == (len(Ms) - 1)
-        conv_layers, H_X = self._conv_layers(Ms[0:-1], feature_maps, strides, filter_sizes, loaded)
-        last = self._last_layer(H_X, Ms[-1], filter_sizes[-1], strides[-1], self._last_layer_parameters(loaded))
+        spec = self.spec()
+        layers = build_layers_from_spec(spec)
+        for layer, c in zip(layers, spec["convs"]):
+            if c["q_sqrt_scale"] is not None:
+                layer.q_sqrt = layer.q_sqrt * c["q_sqrt_scale"]
         X = self.X_train.reshape(-1, int(np.prod(self.X_train.shape[1:])))
         return DGP_Base(X, self.Y_train, likelihood=MultiClass(10), num_samples=self.flags.num_samples,
-                        layers=conv_layers + [last], minibatch_size=self.flags.batch_size, name='DGP')
-
-    def _conv_layers(self, Ms, feature_maps, strides, filter_sizes, loaded):
-        H_X, layers = self.X_train, []
-        for i in range(len(feature_maps)):
-            layer, H_X = self._conv_layer(H_X, Ms[i], feature_maps[i], filter_sizes[i], strides[i], loaded.get(i))
-            layers.append(layer)
-        return layers, H_X
-
-    def _conv_layer(self, NHWC_X, M, feature_map, filter_size, stride, layer_params=None):
-        layer_params = layer_params or {}
-        NHWC = NHWC_X.shape
-        view = FullView(input_size=NHWC[1:3], filter_size=filter_size, feature_maps=NHWC[3], stride=stride)
-        conv_mean = 'conv2d' if getattr(self.flags, "identity_mean", False) else None
-        H_X = identity_conv(NHWC_X, filter_size, NHWC[3], feature_map, stride)
-        if len(layer_params) == 0:
-            conv_features = PatchInducingFeatures.from_images(NHWC_X, M, filter_size)
-        else:
-            conv_features = PatchInducingFeatures(layer_params.get('Z'))
-        patch_length = filter_size ** 2 * NHWC[3]
-        if self.flags.base_kernel == 'rbf':
-            base_kernel = RBF(patch_length, variance=float(layer_params.get('base_kernel/variance', 5.0)),
-                              lengthscales=float(layer_params.get('base_kernel/lengthscales', 5.0)))
-        elif self.flags.base_kernel == 'acos':
-            base_kernel = ArcCosine(patch_length, order=0)   # gpflow defaults: variance = weight = bias = 1 (models.py:119)
-        else:
-            raise ValueError("Not a valid base-kernel value")
-        q_mu, q_sqrt = layer_params.get('q_mu'), layer_params.get('q_sqrt')
-        conv_layer = ConvLayer(base_kernel=base_kernel, mean_function=conv_mean, feature=conv_features, view=view,
-                               white=self.flags.white, gp_count=feature_map, q_mu=q_mu, q_sqrt=q_sqrt)
-        if q_sqrt is None:
-            conv_layer.q_sqrt = conv_layer.q_sqrt * 1e-5      # start with low variance (models.py:136-138)
-        return conv_layer, H_X
-
-    def _last_layer(self, H_X, M, filter_size, stride, layer_params=None):
-        layer_params = layer_params or {}
-        NHWC = H_X.shape
-        Z, q_mu, q_sqrt = layer_params.get('Z'), layer_params.get('q_mu'), layer_params.get('q_sqrt')
-        if Z is not None:
-            saved = int(np.sqrt(Z.shape[1] / NHWC[3]))
-            if filter_size != saved:
-                print("filter_size {} != {} for last layer. Resetting parameters.".format(filter_size, saved))
-                Z = q_mu = q_sqrt = None
-        if self.flags.last_kernel == 'rbf':
-            # dense head on the flattened features: RBF with one lengthscale per dimension, k-means inducing points
-            # (conv_gp/models.py:160-168, select_initial_inducing_points :24-27)
-            flat = H_X.reshape(H_X.shape[0], -1)
-            kernel = RBF(flat.shape[1], variance=float(layer_params.get('variance', 5.0)),
-                         lengthscales=layer_params.get('lengthscales', 5.0), ARD=True)
-            Z = layer_params.get('Z')
-            if Z is None:
-                from sklearn import cluster
-                Z = cluster.KMeans(n_clusters=M, init='k-means++', n_init=1).fit(flat).cluster_centers_
-            return SVGP_Layer(kern=kernel, num_outputs=10, feature=InducingPoints(Z), mean_function=None,
-                              white=self.flags.white, q_mu=q_mu, q_sqrt=q_sqrt)
-        variance = float(layer_params.get('base_kernel/variance', 5.0))
-        lengthscales = float(layer_params.get('base_kernel/lengthscales', 5.0))
-        input_dim = filter_size ** 2 * NHWC[3]
-        view = FullView(input_size=NHWC[1:], filter_size=filter_size, feature_maps=NHWC[3], stride=stride)
-        inducing = PatchInducingFeatures.from_images(H_X, M, filter_size) if Z is None else PatchInducingFeatures(Z)
-        patch_weights = layer_params.get('patch_weights')
-        if self.flags.last_kernel == 'conv':
-            kernel = ConvKernel(RBF(input_dim, variance=variance, lengthscales=lengthscales), view, patch_weights)
-        elif self.flags.last_kernel == 'add':
-            kernel = AdditivePatchKernel(RBF(input_dim, variance=variance, lengthscales=lengthscales), view, patch_weights)
-        else:
-            raise ValueError("Invalid last layer kernel")
-        return SVGP_Layer(kern=kernel, num_outputs=10, feature=inducing, mean_function=None,
-                          white=self.flags.white, q_mu=q_mu, q_sqrt=q_sqrt)
-
-    def _load_layer_parameters(self, Ms):
-        parameters = np.load(self.model_path, allow_pickle=True).item()
-        global_step = parameters.pop('global_step')
-        layer_params = {}
-        for key, value in parameters.items():
-            if 'layers' not in key:
-                continue
-            parts = key.split('/')
-            layer, path = int(parts[2]), "/".join(parts[3:])
-            vals = layer_params.setdefault(layer, {})
-            for tag in ('q_mu', 'q_sqrt', 'Z', 'base_kernel/variance', 'base_kernel/lengthscales', 'patch_weights'):
-                if tag in path:
-                    vals[tag] = value
-                    break
-        stored, model_layers = max(layer_params.keys()) + 1, len(Ms)
-        assert stored <= model_layers, "Can't load model if it has more layers than the one being built"
-        if stored != model_layers:
-            layer_params[model_layers - 1] = layer_params.pop(stored - 1)
-        return global_step, layer_params
-
-    def _last_layer_parameters(self, layer_params):
-        keys = list(layer_params.keys())
-        return layer_params[max(keys)] if keys else None
+                        layers=layers, minibatch_size=self.flags.batch_size, name='DGP')

@@ -20,12 +20,15 @@ class MultiOutputConvKernel:
     def Kuf(self, ML_Z, PNL_patches):                            # :23-32  -> P x M x N
         return np.stack([self.base_kernel.K(ML_Z, NL) for NL in PNL_patches])
 
+    def Kff(self, PNL_patches):                                  # :34-41  -> P x N x N
+        return np.stack([self.base_kernel.K(NL) for NL in PNL_patches])
+
     def Kdiag(self, PNL_patches):                                # :43-50  -> P x N
         return np.stack([self.base_kernel.Kdiag(NL) for NL in PNL_patches])
 
 
 class ConvLayer:
-    """conv_gp/layers.py:52-161 (full_cov=False path).  ``feature_Z`` is the M x L inducing patches
+    """conv_gp/layers.py:52-161.  ``feature_Z`` is the M x L inducing patches
     (PatchInducingFeatures.Z, conv_gp/kernels.py:166-170)."""
 
     def __init__(self, base_kernel, mean_function, feature_Z, view, white=False, gp_count=1,
@@ -64,10 +67,13 @@ class ConvLayer:
         PNL = self.view.extract_patches_PNL(NHWC_X)
         Kuu = self.conv_kernel.Kuu(self.Z)
         Kuf = self.conv_kernel.Kuf(self.Z, PNL)
-        Knn = self.conv_kernel.Kdiag(PNL)
+        Knn = self.conv_kernel.Kff(PNL) if full_cov else self.conv_kernel.Kdiag(PNL)      # :114-117
         mean, var = conditional(Kuf, Kuu, Knn, self.q_mu, full_cov=full_cov,
                                 q_sqrt=self.q_sqrt, white=self.white)
-        var = np.transpose(var, [2, 1, 0]).reshape(N, self.num_outputs)      # :128-129
+        if full_cov:
+            var = np.transpose(var, [2, 3, 1, 0]).reshape(N, N, self.num_outputs)    # :122-125
+        else:
+            var = np.transpose(var, [2, 1, 0]).reshape(N, self.num_outputs)      # :128-129
         mean = mean.reshape(N, self.num_outputs)                             # :131
         if self.mean_function is not None:                                   # :133-134
             mean = mean + self.mean_function(self.view.mean_view(NHWC_X, PNL))

@@ -447,6 +447,39 @@ def test_model_builder_from_flags(ctx):
     model.close()
 
 
+def test_reference_format_checkpoint_loads_and_evaluates(ctx):
+    """A checkpoint in the reference's own key set (tests/golden/checkpoint/ref_checkpoint_3layer.npy: the path names of
+    notebooks/Inspect.ipynb cell 6 + global_step) -- not a file this repo wrote -- through ModelBuilder(--load-model): every
+    parameter lands where the file says, the model evaluates to the oracle's ELBO and layer moments for those parameters, and
+    writing it back gives the same key set."""
+    import tempfile
+    from deepcgp_amd.arguments import default_parser
+    from deepcgp_amd.models import ModelBuilder, save_model_parameters
+    here = os.path.join(os.path.dirname(__file__), "golden", "checkpoint")
+    path = os.path.join(here, "ref_checkpoint_3layer.npy")
+    raw = np.load(path, allow_pickle=True).item()
+    d = np.load(os.path.join(here, "ref_checkpoint_3layer_expected.npz"))
+    flags = default_parser().parse_args([str(a) for a in d["flags"]])
+    flags.load_model = "fixture"
+    b = ModelBuilder(flags, np.zeros((int(d["num_data"]), 14, 14, 1)), np.zeros((int(d["num_data"]), 1), np.int64), model_path=path)
+    model = b.build()
+    assert b.global_step == 25000 and [type(l).__name__ for l in model.layers] == ['ConvLayer', 'ConvLayer', 'SVGP_Layer']
+    for p in model.parameters:
+        assert p.pathname in raw, p.pathname
+        np.testing.assert_array_equal(np.asarray(p.value), np.asarray(raw[p.pathname]), err_msg=p.pathname)
+    zs = [d["z%d" % i] for i in range(3)]
+    e, data, kl = model.compute_log_likelihood(d["X"], d["Y"], zs=zs, return_parts=True)
+    assert abs(e - float(d["elbo"])) <= 1e-9 * abs(float(d["elbo"]))
+    assert abs(data - float(d["data_term"])) <= 1e-9 * abs(float(d["data_term"])) and abs(kl - float(d["kl"])) <= 1e-9 * abs(float(d["kl"]))
+    _, Fm, Fv = model.propagate(d["X"], S=2, zs=zs)
+    for i in range(3):
+        assert rel(Fm[i], d["Fmean%d" % i]) < 1e-9 and rel(Fv[i], d["Fvar%d" % i]) < 1e-9, i
+    with tempfile.TemporaryDirectory() as tmp:
+        saved = save_model_parameters(model, os.path.join(tmp, "w.npy"), global_step=b.global_step)
+    assert set(saved) == set(raw)
+    model.close()
+
+
 def test_elbo_acos_base_kernel(ctx):
     """--base-kernel acos (conv_gp/models.py:118-119): ArcCosine(order=0) conv layer + RBF ConvKernel head, whole ELBO and
     layer moments against the oracle.  1e-8: acos() near cos = 1 is ill-conditioned in both implementations."""

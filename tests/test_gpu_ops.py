@@ -179,6 +179,56 @@ def test_conditional_large_M_realistic(ctx, white, M):
     assert np.all(v > -1e-9)
 
 
+@pytest.mark.parametrize("white", [False, True])
+@pytest.mark.parametrize("P,M,N,R", [(3, 7, 4, 2), (5, 40, 9, 10), (2, 130, 33, 3)])
+def test_conditional_full_cov(ctx, white, P, M, N, R):
+    """full_cov=True (conv_gp/conditionals.py:36-38,62-63; the per-patch shapes its comments declare, see
+    deepcgp_amd/conditionals.py): R x P x N x N against the oracle, with and without q_sqrt."""
+    from deepcgp_amd.conditionals import conditional
+    rng = np.random.default_rng(11 * M + P)
+    L = 6
+    Z, q_mu, q_sqrt = rand_spd_inputs(rng, M, R, L)
+    k = ORBF(L, 5.0, 3.0)
+    Kmm = k.K(Z) + JITTER * np.eye(M)
+    Xp = rng.standard_normal((P, N, L))
+    Kmn = np.stack([k.K(Z, Xp[p]) for p in range(P)])
+    Knn = np.stack([k.K(Xp[p]) for p in range(P)])
+    m, v = conditional(Kmn, Kmm, Knn, q_mu, full_cov=True, q_sqrt=q_sqrt + np.triu(rng.standard_normal((R, M, M)), 1), white=white)
+    om, ov = o_conditional(Kmn, Kmm, Knn, q_mu, full_cov=True, q_sqrt=q_sqrt, white=white)
+    close(m, om, 1e-9, "mean")
+    close(v, ov, 1e-9, "var")
+    m2, v2 = conditional(Kmn, Kmm, Knn, q_mu, full_cov=True, q_sqrt=None, white=white)
+    om2, ov2 = o_conditional(Kmn, Kmm, Knn, q_mu, full_cov=True, q_sqrt=None, white=white)
+    close(m2, om2, 1e-9, "mean(no q_sqrt)")
+    close(v2, ov2, 1e-9, "var(no q_sqrt)")
+    with pytest.raises(ValueError):
+        conditional(Kmn, Kmm, Knn[:, :, 0], q_mu, full_cov=True)          # full_cov needs the P x N x N auto-covariance
+
+
+@pytest.mark.parametrize("idmean", [False, True])
+def test_conv_layer_full_cov(ctx, idmean):
+    """ConvLayer.conditional_ND(full_cov=True) (conv_gp/layers.py:114-126): N x N x num_outputs, its diagonal the marginal variance."""
+    from deepcgp_amd.kernels import RBF, PatchInducingFeatures
+    from deepcgp_amd.layers import ConvLayer
+    from deepcgp_amd.views import FullView
+    rng = np.random.default_rng(3)
+    H, W, C, f, s, M, R, N = 9, 7, 2, 3, 2, 11, 3, 5
+    v, ov = FullView((H, W), f, C, s), OFullView((H, W), f, C, s)
+    Z, q_mu, q_sqrt = rand_spd_inputs(rng, M, R, v.patch_length, scale=0.2)
+    X = rng.standard_normal((N, H * W * C))
+    layer = ConvLayer(RBF(v.patch_length, 5.0, 5.0), "conv2d" if idmean else None, PatchInducingFeatures(Z), v, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
+    mean, var = layer.conditional_ND(X, full_cov=True)
+    mean_d, var_d = layer.conditional_ND(X)
+    assert var.shape == (N, N, layer.num_outputs)
+    close(mean, mean_d, 1e-12, "mean")
+    close(np.einsum("nnd->nd", var), var_d, 1e-9, "diagonal of the full covariance")
+    if not idmean:
+        olayer = OConvLayer(ORBF(v.patch_length, 5.0, 5.0), None, Z, ov, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
+        om, ovar = olayer.conditional_ND(X, full_cov=True)
+        close(mean, om, 1e-9, "mean vs oracle")
+        close(var, ovar, 1e-9, "var vs oracle")
+
+
 def test_conditional_errors(ctx):
     from deepcgp_amd.conditionals import conditional
     with pytest.raises(ValueError):

@@ -129,6 +129,76 @@ def test_spawn_ranks_sets_the_rank_environment(tmp_path):
     assert spawn_ranks(2, [str(script), "fail"]) == 3
 
 
+def test_reference_format_checkpoint_fixture_and_loader(tmp_path):
+    """tests/golden/checkpoint/ref_checkpoint_3layer.npy carries exactly the path names a reference-trained 3-layer model prints
+    (notebooks/Inspect.ipynb cell 6) plus 'global_step' (conv_gp/experiment.py:56-64); the table-driven loader files every layer key
+    under the right field, applies the reference's "last stored layer becomes the last model layer" rule and refuses a deeper file."""
+    from golden.checkpoint.make_checkpoint_fixture import INSPECT_CELL6
+    from deepcgp_amd.models import read_checkpoint, CHECKPOINT_FIELDS
+    path = os.path.join(ROOT, "tests", "golden", "checkpoint", "ref_checkpoint_3layer.npy")
+    raw = np.load(path, allow_pickle=True).item()
+    assert set(raw) == set(INSPECT_CELL6) | {"global_step"}
+    step, rec = read_checkpoint(path, 3)
+    assert step == 25000 and sorted(rec) == [0, 1, 2]
+    assert set(rec[0]) == set(rec[1]) == {"Z", "q_mu", "q_sqrt", "variance", "ls"} and set(rec[2]) == {"Z", "q_mu", "q_sqrt", "variance", "ls", "w"}
+    assert rec[0]["Z"].shape == (6, 16) and rec[1]["Z"].shape == (6, 27) and rec[2]["Z"].shape == (6, 18) and rec[2]["w"].shape == (4,)
+    assert rec[0]["q_sqrt"].shape == (3, 6, 6) and rec[1]["q_sqrt"].shape == (2, 6, 6) and rec[2]["q_sqrt"].shape == (10, 6, 6)
+    for i in range(3):
+        kern = "kern" if i == 2 else "conv_kernel"
+        assert rec[i]["variance"] == raw["DGP/layers/%d/%s/base_kernel/variance" % (i, kern)]
+        assert rec[i]["ls"] == raw["DGP/layers/%d/%s/base_kernel/lengthscales" % (i, kern)]
+        np.testing.assert_array_equal(rec[i]["q_mu"], raw["DGP/layers/%d/q_mu" % i])
+    # every key under layers/ is claimed by exactly the first matching row of the table
+    for key in raw:
+        if "/layers/" in key:
+            assert sum(key.endswith(tail) for tail, _ in CHECKPOINT_FIELDS) >= 1, key
+    _, rec4 = read_checkpoint(path, 4)            # a 4-layer model: the stored head parameters go to ITS last layer
+    assert sorted(rec4) == [0, 1, 3] and "w" in rec4[3]
+    with pytest.raises(AssertionError):
+        read_checkpoint(path, 2)
+    # the dense RBF head's keys (--last-kernel rbf): kernel directly under kern/
+    dense = {"DGP/layers/0/kern/variance": np.array(2.0), "DGP/layers/0/kern/lengthscales": np.arange(1.0, 4.0),
+             "DGP/layers/0/feature/Z": np.zeros((2, 3)), "global_step": 7}
+    np.save(tmp_path / "dense.npy", dense)
+    step, rec = read_checkpoint(str(tmp_path / "dense.npy"), 1)
+    assert step == 7 and rec[0]["variance"] == 2.0 and rec[0]["ls"].shape == (3,) and rec[0]["Z"].shape == (2, 3)
+
+
+def test_model_builder_stages_and_patch_draw():
+    """flags -> stage list (conv_gp/arguments.py:27-31 comma lists, the two length invariants of models.py:54-55) and the
+    vectorised patch draw: every row is one contiguous f x f window in FullView's (kh, kw, c) element order."""
+    from deepcgp_amd.arguments import default_parser
+    from deepcgp_amd.models import ModelBuilder, draw_patches
+    fl = default_parser().parse_args(['--name', 't', '-M', '6,7,8', '--feature-maps', '3,2', '--filter-sizes', '4,3,3', '--strides', '2,1,1'])
+    b = ModelBuilder(fl, np.zeros((4, 14, 14, 1)), np.zeros((4, 1)))
+    assert b.stages() == ([(6, 4, 2, 3), (7, 3, 1, 2)], (8, 3, 1))
+    fl.feature_maps = '3'
+    with pytest.raises(AssertionError):
+        b.stages()
+    fl.feature_maps, fl.M = '', '32'                  # the paper's "1-layer": scalar M = head only (results/N60000_M256/options.toml)
+    fl.filter_sizes, fl.strides = '5', '1'
+    assert b.stages() == ([], (32, 5, 1))
+    X = np.arange(3 * 6 * 5 * 2, dtype=np.float64).reshape(3, 6, 5, 2)
+    rows = draw_patches(X, 50, 2, np.random.RandomState(1))
+    assert rows.shape == (50, 8)
+    for r in rows:
+        w = r.reshape(2, 2, 2)
+        assert w[0, 0, 1] - w[0, 0, 0] == 1 and w[0, 1, 0] - w[0, 0, 0] == 2 and w[1, 0, 0] - w[0, 0, 0] == 10
+    assert len({tuple(r) for r in rows}) > 10
+
+
+def test_flat_import_shim():
+    """SURVEY 8(b) Level 1: the reference's modules are imported flat (``from layers import ConvLayer``, conv_gp/models.py:8-11);
+    with deepcgp_amd/flat on sys.path the same statements resolve to this package's classes."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from layers import ConvLayer, MultiOutputConvKernel; from kernels import ConvKernel, PatchInducingFeatures, _sample_patches;"
+            "from views import FullView; from conditionals import conditional; from models import ModelBuilder; from arguments import default_parser;"
+            "import deepcgp_amd.layers as L; assert ConvLayer is L.ConvLayer; print(FullView((28, 28), 5, 1).patch_count)"
+            % (ROOT, os.path.join(ROOT, "deepcgp_amd", "flat")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "576", out.stderr
+
+
 def test_kernel_host_classes_validate_without_a_device():
     """Constructor-level behaviour of the gpflow stand-ins that needs no GPU: parameter validation, ARD expansion,
     the {type, variance, p1, p2} description pushed to the device model, InducingPoints length."""

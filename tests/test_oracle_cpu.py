@@ -313,3 +313,44 @@ def test_arccosine_adjoint_against_finite_differences():
     np.fill_diagonal(dK2, 0.0)
     dZ2, dv2, dw2, db2 = _acos_kuu_backward(k, Z, dK2)
     check(lambda: float(np.sum(dK2 * k.K(Z))), {"Z": dZ2, "variance": dv2, "weight_variances": dw2, "bias_variance": db2}, {"Z": Z})
+
+
+def test_oracle_full_cov_branch_agrees_with_the_marginal_path_and_the_closed_form():
+    """full_cov=True (conv_gp/conditionals.py:36-38,62-63 in the per-patch shapes its comments declare): the diagonal of every
+    N x N block is the full_cov=False variance, every block is symmetric PSD-ish and equals the textbook
+    Knn - Knm Kmm^-1 Kmn + Knm Kmm^-1 S Kmm^-1 Kmn; ConvLayer.conditional_ND lays it out N x N x (P*R)."""
+    from oracle.conditionals import conditional
+    from oracle.gpflow_ref import RBF, JITTER
+    from oracle.layers import ConvLayer
+    from oracle.views import FullView
+    rng = np.random.default_rng(5)
+    P, M, N, R, L = 3, 7, 4, 2, 5
+    Z = rng.standard_normal((M, L))
+    Xp = rng.standard_normal((P, N, L))
+    k = RBF(L, 2.0, 1.5)
+    Kmm = k.K(Z) + JITTER * np.eye(M)
+    Kmn = np.stack([k.K(Z, Xp[p]) for p in range(P)])
+    Knn = np.stack([k.K(Xp[p]) for p in range(P)])
+    f = rng.standard_normal((M, R))
+    q_sqrt = np.tril(rng.standard_normal((R, M, M))) * 0.3 + np.eye(M)[None]
+    for white in (False, True):
+        m_d, v_d = conditional(Kmn, Kmm, np.stack([np.diag(Knn[p]) for p in range(P)]), f, q_sqrt=q_sqrt, white=white)
+        m_f, v_f = conditional(Kmn, Kmm, Knn, f, full_cov=True, q_sqrt=q_sqrt, white=white)
+        assert v_f.shape == (R, P, N, N) and np.allclose(m_f, m_d, rtol=0, atol=1e-13)
+        assert np.allclose(np.einsum("rpnn->rpn", v_f), v_d, rtol=0, atol=1e-12)
+        assert np.allclose(v_f, np.transpose(v_f, (0, 1, 3, 2)), rtol=0, atol=1e-12)
+        if not white:
+            Ki = np.linalg.inv(Kmm)
+            for r in range(R):
+                S = q_sqrt[r] @ q_sqrt[r].T
+                for p in range(P):
+                    want = Knn[p] - Kmn[p].T @ Ki @ Kmn[p] + Kmn[p].T @ Ki @ S @ Ki @ Kmn[p]
+                    assert np.allclose(v_f[r, p], want, rtol=0, atol=1e-10)
+    view = FullView((6, 6), 3, 2, 1)
+    layer = ConvLayer(RBF(view.patch_length, 2.0, 3.0), None, rng.standard_normal((5, view.patch_length)), view, gp_count=3,
+                      q_mu=rng.standard_normal((5, 3)), q_sqrt=np.tril(rng.standard_normal((3, 5, 5))) * 0.2 + np.eye(5)[None])
+    X = rng.standard_normal((4, 72))
+    m1, v1 = layer.conditional_ND(X)
+    m2, v2 = layer.conditional_ND(X, full_cov=True)
+    assert v2.shape == (4, 4, layer.num_outputs) and np.allclose(m1, m2)
+    assert np.allclose(np.einsum("nnd->nd", v2), v1, rtol=0, atol=1e-12)
