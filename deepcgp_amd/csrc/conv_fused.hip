@@ -530,11 +530,19 @@ bool plan_fused(const ConvFusedArgs& a, FusedPlan* p) {
   // M > 256: the 32- / 16-column strips LDS leaves room for re-fetch the A operands 2 - 4 x as often per MFMA and measure
   // 2 % (M = 384) to 16 % (M = 1024) behind the sweep + 128 x 128-tile GEMM route (87 % of the MFMA peak there); opt-in
   if (nf > 16 && force < 0 && !getenv("DCGP_FUSED_LARGE")) return false;
+  // Among the shapes that fit, the one whose busiest CU carries the fewest columns: workgroups go round the 256 CUs, a CU works
+  // through ceil(strips / 256) strips of BN columns at a rate that does not depend on BN (narrow strips share the CU), so few
+  // columns -- a shard of a strongly-scaled batch -- are better cut into narrower strips (4 images x 10 samples x 144 patches:
+  // 90 strips of 64 keep 90 CUs busy for a full strip time, 180 strips of 32 keep 180 busy for half of it).  The wider strip
+  // wins ties: fewer A-operand fetches per MFMA (measured 3 % / 6 % behind at 32 / 16 columns on the full batch).
+  double best = 0.0;
+  bool found = false;
   for (int i = 0; i < kNumShapes; ++i) {
     const FusedShape& sh = kShapes[i];
     if (force >= 0 && i != force) continue;
     if (nf > sh.max_nf) continue;
     if (sh.max_nf > 16 && nf <= 16 && force < 0) continue;   // the many-wave shapes are for the large matrices
+    if (i == 1 && force < 0) continue;                        // (the 8-wave form of shape 0: A/B experiments only)
     const int BN = sh.FN * 16, W = sh.NT / 64, TW = W / sh.NS, KG = W / sh.FN;
     const int nimg = (BN - 1) / a.P + 2;           // images a strip can touch
     const long fin = (long)(TW * a.R + KG * 16) * BN;
@@ -543,10 +551,13 @@ bool plan_fused(const ConvFusedArgs& a, FusedPlan* p) {
     if (img_d < (long)TW * BN) img_d = (long)TW * BN;
     const long bytes = (main_d + img_d + BN) * 8 + (long)a.Lp * 4;
     if (bytes > 160 * 1024) continue;
+    const long strips = a.Kc > 0 ? ((long)a.Kc + BN - 1) / BN : 1;
+    const double cost = (double)((strips + 255) / 256) * BN * (sh.FN == 4 ? 1.0 : (sh.FN == 2 ? 1.03 : 1.06));
+    if (found && cost >= best) continue;
+    found = true; best = cost;
     p->shape = i; p->lds = (size_t)bytes; p->lds_main = (int)main_d; p->lds_img = (int)img_d;
-    return true;
   }
-  return false;
+  return found;
 }
 
 }  // namespace

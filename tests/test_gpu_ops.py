@@ -130,6 +130,23 @@ def test_kuf(ctx, H, W, C, f, s, M):
         close(mok.Kuf(Z, ov.extract_patches_PNL(X)), ref, 1e-12, "Kuf from PNL patches")
 
 
+def test_sweep_exp_is_accurate_to_an_ulp_over_its_whole_range(ctx):
+    """The sweeps' exp (table form, csrc/common.h exp_sweep_n) element by element: exp(-v^2 / 2) for arguments from 0 down
+    through the subnormal range and past underflow -- relative error of a few ulp, exact zeros where double precision underflows."""
+    from deepcgp_amd.kernels import RBF
+    from deepcgp_amd.layers import MultiOutputConvKernel
+    rng = np.random.default_rng(0)
+    arg = -np.concatenate([[0.0, 1e-300, 1e-12, 0.5 * np.log(2) / 64, 700.0, 708.3, 745.0, 746.5, 800.0], rng.random(4000) * 745.0,
+                           rng.random(1000) * 1e-3])
+    v = np.sqrt(-2.0 * arg)
+    Kuf = MultiOutputConvKernel(RBF(1, 1.0, 1.0), 1, 1).Kuf(np.zeros((1, 1)), v.reshape(1, -1, 1))[0, 0]
+    want = np.exp(-0.5 * v * v)
+    normal = want > 1e-300
+    assert np.max(np.abs(Kuf[normal] / want[normal] - 1.0)) < 8e-16 * 2.5
+    assert np.all(np.abs(Kuf[~normal] - want[~normal]) <= 1e-307) and Kuf[arg < -746.0].max() == 0.0
+    assert Kuf[0] == 1.0
+
+
 @pytest.mark.parametrize("white", [False, True])
 @pytest.mark.parametrize("P,M,N,R", [(3, 4, 5, 2), (6, 16, 5, 3), (2, 37, 130, 10), (4, 128, 40, 10), (1, 256, 64, 10),
                                      (16, 264, 144, 10)])   # Mp = 272: 128-row tiles overhang the matrix (zero-filled by the buffer bounds check)

@@ -116,6 +116,18 @@ def test_two_rank_hostgroup_elbo(tmp_path):
         assert len(set(vals)) == 1 and all("OK" in o for o in outs)
 
 
+def test_hostgroup_under_an_external_launcher():
+    """The driver starts multi-GPU runs with `python -m torch.distributed.run ... bench.py --gpus N`: the launcher owns MASTER_PORT,
+    so the host group meets through a file named after the launcher's pid + port and an ephemeral port of its own."""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
+    env.pop("DCGP_RDZV_FILE", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29733", os.path.join(ROOT, "tests", "hostgroup_worker.py")],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("OK rank") == 2
+
+
 def test_spawn_ranks_sets_the_rank_environment(tmp_path):
     """spawn_ranks: one child per rank with RANK / LOCAL_RANK / WORLD_SIZE and a shared rendezvous file; worst exit code."""
     from deepcgp_amd.dist import spawn_ranks

@@ -1,0 +1,34 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/collect_profiles.sh <tag>   -- every profile / bench artefact of a round into gpurun_out/<tag>_*
+# (copy what is to be judged into profiles/ afterwards)
+T=$1
+R=$PWD; export TMPDIR=/tmp; mkdir -p gpurun_out
+# 1. the judged bench line (N = 1) and the same under rocprofv3 (per-kernel stats must agree with the in-bench HIP events)
+timeout 600 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
+tools/prof_bench.sh ${T} --steps 20 --warmup 5 > gpurun_out/${T}_profiled_run_summary.txt 2>&1
+DB=$(find gpurun_out/prof_${T} -name '*.db' | head -1)
+python tools/rocpd_timeline.py $DB -4 > gpurun_out/${T}_step_timeline.txt
+# 2. steps kept in flight
+tools/prof_pipe.sh ${T} cfg2_mnist_CH_M256 40 2 > /dev/null 2>&1
+DB=$(find gpurun_out/pipe_${T} -name '*.db' | head -1)
+python tools/rocpd_timeline.py $DB -4 1700 > gpurun_out/${T}_two_in_flight_timeline.txt
+tail -1 gpurun_out/pipe_${T}.log >> gpurun_out/${T}_two_in_flight_timeline.txt
+# 3. phases inside the one-launch layer kernel
+python tools/fused_trace.py cfg2_mnist_CH_M256 > gpurun_out/${T}_fused_phase_trace.txt 2>&1
+# 4. counters, one set per pass
+tools/pmc_bench.sh ${T}a "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 2 --warmup 1 > gpurun_out/${T}_pmc_sq.txt 2>&1
+tools/pmc_bench.sh ${T}b "FETCH_SIZE" --steps 2 --warmup 1 > gpurun_out/${T}_pmc_fetch.txt 2>&1
+tools/pmc_bench.sh ${T}c "WRITE_SIZE" --steps 2 --warmup 1 > gpurun_out/${T}_pmc_write.txt 2>&1
+for c in cfg4_cifar_3layer_M384 cfg5_mnist_CH_M1024; do
+  tools/pmc_bench.sh ${T}f_$c "FETCH_SIZE" --steps 2 --warmup 1 --config $c > gpurun_out/${T}_pmc_fetch_$c.txt 2>&1
+  tools/pmc_bench.sh ${T}w_$c "WRITE_SIZE" --steps 2 --warmup 1 --config $c > gpurun_out/${T}_pmc_write_$c.txt 2>&1
+  tools/pmc_bench.sh ${T}s_$c "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 2 --warmup 1 --config $c > gpurun_out/${T}_pmc_sq_$c.txt 2>&1
+done
+# 5. the other BASELINE configurations
+for c in cfg1_mnist_H_M32 cfg2_mnist_H_M256 cfg3_mnist_3layer_M256 cfg4_cifar_3layer_M384 cfg5_mnist_H_M1024 cfg5_mnist_CH_M1024; do
+  timeout 300 python bench.py --config $c --steps 30 --no-cpu-baseline --no-grad-leg --no-extra-legs > gpurun_out/${T}_bench_$c.json 2> gpurun_out/${T}_bench_$c.err
+done
+# 6. two ranks on this one GPU: self-launched and under the driver's launcher (RCCL refuses two ranks on one device -> host join)
+timeout 300 python bench.py --gpus 2 --steps 50 --no-cpu-baseline > gpurun_out/${T}_bench_2ranks_selflaunch.json 2> gpurun_out/${T}_bench_2ranks_selflaunch.err
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 50 --no-cpu-baseline > gpurun_out/${T}_bench_2ranks_torchrun.json 2> gpurun_out/${T}_bench_2ranks_torchrun.err
+echo collected
