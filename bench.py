@@ -177,13 +177,16 @@ def head_only_leg(ctx, grp, S, steps):
     P, L, _ = conv_geometry(h, 1)
     rows = 32 * S
     flops = float(rows) * P * P * (2 * L + 4)
-    us = 1e3 * tim["head_kdiag"][1] / max(tim["head_kdiag"][0], 1)
+    # Kzx and Kdiag share one launch (head_sweep_kernel): its flops = N' P^2 (2L+4) [Kdiag, full count; the kernel evaluates the
+    # upper triangle of tile pairs only] + N' P M (2L+4) [Kzx]
+    flops += float(rows) * P * h["M"] * (2 * L + 4)
+    us = 1e3 * tim["head_sweep"][1] / max(tim["head_sweep"][0], 1)
     ach = flops / (us * 1e-6) / 1e12
     out = {"head_only_steps_per_s": steps / dt, "head_only_ms_per_step": 1e3 * dt / steps,
-           "roofline_head": {"kernel": "head_kdiag_kernel (ConvKernel.Kdiag, all patch pairs of an image; upper-triangular tile pairs only)",
+           "roofline_head": {"kernel": "head_sweep_kernel (ConvKernel.Kzx: weighted patch sum reduced in-kernel, + ConvKernel.Kdiag: all patch pairs of an image, in one launch)",
                              "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                              "traffic": None, "algorithmic_flops_per_launch": flops, "avg_us": us,
-                             "note": "full-count N'*P^2*(2L+4) (SURVEY 8(d)); the kernel evaluates the upper triangle of tile pairs only"},
+                             "note": "N'*P^2*(2L+4) + N'*P*M*(2L+4) (SURVEY 8(d)); the Kdiag part evaluates the upper triangle of tile pairs only"},
            "head_only_kernel_times_us": {k: round(1e3 * v[1] / max(v[0], 1), 2) for k, v in sorted(tim.items())}}
     leg.model.close()
     return out

@@ -146,61 +146,6 @@ __device__ __forceinline__ double exp_sweep(double x) {
   return x < -746.0 ? 0.0 : ldexp(p, (int)kf);
 }
 
-// 2^(j/64), j = 0 .. 63 (correctly rounded)
-__device__ static const double kExp2Tab64[64] = {
-    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
-    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
-    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
-    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
-    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
-    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
-    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
-    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
-    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
-    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
-    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
-    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
-    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
-    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
-    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
-    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
-};
-// N exps at once, for the sweep epilogues, where the double-precision VALU work of the exps competes with the MFMAs for the
-// same pipe (the sweeps measured ~25 DP instructions per value with the degree-13 polynomial of exp_sweep above).  Table form:
-// x = (64 k + j) ln2/64 + r, |r| <= ln2/128, exp(x) = 2^k * T[j] * (1 + r + r^2/2 + ... + r^5/120): remainder r^6/720 < 4e-17,
-// 13 DP instructions and one 8-byte table load per value (the 512-byte table stays in the vector L1); every step is issued for
-// all N values before the next one, so that the dependent chain of one value hides behind the others'.
-template <int N>
-__device__ __forceinline__ void exp_sweep_n(double (&x)[N]) {
-  double kf[N], r[N], p[N], t[N];
-  int n[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    kf[i] = rint(x[i] * 92.33248261689366);        // 64 / ln 2
-    n[i] = (int)kf[i];
-    r[i] = fma(-kf[i], 0.01083042469326756, x[i]);     // Cody-Waite: ln 2 / 64 in two pieces (the first with 21 trailing zero bits)
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    t[i] = kExp2Tab64[n[i] & 63];
-    r[i] = fma(-kf[i], 2.9815858269852933e-12, r[i]);
-    p[i] = 8.3333333333333332e-03;                        // 1/120
-  }
-#define DCGP_EXP_STEP_N(c)      \
-  _Pragma("unroll") for (int i = 0; i < N; ++i) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p[i]) : "v"(p[i]), "v"(r[i]), "s"((double)(c)))
-  DCGP_EXP_STEP_N(4.1666666666666664e-02);    // 1/24
-  DCGP_EXP_STEP_N(1.6666666666666666e-01);    // 1/6
-  DCGP_EXP_STEP_N(0.5);
-  DCGP_EXP_STEP_N(1.0);
-#undef DCGP_EXP_STEP_N
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    p[i] = p[i] * r[i];                                   // r + r^2/2 + ... + r^5/120
-    const double e = fma(t[i], p[i], t[i]);
-    x[i] = x[i] < -746.0 ? 0.0 : ldexp(e, n[i] >> 6);     // gradual underflow below ~-708; the guard covers -inf (r would be NaN)
-  }
-}
-
 // The base kernel of a layer, evaluated from (x.z, |x|^2, |z|^2):
 //   type 0  gpflow RBF:           variance * exp(-(|x|^2 + |z|^2 - 2 x.z) / (2 l^2))     p1 = 1 / l^2 (square_dist form, no clamp)
 //   type 1  gpflow ArcCosine(0):  variance * (pi - theta) / pi,  theta = acos(1e-15 + (1 - 2e-15) cos),
@@ -217,19 +162,15 @@ struct BaseKernel {
     // and overshoot the reference's 1e-15 guard -- acos() would return NaN there, as the reference formula does
     return variance * (1.0 - acos(fmin(1e-15 + (1.0 - 2e-15) * c, 1.0)) * 0.31830988618379067154);
   }
-  // N values at once (io: x.z in, kernel value out): the RBF's exps interleaved (exp_sweep_n); bit-identical to eval_as
+  // N values (io: x.z in, kernel value out).  Tried for the RBF and measured no better or worse than this plain loop
+  // (A/B builds, 1 x MI355X): the N exps with every Horner step issued for all of them before the next one (the dependent
+  // chains hide behind each other anyway: the sweeps run four waves per SIMD) -- equal; a 64-entry table of 2^(j/64) with a
+  // degree-5 polynomial (13 instead of ~25 double-precision operations per value) -- equal on the conv layer + head model,
+  // 20 % SLOWER on the head-only model (1664 vs 2105 steps/s: 100 M per-lane table loads per step through the vector L1).
   template <int T, int N>
   __device__ __forceinline__ void eval_n(double (&io)[N], const double (&n1)[N], const double (&n2)[N]) const {
-    if (T == 0) {
 #pragma unroll
-      for (int i = 0; i < N; ++i) io[i] = -0.5 * (n1[i] + n2[i] - 2.0 * io[i]) * p1;
-      exp_sweep_n<N>(io);
-#pragma unroll
-      for (int i = 0; i < N; ++i) io[i] *= variance;
-    } else {
-#pragma unroll
-      for (int i = 0; i < N; ++i) io[i] = eval_as<1>(io[i], n1[i], n2[i]);
-    }
+    for (int i = 0; i < N; ++i) io[i] = eval_as<T>(io[i], n1[i], n2[i]);
   }
   __device__ __forceinline__ double eval(double dot, double n1, double n2) const {
     return type == 0 ? eval_as<0>(dot, n1, n2) : eval_as<1>(dot, n1, n2);

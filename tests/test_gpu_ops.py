@@ -131,7 +131,7 @@ def test_kuf(ctx, H, W, C, f, s, M):
 
 
 def test_sweep_exp_is_accurate_to_an_ulp_over_its_whole_range(ctx):
-    """The sweeps' exp (table form, csrc/common.h exp_sweep_n) element by element: exp(-v^2 / 2) for arguments from 0 down
+    """The sweeps' exp (csrc/common.h exp_sweep) element by element: exp(-v^2 / 2) for arguments from 0 down
     through the subnormal range and past underflow -- relative error of a few ulp, exact zeros where double precision underflows."""
     from deepcgp_amd.kernels import RBF
     from deepcgp_amd.layers import MultiOutputConvKernel
