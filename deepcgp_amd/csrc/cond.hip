@@ -11,6 +11,7 @@
 // conv_gp/layers.py:128-131 and the sample mean + z*sqrt(var + jitter).  (A few-column problem -- the head -- takes
 // the one-launch route of head_cond.hip instead.)
 #include "layer_impl.h"
+#include "tail_dev.h"
 #include "rng.h"
 
 namespace {
@@ -144,72 +145,25 @@ __global__ __launch_bounds__(256) void varexp_kernel(const double* __restrict__ 
 // ---- the ELBO tail in one launch: RobustMax expectations of every row (as varexp_kernel), their sum by the LAST block to
 // arrive (fixed order: reproducible), and -- with fin.nl > 0 -- the assembly  data * scale - sum_l KL_l  with the status words of
 // the factorisations.  Three dependent launches and their gaps otherwise, at the very end of the step where nothing hides them.
-__global__ __launch_bounds__(256) void elbo_tail_kernel(const double* __restrict__ mu, const double* __restrict__ var,
-                                                        const int32_t* __restrict__ y, int n_rows, int n_labels, int K, double eps,
-                                                        const double* __restrict__ gh, double* __restrict__ ve, double inv_s,
-                                                        unsigned* __restrict__ ticket, double* __restrict__ scal, ElboFinish fin) {
+__global__ __launch_bounds__(256) void elbo_tail_kernel(TailArgs t) {
   __shared__ double red[256];
   __shared__ unsigned last;
   const int tid = threadIdx.x, g = tid & 31;
   const int row = blockIdx.x * 8 + (tid >> 5);
-  const bool live = row < n_rows;
-  double contrib = 0.0;
-  if (live && g < 20) {
-    const int yi = y[row % n_labels];
-    const double* m = mu + (long)row * K;
-    const double* v = var + (long)row * K;
-    double t = m[yi] + gh[g] * sqrt(fmax(2.0 * v[yi], 1e-10));
-    double prod = 1.0;
-    for (int k = 0; k < K; ++k) {
-      if (k == yi) continue;
-      double dist = (t - m[k]) / sqrt(fmax(v[k], 1e-10));
-      double cdf = 0.5 * (1.0 + erf(dist * 0.70710678118654752440));
-      prod *= cdf * (1.0 - 2e-4) + 1e-4;
-    }
-    contrib = prod * gh[20 + g] * 0.56418958354775628695;   // w / sqrt(pi)
-  }
+  const bool live = row < t.n_rows;
+  double contrib = live ? robustmax_node(t.mu + (long)row * t.K, t.var + (long)row * t.K, t.y[row % t.n_labels], t.K, t.gh, g) : 0.0;
   for (int o = 1; o < 32; o <<= 1) contrib += __shfl_xor(contrib, o);
-  if (live && g == 0) ve[row] = contrib * log(1.0 - eps) + (1.0 - contrib) * log(eps / (K - 1.0));
-  // publish this block's rows, take a ticket (agent scope: the blocks sit on different XCDs, whose L2s are not coherent)
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  if (!last) return;
+  if (live && g == 0) t.ve[row] = robustmax_logp(contrib, t.eps, t.K);
+  if (!last_to_arrive(t.ticket, gridDim.x, &last)) return;
   double s = 0.0;
-  for (int i = tid; i < n_rows; i += 256) s += __hip_atomic_load(ve + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = tid; i < t.n_rows; i += 256) s += __hip_atomic_load(t.ve + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   red[tid] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (tid < o) red[tid] += red[tid + o];
     __syncthreads();
   }
-  if (tid == 0) {
-    const double data = red[0] * inv_s;
-    scal[0] = data;
-    *ticket = 0u;   // the next launch on this stream starts from zero
-    if (fin.nl > 0) {
-      double kl = 0.0;
-      for (int l = 0; l < fin.nl; ++l) {
-        const double* k4 = scal + 4 + 4 * l;
-        double two = k4[0] - (double)fin.M[l] * fin.R[l] - k4[1] + k4[3];
-        if (!fin.white[l]) two += (double)fin.R[l] * k4[2];
-        kl += 0.5 * two;
-      }
-      int bad = 0;   // first non-positive pivot of any factorisation: rides back with the result (one D2H, one sync)
-      for (int q = 0; q < fin.ngroups; ++q)
-        for (int i = 0; i < fin.ninfo[q]; ++i)
-          if (fin.info[q][i] && !bad) bad = fin.info[q][i];
-      scal[40] = data * fin.scale - kl;
-      scal[41] = data;
-      scal[42] = kl;
-      scal[43] = (double)bad;
-    }
-  }
+  if (tid == 0) elbo_assemble(t, red[0] * t.inv_s);
 }
 
 __global__ __launch_bounds__(1024) void reduce_sum_kernel(const double* __restrict__ in, long n, double scale,
@@ -300,10 +254,10 @@ const double* gauss_hermite_table(dcgp_ctx* ctx) {
   return d;
 }
 
-int elbo_tail(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t* y, int n_rows, int n_labels, int K, double eps,
-              double* ve_rows, double inv_s, double* scal, const ElboFinish& fin) {
-  const double* gh = gauss_hermite_table(ctx);
-  if (!gh) return DCGP_ERR_ALLOC;
+// everything of a TailArgs that does not depend on the rows: Gauss-Hermite table, arrival counters
+int elbo_tail_prepare(dcgp_ctx* ctx, TailArgs* t) {
+  t->gh = gauss_hermite_table(ctx);
+  if (!t->gh) return DCGP_ERR_ALLOC;
   auto it = ctx->ws.find("elbo_ticket");
   unsigned* ticket = it != ctx->ws.end() ? (unsigned*)it->second.first : nullptr;
   if (!ticket) {
@@ -311,9 +265,18 @@ int elbo_tail(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t*
     if (!ticket) return DCGP_ERR_ALLOC;
     HIP_TRY(ctx, hipMemsetAsync(ticket, 0, 256, ctx->stream));   // (a poisoned workspace must not leave a wrong count)
   }
-  ScopedTimer t(ctx, "elbo_tail");
-  hipLaunchKernelGGL(elbo_tail_kernel, dim3((unsigned)((n_rows + 7) / 8)), dim3(256), 0, ctx->stream, mu, var, y, n_rows, n_labels, K,
-                     eps, gh, ve_rows, inv_s, ticket, scal, fin);
+  t->ticket = ticket;
+  return DCGP_OK;
+}
+
+int elbo_tail(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t* y, int n_rows, int n_labels, int K, double eps,
+              double* ve_rows, double inv_s, double* scal, const ElboFinish& fin) {
+  TailArgs t;
+  DCGP_TRY(elbo_tail_prepare(ctx, &t));
+  t.mu = mu; t.var = var; t.y = y; t.n_rows = n_rows; t.n_labels = n_labels; t.K = K; t.eps = eps; t.ve = ve_rows;
+  t.inv_s = inv_s; t.scal = scal; t.fin = fin;
+  ScopedTimer tm(ctx, "elbo_tail");
+  hipLaunchKernelGGL(elbo_tail_kernel, dim3((unsigned)((n_rows + 7) / 8)), dim3(256), 0, ctx->stream, t);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }
@@ -431,7 +394,12 @@ int kl_layer(dcgp_ctx* ctx, const GpMats& g, const double* Lp, const double* Lpi
   const int Mp = g.Mp, R = g.R;
   double *tp = nullptr, *ap = nullptr;
   long tp_count = 0, ap_count = 0;
-  if (!white) {
+  if (!white && g.klp && g.klp_valid && LpinvT == g.LinvT) {
+    // the prior factor is L: prep_solve left the sums of squares of G_r = inv(L) Lq_r and alpha = inv(L) q_mu
+    const int ns = Mp / 16;
+    tp = g.klp; tp_count = (long)R * ns;
+    ap = g.klp + (long)R * ns; ap_count = 1;
+  } else if (!white) {
     const int BM = gemm_row_block(Mp, Mp, R), nrb = (Mp + BM - 1) / BM;
     const int BMa = gemm_row_block(Mp, g.Rp, 1), nrba = (Mp + BMa - 1) / BMa;
     tp_count = (long)R * nrb * Mp;

@@ -164,13 +164,14 @@ __global__ __launch_bounds__(1024, 4) void head_cond_kernel(HeadCondArgs a) {
 // y < R: strip x of Lq_r (lower triangular: k-tiles above the strip are structurally zero and skipped),
 // y == R: q_mu (x == 0 only).  The generic route was two latency-bound GEMM launches per layer (17 + 31 us at cfg2).
 struct PrepSolveLayer {
-  const double* LinvT; const double* Lq; const double* qmu; double* G; double* alpha;
+  const double* LinvT; const double* Lq; const double* qmu; double* G; double* alpha; double* klp;
   int Mp, R, Rp, active;   // active == 0: whitened layer (G / alpha alias Lq / q_mu) or larger than HC_MP
 };
 struct PrepSolveArgs { PrepSolveLayer l[8]; };
 
 __global__ __launch_bounds__(1024, 4) void prep_solve_kernel(PrepSolveArgs args) {
   __shared__ __attribute__((aligned(16))) double Bt[HC_MP * HC_BN];   // [k][16]
+  __shared__ double ssq[16];
   const PrepSolveLayer& a = args.l[blockIdx.z];
   if (!a.active) return;
   const int Mp = a.Mp;
@@ -234,6 +235,20 @@ __global__ __launch_bounds__(1024, 4) void prep_solve_kernel(PrepSolveArgs args)
 #pragma unroll
     for (int v = 0; v < 4; ++v) C[(long)(i0 + lrow + 4 * v) * ldb + c0 + lcol] = acc[v];
   }
+  // sum of squares of the strip just produced, in a fixed order: ||G_r||_F^2 and ||alpha||^2 are the KL's trace and
+  // Mahalanobis terms where the KL prior is K itself (the head) -- its two latency-bound GEMMs recomputed exactly these
+  if (a.klp) {
+    double s = (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    if (lane == 0) ssq[wave] = s;   // waves beyond Mp hold zeros
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < 16; ++w) t += ssq[w];
+      a.klp[(long)y * (Mp / HC_BN) + strip] = t;
+    }
+  }
 }
 
 }  // namespace
@@ -267,6 +282,8 @@ int prep_solve_all(dcgp_ctx* ctx, GpMats* const* gs, const int* white, const boo
     l.active = (!white[i] && head_cond_fused_ok(g) && g.Rp == HC_BN) ? 1 : 0;
     done[i] = l.active != 0;
     l.LinvT = g.LinvT; l.Lq = have_qsqrt[i] ? g.Lq : nullptr; l.qmu = g.qmu; l.G = g.G; l.alpha = g.alpha;
+    l.klp = (l.active && have_qsqrt[i]) ? g.klp : nullptr;
+    gs[i]->klp_valid = l.klp != nullptr;
     l.Mp = g.Mp; l.R = g.R; l.Rp = g.Rp;
     if (l.active) { any = 1; maxMp = g.Mp > maxMp ? g.Mp : maxMp; maxR = g.R > maxR ? g.R : maxR; }
   }

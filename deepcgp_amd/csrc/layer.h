@@ -25,6 +25,9 @@ struct GpMats {
   // derived by cond_prep after the factorisation (alias Lq / qmu in the whitened case):
   double* G = nullptr;      // [R][Mp][Mp]  G_r = inv(L) Lq_r   (lower triangular)
   double* alpha = nullptr;  // [Mp][Rp]     alpha = inv(L) q_mu
+  double* klp = nullptr;    // [(R + 1)][Mp / 16] sums of squares of the 16-column strips of G_r and (row R, entry 0) of alpha,
+                            // left by prep_solve: the KL's trace and Mahalanobis terms when its prior factor is L itself
+  bool klp_valid = false;   // set by prep_solve_all for the launch that filled klp
 };
 
 // parameter-only preparation of all layers in one launch (prep.hip)
@@ -114,9 +117,13 @@ struct ElboFinish {
   const int* info[16];   // per factor group: potrf status words (0 or the 1-based failing column)
   int ninfo[16];
   int ngroups = 0;
+  double* host_out = nullptr;   // pinned host slot (device-visible address): the four result words are also written there,
+                                // so no copy command follows the launch
 };
 // RobustMax expectations of every row -> ve_rows, scal[0] = inv_s * their sum, and (fin.nl > 0) scal[40..43] = ELBO, data term,
 // KL, potrf status from the KL pieces at scal[4 + 4 l ..]: one launch (cond.hip)
+struct TailArgs;   // tail_dev.h
+int elbo_tail_prepare(dcgp_ctx* ctx, TailArgs* t);   // Gauss-Hermite table and arrival counters of a TailArgs
 int elbo_tail(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t* y, int n_rows, int n_labels, int K, double eps,
               double* ve_rows, double inv_s, double* scal, const ElboFinish& fin);
 int varexp_rows(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t* y, int n_rows, int n_labels, int K,

@@ -95,7 +95,7 @@ struct LayerState {
     q.Lq = dalloc((size_t)R * mm);
     q.qmu = dalloc((size_t)Mp * q.Rp);
     if (white) { q.G = q.Lq; q.alpha = q.qmu; }
-    else { q.G = dalloc((size_t)R * mm); q.alpha = dalloc((size_t)Mp * q.Rp); }
+    else { q.G = dalloc((size_t)R * mm); q.alpha = dalloc((size_t)Mp * q.Rp); q.klp = dalloc((size_t)(R + 1) * (Mp / 16 + 1)); }
     ZTb[b] = dalloc((size_t)Lp * Mp);
     znb[b] = dalloc(Mp);
   }

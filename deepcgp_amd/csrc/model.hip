@@ -14,6 +14,7 @@
 #include <memory>
 
 #include "model_state.h"
+#include "tail_dev.h"
 #include <chrono>
 
 
@@ -91,6 +92,7 @@ struct CombineArgs {
   const int* info[16];   // per factor group: potrf status words (0 or the 1-based failing column)
   int ninfo[16];
   int ngroups;
+  double* host_out;   // pinned host slot (device-visible address) or nullptr
 };
 __global__ void combine_kernel(const double* __restrict__ scal_in, double* __restrict__ out, CombineArgs c) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -110,6 +112,10 @@ __global__ void combine_kernel(const double* __restrict__ scal_in, double* __res
     for (int i = 0; i < c.ninfo[g]; ++i)
       if (c.info[g][i] && !bad) bad = c.info[g][i];
   out[3] = (double)bad;
+  if (c.host_out) {
+    for (int i = 0; i < 4; ++i) __hip_atomic_store(c.host_out + i, out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  }
 }
 
 int read_info(dcgp_model* m, int* info_host) {
@@ -275,14 +281,19 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   if (chain_s != main_s && !first_fused) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_sweep[bank], 0));
   const double* F = X;
   int rows = rows0, n_mod = N;
+  // Join the side stream where the wait is already satisfied when the main stream gets to it: in front of the last layer when
+  // other layers precede it (the KL terms finish beside the first of them), behind it otherwise.  In front of the tail kernel
+  // the wait packet sat between two short launches at the very end of the step (6 us).
+  const bool join_early = nl > 1;
   for (int li = 0; li < nl; ++li) {
     int out_rows = 0;
+    if (li == nl - 1 && join_early && kl_s != main_s) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_kl[bank], 0));
     DCGP_TRY(layer_step(li, F, rows, n_mod, &out_rows));
     if (!m->layers[li]->is_head) F = m->outs[li].sample;
     rows = out_rows;
     n_mod = rows;
   }
-  if (kl_s != main_s) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_kl[bank], 0));   // join the side stream
+  if (!join_early && kl_s != main_s) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_kl[bank], 0));   // join the side stream
   *rows_last = rows;
   return DCGP_OK;
 }
@@ -446,6 +457,16 @@ int dcgp_elbo_forward_collect(dcgp_model* model, uint64_t ticket, double* out_ho
 
 }  // extern "C"
 
+// what the assembly at the end of a step needs: layer shapes, the status words of the factor groups, the pinned result slot
+static void fill_finish(dcgp_model* model, std::vector<FactorGroup>& groups, double scale, int slot, ElboFinish* fin) {
+  const int nl = (int)model->layers.size();
+  fin->nl = nl; fin->scale = scale;
+  for (int l = 0; l < nl; ++l) { fin->M[l] = model->layers[l]->M; fin->R[l] = model->layers[l]->R; fin->white[l] = model->layers[l]->white; }
+  fin->ngroups = (int)groups.size();
+  for (int g = 0; g < fin->ngroups && g < 16; ++g) { fin->info[g] = groups[g].d_info; fin->ninfo[g] = (int)groups[g].K.size(); }
+  fin->host_out = model->h_ring_dev + 4 * slot;   // the last kernel of the step writes the result words into the pinned slot itself
+}
+
 int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
                               const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, uint64_t* ticket,
                               bool pipelined) {
@@ -454,7 +475,8 @@ int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t*
   if (model->enq_seq - model->col_seq >= (uint64_t)dcgp_model::RING)
     return ctx_fail(ctx, DCGP_ERR_ARG, "elbo_forward_enqueue: %d steps in flight, collect the oldest first", dcgp_model::RING);
   if (!model->h_ring) {
-    if (hipHostMalloc((void**)&model->h_ring, dcgp_model::RING * 4 * sizeof(double)) != hipSuccess)
+    if (hipHostMalloc((void**)&model->h_ring, dcgp_model::RING * 4 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&model->h_ring_dev, model->h_ring, 0) != hipSuccess)
       return ctx_fail(ctx, DCGP_ERR_ALLOC, "elbo_forward: pinned result slots");
     for (auto& e : model->ring_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
@@ -462,21 +484,19 @@ int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t*
   const int S = model->S;
   const auto host_t0 = std::chrono::steady_clock::now();
   StreamGuard guard(ctx);   // forward_all leaves ctx->stream on the step's main stream
-  DCGP_TRY(forward_all(model, X, N, S, z_per_layer_host, seed, dedup_layer0, true, pipelined, &rows));
   const int nl = (int)model->layers.size();
   LayerState& H = *model->layers[nl - 1];
+  const int slot = (int)(model->enq_seq % dcgp_model::RING);
+  DCGP_TRY(forward_all(model, X, N, S, z_per_layer_host, seed, dedup_layer0, true, pipelined, &rows));
   auto& o = model->outs[nl - 1];
   double* scal = model->d_scal + 64 * model->bank;
-  auto& groups = model->groups[model->bank];
+  auto& groups_now = model->groups[model->bank];
   DCGP_TRY(ensure(ctx, &model->d_ve, &model->ve_cap, (size_t)rows));
   // rows == S*N normally; a head-only model under dedup has rows == N with S identical copies
   const double inv_s = (rows == S * N) ? 1.0 / S : 1.0;
-  if (groups.size() > 16) return ctx_fail(ctx, DCGP_ERR_ARG, "model: too many factor groups");
+  if (groups_now.size() > 16) return ctx_fail(ctx, DCGP_ERR_ARG, "model: too many factor groups");
   ElboFinish fin;
-  fin.nl = nl; fin.scale = scale;
-  for (int l = 0; l < nl; ++l) { fin.M[l] = model->layers[l]->M; fin.R[l] = model->layers[l]->R; fin.white[l] = model->layers[l]->white; }
-  fin.ngroups = (int)groups.size();
-  for (int g = 0; g < fin.ngroups; ++g) { fin.info[g] = groups[g].d_info; fin.ninfo[g] = (int)groups[g].K.size(); }
+  fill_finish(model, groups_now, scale, slot, &fin);
   if (!ctx->comm) {
     // expectations, their sum and the ELBO assembly in one launch
     DCGP_TRY(elbo_tail(ctx, o.mean, o.var, y, rows, N, H.R, model->eps, model->d_ve, inv_s, scal, fin));
@@ -490,11 +510,10 @@ int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t*
     for (int l = 0; l < nl; ++l) { c.M[l] = fin.M[l]; c.R[l] = fin.R[l]; c.white[l] = fin.white[l]; }
     c.ngroups = fin.ngroups;
     for (int g = 0; g < c.ngroups; ++g) { c.info[g] = fin.info[g]; c.ninfo[g] = fin.ninfo[g]; }
+    c.host_out = fin.host_out;
     hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, ctx->stream, scal, scal + 40, c);
     LAUNCH_CHECK(ctx);
   }
-  const int slot = (int)(model->enq_seq % dcgp_model::RING);
-  HIP_TRY(ctx, hipMemcpyAsync(model->h_ring + 4 * slot, scal + 40, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(model->ring_ev[slot], ctx->stream));
   DCGP_TRY(forward_done(model, model->ring_ev[slot]));
   if (ctx->timing) {   // host time to enqueue one step (everything before the wait), reported beside the kernel timers

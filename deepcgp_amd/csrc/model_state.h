@@ -32,6 +32,7 @@ struct dcgp_model {
   // pinned host slots, one event per slot; tickets are handed out and collected in order
   static constexpr int RING = 4;
   double* h_ring = nullptr;            // RING x 4 pinned doubles: ELBO, data term, KL, potrf status
+  double* h_ring_dev = nullptr;        // the same slots as the device addresses them (written by the last kernel of a step)
   hipEvent_t ring_ev[RING] = {};
   uint64_t enq_seq = 0, col_seq = 0;   // tickets handed out / collected
 

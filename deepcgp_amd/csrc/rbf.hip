@@ -124,6 +124,27 @@ __device__ __forceinline__ void patch_rbf_body(const PatchRbfArgs& a, const int 
   const int n = bz, m0 = by * PR_BM;
 
   const double* __restrict__ Xn = a.X + (long)(n % a.n_mod) * HWC;
+  // everything the k loop and the epilogue read from global memory is requested here, in front of the image: one memory
+  // latency for all of it instead of one each (|z|^2 after the image, the first Z^T sub-steps after the barrier and the
+  // patch weights in the epilogue cost ~1 us apiece per workgroup)
+  const double znv = (tid < PR_BM && m0 + tid < a.Mp) ? a.zn[m0 + tid] : 0.0;
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.ZT), 0, a.Lp * a.Mp * 8, 0x00020000);
+  unsigned zoff[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) zoff[x] = (unsigned)((lrow * a.Mp + min(m0 + wm * 32 + x * 16 + lcol, a.Mp - 1)) * 8);
+  const int nk4 = a.Lp >> 2;
+  double ring[PR_D + 1][2];
+  auto ldz = [&](int k4, double (&dst)[2]) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(zrs, (int)zoff[x], k4 * 4 * a.Mp * 8, 0);
+      __builtin_memcpy(&dst[x], &v, 8);
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < PR_D; ++u) ldz(min(u, nk4 - 1), ring[u]);
+  bool primed = true;
   // image -> LDS in batches of 8 loads per thread: a rolled loop waits one memory latency per iteration
   for (int i0 = 0; i0 < HWC; i0 += 8 * 256) {
     double t[8];
@@ -145,19 +166,13 @@ __device__ __forceinline__ void patch_rbf_body(const PatchRbfArgs& a, const int 
     int kw = t % a.f, kh = t / a.f;
     koff[l] = (kh * a.W + kw) * a.C + c;
   }
-  // this lane's A-operand columns: rows m0 + wm*32 + x*16 + lcol of Z (columns of Z^T); beyond Mp: re-read the last one, dropped later
-  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-  const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.ZT), 0, a.Lp * a.Mp * 8, 0x00020000);
-  unsigned zoff[2];
-#pragma unroll
-  for (int x = 0; x < 2; ++x) zoff[x] = (unsigned)((lrow * a.Mp + min(m0 + wm * 32 + x * 16 + lcol, a.Mp - 1)) * 8);
+  // (zoff: this lane's A-operand columns: rows m0 + wm*32 + x*16 + lcol of Z (columns of Z^T); beyond Mp: re-read the last one, dropped later)
   double* znl = red + 2 * PR_BM;   // behind the reduce scratch: |z|^2 of the workgroup's 64 rows (koff follows)
-  if (tid < PR_BM) znl[tid] = (m0 + tid < a.Mp) ? a.zn[m0 + tid] : 0.0;
+  if (tid < PR_BM) znl[tid] = znv;
   __syncthreads();
 
   const int p_tiles = (a.P + PR_BP - 1) / PR_BP;
   const int pt_lo = a.reduce ? 0 : bx, pt_hi = a.reduce ? p_tiles : bx + 1;
-  const int nk4 = a.Lp >> 2;
 
   double rsum[2][4];   // reduce mode: per (fm, v) running row sums
 #pragma unroll
@@ -178,43 +193,67 @@ __device__ __forceinline__ void patch_rbf_body(const PatchRbfArgs& a, const int 
       for (int y = 0; y < 2; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
     double xn[2] = {0.0, 0.0};
 
-    double ring[PR_D + 1][2];
-    auto ldz = [&](int k4, double (&dst)[2]) {
+    double wp[2];   // reduce mode: the patch weights of this lane's two columns (0 beyond the last patch)
 #pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(zrs, (int)zoff[x], k4 * 4 * a.Mp * 8, 0);
-        __builtin_memcpy(&dst[x], &v, 8);
-      }
+    for (int y = 0; y < 2; ++y) wp[y] = (a.reduce && p0 + y * 16 + lcol < a.P) ? a.w[p0 + y * 16 + lcol] : 0.0;
+    // B operand: this lane's two patch columns, gathered from the LDS image ONE sub-step ahead of the MFMAs that use them,
+    // their image offsets read a whole group of sub-steps ahead (offset -> gather -> MFMA inside one step exposed two
+    // dependent LDS round trips per step; with fewer than four waves on the SIMD -- the second round of a 1.5-round grid --
+    // nothing covered them).  Only the last sub-step can reach k >= L, so only gathers that may be the last carry the mask.
+    constexpr int G = PR_D + 1;
+    auto offs = [&](int k4, int (&ko)[G]) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) ko[u] = koff[4 * min(k4 + u, nk4 - 1) + lrow];
     };
-    auto kstep = [&](int k4, const double (&w)[2]) {
-      const int k = 4 * k4 + lrow;
-      const int ko = koff[k];
-      const bool kin = k < a.L;
-      double bv[2];
+    auto gather = [&](int ko, bool kin, double (&bv)[2]) {
 #pragma unroll
       for (int y = 0; y < 2; ++y) {
         const double v = img[pb[y] + ko];
         bv[y] = kin ? v : 0.0;
-        xn[y] = fma(bv[y], bv[y], xn[y]);
       }
+    };
+    auto mma = [&](const double (&w)[2], const double (&bv)[2]) {
 #pragma unroll
       for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[x], bv[y], acc[x][y], 0, 0, 0);
+#pragma unroll
+      for (int y = 0; y < 2; ++y) xn[y] = fma(bv[y], bv[y], xn[y]);
     };
+    if (!primed) {
 #pragma unroll
-    for (int u = 0; u < PR_D; ++u) ldz(min(u, nk4 - 1), ring[u]);
-    int t = 0;
-    for (; t + PR_D + 1 <= nk4; t += PR_D + 1) {   // full groups: no conditionals around the loads
-#pragma unroll
-      for (int u = 0; u <= PR_D; ++u) {
-        ldz(min(t + u + PR_D, nk4 - 1), ring[(u + PR_D) % (PR_D + 1)]);
-        kstep(t + u, ring[u]);
-      }
+      for (int u = 0; u < PR_D; ++u) ldz(min(u, nk4 - 1), ring[u]);
     }
+    primed = false;
+    const bool last_in = 4 * (nk4 - 1) + lrow < a.L;
+    int kc[G], kn[G];
+    double bc[2], bn[2];
+    offs(0, kc);
+    gather(kc[0], nk4 > 1 || last_in, bc);
+    // full groups cover sub-steps [0, T), T the largest multiple of G that leaves the last sub-step to the tail
+    const int T = ((nk4 - 1) / G) * G;
+    int t = 0;
+    for (; t < T; t += G) {   // no conditionals around the loads
+      offs(t + G, kn);
 #pragma unroll
-    for (int u = 0; u < PR_D; ++u)
-      if (t + u < nk4) kstep(t + u, ring[u]);
+      for (int u = 0; u < G; ++u) {
+        ldz(min(t + u + PR_D, nk4 - 1), ring[(u + PR_D) % G]);
+        if (u < PR_D) gather(kc[u + 1], true, bn);
+        else gather(kn[0], t + G < nk4 - 1 || last_in, bn);   // t + G <= T <= nk4 - 1: may be the last sub-step
+        mma(ring[u], bc);
+        bc[0] = bn[0]; bc[1] = bn[1];
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) kc[u] = kn[u];
+    }
+    ldz(min(t + PR_D, nk4 - 1), ring[PR_D]);   // the tail can be G sub-steps long; kc holds their offsets
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+      if (t + u < nk4) {
+        if (u < PR_D && t + u + 1 < nk4) gather(kc[u + 1], t + u + 1 < nk4 - 1 || last_in, bn);
+        mma(ring[u], bc);
+        bc[0] = bn[0]; bc[1] = bn[1];
+      }
     // |x_p|^2 for column lcol of each fragment: combine the 4 k-groups
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
@@ -222,9 +261,6 @@ __device__ __forceinline__ void patch_rbf_body(const PatchRbfArgs& a, const int 
       xn[y] += __shfl_xor(xn[y], 32);
     }
     // epilogue: the 4 accumulator values of a fragment together (their exps interleaved)
-    double wp[2];
-#pragma unroll
-    for (int y = 0; y < 2; ++y) wp[y] = (a.reduce && p0 + y * 16 + lcol < a.P) ? a.w[p0 + y * 16 + lcol] : 0.0;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -245,7 +281,6 @@ __device__ __forceinline__ void patch_rbf_body(const PatchRbfArgs& a, const int 
         }
       }
   }
-
   if (a.reduce) {
     // sum over the 16 lanes of a row group, then over the two p-waves
 #pragma unroll
@@ -274,36 +309,32 @@ __global__ __launch_bounds__(256, BT == 0 ? 4 : 2) void patch_rbf_kernel(PatchRb
 
 // ---------------------------------------------------------------------------------------------
 // ConvKernel.Kdiag: per image sum_{p,p'} w_p w_p' k(x_p, x_p') / P^2, upper triangle of 64x64 patch
-// tile pairs (symmetry: off-diagonal pairs count twice).  grid (pairs, N); partial[n][pair].
+// tiles (symmetry: off-diagonal tiles count twice).  grid (tile-row pairs, N); partial[n][row pair].
 // ---------------------------------------------------------------------------------------------
 struct KdiagArgs {
   const double* X; int n_mod, H, W, C, f, s, Ho, Wo, P, L; BaseKernel bk; const double* w; double* partial; int n_pairs, p_tiles;
 };
+// One workgroup = one image and one PAIR of tile rows (brow, p_tiles - 1 - brow) of the symmetric P x P patch Gram matrix: it
+// walks the tiles on and right of the diagonal of both rows -- p_tiles + 1 tile products whatever brow is -- so the image
+// load, the offset table and the patch norms are paid once per ~p_tiles tile products and every workgroup is the same length
+// (one workgroup per tile PAIR paid them per product: 14400 workgroups of 7 k sub-steps each on the 28x28 head, setup-bound).
 template <int BT>
-__device__ __forceinline__ void head_kdiag_body(const KdiagArgs& k, const int bpair, const int n) {
+__device__ __forceinline__ void head_kdiag_body(const KdiagArgs& k, const int brow, const int n) {
   const double* __restrict__ X = k.X;
-  const int n_mod = k.n_mod, H = k.H, W = k.W, C = k.C, f = k.f, s = k.s, Wo = k.Wo, P = k.P, L = k.L, n_pairs = k.n_pairs, p_tiles = k.p_tiles;
+  const int n_mod = k.n_mod, H = k.H, W = k.W, C = k.C, f = k.f, s = k.s, Wo = k.Wo, P = k.P, L = k.L, p_tiles = k.p_tiles;
   const BaseKernel& bk = k.bk;
   const double* __restrict__ w = k.w;
-  double* __restrict__ partial = k.partial;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int HWC = H * W * C;
   const int Lp = (L + 3) & ~3;
   double* img = smem;                             // [HWC]
-  double* xn = img + ((HWC + 1) & ~1);            // [128] norms: rows tile then cols tile
-  double* red = xn + 128;                         // [4]
+  double* xn = img + ((HWC + 1) & ~1);            // [p_tiles * 64] patch norms
+  double* wl = xn + p_tiles * 64;                 // [p_tiles * 64] patch weights (0 beyond P)
+  double* red = wl + p_tiles * 64;                // [4]
   int* koff = reinterpret_cast<int*>(red + 4);    // [Lp]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lrow = lane >> 4, lcol = lane & 15;
-  // decode pair index -> (tr <= tc)
-  int pair = bpair, tr = 0;
-  while (pair >= p_tiles - tr) {
-    pair -= p_tiles - tr;
-    ++tr;
-  }
-  const int tc = tr + pair;
-
   const double* __restrict__ Xn = X + (long)(n % n_mod) * HWC;
   // image -> LDS in batches of 8 loads per thread: a rolled loop waits one memory latency per iteration
   for (int i0 = 0; i0 < HWC; i0 += 8 * 256) {
@@ -326,84 +357,122 @@ __device__ __forceinline__ void head_kdiag_body(const KdiagArgs& k, const int bp
     koff[l] = (kh * W + kw) * C + c;
   }
   __syncthreads();
-  // patch norms: 2 threads per patch over the 128 patches (rows tile, cols tile)
-  {
-    int q = tid >> 1, half = tid & 1;
-    int p = (q < 64 ? tr * 64 + q : tc * 64 + (q - 64));
-    int pbq = patch_base(p, P, Wo, s, W, C);
+  // patch norms and weights of the whole image: 4 threads per patch, 8 terms in flight per thread (one term at a time each
+  // waited for its two dependent LDS reads: 16 us per workgroup at L = 250, as long as the tile products themselves)
+  for (int q0 = 0; q0 < p_tiles * 64; q0 += 64) {
+    const int p = q0 + (tid >> 2), part = tid & 3;
+    const int pbq = patch_base(p, P, Wo, s, W, C);
     double sacc = 0.0;
-    for (int l = half; l < L; l += 2) {
-      double v = img[pbq + koff[l]];
-      sacc += v * v;
+    int l = part;
+    for (; l + 28 < L; l += 32) {
+      double v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = img[pbq + koff[l + 4 * e]];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sacc = fma(v[e], v[e], sacc);
+    }
+    for (; l < L; l += 4) {
+      const double v = img[pbq + koff[l]];
+      sacc = fma(v, v, sacc);
     }
     sacc += __shfl_xor(sacc, 1);
-    if (half == 0) xn[q] = sacc;
+    sacc += __shfl_xor(sacc, 2);
+    if (part == 0) { xn[p] = sacc; wl[p] = p < P ? w[p] : 0.0; }
   }
   __syncthreads();
 
-  int pa[2], pbc[2];
-#pragma unroll
-  for (int x = 0; x < 2; ++x) pa[x] = patch_base(tr * 64 + wm * 32 + x * 16 + lcol, P, Wo, s, W, C);
-#pragma unroll
-  for (int y = 0; y < 2; ++y) pbc[y] = patch_base(tc * 64 + wn * 32 + y * 16 + lcol, P, Wo, s, W, C);
-  d4 acc[2][2];
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int y = 0; y < 2; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
-  for (int kk = 0; kk < Lp; kk += 4) {
-    const int k = kk + lrow;
-    const int ko = koff[k];
-    const bool kin = k < L;
-    double av[2], bv[2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      double v = img[pa[x] + ko];
-      av[x] = kin ? v : 0.0;
-    }
-#pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      double v = img[pbc[y] + ko];
-      bv[y] = kin ? v : 0.0;
-    }
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-        acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
-  }
+  const int nk4 = Lp >> 2;
   double sum = 0.0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int tr = pass == 0 ? brow : p_tiles - 1 - brow;
+    if (pass == 1 && tr == brow) break;
+    int pa[2];
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < 2; ++x) pa[x] = patch_base(tr * 64 + wm * 32 + x * 16 + lcol, P, Wo, s, W, C);
+    for (int tc = tr; tc < p_tiles; ++tc) {
+      int pbc[2];
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      const int qc = wn * 32 + y * 16 + lcol;
-      const int pc = tc * 64 + qc;
-      const double wc = pc < P ? w[pc] : 0.0, nc = xn[64 + qc];
+      for (int y = 0; y < 2; ++y) pbc[y] = patch_base(tc * 64 + wn * 32 + y * 16 + lcol, P, Wo, s, W, C);
+      d4 acc[2][2];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {   // two dependent exp chains interleaved, times the four waves of the SIMD
-        double kv[2], n1[2], n2[2], ww[2];
+      for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int v = 2 * h + e;
-          const int ql = wm * 32 + x * 16 + lrow + 4 * v;
-          const int p = tr * 64 + ql;
-          kv[e] = acc[x][y][v]; n1[e] = xn[ql]; n2[e] = nc;
-          ww[e] = p < P ? w[p] * wc : 0.0;
+        for (int y = 0; y < 2; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+      // operands gathered one k sub-step ahead of the MFMAs that use them, their image offsets read a group of four sub-steps
+      // ahead: with offset -> gather -> MFMA in one step the two dependent LDS round trips cost 500 cycles a step on a SIMD
+      // with a single wave (the tail of the grid), twice the four MFMAs.  Only the last sub-step can reach k >= L.
+      auto offs = [&](int k4, int (&ko)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ko[u] = koff[4 * min(k4 + u, nk4 - 1) + lrow];
+      };
+      auto gather = [&](int ko, bool kin, double (&av)[2], double (&bv)[2]) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) { const double v = img[pa[x] + ko]; av[x] = kin ? v : 0.0; }
+#pragma unroll
+        for (int y = 0; y < 2; ++y) { const double v = img[pbc[y] + ko]; bv[y] = kin ? v : 0.0; }
+      };
+      auto mma = [&](const double (&av)[2], const double (&bv)[2]) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
+      };
+      const bool last_in = 4 * (nk4 - 1) + lrow < L;
+      int kc[4], kn[4];
+      double ac[2], bc[2], an[2], bn[2];
+      offs(0, kc);
+      gather(kc[0], nk4 > 1 || last_in, ac, bc);
+      int k4 = 0;
+      for (; k4 + 4 < nk4; k4 += 4) {   // the gathers of sub-steps k4+1 .. k4+4 <= nk4-1: only the last may need the mask
+        offs(k4 + 4, kn);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (u < 3) gather(kc[u + 1], true, an, bn);
+          else gather(kn[0], k4 + 4 < nk4 - 1 || last_in, an, bn);
+          mma(ac, bc);
+#pragma unroll
+          for (int x = 0; x < 2; ++x) { ac[x] = an[x]; bc[x] = bn[x]; }
         }
-        bk.template eval_n<BT, 2>(kv, n1, n2);
-        sum += ww[0] * kv[0];
-        sum += ww[1] * kv[1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kc[u] = kn[u];
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)      // 1..4 sub-steps left; kc holds their offsets
+        if (k4 + u < nk4) {
+          if (u < 3 && k4 + u + 1 < nk4) gather(kc[u + 1], k4 + u + 1 < nk4 - 1 || last_in, an, bn);
+          mma(ac, bc);
+#pragma unroll
+          for (int x = 0; x < 2; ++x) { ac[x] = an[x]; bc[x] = bn[x]; }
+        }
+      const double sym = (tr == tc) ? 1.0 : 2.0;
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+          const int pc = tc * 64 + wn * 32 + y * 16 + lcol;
+          const double wc = sym * wl[pc], nc = xn[pc];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {   // two dependent exp chains interleaved, times the four waves of the SIMD
+            double kv[2], n1[2], n2[2], ww[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int v = 2 * h + e;
+              const int p = tr * 64 + wm * 32 + x * 16 + lrow + 4 * v;
+              kv[e] = acc[x][y][v]; n1[e] = xn[p]; n2[e] = nc;
+              ww[e] = wl[p] * wc;
+            }
+            bk.template eval_n<BT, 2>(kv, n1, n2);
+            sum += ww[0] * kv[0];
+            sum += ww[1] * kv[1];
+          }
+        }
     }
+  }
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
   if (lane == 0) red[wave] = sum;
   __syncthreads();
-  if (tid == 0) {
-    double t = (red[0] + red[1]) + (red[2] + red[3]);
-    partial[(long)n * n_pairs + bpair] = (tr == tc) ? t : 2.0 * t;
-  }
+  if (tid == 0) k.partial[(long)n * k.n_pairs + brow] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 template <int BT>
@@ -413,8 +482,7 @@ __global__ __launch_bounds__(256, 4) void head_kdiag_kernel(KdiagArgs k) {
 
 // The head's two sweeps in ONE launch (no second stream, no cross-stream join in front of the head's conditional): first the
 // 64-row blocks of Kzx of every image -- each walks all p_tiles patch tiles of its image, the long workgroups -- then the Kdiag
-// tile pairs, one tile product each, which fill in behind them (longest first: with the pairs in front, the Kzx blocks of the
-// last images started late and ran on alone: 1700 instead of 2190 steps/s on the head-only model, 45 pairs per image).
+// workgroups (a pair of tile rows of the patch Gram matrix each, p_tiles + 1 tile products -- about as long as a Kzx block).
 __global__ __launch_bounds__(256, 4) void head_sweep_kernel(PatchRbfArgs a, KdiagArgs k, int ny) {
   const int nz = a.N * ny;
   if ((int)blockIdx.x < nz) {
@@ -495,11 +563,11 @@ int patch_rbf(dcgp_ctx* ctx, const PatchRbfArgs& a, const char* timer_name) {
 static int kdiag_args(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, int C, int f, int s, BaseKernel bk, const double* w,
                       KdiagArgs* k, size_t* lds) {
   const int Ho = (H - f) / s + 1, Wo = (W - f) / s + 1, P = Ho * Wo, L = f * f * C;
-  const int p_tiles = (P + 63) / 64, n_pairs = p_tiles * (p_tiles + 1) / 2;
+  const int p_tiles = (P + 63) / 64, n_pairs = (p_tiles + 1) / 2;   // workgroups per image: pairs of tile rows
   const int HWC = H * W * C, Lp = (L + 3) & ~3;
   double* partial = (double*)ws_get(ctx, "kdiag_partial", (size_t)N * n_pairs * sizeof(double));
   if (!partial) return DCGP_ERR_ALLOC;
-  *lds = (size_t)(((HWC + 1) & ~1) + 128 + 4) * sizeof(double) + (size_t)Lp * sizeof(int);
+  *lds = (size_t)(((HWC + 1) & ~1) + 2 * p_tiles * 64 + 4) * sizeof(double) + (size_t)Lp * sizeof(int);
   if (*lds > 160 * 1024) return ctx_fail(ctx, DCGP_ERR_ARG, "head_kdiag: image does not fit LDS");
   k->X = X; k->n_mod = n_mod; k->H = H; k->W = W; k->C = C; k->f = f; k->s = s; k->Ho = Ho; k->Wo = Wo; k->P = P; k->L = L;
   k->bk = bk; k->w = w; k->partial = partial; k->n_pairs = n_pairs; k->p_tiles = p_tiles;
