@@ -179,8 +179,8 @@ struct BaseKernel {
 
 // patch-RBF sweep (kuf / head Kzx)
 struct PatchRbfArgs {
-  const double* X = nullptr;   // [n_mod, H, W, C]; image of column block n is X[n % n_mod]
-  int n_mod = 0;
+  const double* X = nullptr;   // [n_mod, H, W, C]; image of column block n is X[(n0 + n) % n_mod]
+  int n_mod = 0, n0 = 0;       // n0: first image of a chunk of a larger batch (the output is indexed by the local n)
   int N = 0, H = 0, W = 0, C = 0, f = 0, s = 0, Ho = 0, Wo = 0, P = 0, L = 0;
   const double* ZT = nullptr;  // [Lp, Mp] k-major, zero padded
   const double* zn = nullptr;  // [Mp] |z|^2 (unscaled)

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
       v = (knn - s1) + s2;
       m = a.mu[(long)r * a.ldk + j];
       if (a.idm && r == 0) {
-        int n = j / a.P, p = j - n * a.P;
+        const long jg = a.col0 + j;
+        int n = (int)(jg / a.P), p = (int)(jg - (long)n * a.P);
         int oh = p / a.Wo, ow = p - oh * a.Wo;
         int c0 = a.f / 2;
         m += a.X[(((long)(n % a.n_mod) * a.H + oh * a.s + c0) * a.W + ow * a.s + c0) * a.C];
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     int jj = idx / a.R, r = idx - jj * a.R, j = j0 + jj;
     if (j >= a.Kc) continue;
     double m = vm[r * 65 + jj], v = vv[r * 65 + jj];
-    long e = (long)j * a.R + r;
+    long e = (a.col0 + j) * a.R + r;
     for (int s = 0; s < a.rep; ++s) {
       long o = (long)s * a.rep_stride + e;
       if (a.out_mean) a.out_mean[o] = m;

@@ -26,6 +26,14 @@ namespace {
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int CF_D_DEFAULT = 3;   // A-operand k-tiles in flight per wave beside the one being multiplied
 
+__device__ __forceinline__ void set_prio(int p) {   // s_setprio takes an immediate
+  switch (p) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+}
 __device__ __forceinline__ int frag_of(int w, int W, int c) { return (c >> 1) * 2 * W + ((c & 1) ? 2 * W - 1 - w : w); }
 
 // phase timestamps for tools/fused_trace.py: [workgroup][wave][16] shader-clock ticks, first 8 workgroups of every 90th
@@ -411,6 +419,10 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
     };
     int t = 0;
     for (; t + CF_D + 1 <= total; t += CF_D + 1) {   // full groups: no conditionals around the loads
+      // issue priority falls with progress: the arbiter favours the oldest wave of a SIMD, which then finishes this phase 50 us
+      // (of 160) ahead of the youngest and leaves it the pipe to itself at the end; a wave a quarter ahead yields (-1 % kernel time;
+      // rotating the priorities per group did the same, pinning the LDS reads ahead of the MFMAs with sched_group_barrier +1 %)
+      set_prio(3 - (4 * t) / total);
 #pragma unroll
       for (int u = 0; u <= CF_D; ++u) {
         if (!(ABL & 1)) ldw(grs, lsoff(), ring[(u + CF_D) % (CF_D + 1)]);
@@ -423,6 +435,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
       if (t + u < total) step(ring[u]);
     }
   }
+  __builtin_amdgcn_s_setprio(0);
   CF_TR(6)
 
   // ---- mean = alpha^T A1: wave (y, g) = (wave % FN, wave / FN) takes column fragment y and the k-tiles g, g + KG, ... -------

@@ -70,6 +70,7 @@ struct FinalizeArgs {
   const double* mu = nullptr;
   long ldk = 0;                  // leading dimension (padded column count) of the above
   int Kc = 0, R = 0;
+  long col0 = 0;                 // first column of a chunk: outputs, noise and the identity mean are indexed by col0 + j
   double knn_scalar = 0.0; const double* knn_vec = nullptr;   // Knn per column (vector wins if set)
   // output: element (j, r) of replica s at  s*rep_stride + j*R + r
   int rep = 1; long rep_stride = 0;

@@ -255,31 +255,46 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
       return conv_fused(ctx, fa);
     }
   }
-  double* B = (double*)ws_get(ctx, pfx + "Kuf", (size_t)Mp * ldb * sizeof(double));
+  // The sweep + GEMM route materialises K_uf [Mp][columns] and fetches whole k-tiles of it through 32-bit-offset buffer
+  // descriptors: an operand slab must stay under 2 GiB.  A forward-only pass takes a larger batch in chunks of whole images
+  // (sweep, conditional, finalize per chunk; outputs and noise stay indexed by the global column); the training step keeps
+  // K_uf and A1 of the whole batch for its reverse pass and is refused by the GEMM as before.
+  int chunk_rows = rows;
+  if (!keep_state)
+    while (chunk_rows > 1 && (long)Mp * col_ld((long)chunk_rows * P) * 8 >= (1L << 31)) chunk_rows = (chunk_rows + 1) / 2;
+  const bool chunked = chunk_rows < rows;
+  if (chunked && !(phase & 2)) return DCGP_OK;   // nothing to run ahead: the slab is reused chunk after chunk
+  const long ldc = col_ld((long)chunk_rows * P);
+  double* B = (double*)ws_get(ctx, pfx + "Kuf", (size_t)Mp * ldc * sizeof(double));
   if (!B) return DCGP_ERR_ALLOC;
-  if ((phase & 1) && Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));
-  PatchRbfArgs a;
-  a.X = X; a.N = rows; a.n_mod = n_mod;
-  a.H = L.v.H; a.W = L.v.W; a.C = L.v.C; a.f = L.v.f; a.s = L.v.s; a.Ho = L.v.Ho; a.Wo = L.v.Wo; a.P = P; a.L = L.v.L;
-  a.ZT = L.ZT; a.zn = L.zn; a.M = L.M; a.Mp = Mp; a.Lp = L.Lp;
-  a.bk = L.base();
-  a.out = B; a.sM = ldb; a.sN = P; a.sP = 1;
-  a.share_cu = phase == 1;
-  if (phase & 1) DCGP_TRY(patch_rbf(ctx, a, "kuf"));
-  if (!(phase & 2)) return DCGP_OK;
-  if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));   // inv(L) comes from the side stream
-  CondScratch sc;
-  DCGP_TRY(cond_core(ctx, L.g, B, ldb, (int)Kc, L.white, L.has_qsqrt, pfx.c_str(), &sc, prep_done));
-  FinalizeArgs fa;
-  fa.s1p = sc.s1p; fa.nrb1 = sc.nrb1; fa.s2p = sc.s2p; fa.nrb3 = sc.nrb3; fa.mu = sc.mu; fa.ldk = ldb;
-  fa.Kc = (int)Kc; fa.R = L.R; fa.knn_scalar = L.variance;
-  fa.rep = rep; fa.rep_stride = rep_stride; fa.z = z; fa.seed = seed; fa.stream_id = stream_id; fa.jitter = jitter;
-  fa.out_sample = out_sample; fa.out_mean = out_mean; fa.out_var = out_var;
-  if (L.identity_mean) {
-    fa.X = X; fa.idm = 1; fa.H = L.v.H; fa.W = L.v.W; fa.C = L.v.C; fa.f = L.v.f; fa.s = L.v.s; fa.Wo = L.v.Wo; fa.P = P;
-    fa.n_mod = n_mod;
+  if ((phase & 1 || chunked) && Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldc, 0, (size_t)(Mp - L.M) * ldc * sizeof(double), ctx->stream));
+  for (int r0 = 0; r0 < rows; r0 += chunk_rows) {
+    const int nr = rows - r0 < chunk_rows ? rows - r0 : chunk_rows;
+    const long kc = (long)nr * P;
+    PatchRbfArgs a;
+    a.X = X; a.N = nr; a.n_mod = n_mod; a.n0 = r0;
+    a.H = L.v.H; a.W = L.v.W; a.C = L.v.C; a.f = L.v.f; a.s = L.v.s; a.Ho = L.v.Ho; a.Wo = L.v.Wo; a.P = P; a.L = L.v.L;
+    a.ZT = L.ZT; a.zn = L.zn; a.M = L.M; a.Mp = Mp; a.Lp = L.Lp;
+    a.bk = L.base();
+    a.out = B; a.sM = ldc; a.sN = P; a.sP = 1;
+    a.share_cu = phase == 1;
+    if ((phase & 1) || chunked) DCGP_TRY(patch_rbf(ctx, a, "kuf"));
+    if (!(phase & 2)) return DCGP_OK;
+    if (factor_done && r0 == 0) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));   // inv(L) comes from the side stream
+    CondScratch sc;
+    DCGP_TRY(cond_core(ctx, L.g, B, ldc, (int)kc, L.white, L.has_qsqrt, pfx.c_str(), &sc, r0 == 0 ? prep_done : nullptr));
+    FinalizeArgs fa;
+    fa.s1p = sc.s1p; fa.nrb1 = sc.nrb1; fa.s2p = sc.s2p; fa.nrb3 = sc.nrb3; fa.mu = sc.mu; fa.ldk = ldc;
+    fa.Kc = (int)kc; fa.R = L.R; fa.knn_scalar = L.variance; fa.col0 = (long)r0 * P;
+    fa.rep = rep; fa.rep_stride = rep_stride; fa.z = z; fa.seed = seed; fa.stream_id = stream_id; fa.jitter = jitter;
+    fa.out_sample = out_sample; fa.out_mean = out_mean; fa.out_var = out_var;
+    if (L.identity_mean) {
+      fa.X = X; fa.idm = 1; fa.H = L.v.H; fa.W = L.v.W; fa.C = L.v.C; fa.f = L.v.f; fa.s = L.v.s; fa.Wo = L.v.Wo; fa.P = P;
+      fa.n_mod = n_mod;
+    }
+    DCGP_TRY(finalize_layer(ctx, fa));
   }
-  return finalize_layer(ctx, fa);
+  return DCGP_OK;
 }
 
 // SVGP head: Kzx / Kdiag from the conv kernel, then the shared conditional

@@ -123,7 +123,7 @@ __device__ __forceinline__ void patch_rbf_body(const PatchRbfArgs& a, const int 
   const int lrow = lane >> 4, lcol = lane & 15;
   const int n = bz, m0 = by * PR_BM;
 
-  const double* __restrict__ Xn = a.X + (long)(n % a.n_mod) * HWC;
+  const double* __restrict__ Xn = a.X + (long)((a.n0 + n) % a.n_mod) * HWC;
   // everything the k loop and the epilogue read from global memory is requested here, in front of the image: one memory
   // latency for all of it instead of one each (|z|^2 after the image, the first Z^T sub-steps after the barrier and the
   // patch weights in the epilogue cost ~1 us apiece per workgroup)

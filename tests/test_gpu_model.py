@@ -334,8 +334,10 @@ def test_baseline_configs_3_to_5_full_size_properties(ctx, name):
 
 def test_oversized_operand_slab(ctx):
     """[M x columns] = 1024 x 288 000 doubles = 2.36 GB.  The one-launch layer (conv_fused.hip) never materialises it and
-    takes the size in its stride; the sweep + GEMM route fetches whole k-tiles through 32-bit-offset buffer descriptors and
-    must REFUSE an operand of 2 GiB or more with DCGP_ERR_ARG and a message naming the limit -- never wrap silently."""
+    takes the size in its stride.  The sweep + GEMM route fetches whole k-tiles through 32-bit-offset buffer descriptors: a
+    forward pass takes the batch in chunks of whole images (same noise per column, so the two routes agree), and the
+    training step -- whose reverse pass needs K_uf and A1 of the whole batch -- must REFUSE an operand of 2 GiB or more with
+    DCGP_ERR_ARG and a message naming the limit, never wrap silently."""
     import os
     from deepcgp_amd import device as dev
     spec, X, Y = syn.make_config("cfg5_mnist_CH_M1024", S=10)
@@ -349,8 +351,12 @@ def test_oversized_operand_slab(ctx):
     finally:
         del os.environ["DCGP_FUSED_LARGE"]
     assert np.isfinite([e, data, kl]).all() and data < lo < 0
+    e2, data2, kl2 = model.compute_log_likelihood(X, Y, seed=0, return_parts=True)      # default route: chunked
+    assert abs(data2 - data) <= 1e-8 * abs(data) and abs(kl2 - kl) <= 1e-10 * abs(kl)
+    lo2 = model.compute_log_likelihood(X[:100], Y[:100], seed=0, return_parts=True)[1]   # under the limit: one chunk
+    assert abs(lo2 - lo) <= 1e-8 * abs(lo)
     with pytest.raises(dev.DcgpError) as ei:
-        model.compute_log_likelihood(X, Y, seed=0)
+        model.compute_gradients(X, Y, seed=0)
     assert ei.value.code == dev.ERR_ARG and "2 GiB" in str(ei.value)
     model.close()
 
