@@ -146,15 +146,22 @@ __global__ __launch_bounds__(256) void varexp_kernel(const double* __restrict__ 
 // ---- the ELBO tail in one launch: RobustMax expectations of every row (as varexp_kernel), their sum by the LAST block to
 // arrive (fixed order: reproducible), and -- with fin.nl > 0 -- the assembly  data * scale - sum_l KL_l  with the status words of
 // the factorisations.  Three dependent launches and their gaps otherwise, at the very end of the step where nothing hides them.
-__global__ __launch_bounds__(256) void elbo_tail_kernel(TailArgs t) {
-  __shared__ double red[256];
+__global__ __launch_bounds__(256) void elbo_tail_kernel(TailArgs t, KlTail kl) {
+  __shared__ double red[4 * 256];
   __shared__ unsigned last;
   const int tid = threadIdx.x, g = tid & 31;
-  const int row = blockIdx.x * 8 + (tid >> 5);
-  const bool live = row < t.n_rows;
-  double contrib = live ? robustmax_node(t.mu + (long)row * t.K, t.var + (long)row * t.K, t.y[row % t.n_labels], t.K, t.gh, g) : 0.0;
-  for (int o = 1; o < 32; o <<= 1) contrib += __shfl_xor(contrib, o);
-  if (live && g == 0) t.ve[row] = robustmax_logp(contrib, t.eps, t.K);
+  const int nb_rows = (t.n_rows + 7) / 8;
+  if ((int)blockIdx.x >= nb_rows) {
+    // the KL pieces of one layer (parameter-only inputs, ready since the chain): no launches, no stream of their own
+    const int l = blockIdx.x - nb_rows;
+    kl_pieces_block(kl.l[l], t.scal + 4 + 4 * l, red);
+  } else {
+    const int row = blockIdx.x * 8 + (tid >> 5);
+    const bool live = row < t.n_rows;
+    double contrib = live ? robustmax_node(t.mu + (long)row * t.K, t.var + (long)row * t.K, t.y[row % t.n_labels], t.K, t.gh, g) : 0.0;
+    for (int o = 1; o < 32; o <<= 1) contrib += __shfl_xor(contrib, o);
+    if (live && g == 0) t.ve[row] = robustmax_logp(contrib, t.eps, t.K);
+  }
   if (!last_to_arrive(t.ticket, gridDim.x, &last)) return;
   double s = 0.0;
   for (int i = tid; i < t.n_rows; i += 256) s += __hip_atomic_load(t.ve + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -271,13 +278,15 @@ int elbo_tail_prepare(dcgp_ctx* ctx, TailArgs* t) {
 }
 
 int elbo_tail(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t* y, int n_rows, int n_labels, int K, double eps,
-              double* ve_rows, double inv_s, double* scal, const ElboFinish& fin) {
+              double* ve_rows, double inv_s, double* scal, const ElboFinish& fin, const KlTail* kl) {
   TailArgs t;
   DCGP_TRY(elbo_tail_prepare(ctx, &t));
   t.mu = mu; t.var = var; t.y = y; t.n_rows = n_rows; t.n_labels = n_labels; t.K = K; t.eps = eps; t.ve = ve_rows;
   t.inv_s = inv_s; t.scal = scal; t.fin = fin;
   ScopedTimer tm(ctx, "elbo_tail");
-  hipLaunchKernelGGL(elbo_tail_kernel, dim3((unsigned)((n_rows + 7) / 8)), dim3(256), 0, ctx->stream, t);
+  KlTail k;   // nl == 0: the KL pieces are already in scal
+  if (kl) k = *kl;
+  hipLaunchKernelGGL(elbo_tail_kernel, dim3((unsigned)((n_rows + 7) / 8 + k.nl)), dim3(256), 0, ctx->stream, t, k);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }
@@ -395,11 +404,12 @@ int kl_layer(dcgp_ctx* ctx, const GpMats& g, const double* Lp, const double* Lpi
   const int Mp = g.Mp, R = g.R;
   double *tp = nullptr, *ap = nullptr;
   long tp_count = 0, ap_count = 0;
-  if (!white && g.klp && g.klp_valid && LpinvT == g.LinvT) {
-    // the prior factor is L: prep_solve left the sums of squares of G_r = inv(L) Lq_r and alpha = inv(L) q_mu
+  const double* sums = (g.klp && g.klp_valid && LpinvT == g.LinvT) ? g.klp : ((g.klpp && g.klpp_valid && LpinvT == g.LpinvT) ? g.klpp : nullptr);
+  if (!white && sums) {
+    // prep_solve left the sums of squares of inv(Lp) Lq_r and inv(Lp) q_mu (Lp = L for a layer without a prior of its own)
     const int ns = Mp / 16;
-    tp = g.klp; tp_count = (long)R * ns;
-    ap = g.klp + (long)R * ns; ap_count = 1;
+    tp = const_cast<double*>(sums); tp_count = (long)R * ns;
+    ap = tp + (long)R * ns; ap_count = 1;
   } else if (!white) {
     const int BM = gemm_row_block(Mp, Mp, R), nrb = (Mp + BM - 1) / BM;
     const int BMa = gemm_row_block(Mp, g.Rp, 1), nrba = (Mp + BMa - 1) / BMa;

@@ -167,7 +167,7 @@ struct PrepSolveLayer {
   const double* LinvT; const double* Lq; const double* qmu; double* G; double* alpha; double* klp;
   int Mp, R, Rp, active;   // active == 0: whitened layer (G / alpha alias Lq / q_mu) or larger than HC_MP
 };
-struct PrepSolveArgs { PrepSolveLayer l[8]; };
+struct PrepSolveArgs { PrepSolveLayer l[16]; };   // layers, then the prior-factor entries (G == nullptr: sums only)
 
 __global__ __launch_bounds__(1024, 4) void prep_solve_kernel(PrepSolveArgs args) {
   __shared__ __attribute__((aligned(16))) double Bt[HC_MP * HC_BN];   // [k][16]
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(1024, 4) void prep_solve_kernel(PrepSolveArgs args)
       }
     }
   }
-  if (live) {
+  if (live && (is_alpha ? a.alpha : a.G)) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) C[(long)(i0 + lrow + 4 * v) * ldb + c0 + lcol] = acc[v];
   }
@@ -275,7 +275,7 @@ int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, i
 // G / alpha of up to 8 layers in one launch (replaces cond_prep for unwhitened layers with M <= 256)
 int prep_solve_all(dcgp_ctx* ctx, GpMats* const* gs, const int* white, const bool* have_qsqrt, int nl, bool* done) {
   PrepSolveArgs a;
-  int any = 0, maxMp = 0, maxR = 0;
+  int any = 0, maxMp = 0, maxR = 0, ne = nl < 8 ? nl : 8;
   for (int i = 0; i < nl && i < 8; ++i) {
     const GpMats& g = *gs[i];
     PrepSolveLayer& l = a.l[i];
@@ -284,12 +284,23 @@ int prep_solve_all(dcgp_ctx* ctx, GpMats* const* gs, const int* white, const boo
     l.LinvT = g.LinvT; l.Lq = have_qsqrt[i] ? g.Lq : nullptr; l.qmu = g.qmu; l.G = g.G; l.alpha = g.alpha;
     l.klp = (l.active && have_qsqrt[i]) ? g.klp : nullptr;
     gs[i]->klp_valid = l.klp != nullptr;
+    gs[i]->klpp_valid = false;
     l.Mp = g.Mp; l.R = g.R; l.Rp = g.Rp;
     if (l.active) { any = 1; maxMp = g.Mp > maxMp ? g.Mp : maxMp; maxR = g.R > maxR ? g.R : maxR; }
   }
+  // layers whose KL prior is Kuu(Z0): the same products with inv(Lp), kept as sums of squares only (the KL's trace and
+  // Mahalanobis terms; two latency-bound GEMM launches per layer otherwise, beside the layer kernel)
+  for (int i = 0; i < nl && i < 8; ++i) {
+    const GpMats& g = *gs[i];
+    if (!a.l[i].active || !have_qsqrt[i] || !g.Kp || !g.klpp || !g.LpinvT) continue;
+    PrepSolveLayer& l = a.l[ne++];
+    l = a.l[i];
+    l.LinvT = g.LpinvT; l.G = nullptr; l.alpha = nullptr; l.klp = g.klpp;
+    gs[i]->klpp_valid = true;
+  }
   if (!any) return DCGP_OK;
   ScopedTimer t(ctx, "prep_solve");
-  hipLaunchKernelGGL(prep_solve_kernel, dim3(maxMp / HC_BN, maxR + 1, nl < 8 ? nl : 8), dim3(1024), 0, ctx->stream, a);
+  hipLaunchKernelGGL(prep_solve_kernel, dim3(maxMp / HC_BN, maxR + 1, ne), dim3(1024), 0, ctx->stream, a);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }

@@ -28,6 +28,9 @@ struct GpMats {
   double* klp = nullptr;    // [(R + 1)][Mp / 16] sums of squares of the 16-column strips of G_r and (row R, entry 0) of alpha,
                             // left by prep_solve: the KL's trace and Mahalanobis terms when its prior factor is L itself
   bool klp_valid = false;   // set by prep_solve_all for the launch that filled klp
+  double* klpp = nullptr;   // the same sums with the PRIOR factor inv(Lp) in place of inv(L) (layers with a prior Kuu(Z0)): nothing
+                            // but the sums is kept of those products
+  bool klpp_valid = false;
 };
 
 // parameter-only preparation of all layers in one launch (prep.hip)
@@ -124,9 +127,18 @@ struct ElboFinish {
 // RobustMax expectations of every row -> ve_rows, scal[0] = inv_s * their sum, and (fin.nl > 0) scal[40..43] = ELBO, data term,
 // KL, potrf status from the KL pieces at scal[4 + 4 l ..]: one launch (cond.hip)
 struct TailArgs;   // tail_dev.h
+// The KL pieces of the layers inside the tail launch (one extra workgroup per layer): everything they read is parameter-only
+// state the chain left behind -- the strip sums of prep_solve and the factors' diagonals.
+struct KlTailLayer {
+  const double* Lfac = nullptr; long ldf = 0;   // the KL prior's Cholesky factor (diagonal read: log-determinant)
+  const double* Lq = nullptr;                   // [R][Mp][Mp] (diagonal read)
+  const double* sums = nullptr;                 // [(R + 1)][Mp / 16] strip sums (GpMats::klp / klpp)
+  int M = 0, Mp = 0, R = 0;
+};
+struct KlTail { int nl = 0; KlTailLayer l[8]; };
 int elbo_tail_prepare(dcgp_ctx* ctx, TailArgs* t);   // Gauss-Hermite table and arrival counters of a TailArgs
 int elbo_tail(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t* y, int n_rows, int n_labels, int K, double eps,
-              double* ve_rows, double inv_s, double* scal, const ElboFinish& fin);
+              double* ve_rows, double inv_s, double* scal, const ElboFinish& fin, const KlTail* kl = nullptr);
 int varexp_rows(dcgp_ctx* ctx, const double* mu, const double* var, const int32_t* y, int n_rows, int n_labels, int K,
                 double eps, double* out_rows, int predict);
 const double* gauss_hermite_table(dcgp_ctx* ctx);   // [40]: 20 nodes then 20 weights (device)

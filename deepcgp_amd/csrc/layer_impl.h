@@ -91,7 +91,7 @@ struct LayerState {
     q.M = M; q.Mp = Mp; q.R = R; q.Rp = round_up(R, 16);
     const size_t mm = (size_t)Mp * Mp;
     q.K = dalloc(mm); q.Linv = dalloc(mm); q.LinvT = dalloc(mm);
-    if (!is_head && !white && need_prior_) { q.Kp = dalloc(mm); q.Lpinv = dalloc(mm); q.LpinvT = dalloc(mm); }
+    if (!is_head && !white && need_prior_) { q.Kp = dalloc(mm); q.Lpinv = dalloc(mm); q.LpinvT = dalloc(mm); q.klpp = dalloc((size_t)(R + 1) * (Mp / 16 + 1)); }
     q.Lq = dalloc((size_t)R * mm);
     q.qmu = dalloc((size_t)Mp * q.Rp);
     if (white) { q.G = q.Lq; q.alpha = q.qmu; }

@@ -214,12 +214,45 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     for (int li = 0; li < nl; ++li) { gs[li] = &m->layers[li]->g; wh[li] = m->layers[li]->white; hq[li] = m->layers[li]->has_qsqrt; }
     rc = prep_solve_all(ctx, gs, wh, hq, nl, prep_done);
   }
+  // The KL pieces need nothing but parameter-only state.  Where prep_solve left the sums of squares they are made of (every
+  // layer unwhitened, M <= 256, with q_sqrt), one extra workgroup per layer of the tail launch adds them up with the factors'
+  // log-determinants: no KL launches, no stream of their own, no fork in front of the first layer and no join (tail_dev.h).
+  bool kl_tail = need_kl && rc == DCGP_OK && nl <= 8 && !getenv("DCGP_KL_SIDE");
+  for (int li = 0; li < nl && kl_tail; ++li) {
+    const LayerState& L = *m->layers[li];
+    kl_tail = !L.white && prep_done[li] && L.has_qsqrt && L.g.klp_valid && (!L.g.Kp || L.g.klpp_valid);
+  }
+  m->kl_in_tail[bank] = kl_tail;
+  if (kl_tail) {
+    KlTail& kt = m->kl_tail[bank];
+    kt.nl = nl;
+    const double* lout = nullptr;   // deferred copy: the factors are still in the chain's scratch, [matrix of the group][Mp][Mp]
+    if (defer) {
+      auto it = ctx->ws.find("chol_Lout" + ctx->ws_tag);
+      if (it != ctx->ws.end()) lout = (const double*)it->second.first;
+    }
+    for (int li = 0; li < nl; ++li) {
+      const LayerState& L = *m->layers[li];
+      KlTailLayer& q = kt.l[li];
+      const double* prior = L.g.Kp ? L.g.Kp : L.g.K;
+      q.Lfac = prior; q.ldf = L.Mp;
+      if (defer) {
+        const auto& gr = m->groups[bank][0];
+        long idx = -1;
+        for (size_t i = 0; i < gr.K.size(); ++i) if (gr.K[i] == prior) idx = (long)i;
+        if (!lout || idx < 0) { rc = ctx_fail(ctx, DCGP_ERR_ARG, "model: factor scratch of layer %d not found", li); break; }
+        q.Lfac = lout + idx * (long)L.Mp * L.Mp;
+      }
+      q.Lq = L.g.Lq; q.sums = L.g.Kp ? L.g.klpp : L.g.klp; q.M = L.M; q.Mp = L.Mp; q.R = L.R;
+    }
+  }
+  const bool side_kl = need_kl && !kl_tail;
   for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
     if (!prep_done[li]) rc = cond_prep(ctx, m->layers[li]->g, m->layers[li]->white, m->layers[li]->has_qsqrt);   // generic GEMMs
-    if (rc == DCGP_OK && (xs || (li == nl - 1 && need_kl && kl_s != chain_s)) && hipEventRecord(m->ev_prep[bank][li], ctx->stream) != hipSuccess)
+    if (rc == DCGP_OK && (xs || (li == nl - 1 && side_kl && kl_s != chain_s)) && hipEventRecord(m->ev_prep[bank][li], ctx->stream) != hipSuccess)
       rc = DCGP_ERR_HIP;   // per layer: layer 0 does not wait for the others (same stream: only the fork of the KL terms needs one)
   }
-  if (rc == DCGP_OK && need_kl) {
+  if (rc == DCGP_OK && side_kl) {
     if (kl_s != chain_s) {   // fork: the KL terms need the factors only, the main stream goes on with the layers
       if (hipStreamWaitEvent(kl_s, m->ev_prep[bank][nl - 1], 0) != hipSuccess) rc = DCGP_ERR_HIP;
       ctx->stream = kl_s;
@@ -233,7 +266,8 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       rc = kl_layer(ctx, L.g, Lp, LpinvT, L.white, (mp + std::to_string(li)).c_str(), scal + 4 + 4 * li);
     }
   }
-  if (rc == DCGP_OK && hipEventRecord(m->ev_kl[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
+  const bool kl_join = side_kl && kl_s != main_s;
+  if (rc == DCGP_OK && kl_join && hipEventRecord(m->ev_kl[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
   ctx->stream = main_s;
   ctx->ws_tag.clear();
   if (rc != DCGP_OK) {
@@ -287,13 +321,13 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   const bool join_early = nl > 1;
   for (int li = 0; li < nl; ++li) {
     int out_rows = 0;
-    if (li == nl - 1 && join_early && kl_s != main_s) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_kl[bank], 0));
+    if (li == nl - 1 && join_early && kl_join) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_kl[bank], 0));
     DCGP_TRY(layer_step(li, F, rows, n_mod, &out_rows));
     if (!m->layers[li]->is_head) F = m->outs[li].sample;
     rows = out_rows;
     n_mod = rows;
   }
-  if (!join_early && kl_s != main_s) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_kl[bank], 0));   // join the side stream
+  if (!join_early && kl_join) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_kl[bank], 0));   // join the side stream
   *rows_last = rows;
   return DCGP_OK;
 }
@@ -497,13 +531,14 @@ int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t*
   if (groups_now.size() > 16) return ctx_fail(ctx, DCGP_ERR_ARG, "model: too many factor groups");
   ElboFinish fin;
   fill_finish(model, groups_now, scale, slot, &fin);
+  const KlTail* klt = model->kl_in_tail[model->bank] ? &model->kl_tail[model->bank] : nullptr;
   if (!ctx->comm) {
-    // expectations, their sum and the ELBO assembly in one launch
-    DCGP_TRY(elbo_tail(ctx, o.mean, o.var, y, rows, N, H.R, model->eps, model->d_ve, inv_s, scal, fin));
+    // expectations, their sum, the KL pieces where the chain left their ingredients, and the ELBO assembly in one launch
+    DCGP_TRY(elbo_tail(ctx, o.mean, o.var, y, rows, N, H.R, model->eps, model->d_ve, inv_s, scal, fin, klt));
   } else {
     // multi-GPU: the data term is summed over the ranks between the reduction and the assembly
     ElboFinish none;
-    DCGP_TRY(elbo_tail(ctx, o.mean, o.var, y, rows, N, H.R, model->eps, model->d_ve, inv_s, scal, none));
+    DCGP_TRY(elbo_tail(ctx, o.mean, o.var, y, rows, N, H.R, model->eps, model->d_ve, inv_s, scal, none, klt));
     DCGP_TRY(allreduce_sum_f64_async(ctx, scal, 1));
     CombineArgs c;
     c.nl = nl; c.scale = scale;

@@ -21,6 +21,9 @@ struct dcgp_model {
   hipEvent_t done_ev[2] = {};                    // not owned: the event that marks the end of the last step on the bank (a result-ring event)
   bool done_valid[2] = {false, false};
   bool events_ok = false;
+  // the KL pieces computed inside the tail launch (layers whose sums prep_solve left behind): per bank, set by forward_all
+  KlTail kl_tail[2];
+  bool kl_in_tail[2] = {false, false};
   // per-layer outputs of the most recent forward
   struct Out { double *sample = nullptr, *mean = nullptr, *var = nullptr; int rows = 0, width = 0; size_t cap = 0; };
   std::vector<Out> outs;
