@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void z_transpose_kernel(const double* __restri
 // ---------------------------------------------------------------------------------------------
 constexpr int PR_BM = 64;    // inducing patches per workgroup
 constexpr int PR_BP = 64;    // image patches per tile
-constexpr int PR_D = 4;      // k sub-steps of Z^T in flight per wave beside the one being multiplied
+constexpr int PR_D = 3;      // k sub-steps of Z^T in flight per wave beside the one being multiplied
 
 __device__ __forceinline__ int patch_base(int p, int P, int Wo, int s, int W, int C) {
   if (p >= P) p = 0;
@@ -266,10 +266,16 @@ __device__ __forceinline__ void patch_rbf_body(const PatchRbfArgs& a, const int 
 #pragma unroll
       for (int y = 0; y < 2; ++y) {
         const int p = p0 + y * 16 + lcol;
-        double kv[4], n1[4], n2[4];
+        double kv[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { kv[v] = acc[x][y][v]; n1[v] = xn[y]; n2[v] = znl[wm * 32 + x * 16 + lrow + 4 * v]; }
-        a.bk.template eval_n<BT, 4>(kv, n1, n2);   // four dependent chains interleaved, times the four waves of the SIMD
+        for (int h = 0; h < 2; ++h) {   // two values at a time: all four interleaved cost 20 spilled registers per lane
+          double k2[2], n1[2], n2[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) { k2[e] = acc[x][y][2 * h + e]; n1[e] = xn[y]; n2[e] = znl[wm * 32 + x * 16 + lrow + 4 * (2 * h + e)]; }
+          a.bk.template eval_n<BT, 2>(k2, n1, n2);
+          kv[2 * h] = k2[0]; kv[2 * h + 1] = k2[1];
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int m = m0 + wm * 32 + x * 16 + lrow + 4 * v;
