@@ -176,6 +176,34 @@ def test_device_rng_path(ctx):
     model.close()
 
 
+def test_kl_pieces_in_the_tail_launch_match_the_kl_launches(ctx):
+    """Unwhitened layers with M <= 256 take their KL pieces from the strip sums prep_solve leaves behind, added up by extra
+    workgroups of the tail launch (no KL launches, no side stream); DCGP_KL_SIDE=1 keeps the GEMM + kl_small route on the
+    side stream.  Same KL to rounding, same data term to the bit, for a conv layer with a frozen-Z prior, and against the oracle."""
+    import os
+    hwc = (14, 14, 1)
+    spec = syn.make_spec(hwc, [(3, 2, 5)], (3, 1), M=24, S=4, num_data=700, seed=33, conv_q_sqrt_scale=0.7)
+    X, Y = syn.make_batch(hwc, 6, seed=33)
+    zs = syn.make_noise(spec, 6, seed=34)
+    model = build_from_spec(spec, X, Y)
+    spec["convs"][0]["Z"] = np.asarray(spec["convs"][0]["Z"]) * 1.1 + 0.05   # live Z != frozen Z0: the prior factor is not L
+    model.layers[0].feature.Z = spec["convs"][0]["Z"]
+    model.sync_parameters()
+    e, data, kl = model.compute_log_likelihood(X, Y, zs=zs, return_parts=True)
+    ref = oracle_model(spec, X, Y).compute_log_likelihood(X, Y, zs=zs)
+    assert abs(e - ref) <= RTOL * abs(ref)
+    os.environ["DCGP_KL_SIDE"] = "1"
+    try:
+        e2, data2, kl2 = model.compute_log_likelihood(X, Y, zs=zs, return_parts=True)
+    finally:
+        del os.environ["DCGP_KL_SIDE"]
+    assert data2 == data and abs(kl2 - kl) <= 1e-12 * abs(kl) and abs(e2 - e) <= 1e-12 * abs(e)
+    assert abs(model.KL() - kl) <= 1e-10 * abs(kl)                   # the operator API, layer by layer
+    tickets = [model.enqueue_log_likelihood(X, Y, zs=zs) for _ in range(3)]
+    assert [model.collect_log_likelihood(t) for t in tickets] == [e] * 3
+    model.close()
+
+
 def test_enqueued_steps_match_the_synchronous_forward(ctx):
     """dcgp_elbo_forward_enqueue / _collect: several steps in flight (different minibatches, explicit noise or the
     device RNG) hand back bit-identical values to dcgp_elbo_forward, in order; misuse is refused."""
