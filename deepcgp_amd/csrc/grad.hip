@@ -805,11 +805,20 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   const GpMats& g = L.g;
   hipLaunchKernelGGL(rowsum_small_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, gv, Kc, R, gvs);
   LAUNCH_CHECK(ctx);
-  double* dA1 = bk.ws("dA1", (size_t)Mp * ld);
+  // The column-wise part of the adjoint -- dT, dA1, dK_uf -- in one strip-resident launch where the shape allows and there are
+  // enough columns to fill the chip (conv_bwd_fused.hip); its operand S_r = G_r G_r^T is parameter-only.
+  ConvBwdArgs fb;
+  fb.A1 = A1; fb.ld = ld; fb.Kc = (int)Kc; fb.alpha = L.g.alpha; fb.Rp = Rp; fb.Linv = L.g.Linv; fb.gv = gv; fb.gm = gm; fb.gvs = gvs;
+  fb.M = M; fb.Mp = Mp; fb.R = R; fb.dKuf = dKuf;
+  const char* min_env = getenv("DCGP_FUSED_BWD_MIN_COLS");   // (tests: the strip kernel at sizes the oracle checks)
+  const long min_cols = min_env ? atol(min_env) : 16384;
+  const bool fused_bwd = L.has_qsqrt && !L.white && Kc >= min_cols && conv_bwd_fused_ok(fb);
+  double* dA1 = fused_bwd ? nullptr : bk.ws("dA1", (size_t)Mp * ld);
   double* dalpha = bk.ws("dalpha", (size_t)Mp * Rp);
   double* dG = bk.ws("dG", (size_t)R * mm);
   double* dL = bk.ws("dL", (size_t)mm);
-  NEED(dA1); NEED(dalpha); NEED(dG); NEED(dL);
+  if (!fused_bwd) NEED(dA1);
+  NEED(dalpha); NEED(dG); NEED(dL);
   const long Rm = (long)R * Mp;
   double* GT = nullptr;
   if (L.has_qsqrt) {
@@ -817,6 +826,15 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
     NEED(GT);
     hipLaunchKernelGGL(restack_transpose_kernel, dim3(blocks_for(R * mm)), dim3(256), 0, ctx->stream, g.G, Mp, R, GT);
     LAUNCH_CHECK(ctx);
+  }
+  if (fused_bwd) {
+    double* Sgg = bk.ws("Sgg", (size_t)R * mm);
+    NEED(Sgg);
+    if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(Sgg, 0, (size_t)R * mm * sizeof(double), ctx->stream));
+    GenGemm sg = mk(g.G, Mp, 1, g.G, 1, Mp, Sgg, Mp, M, M, M);   // S_r = G_r G_r^T
+    sg.batch = R; sg.a_bs = mm; sg.b_bs = mm; sg.c_bs = mm;
+    DCGP_TRY(gemm_gen(ctx, sg));
+    fb.S = Sgg;
   }
   // Two independent chains from here.  Side stream: everything that ends in an M x M result (d alpha, W_r -> dG_r ->
   // dq_sqrt, the first two dL terms) -- long split-k contractions at ~40 % MFMA utilisation.  Main stream: dT, dA1, dK_uf
@@ -889,59 +907,63 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   }
   if (rc_side != DCGP_OK) { if (fork) hipStreamSynchronize(ctx->stream2); return rc_side; }
   // main chain
-  int dA1_acc = 0;
-  // the padded rows M..Mp-1 of dA1 are operands of the gemm_tn launch that forms dK_uf (times zeros of inv(L)'s padding):
-  // they must be finite whichever path writes the live rows
-  if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(dA1 + (size_t)M * ld, 0, (size_t)(Mp - M) * ld * sizeof(double), ctx->stream));
-  if (L.has_qsqrt) {
-    double* dT = bk.ws("dT", (size_t)R * Mp * ld);
-    NEED(dT);
-    const bool tn_ok = (long)Mp * ld * 8 < (1L << 31);
-    if (tn_ok) {   // dT_r = 2 (G_r^T A1) o gv_r: the forward's stage-3 product, stored, columns scaled in the epilogue
+  if (fused_bwd) {
+    DCGP_TRY(conv_bwd_fused(ctx, fb));
+  } else {
+    int dA1_acc = 0;
+    // the padded rows M..Mp-1 of dA1 are operands of the gemm_tn launch that forms dK_uf (times zeros of inv(L)'s padding):
+    // they must be finite whichever path writes the live rows
+    if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(dA1 + (size_t)M * ld, 0, (size_t)(Mp - M) * ld * sizeof(double), ctx->stream));
+    if (L.has_qsqrt) {
+      double* dT = bk.ws("dT", (size_t)R * Mp * ld);
+      NEED(dT);
+      const bool tn_ok = (long)Mp * ld * 8 < (1L << 31);
+      if (tn_ok) {   // dT_r = 2 (G_r^T A1) o gv_r: the forward's stage-3 product, stored, columns scaled in the epilogue
+        GemmArgs a;
+        a.Wt = g.G; a.ldw = Mp; a.wBatch = mm; a.nW = R;
+        a.B = A1; a.ldb = (int)ld;
+        a.C = dT; a.ldc = (int)ld; a.cBatch = (long)Mp * ld;
+        a.cscale = gv; a.csCol = R; a.csBatch = 1; a.calpha = 2.0;
+        a.Mi = Mp; a.Mk = Mp; a.Kc = (int)Kc; a.tri = 2;
+        DCGP_TRY(gemm_tn(ctx, a, nullptr));
+      } else {
+        GenGemm t = mk(g.G, 1, Mp, A1, ld, 1, dT, ld, Mp, (int)Kc, Mp);
+        t.batch = R; t.a_bs = mm; t.c_bs = (long)Mp * ld; t.alpha = 2.0; t.colscale = gv; t.cs_s = R; t.cs_bs = 1;
+        DCGP_TRY(gemm_gen(ctx, t));
+      }
+      // dA1 = sum_r G_r dT_r: ONE product with the R blocks stacked along k (GT [R Mp x Mp], dT [R Mp x ld])
+      // (few columns -- a de-duplicated first layer, the head: the 72-workgroup launch would be one long k chain; gemm_gen splits k)
+      if (Rm * ld * 8 < (1L << 31) && Kc >= 16384) {
+        GemmArgs a;
+        a.Wt = GT; a.ldw = Mp;
+        a.B = dT; a.ldb = (int)ld;
+        a.C = dA1; a.ldc = (int)ld;
+        a.Mi = Mp; a.Mk = (int)Rm; a.Kc = (int)Kc; a.tri = 0;
+        DCGP_TRY(gemm_tn(ctx, a, nullptr));
+      } else {
+        DCGP_TRY(gemm_gen(ctx, mk(GT, 1, Mp, dT, ld, 1, dA1, ld, M, (int)Kc, (int)Rm)));
+      }
+      dA1_acc = 1;
+    }
+    // dA1 (+)= alpha gm^T - 2 A1 o gvs
+    {
+      GenGemm a = mk(g.alpha, Rp, 1, gm, 1, R, dA1, ld, M, (int)Kc, R);
+      a.accumulate = dA1_acc;
+      DCGP_TRY(gemm_gen(ctx, a));
+    }
+    hipLaunchKernelGGL(dA1_fix_kernel, dim3(blocks_for(Kc), M), dim3(256), 0, ctx->stream, dA1, A1, gvs, M, Kc, ld);
+    LAUNCH_CHECK(ctx);
+    // dKuf = inv(L)^T dA1;  dL -= tril(dKuf A1^T)
+    if ((long)Mp * ld * 8 < (1L << 31)) {   // inv(L) row-major IS the k-major operand of inv(L)^T; upper-triangular product
       GemmArgs a;
-      a.Wt = g.G; a.ldw = Mp; a.wBatch = mm; a.nW = R;
-      a.B = A1; a.ldb = (int)ld;
-      a.C = dT; a.ldc = (int)ld; a.cBatch = (long)Mp * ld;
-      a.cscale = gv; a.csCol = R; a.csBatch = 1; a.calpha = 2.0;
+      a.Wt = g.Linv; a.ldw = Mp;
+      a.B = dA1; a.ldb = (int)ld;
+      a.C = dKuf; a.ldc = (int)ld;
       a.Mi = Mp; a.Mk = Mp; a.Kc = (int)Kc; a.tri = 2;
       DCGP_TRY(gemm_tn(ctx, a, nullptr));
     } else {
-      GenGemm t = mk(g.G, 1, Mp, A1, ld, 1, dT, ld, Mp, (int)Kc, Mp);
-      t.batch = R; t.a_bs = mm; t.c_bs = (long)Mp * ld; t.alpha = 2.0; t.colscale = gv; t.cs_s = R; t.cs_bs = 1;
-      DCGP_TRY(gemm_gen(ctx, t));
+      DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dA1, ld, 1, dKuf, ld, M, (int)Kc, M)));
     }
-    // dA1 = sum_r G_r dT_r: ONE product with the R blocks stacked along k (GT [R Mp x Mp], dT [R Mp x ld])
-    // (few columns -- a de-duplicated first layer, the head: the 72-workgroup launch would be one long k chain; gemm_gen splits k)
-    if (Rm * ld * 8 < (1L << 31) && Kc >= 16384) {
-      GemmArgs a;
-      a.Wt = GT; a.ldw = Mp;
-      a.B = dT; a.ldb = (int)ld;
-      a.C = dA1; a.ldc = (int)ld;
-      a.Mi = Mp; a.Mk = (int)Rm; a.Kc = (int)Kc; a.tri = 0;
-      DCGP_TRY(gemm_tn(ctx, a, nullptr));
-    } else {
-      DCGP_TRY(gemm_gen(ctx, mk(GT, 1, Mp, dT, ld, 1, dA1, ld, M, (int)Kc, (int)Rm)));
-    }
-    dA1_acc = 1;
-  }
-  // dA1 (+)= alpha gm^T - 2 A1 o gvs
-  {
-    GenGemm a = mk(g.alpha, Rp, 1, gm, 1, R, dA1, ld, M, (int)Kc, R);
-    a.accumulate = dA1_acc;
-    DCGP_TRY(gemm_gen(ctx, a));
-  }
-  hipLaunchKernelGGL(dA1_fix_kernel, dim3(blocks_for(Kc), M), dim3(256), 0, ctx->stream, dA1, A1, gvs, M, Kc, ld);
-  LAUNCH_CHECK(ctx);
-  // dKuf = inv(L)^T dA1;  dL -= tril(dKuf A1^T)
-  if ((long)Mp * ld * 8 < (1L << 31)) {   // inv(L) row-major IS the k-major operand of inv(L)^T; upper-triangular product
-    GemmArgs a;
-    a.Wt = g.Linv; a.ldw = Mp;
-    a.B = dA1; a.ldb = (int)ld;
-    a.C = dKuf; a.ldc = (int)ld;
-    a.Mi = Mp; a.Mk = Mp; a.Kc = (int)Kc; a.tri = 2;
-    DCGP_TRY(gemm_tn(ctx, a, nullptr));
-  } else {
-    DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dA1, ld, 1, dKuf, ld, M, (int)Kc, M)));
   }
   if (fork) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux2, 0));   // join: dL's first terms, dq_mu, dq_sqrt are done
   GenGemm l3 = mk(dKuf, ld, 1, A1, 1, ld, dL, Mp, M, M, (int)Kc);

@@ -106,6 +106,18 @@ struct ConvFusedArgs {
   int lds_main = 0, lds_img = 0;                           // set by the launcher
   long long* trace = nullptr;                              // debugging aid: phase timestamps (dcgp_debug_set_fused_trace)
 };
+// the reverse pass of the same strip (conv_bwd_fused.hip): dK_uf = inv(L)^T [sum_r (S_r A1) o (2 gv_r) + alpha gm^T - 2 A1 o gvs]
+struct ConvBwdArgs {
+  const double* A1 = nullptr; long ld = 0; int Kc = 0;   // [Mp][ld], k-major (left by the forward's training form)
+  const double* S = nullptr;                              // [R][Mp][Mp]  S_r = G_r G_r^T, zero beyond M
+  const double* alpha = nullptr; int Rp = 0;              // [Mp][Rp]
+  const double* Linv = nullptr;                           // [Mp][Mp] inv(L), row-major
+  const double *gv = nullptr, *gm = nullptr, *gvs = nullptr;   // d var [Kc][R], d mean [Kc][R], row sums of d var [Kc]
+  int M = 0, Mp = 0, R = 0;
+  double* dKuf = nullptr;                                 // [Mp][ld]
+};
+bool conv_bwd_fused_ok(const ConvBwdArgs& a);
+int conv_bwd_fused(dcgp_ctx* ctx, const ConvBwdArgs& a);
 bool conv_fused_ok(const ConvFusedArgs& a);
 int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a);
 

@@ -601,14 +601,23 @@ def test_gradients_match_oracle(ctx, white, additive, idmean):
         k = ref.layers[-1].kern
         ref.layers[-1].kern = AdditivePatchKernel(k.base_kernel, k.view, k.patch_weights)
     model = build_from_spec(spec, X, Y)
-    e, grads = model.compute_gradients(X, Y, zs=zs)
     eo, go = elbo_and_grad(ref, X, Y, zs)
-    assert abs(e - eo) <= RTOL * abs(eo)
-    for li, (g, o) in enumerate(zip(grads, go)):
-        for name, val in o.items():
-            # relative to the largest entry, or 1e-8 absolute where data and KL parts cancel to a tiny net gradient
-            err = np.abs(g[name] - val).max()
-            assert err < 1e-7 * np.abs(val).max() or err < 1e-8, (li, name, err, np.abs(val).max())
+    import os
+    # twice: the launch-per-product reverse pass of the conditional (few columns), then its one-launch strip form
+    # (csrc/conv_bwd_fused.hip, taken from 16 384 columns on; unwhitened layers with q_sqrt) forced onto these sizes
+    for min_cols in (None, "0"):
+        if min_cols is not None:
+            os.environ["DCGP_FUSED_BWD_MIN_COLS"] = min_cols
+        try:
+            e, grads = model.compute_gradients(X, Y, zs=zs)
+        finally:
+            os.environ.pop("DCGP_FUSED_BWD_MIN_COLS", None)
+        assert abs(e - eo) <= RTOL * abs(eo)
+        for li, (g, o) in enumerate(zip(grads, go)):
+            for name, val in o.items():
+                # relative to the largest entry, or 1e-8 absolute where data and KL parts cancel to a tiny net gradient
+                err = np.abs(g[name] - val).max()
+                assert err < 1e-7 * np.abs(val).max() or err < 1e-8, (min_cols, li, name, err, np.abs(val).max())
     model.close()
 
 
@@ -706,13 +715,20 @@ def test_gradients_match_oracle_mnist_geometry(ctx):
     zs = syn.make_noise(spec, N, seed=21)
     ref = oracle_model(spec, X, Y)
     model = build_from_spec(spec, X, Y)
-    e, grads = model.compute_gradients(X, Y, zs=zs)
     eo, go = elbo_and_grad(ref, X, Y, zs)
-    assert abs(e - eo) <= RTOL * abs(eo)
-    for li, (g, o) in enumerate(zip(grads, go)):
-        for name, val in o.items():
-            err = np.abs(g[name] - val).max()
-            assert err < 1e-7 * np.abs(val).max() or err < 1e-8, (li, name, err, np.abs(val).max())
+    import os
+    for min_cols in (None, "0"):     # second pass: the strip form of the conditional's reverse pass (M = 136: 9 row fragments, 7 idle waves)
+        if min_cols is not None:
+            os.environ["DCGP_FUSED_BWD_MIN_COLS"] = min_cols
+        try:
+            e, grads = model.compute_gradients(X, Y, zs=zs)
+        finally:
+            os.environ.pop("DCGP_FUSED_BWD_MIN_COLS", None)
+        assert abs(e - eo) <= RTOL * abs(eo)
+        for li, (g, o) in enumerate(zip(grads, go)):
+            for name, val in o.items():
+                err = np.abs(g[name] - val).max()
+                assert err < 1e-7 * np.abs(val).max() or err < 1e-8, (min_cols, li, name, err, np.abs(val).max())
     model.close()
 
 
