@@ -811,7 +811,7 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   fb.A1 = A1; fb.ld = ld; fb.Kc = (int)Kc; fb.alpha = L.g.alpha; fb.Rp = Rp; fb.Linv = L.g.Linv; fb.gv = gv; fb.gm = gm; fb.gvs = gvs;
   fb.M = M; fb.Mp = Mp; fb.R = R; fb.dKuf = dKuf;
   const char* min_env = getenv("DCGP_FUSED_BWD_MIN_COLS");   // (tests: the strip kernel at sizes the oracle checks)
-  const long min_cols = min_env ? atol(min_env) : 16384;
+  const long min_cols = min_env ? atol(min_env) : 4096;
   const bool fused_bwd = L.has_qsqrt && !L.white && Kc >= min_cols && conv_bwd_fused_ok(fb);
   double* dA1 = fused_bwd ? nullptr : bk.ws("dA1", (size_t)Mp * ld);
   double* dalpha = bk.ws("dalpha", (size_t)Mp * Rp);

@@ -604,7 +604,7 @@ def test_gradients_match_oracle(ctx, white, additive, idmean):
     eo, go = elbo_and_grad(ref, X, Y, zs)
     import os
     # twice: the launch-per-product reverse pass of the conditional (few columns), then its one-launch strip form
-    # (csrc/conv_bwd_fused.hip, taken from 16 384 columns on; unwhitened layers with q_sqrt) forced onto these sizes
+    # (csrc/conv_bwd_fused.hip, taken from 4096 columns on; unwhitened layers with q_sqrt) forced onto these sizes
     for min_cols in (None, "0"):
         if min_cols is not None:
             os.environ["DCGP_FUSED_BWD_MIN_COLS"] = min_cols
