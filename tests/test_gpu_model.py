@@ -979,12 +979,15 @@ def test_model_destroy_releases_its_workspaces(ctx):
     assert base - free_bytes() < 8 * 1024 * 1024, (base, free_bytes())
 
 
-def test_gradients_match_oracle_odd_shapes(ctx):
+@pytest.mark.parametrize("maps,strip_kernel", [(17, False), (13, True), (1, True)])
+def test_gradients_match_oracle_odd_shapes(ctx, maps, strip_kernel):
     """Padding paths of the reverse pass: M = 33 (Mp = 48), 17 feature maps (R padded to 32), two input channels,
-    stride 3, a 2 x 2 head filter, 5 images x 3 samples."""
+    stride 3, a 2 x 2 head filter, 5 images x 3 samples.  With 13 maps / 1 map the conditional's column-wise adjoint also runs as
+    the one-launch strip kernel (R <= 16; 240 columns = three full strips and a ragged one, 3 of 16 waves with rows)."""
+    import os
     from oracle.grad import elbo_and_grad
     hwc, N, S = (13, 13, 2), 5, 3
-    spec = syn.make_spec(hwc, [(4, 3, 17)], (2, 1), 33, S=S, num_data=777, seed=41, conv_q_sqrt_scale=0.3, variance=1.3, ls=2.1)
+    spec = syn.make_spec(hwc, [(4, 3, maps)], (2, 1), 33, S=S, num_data=777, seed=41, conv_q_sqrt_scale=0.3, variance=1.3, ls=2.1)
     rng = np.random.default_rng(41)
     spec["head"]["w"] = 0.5 + rng.random(spec["head"]["w"].shape)
     X, Y = syn.make_batch(hwc, N, seed=41)
@@ -992,14 +995,19 @@ def test_gradients_match_oracle_odd_shapes(ctx):
     ref = oracle_model(spec, X, Y)
     model = build_from_spec(spec, X, Y)
     eo, go = elbo_and_grad(ref, X, Y, zs)
-    for dedup in (False, True):
-        model.dedup_layer0 = dedup
-        e, grads = model.compute_gradients(X, Y, zs=zs)
-        assert abs(e - eo) <= RTOL * abs(eo)
-        for li, (g, o) in enumerate(zip(grads, go)):
-            for name, val in o.items():
-                err = np.abs(g[name] - val).max()
-                assert err < 1e-7 * np.abs(val).max() or err < 1e-8, (dedup, li, name, err, np.abs(val).max())
+    if strip_kernel:
+        os.environ["DCGP_FUSED_BWD_MIN_COLS"] = "0"
+    try:
+        for dedup in (False, True):
+            model.dedup_layer0 = dedup
+            e, grads = model.compute_gradients(X, Y, zs=zs)
+            assert abs(e - eo) <= RTOL * abs(eo)
+            for li, (g, o) in enumerate(zip(grads, go)):
+                for name, val in o.items():
+                    err = np.abs(g[name] - val).max()
+                    assert err < 1e-7 * np.abs(val).max() or err < 1e-8, (dedup, li, name, err, np.abs(val).max())
+    finally:
+        os.environ.pop("DCGP_FUSED_BWD_MIN_COLS", None)
     model.close()
 
 
