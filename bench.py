@@ -251,7 +251,8 @@ def main():
     leg = Leg(ctx, grp, comm, args.config, S, cfg["batch"], lo, hi, args.dedup_layer0)
     model, spec = leg.model, leg.spec
 
-    # HIP events bracket only the two roofline kernels (gemm_cond_s3, kuf) on their launch stream; the mode is
+    # HIP events bracket only the roofline kernels (conv_fused | gemm_cond_s3, kuf) on their launch stream, every 7th launch of them
+    # (the two event records cost the step they sit in ~10 us of stream time; a sample gives the same average); the mode is
     # switched on before the warm-up so that every lazy first-use cost of the event path is paid outside the timed region
     ctx.timing_enable(2)
     # The HIP runtime has a one-off ~50 ms hiccup somewhere in the first few dozen steps of a process (seen in 1 run
@@ -408,7 +409,8 @@ def main():
             fused = timing.get("conv_fused", (0, 0.0))[0] > 0
             t_dom = timing.get("conv_fused" if fused else "gemm_cond_s3", (0, 0.0))
             flops_dom = flops_fused if fused else flops_s3
-            per_step_ms = t_dom[1] / max(args.steps, 1)
+            # (mode 2 brackets every 7th launch of the kernel: average launch x launches per step)
+            per_step_ms = (t_dom[1] / t_dom[0]) * n_conv if t_dom[0] else 0.0
             ach = flops_dom / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else None
             out["roofline"] = {"kernel": ("conv_fused_kernel<4,2,2,1024> (whole conv layer of a 64-column strip per workgroup: patch sweep, inv(L) K_uf, "
                                           "R x G_r^T A1 with fused sums of squares, mean, sample; %d launch(es)/step)" % n_conv) if fused else

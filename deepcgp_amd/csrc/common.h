@@ -50,7 +50,8 @@ struct dcgp_ctx {
   std::map<std::string, std::pair<void*, size_t>> ws;
   // timing
   bool timing = false;
-  int timing_mode = 0;   // 1: every bracketed kernel family; 2: only the roofline kernels (gemm_cond_s3, kuf)
+  int timing_mode = 0;   // 1: every bracketed kernel family; 2: only the roofline kernels (conv_fused, gemm_cond_s3, kuf), every 7th launch
+  unsigned timing_sample = 0;
   std::map<std::string, TimingAcc> tim;
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;

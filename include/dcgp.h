@@ -52,7 +52,7 @@ int dcgp_sync(dcgp_ctx* ctx);
 /* ---- per-kernel HIP-event timing (bench.py's roofline leg) -------------------------------- */
 /* When enabled, the launches of the named kernel families ("kuf", "gemm_cond", "potrf", "trtri",
  * "head_kzx", "head_kdiag", ...) are bracketed by hipEvents on the ctx stream.                 */
-int dcgp_timing_enable(dcgp_ctx* ctx, int on);   /* 0 off, 1 every family, 2 only the roofline kernels: "conv_fused", "gemm_cond_s3", "kuf" */
+int dcgp_timing_enable(dcgp_ctx* ctx, int on);   /* 0 off, 1 every family, 2 only the roofline kernels ("conv_fused", "gemm_cond_s3", "kuf"), every 7th launch of them */
 int dcgp_timing_reset(dcgp_ctx* ctx);
 int dcgp_timing_query(dcgp_ctx* ctx, const char* name, int* launches, double* total_ms);
 int dcgp_timing_names(dcgp_ctx* ctx, char* buf, size_t buflen);   /* ';'-separated list */
