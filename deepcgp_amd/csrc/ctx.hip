@@ -252,6 +252,7 @@ int dcgp_timing_reset(dcgp_ctx* ctx) {
   if (!ctx) return DCGP_ERR_ARG;
   timing_flush(ctx);
   ctx->tim.clear();
+  ctx->timing_sample = 0;   // the first launch after a reset is one of the sampled ones
   return DCGP_OK;
 }
 int dcgp_timing_query(dcgp_ctx* ctx, const char* name, int* launches, double* total_ms) {
