@@ -409,8 +409,9 @@ def main():
             fused = timing.get("conv_fused", (0, 0.0))[0] > 0
             t_dom = timing.get("conv_fused" if fused else "gemm_cond_s3", (0, 0.0))
             flops_dom = flops_fused if fused else flops_s3
-            # (mode 2 brackets every 7th launch of the kernel: average launch x launches per step)
-            per_step_ms = (t_dom[1] / t_dom[0]) * n_conv if t_dom[0] else 0.0
+            # (mode 2 times every 7th launch of the kernel and counts all of them: average launch x launches per step)
+            calls = timing.get(("conv_fused" if fused else "gemm_cond_s3") + "#calls", (0, 0.0))[0]
+            per_step_ms = (t_dom[1] / t_dom[0]) * (calls / max(args.steps, 1)) if t_dom[0] else 0.0
             ach = flops_dom / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else None
             out["roofline"] = {"kernel": ("conv_fused_kernel<4,2,2,1024> (whole conv layer of a 64-column strip per workgroup: patch sweep, inv(L) K_uf, "
                                           "R x G_r^T A1 with fused sums of squares, mean, sample; %d launch(es)/step)" % n_conv) if fused else

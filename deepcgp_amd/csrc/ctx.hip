@@ -48,7 +48,10 @@ ScopedTimer::ScopedTimer(dcgp_ctx* c, const char* name) : ctx(c), on(c->timing) 
     if (strcmp(name, "gemm_cond_s3") != 0 && strcmp(name, "kuf") != 0 && strcmp(name, "conv_fused") != 0) on = false;
     // every 7th launch of a roofline kernel (odd: a step with two such launches has both sampled in turn): the two event records are packets in front of and behind the launch (~5 us each of
     // stream time), paid by the very step that is being timed; a sample of the launches gives the same average
-    else if (c->timing_sample++ % 7 != 0) on = false;
+    else {
+      c->tim[std::string(name) + "#calls"].launches += 1;   // every launch is counted ("<name>#calls"), every 7th timed
+      if (c->timing_sample++ % 7 != 0) on = false;
+    }
   }
   if (!on) return;
   pe.name = name;
