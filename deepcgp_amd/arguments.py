@@ -1,34 +1,48 @@
-"""Command-line flags -- the same names, defaults and help semantics as
-/root/reference/conv_gp/arguments.py:9-43 (it is the reference's whole config system)."""
+"""Command-line flags of an experiment, as a table.
+
+The flag NAMES and DEFAULTS are the reference's whole configuration system (/root/reference/conv_gp/arguments.py:9-43) and are
+what its option files (results/*/options.toml) record, so they are kept to the letter; everything else here is this
+repository's: one table, one loop, and a note per flag on what the device path does with it."""
 import argparse
 import math
 
-
-def train_steps(flags):
-    # roughly until the learning rate becomes 1e-5 (conv_gp/arguments.py:4-7)
-    decay_count = math.log(5e-5 / flags.lr, 0.1)
-    return math.ceil(flags.lr_decay_steps * decay_count / flags.test_every)
+# (flag, type or None for a switch, default, what it selects)
+FLAGS = (
+    ("--name", str, "experiment", "run name (log directory, checkpoint file name)"),
+    ("--lr-decay-steps", int, 100000, "staircase period of the learning-rate decay (x 0.1 per period)"),
+    ("--test-every", int, 50000, "optimisation steps between two test-set evaluations"),
+    ("--test-size", int, 10000, "test images used per evaluation"),
+    ("--num-samples", int, 10, "S: Monte-Carlo samples per image in the doubly-stochastic ELBO"),
+    ("--log-dir", str, "results", "where logs and checkpoints go"),
+    ("--lr", float, 0.01, "Adam / SGD learning rate (device optimiser: dcgp_model_adam_step / _sgd_step)"),
+    ("--batch-size", int, 32, "minibatch size (images)"),
+    ("--optimizer", str, "Adam", "Adam | SGD | NatGrad (NatGrad: variational parameters by natural gradient, rest by Adam)"),
+    ("-M", str, "384,384", "inducing patches per layer, comma separated; one value = SVGP head only"),
+    ("--feature-maps", str, "10", "outputs of each conv layer, comma separated ('' with a head-only model)"),
+    ("--filter-sizes", str, "5,5", "patch size of each layer incl. the head"),
+    ("--strides", str, "2,1", "patch stride of each layer incl. the head"),
+    ("--base-kernel", str, "rbf", "base kernel of the conv layers: rbf | acos"),
+    ("--white", None, False, "whitened variational parameters"),
+    ("--last-kernel", str, "conv", "head kernel: conv | add | rbf"),
+    ("--gamma", float, 0.001, "NatGrad step size"),
+    ("--identity-mean", None, False, "Conv2dMean identity mean function on the conv layers"),
+    ("--load-model", str, None, "checkpoint (.npy, reference key set) to start from"),
+)
+REQUIRED = ("--name",)
 
 
 def default_parser():
-    p = argparse.ArgumentParser()
-    p.add_argument('--name', type=str, required=True, default='experiment')
-    p.add_argument('--lr-decay-steps', type=int, default=100000)
-    p.add_argument('--test-every', type=int, default=50000)
-    p.add_argument('--test-size', type=int, default=10000)
-    p.add_argument('--num-samples', type=int, default=10)
-    p.add_argument('--log-dir', type=str, default='results')
-    p.add_argument('--lr', type=float, default=0.01)
-    p.add_argument('--batch-size', type=int, default=32)
-    p.add_argument('--optimizer', type=str, default='Adam')
-    p.add_argument('-M', type=str, default='384,384')
-    p.add_argument('--feature-maps', type=str, default='10')
-    p.add_argument('--filter-sizes', type=str, default='5,5')
-    p.add_argument('--strides', type=str, default='2,1')
-    p.add_argument('--base-kernel', type=str, default='rbf')
-    p.add_argument('--white', action='store_true', default=False)
-    p.add_argument('--last-kernel', type=str, default='conv')
-    p.add_argument('--gamma', type=float, default=0.001)
-    p.add_argument('--identity-mean', action='store_true')
-    p.add_argument('--load-model', type=str, default=None)
-    return p
+    """argparse parser over FLAGS (same namespace attributes as the reference's parser)."""
+    parser = argparse.ArgumentParser(description="Deep convolutional GP experiment flags")
+    for flag, kind, default, doc in FLAGS:
+        if kind is None:
+            parser.add_argument(flag, action="store_true", default=default, help=doc)
+        else:
+            parser.add_argument(flag, type=kind, default=default, required=flag in REQUIRED, help=doc)
+    return parser
+
+
+def train_steps(flags):
+    """Number of test periods until the decayed learning rate reaches about 1e-5 (conv_gp/arguments.py:4-7)."""
+    decades = math.log(5e-5 / flags.lr, 0.1)
+    return math.ceil(decades * flags.lr_decay_steps / flags.test_every)
