@@ -949,6 +949,19 @@ def test_gradients_are_bitwise_reproducible_at_full_size(ctx):
     # and the two paths agree with each other (not bitwise: different summation orders)
     assert abs(first[True][0] - first[False][0]) <= 1e-10 * abs(first[False][0])
     assert np.abs(first[True][1] - first[False][1]).max() <= 1e-8 * max(np.abs(first[False][1]).max(), 1.0)
+    # the conditional's column-wise reverse pass as ONE strip-resident launch (default at this size, csrc/conv_bwd_fused.hip) against
+    # its launch-per-product form at the full 46 080 columns: the same gradients to rounding
+    import os
+    os.environ["DCGP_NO_FUSED_BWD"] = "1"
+    try:
+        for dedup in (False, True):
+            model.dedup_layer0 = dedup
+            e, g = model.compute_gradients(X, Y, seed=7)
+            flat = np.concatenate([np.ravel(v) for gl in g for v in gl.values()])
+            assert abs(e - first[dedup][0]) <= 1e-12 * abs(e)
+            assert np.abs(flat - first[dedup][1]).max() <= 1e-9 * max(np.abs(flat).max(), 1.0), dedup
+    finally:
+        del os.environ["DCGP_NO_FUSED_BWD"]
     model.close()
 
 
