@@ -58,6 +58,7 @@ struct dcgp_ctx {
   // pinned host scratch for small result read-backs
   double* h_scratch = nullptr;   // 64 doubles
   int* h_info = nullptr;         // 16 ints
+  long long* fused_trace = nullptr;   // debugging aid (dcgp_debug_set_fused_trace): phase stamps of the one-launch layer kernel
   // RCCL
   void* comm = nullptr;
   int nranks = 1, rank = 0;
@@ -199,6 +200,28 @@ int patch_rbf(dcgp_ctx* ctx, const PatchRbfArgs& a, const char* timer_name);
 int head_sweep(dcgp_ctx* ctx, const PatchRbfArgs& a, const double* w, const double** kd_partial, int* n_pairs, double* kd_scale);
 int head_kdiag(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, int C, int f, int s, BaseKernel bk,
                const double* w, double* out_N);
+
+// head_units.hip: ConvKernel.Kzx (weighted patch sum) and ConvKernel.Kdiag (partial sums per image) in one launch.
+// RBF base kernel; the operands carry the kernel's scales: ZS = sqrt(c) Z^T with c = log2(e) / lengthscale^2, rows L, L + 1 =
+// (-c |z|^2 / 2 + log2 variance, 1), zero behind (prepare_all writes it beside Z^T).
+struct HeadUnitsArgs {
+  const double* X = nullptr; int n_mod = 0, N = 0;         // image of row n is X[n % n_mod]
+  int H = 0, W = 0, C = 0, f = 0, s = 0, Wo = 0, P = 0, L = 0, Lq = 0, HWC = 0;
+  const double* ZS = nullptr; int M = 0, Mp = 0;           // [Lq][Mp]
+  double csq = 1.0, log2var = 0.0;                         // sqrt(c); log2(variance)
+  const double* w = nullptr;                               // [P] patch weights
+  double* kzx = nullptr; long ldk = 0; double kzx_scale = 1.0;   // kzx[m * ldk + n] = kzx_scale * sum_p w_p k(z_m, x_np), rows M..Mp-1 zeroed
+  int kzx_rows = 0;                                        // rows of kzx that exist (0: all Mp)
+  double* kd = nullptr;                                    // kd[n * n_kd + i]: Kdiag[n] = sum_i kd[..] / P^2   (nullptr / kzx == nullptr: that half is skipped)
+  int nfm = 0, nfp = 0, n_kd = 0, U = 0, u_lo = 0, wgs_per_img = 0;  // set by head_units_plan (call it with kzx / kd already set)
+  float inv_C = 1.f, inv_f = 1.f, inv_Wo = 1.f, inv_Wr = 1.f;         // reciprocals for the set-up's index splits
+};
+void head_units_plan(HeadUnitsArgs* a);
+bool head_units_ok(const HeadUnitsArgs& a);
+int head_units(dcgp_ctx* ctx, const HeadUnitsArgs& a);
+int sweep_operand(dcgp_ctx* ctx, const double* Z, const double* in_scale, int M, int Mp, int L, double variance, double lengthscale, double* ZS);
+int kdiag_reduce(dcgp_ctx* ctx, const double* partial, int n_parts, int N, double scale, double* out_N);   // out[n] = scale * sum_i partial[n * n_parts + i]
+inline int sweep_lq(int L) { return (L + 2 + 3) / 4 * 4; }   // patch length + the two norm slots, in whole sub-steps of 4
 
 // small-matrix helpers (rbf.hip / chol.hip / misc.hip)
 int rbf_gram_padded(dcgp_ctx* ctx, const double* Z, int M, int L, BaseKernel bk, double jitter,

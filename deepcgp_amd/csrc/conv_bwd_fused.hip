@@ -211,10 +211,11 @@ int conv_bwd_fused(dcgp_ctx* ctx, const ConvBwdArgs& a) {
   if (!conv_bwd_fused_ok(a)) return ctx_fail(ctx, DCGP_ERR_ARG, "conv_bwd_fused: layer shape not supported (M = %d, R = %d)", a.M, a.R);
   const int Rk = (a.R + 3) & ~3;
   const size_t lds = ((size_t)a.Mp * CB_BN + (size_t)(a.R + Rk + 1) * CB_BN) * sizeof(double);
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[64] = {};   // per device
+  const int dv = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+  if (!attr[dv]) {
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)conv_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
+    attr[dv] = true;
   }
   ScopedTimer t(ctx, "conv_bwd_fused");
   hipLaunchKernelGGL(conv_bwd_fused_kernel, dim3((unsigned)((a.Kc + CB_BN - 1) / CB_BN)), dim3(CB_NT), lds, ctx->stream, a);

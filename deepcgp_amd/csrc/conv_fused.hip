@@ -521,11 +521,12 @@ template <int FN, int NS, int MAXF, int NT>
 int launch_fused(dcgp_ctx* ctx, const ConvFusedArgs& a, size_t lds) {
   const int BN = FN * 16;
   const unsigned grid = (unsigned)((a.Kc + BN - 1) / BN);
-  static bool attr_done = false;
-  if (!attr_done) {   // more than 64 KB of dynamic LDS needs the opt-in
+  static bool attr_done[64] = {};   // per device: a second ctx on another device of this process needs the opt-in too
+  const int dv = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+  if (!attr_done[dv]) {   // more than 64 KB of dynamic LDS needs the opt-in
     hipFuncSetAttribute((const void*)conv_fused_kernel<FN, NS, MAXF, NT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)conv_fused_kernel<FN, NS, MAXF, NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+    attr_done[dv] = true;
   }
   if (a.bk.type == 0) hipLaunchKernelGGL((conv_fused_kernel<FN, NS, MAXF, NT, 0>), dim3(grid), dim3(NT), lds, ctx->stream, a);
   else hipLaunchKernelGGL((conv_fused_kernel<FN, NS, MAXF, NT, 1>), dim3(grid), dim3(NT), lds, ctx->stream, a);
@@ -575,11 +576,10 @@ bool plan_fused(const ConvFusedArgs& a, FusedPlan* p) {
 
 }  // namespace
 
-static long long* g_cf_trace = nullptr;
 // debugging aid (tools/fused_trace.py): device buffer of 8 x 16 x 16 int64 that the fused layer kernel stamps its phases into
 extern "C" int dcgp_debug_set_fused_trace(dcgp_ctx* ctx, long long* buf_dev) {
-  (void)ctx;
-  g_cf_trace = buf_dev;
+  if (!ctx) return DCGP_ERR_ARG;
+  ctx->fused_trace = buf_dev;   // per ctx: goes away with it (nullptr switches the stamps off)
   return DCGP_OK;
 }
 
@@ -596,9 +596,10 @@ int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a_in) {
   if ((long)a_in.R * a_in.Mp * a_in.Mp * 8 >= (1L << 31)) return ctx_fail(ctx, DCGP_ERR_ARG, "conv_fused: G exceeds 2 GiB");
   ConvFusedArgs a = a_in;
   a.lds_main = p.lds_main; a.lds_img = p.lds_img;
-  a.trace = g_cf_trace;
+  a.trace = ctx->fused_trace;
   ScopedTimer t(ctx, "conv_fused");
-  const int abl = getenv("DCGP_FUSED_ABL") ? atoi(getenv("DCGP_FUSED_ABL")) : 0;   // timing experiments (wrong results)
+#ifdef DCGP_EXPERIMENTS
+  const int abl = getenv("DCGP_FUSED_ABL") ? atoi(getenv("DCGP_FUSED_ABL")) : 0;   // timing build only (make EXPERIMENTS=1): wrong results
   if (abl && p.shape == 0 && a.bk.type == 0) {
     const unsigned grid = (unsigned)((a.Kc + 63) / 64);
 #define CF_ABL(X)                                                                                                                       \
@@ -606,11 +607,12 @@ int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a_in) {
     hipFuncSetAttribute((const void*)conv_fused_kernel<4, 2, 2, 1024, 0, X>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     hipLaunchKernelGGL((conv_fused_kernel<4, 2, 2, 1024, 0, X>), dim3(grid), dim3(1024), p.lds, ctx->stream, a);                        \
     break;
-    switch (abl) { CF_ABL(1) CF_ABL(2) CF_ABL(3) CF_ABL(4) default: break; }
+    switch (abl) { CF_ABL(1) CF_ABL(2) CF_ABL(3) CF_ABL(4) default: return ctx_fail(ctx, DCGP_ERR_ARG, "conv_fused: unknown DCGP_FUSED_ABL value %d", abl); }
 #undef CF_ABL
     LAUNCH_CHECK(ctx);
     return DCGP_OK;
   }
+#endif
   switch (p.shape) {
     case 0: return launch_fused<4, 2, 2, 1024>(ctx, a, p.lds);
     case 1: return launch_fused<4, 1, 2, 512>(ctx, a, p.lds);

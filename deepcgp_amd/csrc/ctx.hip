@@ -282,7 +282,11 @@ int dcgp_timing_names(dcgp_ctx* ctx, char* buf, size_t buflen) {
 }  // extern "C"
 
 long col_ld(long columns) {
-  static long skew = -1;
+#ifdef DCGP_EXPERIMENTS
+  static long skew = -1;   // timing build only
   if (skew < 0) { const char* e = getenv("DCGP_LD_SKEW"); skew = e ? atol(e) : 0; if (skew < 0 || (skew & 1)) skew = 0; }
   return round_up_l(columns, 128) + skew;
+#else
+  return round_up_l(columns, 128);
+#endif
 }

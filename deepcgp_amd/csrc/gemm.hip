@@ -288,7 +288,11 @@ int launch(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
   size_t red = (size_t)WAVES_M * BN * sizeof(double);
   if (red > lds) lds = red;
   GemmArgs k = a;
-  static const bool mixed = getenv("DCGP_RB_MIXED") != nullptr;   // A/B switch: Thue-Morse mixed order for launches of many rounds
+#ifdef DCGP_EXPERIMENTS
+  static const bool mixed = getenv("DCGP_RB_MIXED") != nullptr;   // timing build only: Thue-Morse mixed order for launches of many rounds
+#else
+  constexpr bool mixed = false;
+#endif
   k.rb_major = a.tri != 0 && (nwg <= 1024 || !mixed);
   hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WAVES_M, WAVES_N, ABL>), dim3((unsigned)nwg), dim3(NT), lds, ctx->stream,
                      k, nct, nrb);
@@ -298,11 +302,17 @@ int launch(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
 
 }  // namespace
 
+// Timing builds (make EXPERIMENTS=1) read DCGP_GEMM_ABLATE: tuning / timing experiments (ablations 1..15 give wrong results);
+// the shipped library has no such switch.
+#ifdef DCGP_EXPERIMENTS
 static int gemm_variant() {
-  static int v = -1;   // DCGP_GEMM_ABLATE: tuning / timing experiments (ablations 1..15 give wrong results)
+  static int v = -1;
   if (v < 0) { const char* e = getenv("DCGP_GEMM_ABLATE"); v = e ? atoi(e) : 0; }
   return v;
 }
+#else
+static constexpr int gemm_variant() { return 0; }
+#endif
 
 // Row-block height for an Mi x Kc product with `batch` independent instances.  Large problems use 128-row tiles
 // (best reuse); problems that would not even put one workgroup on every CU use shorter tiles -- their run time is
@@ -329,6 +339,7 @@ int gemm_tn(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
   switch (gemm_row_block(a.Mi, a.Kc, a.nW * a.nB)) {
     case 128:
       switch (gemm_variant()) {
+#ifdef DCGP_EXPERIMENTS
         case 1: return launch<128, 128, 4, 2, 1>(ctx, a, nrb_out);
         case 7: return launch<128, 128, 4, 2, 7>(ctx, a, nrb_out);
         case 15: return launch<128, 128, 4, 2, 15>(ctx, a, nrb_out);
@@ -337,6 +348,7 @@ int gemm_tn(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
         case 104: return launch<128, 128, 4, 4, 4>(ctx, a, nrb_out);
         case 107: return launch<128, 128, 4, 4, 7>(ctx, a, nrb_out);
         case 115: return launch<128, 128, 4, 4, 15>(ctx, a, nrb_out);
+#endif
         default: return launch<128, 128, 4, 4>(ctx, a, nrb_out);   // 16 waves: +6% over 8 waves (more MFMA-phase waves per SIMD)
       }
     // short tiles = small problems whose run time is one workgroup's serial k-chain: spread each tile over 16

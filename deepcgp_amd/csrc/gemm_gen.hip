@@ -208,8 +208,9 @@ static int gemm_gen_launch(dcgp_ctx* ctx, const GenGemm& g, int slots_per_round)
     kchunk = round_up((g.K + ksplit - 1) / ksplit, GK);
     ksplit = (g.K + kchunk - 1) / kchunk;
     // one partial buffer per stream: the backward pass runs two chains concurrently
-    part = (double*)ws_get(ctx, ctx->stream == ctx->stream2 ? "gemm_gen_part_side" : "gemm_gen_part",
-                           (size_t)ksplit * g.batch * g.M * g.N * sizeof(double));
+    char pname[48];
+    snprintf(pname, sizeof pname, "gemm_gen_part@%p", (void*)ctx->stream);
+    part = (double*)ws_get(ctx, pname, (size_t)ksplit * g.batch * g.M * g.N * sizeof(double));
     if (!part) return DCGP_ERR_ALLOC;
   }
   if ((long)g.batch * ksplit > 65535) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_gen: batch %d x split %d too large", g.batch, ksplit);
@@ -248,14 +249,18 @@ int gemm_gen(dcgp_ctx* ctx, const GenGemm& g) {
   // the 1024-thread 128-tile (twice the flop per operand byte) pays off where it can fill its 512 slots, split included:
   // the tiled batch's contractions (K = 46080 columns at the headline size), M = 1024.  With a few thousand columns and
   // M = 256 (de-duplicated first layer) its ~270 workgroups lose to ~900 64-tiles (training step 2.05 -> 1.93 ms)
+#ifdef DCGP_EXPERIMENTS
   static const long big_fill = getenv("DCGP_GEMM_BIG_FILL") ? atol(getenv("DCGP_GEMM_BIG_FILL")) : 512;
+  static const long small_wgs = getenv("DCGP_GEMM_SMALL_WGS") ? atol(getenv("DCGP_GEMM_SMALL_WGS")) : 256;
+#else
+  constexpr long big_fill = 512, small_wgs = 256;
+#endif
   const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch / (g.lower_only ? 2 : 1);
   if (g.M >= 128 && g.N >= 128 && g.K >= 4096 && tiles128 * (g.K / 512) >= big_fill) return gemm_gen_launch<128, 1024, 32>(ctx, g, 512);
   // the M x M x M products of the Cholesky / KL adjoint chains would launch a few dozen 64-tile workgroups on 256 CUs and
   // take as long as one wave needs for its 32 x 32 x K block (K x 64 cycles of fp64 MFMA); 32-tiles with a 16 x 16 block per
   // wave put four times as many CUs to work on a quarter of that each.  Likewise the long contractions with a narrow
   // output (d alpha = A1 gm: M x R): a handful of tiles, split into 128-deep chunks instead of 512-deep ones
-  static const long small_wgs = getenv("DCGP_GEMM_SMALL_WGS") ? atol(getenv("DCGP_GEMM_SMALL_WGS")) : 256;
   const long wgs = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.batch / (g.lower_only ? 2 : 1);
   const long max_wgs = wgs * (g.K >= 2048 ? g.K / 512 : 1);   // what the 64-tile configuration could launch, split included
   if (max_wgs <= small_wgs) return gemm_gen_launch<32, 256, 16>(ctx, g, 1024);

@@ -1,0 +1,363 @@
+// head_units.hip -- ConvKernel.Kzx and ConvKernel.Kdiag of the head (conv_gp/kernels.py:106-133) in one launch,
+// cut into equal WAVE-sized units.
+//
+// What bounds these sweeps on gfx950 (tools/pipe_mix.hip, profiles/r03_pipe_mix.txt): v_mfma_f64_16x16x4_f64 and every
+// VALU instruction of a SIMD issue one after the other -- 64 cycles per MFMA, 4.4 per fp64 FMA, no overlap even across
+// waves.  A 16 x 16 tile of kernel values at patch length L costs ceil((L+2)/4) MFMAs plus, per value, whatever the
+// epilogue spends in the VALU, so the epilogue's instruction count is as much the kernel as the products are:
+//   * both operands arrive scaled by sqrt(log2(e))/lengthscale, and the two free slots behind a patch (L = 25 or 250
+//     pads to 28 / 252) carry (-|z|^2/2 + log2 variance, 1) against (1, -|x|^2/2): the MFMA accumulator IS the base-2
+//     exponent of the kernel value, no norm / scale arithmetic per value;
+//   * 2^t by a magic-number split (t + 1.5*2^52: integer part in the low mantissa word, no v_rndne / v_cvt), a
+//     degree-11 minimax polynomial on [-1/2, 1/2] (11 FMAs with scalar coefficient operands; |error| 2e-17) and
+//     v_ldexp_f64: 16 VALU instructions per value with the clamp, 17 with its weighted accumulation (the previous
+//     epilogue: 29 and 8 hazard nops);
+//   * chains of 8 values interleaved, so no dependent fp64 pair is adjacent (no s_nop).
+// Work decomposition: per image, one unit per 16-row fragment of Z (its Kzx row sums over all patches) and one per
+// PAIR of fragment rows (i, nf-1-i) of the symmetric patch Gram matrix (tiles on and right of the diagonal, off-diagonal
+// tiles counted twice) -- nf or nf+1 tile products each.  A workgroup is 4 waves = 4 units of one image behind ONE
+// image load and one pass of patch norms; waves never synchronise after that.  ~11 000 units at the headline size, so
+// the tail of the launch is one unit (~10 us) whatever the image count is relative to 256 CUs.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr double kExp2Magic = 6755399441055744.0;   // 1.5 * 2^52
+
+// 2^t for N values, interleaved step by step.  t is clamped at -1100 (ldexp then returns an exact zero; -inf would
+// otherwise leave NaN).  Relative error ~1.3e-16 of the polynomial evaluation plus what the argument carries.
+template <int N>
+__device__ __forceinline__ void exp2_n(double (&t)[N]) {
+  double u[N], r[N], p[N];
+  const double lo = -1100.0, magic = kExp2Magic;
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm("v_max_f64 %0, %1, %2" : "=v"(t[i]) : "v"(t[i]), "s"(lo));
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm("v_add_f64 %0, %1, %2" : "=v"(u[i]) : "v"(t[i]), "s"(magic));
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm("v_add_f64 %0, %1, -%2" : "=v"(r[i]) : "v"(u[i]), "s"(magic));   // rint(t)
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm("v_add_f64 %0, %1, -%2" : "=v"(r[i]) : "v"(t[i]), "v"(r[i]));     // |r| <= 1/2
+  double c11 = 4.4549605981865186e-10;
+  asm("" : "+v"(c11));   // one VGPR pair for the kernel's lifetime (a scalar operand is already taken by the addend)
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p[i]) : "v"(c11), "v"(r[i]), "s"(7.0725859492692234e-09));
+#define DCGP_E2(c)                          \
+  _Pragma("unroll") for (int i = 0; i < N; ++i) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p[i]) : "v"(p[i]), "v"(r[i]), "s"((double)(c)))
+  DCGP_E2(1.0178062445845774e-07);
+  DCGP_E2(1.3215442587921689e-06);
+  DCGP_E2(1.5252733829836119e-05);
+  DCGP_E2(0.0001540353044173605);
+  DCGP_E2(0.0013333558146416936);
+  DCGP_E2(0.0096181291076068882);
+  DCGP_E2(0.055504108664821597);
+  DCGP_E2(0.24022650695910097);
+  DCGP_E2(0.69314718055994529);
+  DCGP_E2(1.0);
+#undef DCGP_E2
+#pragma unroll
+  for (int i = 0; i < N; ++i) t[i] = __builtin_amdgcn_ldexp(p[i], __double2loint(u[i]));
+}
+
+// small-range integer division by a launch-time constant without the ~40-instruction sequence: q = floor((i + 0.5) / d)
+__device__ __forceinline__ int fdiv_small(int i, float inv_d) { return (int)(((float)i + 0.5f) * inv_d); }
+
+// NK4 > 0 (with TL = L & 3): the k extent is NK4 sub-steps of 4, known at compile time -- the A operand of a unit is fetched
+// once into registers, the patch-element offsets are per-lane constants, the product is straight-line code (L = 25: <7, 1>).
+// NK4 == 0: any patch length, both operands streamed (L = 250: 63 sub-steps).
+template <int NK4, int TL>
+__global__ __launch_bounds__(256, 2) void head_units_kernel(HeadUnitsArgs a) {
+  constexpr bool RES = NK4 > 0;
+  constexpr int NKR = RES ? NK4 : 1;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int HWC = a.HWC, L = a.L, nk4 = RES ? NK4 : a.Lq >> 2, nfp = a.nfp, P = a.P, np16 = nfp * 16;
+  const int HWCe = (HWC + 1) & ~1;
+  double* img = smem;                                   // [HWC] image times sqrt(c)
+  double* xb = img + HWCe;                              // [np16]  -c |x_p|^2 / 2
+  double* wl = xb + np16;                               // [np16]  patch weights, 0 beyond P
+  double* rs = wl + np16;                               // [H * Wr] row sums of squares (set-up only)
+  int* pbl = reinterpret_cast<int*>(rs + ((a.H * (a.W - a.f + 1) + 1) & ~1));   // [np16]  byte offset of the patch's first element in img
+  int* koff = pbl + np16;                               // [Lq]    byte offset of patch element l
+  const char* imgb = reinterpret_cast<const char*>(img);
+  const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.x / a.wgs_per_img, bw = blockIdx.x - n * a.wgs_per_img;
+  const double* __restrict__ Xn = a.X + (long)(n % a.n_mod) * HWC;
+  auto ldi = [&](int byte_off) { return *reinterpret_cast<const double*>(imgb + byte_off); };
+
+  // ---- set-up, once per workgroup: the scaled image, the offset tables, patch norms from a separable window sum ----
+  for (int i0 = 0; i0 < HWC; i0 += 8 * 256) {   // batches of 8 loads per thread: one memory latency for all of them
+    double t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = i0 + e * 256 + tid;
+      t[e] = (i < HWC) ? Xn[i] : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = i0 + e * 256 + tid;
+      if (i < HWC) img[i] = t[e] * a.csq;
+    }
+  }
+  for (int l = tid; l < a.Lq; l += 256) {
+    const int ll = l < L ? l : 0;
+    const int t = fdiv_small(ll, a.inv_C), c = ll - t * a.C;
+    const int kh = fdiv_small(t, a.inv_f), kw = t - kh * a.f;
+    koff[l] = ((kh * a.W + kw) * a.C + c) * 8;
+  }
+  for (int p = tid; p < np16; p += 256) {
+    const int q = p < P ? p : 0;                 // patches beyond P repeat the first one (finite values, weight 0)
+    const int oh = fdiv_small(q, a.inv_Wo), ow = q - oh * a.Wo;
+    pbl[p] = (oh * a.s * a.W + ow * a.s) * a.C * 8;
+    wl[p] = p < P ? a.w[p] : 0.0;
+  }
+  __syncthreads();
+  {
+    // rs[r][x] = sum over the f*C contiguous elements of image row r that a patch starting at column x covers
+    const int Wr = a.W - a.f + 1, fC = a.f * a.C;
+    for (int i = tid; i < a.H * Wr; i += 256) {
+      const int r = fdiv_small(i, a.inv_Wr), x = i - r * Wr;
+      const double* src = img + (r * a.W + x) * a.C;
+      double acc = 0.0;
+      for (int j = 0; j < fC; ++j) acc = fma(src[j], src[j], acc);
+      rs[i] = acc;
+    }
+    __syncthreads();
+    for (int p = tid; p < np16; p += 256) {
+      const int q = p < P ? p : 0;
+      const int oh = fdiv_small(q, a.inv_Wo), ow = q - oh * a.Wo;
+      const double* src = rs + oh * a.s * Wr + ow * a.s;
+      double acc = 0.0;
+      for (int kh = 0; kh < a.f; ++kh) acc += src[kh * Wr];
+      xb[p] = -0.5 * acc;
+    }
+  }
+  __syncthreads();
+
+  // this wave's unit: rotated by the image so that the empty slots of the last workgroup of an image (U % 4 != 0) do not
+  // always fall on the same SIMDs
+  const int u = a.u_lo + 4 * bw + ((wave + n) & 3);
+  if (u >= a.U) return;
+
+  // The operand slots k = 4 s + lrow behind the patch (k >= L) sit in the last one or two sub-steps (ts = s - sL): the A side
+  // (rows) carries (norm + log2 variance, 1) at k = L, L + 1, the B side (columns) (1, norm).  Per lane and tail sub-step:
+  //   operand = v * t_real + norm * t_nrm + t_one       (v: the gathered element; two FMAs where a select chain was ten)
+  const int sL = RES ? NK4 - (TL == 3 ? 2 : 1) : L >> 2;
+  double tB_real[2], tB_nrm[2], tB_one[2];
+#pragma unroll
+  for (int ts = 0; ts < 2; ++ts) {
+    const int k = 4 * (sL + ts) + lrow;
+    tB_real[ts] = k < L ? 1.0 : 0.0;
+    tB_one[ts] = k == L ? 1.0 : 0.0;
+    tB_nrm[ts] = k == L + 1 ? 1.0 : 0.0;
+  }
+  int kob[NKR];   // RES: byte offsets of this lane's patch elements, all sub-steps (0 for the slots behind the patch)
+  if (RES) {
+#pragma unroll
+    for (int s = 0; s < NKR; ++s) kob[s] = koff[4 * s + lrow];
+  }
+  auto fixB = [&](double v, int s, double nrm) {   // s >= sL (wave-uniform test at the call site)
+    const int ts = s - sL;
+    const double t0 = ts ? tB_real[1] : tB_real[0], t1 = ts ? tB_nrm[1] : tB_nrm[0], t2 = ts ? tB_one[1] : tB_one[0];
+    return fma(v, t0, fma(nrm, t1, t2));
+  };
+  auto fixA = [&](double v, int s, double nrm) {   // the A side carries the two slots the other way round
+    const int ts = s - sL;
+    const double t0 = ts ? tB_real[1] : tB_real[0], t1 = ts ? tB_one[1] : tB_one[0], t2 = ts ? tB_nrm[1] : tB_nrm[0];
+    return fma(v, t0, fma(nrm, t1, t2));
+  };
+
+  // NY column fragments starting at fragment j0 against one row fragment: product (operands of the next sub-step requested
+  // before the MFMAs of the current one), then 2^t and the weighted row sums.  getA(s): the A operand of sub-step s.
+  // `pre`: the caller has already put this group's patch offsets into pb and its sub-step-0 operands into bv (requested
+  // before the previous group's epilogue); next_j0 >= 0: do the same for the group that follows.
+  auto group = [&](auto ny_tag, auto&& getA, int j0, int next_j0, auto next_tag, double sym_off, int diag_j, double (&rsum)[4], int (&pb)[4], double (&bv)[4]) {
+    constexpr int NY = decltype(ny_tag)::value;
+    constexpr int NYN = decltype(next_tag)::value;
+    d4 acc[NY];
+#pragma unroll
+    for (int y = 0; y < NY; ++y) acc[y] = d4{0.0, 0.0, 0.0, 0.0};
+    auto xbv = [&](int y) { return xb[16 * (j0 + y) + lcol]; };
+    if (RES) {
+#pragma unroll
+      for (int s = 0; s < NKR; ++s) {
+        double bn[NY];
+        if (s + 1 < NKR) {
+#pragma unroll
+          for (int y = 0; y < NY; ++y) bn[y] = ldi(pb[y] + kob[s + 1]);
+        }
+        const double av = getA(s);
+        if (s >= sL) {
+#pragma unroll
+          for (int y = 0; y < NY; ++y) bv[y] = fixB(bv[y], s, xbv(y));
+        }
+#pragma unroll
+        for (int y = 0; y < NY; ++y) acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[y], acc[y], 0, 0, 0);
+        if (s + 1 < NKR) {
+#pragma unroll
+          for (int y = 0; y < NY; ++y) bv[y] = bn[y];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one sub-step of prefetch, not all of them (the scheduler would hoist every gather: 56 registers)
+      }
+    } else {
+      double av = getA(0);
+      for (int s = 0; s < nk4; ++s) {
+        const int sn = min(s + 1, nk4 - 1);
+        const int ko = koff[4 * sn + lrow];
+        const double an = getA(sn);
+        double bn[NY];
+#pragma unroll
+        for (int y = 0; y < NY; ++y) bn[y] = ldi(pb[y] + ko);
+        if (s >= sL) {
+#pragma unroll
+          for (int y = 0; y < NY; ++y) bv[y] = fixB(bv[y], s, xbv(y));
+        }
+#pragma unroll
+        for (int y = 0; y < NY; ++y) acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[y], acc[y], 0, 0, 0);
+        av = an;
+#pragma unroll
+        for (int y = 0; y < NY; ++y) bv[y] = bn[y];
+      }
+    }
+    // weights of this group's columns, then the next group's first operands on their way before the VALU-only epilogue
+    double wc[NY];
+#pragma unroll
+    for (int y = 0; y < NY; ++y) wc[y] = wl[16 * (j0 + y) + lcol] * (j0 + y == diag_j ? 1.0 : sym_off);
+    if (NYN > 0) {
+      const int ko0 = RES ? kob[0] : koff[lrow];
+#pragma unroll
+      for (int y = 0; y < NYN; ++y) {
+        pb[y] = pbl[16 * (next_j0 + y) + lcol];
+        bv[y] = ldi(pb[y] + ko0);
+      }
+    }
+#pragma unroll
+    for (int y = 0; y < NY; ++y) {   // four chains at a time: a dependent pair is three instructions apart
+      double t[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) t[v] = acc[y][v];
+      exp2_n<4>(t);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) rsum[v] = fma(wc[y], t[v], rsum[v]);
+    }
+  };
+  using T0 = std::integral_constant<int, 0>;
+  using T1 = std::integral_constant<int, 1>;
+  using T4 = std::integral_constant<int, 4>;
+
+  // one row fragment against column fragments [j_lo, nfp): groups of four, then the remaining 0..3 one at a time
+  auto row_pass = [&](auto&& getA, int j_lo, double sym_off, int diag_j, double (&rsum)[4]) {
+    const int nfull = (nfp - j_lo) >> 2, nrem = (nfp - j_lo) & 3;
+    int pb[4];
+    double bv[4];
+    const int ko0 = RES ? kob[0] : koff[lrow];
+    int j0 = j_lo;
+    if (nfull) {
+#pragma unroll
+      for (int y = 0; y < 4; ++y) { pb[y] = pbl[16 * (j0 + y) + lcol]; bv[y] = ldi(pb[y] + ko0); }
+      for (int g = 0; g < nfull - 1; ++g, j0 += 4) group(T4{}, getA, j0, j0 + 4, T4{}, sym_off, diag_j, rsum, pb, bv);
+      if (nrem) group(T4{}, getA, j0, j0 + 4, T1{}, sym_off, diag_j, rsum, pb, bv);
+      else group(T4{}, getA, j0, -1, T0{}, sym_off, diag_j, rsum, pb, bv);
+      j0 += 4;
+    } else if (nrem) {
+      pb[0] = pbl[16 * j0 + lcol]; bv[0] = ldi(pb[0] + ko0);
+    }
+    for (int q = 0; q < nrem; ++q, ++j0) {
+      if (q + 1 < nrem) group(T1{}, getA, j0, j0 + 1, T1{}, sym_off, diag_j, rsum, pb, bv);
+      else group(T1{}, getA, j0, -1, T0{}, sym_off, diag_j, rsum, pb, bv);
+    }
+  };
+
+  if (u < a.nfm) {
+    // ---- Kzx rows 16 u .. 16 u + 15: out[m][n] = scale * sum_p w_p k(z_m, x_p) ----
+    const double* __restrict__ zs = a.ZS + 16 * u + lcol;
+    double rsum[4] = {0.0, 0.0, 0.0, 0.0};
+    if (RES) {
+      double areg[NKR];
+#pragma unroll
+      for (int s = 0; s < NKR; ++s) areg[s] = zs[(long)(4 * s + lrow) * a.Mp];
+      row_pass([&](int s) { return areg[s]; }, 0, 1.0, -1, rsum);
+    } else {
+      row_pass([&](int s) { return zs[(long)(4 * s + lrow) * a.Mp]; }, 0, 1.0, -1, rsum);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      double s = rsum[v];
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      s += __shfl_xor(s, 8);
+      const int m = 16 * u + lrow + 4 * v;
+      if (lcol == 0 && m < a.kzx_rows) a.kzx[(long)m * a.ldk + n] = m < a.M ? a.kzx_scale * s : 0.0;
+    }
+  } else {
+    // ---- Kdiag: fragment rows i and nfp - 1 - i of the patch Gram matrix, tiles on and right of the diagonal ----
+    const int i = u - a.nfm;
+    double total = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+      const int fr = pass == 0 ? i : nfp - 1 - i;
+      if (pass == 1 && fr <= i) break;
+      const int pr = 16 * fr + lcol;
+      const int pa = pbl[pr];
+      const double xav = xb[pr] + a.log2var;
+      double rsum[4] = {0.0, 0.0, 0.0, 0.0};
+      auto getA_img = [&](int s, int ko) {
+        double v = ldi(pa + ko);
+        if (s >= sL) v = fixA(v, s, xav);
+        return v;
+      };
+      if (RES) {
+        double areg[NKR];
+#pragma unroll
+        for (int s = 0; s < NKR; ++s) areg[s] = getA_img(s, kob[s]);
+        row_pass([&](int s) { return areg[s]; }, fr, 2.0, fr, rsum);
+      } else {
+        row_pass([&](int s) { return getA_img(s, koff[4 * s + lrow]); }, fr, 2.0, fr, rsum);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) total = fma(wl[16 * fr + lrow + 4 * v], rsum[v], total);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) total += __shfl_xor(total, o);
+    if (lane == 0) a.kd[(long)n * a.n_kd + i] = total;
+  }
+}
+
+}  // namespace
+
+static size_t head_units_lds(const HeadUnitsArgs& a) {
+  return (size_t)(((a.HWC + 1) & ~1) + 2 * a.nfp * 16 + ((a.H * (a.W - a.f + 1) + 1) & ~1)) * sizeof(double) +
+         (size_t)(a.nfp * 16 + a.Lq) * sizeof(int);
+}
+
+bool head_units_ok(const HeadUnitsArgs& a) {
+  return head_units_lds(a) <= 64 * 1024 && (long)a.Lq * a.Mp * 8 < (1L << 31);
+}
+
+// fills the derived fields of `a` (fragment counts, units per image)
+void head_units_plan(HeadUnitsArgs* a) {
+  a->HWC = a->H * a->W * a->C;
+  a->nfm = a->Mp / 16;
+  a->nfp = (a->P + 15) / 16;
+  a->n_kd = (a->nfp + 1) / 2;
+  a->U = a->kd ? a->nfm + a->n_kd : a->nfm;     // no Kdiag output: the Kzx units only
+  a->u_lo = a->kzx ? 0 : a->nfm;                // no Kzx output: the Kdiag units only
+  a->wgs_per_img = (a->U - a->u_lo + 3) / 4;
+  if (a->kzx_rows <= 0) a->kzx_rows = a->Mp;
+  a->inv_C = 1.0f / (float)a->C; a->inv_f = 1.0f / (float)a->f; a->inv_Wo = 1.0f / (float)a->Wo; a->inv_Wr = 1.0f / (float)(a->W - a->f + 1);
+}
+
+int head_units(dcgp_ctx* ctx, const HeadUnitsArgs& a) {
+  if (a.N <= 0) return DCGP_OK;
+  if (!head_units_ok(a) || a.n_mod <= 0 || a.Lq != round_up(a.L + 2, 4) || a.Mp % 16)
+    return ctx_fail(ctx, DCGP_ERR_ARG, "head_units: unsupported shape (image %d doubles, L = %d, Mp = %d)", a.HWC, a.L, a.Mp);
+  const long nwg = (long)a.N * a.wgs_per_img;
+  if (nwg > 0x7fffffffL) return ctx_fail(ctx, DCGP_ERR_ARG, "head_units: too many workgroups");
+  const size_t lds = head_units_lds(a);
+  ScopedTimer t(ctx, "head_sweep");
+  if (a.L == 25) hipLaunchKernelGGL((head_units_kernel<7, 1>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);   // 5 x 5 x 1 patches
+  else hipLaunchKernelGGL((head_units_kernel<0, 0>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}

@@ -40,6 +40,7 @@ struct PrepLayerArgs {
   int M = 0, Mp = 0, L = 0, Lp = 0, R = 0, Rp = 0;
   BaseKernel bk; double jitter = 0.0;
   const double* in_scale = nullptr;   // [L] or nullptr: Z is read as Z * in_scale (ARD lengthscales)
+  double* ZS = nullptr; int Lz = 0;   // the sweeps' scaled operand (sweep_dev.h); nullptr: not an RBF layer
 };
 struct PrepArgs {
   int nl = 0;

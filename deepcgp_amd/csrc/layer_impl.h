@@ -38,9 +38,10 @@ struct LayerState {
   // step i + 1 can run while the data path of step i still reads the other bank (dcgp_elbo_forward_enqueue).  g / ZT / zn are the
   // bank in use (use_bank); bank 1 is allocated on first use.
   GpMats g;
-  double *ZT = nullptr, *zn = nullptr;
+  double *ZT = nullptr, *zn = nullptr, *ZS = nullptr;   // ZS: the sweeps' scaled operand [Lq][Mp] (sweep_dev.h)
+  int Lz = 0;   // rows of ZS: patch length + the two norm slots, padded to a multiple of 4
   GpMats gbank[2];
-  double *ZTb[2] = {}, *znb[2] = {};
+  double *ZTb[2] = {}, *znb[2] = {}, *ZSb[2] = {};
   bool need_prior_ = true;
   // gradients of the ELBO with respect to the (constrained) parameter values, caller's layouts (grad.hip); allocated on
   // first use.  gscal = {d variance, d p1, d p2} (p1 = lengthscale | ArcCosine weight variance, p2 = ArcCosine bias variance);
@@ -74,6 +75,7 @@ struct LayerState {
     M = M_; R = R_; white = white_; identity_mean = idm; kernel_type = ktype; variance = var; ls = ls_;
     Mp = round_up(M, 16);
     Lp = round_up(v.L, 4);
+    Lz = sweep_lq(v.L);
     Z = dalloc((size_t)M * v.L);
     Z0 = head ? nullptr : dalloc((size_t)M * v.L);
     q_mu = dalloc((size_t)M * R);
@@ -98,6 +100,7 @@ struct LayerState {
     else { q.G = dalloc((size_t)R * mm); q.alpha = dalloc((size_t)Mp * q.Rp); q.klp = dalloc((size_t)(R + 1) * (Mp / 16 + 1)); }
     ZTb[b] = dalloc((size_t)Lp * Mp);
     znb[b] = dalloc(Mp);
+    ZSb[b] = dalloc((size_t)Lz * Mp);
   }
   int use_bank(int b) {
     if (!gbank[b].K) {
@@ -106,7 +109,7 @@ struct LayerState {
       for (size_t i = before; i < owned.size(); ++i)
         if (!owned[i]) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: device allocation failed");
     }
-    g = gbank[b]; ZT = ZTb[b]; zn = znb[b];
+    g = gbank[b]; ZT = ZTb[b]; zn = znb[b]; ZS = ZSb[b];
     return DCGP_OK;
   }
   // one contiguous block per layer [gZ | gq_mu | gq_sqrt | gw | gscal] so that a single all-reduce covers the layer
@@ -153,6 +156,7 @@ struct LayerState {
     p.K = g.K; p.Kp = g.Kp; p.ZT = ZT; p.zn = zn; p.Lq = g.Lq; p.qmu = g.qmu;
     p.M = M; p.Mp = Mp; p.L = v.L; p.Lp = Lp; p.R = R; p.Rp = g.Rp;
     p.bk = base(); p.jitter = jitter; p.in_scale = in_scale;
+    p.ZS = base_type == 0 ? ZS : nullptr; p.Lz = Lz;
     return p;
   }
   // step 1 of the forward: everything that depends only on this layer's parameters
@@ -160,6 +164,7 @@ struct LayerState {
     DCGP_TRY(rbf_gram_padded(ctx, Z, M, v.L, base(), jitter, g.K, Mp, Mp));
     if (g.Kp) DCGP_TRY(rbf_gram_padded(ctx, Z0, M, v.L, base(), jitter, g.Kp, Mp, Mp));
     DCGP_TRY(z_transpose_norms(ctx, Z, M, v.L, ZT, Mp, Lp, zn));
+    if (base_type == 0) DCGP_TRY(sweep_operand(ctx, Z, in_scale, M, Mp, v.L, variance, ls, ZS));
     if (has_qsqrt)
       DCGP_TRY(pad_copy(ctx, q_sqrt, M, M, M, g.Lq, Mp, Mp, Mp, 1, R, (long)M * M, (long)Mp * Mp));
     DCGP_TRY(pad_copy(ctx, q_mu, M, R, R, g.qmu, g.Rp, Mp, g.Rp, 0, 1, 0, 0));
@@ -316,6 +321,34 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   a.in_scale = L.in_scale;
   a.share_cu = phase == 1;
   static const bool unfused = getenv("DCGP_HEAD_UNFUSED") != nullptr;   // A/B switch
+  if (phase == 3 && L.kernel_type == 0 && a.bk.type == 0 && !L.in_scale && !getenv("DCGP_HEAD_OLD_SWEEP")) {
+    // ConvKernel head: Kzx and Kdiag as wave-sized units of one launch (head_units.hip), any M
+    HeadUnitsArgs h;
+    h.X = X; h.n_mod = n_mod; h.N = rows;
+    h.H = L.v.H; h.W = L.v.W; h.C = L.v.C; h.f = L.v.f; h.s = L.v.s; h.Wo = L.v.Wo; h.P = L.v.P; h.L = L.v.L; h.Lq = L.Lz;
+    h.ZS = L.ZS; h.M = L.M; h.Mp = Mp;
+    h.csq = sqrt(1.4426950408889634074) / L.ls; h.log2var = log2(L.variance);
+    h.w = L.w; h.kzx = B; h.ldk = ldb; h.kzx_scale = 1.0 / (double)L.v.P;
+    h.kd = (double*)ws_get(ctx, "kdiag_partial", (size_t)rows * ((L.v.P + 31) / 32) * sizeof(double));
+    if (!h.kd) return DCGP_ERR_ALLOC;
+    head_units_plan(&h);
+    if (head_units_ok(h)) {
+      DCGP_TRY(head_units(ctx, h));
+      const double kd_scale = 1.0 / ((double)L.v.P * (double)L.v.P);
+      if (prep_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, prep_done, 0));
+      else if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
+      if (head_cond_fused_ok(L.g) && !unfused)
+        return head_cond_fused(ctx, L.g, B, ldb, rows, L.has_qsqrt, h.kd, out_mean, out_var, h.n_kd, kd_scale);
+      DCGP_TRY(kdiag_reduce(ctx, h.kd, h.n_kd, rows, kd_scale, kd));
+      CondScratch sc;
+      DCGP_TRY(cond_core(ctx, L.g, B, ldb, rows, L.white, L.has_qsqrt, pfx.c_str(), &sc, nullptr, true));
+      FinalizeArgs fa;
+      fa.s1p = sc.s1p; fa.nrb1 = sc.nrb1; fa.s2p = sc.s2p; fa.nrb3 = sc.nrb3; fa.mu = sc.mu; fa.ldk = ldb;
+      fa.Kc = rows; fa.R = L.R; fa.knn_vec = kd;
+      fa.out_mean = out_mean; fa.out_var = out_var;
+      return finalize_layer(ctx, fa);
+    }
+  }
   if (phase == 3 && L.kernel_type == 0 && a.bk.type == 0 && head_cond_fused_ok(L.g) && !unfused && !getenv("DCGP_HEAD_TWO_SWEEPS")) {
     // ConvKernel head, M <= 256: Kzx and Kdiag in one launch, then the whole conditional in one launch that adds up the Kdiag
     // tile-pair sums itself -- two launches on one stream for the layer

@@ -187,7 +187,10 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
 
   // ---- the parameter-only chain ----
   ctx->stream = chain_s;
-  ctx->ws_tag = bank ? "~b1" : "";   // its scratch per bank: the chains / KL terms of two steps in flight may overlap
+  // its scratch per model and bank: the chains / KL terms of two steps in flight may overlap, and with the deferred copy the tail
+  // launch reads the prior factor's diagonal out of this scratch at the END of the step -- another model's chain on the same
+  // ctx must not have overwritten it by then
+  ctx->ws_tag = "~m" + std::to_string(m->id) + "b" + std::to_string(bank);
   if (chain_s != main_s) {
     if (m->done_valid[bank]) HIP_TRY(ctx, hipStreamWaitEvent(chain_s, m->done_ev[bank], 0));   // the bank's previous reader
     else if (ctx->ev_last_valid) HIP_TRY(ctx, hipStreamWaitEvent(chain_s, ctx->ev_last, 0));    // first use: behind whatever ran last
@@ -365,8 +368,9 @@ int dcgp_model_destroy(dcgp_model* model) {
   // the per-model workspaces of the forward / reverse pass live in the ctx under "m<id>_..." (the training step's are large:
   // R x M x columns doubles per conv layer); they go with the model
   const std::string pfx = "m" + std::to_string(model->id) + "_";
+  const std::string tag = "~m" + std::to_string(model->id) + "b";   // the chain's scratch (forward_all's ws_tag)
   for (auto it = ctx->ws.begin(); it != ctx->ws.end();) {
-    if (it->first.compare(0, pfx.size(), pfx) == 0) {
+    if (it->first.compare(0, pfx.size(), pfx) == 0 || it->first.find(tag) != std::string::npos) {
       hipFree(it->second.first);
       it = ctx->ws.erase(it);
     } else {

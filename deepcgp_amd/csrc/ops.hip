@@ -290,12 +290,43 @@ int dcgp_conv_layer_forward(dcgp_ctx* ctx, const double* X, int N, int H, int W,
   return DCGP_OK;
 }
 
+// ConvKernel.Kzx / Kdiag through the unit sweep (head_units.hip): what the model-level head runs.  false: shape not covered
+static bool convkernel_units(dcgp_ctx* ctx, const double* X, int N, const ViewGeom& v, const double* Z, int M, double variance,
+                             double lengthscale, const double* w, double* out_MN, double* out_N, int* rc) {
+  if (getenv("DCGP_HEAD_OLD_SWEEP")) return false;   // A/B switch: the separate Kzx / Kdiag sweeps of rbf.hip
+  HeadUnitsArgs h;
+  h.X = X; h.n_mod = N; h.N = N;
+  h.H = v.H; h.W = v.W; h.C = v.C; h.f = v.f; h.s = v.s; h.Wo = v.Wo; h.P = v.P; h.L = v.L; h.Lq = sweep_lq(v.L);
+  h.M = Z ? M : 16; h.Mp = round_up(h.M, 16);
+  h.csq = sqrt(1.4426950408889634074) / lengthscale; h.log2var = log2(variance);
+  h.w = w; h.kzx = out_MN; h.ldk = N; h.kzx_rows = M; h.kzx_scale = 1.0 / (double)v.P;
+  *rc = DCGP_OK;
+  if (out_N) {
+    h.kd = (double*)ws_get(ctx, "kdiag_partial", (size_t)N * ((v.P + 31) / 32) * sizeof(double));
+    if (!h.kd) { *rc = DCGP_ERR_ALLOC; return true; }
+  }
+  head_units_plan(&h);
+  if (!head_units_ok(h)) return false;
+  if (Z) {
+    double* ZS = (double*)ws_get(ctx, "op_ZS", (size_t)h.Lq * h.Mp * sizeof(double));
+    if (!ZS) { *rc = DCGP_ERR_ALLOC; return true; }
+    if ((*rc = sweep_operand(ctx, Z, nullptr, M, h.Mp, v.L, variance, lengthscale, ZS)) != DCGP_OK) return true;
+    h.ZS = ZS;
+  }
+  if ((*rc = head_units(ctx, h)) != DCGP_OK) return true;
+  if (out_N) *rc = kdiag_reduce(ctx, h.kd, h.n_kd, N, 1.0 / ((double)v.P * (double)v.P), out_N);
+  if (*rc == DCGP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) *rc = ctx_fail(ctx, DCGP_ERR_HIP, "convkernel: stream synchronisation failed");
+  return true;
+}
+
 int dcgp_convkernel_kzx(dcgp_ctx* ctx, const double* X, int N, int H, int W, int C, int f, int stride, const double* Z,
                         int M, double variance, double lengthscale, const double* w, double* out_MN) {
   ARG_CHECK(ctx && X && Z && w && out_MN && N > 0 && M > 0 && f > 0 && stride > 0 && f <= H && f <= W && C > 0 &&
                 variance > 0 && lengthscale > 0, "convkernel_kzx: bad args");
   ViewGeom v;
   v.set(H, W, C, f, stride);
+  int urc = DCGP_OK;
+  if (convkernel_units(ctx, X, N, v, Z, M, variance, lengthscale, w, out_MN, nullptr, &urc)) return urc;
   const int Mp = round_up(M, 16), Lp = round_up(v.L, 4);
   double* ZT = (double*)ws_get(ctx, "op_ZT", (size_t)Lp * Mp * sizeof(double));
   double* zn = (double*)ws_get(ctx, "op_zn", (size_t)Mp * sizeof(double));
@@ -317,6 +348,12 @@ int dcgp_convkernel_kdiag(dcgp_ctx* ctx, const double* X, int N, int H, int W, i
                           double lengthscale, const double* w, double* out_N) {
   ARG_CHECK(ctx && X && w && out_N && N > 0 && f > 0 && stride > 0 && f <= H && f <= W && C > 0 && variance > 0 &&
                 lengthscale > 0, "convkernel_kdiag: bad args");
+  {
+    ViewGeom v;
+    v.set(H, W, C, f, stride);
+    int urc = DCGP_OK;
+    if (convkernel_units(ctx, X, N, v, nullptr, 0, variance, lengthscale, w, nullptr, out_N, &urc)) return urc;
+  }
   DCGP_TRY(head_kdiag(ctx, X, N, N, H, W, C, f, stride, rbf_bk(variance, lengthscale), w, out_N));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return DCGP_OK;

@@ -3,9 +3,11 @@
 //   task 2    Z^T (k-major, zero padded) and |z|^2                                    (operands of the patch sweep)
 //   task 3    lower-masked, zero-padded q_sqrt  (matrix_band_part, conv_gp/conditionals.py:55)
 //   task 4    zero-padded q_mu
+//   task 5    the sweeps' scaled Z operand (sweep_dev.h)
 // These are ~5 tiny launches per layer when issued one by one; at ~5 us of launch latency each they cost more
 // than the work itself and sit on the critical path in front of the factorisation chain.
 #include "layer.h"
+#include "sweep_dev.h"
 
 namespace {
 
@@ -132,6 +134,14 @@ __global__ __launch_bounds__(256) void prepare_all_kernel(PrepArgs a) {
         }
       }
       break;
+    case 5:
+      if (p.ZS) {
+        ZsTask z;
+        z.Z = p.Z; z.in_scale = p.in_scale; z.ZS = p.ZS; z.M = p.M; z.Mp = p.Mp; z.L = p.L; z.Lq = p.Lz;
+        z.csq = sqrt(1.4426950408889634074 * p.bk.p1); z.log2var = log2(p.bk.variance);
+        zs_task(z, bx, nbx);
+      }
+      break;
     default: {
       const long total = (long)p.Mp * p.Rp;
       for (long idx = (long)bx * 256 + threadIdx.x; idx < total; idx += (long)nbx * 256) {
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(256) void prepare_all_kernel(PrepArgs a) {
 int prepare_all(dcgp_ctx* ctx, const PrepArgs& a) {
   if (a.nl <= 0) return DCGP_OK;
   ScopedTimer t(ctx, "prepare");
-  hipLaunchKernelGGL(prepare_all_kernel, dim3(256, 5, a.nl), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL(prepare_all_kernel, dim3(256, 6, a.nl), dim3(256), 0, ctx->stream, a);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }

@@ -12,6 +12,7 @@
 // v_mfma_f64_16x16x4_f64; |x_p|^2 is accumulated from the same operand registers; the epilogue applies
 // exp(-0.5 (|z|^2+|x|^2-2 z.x)/l^2) in fp64 and writes 16-double contiguous row segments.
 #include "common.h"
+#include "sweep_dev.h"
 
 namespace {
 
@@ -508,6 +509,8 @@ __global__ void kdiag_reduce_kernel(const double* __restrict__ partial, int n_pa
   out[n] = s * scale;
 }
 
+__global__ __launch_bounds__(256) void zs_build_kernel(ZsTask t) { zs_task(t, blockIdx.x, gridDim.x); }
+
 __global__ void extract_patches_kernel(const double* __restrict__ X, int N, int H, int W, int C, int f, int s,
                                        int Ho, int Wo, double* __restrict__ out, int pnl) {
   const int P = Ho * Wo, L = f * f * C;
@@ -538,6 +541,22 @@ int rbf_gram_padded(dcgp_ctx* ctx, const double* Z, int M, int L, BaseKernel bk,
 
 int z_transpose_norms(dcgp_ctx* ctx, const double* Z, int M, int L, double* ZT, int Mp, int Lp, double* zn) {
   hipLaunchKernelGGL(z_transpose_kernel, dim3((Mp + 31) / 32), dim3(256), 0, ctx->stream, Z, M, L, ZT, Mp, Lp, zn);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
+// the sweeps' scaled Z operand (sweep_dev.h) for callers outside the one-launch prepare_all
+int sweep_operand(dcgp_ctx* ctx, const double* Z, const double* in_scale, int M, int Mp, int L, double variance, double lengthscale, double* ZS) {
+  ZsTask t;
+  t.Z = Z; t.in_scale = in_scale; t.ZS = ZS; t.M = M; t.Mp = Mp; t.L = L; t.Lq = sweep_lq(L);
+  t.csq = sqrt(1.4426950408889634074) / lengthscale; t.log2var = log2(variance);
+  hipLaunchKernelGGL(zs_build_kernel, dim3((Mp + 31) / 32), dim3(256), 0, ctx->stream, t);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
+int kdiag_reduce(dcgp_ctx* ctx, const double* partial, int n_parts, int N, double scale, double* out_N) {
+  hipLaunchKernelGGL(kdiag_reduce_kernel, dim3((N + 127) / 128), dim3(128), 0, ctx->stream, partial, n_parts, N, scale, out_N);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }

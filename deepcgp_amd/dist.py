@@ -7,8 +7,10 @@ exchange per step is a sum all-reduce of ONE float64 (the per-rank data term): a
 issued on the ctx stream inside ``dcgp_elbo_forward``.
 
 Host-side plumbing (who am I, hand the 128-byte RCCL id to the other ranks, start/stop the clock together)
-needs no framework: ``HostGroup`` is a few dozen lines of TCP on the loopback/cluster interface -- rank 0
-listens, the others connect, every exchange is gather-to-0 + broadcast.  It is used for set-up and for the
+needs no framework: ``HostGroup`` is a few dozen lines of TCP -- rank 0 listens on MASTER_ADDR (loopback by
+default), the others connect, every exchange is gather-to-0 + broadcast.  SINGLE NODE: the port rank 0 picked is
+published through a file (mode 0600) that all ranks must see, which is what one node with 8 GPUs -- the
+configuration this path is built for -- gives.  It is used for set-up and for the
 timing barriers only, never on the data path.  ``spawn_ranks`` starts one process per GPU when the caller was
 not already launched by a process launcher (RANK / WORLD_SIZE in the environment).
 """
@@ -97,12 +99,16 @@ class HostGroup:
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind(("", 0))
+            try:
+                srv.bind((addr, 0))        # the interface the other ranks connect to, not every interface
+            except OSError:
+                srv.bind(("127.0.0.1", 0))
             srv.listen(self.world)
             srv.settimeout(timeout)
-            token = os.urandom(8).hex()
+            token = os.urandom(16).hex()
             tmp = path + ".%d.tmp" % os.getpid()
-            with open(tmp, "w") as fh:
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)   # the token is the group's only credential
+            with os.fdopen(fd, "w") as fh:
                 json.dump({"port": srv.getsockname()[1], "token": token}, fh)
             os.replace(tmp, path)          # atomic: a reader sees the old file or the new one, never half of it
             self._path = path
@@ -197,10 +203,19 @@ def spawn_ranks(n, argv=None, env=None):
         e.setdefault("MASTER_ADDR", "127.0.0.1")
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs across processes on this driver
         procs.append(subprocess.Popen([sys.executable] + argv, env=e, stdout=None if r == 0 else subprocess.DEVNULL))
+    # a rank that dies takes the others with it (they would otherwise sit in a group exchange until the socket timeout)
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            if p.poll() is None:
+                continue
+            live.remove(p)
+            if p.returncode and not rc:
+                rc = p.returncode
+                for q in live:
+                    q.terminate()
     try:
         os.unlink(path)
     except OSError:

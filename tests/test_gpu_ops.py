@@ -371,6 +371,54 @@ def test_head_kernels(ctx, H, W, C, f, s, M):
     close(a.Kdiag(X), oa.Kdiag(X), 1e-12, "add Kdiag")
 
 
+@pytest.mark.parametrize("H,W,C,f,s,M,N", [(7, 7, 1, 2, 1, 5, 3),        # L = 4: the norm slots need a sub-step of their own
+                                            (6, 6, 3, 1, 1, 3, 2),        # L = 3: slots split over two sub-steps
+                                            (8, 8, 2, 3, 2, 17, 5),       # L = 18, stride 2, P = 9 < 16
+                                            (10, 10, 1, 5, 1, 16, 6),     # 5 x 5 x 1 patches: the register-resident form, P = 36
+                                            (28, 28, 1, 5, 1, 256, 3),    # the MNIST head at full size (36 column fragments)
+                                            (28, 28, 1, 5, 1, 40, 1),
+                                            (13, 11, 10, 5, 1, 33, 4)])   # L = 250, P = 63, M not a multiple of 16
+def test_head_unit_sweep(ctx, H, W, C, f, s, M, N):
+    """ConvKernel.Kzx / Kdiag (conv_gp/kernels.py:106-133) through the unit sweep (csrc/head_units.hip): every slot layout of the
+    folded norms, ragged patch and inducing counts, signed patch weights, and image rows far from everything (underflow)."""
+    from deepcgp_amd.kernels import RBF, ConvKernel
+    from deepcgp_amd.views import FullView
+    rng = np.random.default_rng(11 * M + H)
+    X = rng.standard_normal((N, H * W * C))
+    X[0, : H * W * C // 2] += 6.0           # half an image far away: kernel values down to exp(-hundreds)
+    v, ov = FullView((H, W, C), f, C, s), OFullView((H, W, C), f, C, s)
+    w = rng.standard_normal(v.patch_count)
+    Z = rng.standard_normal((M, v.patch_length))
+    for var, ls in ((5.0, 5.0), (0.7, 1.3)):
+        k, okk = ConvKernel(RBF(v.patch_length, var, ls), v, w), OConvKernel(ORBF(v.patch_length, var, ls), ov, w)
+        # (1e-11: with the shifted half image |x|^2 c reaches several thousand, and |x|^2 + |z|^2 - 2 x.z -- the reference's own
+        # square_dist form -- cancels to ~1e-12 whatever the order of the additions)
+        close(k.Kzx(Z, X), okk.Kzx(Z, X), 1e-11, "Kzx")
+        close(k.Kdiag(X), okk.Kdiag(X), 1e-11, "Kdiag")
+
+
+def test_head_unit_sweep_exp_accuracy(ctx):
+    """The unit sweep's 2^t (magic-number split + degree-11 minimax polynomial + ldexp) value by value: one patch per image
+    (P = 1, weight 1), one inducing patch at the origin, so Kzx[0, n] = variance * exp(-|x_n|^2 / (2 l^2)).  The exponent reaches the
+    kernel through the MFMA accumulator (both norms folded into the product), so its rounding error scales with |t|: relative error
+    <= (4 + |t|) ulp, exact zeros below the subnormal range, 1 ulp at t = 0."""
+    from deepcgp_amd.kernels import RBF, ConvKernel
+    from deepcgp_amd.views import FullView
+    rng = np.random.default_rng(0)
+    arg = -np.concatenate([[0.0, 1e-300, 1e-12, 0.5 * np.log(2) / 64, 700.0, 708.3, 745.0, 760.0, 800.0, 5000.0], rng.random(4000) * 745.0,
+                           rng.random(1000) * 1e-3])
+    X = np.zeros((arg.size, 25))
+    X[:, 7] = np.sqrt(-2.0 * arg)
+    v = FullView((5, 5, 1), 5, 1, 1)
+    got = ConvKernel(RBF(25, 1.0, 1.0), v, np.ones(1)).Kzx(np.zeros((1, 25)), X)[0]
+    want = np.exp(arg)
+    normal = want > 1e-300
+    rel = np.abs(got[normal] / want[normal] - 1.0)
+    assert np.all(rel <= 2.3e-16 * (4.0 + np.abs(arg[normal]))), rel.max()
+    assert np.all(np.abs(got[~normal] - want[~normal]) <= 1e-300) and got[arg < -765.0].max() == 0.0
+    assert abs(got[0] - 1.0) <= 2.3e-16
+
+
 @pytest.mark.parametrize("white", [False, True])
 def test_svgp_head(ctx, white):
     from deepcgp_amd.kernels import RBF, ConvKernel, PatchInducingFeatures
