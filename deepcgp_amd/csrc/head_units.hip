@@ -66,8 +66,21 @@ __device__ __forceinline__ int fdiv_small(int i, float inv_d) { return (int)(((f
 // NK4 > 0 (with TL = L & 3): the k extent is NK4 sub-steps of 4, known at compile time -- the A operand of a unit is fetched
 // once into registers, the patch-element offsets are per-lane constants, the product is straight-line code (L = 25: <7, 1>).
 // NK4 == 0: any patch length, both operands streamed (L = 250: 63 sub-steps).
+#ifndef HU_SB1
+#define HU_SB1 __builtin_amdgcn_sched_barrier(0)   // the gathers of sub-step s + 1 issue BEFORE the MFMAs of sub-step s
+#endif
+#ifndef HU_WAVES
+#define HU_WAVES 4
+#endif
+#ifndef HU_EXPN
+#define HU_EXPN 4
+#endif
+#ifndef HU_NT
+#define HU_NT 256          // threads per workgroup = 64 x units per workgroup
+#endif
+constexpr int HU_WPG = HU_NT / 64;
 template <int NK4, int TL>
-__global__ __launch_bounds__(256, 2) void head_units_kernel(HeadUnitsArgs a) {
+__global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsArgs a) {
   constexpr bool RES = NK4 > 0;
   constexpr int NKR = RES ? NK4 : 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -87,26 +100,26 @@ __global__ __launch_bounds__(256, 2) void head_units_kernel(HeadUnitsArgs a) {
   auto ldi = [&](int byte_off) { return *reinterpret_cast<const double*>(imgb + byte_off); };
 
   // ---- set-up, once per workgroup: the scaled image, the offset tables, patch norms from a separable window sum ----
-  for (int i0 = 0; i0 < HWC; i0 += 8 * 256) {   // batches of 8 loads per thread: one memory latency for all of them
+  for (int i0 = 0; i0 < HWC; i0 += 8 * HU_NT) {   // batches of 8 loads per thread: one memory latency for all of them
     double t[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int i = i0 + e * 256 + tid;
+      const int i = i0 + e * HU_NT + tid;
       t[e] = (i < HWC) ? Xn[i] : 0.0;
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int i = i0 + e * 256 + tid;
+      const int i = i0 + e * HU_NT + tid;
       if (i < HWC) img[i] = t[e] * a.csq;
     }
   }
-  for (int l = tid; l < a.Lq; l += 256) {
+  for (int l = tid; l < a.Lq; l += HU_NT) {
     const int ll = l < L ? l : 0;
     const int t = fdiv_small(ll, a.inv_C), c = ll - t * a.C;
     const int kh = fdiv_small(t, a.inv_f), kw = t - kh * a.f;
     koff[l] = ((kh * a.W + kw) * a.C + c) * 8;
   }
-  for (int p = tid; p < np16; p += 256) {
+  for (int p = tid; p < np16; p += HU_NT) {
     const int q = p < P ? p : 0;                 // patches beyond P repeat the first one (finite values, weight 0)
     const int oh = fdiv_small(q, a.inv_Wo), ow = q - oh * a.Wo;
     pbl[p] = (oh * a.s * a.W + ow * a.s) * a.C * 8;
@@ -114,17 +127,22 @@ __global__ __launch_bounds__(256, 2) void head_units_kernel(HeadUnitsArgs a) {
   }
   __syncthreads();
   {
-    // rs[r][x] = sum over the f*C contiguous elements of image row r that a patch starting at column x covers
+    // rs[r][x] = sum over the f*C contiguous elements of image row r that a patch starting at column x covers; 4 threads per entry
     const int Wr = a.W - a.f + 1, fC = a.f * a.C;
-    for (int i = tid; i < a.H * Wr; i += 256) {
-      const int r = fdiv_small(i, a.inv_Wr), x = i - r * Wr;
-      const double* src = img + (r * a.W + x) * a.C;
+    for (int i0 = 0; i0 < a.H * Wr; i0 += HU_NT / 4) {
+      const int i = i0 + (tid >> 2), part = tid & 3;
       double acc = 0.0;
-      for (int j = 0; j < fC; ++j) acc = fma(src[j], src[j], acc);
-      rs[i] = acc;
+      if (i < a.H * Wr) {
+        const int r = fdiv_small(i, a.inv_Wr), x = i - r * Wr;
+        const double* src = img + (r * a.W + x) * a.C;
+        for (int j = part; j < fC; j += 4) acc = fma(src[j], src[j], acc);
+      }
+      acc += __shfl_xor(acc, 1);
+      acc += __shfl_xor(acc, 2);
+      if (part == 0 && i < a.H * Wr) rs[i] = acc;
     }
     __syncthreads();
-    for (int p = tid; p < np16; p += 256) {
+    for (int p = tid; p < np16; p += HU_NT) {
       const int q = p < P ? p : 0;
       const int oh = fdiv_small(q, a.inv_Wo), ow = q - oh * a.Wo;
       const double* src = rs + oh * a.s * Wr + ow * a.s;
@@ -137,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void head_units_kernel(HeadUnitsArgs a) {
 
   // this wave's unit: rotated by the image so that the empty slots of the last workgroup of an image (U % 4 != 0) do not
   // always fall on the same SIMDs
-  const int u = a.u_lo + 4 * bw + ((wave + n) & 3);
+  const int u = a.u_lo + HU_WPG * bw + ((wave + n) & (HU_WPG - 1));
   if (u >= a.U) return;
 
   // The operand slots k = 4 s + lrow behind the patch (k >= L) sit in the last one or two sub-steps (ts = s - sL): the A side
@@ -172,9 +190,8 @@ __global__ __launch_bounds__(256, 2) void head_units_kernel(HeadUnitsArgs a) {
   // before the MFMAs of the current one), then 2^t and the weighted row sums.  getA(s): the A operand of sub-step s.
   // `pre`: the caller has already put this group's patch offsets into pb and its sub-step-0 operands into bv (requested
   // before the previous group's epilogue); next_j0 >= 0: do the same for the group that follows.
-  auto group = [&](auto ny_tag, auto&& getA, int j0, int next_j0, auto next_tag, double sym_off, int diag_j, double (&rsum)[4], int (&pb)[4], double (&bv)[4]) {
+  auto group = [&](auto ny_tag, auto&& getA, int j0, int next_j0, int nyn, double* rdiag, double (&rsum)[4], int (&pb)[4], double (&bv)[4]) {
     constexpr int NY = decltype(ny_tag)::value;
-    constexpr int NYN = decltype(next_tag)::value;
     d4 acc[NY];
 #pragma unroll
     for (int y = 0; y < NY; ++y) acc[y] = d4{0.0, 0.0, 0.0, 0.0};
@@ -187,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void head_units_kernel(HeadUnitsArgs a) {
 #pragma unroll
           for (int y = 0; y < NY; ++y) bn[y] = ldi(pb[y] + kob[s + 1]);
         }
+        HU_SB1;
         const double av = getA(s);
         if (s >= sL) {
 #pragma unroll
@@ -201,21 +219,52 @@ __global__ __launch_bounds__(256, 2) void head_units_kernel(HeadUnitsArgs a) {
         __builtin_amdgcn_sched_barrier(0);   // one sub-step of prefetch, not all of them (the scheduler would hoist every gather: 56 registers)
       }
     } else {
-      double av = getA(0);
-      for (int s = 0; s < nk4; ++s) {
-        const int sn = min(s + 1, nk4 - 1);
-        const int ko = koff[4 * sn + lrow];
-        const double an = getA(sn);
-        double bn[NY];
+      // Sub-steps [0, sL) hold patch elements only.  They go in chunks of 4: the A operands (global memory for Kzx) and the patch-element
+      // offsets of chunk c + 1 are requested before the products of chunk c (16 MFMAs = 1024 cycles against ~600 of a global load),
+      // and inside a chunk the B gathers run one sub-step ahead of their MFMAs -- no conditional anywhere in the chunk.
+      double ac[4], an[4];
+      int kc[4], kn[4];
+      auto fetch_chunk = [&](int s0, double (&A)[4], int (&K)[4]) {
 #pragma unroll
-        for (int y = 0; y < NY; ++y) bn[y] = ldi(pb[y] + ko);
+        for (int q = 0; q < 4; ++q) {
+          const int sq = min(s0 + q, nk4 - 1);
+          A[q] = getA(sq);
+          K[q] = koff[4 * sq + lrow];
+        }
+      };
+      fetch_chunk(0, ac, kc);
+      int s = 0;
+      for (; s + 4 <= sL; s += 4) {
+        fetch_chunk(s + 4, an, kn);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          double bn[NY];
+          const int kon = q < 3 ? kc[q + 1] : kn[0];   // sub-step s + q + 1 <= sL exists
+#pragma unroll
+          for (int y = 0; y < NY; ++y) bn[y] = ldi(pb[y] + kon);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int y = 0; y < NY; ++y) acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[q], bv[y], acc[y], 0, 0, 0);
+#pragma unroll
+          for (int y = 0; y < NY; ++y) bv[y] = bn[y];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ac[q] = an[q]; kc[q] = kn[q]; }
+      }
+      // what is left: at most three sub-steps of patch elements and the one or two that carry the norm slots
+      for (; s < nk4; ++s) {
+        const double av = getA(s);
+        double bn[NY];
+        const int kon = koff[4 * min(s + 1, nk4 - 1) + lrow];
+#pragma unroll
+        for (int y = 0; y < NY; ++y) bn[y] = ldi(pb[y] + kon);
         if (s >= sL) {
 #pragma unroll
           for (int y = 0; y < NY; ++y) bv[y] = fixB(bv[y], s, xbv(y));
         }
 #pragma unroll
         for (int y = 0; y < NY; ++y) acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[y], acc[y], 0, 0, 0);
-        av = an;
 #pragma unroll
         for (int y = 0; y < NY; ++y) bv[y] = bn[y];
       }
@@ -223,50 +272,59 @@ __global__ __launch_bounds__(256, 2) void head_units_kernel(HeadUnitsArgs a) {
     // weights of this group's columns, then the next group's first operands on their way before the VALU-only epilogue
     double wc[NY];
 #pragma unroll
-    for (int y = 0; y < NY; ++y) wc[y] = wl[16 * (j0 + y) + lcol] * (j0 + y == diag_j ? 1.0 : sym_off);
-    if (NYN > 0) {
+    for (int y = 0; y < NY; ++y) wc[y] = wl[16 * (j0 + y) + lcol];
+    if (nyn > 0) {
       const int ko0 = RES ? kob[0] : koff[lrow];
 #pragma unroll
-      for (int y = 0; y < NYN; ++y) {
-        pb[y] = pbl[16 * (next_j0 + y) + lcol];
-        bv[y] = ldi(pb[y] + ko0);
+      for (int y = 0; y < 4; ++y) {
+        if (y < nyn) {
+          pb[y] = pbl[16 * (next_j0 + y) + lcol];
+          bv[y] = ldi(pb[y] + ko0);
+        }
       }
     }
+    constexpr int YE = (HU_EXPN == 8 && NY % 2 == 0) ? 2 : 1;   // fragments per batch of interleaved chains
 #pragma unroll
-    for (int y = 0; y < NY; ++y) {   // four chains at a time: a dependent pair is three instructions apart
-      double t[4];
+    for (int y0 = 0; y0 < NY; y0 += YE) {
+      double t[4 * YE];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) t[v] = acc[y][v];
-      exp2_n<4>(t);
+      for (int y = 0; y < YE; ++y)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) rsum[v] = fma(wc[y], t[v], rsum[v]);
+        for (int v = 0; v < 4; ++v) t[4 * y + v] = acc[y0 + y][v];
+      exp2_n<4 * YE>(t);
+#pragma unroll
+      for (int y = 0; y < YE; ++y) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) rsum[v] = fma(wc[y0 + y], t[4 * y + v], rsum[v]);
+        if (y0 + y == 0 && rdiag) {   // first fragment of a Kdiag row pass = the diagonal tile: its share, counted once
+#pragma unroll
+          for (int v = 0; v < 4; ++v) rdiag[v] = rsum[v];
+        }
+      }
     }
   };
-  using T0 = std::integral_constant<int, 0>;
   using T1 = std::integral_constant<int, 1>;
+  using T2 = std::integral_constant<int, 2>;
+  using T3 = std::integral_constant<int, 3>;
   using T4 = std::integral_constant<int, 4>;
 
-  // one row fragment against column fragments [j_lo, nfp): groups of four, then the remaining 0..3 one at a time
-  auto row_pass = [&](auto&& getA, int j_lo, double sym_off, int diag_j, double (&rsum)[4]) {
+  // one row fragment against column fragments [j_lo, nfp): groups of four, then one group of the remaining 1..3.
+  // rdiag != nullptr: receives the share of the first fragment (the diagonal tile of a Kdiag row; rsum must start at zero)
+  auto row_pass = [&](auto&& getA, int j_lo, double* rdiag, double (&rsum)[4]) {
     const int nfull = (nfp - j_lo) >> 2, nrem = (nfp - j_lo) & 3;
     int pb[4];
     double bv[4];
     const int ko0 = RES ? kob[0] : koff[lrow];
     int j0 = j_lo;
-    if (nfull) {
 #pragma unroll
-      for (int y = 0; y < 4; ++y) { pb[y] = pbl[16 * (j0 + y) + lcol]; bv[y] = ldi(pb[y] + ko0); }
-      for (int g = 0; g < nfull - 1; ++g, j0 += 4) group(T4{}, getA, j0, j0 + 4, T4{}, sym_off, diag_j, rsum, pb, bv);
-      if (nrem) group(T4{}, getA, j0, j0 + 4, T1{}, sym_off, diag_j, rsum, pb, bv);
-      else group(T4{}, getA, j0, -1, T0{}, sym_off, diag_j, rsum, pb, bv);
-      j0 += 4;
-    } else if (nrem) {
-      pb[0] = pbl[16 * j0 + lcol]; bv[0] = ldi(pb[0] + ko0);
+    for (int y = 0; y < 4; ++y) {
+      if (y < (nfull ? 4 : nrem)) { pb[y] = pbl[16 * (j0 + y) + lcol]; bv[y] = ldi(pb[y] + ko0); }
     }
-    for (int q = 0; q < nrem; ++q, ++j0) {
-      if (q + 1 < nrem) group(T1{}, getA, j0, j0 + 1, T1{}, sym_off, diag_j, rsum, pb, bv);
-      else group(T1{}, getA, j0, -1, T0{}, sym_off, diag_j, rsum, pb, bv);
-    }
+    for (int g = 0; g < nfull; ++g, j0 += 4) group(T4{}, getA, j0, j0 + 4, g + 1 < nfull ? 4 : nrem, g == 0 ? rdiag : nullptr, rsum, pb, bv);
+    double* rd = nfull == 0 ? rdiag : nullptr;
+    if (nrem == 1) group(T1{}, getA, j0, -1, 0, rd, rsum, pb, bv);
+    else if (nrem == 2) group(T2{}, getA, j0, -1, 0, rd, rsum, pb, bv);
+    else if (nrem == 3) group(T3{}, getA, j0, -1, 0, rd, rsum, pb, bv);
   };
 
   if (u < a.nfm) {
@@ -277,9 +335,9 @@ __global__ __launch_bounds__(256, 2) void head_units_kernel(HeadUnitsArgs a) {
       double areg[NKR];
 #pragma unroll
       for (int s = 0; s < NKR; ++s) areg[s] = zs[(long)(4 * s + lrow) * a.Mp];
-      row_pass([&](int s) { return areg[s]; }, 0, 1.0, -1, rsum);
+      row_pass([&](int s) { return areg[s]; }, 0, nullptr, rsum);
     } else {
-      row_pass([&](int s) { return zs[(long)(4 * s + lrow) * a.Mp]; }, 0, 1.0, -1, rsum);
+      row_pass([&](int s) { return zs[(long)(4 * s + lrow) * a.Mp]; }, 0, nullptr, rsum);
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -301,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void head_units_kernel(HeadUnitsArgs a) {
       const int pr = 16 * fr + lcol;
       const int pa = pbl[pr];
       const double xav = xb[pr] + a.log2var;
-      double rsum[4] = {0.0, 0.0, 0.0, 0.0};
+      double rsum[4] = {0.0, 0.0, 0.0, 0.0}, rdiag[4] = {0.0, 0.0, 0.0, 0.0};
       auto getA_img = [&](int s, int ko) {
         double v = ldi(pa + ko);
         if (s >= sL) v = fixA(v, s, xav);
@@ -311,12 +369,12 @@ __global__ __launch_bounds__(256, 2) void head_units_kernel(HeadUnitsArgs a) {
         double areg[NKR];
 #pragma unroll
         for (int s = 0; s < NKR; ++s) areg[s] = getA_img(s, kob[s]);
-        row_pass([&](int s) { return areg[s]; }, fr, 2.0, fr, rsum);
+        row_pass([&](int s) { return areg[s]; }, fr, rdiag, rsum);
       } else {
-        row_pass([&](int s) { return getA_img(s, koff[4 * s + lrow]); }, fr, 2.0, fr, rsum);
+        row_pass([&](int s) { return getA_img(s, koff[4 * s + lrow]); }, fr, rdiag, rsum);
       }
 #pragma unroll
-      for (int v = 0; v < 4; ++v) total = fma(wl[16 * fr + lrow + 4 * v], rsum[v], total);
+      for (int v = 0; v < 4; ++v) total = fma(wl[16 * fr + lrow + 4 * v], 2.0 * rsum[v] - rdiag[v], total);   // off-diagonal tiles count twice
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) total += __shfl_xor(total, o);
@@ -343,7 +401,7 @@ void head_units_plan(HeadUnitsArgs* a) {
   a->n_kd = (a->nfp + 1) / 2;
   a->U = a->kd ? a->nfm + a->n_kd : a->nfm;     // no Kdiag output: the Kzx units only
   a->u_lo = a->kzx ? 0 : a->nfm;                // no Kzx output: the Kdiag units only
-  a->wgs_per_img = (a->U - a->u_lo + 3) / 4;
+  a->wgs_per_img = (a->U - a->u_lo + HU_WPG - 1) / HU_WPG;
   if (a->kzx_rows <= 0) a->kzx_rows = a->Mp;
   a->inv_C = 1.0f / (float)a->C; a->inv_f = 1.0f / (float)a->f; a->inv_Wo = 1.0f / (float)a->Wo; a->inv_Wr = 1.0f / (float)(a->W - a->f + 1);
 }
@@ -356,8 +414,8 @@ int head_units(dcgp_ctx* ctx, const HeadUnitsArgs& a) {
   if (nwg > 0x7fffffffL) return ctx_fail(ctx, DCGP_ERR_ARG, "head_units: too many workgroups");
   const size_t lds = head_units_lds(a);
   ScopedTimer t(ctx, "head_sweep");
-  if (a.L == 25) hipLaunchKernelGGL((head_units_kernel<7, 1>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);   // 5 x 5 x 1 patches
-  else hipLaunchKernelGGL((head_units_kernel<0, 0>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
+  if (a.L == 25) hipLaunchKernelGGL((head_units_kernel<7, 1>), dim3((unsigned)nwg), dim3(HU_NT), lds, ctx->stream, a);   // 5 x 5 x 1 patches
+  else hipLaunchKernelGGL((head_units_kernel<0, 0>), dim3((unsigned)nwg), dim3(HU_NT), lds, ctx->stream, a);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }

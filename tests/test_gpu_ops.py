@@ -400,8 +400,9 @@ def test_head_unit_sweep(ctx, H, W, C, f, s, M, N):
 def test_head_unit_sweep_exp_accuracy(ctx):
     """The unit sweep's 2^t (magic-number split + degree-11 minimax polynomial + ldexp) value by value: one patch per image
     (P = 1, weight 1), one inducing patch at the origin, so Kzx[0, n] = variance * exp(-|x_n|^2 / (2 l^2)).  The exponent reaches the
-    kernel through the MFMA accumulator (both norms folded into the product), so its rounding error scales with |t|: relative error
-    <= (4 + |t|) ulp, exact zeros below the subnormal range, 1 ulp at t = 0."""
+    kernel through the MFMA accumulator (both norms folded into the product: scaled pixel, square, sum -- three roundings of a
+    base-2 exponent 1.44 |t| large), so its rounding error scales with |t|: relative error <= (4 + 2.5 |t|) ulp -- 1e-14 where kernel
+    values matter (|t| < 30) --, exact zeros below the subnormal range, 1 ulp at t = 0."""
     from deepcgp_amd.kernels import RBF, ConvKernel
     from deepcgp_amd.views import FullView
     rng = np.random.default_rng(0)
@@ -414,7 +415,7 @@ def test_head_unit_sweep_exp_accuracy(ctx):
     want = np.exp(arg)
     normal = want > 1e-300
     rel = np.abs(got[normal] / want[normal] - 1.0)
-    assert np.all(rel <= 2.3e-16 * (4.0 + np.abs(arg[normal]))), rel.max()
+    assert np.all(rel <= 2.3e-16 * (4.0 + 2.5 * np.abs(arg[normal]))), rel.max()
     assert np.all(np.abs(got[~normal] - want[~normal]) <= 1e-300) and got[arg < -765.0].max() == 0.0
     assert abs(got[0] - 1.0) <= 2.3e-16
 
