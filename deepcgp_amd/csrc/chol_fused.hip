@@ -40,15 +40,40 @@ struct RlArgs {
   int* info;
 };
 
+// Accesses to data another workgroup of the SAME launch wrote or will read (chol_persist_kernel) are relaxed atomics of agent
+// scope = global_load / global_store with the sc1 bit: coherent across the 8 XCDs one access at a time, served by the memory side.
+// What was measured on the way (tools/flag_latency.hip, tools/flag_latency2.hip, profiles/r03_flag_latency*.txt):
+//   * ordinary accesses bracketed by agent-scope release / acquire fences: every release writes back all dirty lines of the XCD's L2,
+//     and the kernels in front of the chain have just left megabytes of them -- 154 us for the 8 panels of M = 256;
+//   * sc1 accesses, no fences (this code): a flag hop is 0.5-0.7 us, 8 KB of payload behind it 1.5 us more: 129 us;
+//   * everything confined to one XCD (workgroup i of a launch runs on XCD i % 8) with plain data accesses: sc0 (workgroup-scope)
+//     loads and `buffer_inv sc0` both leave stale lines in the vector L1 (the ping-pong test fails); `buffer_inv sc1` + plain
+//     accesses is coherent inside an XCD (and, as it must, not across two) at 1.1 us per hop -- no better than a launch boundary.
+// A launch boundary on one stream costs ~3 us, so a panel's hand-off between workgroups buys at most 1-2 us, and the look-ahead
+// it enables is eaten by the round trip chain -> tiles -> chain (~8 us against a 6 us panel period).  The one-launch chain is
+// therefore kept as a tested alternative (DCGP_CHOL_ONE_LAUNCH=1), not the default.
+constexpr int SC_NONE = -1;
+template <int SC>
+__device__ __forceinline__ double ldg(const double* p) {
+  if constexpr (SC == SC_NONE) return *p;
+  else return __hip_atomic_load(p, __ATOMIC_RELAXED, SC);
+}
+template <int SC>
+__device__ __forceinline__ void stg(double* p, double v) {
+  if constexpr (SC == SC_NONE) *p = v;
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, SC);
+}
+
 // The prologue loads are written as fully unrolled register batches (all global loads issued, then all LDS stores):
 // as rolled loops each iteration waited for its own load -- 4 + 8 + 8 serial memory latencies per workgroup.
+template <int SH = SC_NONE>
 __device__ __forceinline__ void load_diag(const double* __restrict__ A, int ld, int j, int nb, double (*D)[NB + 1], int tid) {
   double t[NB * NB / 256];
 #pragma unroll
   for (int e = 0; e < NB * NB / 256; ++e) {
     const int idx = tid + e * 256, r = idx / NB, c = idx % NB;
     t[e] = (r == c) ? 1.0 : 0.0;
-    if (r < nb && c < nb && c <= r) t[e] = A[(long)(j + r) * ld + j + c];
+    if (r < nb && c < nb && c <= r) t[e] = ldg<SH>(A + (long)(j + r) * ld + j + c);
   }
 #pragma unroll
   for (int e = 0; e < NB * NB / 256; ++e) {
@@ -57,13 +82,14 @@ __device__ __forceinline__ void load_diag(const double* __restrict__ A, int ld, 
   }
 }
 // rows [r0, r0+64) of the panel columns -> U[64][33] (zero beyond the matrix)
+template <int SH = SC_NONE>
 __device__ __forceinline__ void load_panel_rows(const double* __restrict__ A, int ld, int Mp, int j, int nb, int r0,
                                                 double (*U)[NB + 1], int tid) {
   double t[64 * NB / 256];
 #pragma unroll
   for (int e = 0; e < 64 * NB / 256; ++e) {
     const int idx = tid + e * 256, i = idx / NB, c = idx % NB;
-    t[e] = (r0 + i < Mp && c < nb) ? A[(long)(r0 + i) * ld + j + c] : 0.0;
+    t[e] = (r0 + i < Mp && c < nb) ? ldg<SH>(A + (long)(r0 + i) * ld + j + c) : 0.0;
   }
 #pragma unroll
   for (int e = 0; e < 64 * NB / 256; ++e) {
@@ -317,6 +343,384 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   TR(5)
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same chain in ONE launch (opt-in: DCGP_CHOL_ONE_LAUNCH=1; correct and tested, slower than the launches it replaces -- see the
+// note above ldg<>).  Eight dependent launches cost eight stream boundaries (~3 us each) and, worse, put
+// everything a panel does -- loads, the trailing update, the write-back -- on the serial path beside the only part that is
+// inherently serial, the 32-step pivot recurrence of the diagonal block (5.5 us).  Here, per matrix:
+//   * ONE chain workgroup walks the diagonal: factor + invert block j (wave_potrf_inv32), publish L_jj and inv(L_jj),
+//     then form the NEXT diagonal block itself -- A[j+1,j+1] - P P^T with P = A[j+1,j] inv(L_jj)^T, 16 MFMAs on operands
+//     that waves 1-3 fetched while wave 0 ran the recurrence -- and go straight on.  Its period is recurrence + ~1 us.
+//   * T trailing workgroups take the tiles of every panel (the code of chol_rl_kernel, with inv(L_jj) read instead of
+//     recomputed).  Panel j's tiles wait for two things: the chain's flag j (a release store, ~0.7 us to be seen: measured
+//     by tools/flag_latency.hip) and the counter of panel j-1's tiles (the 64 x 64 tiles shift by 32 from panel to panel, so
+//     a tile reads what several tiles of the previous panel wrote).  They run one panel period behind the chain, off its path.
+// Flags are monotone across launches (base values from an epoch the host advances), so nothing is cleared between steps.
+// Every workgroup of the launch must be resident at once (they wait for each other): the launcher caps the grid.
+struct PcArgs {
+  RlArgs r;               // A, Lout, Y, Linv, LinvT, Mp, ld, info (j, nt, nT, nct are per panel: computed in the kernel)
+  int np, T;
+  double* Xpub;           // [batch][np][NB][NB]  inv(L_jj), row-major, identity-padded where the last panel is narrow
+  unsigned* sync;         // [batch][1 + np]: chain flag, then one counter of finished trailing workgroups per panel
+  unsigned base_chain, base_trail;   // epoch * 4096, epoch * T
+};
+
+// Polls until *p has reached target (wrap-safe).  Gives up after ~a second of polling -- a workgroup that never arrives must not
+// hang the device: the caller's results are then garbage and the launch's status word says so.
+template <int SC>
+__device__ __forceinline__ bool spin_until(const unsigned* p, unsigned target) {
+  for (int it = 0; it < (1 << 22); ++it) {
+    if ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, SC) - target) >= 0) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+
+// one tile (index bx of panel j's nT + nY tiles) of the trailing update / running inverse, inv(L_jj) given in Xs.
+// Same arithmetic as chol_rl_kernel.  Ends with a barrier-free state: the caller synchronises before the LDS arrays are reused.
+template <int SC>
+__device__ __forceinline__ void pc_tile(const RlArgs& a, int b, int bx, int j, int nt, int nT, int nct, const double* __restrict__ xpub,
+                                        const unsigned* chain_flag, unsigned chain_target, double (*Ui)[NB + 1], double* UcTs, double (*Xs)[NB + 1]) {
+  double (*Uc)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(UcTs);
+  double (*Ts)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(UcTs);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lrow = lane >> 4, lcol = lane & 15;
+  const int Mp = a.Mp, ld = a.ld, nb = min(NB, Mp - j);
+  double* __restrict__ A = a.A[b];
+  double* __restrict__ Lout = a.Lout + (long)b * Mp * ld;
+  double* __restrict__ Y = a.Y + (long)b * Mp * ld;
+  const int below0 = j + NB;
+  const bool is_trailing = bx < nT;
+  int ti = 0, tc = 0, rt = -1, ct = 0;
+  double old[2][2][4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) old[x][y][v] = 0.0;
+  if (is_trailing) {
+    int pair = bx;
+    while (pair >= nt - tc) { pair -= nt - tc; ++tc; }
+    ti = tc + pair;
+    load_panel_rows<SC>(A, ld, Mp, j, nb, below0 + ti * 64, Ui, tid);
+    if (tc != ti) load_panel_rows<SC>(A, ld, Mp, j, nb, below0 + tc * 64, Uc, tid);
+    const int ri0 = below0 + ti * 64, rc0 = below0 + tc * 64;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int i = ri0 + wm * 32 + x * 16 + lrow + 4 * v, jj = rc0 + wn * 32 + y * 16 + lcol;
+          if (i < Mp && jj < Mp && jj <= i) old[x][y][v] = ldg<SC>(A + (long)i * ld + jj);
+        }
+  } else {
+    const int yy = bx - nT;
+    rt = yy / nct - 1;
+    ct = yy % nct;
+    const int c0 = ct * 64;
+    if (rt >= 0) {
+      load_panel_rows<SC>(A, ld, Mp, j, nb, below0 + rt * 64, Ui, tid);
+      const int r0 = below0 + rt * 64;
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int i = r0 + wm * 32 + x * 16 + lrow + 4 * v, gc = c0 + wn * 32 + y * 16 + lcol;
+            if (i < Mp && gc < j) old[x][y][v] = ldg<SC>(Y + (long)i * ld + gc);
+          }
+    }
+    double tt[NB * 64 / 256];
+#pragma unroll
+    for (int e = 0; e < NB * 64 / 256; ++e) {
+      const int idx = tid + e * 256, q = idx >> 6, c = idx & 63, gc = c0 + c;
+      tt[e] = 0.0;
+      if (q < nb && gc < j) tt[e] = ldg<SC>(Y + (long)(j + q) * ld + gc);
+      else if (gc == j + q) tt[e] = 1.0;
+    }
+#pragma unroll
+    for (int e = 0; e < NB * 64 / 256; ++e) {
+      const int idx = tid + e * 256;
+      Ts[idx >> 6][idx & 63] = tt[e];
+    }
+  }
+  // inv(L_jj): wait for the chain workgroup's flag, then fetch the published block
+  if (tid == 0) spin_until<SC>(chain_flag, chain_target);
+  __syncthreads();   // (the published block is read with coherent loads: no cache invalidate)
+  {
+    double t[NB * NB / 256];
+#pragma unroll
+    for (int e = 0; e < NB * NB / 256; ++e) t[e] = ldg<SC>(xpub + tid + e * 256);
+#pragma unroll
+    for (int e = 0; e < NB * NB / 256; ++e) { const int idx = tid + e * 256; Xs[idx / NB][idx % NB] = t[e]; }
+  }
+  __syncthreads();
+
+  d4 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+
+  if (is_trailing) {
+    d4 pi[2], pc[2];
+    panel_solve_mfma(Ui, Xs, wm, wn, lrow, lcol, pi);
+    if (tc != ti) panel_solve_mfma(Uc, Xs, wm, wn, lrow, lcol, pc);
+    __syncthreads();
+    panel_store(Ui, wm, wn, lrow, lcol, pi);
+    if (tc != ti) panel_store(Uc, wm, wn, lrow, lcol, pc);
+    __syncthreads();
+    const int ri0 = below0 + ti * 64, rc0 = below0 + tc * 64;
+    double (*Ub)[NB + 1] = (tc == ti) ? Ui : Uc;
+    if (tc == ti) {   // the diagonal tiles publish the panel rows of L (final)
+      for (int idx = tid; idx < 64 * NB; idx += 256) {
+        const int i = idx / NB, c = idx % NB;
+        if (ri0 + i < Mp && c < nb) Lout[(long)(ri0 + i) * ld + j + c] = Ui[i][c];
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < NB; kk += 4) {
+      double avv[2], bvv[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) avv[x] = Ui[wm * 32 + x * 16 + lcol][kk + lrow];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) bvv[y] = Ub[wn * 32 + y * 16 + lcol][kk + lrow];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(avv[x], bvv[y], acc[x][y], 0, 0, 0);
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int i = ri0 + wm * 32 + x * 16 + lrow + 4 * v, jj = rc0 + wn * 32 + y * 16 + lcol;
+          if (i < Mp && jj < Mp && jj <= i) stg<SC>(A + (long)i * ld + jj, old[x][y][v] - acc[x][y][v]);
+        }
+    return;
+  }
+
+  double* __restrict__ Linv = a.Linv[b];
+  const int c0 = ct * 64;
+  d4 yn[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+  for (int kk = 0; kk < NB; kk += 4) {
+    const double bv = Ts[kk + lrow][wave * 16 + lcol];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) yn[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[x * 16 + lcol][kk + lrow], bv, yn[x], 0, 0, 0);
+  }
+  d4 pi[2];
+  if (rt >= 0) panel_solve_mfma(Ui, Xs, wm, wn, lrow, lcol, pi);
+  __syncthreads();
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Ts[x * 16 + lrow + 4 * v][wave * 16 + lcol] = yn[x][v];
+  if (rt >= 0) panel_store(Ui, wm, wn, lrow, lcol, pi);
+  __syncthreads();
+  if (rt < 0) {
+    double* __restrict__ LinvT = a.LinvT ? a.LinvT[b] : nullptr;
+    const int cend = (ct == nct - 1) ? Mp : c0 + 64;
+    for (int cb = c0; cb < cend; cb += 64)
+      for (int idx = tid; idx < NB * 64; idx += 256) {
+        const int r = idx >> 6, c = idx & 63, gc = cb + c;
+        if (r < nb && gc < Mp) Linv[(long)(j + r) * ld + gc] = (cb == c0 && gc < j + nb) ? Ts[r][c] : 0.0;
+      }
+    if (LinvT)
+      for (int cb = c0; cb < cend; cb += 64)
+        for (int idx = tid; idx < NB * 64; idx += 256) {
+          const int r = idx & 31, c = idx >> 5, gc = cb + c;
+          if (r < nb && gc < Mp) LinvT[(long)gc * ld + j + r] = (cb == c0 && gc < j + nb) ? Ts[r][c] : 0.0;
+        }
+    return;
+  }
+  const int r0 = below0 + rt * 64;
+#pragma unroll
+  for (int kk = 0; kk < NB; kk += 4) {
+    double avv[2], bvv[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) avv[x] = Ui[wm * 32 + x * 16 + lcol][kk + lrow];
+#pragma unroll
+    for (int y = 0; y < 2; ++y) bvv[y] = Ts[kk + lrow][wn * 32 + y * 16 + lcol];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(avv[x], bvv[y], acc[x][y], 0, 0, 0);
+  }
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int i = r0 + wm * 32 + x * 16 + lrow + 4 * v, gc = c0 + wn * 32 + y * 16 + lcol;
+        if (i < Mp && gc < j + nb) stg<SC>(Y + (long)i * ld + gc, old[x][y][v] - acc[x][y][v]);
+      }
+}
+
+struct PcLds {
+  double D[NB][NB + 1];
+  double col[2 * NB];
+  double Ui[64][NB + 1];
+  double UcTs[64 * (NB + 1)];
+  double Xs[NB][NB + 1];
+};
+
+template <int SC>
+__device__ __forceinline__ void pc_run(const PcArgs& p, const int b, const int role, PcLds& sh) {
+  double (&D)[NB][NB + 1] = sh.D;
+  double (&col)[2 * NB] = sh.col;
+  double (*Ui)[NB + 1] = sh.Ui;
+  double* UcTs = sh.UcTs;
+  double (*Xs)[NB + 1] = sh.Xs;
+  const RlArgs& a = p.r;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane >> 4, lcol = lane & 15;
+  const int Mp = a.Mp, ld = a.ld, np = p.np;
+  unsigned* chain_flag = p.sync + (long)b * (1 + np);
+  unsigned* trail_cnt = chain_flag + 1;
+  double* __restrict__ xpub_b = p.Xpub + (long)b * np * NB * NB;
+  const unsigned trail_target = p.base_trail + (unsigned)p.T;
+
+  if (role == 0) {
+    // ---------------- the chain workgroup ----------------
+    double* __restrict__ A = a.A[b];
+    double* __restrict__ Lout = a.Lout + (long)b * Mp * ld;
+    double (*U)[NB + 1] = Ui;                                              // block row j + 1, panel columns (32 x 32)
+    double (*Pm)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(UcTs);     // P = U inv(L_jj)^T
+    load_diag(A, ld, 0, min(NB, Mp), D, tid);   // (written by an earlier launch: ordinary loads)
+    __syncthreads();
+    for (int jp = 0; jp < np; ++jp) {
+      const int j = jp * NB, nb = min(NB, Mp - j);
+      const bool more = jp + 1 < np;
+      const int jn = j + NB, nbn = more ? min(NB, Mp - jn) : 0;
+      // waves 1-3: operands of the look-ahead -- A[jn.., j..] and the lower triangle of A[jn.., jn..] as the trailing tiles of
+      // panel jp - 1 left them -- into registers while wave 0 runs the recurrence (elements e*192 + tid-64 of 2 x 1024)
+      constexpr int PF = (2 * NB * NB + 191) / 192;
+      double pf[PF];
+      if (tid < 64) {
+        double v[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) v[c] = (tid < NB) ? D[tid][c] : ((c == tid - NB) ? 1.0 : 0.0);
+        const int fail = wave_potrf_inv32(v, tid, col);
+        if (tid < NB) {
+#pragma unroll
+          for (int c = 0; c < NB; ++c) D[tid][c] = (c <= tid) ? v[c] : 0.0;
+        } else {
+#pragma unroll
+          for (int r = 0; r < NB; ++r) Xs[r][tid - NB] = v[r];
+        }
+        if (tid == 0 && (jp == 0 || (fail && a.info[b] == 0))) a.info[b] = fail ? j + fail : 0;
+      } else if (more) {
+        if (jp > 0) {   // every wave waits for itself (one lane polls; the acquire's cache invalidate is per wave)
+          if (lane == 0) spin_until<SC>(trail_cnt + (jp - 1), trail_target);
+        }
+#pragma unroll
+        for (int e = 0; e < PF; ++e) {
+          const int idx = e * 192 + tid - 64;
+          pf[e] = 0.0;
+          if (idx < NB * NB) {
+            const int r = idx / NB, c = idx % NB;
+            if (r < nbn && c < nb) pf[e] = ldg<SC>(A + (long)(jn + r) * ld + j + c);
+          } else if (idx < 2 * NB * NB) {
+            const int r = (idx - NB * NB) / NB, c = (idx - NB * NB) % NB;
+            pf[e] = (r == c) ? 1.0 : 0.0;
+            if (r < nbn && c < nbn && c <= r) pf[e] = ldg<SC>(A + (long)(jn + r) * ld + jn + c);
+          }
+        }
+      }
+      __syncthreads();
+      // publish L_jj and inv(L_jj), then the flag
+      for (int idx = tid; idx < nb * nb; idx += 256) {
+        const int r = idx / nb, c = idx % nb;
+        Lout[(long)(j + r) * ld + j + c] = D[r][c];
+      }
+      {
+        double* __restrict__ xp = xpub_b + (long)jp * NB * NB;
+#pragma unroll
+        for (int e = 0; e < NB * NB / 256; ++e) { const int idx = tid + e * 256; stg<SC>(xp + idx, Xs[idx / NB][idx % NB]); }
+      }
+      __builtin_amdgcn_s_waitcnt(0);   // the coherent stores have been acknowledged before the barrier in front of the flag
+      // look-ahead operands -> LDS (U; the next diagonal block goes to D once L_jj has been published from it)
+      if (more && tid >= 64) {
+#pragma unroll
+        for (int e = 0; e < PF; ++e) {
+          const int idx = e * 192 + tid - 64;
+          if (idx < NB * NB) U[idx / NB][idx % NB] = pf[e];
+        }
+      }
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(chain_flag, p.base_chain + (unsigned)(jp + 1), __ATOMIC_RELAXED, SC);
+      if (!more) break;
+      if (tid >= 64) {
+#pragma unroll
+        for (int e = 0; e < PF; ++e) {
+          const int idx = e * 192 + tid - 64;
+          if (idx >= NB * NB && idx < 2 * NB * NB) D[(idx - NB * NB) / NB][(idx - NB * NB) % NB] = pf[e];
+        }
+      }
+      // P = U inv(L_jj)^T: wave w owns the 16 x 16 block (w >> 1, w & 1)
+      {
+        const int bm = wave >> 1, bn = wave & 1;
+        d4 pacc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < NB; kk += 4)
+          pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(U[bm * 16 + lcol][kk + lrow], Xs[bn * 16 + lcol][kk + lrow], pacc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Pm[bm * 16 + lrow + 4 * v][bn * 16 + lcol] = pacc[v];
+      }
+      __syncthreads();
+      // D_next -= P P^T
+      {
+        const int bm = wave >> 1, bn = wave & 1;
+        d4 dacc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < NB; kk += 4)
+          dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pm[bm * 16 + lcol][kk + lrow], Pm[bn * 16 + lcol][kk + lrow], dacc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int r = bm * 16 + lrow + 4 * v, c = bn * 16 + lcol;
+          if (c <= r && r < nbn) D[r][c] -= dacc[v];
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---------------- trailing workgroups ----------------
+  const int w = role - 1;
+  for (int jp = 0; jp < np; ++jp) {
+    const int j = jp * NB;
+    const int below = Mp - (j + NB);
+    const int nt = below > 0 ? (below + 63) / 64 : 0;
+    const int nT = nt * (nt + 1) / 2;
+    const int nct = (min(j + NB, Mp) + 63) / 64;
+    const int ntiles = nT + (1 + nt) * nct;
+    if (jp > 0) {   // what this panel reads was written by the tiles of the previous one
+      if (tid == 0) spin_until<SC>(trail_cnt + (jp - 1), trail_target);
+      __syncthreads();
+    }
+    for (int t = w; t < ntiles; t += p.T) {
+      pc_tile<SC>(a, b, t, j, nt, nT, nct, xpub_b + (long)jp * NB * NB, chain_flag, p.base_chain + (unsigned)(jp + 1), Ui, UcTs, Xs);
+      __syncthreads();
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // this workgroup's coherent stores have been acknowledged
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(trail_cnt + jp, 1u, __ATOMIC_RELAXED, SC);
+  }
+}
+
+// grid (1 + T, batch): blockIdx.x == 0 is the matrix's chain workgroup
+__global__ __launch_bounds__(256, 2) void chol_persist_kernel(PcArgs p) {
+  __shared__ PcLds sh;
+  pc_run<__HIP_MEMORY_SCOPE_AGENT>(p, blockIdx.y, blockIdx.x, sh);
+}
+
 // final factor back over A (lower triangle from Lout, strict upper triangle zero).  grid (Mp, batch)
 __global__ void chol_finish_kernel(double* const* __restrict__ Ap, const double* __restrict__ Lout, int Mp, int ld) {
   double* __restrict__ A = Ap[blockIdx.y];
@@ -336,6 +740,43 @@ int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_L
   double* Lout = (double*)ws_get(ctx, "chol_Lout" + ctx->ws_tag, (size_t)batch * mm * sizeof(double));
   double* Y = d_Linv ? (double*)ws_get(ctx, "chol_Y" + ctx->ws_tag, (size_t)batch * mm * sizeof(double)) : nullptr;
   if (!Lout || (d_Linv && !Y)) return DCGP_ERR_ALLOC;
+  // one launch for the whole chain (chol_persist_kernel) where its workgroups are sure to be co-resident
+  static const bool one_launch = getenv("DCGP_CHOL_ONE_LAUNCH") != nullptr;   // A/B switch (see the note above ldg<>)
+  if (d_Linv && one_launch) {
+    const int np = (Mp + NB - 1) / NB;
+    int max_tiles = 1;
+    for (int j = 0; j < Mp; j += NB) {
+      const int below = Mp - (j + NB), nt = below > 0 ? (below + 63) / 64 : 0;
+      const int tiles = nt * (nt + 1) / 2 + (1 + nt) * ((min(j + NB, Mp) + 63) / 64);
+      max_tiles = tiles > max_tiles ? tiles : max_tiles;
+    }
+    constexpr int kMaxResident = 192;   // workgroups of 256 threads / ~50 KB LDS: two fit a CU, 256 CUs -- far inside what is resident at once
+    int T = kMaxResident / batch - 1;
+    if (T > max_tiles) T = max_tiles;
+    if (T >= 1 && np < 4096) {
+      const std::string sname = "chol_sync" + ctx->ws_tag;
+      const size_t sync_bytes = (size_t)batch * (1 + np) * sizeof(unsigned);
+      const bool fresh = ctx->ws.find(sname) == ctx->ws.end() || ctx->ws[sname].second < sync_bytes;
+      unsigned* sync = (unsigned*)ws_get(ctx, sname, sync_bytes);
+      double* Xpub = (double*)ws_get(ctx, "chol_Xpub" + ctx->ws_tag, (size_t)batch * np * NB * NB * sizeof(double));
+      if (!sync || !Xpub) return DCGP_ERR_ALLOC;
+      ChainEpoch& ep = ctx->chain_epochs[sname];
+      if (fresh || ep.T != T || ep.np != np || ep.batch != batch) {   // counters are monotone across launches of ONE shape
+        HIP_TRY(ctx, hipMemsetAsync(sync, 0, sync_bytes, ctx->stream));
+        ep.epoch = 0; ep.T = T; ep.np = np; ep.batch = batch;
+      }
+      PcArgs p;
+      p.r.A = d_A; p.r.Lout = Lout; p.r.Y = Y; p.r.Linv = d_Linv; p.r.LinvT = d_LinvT; p.r.Mp = Mp; p.r.ld = ld; p.r.info = d_info;
+      p.r.j = p.r.nt = p.r.nT = p.r.nct = 0;
+      p.np = np; p.T = T; p.Xpub = Xpub; p.sync = sync;
+      p.base_chain = ep.epoch * 4096u; p.base_trail = ep.epoch * (unsigned)T;
+      ++ep.epoch;
+      hipLaunchKernelGGL(chol_persist_kernel, dim3(1 + T, batch), dim3(256), 0, ctx->stream, p);
+      LAUNCH_CHECK(ctx);
+      if (defer_finish) return DCGP_OK;
+      return factor_finish_batched(ctx, d_A, batch, Mp, ld);
+    }
+  }
   for (int j = 0; j < Mp; j += NB) {
     RlArgs a;
     a.A = d_A; a.Lout = Lout; a.Y = Y; a.Linv = d_Linv; a.LinvT = d_Linv ? d_LinvT : nullptr; a.Mp = Mp; a.ld = ld; a.j = j; a.info = d_info;

@@ -27,6 +27,8 @@ struct PendingEvent {
   hipEvent_t start, stop;
 };
 
+struct ChainEpoch { unsigned epoch = 0; int T = 0, np = 0, batch = 0; };   // launches so far of the one-launch factorisation chain on a sync area
+
 struct dcgp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;    // the stream launches go to (temporarily swapped to stream2 for the side branch)
@@ -45,6 +47,7 @@ struct dcgp_ctx {
                                    // the profiler serialises dispatches and cross-stream waits can deadlock it)
   hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;  // fork / join of a short side-stream excursion inside a layer
   std::string err;
+  std::map<std::string, ChainEpoch> chain_epochs;   // per sync workspace of chol_persist_kernel (chol_fused.hip)
   std::string ws_tag;   // suffix of the chain's / KL terms' scratch names: steps in flight on the two banks must not share them
   // named, grow-only device workspaces owned by the ctx
   std::map<std::string, std::pair<void*, size_t>> ws;

@@ -1062,3 +1062,44 @@ print("RESULT", " ".join(repr(v) for v in out))
     clean, poisoned = run({}), run({"DCGP_POISON_WS": "1"})
     assert all(np.isfinite(poisoned)), poisoned
     assert clean == poisoned, (clean, poisoned)
+
+
+def test_one_launch_factorisation_chain_matches_the_launch_per_panel_chain(ctx):
+    """DCGP_CHOL_ONE_LAUNCH=1 runs the Cholesky + inverse chain (conv_gp/conditionals.py:29, layers.py:151,156) as ONE launch whose
+    workgroups hand panels to each other through flags (csrc/chol_fused.hip, chol_persist_kernel; opt-in: measured slower than the
+    launches it replaces).  Same arithmetic per tile: the ELBO and a training step of a 3-layer model with a ragged M (41: a 16-wide
+    last panel) and of an M = 256 head must agree with the default chain to rounding, poisoned workspaces included."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from deepcgp_amd import synthetic as syn
+from deepcgp_amd.models import build_from_spec
+out = []
+for hwc, convs, head, M in (((13, 13, 2), [(4, 3, 7), (3, 1, 3)], (2, 1), 41), ((28, 28, 1), [], (5, 1), 256)):
+    N, S = 4, 2
+    spec = syn.make_spec(hwc, convs, head, M, S=S, num_data=777, seed=47, conv_q_sqrt_scale=0.3, variance=1.3, ls=2.1)
+    X, Y = syn.make_batch(hwc, N, seed=47)
+    zs = syn.make_noise(spec, N, seed=47)
+    model = build_from_spec(spec, X, Y)
+    for rep in range(3):          # the flags are monotone across launches: several steps on the same sync area
+        out.append(model.compute_log_likelihood(X, Y, zs=zs))
+    e, g = model.compute_gradients(X, Y, zs=zs)
+    out.append(e)
+    out.append(float(sum(np.sum(np.abs(v)) for gl in g for v in gl.values())))
+    model.close()
+print("RESULT", " ".join(repr(v) for v in out))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env_extra):
+        env = dict(os.environ)
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1]
+        return np.array([float(v) for v in line.split()[1:]])
+    ref, one = run({}), run({"DCGP_CHOL_ONE_LAUNCH": "1", "DCGP_POISON_WS": "1"})
+    assert np.all(np.isfinite(one)), one
+    assert np.max(np.abs(one - ref) / np.maximum(np.abs(ref), 1.0)) < 1e-9, (ref, one)
