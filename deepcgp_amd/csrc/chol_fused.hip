@@ -127,6 +127,9 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   double (*Uc)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(UcTs);
   double (*Ts)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(UcTs);   // [NB][65]: old Y rows, then new
   static_assert(NB * 65 <= 64 * (NB + 1), "Y tile fits the shared slot");
+  // the chain is latency: when it shares CUs with a throughput kernel (the head sweep of a head-first model, the previous step's layer
+  // kernel with steps in flight) its waves go first in the issue arbitration
+  __builtin_amdgcn_s_setprio(3);
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, lrow = lane >> 4, lcol = lane & 15;
   const int Mp = a.Mp, ld = a.ld, j = a.j, nb = min(NB, Mp - j);

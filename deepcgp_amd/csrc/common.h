@@ -215,6 +215,7 @@ struct HeadUnitsArgs {
   const double* w = nullptr;                               // [P] patch weights
   double* kzx = nullptr; long ldk = 0; double kzx_scale = 1.0;   // kzx[m * ldk + n] = kzx_scale * sum_p w_p k(z_m, x_np), rows M..Mp-1 zeroed
   int kzx_rows = 0;                                        // rows of kzx that exist (0: all Mp)
+  int share_cu = 0;                                        // leave room on every CU for a workgroup of the factorisation chain (see head_units)
   double* kd = nullptr;                                    // kd[n * n_kd + i]: Kdiag[n] = sum_i kd[..] / P^2   (nullptr / kzx == nullptr: that half is skipped)
   int nfm = 0, nfp = 0, n_kd = 0, U = 0, u_lo = 0, wgs_per_img = 0;  // set by head_units_plan (call it with kzx / kd already set)
   float inv_C = 1.f, inv_f = 1.f, inv_Wo = 1.f, inv_Wr = 1.f;         // reciprocals for the set-up's index splits

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(1024, 4) void prep_solve_kernel(PrepSolveArgs args)
   __shared__ double ssq[16];
   const PrepSolveLayer& a = args.l[blockIdx.z];
   if (!a.active) return;
+  __builtin_amdgcn_s_setprio(3);   // part of the latency-bound parameter-only chain (see chol_rl_kernel)
   const int Mp = a.Mp;
   const int strip = blockIdx.x, y = blockIdx.y;
   const bool is_alpha = y == a.R;

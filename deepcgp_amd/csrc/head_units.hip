@@ -390,7 +390,7 @@ static size_t head_units_lds(const HeadUnitsArgs& a) {
 }
 
 bool head_units_ok(const HeadUnitsArgs& a) {
-  return head_units_lds(a) <= 64 * 1024 && (long)a.Lq * a.Mp * 8 < (1L << 31);
+  return head_units_lds(a) <= 54 * 1024 && (long)a.Lq * a.Mp * 8 < (1L << 31);
 }
 
 // fills the derived fields of `a` (fragment counts, units per image)
@@ -412,7 +412,12 @@ int head_units(dcgp_ctx* ctx, const HeadUnitsArgs& a) {
     return ctx_fail(ctx, DCGP_ERR_ARG, "head_units: unsupported shape (image %d doubles, L = %d, Mp = %d)", a.HWC, a.L, a.Mp);
   const long nwg = (long)a.N * a.wgs_per_img;
   if (nwg > 0x7fffffffL) return ctx_fail(ctx, DCGP_ERR_ARG, "head_units: too many workgroups");
-  const size_t lds = head_units_lds(a);
+  size_t lds = head_units_lds(a);
+  // Beside the factorisation chain (a head-first model: the sweep needs Z only): a chain workgroup is one wave of 250 VGPRs per SIMD
+  // and 50 KB of LDS, and would never find that much free at once on a CU this launch keeps refilling with four 128-register
+  // workgroups.  Claiming 54 KB per workgroup holds the sweep to two per CU (half the register file stays free; 2 waves per SIMD
+  // cost it ~3 %) -- the chain's workgroups then start the moment they are launched.
+  if (a.share_cu && lds < 54 * 1024) lds = 54 * 1024;
   ScopedTimer t(ctx, "head_sweep");
   if (a.L == 25) hipLaunchKernelGGL((head_units_kernel<7, 1>), dim3((unsigned)nwg), dim3(HU_NT), lds, ctx->stream, a);   // 5 x 5 x 1 patches
   else hipLaunchKernelGGL((head_units_kernel<0, 0>), dim3((unsigned)nwg), dim3(HU_NT), lds, ctx->stream, a);

@@ -173,7 +173,9 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   // fork to the side stream.  A step enqueued beside others: the side stream of its bank, so that it overtakes the step in flight.
   const hipStream_t kl_s = no_side ? main_s : (part ? ctx->stream2_m : (pipelined ? (bank ? ctx->stream2b : ctx->stream2) : ctx->stream2));
   // (A first layer on the sweep + GEMM route keeps the side stream: its sweep needs Z only and runs beside the chain.)
-  bool first_fused = true;
+  // (A model that opens with the head -- the reference's "1-layer" -- has a first kernel that needs Z only: its sweep runs on the main
+  // stream beside the chain on the side stream, and the step is the longer of the two instead of their sum.)
+  bool first_fused = !(m->layers[0]->is_head && m->layers[0]->Mp >= 96);   // (a chain of one or two panels is shorter than the hand-off between streams)
   if (!m->layers[0]->is_head) {
     const LayerState& L0 = *m->layers[0];
     ConvFusedArgs fa;
