@@ -159,6 +159,71 @@ def shard_sweep(leg, steps, warmup):
             "predicted_strong_speedup_excluding_allreduce": {str(G): round(t1 / t, 3) for G, (b, t) in out.items()}}
 
 
+def kuf_measure(leg, ctx, steps):
+    """K_uf of layer 0, measured two ways on the bench workload (device-resident inputs, the model's own step):
+      * materialised: the sweep + GEMM route (DCGP_NO_FUSED_LAYER=1, read per call) really writes K_uf [M, N' P] to HBM and reads
+        it back; its sweep launch ("kuf" timer, HIP events on the launch stream, every launch) gives achieved HBM GB/s on the
+        algorithmic bytes -- this is `kuf_hbm_gbs`;
+      * one-launch route (what `value` runs): K_uf never leaves the chip.  The shader-clock stamps of sampled workgroups give the time
+        a strip spends in its K_uf phase; rounds x that is the launch's K_uf time, and bytes / time the materialised-EQUIVALENT rate --
+        reported beside the true HBM bytes of that phase (images and Z in, nothing out)."""
+    from deepcgp_amd import device as dev
+    res = {}
+    os.environ["DCGP_NO_FUSED_LAYER"] = "1"
+    try:
+        for i in range(3):
+            leg.step(i)
+        ctx.timing_enable(3)
+        ctx.timing_reset()
+        n = max(20, min(steps, 60))
+        for i in range(n):
+            leg.step(100 + i)
+        leg.barrier()
+        t = ctx.timing().get("kuf", (0, 0.0))
+        ctx.timing_enable(0)
+        if t[0]:
+            res["sweep_us"] = 1e3 * t[1] / t[0]
+            res["sweep_launches_sampled"] = t[0]
+    finally:
+        del os.environ["DCGP_NO_FUSED_LAYER"]
+    for i in range(3):
+        leg.step(i)
+    # phase stamps of the one-launch layer kernel (csrc/conv_fused.hip CF_TR): [8 sampled workgroups][16 waves][16 stamps]
+    buf = ctx.to_device(np.zeros((8, 16, 16), np.int64), np.int64)
+    dev.lib().dcgp_debug_set_fused_trace(ctx.handle, buf.ptr)
+    leg.step(7)
+    ctx.sync()
+    dev.lib().dcgp_debug_set_fused_trace(ctx.handle, None)
+    t = buf.numpy().astype(np.float64)
+    phase, ghz = [], []
+    for b in range(8):
+        live = t[b, :, 0] > 0
+        if not live.any() or not t[b, 0, 11] > t[b, 0, 10]:
+            continue
+        clk = (t[b, 0, 9] - t[b, 0, 0]) / ((t[b, 0, 11] - t[b, 0, 10]) / 100.0) / 1e3        # shader GHz from wall_clock64 (100 MHz)
+        ghz.append(clk)
+        # K_uf phase of the workgroup: from the last wave past the image / norm stage (stamp 1) to the last wave done with K_uf (stamp 2)
+        phase.append((t[b, live, 2].max() - t[b, live, 1].max()) / clk / 1e3)
+    if phase:
+        res["fused_phase_us_per_strip"] = float(np.mean(phase))
+        res["shader_ghz"] = float(np.mean(ghz))
+    return res
+
+
+def head_sweep_flops(h, rows):
+    """ConvKernel.Kdiag N' P^2 (2L+4) [full count; the kernel evaluates tiles on and right of the diagonal] + ConvKernel.Kzx N' P M (2L+4)
+    (conv_gp/kernels.py:106-133)."""
+    P, L, _ = conv_geometry(h, 1)
+    return float(rows) * P * P * (2 * L + 4) + float(rows) * P * h["M"] * (2 * L + 4)
+
+
+HEAD_KERNEL = ("head_units_kernel (ConvKernel.Kzx: weighted patch sum reduced in-kernel, + ConvKernel.Kdiag: all patch pairs of an image; "
+               "wave-sized units of one launch, norms folded into the MFMA, 17-instruction 2^t epilogue)")
+HEAD_NOTE = ("N'*P^2*(2L+4) + N'*P*M*(2L+4) (SURVEY 8(d)); the Kdiag part evaluates the tiles on and right of the diagonal only.  On gfx950 the "
+             "fp64 MFMA and every VALU instruction of a SIMD issue one after the other (tools/pipe_mix.hip), so the exp of each kernel value "
+             "(17 VALU instructions = 68 cycles against 112 MFMA cycles per value at L = 25) is part of the bound: ~0.87 by this count is the ceiling")
+
+
 def head_only_leg(ctx, grp, S, steps):
     """The reference's literal "1-layer M=256" (results/N60000_M256/options.toml:3: scalar M = SVGP head with the ConvKernel,
     no ConvLayer): forward ELBO steps/s and the roofline of its largest term, ConvKernel.Kdiag (kernels.py:106-115)."""
@@ -168,25 +233,37 @@ def head_only_leg(ctx, grp, S, steps):
     dt, _ = leg.timed(20, steps)
     ctx.timing_enable(1)
     ctx.timing_reset()
-    for i in range(10):
+    for i in range(50):
         leg.step(i)
     ctx.sync()
     tim = ctx.timing()
+    # the sweep alone on the chip (the step above runs it beside the factorisation chain, two workgroups per CU)
+    os.environ["DCGP_HEAD_NO_OVERLAP"] = "1"
+    try:
+        for i in range(3):
+            leg.step(i)
+        ctx.timing_reset()
+        for i in range(50):
+            leg.step(i)
+        ctx.sync()
+        tim_alone = ctx.timing()
+    finally:
+        del os.environ["DCGP_HEAD_NO_OVERLAP"]
     ctx.timing_enable(0)
     h = leg.spec["head"]
-    P, L, _ = conv_geometry(h, 1)
     rows = 32 * S
-    flops = float(rows) * P * P * (2 * L + 4)
-    # Kzx and Kdiag share one launch (head_sweep_kernel): its flops = N' P^2 (2L+4) [Kdiag, full count; the kernel evaluates the
-    # upper triangle of tile pairs only] + N' P M (2L+4) [Kzx]
-    flops += float(rows) * P * h["M"] * (2 * L + 4)
-    us = 1e3 * tim["head_sweep"][1] / max(tim["head_sweep"][0], 1)
+    flops = head_sweep_flops(h, rows)
+    us_in_step = 1e3 * tim["head_sweep"][1] / max(tim["head_sweep"][0], 1)
+    us = 1e3 * tim_alone["head_sweep"][1] / max(tim_alone["head_sweep"][0], 1)
     ach = flops / (us * 1e-6) / 1e12
     out = {"head_only_steps_per_s": steps / dt, "head_only_ms_per_step": 1e3 * dt / steps,
-           "roofline_head": {"kernel": "head_sweep_kernel (ConvKernel.Kzx: weighted patch sum reduced in-kernel, + ConvKernel.Kdiag: all patch pairs of an image, in one launch)",
-                             "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
-                             "traffic": None, "algorithmic_flops_per_launch": flops, "avg_us": us,
-                             "note": "N'*P^2*(2L+4) + N'*P*M*(2L+4) (SURVEY 8(d)); the Kdiag part evaluates the upper triangle of tile pairs only"},
+           "roofline_head": {"kernel": HEAD_KERNEL, "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("head_sweep", "cfg2_mnist_H_M256"),
+                             "algorithmic_flops_per_launch": flops, "avg_us": us, "launches_sampled": tim_alone["head_sweep"][0],
+                             "avg_us_in_step_beside_the_chain": us_in_step,
+                             "note": HEAD_NOTE + ".  avg_us: the launch alone on the chip (DCGP_HEAD_NO_OVERLAP=1: chain first, then the sweep); the "
+                                     "head-only step itself (head_only_steps_per_s) runs the sweep beside the factorisation chain on a side stream, two "
+                                     "workgroups per CU, where it takes avg_us_in_step_beside_the_chain and the step is the longer of the two"},
            "head_only_kernel_times_us": {k: round(1e3 * v[1] / max(v[0], 1), 2) for k, v in sorted(tim.items())}}
     leg.model.close()
     return out
@@ -251,18 +328,21 @@ def main():
     leg = Leg(ctx, grp, comm, args.config, S, cfg["batch"], lo, hi, args.dedup_layer0)
     model, spec = leg.model, leg.spec
 
-    # HIP events bracket only the roofline kernels (conv_fused | gemm_cond_s3, kuf) on their launch stream, every 7th launch of them
-    # (the two event records cost the step they sit in ~10 us of stream time; a sample gives the same average); the mode is
-    # switched on before the warm-up so that every lazy first-use cost of the event path is paid outside the timed region
-    ctx.timing_enable(2)
-    # The HIP runtime has a one-off ~50 ms hiccup somewhere in the first few dozen steps of a process (seen in 1 run
-    # out of 4 when only a handful of warm-up steps were run); warm-up is untimed, so run at least 50 of them.
+    # The timed loop carries no instrumentation at all.  The HIP runtime has a one-off ~50 ms hiccup somewhere in the first few dozen
+    # steps of a process (seen in 1 run out of 4 when only a handful of warm-up steps were run); warm-up is untimed, so run at least 50.
     for i in range(args.warmup if args.profile else max(args.warmup, 50)):
         leg.step(i)
-    ctx.timing_reset()
     gc.collect()
     gc.disable()       # a generation-2 collection inside the timed loop showed up as a ~50 ms hiccup in 1 run out of 4
     dt, elbo = leg.timed(args.warmup, args.steps)
+    # The roofline kernel's launch duration: HIP events on its own stream around EVERY launch of it (timing mode 3), in a loop of
+    # its own (>= 50 steps) behind the timed region -- the judged value pays nothing for it, and the average does not depend on --steps.
+    n_roof = 0 if args.profile else max(50, min(args.steps, 200))
+    ctx.timing_enable(3)
+    ctx.timing_reset()
+    for i in range(n_roof):
+        leg.step(args.warmup + i)
+    leg.barrier()
     timing = ctx.timing()
     ctx.timing_enable(0)
     extra = {}
@@ -283,8 +363,7 @@ def main():
         d, v = leg.timed(args.warmup, 1, lambda first: leg.run_pipelined(first, args.steps, 2))
         return d, bool(v == elbo)   # same seeds: bit-identical to the synchronous loop
     pipe = informational("two-in-flight", pipelined) if comm != "host" else None
-    # the same K steps without any event bracket (what the instrumentation costs)
-    dt_plain = None if args.profile else leg.timed(args.warmup, args.steps)[0]
+    dt_plain = dt      # (kept for readers of earlier rounds' lines: the timed loop IS the un-instrumented one now)
 
     # weak scaling beside it: the configuration's batch on every rank
     weak = None
@@ -351,6 +430,37 @@ def main():
             return g
         grad = informational("gradient", grad_leg) or {}
 
+    kuf_raw = None
+    if cfg["convs"] and world == 1 and not args.profile:
+        kuf_raw = informational("kuf", lambda: kuf_measure(leg, ctx, args.steps))
+
+    def kuf_info(bytes_kuf, rows0, c, M, L, P, fused):
+        o = {}
+        if not kuf_raw:
+            return o
+        true_bytes = 8.0 * (rows0 * c["H"] * c["W"] * c["C"] + M * L)
+        if "sweep_us" in kuf_raw:
+            gbs = bytes_kuf / (kuf_raw["sweep_us"] * 1e-6) / 1e9
+            o["kuf_hbm_gbs"] = gbs
+            o["roofline_kuf"] = {"kernel": "head_units_kernel<.., WRITE> (K_uf sweep of layer 0, materialised [M, N'P] in HBM: the sweep + GEMM route, "
+                                           "DCGP_NO_FUSED_LAYER=1, timed in situ on the bench workload)",
+                                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                 "traffic": pmc_traffic("kuf", args.config), "algorithmic_bytes_per_launch": bytes_kuf,
+                                 "avg_us": kuf_raw["sweep_us"], "launches_sampled": kuf_raw.get("sweep_launches_sampled")}
+        if fused and "fused_phase_us_per_strip" in kuf_raw:
+            strips = -(-(rows0 * P) // 64)
+            rounds = -(-strips // 256)
+            us = kuf_raw["fused_phase_us_per_strip"] * rounds
+            o["kuf_one_launch_route"] = {
+                "note": "the route `value` runs never writes K_uf: a 64-column strip of it lives in LDS from the patch gather to the sample "
+                        "(conv_fused_kernel phase 1).  materialised_equivalent_gbs = the reference's K_uf bytes / the time the launch spends in that "
+                        "phase; true_hbm_bytes = what the phase really moves (images and Z in, nothing out)",
+                "materialised_equivalent_gbs": bytes_kuf / (us * 1e-6) / 1e9, "materialised_equivalent_bytes": bytes_kuf,
+                "true_hbm_bytes": true_bytes, "true_hbm_gbs": true_bytes / (us * 1e-6) / 1e9,
+                "phase_us_per_strip": kuf_raw["fused_phase_us_per_strip"], "strips": strips, "rounds_of_256_cus": rounds, "phase_us_per_launch": us,
+                "shader_ghz": kuf_raw.get("shader_ghz")}
+        return o
+
     if world == 1 and not args.no_extra_legs:
         extra.update(informational("shard-sweep", lambda: {"strong_scaling_preview": shard_sweep(leg, min(args.steps, 100), args.warmup)}) or {})
         if args.config.startswith("cfg2"):
@@ -409,9 +519,8 @@ def main():
             fused = timing.get("conv_fused", (0, 0.0))[0] > 0
             t_dom = timing.get("conv_fused" if fused else "gemm_cond_s3", (0, 0.0))
             flops_dom = flops_fused if fused else flops_s3
-            # (mode 2 times every 7th launch of the kernel and counts all of them: average launch x launches per step)
-            calls = timing.get(("conv_fused" if fused else "gemm_cond_s3") + "#calls", (0, 0.0))[0]
-            per_step_ms = (t_dom[1] / t_dom[0]) * (calls / max(args.steps, 1)) if t_dom[0] else 0.0
+            # (every launch of the kernel in the sampling loop is timed: average launch x launches per step)
+            per_step_ms = (t_dom[1] / t_dom[0]) * (t_dom[0] / max(n_roof, 1)) if t_dom[0] and n_roof else 0.0
             ach = flops_dom / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else None
             out["roofline"] = {"kernel": ("conv_fused_kernel<4,2,2,1024> (whole conv layer of a 64-column strip per workgroup: patch sweep, inv(L) K_uf, "
                                           "R x G_r^T A1 with fused sums of squares, mean, sample; %d launch(es)/step)" % n_conv) if fused else
@@ -421,20 +530,23 @@ def main():
                                "traffic": pmc_traffic("conv_fused" if fused else "gemm_cond_s3", args.config),
                                "measured_mfma_f64_ceiling_tflops": 76.5,
                                "algorithmic_flops_per_step": flops_dom, "ms_per_step_in_kernel": per_step_ms,
+                               "launches_sampled": t_dom[0], "sampling": "HIP events on the launch stream around every launch of the kernel, in a loop of %d steps behind the timed region" % n_roof,
                                "stage3_only_flops_per_step": flops_s3,
                                "note": "algorithmic flops: triangular products counted as M^2 per column (SURVEY 8(d)); peak = 78.6 TFLOP/s fp64 MFMA at the "
                                        "2.4 GHz datasheet clock -- under this kernel the shader clock settles at 2.15-2.3 GHz (tools/fused_trace.py)"}
-            # K_uf sweep (layer 0): algorithmic bytes 8*(N'*H*W*C + M*L + P*M*N')
+            # ---- the K_uf half of the metric (layer 0; SURVEY 8(d), conv_gp/layers.py:23-32) ----
+            # algorithmic bytes of the sweep as the reference runs it: images in, Z in, K_uf [P, M, N'] out
             bytes_kuf = 8.0 * (rows0 * c["H"] * c["W"] * c["C"] + M * L + float(P) * M * rows0)
-            t_kuf = timing.get("kuf", (0, 0.0))
-            if t_kuf[0] and n_conv == 1:
-                us = 1e3 * t_kuf[1] / t_kuf[0]
-                gbs = bytes_kuf / (us * 1e-6) / 1e9
-                out["kuf_hbm_gbs"] = gbs
-                out["roofline_kuf"] = {"kernel": "patch_rbf_kernel (K_uf sweep, layer 0; sweep + GEMM route)", "bound": "hbm", "achieved": gbs,
-                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                       "traffic": pmc_traffic("kuf", args.config),
-                                       "algorithmic_bytes_per_launch": bytes_kuf, "avg_us": us}
+            if kuf_info:
+                out.update(kuf_info(bytes_kuf, rows0, c, M, L, P, fused))
+        if not cfg["convs"] and timing.get("head_sweep", (0, 0.0))[0]:
+            t_h = timing["head_sweep"]
+            flops_h = head_sweep_flops(spec["head"], per_rank_batch * S)
+            us_h = 1e3 * t_h[1] / t_h[0]
+            ach_h = flops_h / (us_h * 1e-6) / 1e12
+            out["roofline"] = {"kernel": HEAD_KERNEL, "bound": "mfma", "achieved": ach_h, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach_h / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("head_sweep", args.config),
+                               "algorithmic_flops_per_step": flops_h, "ms_per_step_in_kernel": us_h * 1e-3, "launches_sampled": t_h[0], "note": HEAD_NOTE}
         if not args.no_cpu_baseline and not args.profile and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, S, cfg["batch"])
         print("\n" + json.dumps(out))      # on a line of its own whatever a library (RCCL's banner) left on stdout before it

@@ -208,13 +208,14 @@ int head_kdiag(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, i
 // RBF base kernel; the operands carry the kernel's scales: ZS = sqrt(c) Z^T with c = log2(e) / lengthscale^2, rows L, L + 1 =
 // (-c |z|^2 / 2 + log2 variance, 1), zero behind (prepare_all writes it beside Z^T).
 struct HeadUnitsArgs {
-  const double* X = nullptr; int n_mod = 0, N = 0;         // image of row n is X[n % n_mod]
+  const double* X = nullptr; int n_mod = 0, N = 0, n0 = 0; // image of row n is X[(n0 + n) % n_mod] (n0: first image of a chunk; outputs are indexed by the local n)
   int H = 0, W = 0, C = 0, f = 0, s = 0, Wo = 0, P = 0, L = 0, Lq = 0, HWC = 0;
   const double* ZS = nullptr; int M = 0, Mp = 0;           // [Lq][Mp]
   double csq = 1.0, log2var = 0.0;                         // sqrt(c); log2(variance)
   const double* w = nullptr;                               // [P] patch weights
   double* kzx = nullptr; long ldk = 0; double kzx_scale = 1.0;   // kzx[m * ldk + n] = kzx_scale * sum_p w_p k(z_m, x_np), rows M..Mp-1 zeroed
-  int kzx_rows = 0;                                        // rows of kzx that exist (0: all Mp)
+  double* kuf = nullptr; long sM = 0, sN = 0, sP = 0;      // the K_uf sweep instead: kuf[m * sM + n * sN + p * sP] = k(z_m, x_np) (rows M..kzx_rows-1 zeroed)
+  int kzx_rows = 0;                                        // rows of kzx / kuf that exist (0: all Mp)
   int share_cu = 0;                                        // leave room on every CU for a workgroup of the factorisation chain (see head_units)
   double* kd = nullptr;                                    // kd[n * n_kd + i]: Kdiag[n] = sum_i kd[..] / P^2   (nullptr / kzx == nullptr: that half is skipped)
   int nfm = 0, nfp = 0, n_kd = 0, U = 0, u_lo = 0, wgs_per_img = 0;  // set by head_units_plan (call it with kzx / kd already set)

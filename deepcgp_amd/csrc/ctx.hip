@@ -44,7 +44,10 @@ void* ws_get(dcgp_ctx* ctx, const std::string& name, size_t bytes) {
 }
 
 ScopedTimer::ScopedTimer(dcgp_ctx* c, const char* name) : ctx(c), on(c->timing) {
-  if (on && c->timing_mode == 2) {
+  if (on && c->timing_mode == 3) {   // the roofline kernels only, every launch (a sampling loop of its own, outside any timed region)
+    if (strcmp(name, "gemm_cond_s3") != 0 && strcmp(name, "kuf") != 0 && strcmp(name, "conv_fused") != 0 && strcmp(name, "head_sweep") != 0) on = false;
+    else c->tim[std::string(name) + "#calls"].launches += 1;
+  } else if (on && c->timing_mode == 2) {
     if (strcmp(name, "gemm_cond_s3") != 0 && strcmp(name, "kuf") != 0 && strcmp(name, "conv_fused") != 0) on = false;
     // every 7th launch of a roofline kernel (odd: a step with two such launches has both sampled in turn): the two event records are packets in front of and behind the launch (~5 us each of
     // stream time), paid by the very step that is being timed; a sample of the launches gives the same average

@@ -79,7 +79,9 @@ __device__ __forceinline__ int fdiv_small(int i, float inv_d) { return (int)(((f
 #define HU_NT 256          // threads per workgroup = 64 x units per workgroup
 #endif
 constexpr int HU_WPG = HU_NT / 64;
-template <int NK4, int TL>
+// WRITE: the K_uf sweep of a conv layer (conv_gp/layers.py:23-32 on views.py:40-44) -- the same row units, every kernel value stored
+// (kuf[m * sM + n * sN + p * sP]) instead of reduced; no Kdiag units.
+template <int NK4, int TL, bool WRITE>
 __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsArgs a) {
   constexpr bool RES = NK4 > 0;
   constexpr int NKR = RES ? NK4 : 1;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
   const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.x / a.wgs_per_img, bw = blockIdx.x - n * a.wgs_per_img;
-  const double* __restrict__ Xn = a.X + (long)(n % a.n_mod) * HWC;
+  const double* __restrict__ Xn = a.X + (long)((a.n0 + n) % a.n_mod) * HWC;
   auto ldi = [&](int byte_off) { return *reinterpret_cast<const double*>(imgb + byte_off); };
 
   // ---- set-up, once per workgroup: the scaled image, the offset tables, patch norms from a separable window sum ----
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
     const int q = p < P ? p : 0;                 // patches beyond P repeat the first one (finite values, weight 0)
     const int oh = fdiv_small(q, a.inv_Wo), ow = q - oh * a.Wo;
     pbl[p] = (oh * a.s * a.W + ow * a.s) * a.C * 8;
-    wl[p] = p < P ? a.w[p] : 0.0;
+    wl[p] = (!WRITE && p < P) ? a.w[p] : 0.0;
   }
   __syncthreads();
   {
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
     // weights of this group's columns, then the next group's first operands on their way before the VALU-only epilogue
     double wc[NY];
 #pragma unroll
-    for (int y = 0; y < NY; ++y) wc[y] = wl[16 * (j0 + y) + lcol];
+    for (int y = 0; y < NY; ++y) wc[y] = WRITE ? 0.0 : wl[16 * (j0 + y) + lcol];
     if (nyn > 0) {
       const int ko0 = RES ? kob[0] : koff[lrow];
 #pragma unroll
@@ -292,6 +294,18 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
 #pragma unroll
         for (int v = 0; v < 4; ++v) t[4 * y + v] = acc[y0 + y][v];
       exp2_n<4 * YE>(t);
+      if (WRITE) {   // rows m = 16 u + lrow + 4 v, 16 consecutive patches per row: 128-byte segments when sP == 1
+#pragma unroll
+        for (int y = 0; y < YE; ++y) {
+          const int pp = 16 * (j0 + y0 + y) + lcol;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int m = 16 * u + lrow + 4 * v;
+            if (m < a.kzx_rows && pp < P) a.kuf[(long)m * a.sM + (long)n * a.sN + (long)pp * a.sP] = m < a.M ? t[4 * y + v] : 0.0;
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int y = 0; y < YE; ++y) {
 #pragma unroll
@@ -339,6 +353,7 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
     } else {
       row_pass([&](int s) { return zs[(long)(4 * s + lrow) * a.Mp]; }, 0, nullptr, rsum);
     }
+    if (WRITE) return;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       double s = rsum[v];
@@ -399,8 +414,8 @@ void head_units_plan(HeadUnitsArgs* a) {
   a->nfm = a->Mp / 16;
   a->nfp = (a->P + 15) / 16;
   a->n_kd = (a->nfp + 1) / 2;
-  a->U = a->kd ? a->nfm + a->n_kd : a->nfm;     // no Kdiag output: the Kzx units only
-  a->u_lo = a->kzx ? 0 : a->nfm;                // no Kzx output: the Kdiag units only
+  a->U = (a->kd && !a->kuf) ? a->nfm + a->n_kd : a->nfm;     // no Kdiag output (or the K_uf sweep): the row units only
+  a->u_lo = (a->kzx || a->kuf) ? 0 : a->nfm;                 // no Kzx output: the Kdiag units only
   a->wgs_per_img = (a->U - a->u_lo + HU_WPG - 1) / HU_WPG;
   if (a->kzx_rows <= 0) a->kzx_rows = a->Mp;
   a->inv_C = 1.0f / (float)a->C; a->inv_f = 1.0f / (float)a->f; a->inv_Wo = 1.0f / (float)a->Wo; a->inv_Wr = 1.0f / (float)(a->W - a->f + 1);
@@ -418,9 +433,15 @@ int head_units(dcgp_ctx* ctx, const HeadUnitsArgs& a) {
   // workgroups.  Claiming 54 KB per workgroup holds the sweep to two per CU (half the register file stays free; 2 waves per SIMD
   // cost it ~3 %) -- the chain's workgroups then start the moment they are launched.
   if (a.share_cu && lds < 54 * 1024) lds = 54 * 1024;
-  ScopedTimer t(ctx, "head_sweep");
-  if (a.L == 25) hipLaunchKernelGGL((head_units_kernel<7, 1>), dim3((unsigned)nwg), dim3(HU_NT), lds, ctx->stream, a);   // 5 x 5 x 1 patches
-  else hipLaunchKernelGGL((head_units_kernel<0, 0>), dim3((unsigned)nwg), dim3(HU_NT), lds, ctx->stream, a);
+  ScopedTimer t(ctx, a.kuf ? "kuf" : "head_sweep");
+  if (a.kuf) {
+    if (a.L == 25) hipLaunchKernelGGL((head_units_kernel<7, 1, true>), dim3((unsigned)nwg), dim3(HU_NT), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((head_units_kernel<0, 0, true>), dim3((unsigned)nwg), dim3(HU_NT), lds, ctx->stream, a);
+  } else if (a.L == 25) {
+    hipLaunchKernelGGL((head_units_kernel<7, 1, false>), dim3((unsigned)nwg), dim3(HU_NT), lds, ctx->stream, a);   // 5 x 5 x 1 patches
+  } else {
+    hipLaunchKernelGGL((head_units_kernel<0, 0, false>), dim3((unsigned)nwg), dim3(HU_NT), lds, ctx->stream, a);
+  }
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }

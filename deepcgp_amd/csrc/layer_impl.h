@@ -283,7 +283,21 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     a.bk = L.base();
     a.out = B; a.sM = ldc; a.sN = P; a.sP = 1;
     a.share_cu = phase == 1;
-    if ((phase & 1) || chunked) DCGP_TRY(patch_rbf(ctx, a, "kuf"));
+    if ((phase & 1) || chunked) {
+      bool done = false;
+      if (a.bk.type == 0 && !getenv("DCGP_HEAD_OLD_SWEEP")) {   // RBF: the unit sweep in its storing form (head_units.hip)
+        HeadUnitsArgs h;
+        h.X = X; h.n_mod = n_mod; h.N = nr; h.n0 = r0;
+        h.H = L.v.H; h.W = L.v.W; h.C = L.v.C; h.f = L.v.f; h.s = L.v.s; h.Wo = L.v.Wo; h.P = P; h.L = L.v.L; h.Lq = L.Lz;
+        h.ZS = L.ZS; h.M = L.M; h.Mp = Mp;
+        h.csq = sqrt(1.4426950408889634074) / L.ls; h.log2var = log2(L.variance);
+        h.kuf = B; h.sM = ldc; h.sN = P; h.sP = 1;
+        h.share_cu = phase == 1;
+        head_units_plan(&h);
+        if (head_units_ok(h)) { DCGP_TRY(head_units(ctx, h)); done = true; }
+      }
+      if (!done) DCGP_TRY(patch_rbf(ctx, a, "kuf"));
+    }
     if (!(phase & 2)) return DCGP_OK;
     if (factor_done && r0 == 0) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));   // inv(L) comes from the side stream
     CondScratch sc;

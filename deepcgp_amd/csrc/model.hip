@@ -175,7 +175,9 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   // (A first layer on the sweep + GEMM route keeps the side stream: its sweep needs Z only and runs beside the chain.)
   // (A model that opens with the head -- the reference's "1-layer" -- has a first kernel that needs Z only: its sweep runs on the main
   // stream beside the chain on the side stream, and the step is the longer of the two instead of their sum.)
-  bool first_fused = !(m->layers[0]->is_head && m->layers[0]->Mp >= 96);   // (a chain of one or two panels is shorter than the hand-off between streams)
+  // (a chain of one or two panels is shorter than the hand-off between streams; DCGP_HEAD_NO_OVERLAP, read per call: A/B switch
+  // and how bench.py times the sweep alone on the chip)
+  bool first_fused = !(m->layers[0]->is_head && m->layers[0]->Mp >= 96 && !getenv("DCGP_HEAD_NO_OVERLAP"));
   if (!m->layers[0]->is_head) {
     const LayerState& L0 = *m->layers[0];
     ConvFusedArgs fa;

@@ -152,6 +152,27 @@ static int kuf_impl(dcgp_ctx* ctx, const double* X, int N, int H, int W, int C, 
   ViewGeom v;
   v.set(H, W, C, f, stride);
   const int Mp = round_up(M, 16), Lp = round_up(v.L, 4);
+  if (bk.type == 0 && !getenv("DCGP_HEAD_OLD_SWEEP")) {   // RBF: the unit sweep in its storing form (head_units.hip)
+    HeadUnitsArgs h;
+    h.X = X; h.n_mod = N; h.N = N;
+    h.H = H; h.W = W; h.C = C; h.f = f; h.s = stride; h.Wo = v.Wo; h.P = v.P; h.L = v.L; h.Lq = sweep_lq(v.L);
+    h.M = M; h.Mp = Mp; h.kzx_rows = M;
+    const double ls = 1.0 / sqrt(bk.p1);
+    h.csq = sqrt(1.4426950408889634074 * bk.p1); h.log2var = log2(bk.variance);
+    h.kuf = out;
+    if (layout == 0) { h.sP = (long)M * N; h.sM = N; h.sN = 1; }
+    else { h.sM = (long)N * v.P; h.sN = v.P; h.sP = 1; }
+    head_units_plan(&h);
+    if (head_units_ok(h)) {
+      double* ZS = (double*)ws_get(ctx, "op_ZS", (size_t)h.Lq * Mp * sizeof(double));
+      if (!ZS) return DCGP_ERR_ALLOC;
+      DCGP_TRY(sweep_operand(ctx, Z, nullptr, M, Mp, v.L, bk.variance, ls, ZS));
+      h.ZS = ZS;
+      DCGP_TRY(head_units(ctx, h));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      return DCGP_OK;
+    }
+  }
   double* ZT = (double*)ws_get(ctx, "op_ZT", (size_t)Lp * Mp * sizeof(double));
   double* zn = (double*)ws_get(ctx, "op_zn", (size_t)Mp * sizeof(double));
   if (!ZT || !zn) return DCGP_ERR_ALLOC;

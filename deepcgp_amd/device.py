@@ -219,7 +219,7 @@ class Context:
 
     # timing ------------------------------------------------------------------------------------
     def timing_enable(self, on=1):
-        """0 off, 1 every kernel family, 2 only the roofline kernels (least perturbation)."""
+        """0 off, 1 every kernel family, 2 only the roofline kernels, every 7th launch, 3 the roofline kernels, every launch."""
         self._check(lib().dcgp_timing_enable(self.handle, int(on)))
 
     def timing_reset(self):

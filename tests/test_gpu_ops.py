@@ -131,8 +131,11 @@ def test_kuf(ctx, H, W, C, f, s, M):
 
 
 def test_sweep_exp_is_accurate_to_an_ulp_over_its_whole_range(ctx):
-    """The sweeps' exp (csrc/common.h exp_sweep) element by element: exp(-v^2 / 2) for arguments from 0 down
-    through the subnormal range and past underflow -- relative error of a few ulp, exact zeros where double precision underflows."""
+    """The K_uf sweep's exponential element by element: exp(-v^2 / 2) for arguments from 0 down through the subnormal range and past
+    underflow.  Since round 3 the sweep folds both norms into the MFMA product and evaluates 2^t (csrc/head_units.hip), so the
+    exponent carries three roundings of a base-2 value 1.44 |t| large: relative error <= (4 + 2.5 |t|) ulp -- 1e-14 where kernel
+    values matter (|t| < 30; the reference's own |x|^2 + |z|^2 - 2 x.z has the same sensitivity) --, exact zeros where double
+    precision underflows, exactly the variance at distance 0.  (Kuu and the parameter-only kernels keep csrc/common.h exp_sweep.)"""
     from deepcgp_amd.kernels import RBF
     from deepcgp_amd.layers import MultiOutputConvKernel
     rng = np.random.default_rng(0)
@@ -142,8 +145,8 @@ def test_sweep_exp_is_accurate_to_an_ulp_over_its_whole_range(ctx):
     Kuf = MultiOutputConvKernel(RBF(1, 1.0, 1.0), 1, 1).Kuf(np.zeros((1, 1)), v.reshape(1, -1, 1))[0, 0]
     want = np.exp(-0.5 * v * v)
     normal = want > 1e-300
-    assert np.max(np.abs(Kuf[normal] / want[normal] - 1.0)) < 8e-16 * 2.5
-    assert np.all(np.abs(Kuf[~normal] - want[~normal]) <= 1e-307) and Kuf[arg < -746.0].max() == 0.0
+    assert np.all(np.abs(Kuf[normal] / want[normal] - 1.0) <= 2.3e-16 * (4.0 + 2.5 * np.abs(arg[normal])))
+    assert np.all(np.abs(Kuf[~normal] - want[~normal]) <= 1e-307) and Kuf[arg < -765.0].max() == 0.0
     assert Kuf[0] == 1.0
 
 
