@@ -93,6 +93,8 @@ class Leg:
         self.model = build_from_spec(self.spec, self.Xh, self.Yh)
         self.model.dedup_layer0 = bool(dedup)
         self.model.global_batch = global_batch
+        if hi - lo != global_batch:
+            self.model.set_shard(lo, global_batch)   # noise drawn at the element's place in the un-sharded batch: same ELBO for any rank count
         self.dX, self.dY = ctx.to_device(self.Xh), ctx.to_device(self.Yh, np.int32)
         self.scale = float(self.spec["num_data"]) / float(global_batch)
 

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
       if (a.out_mean) a.out_mean[o] = m;
       if (a.out_var) a.out_var[o] = v;
       if (a.out_sample) {
-        const double zz = a.z ? a.z[o] : philox_normal(a.seed, a.stream_id, (uint64_t)o);
+        const double zz = a.z ? a.z[o] : philox_normal(a.seed, a.stream_id, rng_index(a.rmap, o));
         a.out_sample[o] = m + zz * sqrt(v + a.jitter);
       }
     }

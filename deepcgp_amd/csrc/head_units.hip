@@ -157,7 +157,8 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
 
   // this wave's unit: rotated by the image so that the empty slots of the last workgroup of an image (U % 4 != 0) do not
   // always fall on the same SIMDs
-  const int u = a.u_lo + HU_WPG * bw + ((wave + n) & (HU_WPG - 1));
+  // (a workgroup covers HU_WPG * upw consecutive units, wave w the units w, w + HU_WPG, ...: one set-up for upw units per wave)
+  int u = a.u_lo + HU_WPG * a.upw * bw + ((wave + n) & (HU_WPG - 1));
   if (u >= a.U) return;
 
   // The operand slots k = 4 s + lrow behind the patch (k >= L) sit in the last one or two sub-steps (ts = s - sL): the A side
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
     else if (nrem == 3) group(T3{}, getA, j0, -1, 0, rd, rsum, pb, bv);
   };
 
+  for (int uu = 0; uu < a.upw && u < a.U; ++uu, u += HU_WPG) {
   if (u < a.nfm) {
     // ---- Kzx rows 16 u .. 16 u + 15: out[m][n] = scale * sum_p w_p k(z_m, x_p) ----
     const double* __restrict__ zs = a.ZS + 16 * u + lcol;
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
     } else {
       row_pass([&](int s) { return zs[(long)(4 * s + lrow) * a.Mp]; }, 0, nullptr, rsum);
     }
-    if (WRITE) return;
+    if (WRITE) continue;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       double s = rsum[v];
@@ -395,6 +397,7 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
     for (int o = 1; o < 64; o <<= 1) total += __shfl_xor(total, o);
     if (lane == 0) a.kd[(long)n * a.n_kd + i] = total;
   }
+  }
 }
 
 }  // namespace
@@ -416,7 +419,18 @@ void head_units_plan(HeadUnitsArgs* a) {
   a->n_kd = (a->nfp + 1) / 2;
   a->U = (a->kd && !a->kuf) ? a->nfm + a->n_kd : a->nfm;     // no Kdiag output (or the K_uf sweep): the row units only
   a->u_lo = (a->kzx || a->kuf) ? 0 : a->nfm;                 // no Kzx output: the Kdiag units only
-  a->wgs_per_img = (a->U - a->u_lo + HU_WPG - 1) / HU_WPG;
+  // units per wave: the set-up of a workgroup (image, window sums, tables: ~3 us of latency) is as long as a short unit (a 16-row
+  // fragment against the 9 patch fragments of a 12 x 12 view), so such launches put several units behind one set-up -- as many as
+  // leave >= 512 workgroups (two per CU), and never a count between one and two rounds of the 1024 resident slots
+  const int nu = a->U - a->u_lo;
+  a->upw = 1;
+  if (a->upw_force > 0) a->upw = a->upw_force;
+  else
+    for (int k = 4; k > 1; k >>= 1) {
+      const long nwg = (long)a->N * ((nu + HU_WPG * k - 1) / (HU_WPG * k));
+      if (a->nfp <= 16 && nwg >= 512 && nu % (HU_WPG * k) == 0) { a->upw = k; break; }
+    }
+  a->wgs_per_img = (nu + HU_WPG * a->upw - 1) / (HU_WPG * a->upw);
   if (a->kzx_rows <= 0) a->kzx_rows = a->Mp;
   a->inv_C = 1.0f / (float)a->C; a->inv_f = 1.0f / (float)a->f; a->inv_Wo = 1.0f / (float)a->Wo; a->inv_Wr = 1.0f / (float)(a->W - a->f + 1);
 }

@@ -1,6 +1,7 @@
 // Internal: device-resident state of one GP layer and the shared forward building blocks.
 #pragma once
 #include "common.h"
+#include "rng.h"
 
 // Geometry of a patch view (FullView, conv_gp/views.py:20-30,56-68)
 struct ViewGeom {
@@ -80,6 +81,7 @@ struct FinalizeArgs {
   int rep = 1; long rep_stride = 0;
   const double* z = nullptr;     // same indexing as the output; nullptr + want sample -> device RNG
   uint64_t seed = 0; uint32_t stream_id = 0;
+  RngMap rmap;                    // device RNG: the element's counter in the un-sharded batch
   double jitter = 0.0;
   double *out_sample = nullptr, *out_mean = nullptr, *out_var = nullptr;
   // Conv2dMean (conv_gp/mean_functions.py:28-41): adds the centre pixel of channel 0 to map r == 0
@@ -101,6 +103,7 @@ struct ConvFusedArgs {
   double knn = 0.0;
   int rep = 1; long rep_stride = 0;
   const double* z = nullptr; uint64_t seed = 0; uint32_t stream_id = 0; double jitter = 0.0;
+  RngMap rmap;                                             // device RNG: the element's counter in the un-sharded batch
   double *out_sample = nullptr, *out_mean = nullptr, *out_var = nullptr;
   int idm = 0;
   double *Kuf_out = nullptr, *A1_out = nullptr; long ldk = 0;   // training step: k-major [Mp][ldk] copies for the reverse pass

@@ -225,7 +225,7 @@ struct FactorGroup {
 static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, int rows, int n_mod, int rep, long rep_stride,
                  const double* z, uint64_t seed, uint32_t stream_id, double jitter, double* out_sample, double* out_mean,
                  double* out_var, const std::string& pfx, hipEvent_t factor_done = nullptr,
-                               hipEvent_t prep_done = nullptr, int phase = 3, bool keep_state = true) {
+                               hipEvent_t prep_done = nullptr, int phase = 3, bool keep_state = true, const RngMap* rmap = nullptr) {
   // phase bit 0: the K_uf sweep (needs only Z); bit 1: conditional + finalize (needs the factorisation).  The model
   // path enqueues bit 0 of its first layer BEFORE the long side-stream sequence so that the sweep is not held up
   // by the host still enqueueing the factorisation chain.
@@ -246,6 +246,7 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     fa.Kc = (int)Kc; fa.knn = L.variance;
     fa.rep = rep; fa.rep_stride = rep_stride; fa.z = z; fa.seed = seed; fa.stream_id = stream_id; fa.jitter = jitter;
     fa.out_sample = out_sample; fa.out_mean = out_mean; fa.out_var = out_var; fa.idm = L.identity_mean;
+    if (rmap) fa.rmap = *rmap;
     if (conv_fused_ok(fa)) {
       if (!(phase & 2)) return DCGP_OK;   // nothing to run ahead of the factorisation: the sweep is part of the one launch
       if (keep_state) {
@@ -293,6 +294,7 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
         h.csq = sqrt(1.4426950408889634074) / L.ls; h.log2var = log2(L.variance);
         h.kuf = B; h.sM = ldc; h.sN = P; h.sP = 1;
         h.share_cu = phase == 1;
+        if (getenv("DCGP_KUF_UPW")) h.upw_force = atoi(getenv("DCGP_KUF_UPW"));   // A/B switch
         head_units_plan(&h);
         if (head_units_ok(h)) { DCGP_TRY(head_units(ctx, h)); done = true; }
       }
@@ -307,6 +309,7 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     fa.Kc = (int)kc; fa.R = L.R; fa.knn_scalar = L.variance; fa.col0 = (long)r0 * P;
     fa.rep = rep; fa.rep_stride = rep_stride; fa.z = z; fa.seed = seed; fa.stream_id = stream_id; fa.jitter = jitter;
     fa.out_sample = out_sample; fa.out_mean = out_mean; fa.out_var = out_var;
+    if (rmap) fa.rmap = *rmap;
     if (L.identity_mean) {
       fa.X = X; fa.idm = 1; fa.H = L.v.H; fa.W = L.v.W; fa.C = L.v.C; fa.f = L.v.f; fa.s = L.v.s; fa.Wo = L.v.Wo; fa.P = P;
       fa.n_mod = n_mod;

@@ -296,9 +296,14 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       const int out_rows = expand ? S * N : rows;
       DCGP_TRY(ensure_out(m, li, out_rows, width, true));
       auto& o = m->outs[li];
-      DCGP_TRY(conv_forward(ctx, L, F, rows, n_mod, expand ? S : 1, (long)N * width, z, seed, (uint32_t)(li + 1 + 64 * ctx->rank),
+      // device RNG: with a shard declared (dcgp_model_set_shard) every element draws at its counter in the un-sharded batch, one
+      // stream per layer -- the step's value is then independent of the number of ranks; otherwise one stream per (layer, rank)
+      RngMap rm;
+      const bool sharded = m->shard_global > 0;
+      if (sharded && (m->shard_global != N || m->shard_lo != 0)) { rm.W = width; rm.Nl = N; rm.Ng = m->shard_global; rm.lo = m->shard_lo; }
+      DCGP_TRY(conv_forward(ctx, L, F, rows, n_mod, expand ? S : 1, (long)N * width, z, seed, (uint32_t)(li + 1 + (sharded ? 0 : 64 * ctx->rank)),
                             m->jitter, o.sample, m->keep_outputs ? o.mean : nullptr, m->keep_outputs ? o.var : nullptr, pfx,
-                            fdone, pdone, 3, m->keep_state));
+                            fdone, pdone, 3, m->keep_state, &rm));
       *out_rows_p = out_rows;
     } else {
       DCGP_TRY(ensure_out(m, li, rows, L.R, true));
@@ -382,6 +387,14 @@ int dcgp_model_destroy(dcgp_model* model) {
     }
   }
   delete model;
+  return DCGP_OK;
+}
+
+int dcgp_model_set_shard(dcgp_model* model, int first_image, int global_batch) {
+  if (!model) return DCGP_ERR_ARG;
+  if (global_batch < 0 || first_image < 0 || (global_batch > 0 && first_image >= global_batch))
+    return ctx_fail(model->ctx, DCGP_ERR_ARG, "set_shard: first image %d of a global batch of %d", first_image, global_batch);
+  model->shard_lo = first_image; model->shard_global = global_batch;
   return DCGP_OK;
 }
 

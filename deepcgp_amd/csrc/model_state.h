@@ -12,6 +12,7 @@ struct dcgp_model {
   bool keep_outputs = false;
   bool keep_state = false;   // the forward leaves K_uf / A1 of every conv layer in HBM (set around the forward of dcgp_elbo_grad)
   int adam_t = 0;        // Adam steps taken on this model's moment buffers (bias correction; dcgp_model_adam_step with t = 0)
+  int shard_lo = 0, shard_global = 0;   // this rank's first image and the global batch (dcgp_model_set_shard): device-RNG counters
   int grad_shards = 0;   // KL gradient weight 1 / shards; 0 = number of ranks of the ctx's communicator (1 without one)
   // two banks of parameter-only state (LayerState::use_bank): factor groups, events and ELBO scalars follow the bank
   std::vector<FactorGroup> groups[2];

@@ -27,3 +27,16 @@ static __device__ __forceinline__ double philox_normal(uint64_t seed, uint32_t s
   return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
 }
 
+
+// Where a rank's output element sits in the GLOBAL batch: a rank holds images [lo, lo + Nl) of Ng, its rows are (sample s, local
+// image n) -> s * Nl + n, W outputs each.  The noise of element o is drawn at the counter of the same (sample, image, output) of the
+// un-sharded batch, so a step's value does not depend on the number of ranks (W == 0: not sharded, identity).
+struct RngMap {
+  int W = 0, Nl = 0, Ng = 0, lo = 0;
+};
+static __device__ __forceinline__ uint64_t rng_index(const RngMap& m, long o) {
+  if (m.W == 0) return (uint64_t)o;
+  const long row = o / m.W, w = o - row * m.W;
+  const long s = row / m.Nl, n = row - s * m.Nl;
+  return (uint64_t)(((s * m.Ng + m.lo + n) * m.W) + w);
+}

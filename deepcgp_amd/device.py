@@ -89,6 +89,7 @@ _SIGS = {
     "dcgp_model_adam_step": [_vp, _d, _d, _d, _d, _i],
     "dcgp_model_get_param": [_vp, _i, C.c_char_p, _vp, C.c_size_t],
     "dcgp_model_set_grad_shards": [_vp, _i],
+    "dcgp_model_set_shard": [_vp, _i, _i],
     "dcgp_model_grad_block": [_vp, _i, C.POINTER(_vp), C.POINTER(C.c_size_t)],
     "dcgp_model_sgd_step": [_vp, _d],
     "dcgp_model_set_trainable": [_vp, _i, C.c_char_p, _i],

@@ -278,6 +278,14 @@ class DGP_Base:
         """Plain gradient ascent step in the unconstrained space (the "SGD" branch, conv_gp/experiment.py:100-103)."""
         self._ctx._check(dev.lib().dcgp_model_sgd_step(self._model, float(lr)))
 
+    def set_shard(self, first_image, global_batch):
+        """Multi-GPU: this rank holds images [first_image, first_image + N) of a minibatch of ``global_batch`` images (dist.shard_range).
+        Also sets ``global_batch`` for the default ELBO scale.  The device RNG then draws every element at its position in the un-sharded
+        batch: a step's ELBO is the same whatever the number of ranks."""
+        self._build()
+        dev.get_context()._check(dev.lib().dcgp_model_set_shard(self._model, int(first_image), int(global_batch)))
+        self.global_batch = int(global_batch) if global_batch else None
+
     def set_trainable(self, layer, which, on):
         """param.set_trainable(on) for the device optimiser steps: which in Z, q_mu, q_sqrt, w, hyper."""
         self._build()

@@ -33,11 +33,18 @@ def gauss_kl(q_mu, q_sqrt, K=None):
 
 
 def reparameterize(mean, var, z, full_cov=False):
-    """doubly_stochastic_dgp.utils.reparameterize: mean + z * sqrt(var + jitter)."""
-    if full_cov:
-        raise NotImplementedError
+    """doubly_stochastic_dgp.utils.reparameterize: mean + z * sqrt(var + jitter); full_cov=True: mean S x N x D, var S x N x N x D,
+    per (sample, output) mean + chol(var + jitter I) z (off the training path: one device factorisation per matrix)."""
     if var is None:
         return mean
+    if full_cov:
+        mean, var, z = (np.asarray(a, np.float64) for a in (mean, var, z))
+        S, N, D = mean.shape
+        out = np.empty_like(mean)
+        for s_ in range(S):
+            for d_ in range(D):
+                out[s_, :, d_] = mean[s_, :, d_] + _potrf(var[s_, :, :, d_] + JITTER * np.eye(N)) @ z[s_, :, d_]
+        return out
     ctx = dev.get_context()
     mean = np.ascontiguousarray(mean, np.float64)
     dm, dv, dz = ctx.to_device(mean), ctx.to_device(var), ctx.to_device(z)
@@ -104,10 +111,13 @@ class Layer:
         return 0.0
 
     def conditional_SND(self, X, full_cov=False):
-        if full_cov:
-            raise NotImplementedError("full_cov=True is outside the accelerated hot path")
+        """mean S x N x D and var S x N x D; full_cov=True: the samples one by one through conditional_ND(full_cov=True)
+        (the reference's tf.map_fn branch), var S x N x N x D."""
         X = np.asarray(X, np.float64)
         S, N, D = X.shape
+        if full_cov:
+            mv = [self.conditional_ND(X[s_], full_cov=True) for s_ in range(S)]
+            return np.stack([m for m, _ in mv]), np.stack([v for _, v in mv])
         mean, var = self.conditional_ND(X.reshape(S * N, D))
         return mean.reshape(S, N, self.num_outputs), var.reshape(S, N, self.num_outputs)
 
@@ -115,7 +125,7 @@ class Layer:
         mean, var = self.conditional_SND(X, full_cov=full_cov)
         if z is None:
             z = np.random.standard_normal(mean.shape)
-        samples = reparameterize(mean, var, np.reshape(z, mean.shape))
+        samples = reparameterize(mean, var, np.reshape(z, mean.shape), full_cov=full_cov)
         return samples, mean, var
 
 
@@ -234,8 +244,8 @@ class ConvLayer(Layer):
         return sample, mean, var
 
     def sample_from_conditional(self, X, z=None, full_cov=False):
-        if full_cov:
-            raise NotImplementedError("full_cov=True is outside the accelerated hot path")
+        if full_cov:   # (the call shape of conv_gp/utils/tensorboard.py:73-81) off the one-launch path: Layer's generic route
+            return Layer.sample_from_conditional(self, X, z=z, full_cov=True)
         X = np.asarray(X, np.float64)
         S, N, D = X.shape
         if z is None:

@@ -219,6 +219,10 @@ int dcgp_model_get_grad(dcgp_model* model, int layer, const char* which, double*
  * (p1 = lengthscale or ArcCosine weight variance, p2 = ArcCosine bias variance).  shards = 0
  * restores the default (ranks of the communicator, else 1). */
 int dcgp_model_set_grad_shards(dcgp_model* model, int shards);
+/* Multi-GPU: this rank holds images [first_image, first_image + N) of a minibatch of global_batch images.  With it
+ * declared the device RNG of Layer.sample_from_conditional draws every element at its counter in the UN-sharded batch, so the ELBO
+ * of a step does not depend on the number of ranks (global_batch = 0: not sharded, one RNG stream per rank). */
+int dcgp_model_set_shard(dcgp_model* model, int first_image, int global_batch);
 int dcgp_model_grad_block(dcgp_model* model, int layer, double** block_dev, size_t* count);
 /* One optimiser step on the gradients dcgp_elbo_grad left on the device: tf.train.AdamOptimizer semantics
  * (lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t); theta -= lr_t m / (sqrt(v) + eps); t = 1, 2, ...) ascending the

@@ -17,27 +17,37 @@ from . import kernels as _kernels
 
 
 def reparameterize(mean, var, z, full_cov=False):
-    """doubly_stochastic_dgp.utils.reparameterize, full_cov=False: mean + z * sqrt(var + jitter)."""
-    if full_cov:
-        raise NotImplementedError
+    """doubly_stochastic_dgp.utils.reparameterize: mean + z * sqrt(var + jitter); full_cov=True (UNVERIFIED, recalled -- SURVEY
+    App. A): mean S x N x D, var S x N x N x D -> SDN / SDNN, chol(var + jitter I) applied to z per (sample, output), back to SND."""
     if var is None:
         return mean
+    if full_cov:
+        S, N, D = mean.shape
+        m = np.transpose(mean, (0, 2, 1))                                  # S D N
+        v = np.transpose(var, (0, 3, 1, 2)) + JITTER * np.eye(N)[None, None]   # S D N N
+        chol = np.linalg.cholesky(v)
+        f = m + np.matmul(chol, np.transpose(z, (0, 2, 1))[..., None])[..., 0]
+        return np.transpose(f, (0, 2, 1))
     return mean + z * (var + JITTER) ** 0.5
 
 
-def conditional_SND(layer, X):
-    """Layer.conditional_SND: flatten S x N x D -> (S*N) x D, conditional_ND, reshape back."""
+def conditional_SND(layer, X, full_cov=False):
+    """Layer.conditional_SND: flatten S x N x D -> (S*N) x D, conditional_ND, reshape back; full_cov=True: sample by sample
+    (the tf.map_fn branch), var S x N x N x D."""
     S, N, D = X.shape
+    if full_cov:
+        mv = [layer.conditional_ND(X[s], full_cov=True) for s in range(S)]
+        return np.stack([m for m, _ in mv]), np.stack([v for _, v in mv])
     mean, var = layer.conditional_ND(X.reshape(S * N, D))
     return mean.reshape(S, N, layer.num_outputs), var.reshape(S, N, layer.num_outputs)
 
 
-def sample_from_conditional(layer, X, z=None, rng=None):
+def sample_from_conditional(layer, X, z=None, rng=None, full_cov=False):
     """Layer.sample_from_conditional(X[S,N,D], z=None) -> (samples, mean, var)."""
-    mean, var = conditional_SND(layer, X)
+    mean, var = conditional_SND(layer, X, full_cov=full_cov)
     if z is None:
         z = (rng or np.random.default_rng()).standard_normal(mean.shape)
-    return reparameterize(mean, var, z), mean, var
+    return reparameterize(mean, var, z, full_cov=full_cov), mean, var
 
 
 class SVGP_Layer:

@@ -8,7 +8,7 @@ import pytest
 
 from deepcgp_amd import synthetic as syn
 from deepcgp_amd.models import build_from_spec
-from deepcgp_amd.dist import shard_batch, assemble_elbo
+from deepcgp_amd.dist import shard_range, shard_batch, assemble_elbo
 from oracle_build import oracle_model
 from golden.make_golden import unflatten_spec
 
@@ -263,6 +263,19 @@ def test_shards_sum_to_full_batch_on_gpu(ctx):
             Xs, Ys, zl = shard_batch(X, Y, zs, rank, world)
             tot += model.compute_log_likelihood(Xs, Ys, zs=zl, return_parts=True)[1]
         assert abs(assemble_elbo(tot, kl, spec["num_data"], 7) - full) <= 1e-12 * abs(full)
+    # the same with the DEVICE RNG (what bench.py runs): a shard declared with set_shard draws its noise at the elements' places in the
+    # un-sharded batch, so the ranks' data terms still add up to the full batch's -- for the 3-layer stack and both de-dup settings too
+    for dedup in (False, True):
+        model.dedup_layer0 = dedup
+        full, data, kl = model.compute_log_likelihood(X, Y, seed=11, return_parts=True)
+        for world in (2, 3):
+            tot = 0.0
+            for rank in range(world):
+                lo, hi = shard_range(7, rank, world)
+                model.set_shard(lo, 7)
+                tot += model.compute_log_likelihood(X[lo:hi], Y[lo:hi], seed=11, return_parts=True, scale=spec["num_data"] / 7.0)[1]
+            model.set_shard(0, 0)
+            assert abs(assemble_elbo(tot, kl, spec["num_data"], 7) - full) <= 1e-12 * abs(full), (dedup, world)
     model.close()
 
 
@@ -1103,3 +1116,28 @@ print("RESULT", " ".join(repr(v) for v in out))
     ref, one = run({}), run({"DCGP_CHOL_ONE_LAUNCH": "1", "DCGP_POISON_WS": "1"})
     assert np.all(np.isfinite(one)), one
     assert np.max(np.abs(one - ref) / np.maximum(np.abs(ref), 1.0)) < 1e-9, (ref, one)
+
+
+def test_two_gpu_bench_runs_rccl_and_matches_one_rank(ctx):
+    """Skipped unless the box has two GPUs (the round's 1-GPU boxes skip it; the driver's 8-GPU node runs it): `bench.py --gpus 2`
+    must come up over RCCL -- both ranks in one communicator, not the host fallback -- and reproduce the 1-rank ELBO of the same
+    global batch (image-sharded data term + one in-stream ncclAllReduce)."""
+    import json
+    import subprocess
+    import sys
+    from deepcgp_amd import device as dev
+    if dev.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+
+    def line(gpus):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                            "--no-grad-leg", "--no-extra-legs"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    one, two = line(1), line(2)
+    assert two["n_gpus"] == 2 and two["ranks_seen_by_rccl"] == 2, two["config"]
+    assert "ncclAllReduce" in two["config"]["parallelism"]
+    assert abs(two["elbo"] - one["elbo"]) <= 1e-9 * abs(one["elbo"]), (one["elbo"], two["elbo"])
+    assert two["steps_per_s_two_in_flight"] is not None

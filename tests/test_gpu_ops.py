@@ -249,6 +249,34 @@ def test_conv_layer_full_cov(ctx, idmean):
         close(var, ovar, 1e-9, "var vs oracle")
 
 
+def test_sample_from_conditional_full_cov(ctx):
+    """Layer.conditional_SND / sample_from_conditional(full_cov=True) (doubly_stochastic_dgp Layer + reparameterize's full_cov branch;
+    the call shape of conv_gp/utils/tensorboard.py:73-81) on a ConvLayer: S x N x N x D covariance, samples through chol(var + jitter I)."""
+    from deepcgp_amd.kernels import RBF, PatchInducingFeatures
+    from deepcgp_amd.layers import ConvLayer
+    from deepcgp_amd.views import FullView
+    from oracle.dgp import sample_from_conditional as o_sample
+    rng = np.random.default_rng(4)
+    H, W, C, f, s, M, R, N, S = 7, 6, 2, 3, 2, 9, 2, 4, 3
+    v, ov = FullView((H, W), f, C, s), OFullView((H, W), f, C, s)
+    Z, q_mu, q_sqrt = rand_spd_inputs(rng, M, R, v.patch_length, scale=0.2)
+    X = rng.standard_normal((S, N, H * W * C))
+    layer = ConvLayer(RBF(v.patch_length, 5.0, 5.0), None, PatchInducingFeatures(Z), v, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
+    olayer = OConvLayer(ORBF(v.patch_length, 5.0, 5.0), None, Z, ov, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
+    z = rng.standard_normal((S, N, layer.num_outputs))
+    smp, mean, var = layer.sample_from_conditional(X, z=z, full_cov=True)
+    osmp, omean, ovar = o_sample(olayer, X, z=z, full_cov=True)
+    assert var.shape == (S, N, N, layer.num_outputs) and smp.shape == (S, N, layer.num_outputs)
+    close(mean, omean, 1e-9, "mean")
+    close(var, ovar, 1e-9, "var")
+    close(smp, osmp, 1e-8, "sample")
+    # one input per sample: the full covariance is the marginal variance, and the sample the diagonal path's
+    s1, m1, v1 = layer.sample_from_conditional(X[:, :1], z=z[:, :1], full_cov=True)
+    s0, m0, v0 = layer.sample_from_conditional(X[:, :1], z=z[:, :1])
+    close(v1[:, 0], v0, 1e-9, "1 x 1 covariance")
+    close(s1, s0, 1e-9, "sample, N = 1")
+
+
 def test_conditional_errors(ctx):
     from deepcgp_amd.conditionals import conditional
     with pytest.raises(ValueError):

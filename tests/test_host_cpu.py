@@ -141,6 +141,44 @@ def test_spawn_ranks_sets_the_rank_environment(tmp_path):
     assert spawn_ranks(2, [str(script), "fail"]) == 3
 
 
+def test_spawn_ranks_eight_ranks_through_the_host_group(tmp_path):
+    """The shape of the driver's 8-GPU run on CPU: spawn_ranks(8) starts the ranks, they meet over the host group (file rendezvous,
+    0600), ship the 128-byte id, sum the sharded data term of a batch of 11 images (ragged shards: 2,2,2,1,1,1,1,1) to the full-batch
+    ELBO, and a rank that dies takes the others down with its exit code instead of leaving them in the group's socket timeout."""
+    from deepcgp_amd.dist import spawn_ranks, shard_range
+    assert [shard_range(11, r, 8)[1] - shard_range(11, r, 8)[0] for r in range(8)] == [2, 2, 2, 1, 1, 1, 1, 1]
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys, time\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from deepcgp_amd import synthetic as syn\n"
+        "from deepcgp_amd.dist import HostGroup, shard_batch, assemble_elbo, env_rank_world\n"
+        "from oracle_build import oracle_model\n"
+        "rank, world, _ = env_rank_world()\n"
+        "if len(sys.argv) > 1 and rank == 5: sys.exit(7)          # dies before the rendezvous\n"
+        "grp = HostGroup(rank, world, timeout=60.0)\n"
+        "assert grp.broadcast_bytes(bytes(range(128)) if rank == 0 else b'') == bytes(range(128))\n"
+        "hwc = (8, 8, 1)\n"
+        "spec = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), M=5, S=2, num_data=500, seed=3, conv_q_sqrt_scale=0.3)\n"
+        "X, Y = syn.make_batch(hwc, 11, seed=3); zs = syn.make_noise(spec, 11, seed=3)\n"
+        "model = oracle_model(spec, X, Y)\n"
+        "Xs, Ys, zl = shard_batch(X, Y, zs, rank, world)\n"
+        "total = float(grp.allreduce([model.data_term(Xs, Ys, zs=zl)], 'sum')[0])\n"
+        "elbo = assemble_elbo(total, model.KL(), spec['num_data'], 11)\n"
+        "full = model.compute_log_likelihood(X, Y, zs=zs)\n"
+        "assert abs(elbo - full) <= 1e-12 * abs(full), (elbo, full)\n"
+        "assert float(grp.allreduce([float(rank)], 'max')[0]) == world - 1\n"
+        "grp.barrier(); grp.close()\n"
+        "open(os.path.join(%r, 'ok%%d' %% rank), 'w').write(repr(elbo))\n" % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path)))
+    assert spawn_ranks(8, [str(script)]) == 0
+    vals = {(tmp_path / ("ok%d" % r)).read_text() for r in range(8)}
+    assert len(vals) == 1
+    t0 = __import__("time").time()
+    assert spawn_ranks(8, [str(script), "die"]) == 7
+    assert __import__("time").time() - t0 < 50.0          # not the 60 s socket timeout of the survivors
+
+
 def test_reference_format_checkpoint_fixture_and_loader(tmp_path):
     """tests/golden/checkpoint/ref_checkpoint_3layer.npy carries exactly the path names a reference-trained 3-layer model prints
     (notebooks/Inspect.ipynb cell 6) plus 'global_step' (conv_gp/experiment.py:56-64); the table-driven loader files every layer key
