@@ -15,20 +15,22 @@ python tools/rocpd_timeline.py $DB -4 1700 > gpurun_out/${T}_two_in_flight_timel
 tail -1 gpurun_out/pipe_${T}.log >> gpurun_out/${T}_two_in_flight_timeline.txt
 # 3. phases inside the one-launch layer kernel
 python tools/fused_trace.py cfg2_mnist_CH_M256 > gpurun_out/${T}_fused_phase_trace.txt 2>&1
-# 4. counters, one set per pass
-tools/pmc_bench.sh ${T}a "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 2 --warmup 1 > gpurun_out/${T}_pmc_sq.txt 2>&1
-tools/pmc_bench.sh ${T}b "FETCH_SIZE" --steps 2 --warmup 1 > gpurun_out/${T}_pmc_fetch.txt 2>&1
-tools/pmc_bench.sh ${T}c "WRITE_SIZE" --steps 2 --warmup 1 > gpurun_out/${T}_pmc_write.txt 2>&1
-for c in cfg4_cifar_3layer_M384 cfg5_mnist_CH_M1024; do
+# 4. counters, one set per pass, every BASELINE configuration (head-only ones included)
+for c in cfg2_mnist_CH_M256 cfg2_mnist_H_M256 cfg1_mnist_H_M32 cfg3_mnist_3layer_M256 cfg4_cifar_3layer_M384 cfg5_mnist_H_M1024 cfg5_mnist_CH_M1024; do
   tools/pmc_bench.sh ${T}f_$c "FETCH_SIZE" --steps 2 --warmup 1 --config $c > gpurun_out/${T}_pmc_fetch_$c.txt 2>&1
   tools/pmc_bench.sh ${T}w_$c "WRITE_SIZE" --steps 2 --warmup 1 --config $c > gpurun_out/${T}_pmc_write_$c.txt 2>&1
-  tools/pmc_bench.sh ${T}s_$c "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 2 --warmup 1 --config $c > gpurun_out/${T}_pmc_sq_$c.txt 2>&1
+  tools/pmc_bench.sh ${T}s_$c "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 2 --warmup 1 --config $c > gpurun_out/${T}_pmc_sq_$c.txt 2>&1
 done
+python tools/pmc_summary.py ${T} > gpurun_out/${T}_pmc_summary.txt 2>&1
+python tools/pmc_traffic.py ${T} > gpurun_out/${T}_pmc_traffic.json 2> gpurun_out/${T}_pmc_traffic.err
 # 5. the other BASELINE configurations
 for c in cfg1_mnist_H_M32 cfg2_mnist_H_M256 cfg3_mnist_3layer_M256 cfg4_cifar_3layer_M384 cfg5_mnist_H_M1024 cfg5_mnist_CH_M1024; do
   timeout 300 python bench.py --config $c --steps 30 --no-cpu-baseline --no-grad-leg --no-extra-legs > gpurun_out/${T}_bench_$c.json 2> gpurun_out/${T}_bench_$c.err
 done
-# 6. two ranks on this one GPU: self-launched and under the driver's launcher (RCCL refuses two ranks on one device -> host join)
+# 6. the training step (forward + reverse pass), tiled and with the exact layer-0 de-duplication
+tools/prof_grad.sh ${T}g cfg2_mnist_CH_M256 20 > gpurun_out/${T}_grad_step_summary.txt 2>&1
+DCGP_DEDUP=1 tools/prof_grad.sh ${T}gd cfg2_mnist_CH_M256 20 > gpurun_out/${T}_grad_step_dedup_summary.txt 2>&1
+# 7. two ranks on this one GPU: self-launched and under the driver's launcher (RCCL refuses two ranks on one device -> host join)
 timeout 300 python bench.py --gpus 2 --steps 50 --no-cpu-baseline > gpurun_out/${T}_bench_2ranks_selflaunch.json 2> gpurun_out/${T}_bench_2ranks_selflaunch.err
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 50 --no-cpu-baseline > gpurun_out/${T}_bench_2ranks_torchrun.json 2> gpurun_out/${T}_bench_2ranks_torchrun.err
 echo collected
