@@ -193,7 +193,7 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
   // before the MFMAs of the current one), then 2^t and the weighted row sums.  getA(s): the A operand of sub-step s.
   // `pre`: the caller has already put this group's patch offsets into pb and its sub-step-0 operands into bv (requested
   // before the previous group's epilogue); next_j0 >= 0: do the same for the group that follows.
-  auto group = [&](auto ny_tag, auto&& getA, int j0, int next_j0, int nyn, double* rdiag, double (&rsum)[4], int (&pb)[4], double (&bv)[4]) {
+  auto group = [&](auto ny_tag, auto&& getA, auto&& getA_raw, int j0, int next_j0, int nyn, double* rdiag, double (&rsum)[4], int (&pb)[4], double (&bv)[4]) {
     constexpr int NY = decltype(ny_tag)::value;
     d4 acc[NY];
 #pragma unroll
@@ -225,20 +225,23 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
       // Sub-steps [0, sL) hold patch elements only.  They go in chunks of 4: the A operands (global memory for Kzx) and the patch-element
       // offsets of chunk c + 1 are requested before the products of chunk c (16 MFMAs = 1024 cycles against ~600 of a global load),
       // and inside a chunk the B gathers run one sub-step ahead of their MFMAs -- no conditional anywhere in the chunk.
+      // (the offsets run two chunks ahead, so that a Kdiag row's A operands -- gathered from the image through them -- are requested
+      // with offsets that have long arrived: offset -> gather -> MFMA in one chunk stalled the wave for two LDS round trips per sub-step)
       double ac[4], an[4];
-      int kc[4], kn[4];
-      auto fetch_chunk = [&](int s0, double (&A)[4], int (&K)[4]) {
+      int kc[4], kn[4], kf[4];
+      auto ldk = [&](int s0, int (&K)[4]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int sq = min(s0 + q, nk4 - 1);
-          A[q] = getA(sq);
-          K[q] = koff[4 * sq + lrow];
-        }
+        for (int q = 0; q < 4; ++q) K[q] = koff[4 * min(s0 + q, nk4 - 1) + lrow];
       };
-      fetch_chunk(0, ac, kc);
+      ldk(0, kc);
+      ldk(4, kn);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ac[q] = getA_raw(min(q, nk4 - 1), kc[q]);
       int s = 0;
       for (; s + 4 <= sL; s += 4) {
-        fetch_chunk(s + 4, an, kn);
+        ldk(s + 8, kf);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) an[q] = getA_raw(min(s + 4 + q, nk4 - 1), kn[q]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           double bn[NY];
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { ac[q] = an[q]; kc[q] = kn[q]; }
+        for (int q = 0; q < 4; ++q) { ac[q] = an[q]; kc[q] = kn[q]; kn[q] = kf[q]; }
       }
       // what is left: at most three sub-steps of patch elements and the one or two that carry the norm slots
       for (; s < nk4; ++s) {
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
 
   // one row fragment against column fragments [j_lo, nfp): groups of four, then one group of the remaining 1..3.
   // rdiag != nullptr: receives the share of the first fragment (the diagonal tile of a Kdiag row; rsum must start at zero)
-  auto row_pass = [&](auto&& getA, int j_lo, double* rdiag, double (&rsum)[4]) {
+  auto row_pass = [&](auto&& getA, auto&& getA_raw, int j_lo, double* rdiag, double (&rsum)[4]) {
     const int nfull = (nfp - j_lo) >> 2, nrem = (nfp - j_lo) & 3;
     int pb[4];
     double bv[4];
@@ -335,11 +338,11 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
     for (int y = 0; y < 4; ++y) {
       if (y < (nfull ? 4 : nrem)) { pb[y] = pbl[16 * (j0 + y) + lcol]; bv[y] = ldi(pb[y] + ko0); }
     }
-    for (int g = 0; g < nfull; ++g, j0 += 4) group(T4{}, getA, j0, j0 + 4, g + 1 < nfull ? 4 : nrem, g == 0 ? rdiag : nullptr, rsum, pb, bv);
+    for (int g = 0; g < nfull; ++g, j0 += 4) group(T4{}, getA, getA_raw, j0, j0 + 4, g + 1 < nfull ? 4 : nrem, g == 0 ? rdiag : nullptr, rsum, pb, bv);
     double* rd = nfull == 0 ? rdiag : nullptr;
-    if (nrem == 1) group(T1{}, getA, j0, -1, 0, rd, rsum, pb, bv);
-    else if (nrem == 2) group(T2{}, getA, j0, -1, 0, rd, rsum, pb, bv);
-    else if (nrem == 3) group(T3{}, getA, j0, -1, 0, rd, rsum, pb, bv);
+    if (nrem == 1) group(T1{}, getA, getA_raw, j0, -1, 0, rd, rsum, pb, bv);
+    else if (nrem == 2) group(T2{}, getA, getA_raw, j0, -1, 0, rd, rsum, pb, bv);
+    else if (nrem == 3) group(T3{}, getA, getA_raw, j0, -1, 0, rd, rsum, pb, bv);
   };
 
   for (int uu = 0; uu < a.upw && u < a.U; ++uu, u += HU_WPG) {
@@ -351,9 +354,9 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
       double areg[NKR];
 #pragma unroll
       for (int s = 0; s < NKR; ++s) areg[s] = zs[(long)(4 * s + lrow) * a.Mp];
-      row_pass([&](int s) { return areg[s]; }, 0, nullptr, rsum);
+      row_pass([&](int s) { return areg[s]; }, [&](int s, int) { return areg[RES ? s : 0]; }, 0, nullptr, rsum);
     } else {
-      row_pass([&](int s) { return zs[(long)(4 * s + lrow) * a.Mp]; }, 0, nullptr, rsum);
+      row_pass([&](int s) { return zs[(long)(4 * s + lrow) * a.Mp]; }, [&](int s, int) { return zs[(long)(4 * s + lrow) * a.Mp]; }, 0, nullptr, rsum);
     }
     if (WRITE) continue;
 #pragma unroll
@@ -386,9 +389,9 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
         double areg[NKR];
 #pragma unroll
         for (int s = 0; s < NKR; ++s) areg[s] = getA_img(s, kob[s]);
-        row_pass([&](int s) { return areg[s]; }, fr, rdiag, rsum);
+        row_pass([&](int s) { return areg[s]; }, [&](int s, int) { return areg[RES ? s : 0]; }, fr, rdiag, rsum);
       } else {
-        row_pass([&](int s) { return getA_img(s, koff[4 * s + lrow]); }, fr, rdiag, rsum);
+        row_pass([&](int s) { return getA_img(s, koff[4 * s + lrow]); }, [&](int, int ko) { return ldi(pa + ko); }, fr, rdiag, rsum);
       }
 #pragma unroll
       for (int v = 0; v < 4; ++v) total = fma(wl[16 * fr + lrow + 4 * v], 2.0 * rsum[v] - rdiag[v], total);   // off-diagonal tiles count twice
