@@ -139,6 +139,121 @@ __device__ __forceinline__ int wave_potrf_inv32(double (&v)[NB], int lane, doubl
   for (int c = 0; c < NB; ++c) v[c] = (lane == c) ? d : v[c] * col[c];
   return fail;
 }
+// one wavefront hands values to itself through LDS: LDS operations of a wave complete in order; this keeps the compiler from moving
+// accesses across the hand-off and drains the queue
+#define DCGP_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// The same recurrence on a W-column panel of any height: lanes [0, rows) hold the rows (lanes < W the pivot rows), any other lane a
+// vector that takes the same eliminations (a unit vector e_c yields column c of the inverse of the W x W factor; a zero vector stays zero).
+// Unscaled columns, deferred scalings and the one-step-early publication exactly as in wave_potrf_inv32.
+template <int W>
+__device__ __forceinline__ int wave_potrf_inv_panel(double (&v)[W], int lane, double (&col)[64]) {
+  int fail = 0;
+  double mypiv = 1.0;
+  double ua[W], ub[W];
+  col[lane] = v[0];
+#pragma unroll
+  for (int cc = 1; cc < W; ++cc) ua[cc] = col[cc];
+#pragma unroll
+  for (int c = 0; c < W; ++c) {
+    double (&u)[W] = (c & 1) ? ub : ua;
+    double (&un)[W] = (c & 1) ? ua : ub;
+    const double piv = bcast_lane(v[c], c);
+    if (!(piv > 0.0) && fail == 0) fail = c + 1;
+    mypiv = (lane == c) ? piv : mypiv;
+    const double t = v[c] * rcp_nr(piv);
+    if (c + 1 < W) {
+      v[c + 1] = fma(-t, u[c + 1], v[c + 1]);
+      col[lane] = v[c + 1];
+#pragma unroll
+      for (int cc = c + 2; cc < W; ++cc) un[cc] = col[cc];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int cc = c + 2; cc < W; ++cc) v[cc] = fma(-t, u[cc], v[cc]);
+  }
+  const double y = rsqrt_nr(mypiv);
+  double d = mypiv * y;
+  d = fma(0.5 * y, fma(-d, d, mypiv), d);
+  col[lane] = y;
+#pragma unroll
+  for (int c = 0; c < W; ++c) v[c] = (lane == c) ? d : v[c] * col[c];
+  return fail;
+}
+
+// Cholesky factor AND inverse of the 32 x 32 block D (lower triangle; LDS, row stride NB + 1) on one wavefront, as two 16-column
+// panels with the block work between them on the matrix cores.  The 32-column recurrence above is issue-bound: step c reads
+// 31 - c multipliers back from LDS and applies as many FMAs, ~400 cycles a step.  Here
+//   1. panel 1 (32 rows x 16 columns; lanes 32..47 carry e_0..e_15): L11, L21 and X11 = inv(L11) in 16 steps of <= 15 multipliers;
+//   2. A22' = A22 - L21 L21^T (4 MFMAs);
+//   3. panel 2 (16 rows; lanes 16..31 carry the unit vectors): L22 and X22 = inv(L22) in 16 steps;
+//   4. X21 = -X22 (L21 X11) (8 MFMAs)
+// -- about half the cycles.  On return D holds L (zero above the diagonal), Xs holds inv(L) (zero above), both [NB][NB + 1].
+// col: 64 doubles, T: 16 x 17 doubles of LDS scratch.  Returns 0 or the 1-based column of the first non-positive pivot.
+__device__ __forceinline__ int wave_potrf_inv32_2x16(double (*D)[NB + 1], double (*Xs)[NB + 1], double (&col)[64], double (*T)[17], int lane) {
+  constexpr int W = 16;
+  const int lrow = lane >> 4, lcol = lane & 15;
+  // ---- panel 1 ----
+  double v[W];
+#pragma unroll
+  for (int c = 0; c < W; ++c) v[c] = lane < NB ? D[lane][c] : ((lane < NB + W && c == lane - NB) ? 1.0 : 0.0);
+  int fail = wave_potrf_inv_panel<W>(v, lane, col);
+  if (lane < NB) {
+#pragma unroll
+    for (int c = 0; c < W; ++c) D[lane][c] = (c <= lane) ? v[c] : 0.0;          // L11 (rows < 16: lower part) and L21 (rows >= 16: all 16)
+  } else if (lane < NB + W) {
+#pragma unroll
+    for (int r = 0; r < W; ++r) Xs[r][lane - NB] = v[r];                          // X11 (column lane - 32)
+  }
+  DCGP_WAVE_LDS_SYNC();
+  // ---- A22' = A22 - L21 L21^T ----
+  {
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const double a = D[W + lcol][4 * s + lrow];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) D[W + lrow + 4 * q][W + lcol] -= acc[q];
+  }
+  DCGP_WAVE_LDS_SYNC();
+  // ---- panel 2 ----
+  double w[W];
+#pragma unroll
+  for (int c = 0; c < W; ++c) w[c] = lane < W ? D[W + lane][W + c] : ((lane < 2 * W && c == lane - W) ? 1.0 : 0.0);
+  const int fail2 = wave_potrf_inv_panel<W>(w, lane, col);
+  if (fail == 0 && fail2) fail = W + fail2;
+  if (lane < W) {
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      D[W + lane][W + c] = (c <= lane) ? w[c] : 0.0;                              // L22
+      D[lane][W + c] = 0.0;                                                        // block above the diagonal
+      Xs[lane][W + c] = 0.0;
+    }
+  } else if (lane < 2 * W) {
+#pragma unroll
+    for (int r = 0; r < W; ++r) Xs[W + r][lane] = w[r];                            // X22 (column lane - 16 of the block = column lane of Xs)
+  }
+  DCGP_WAVE_LDS_SYNC();
+  // ---- X21 = -X22 (L21 X11) ----
+  {
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[W + lcol][4 * s + lrow], Xs[4 * s + lrow][lcol], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T[lrow + 4 * q][lcol] = acc[q];
+    DCGP_WAVE_LDS_SYNC();
+    d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[W + lcol][W + 4 * s + lrow], T[4 * s + lrow][lcol], x, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Xs[W + lrow + 4 * q][lcol] = -x[q];
+  }
+  DCGP_WAVE_LDS_SYNC();
+  return fail;
+}
+
 // Column c of inv(L) for a 32x32 lower-triangular L held in LDS (D) with its reciprocal diagonal (Dr):
 // forward substitution, the row of L being read as broadcast loads once per step.
 __device__ __forceinline__ void lane_trtri32(const double (*D)[NB + 1], const double* Dr, int c, double (&x)[NB]) {

@@ -30,6 +30,27 @@ __device__ long long g_chol_trace[64 * 32];
 
 namespace {
 
+// factor + inverse of a diagonal block held in LDS: two 16-column panels + MFMA block work (chol_dev.h); DCGP_POTRF32 (compile time):
+// the single 32-column recurrence it replaced
+__device__ __forceinline__ int potrf_inv32(double (*D)[NB + 1], double (*Xs)[NB + 1], double (&col)[2 * NB], double (*Tp)[17], int lane) {
+#ifdef DCGP_POTRF32
+  double v[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) v[c] = (lane < NB) ? D[lane][c] : ((c == lane - NB) ? 1.0 : 0.0);
+  const int fail = wave_potrf_inv32(v, lane, col);
+  if (lane < NB) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) D[lane][c] = (c <= lane) ? v[c] : 0.0;
+  } else {
+#pragma unroll
+    for (int r = 0; r < NB; ++r) Xs[r][lane - NB] = v[r];
+  }
+  return fail;
+#else
+  return wave_potrf_inv32_2x16(D, Xs, col, Tp, lane);
+#endif
+}
+
 struct RlArgs {
   double* const* A;      // working matrices (destroyed): trailing part updated in place
   double* Lout;          // [batch][Mp][ld] final factor (lower), then copied back over A by the finish kernel
@@ -133,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   __shared__ double Ui[64][NB + 1];
   __shared__ double UcTs[64 * (NB + 1)];   // trailing tiles: second panel row block; inverse tiles: the Y tile
   __shared__ double Xs[NB][NB + 1];   // inv(L_jj)
+  __shared__ double Tp[16][17];       // scratch of the two-panel factorisation
   double (*Uc)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(UcTs);
   double (*Ts)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(UcTs);   // [NB][65]: old Y rows, then new
   static_assert(NB * 65 <= 64 * (NB + 1), "Y tile fits the shared slot");
@@ -242,17 +264,7 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   // ---- L_jj and inv(L_jj): one wavefront (unless the previous launch left them) ----
   int fail_j = 0;
   if (!have_x && tid < 64) {
-    double v[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) v[c] = (tid < NB) ? D[tid][c] : ((c == tid - NB) ? 1.0 : 0.0);
-    const int fail = wave_potrf_inv32(v, tid, col);
-    if (tid < NB) {
-#pragma unroll
-      for (int c = 0; c < NB; ++c) D[tid][c] = (c <= tid) ? v[c] : 0.0;
-    } else {
-#pragma unroll
-      for (int r = 0; r < NB; ++r) Xs[r][tid - NB] = v[r];
-    }
+    const int fail = potrf_inv32(D, Xs, col, Tp, tid);
     fail_j = fail;
     // (with a look-ahead workgroup in the launch it is the one writer of the status word: it sees this panel's failure too)
     if (tid == 0 && blockIdx.x == 0 && a.la_idx < 0 && (j == 0 || (fail && a.info[b] == 0))) a.info[b] = fail ? j + fail : 0;
@@ -292,22 +304,17 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
       }
     }
     __syncthreads();
-    if (tid < 64) {
-      double v[NB];
+    int fail = 0;
+    if (tid < 64) fail = potrf_inv32(D, Xs, col, Tp, tid);
+    __syncthreads();
 #pragma unroll
-      for (int c = 0; c < NB; ++c) v[c] = (tid < NB) ? D[tid][c] : ((c == tid - NB) ? 1.0 : 0.0);
-      const int fail = wave_potrf_inv32(v, tid, col);
-      if (tid < NB) {
-#pragma unroll
-        for (int c = 0; c < NB; ++c) {
-          const double lv = (c <= tid) ? v[c] : 0.0;
-          xn[tid * NB + c] = lv;
-          if (tid < nbn && c < nbn) Lout[(long)(jn + tid) * ld + jn + c] = lv;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < NB; ++r) xn[NB * NB + r * NB + (tid - NB)] = v[r];
-      }
+    for (int e = 0; e < NB * NB / 256; ++e) {
+      const int idx = tid + e * 256, r = idx / NB, c = idx % NB;
+      xn[idx] = D[r][c];
+      xn[NB * NB + idx] = Xs[r][c];
+      if (r < nbn && c < nbn) Lout[(long)(jn + r) * ld + jn + c] = D[r][c];
+    }
+    {
       if (tid == 0) {   // status word: first failing column of the chain so far (launch 0 initialises it)
         const int mine = fail_j ? j + fail_j : (fail ? jn + fail : 0);
         if (j == 0) a.info[b] = mine;
@@ -668,6 +675,7 @@ struct PcLds {
   double Ui[64][NB + 1];
   double UcTs[64 * (NB + 1)];
   double Xs[NB][NB + 1];
+  double Tp[16][17];
 };
 
 template <int SC>
@@ -702,17 +710,7 @@ __device__ __forceinline__ void pc_run(const PcArgs& p, const int b, const int r
       constexpr int PF = (2 * NB * NB + 191) / 192;
       double pf[PF];
       if (tid < 64) {
-        double v[NB];
-#pragma unroll
-        for (int c = 0; c < NB; ++c) v[c] = (tid < NB) ? D[tid][c] : ((c == tid - NB) ? 1.0 : 0.0);
-        const int fail = wave_potrf_inv32(v, tid, col);
-        if (tid < NB) {
-#pragma unroll
-          for (int c = 0; c < NB; ++c) D[tid][c] = (c <= tid) ? v[c] : 0.0;
-        } else {
-#pragma unroll
-          for (int r = 0; r < NB; ++r) Xs[r][tid - NB] = v[r];
-        }
+        const int fail = potrf_inv32(D, Xs, col, sh.Tp, tid);
         if (tid == 0 && (jp == 0 || (fail && a.info[b] == 0))) a.info[b] = fail ? j + fail : 0;
       } else if (more) {
         if (jp > 0) {   // every wave waits for itself (one lane polls; the acquire's cache invalidate is per wave)
