@@ -219,7 +219,7 @@ struct HeadUnitsArgs {
   int share_cu = 0;                                        // leave room on every CU for a workgroup of the factorisation chain (see head_units)
   double* kd = nullptr;                                    // kd[n * n_kd + i]: Kdiag[n] = sum_i kd[..] / P^2   (nullptr / kzx == nullptr: that half is skipped)
   int upw_force = 0;                                       // units per wave (0: chosen by head_units_plan)
-  int nfm = 0, nfp = 0, n_kd = 0, U = 0, u_lo = 0, upw = 1, wgs_per_img = 0;  // set by head_units_plan (call it with kzx / kd already set)
+  int nfm = 0, nfp = 0, n_kd = 0, U = 0, u_lo = 0, upw = 1, wpg = 4, wgs_per_img = 0;  // set by head_units_plan (call it with kzx / kd already set)
   float inv_C = 1.f, inv_f = 1.f, inv_Wo = 1.f, inv_Wr = 1.f;         // reciprocals for the set-up's index splits
 };
 void head_units_plan(HeadUnitsArgs* a);

@@ -75,14 +75,11 @@ __device__ __forceinline__ int fdiv_small(int i, float inv_d) { return (int)(((f
 #ifndef HU_EXPN
 #define HU_EXPN 4
 #endif
-#ifndef HU_NT
-#define HU_NT 256          // threads per workgroup = 64 x units per workgroup
-#endif
-constexpr int HU_WPG = HU_NT / 64;
 // WRITE: the K_uf sweep of a conv layer (conv_gp/layers.py:23-32 on views.py:40-44) -- the same row units, every kernel value stored
 // (kuf[m * sM + n * sN + p * sP]) instead of reduced; no Kdiag units.
-template <int NK4, int TL, bool WRITE>
-__global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsArgs a) {
+template <int NK4, int TL, bool WRITE, int NT>
+__global__ __launch_bounds__(NT, HU_WAVES) void head_units_kernel(HeadUnitsArgs a) {
+  constexpr int WPG = NT / 64;   // units (waves) per workgroup
   constexpr bool RES = NK4 > 0;
   constexpr int NKR = RES ? NK4 : 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -102,26 +99,26 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
   auto ldi = [&](int byte_off) { return *reinterpret_cast<const double*>(imgb + byte_off); };
 
   // ---- set-up, once per workgroup: the scaled image, the offset tables, patch norms from a separable window sum ----
-  for (int i0 = 0; i0 < HWC; i0 += 8 * HU_NT) {   // batches of 8 loads per thread: one memory latency for all of them
+  for (int i0 = 0; i0 < HWC; i0 += 8 * NT) {   // batches of 8 loads per thread: one memory latency for all of them
     double t[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int i = i0 + e * HU_NT + tid;
+      const int i = i0 + e * NT + tid;
       t[e] = (i < HWC) ? Xn[i] : 0.0;
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int i = i0 + e * HU_NT + tid;
+      const int i = i0 + e * NT + tid;
       if (i < HWC) img[i] = t[e] * a.csq;
     }
   }
-  for (int l = tid; l < a.Lq; l += HU_NT) {
+  for (int l = tid; l < a.Lq; l += NT) {
     const int ll = l < L ? l : 0;
     const int t = fdiv_small(ll, a.inv_C), c = ll - t * a.C;
     const int kh = fdiv_small(t, a.inv_f), kw = t - kh * a.f;
     koff[l] = ((kh * a.W + kw) * a.C + c) * 8;
   }
-  for (int p = tid; p < np16; p += HU_NT) {
+  for (int p = tid; p < np16; p += NT) {
     const int q = p < P ? p : 0;                 // patches beyond P repeat the first one (finite values, weight 0)
     const int oh = fdiv_small(q, a.inv_Wo), ow = q - oh * a.Wo;
     pbl[p] = (oh * a.s * a.W + ow * a.s) * a.C * 8;
@@ -131,7 +128,7 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
   {
     // rs[r][x] = sum over the f*C contiguous elements of image row r that a patch starting at column x covers; 4 threads per entry
     const int Wr = a.W - a.f + 1, fC = a.f * a.C;
-    for (int i0 = 0; i0 < a.H * Wr; i0 += HU_NT / 4) {
+    for (int i0 = 0; i0 < a.H * Wr; i0 += NT / 4) {
       const int i = i0 + (tid >> 2), part = tid & 3;
       double acc = 0.0;
       if (i < a.H * Wr) {
@@ -144,7 +141,7 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
       if (part == 0 && i < a.H * Wr) rs[i] = acc;
     }
     __syncthreads();
-    for (int p = tid; p < np16; p += HU_NT) {
+    for (int p = tid; p < np16; p += NT) {
       const int q = p < P ? p : 0;
       const int oh = fdiv_small(q, a.inv_Wo), ow = q - oh * a.Wo;
       const double* src = rs + oh * a.s * Wr + ow * a.s;
@@ -157,8 +154,8 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
 
   // this wave's unit: rotated by the image so that the empty slots of the last workgroup of an image (U % 4 != 0) do not
   // always fall on the same SIMDs
-  // (a workgroup covers HU_WPG * upw consecutive units, wave w the units w, w + HU_WPG, ...: one set-up for upw units per wave)
-  int u = a.u_lo + HU_WPG * a.upw * bw + ((wave + n) & (HU_WPG - 1));
+  // (a workgroup covers WPG * upw consecutive units, wave w the units w, w + WPG, ...: one set-up for upw units per wave)
+  int u = a.u_lo + WPG * a.upw * bw + ((wave + n) & (WPG - 1));
   if (u >= a.U) return;
 
   // The operand slots k = 4 s + lrow behind the patch (k >= L) sit in the last one or two sub-steps (ts = s - sL): the A side
@@ -345,7 +342,7 @@ __global__ __launch_bounds__(HU_NT, HU_WAVES) void head_units_kernel(HeadUnitsAr
     else if (nrem == 3) group(T3{}, getA, getA_raw, j0, -1, 0, rd, rsum, pb, bv);
   };
 
-  for (int uu = 0; uu < a.upw && u < a.U; ++uu, u += HU_WPG) {
+  for (int uu = 0; uu < a.upw && u < a.U; ++uu, u += WPG) {
   if (u < a.nfm) {
     // ---- Kzx rows 16 u .. 16 u + 15: out[m][n] = scale * sum_p w_p k(z_m, x_p) ----
     const double* __restrict__ zs = a.ZS + 16 * u + lcol;
@@ -425,6 +422,11 @@ void head_units_plan(HeadUnitsArgs* a) {
   // units per wave: the set-up of a workgroup (image, window sums, tables: ~3 us of latency) is as long as a short unit (a 16-row
   // fragment against the 9 patch fragments of a 12 x 12 view), so such launches put several units behind one set-up -- as many as
   // leave >= 512 workgroups (two per CU), and never a count between one and two rounds of the 1024 resident slots
+  // waves per workgroup: 4 where the patch fits registers (one set-up for four long units); 2 for long patches on small views
+  // (a 12 x 12 x 10 head input: 18 units of 252 MFMAs per image -- 1600 four-wave workgroups are 1.56 rounds of the resident
+  // slots, 2880 two-wave ones 1.4, and with no empty unit slot: 84 -> 79 us)
+  a->wpg = (a->L == 25 || a->kuf || a->nfp > 8) ? 4 : 2;
+  const int HU_WPG = a->wpg;
   const int nu = a->U - a->u_lo;
   a->upw = 1;
   if (a->upw_force > 0) a->upw = a->upw_force;
@@ -452,12 +454,14 @@ int head_units(dcgp_ctx* ctx, const HeadUnitsArgs& a) {
   if (a.share_cu && lds < 54 * 1024) lds = 54 * 1024;
   ScopedTimer t(ctx, a.kuf ? "kuf" : "head_sweep");
   if (a.kuf) {
-    if (a.L == 25) hipLaunchKernelGGL((head_units_kernel<7, 1, true>), dim3((unsigned)nwg), dim3(HU_NT), lds, ctx->stream, a);
-    else hipLaunchKernelGGL((head_units_kernel<0, 0, true>), dim3((unsigned)nwg), dim3(HU_NT), lds, ctx->stream, a);
+    if (a.L == 25) hipLaunchKernelGGL((head_units_kernel<7, 1, true, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((head_units_kernel<0, 0, true, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
   } else if (a.L == 25) {
-    hipLaunchKernelGGL((head_units_kernel<7, 1, false>), dim3((unsigned)nwg), dim3(HU_NT), lds, ctx->stream, a);   // 5 x 5 x 1 patches
+    hipLaunchKernelGGL((head_units_kernel<7, 1, false, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);   // 5 x 5 x 1 patches
+  } else if (a.wpg == 4) {
+    hipLaunchKernelGGL((head_units_kernel<0, 0, false, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
   } else {
-    hipLaunchKernelGGL((head_units_kernel<0, 0, false>), dim3((unsigned)nwg), dim3(HU_NT), lds, ctx->stream, a);
+    hipLaunchKernelGGL((head_units_kernel<0, 0, false, 128>), dim3((unsigned)nwg), dim3(128), lds, ctx->stream, a);
   }
   LAUNCH_CHECK(ctx);
   return DCGP_OK;

@@ -346,7 +346,7 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     h.ZS = L.ZS; h.M = L.M; h.Mp = Mp;
     h.csq = sqrt(1.4426950408889634074) / L.ls; h.log2var = log2(L.variance);
     h.w = L.w; h.kzx = B; h.ldk = ldb; h.kzx_scale = 1.0 / (double)L.v.P;
-    h.share_cu = prep_done != nullptr || factor_done != nullptr;   // the factorisation chain runs beside this launch on another stream
+    h.share_cu = factor_done != nullptr;   // first layer of the model with the chain on another stream: the chain runs beside this launch
     h.kd = (double*)ws_get(ctx, "kdiag_partial", (size_t)rows * ((L.v.P + 31) / 32) * sizeof(double));
     if (!h.kd) return DCGP_ERR_ALLOC;
     head_units_plan(&h);
