@@ -92,10 +92,10 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int i = i0 + e * NT + tid;
-        if (i < total) aux[i] = t[e];
+        if (i < total) aux[i] = BT == 0 ? t[e] * a.csq : t[e];   // RBF: the sweep's operands carry the kernel's scales (sweep_dev.h)
       }
     }
-    for (int l = tid; l < a.Lp; l += NT) {
+    for (int l = tid; l < (BT == 0 ? a.Lz : a.Lp); l += NT) {
       const int ll = l < a.L ? l : 0;
       const int c = ll % a.C, t = ll / a.C;
       const int kw = t % a.f, kh = t / a.f;
@@ -109,12 +109,14 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
     const int oh = p / a.Wo, ow = p - oh * a.Wo;
     return (n - n_first) * a.HWC + (oh * a.s * a.W + ow * a.s) * a.C;
   };
-  // |z_m|^2 of this lane's accumulator rows: fetched here, needed after the sweep
-  double znv[MAXF][4];
+  // acos: |z_m|^2 of this lane's accumulator rows: fetched here, needed after the sweep (RBF: the norms ride in the product)
+  double znv[BT == 0 ? 1 : MAXF][4];
+  if (BT != 0) {
 #pragma unroll
-  for (int c = 0; c < MAXF; ++c)
+    for (int c = 0; c < MAXF; ++c)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) znv[c][v] = a.zn[16 * fr[c] + lrow + 4 * v];
+      for (int v = 0; v < 4; ++v) znv[c][v] = a.zn[16 * fr[c] + lrow + 4 * v];
+  }
   __syncthreads();
   if (tid < 8 * BN) {   // 8 threads per column
     const int c = tid >> 3, sub = tid & 7;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
     s += __shfl_xor(s, 4);
-    if (sub == 0) xn[c] = s;
+    if (sub == 0) xn[c] = BT == 0 ? -0.5 * s : s;   // RBF: the column's norm slot, -c |x|^2 / 2 (the image is already scaled)
   }
   __syncthreads();
   CF_TR(1)
@@ -146,13 +148,18 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
     int pb[FNS];
 #pragma unroll
     for (int y = 0; y < FNS; ++y) pb[y] = patch_off((sp * FNS + y) * 16 + lcol);
-    const int nk4 = a.Lp >> 2;
+    const int nk4 = (BT == 0 ? a.Lz : a.Lp) >> 2;
     d4 kacc[MAXF][FNS];
 #pragma unroll
     for (int c = 0; c < MAXF; ++c)
 #pragma unroll
       for (int y = 0; y < FNS; ++y) kacc[c][y] = d4{0.0, 0.0, 0.0, 0.0};
-    const double* __restrict__ zt = a.ZT + lcol;
+    // RBF: ZS = sqrt(c) Z^T with the rows (-c |z|^2 / 2 + log2 variance, 1) behind the patch, against columns
+    // (sqrt(c) x, 1, -c |x|^2 / 2): the accumulator is log2 of the kernel value (sweep_dev.h, head_units.hip)
+    const double* __restrict__ zt = (BT == 0 ? a.ZS : a.ZT) + lcol;
+    double xnv[FNS];
+#pragma unroll
+    for (int y = 0; y < FNS; ++y) xnv[y] = xn[(sp * FNS + y) * 16 + lcol];
     constexpr int D4 = 4;
     double ring[D4 + 1][MAXF];
     auto ldz = [&](int k4, double (&dst)[MAXF]) {
@@ -162,12 +169,19 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
     auto kstep = [&](int k4, const double (&w)[MAXF]) {
       const int k = 4 * k4 + lrow;
       const int ko = koff[k];
-      const bool kin = k < a.L;
       double bv[FNS];
+      if (BT == 0) {
+        // slots behind the patch: k == L carries 1, k == L + 1 the column's norm, anything further 0
+        const double f_real = k < a.L ? 1.0 : 0.0, f_one = k == a.L ? 1.0 : 0.0, f_nrm = k == a.L + 1 ? 1.0 : 0.0;
 #pragma unroll
-      for (int y = 0; y < FNS; ++y) {
-        const double v = aux[pb[y] + ko];
-        bv[y] = kin ? v : 0.0;
+        for (int y = 0; y < FNS; ++y) bv[y] = fma(aux[pb[y] + ko], f_real, fma(xnv[y], f_nrm, f_one));
+      } else {
+        const bool kin = k < a.L;
+#pragma unroll
+        for (int y = 0; y < FNS; ++y) {
+          const double v = aux[pb[y] + ko];
+          bv[y] = kin ? v : 0.0;
+        }
       }
 #pragma unroll
       for (int c = 0; c < MAXF; ++c)
@@ -187,18 +201,24 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
 #pragma unroll
     for (int u = 0; u < D4; ++u)
       if (t + u < nk4) kstep(t + u, ring[u]);
-    double xnv[FNS];
-#pragma unroll
-    for (int y = 0; y < FNS; ++y) xnv[y] = xn[(sp * FNS + y) * 16 + lcol];
 #pragma unroll
     for (int c = 0; c < MAXF; ++c) {
       if (c < nfw) {
-        double kv[FNS * 4], n1[FNS * 4], n2[FNS * 4];   // this fragment's accumulator values: their exps interleaved
+        double kv[FNS * 4];   // this fragment's accumulator values: their exponentials interleaved
 #pragma unroll
         for (int y = 0; y < FNS; ++y)
 #pragma unroll
-          for (int v = 0; v < 4; ++v) { kv[y * 4 + v] = kacc[c][y][v]; n1[y * 4 + v] = xnv[y]; n2[y * 4 + v] = znv[c][v]; }
-        a.bk.template eval_n<BT, FNS * 4>(kv, n1, n2);
+          for (int v = 0; v < 4; ++v) kv[y * 4 + v] = kacc[c][y][v];
+        if (BT == 0) {
+          exp2_n<FNS * 4>(kv);
+        } else {
+          double n1[FNS * 4], n2[FNS * 4];
+#pragma unroll
+          for (int y = 0; y < FNS; ++y)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { n1[y * 4 + v] = xnv[y]; n2[y * 4 + v] = znv[BT == 0 ? 0 : c][v]; }
+          a.bk.template eval_n<BT, FNS * 4>(kv, n1, n2);
+        }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int m = 16 * fr[c] + lrow + 4 * v;
@@ -563,7 +583,7 @@ bool plan_fused(const ConvFusedArgs& a, FusedPlan* p) {
     const long main_d = (long)a.Mp * BN > fin ? (long)a.Mp * BN : fin;
     long img_d = ((long)nimg * a.HWC + 1) & ~1L;
     if (img_d < (long)TW * BN) img_d = (long)TW * BN;
-    const long bytes = (main_d + img_d + BN) * 8 + (long)a.Lp * 4;
+    const long bytes = (main_d + img_d + BN) * 8 + (long)(a.Lz > a.Lp ? a.Lz : a.Lp) * 4;
     if (bytes > 160 * 1024) continue;
     const long strips = a.Kc > 0 ? ((long)a.Kc + BN - 1) / BN : 1;
     const double cost = (double)((strips + 255) / 256) * BN * (sh.FN == 4 ? 1.0 : (sh.FN == 2 ? 1.03 : 1.06));

@@ -23,43 +23,6 @@
 
 namespace {
 
-constexpr double kExp2Magic = 6755399441055744.0;   // 1.5 * 2^52
-
-// 2^t for N values, interleaved step by step.  t is clamped at -1100 (ldexp then returns an exact zero; -inf would
-// otherwise leave NaN).  Relative error ~1.3e-16 of the polynomial evaluation plus what the argument carries.
-template <int N>
-__device__ __forceinline__ void exp2_n(double (&t)[N]) {
-  double u[N], r[N], p[N];
-  const double lo = -1100.0, magic = kExp2Magic;
-#pragma unroll
-  for (int i = 0; i < N; ++i) asm("v_max_f64 %0, %1, %2" : "=v"(t[i]) : "v"(t[i]), "s"(lo));
-#pragma unroll
-  for (int i = 0; i < N; ++i) asm("v_add_f64 %0, %1, %2" : "=v"(u[i]) : "v"(t[i]), "s"(magic));
-#pragma unroll
-  for (int i = 0; i < N; ++i) asm("v_add_f64 %0, %1, -%2" : "=v"(r[i]) : "v"(u[i]), "s"(magic));   // rint(t)
-#pragma unroll
-  for (int i = 0; i < N; ++i) asm("v_add_f64 %0, %1, -%2" : "=v"(r[i]) : "v"(t[i]), "v"(r[i]));     // |r| <= 1/2
-  double c11 = 4.4549605981865186e-10;
-  asm("" : "+v"(c11));   // one VGPR pair for the kernel's lifetime (a scalar operand is already taken by the addend)
-#pragma unroll
-  for (int i = 0; i < N; ++i) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p[i]) : "v"(c11), "v"(r[i]), "s"(7.0725859492692234e-09));
-#define DCGP_E2(c)                          \
-  _Pragma("unroll") for (int i = 0; i < N; ++i) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p[i]) : "v"(p[i]), "v"(r[i]), "s"((double)(c)))
-  DCGP_E2(1.0178062445845774e-07);
-  DCGP_E2(1.3215442587921689e-06);
-  DCGP_E2(1.5252733829836119e-05);
-  DCGP_E2(0.0001540353044173605);
-  DCGP_E2(0.0013333558146416936);
-  DCGP_E2(0.0096181291076068882);
-  DCGP_E2(0.055504108664821597);
-  DCGP_E2(0.24022650695910097);
-  DCGP_E2(0.69314718055994529);
-  DCGP_E2(1.0);
-#undef DCGP_E2
-#pragma unroll
-  for (int i = 0; i < N; ++i) t[i] = __builtin_amdgcn_ldexp(p[i], __double2loint(u[i]));
-}
-
 // small-range integer division by a launch-time constant without the ~40-instruction sequence: q = floor((i + 0.5) / d)
 __device__ __forceinline__ int fdiv_small(int i, float inv_d) { return (int)(((float)i + 0.5f) * inv_d); }
 

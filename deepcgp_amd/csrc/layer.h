@@ -95,6 +95,7 @@ struct ConvFusedArgs {
   const double* X = nullptr; int n_mod = 0;               // [n_mod, H, W, C]; image of row n is X[n % n_mod]
   int H = 0, W = 0, C = 0, f = 0, s = 0, Wo = 0, P = 0, L = 0, Lp = 0, HWC = 0;
   const double* ZT = nullptr; const double* zn = nullptr; int M = 0, Mp = 0;
+  const double* ZS = nullptr; int Lz = 0; double csq = 1.0;   // RBF: the sweep's scaled operand [Lz][Mp] and image scale sqrt(c) (sweep_dev.h)
   BaseKernel bk;
   const double* LinvT = nullptr;                           // [Mp][Mp]
   const double* G = nullptr;                               // [R][Mp][Mp] or nullptr (no q_sqrt term)

@@ -242,6 +242,7 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     fa.H = L.v.H; fa.W = L.v.W; fa.C = L.v.C; fa.f = L.v.f; fa.s = L.v.s; fa.Wo = L.v.Wo; fa.P = P; fa.L = L.v.L; fa.Lp = L.Lp;
     fa.HWC = L.v.H * L.v.W * L.v.C;
     fa.ZT = L.ZT; fa.zn = L.zn; fa.M = L.M; fa.Mp = Mp; fa.bk = L.base();
+    fa.ZS = L.ZS; fa.Lz = L.Lz; fa.csq = sqrt(1.4426950408889634074) / L.ls;
     fa.LinvT = L.g.LinvT; fa.G = L.has_qsqrt ? L.g.G : nullptr; fa.alpha = L.g.alpha; fa.R = L.R; fa.Rp = L.g.Rp;
     fa.Kc = (int)Kc; fa.knn = L.variance;
     fa.rep = rep; fa.rep_stride = rep_stride; fa.z = z; fa.seed = seed; fa.stream_id = stream_id; fa.jitter = jitter;

@@ -181,7 +181,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   if (!m->layers[0]->is_head) {
     const LayerState& L0 = *m->layers[0];
     ConvFusedArgs fa;
-    fa.Mp = L0.Mp; fa.M = L0.M; fa.R = L0.R; fa.Rp = L0.g.Rp; fa.P = L0.v.P; fa.HWC = L0.v.H * L0.v.W * L0.v.C; fa.Lp = L0.Lp;
+    fa.Mp = L0.Mp; fa.M = L0.M; fa.R = L0.R; fa.Rp = L0.g.Rp; fa.P = L0.v.P; fa.HWC = L0.v.H * L0.v.W * L0.v.C; fa.Lp = L0.Lp; fa.Lz = L0.Lz;
     first_fused = conv_fused_ok(fa);
   }
   const hipStream_t chain_s = (pipelined || !first_fused) ? kl_s : main_s;
