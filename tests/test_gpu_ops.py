@@ -383,7 +383,8 @@ def test_conv_layer_identity_mean(ctx):
 
 
 @pytest.mark.parametrize("H,W,C,f,s,M", [(8, 8, 1, 3, 1, 4), (12, 12, 10, 5, 1, 8), (28, 28, 1, 5, 1, 32), (9, 9, 10, 5, 1, 20),
-                                          (11, 11, 10, 5, 1, 70)])
+                                          (11, 11, 10, 5, 1, 70),
+                                          (40, 40, 4, 5, 3, 8)])   # an image past the unit sweep's LDS budget: the one-image-per-workgroup sweeps of rbf.hip take over
 def test_head_kernels(ctx, H, W, C, f, s, M):
     from deepcgp_amd.kernels import RBF, ConvKernel, AdditivePatchKernel
     from deepcgp_amd.views import FullView
