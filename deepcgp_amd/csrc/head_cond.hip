@@ -181,7 +181,11 @@ __global__ __launch_bounds__(1024, 4) void prep_solve_kernel(PrepSolveArgs args)
   if (y > a.R || strip * HC_BN >= (is_alpha ? a.Rp : Mp) || (!is_alpha && !a.Lq)) return;
   const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i0 = wave * 16;
+  // Row fragment of this wave.  Fragment f costs f + 1 - kt_lo k-tiles and the four waves of a SIMD (w, w + 4, w + 8, w + 12) share its
+  // matrix pipe: dealt in order, SIMD 3 carries 4 + 8 + 12 + 16 = 40 tiles against 28 on SIMD 0, and the stage is as long as the
+  // busiest SIMD (traced: 9.3 us for strip 0).  Dealt (s, 7 - s, 8 + s, 15 - s) every SIMD carries 34.
+  const int rf = (wave >> 2) == 0 ? (wave & 3) : ((wave >> 2) == 1 ? 7 - (wave & 3) : ((wave >> 2) == 2 ? 8 + (wave & 3) : 15 - (wave & 3)));
+  const int i0 = rf * 16;
   const bool live = i0 < Mp;
   const double* __restrict__ B = is_alpha ? a.qmu : a.Lq + (long)y * Mp * Mp;
   const int ldb = is_alpha ? a.Rp : Mp;
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(1024, 4) void prep_solve_kernel(PrepSolveArgs args)
   };
   d4 acc = d4{0.0, 0.0, 0.0, 0.0};
   __syncthreads();   // strip resident
-  const int lo = kt_lo, hi = wave + 1;   // inv(L) lower triangular: k <= i
+  const int lo = kt_lo, hi = rf + 1;   // inv(L) lower triangular: k <= i
   if (live && lo < hi) {
     double wb[HC_D + 1][4];
 #pragma unroll
