@@ -323,13 +323,28 @@ int varexp_rows(dcgp_ctx* ctx, const double* mu, const double* var, const int32_
 // alpha = inv(L) q_mu) that run next to the factorisation on the side stream.  Whitened case: G = Lq, alpha = q_mu.
 int cond_prep(dcgp_ctx* ctx, GpMats& g, int white, bool have_qsqrt) {
   const int Mp = g.Mp, R = g.R;
+  g.prep_sums_valid = false;
   if (white) return DCGP_OK;   // G / alpha alias Lq / qmu (set by the owner of g)
   ScopedTimer t(ctx, "gemm_prep");
+  // The products' epilogues also leave the column sums of squares of G_r and alpha (per row block): ||inv(L) Lq_r||_F^2 and
+  // ||inv(L) q_mu||^2 are the KL's trace and Mahalanobis terms where the KL prior is K itself (the head), and kl_layer used to
+  // run both products a second time just for them (gemm_kl: 280 us at M = 1024).
+  const int BM = gemm_row_block(Mp, Mp, R), nrb = (Mp + BM - 1) / BM;
+  const int BMa = gemm_row_block(Mp, g.Rp, 1), nrba = (Mp + BMa - 1) / BMa;
+  char nm[64];
+  snprintf(nm, sizeof nm, "prep_tp@%p", (void*)g.G);
+  g.prep_tp_count = (long)R * nrb * Mp;
+  g.prep_tp = have_qsqrt ? (double*)ws_get(ctx, nm, (size_t)g.prep_tp_count * sizeof(double)) : nullptr;
+  snprintf(nm, sizeof nm, "prep_ap@%p", (void*)g.alpha);
+  g.prep_ap_count = (long)nrba * g.Rp;
+  g.prep_ap = (double*)ws_get(ctx, nm, (size_t)g.prep_ap_count * sizeof(double));
+  if ((have_qsqrt && !g.prep_tp) || !g.prep_ap) return DCGP_ERR_ALLOC;
   if (have_qsqrt) {
     GemmArgs a;   // G_r = inv(L) Lq_r : lower x lower
     a.Wt = g.LinvT; a.ldw = Mp;
     a.B = g.Lq; a.ldb = Mp; a.bBatch = (long)Mp * Mp; a.nB = R;
     a.C = g.G; a.ldc = Mp; a.cBatch = (long)Mp * Mp;
+    a.colsq = g.prep_tp; a.sBatch = (long)nrb * Mp; a.sRowBlk = Mp;
     a.Mi = Mp; a.Mk = Mp; a.Kc = Mp; a.tri = 1; a.b_lower = 1;
     DCGP_TRY(gemm_tn(ctx, a, nullptr));
   }
@@ -337,8 +352,11 @@ int cond_prep(dcgp_ctx* ctx, GpMats& g, int white, bool have_qsqrt) {
   b.Wt = g.LinvT; b.ldw = Mp;
   b.B = g.qmu; b.ldb = g.Rp;
   b.C = g.alpha; b.ldc = g.Rp;
+  b.colsq = g.prep_ap; b.sRowBlk = g.Rp;
   b.Mi = Mp; b.Mk = Mp; b.Kc = g.Rp; b.tri = 1;
-  return gemm_tn(ctx, b, nullptr);
+  DCGP_TRY(gemm_tn(ctx, b, nullptr));
+  g.prep_sums_valid = have_qsqrt;
+  return DCGP_OK;
 }
 
 int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, int white, bool have_qsqrt,
@@ -410,6 +428,9 @@ int kl_layer(dcgp_ctx* ctx, const GpMats& g, const double* Lp, const double* Lpi
     const int ns = Mp / 16;
     tp = const_cast<double*>(sums); tp_count = (long)R * ns;
     ap = tp + (long)R * ns; ap_count = 1;
+  } else if (!white && g.prep_sums_valid && LpinvT == g.LinvT) {
+    tp = g.prep_tp; tp_count = g.prep_tp_count;   // cond_prep's products left them (same launch stream: ordered behind them)
+    ap = g.prep_ap; ap_count = g.prep_ap_count;
   } else if (!white) {
     const int BM = gemm_row_block(Mp, Mp, R), nrb = (Mp + BM - 1) / BM;
     const int BMa = gemm_row_block(Mp, g.Rp, 1), nrba = (Mp + BMa - 1) / BMa;

@@ -32,6 +32,10 @@ struct GpMats {
   double* klpp = nullptr;   // the same sums with the PRIOR factor inv(Lp) in place of inv(L) (layers with a prior Kuu(Z0)): nothing
                             // but the sums is kept of those products
   bool klpp_valid = false;
+  // M > 256 (cond_prep's generic GEMMs): the same column sums of squares, per row block, from the G / alpha products' epilogues
+  double* prep_tp = nullptr; long prep_tp_count = 0;   // [R][nrb][Mp] sums of squares of G
+  double* prep_ap = nullptr; long prep_ap_count = 0;   // [nrb][Rp] of alpha
+  bool prep_sums_valid = false;
 };
 
 // parameter-only preparation of all layers in one launch (prep.hip)
