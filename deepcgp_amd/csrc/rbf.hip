@@ -509,7 +509,10 @@ __global__ void kdiag_reduce_kernel(const double* __restrict__ partial, int n_pa
   out[n] = s * scale;
 }
 
-__global__ __launch_bounds__(256) void zs_build_kernel(ZsTask t) { zs_task(t, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void zs_build_kernel(ZsTask t) {
+  __shared__ double tile[32][33];
+  zs_task(t, blockIdx.x, gridDim.x, tile);
+}
 
 __global__ void extract_patches_kernel(const double* __restrict__ X, int N, int H, int W, int C, int f, int s,
                                        int Ho, int Wo, double* __restrict__ out, int pnl) {
@@ -550,7 +553,7 @@ int sweep_operand(dcgp_ctx* ctx, const double* Z, const double* in_scale, int M,
   ZsTask t;
   t.Z = Z; t.in_scale = in_scale; t.ZS = ZS; t.M = M; t.Mp = Mp; t.L = L; t.Lq = sweep_lq(L);
   t.csq = sqrt(1.4426950408889634074) / lengthscale; t.log2var = log2(variance);
-  hipLaunchKernelGGL(zs_build_kernel, dim3((Mp + 31) / 32), dim3(256), 0, ctx->stream, t);
+  hipLaunchKernelGGL(zs_build_kernel, dim3(zs_items(Mp, L)), dim3(256), 0, ctx->stream, t);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }
