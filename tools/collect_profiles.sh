@@ -21,6 +21,9 @@ for c in cfg2_mnist_CH_M256 cfg2_mnist_H_M256 cfg1_mnist_H_M32 cfg3_mnist_3layer
   tools/pmc_bench.sh ${T}w_$c "WRITE_SIZE" --steps 2 --warmup 1 --config $c > gpurun_out/${T}_pmc_write_$c.txt 2>&1
   tools/pmc_bench.sh ${T}s_$c "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 2 --warmup 1 --config $c > gpurun_out/${T}_pmc_sq_$c.txt 2>&1
 done
+# the materialised K_uf sweep of the headline configuration (its step uses the one-launch layer): traffic of bench.py's roofline_kuf
+DCGP_NO_FUSED_LAYER=1 tools/pmc_bench.sh ${T}f_cfg2_mnist_CH_M256_unfused "FETCH_SIZE" --steps 2 --warmup 1 --config cfg2_mnist_CH_M256 > /dev/null 2>&1
+DCGP_NO_FUSED_LAYER=1 tools/pmc_bench.sh ${T}w_cfg2_mnist_CH_M256_unfused "WRITE_SIZE" --steps 2 --warmup 1 --config cfg2_mnist_CH_M256 > /dev/null 2>&1
 python tools/pmc_summary.py ${T} > gpurun_out/${T}_pmc_summary.txt 2>&1
 python tools/pmc_traffic.py ${T} > gpurun_out/${T}_pmc_traffic.json 2> gpurun_out/${T}_pmc_traffic.err
 # 5. the other BASELINE configurations

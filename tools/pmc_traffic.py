@@ -48,12 +48,18 @@ for fd in sorted(d for d in glob.glob(os.path.join(root, "pmc_%sf_*" % tag)) if 
     fetch, write = per_kernel(fd, "FETCH_SIZE"), per_kernel(wd, "WRITE_SIZE")
     e = {}
     e["conv_fused"] = bytes_of(fetch, write, lambda k, g: k.startswith("conv_fused_kernel"))
-    e["head_sweep"] = bytes_of(fetch, write, lambda k, g: k.startswith("head_units_kernel") and ", false>" in k.split("(")[0])
-    e["kuf"] = bytes_of(fetch, write, lambda k, g: (k.startswith("head_units_kernel") and ", true>" in k.split("(")[0]) or k.startswith("patch_rbf_kernel"))
+    # head_units_kernel<NK4, TL, WRITE, NT>: WRITE = the storing form (K_uf sweep)
+    e["head_sweep"] = bytes_of(fetch, write, lambda k, g: k.startswith("head_units_kernel") and ", false" in k.split("(")[0])
+    e["kuf"] = bytes_of(fetch, write, lambda k, g: (k.startswith("head_units_kernel") and ", true" in k.split("(")[0]) or k.startswith("patch_rbf_kernel"))
     tn = sorted({g for (k, g) in (set(fetch) | set(write)) if k.startswith("gemm_tn_kernel<128")}, reverse=True)
     if tn:   # the R-batched second product is the largest grid of the 128-row tile kernel, the first product the next one
         e["gemm_cond_s3"] = bytes_of(fetch, write, lambda k, g: k.startswith("gemm_tn_kernel<128") and g == tn[0])
         if len(tn) > 1:
             e["gemm_cond_s1"] = bytes_of(fetch, write, lambda k, g: k.startswith("gemm_tn_kernel<128") and g == tn[1])
     out[cfg] = {k: v for k, v in e.items() if v is not None}
+# passes taken with DCGP_NO_FUSED_LAYER=1 (<config>_unfused): the materialised K_uf sweep of a configuration whose step uses the one-launch layer
+for cfg in [c for c in out if c.endswith("_unfused")]:
+    e = out.pop(cfg)
+    if "kuf" in e:
+        out.setdefault(cfg[:-len("_unfused")], {})["kuf"] = e["kuf"]
 print(json.dumps(out, indent=1))
