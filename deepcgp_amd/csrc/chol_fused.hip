@@ -304,9 +304,11 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
       }
     }
     __syncthreads();
+    TR(3)
     int fail = 0;
     if (tid < 64) fail = potrf_inv32(D, Xs, col, Tp, tid);
     __syncthreads();
+    TR(4)
 #pragma unroll
     for (int e = 0; e < NB * NB / 256; ++e) {
       const int idx = tid + e * 256, r = idx / NB, c = idx % NB;
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
         else if (mine && a.info[b] == 0) a.info[b] = mine;
       }
     }
+    TR(5)
     return;
   }
   if (blockIdx.x == 0 && !have_x) {   // publish L_jj (final; with Xin the previous launch's look-ahead workgroup already has)

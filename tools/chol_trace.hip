@@ -1,5 +1,5 @@
 // Phase timing of the fused Cholesky + inverse panel kernel (wall_clock64 stamps of one trailing-tile workgroup and
-// one inverse-tile workgroup per panel).  Includes the library source with -DCHOL_TRACE; links libdcgp for the context.
+// the launch's last workgroup per panel: the look-ahead workgroup, or an inverse tile in the last launch).  Includes the library source with -DCHOL_TRACE; links libdcgp for the context.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCHOL_TRACE -I deepcgp_amd/csrc tools/chol_trace.hip -o /tmp/chol_trace -L deepcgp_amd -ldcgp -Wl,-rpath,$PWD/deepcgp_amd
 #include "../deepcgp_amd/csrc/chol_fused.hip"
 #include <cstdio>
@@ -31,6 +31,11 @@ int main(int argc, char** argv) {
   }
   std::vector<long long> tr(64 * 32);
   hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(g_chol_trace), sizeof(long long) * 64 * 32);
+  for (int p = 0; p + 1 < M / 32; ++p) {   // the last workgroup of a launch is the look-ahead workgroup (except in the last launch): the launch's critical path
+    const long long* t = &tr[p * 32];
+    printf("panel %2d look-ahead WG (start +%.2f): load %.2f own potrf %.2f P, D %.2f potrf %.2f store %.2f | total %.2f us\n", p, (t[16] - t[0]) * 0.01,
+           (t[17] - t[16]) * 0.01, (t[18] - t[17]) * 0.01, (t[19] - t[18]) * 0.01, (t[20] - t[19]) * 0.01, (t[21] - t[20]) * 0.01, (t[21] - t[16]) * 0.01);
+  }
   for (int p = 0; p < M / 32; ++p) {
     const long long* t = &tr[p * 32];
     printf("panel %2d trailing WG: load %.2f potrf %.2f trsm %.2f mfma+store %.2f | inverse WG (start +%.2f): load %.2f potrf %.2f trtri/trsm/Yload %.2f Ynew %.2f mfma+store %.2f  [us]\n", p,
