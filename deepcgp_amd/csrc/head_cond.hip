@@ -172,11 +172,16 @@ struct PrepSolveArgs { PrepSolveLayer l[16]; };   // layers, then the prior-fact
 __global__ __launch_bounds__(1024, 4) void prep_solve_kernel(PrepSolveArgs args) {
   __shared__ __attribute__((aligned(16))) double Bt[HC_MP * HC_BN];   // [k][16]
   __shared__ double ssq[16];
-  const PrepSolveLayer& a = args.l[blockIdx.z];
+  // Heaviest strips first.  Strip s of a triangular right-hand side costs (16 - s)(17 - s) / 2 k-tiles -- 136 for strip 0, 1 for strip 15 --
+  // and the launch is 1.4 rounds of the resident slots: in grid order (strips fastest) the second round still held strip-0 workgroups,
+  // 9 us each, behind a first round of the same length.  Workgroups start in the order of their linear id, so the id is re-read as
+  // (strip slowest): every strip-0 workgroup of every (r, layer) starts first and the second round is the 1- to 10-tile strips.
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nyz = gridDim.y * gridDim.z;
+  const int strip = lin / nyz, y = (lin % nyz) % gridDim.y, z = (lin % nyz) / gridDim.y;
+  const PrepSolveLayer& a = args.l[z];
   if (!a.active) return;
   __builtin_amdgcn_s_setprio(3);   // part of the latency-bound parameter-only chain (see chol_rl_kernel)
   const int Mp = a.Mp;
-  const int strip = blockIdx.x, y = blockIdx.y;
   const bool is_alpha = y == a.R;
   if (y > a.R || strip * HC_BN >= (is_alpha ? a.Rp : Mp) || (!is_alpha && !a.Lq)) return;
   const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
