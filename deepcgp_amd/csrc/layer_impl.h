@@ -323,12 +323,15 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
 // SVGP head: Kzx / Kdiag from the conv kernel, then the shared conditional
 static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, int rows, int n_mod, double* kd, double* out_mean,
                  double* out_var, const std::string& pfx, hipEvent_t factor_done = nullptr,
-                               hipEvent_t prep_done = nullptr, int phase = 3) {
+                               hipEvent_t prep_done = nullptr, int phase = 3, int sweep_mode = 0, bool* early_done = nullptr) {
+  // sweep_mode (the unit-sweep route only): 1 = the sweep launch alone (it needs Z only: the model enqueues it in front of the long
+  // factorisation chain so that the host still enqueueing the chain does not hold it up; *early_done tells whether anything was launched),
+  // 2 = everything behind a sweep launched that way, 0 = both
   const int Mp = L.Mp;
   const long ldb = col_ld(rows);
   double* B = (double*)ws_get(ctx, pfx + "Kzx", (size_t)Mp * ldb * sizeof(double));
   if (!B) return DCGP_ERR_ALLOC;
-  if ((phase & 1) && Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));
+  if ((phase & 1) && sweep_mode != 2 && Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));
   PatchRbfArgs a;
   a.X = X; a.N = rows; a.n_mod = n_mod;
   a.H = L.v.H; a.W = L.v.W; a.C = L.v.C; a.f = L.v.f; a.s = L.v.s; a.Ho = L.v.Ho; a.Wo = L.v.Wo; a.P = L.v.P; a.L = L.v.L;
@@ -352,7 +355,11 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     if (!h.kd) return DCGP_ERR_ALLOC;
     head_units_plan(&h);
     if (head_units_ok(h)) {
-      DCGP_TRY(head_units(ctx, h));
+      if (sweep_mode != 2) DCGP_TRY(head_units(ctx, h));
+      if (sweep_mode == 1) {
+        if (early_done) *early_done = true;
+        return DCGP_OK;
+      }
       const double kd_scale = 1.0 / ((double)L.v.P * (double)L.v.P);
       if (prep_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, prep_done, 0));
       else if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
@@ -368,6 +375,7 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
       return finalize_layer(ctx, fa);
     }
   }
+  if (sweep_mode == 1) return DCGP_OK;   // not the unit-sweep route: nothing is launched ahead
   if (phase == 3 && L.kernel_type == 0 && a.bk.type == 0 && head_cond_fused_ok(L.g) && !unfused && !getenv("DCGP_HEAD_TWO_SWEEPS")) {
     // ConvKernel head, M <= 256: Kzx and Kdiag in one launch, then the whole conditional in one launch that adds up the Kdiag
     // tile-pair sums itself -- two launches on one stream for the layer

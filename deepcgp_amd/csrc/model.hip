@@ -189,6 +189,50 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   if (ctx->ev_last_valid && ctx->last_main != main_s) HIP_TRY(ctx, hipStreamWaitEvent(main_s, ctx->ev_last, 0));
   ctx->last_main = main_s;
 
+  // one layer of the data path on ctx->stream.  phase 1: only what needs Z alone (the layer's sweep, where it is a launch of its own),
+  // 2: the rest, 3: both
+  bool early_head = false;
+  auto layer_step = [&](int li, const double* F, int rows, int n_mod, int* out_rows_p, int phase) -> int {
+    LayerState& L = *m->layers[li];
+    const std::string pfx = mp + std::to_string(li) + "_";
+    const double* z = zs ? zs[li] : nullptr;
+    hipEvent_t fdone = (li == 0 && chain_s != main_s) ? m->ev_factor[bank] : nullptr;   // later layers are stream-ordered behind layer 0
+    hipEvent_t pdone = chain_s != main_s ? m->ev_prep[bank][li] : nullptr;
+    if (!L.is_head) {
+      const int width = L.v.P * L.R;
+      const bool expand = dedup && li == 0;          // N distinct images -> S*N sampled rows
+      const int out_rows = expand ? S * N : rows;
+      DCGP_TRY(ensure_out(m, li, out_rows, width, true));
+      auto& o = m->outs[li];
+      // device RNG: with a shard declared (dcgp_model_set_shard) every element draws at its counter in the un-sharded batch, one
+      // stream per layer -- the step's value is then independent of the number of ranks; otherwise one stream per (layer, rank)
+      RngMap rm;
+      const bool sharded = m->shard_global > 0;
+      if (sharded && (m->shard_global != N || m->shard_lo != 0)) { rm.W = width; rm.Nl = N; rm.Ng = m->shard_global; rm.lo = m->shard_lo; }
+      DCGP_TRY(conv_forward(ctx, L, F, rows, n_mod, expand ? S : 1, (long)N * width, z, seed, (uint32_t)(li + 1 + (sharded ? 0 : 64 * ctx->rank)),
+                            m->jitter, o.sample, m->keep_outputs ? o.mean : nullptr, m->keep_outputs ? o.var : nullptr, pfx,
+                            fdone, pdone, phase, m->keep_state, &rm));
+      *out_rows_p = out_rows;
+    } else {
+      DCGP_TRY(ensure_out(m, li, rows, L.R, true));
+      auto& o = m->outs[li];
+      DCGP_TRY(ensure(ctx, &m->d_kd, &m->kd_cap, (size_t)rows));
+      DCGP_TRY(head_forward(ctx, L, F, rows, n_mod, m->d_kd, o.mean, o.var, pfx, fdone, pdone, 3,
+                            phase == 1 ? 1 : (phase == 2 && early_head ? 2 : 0), phase == 1 ? &early_head : nullptr));
+      if (phase == 1) { *out_rows_p = rows; return DCGP_OK; }
+      if (m->keep_outputs) {
+        // the head's sample is not needed by the ELBO; produce it only on request
+        size_t n = (size_t)rows * L.R;
+        if (z) {
+          DCGP_TRY(reparam_async(ctx, o.mean, o.var, z, n, m->jitter, o.sample));
+        } else {
+          HIP_TRY(ctx, hipMemcpyAsync(o.sample, o.mean, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+      }
+      *out_rows_p = rows;
+    }
+    return DCGP_OK;
+  };
   // ---- the parameter-only chain ----
   ctx->stream = chain_s;
   // its scratch per model and bank: the chains / KL terms of two steps in flight may overlap, and with the deferred copy the tail
@@ -209,6 +253,17 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   // (events only where another stream waits for them: each record is a packet in front of the next launch)
   const bool xs = chain_s != main_s;
   if (rc == DCGP_OK && xs && !first_fused && hipEventRecord(m->ev_sweep[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;   // Z^T, |z|^2: what a sweep needs
+  // The first layer's sweep needs nothing else: it goes to the main stream NOW, in front of the chain's ~12 launches -- enqueued behind
+  // them it started when the host was done with those, 60 us after prepare_all had finished (cfg2 head-only: 0.287 -> 0.24 ms).
+  bool early0 = false;
+  if (rc == DCGP_OK && xs && !first_fused && !getenv("DCGP_NO_EARLY_SWEEP")) {
+    ctx->stream = main_s;
+    if (hipStreamWaitEvent(main_s, m->ev_sweep[bank], 0) != hipSuccess) rc = DCGP_ERR_HIP;
+    int out_rows = 0;
+    if (rc == DCGP_OK) rc = layer_step(0, X, rows0, N, &out_rows, 1);
+    early0 = rc == DCGP_OK;
+    ctx->stream = chain_s;
+  }
   // with a single factor group its "chol_Lout" scratch stays untouched until the deferred copy runs on the KL stream
   const bool defer = m->groups[bank].size() == 1 && need_kl && !m->keep_state;
   for (auto& gr : m->groups[bank])
@@ -283,46 +338,6 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     return rc;
   }
 
-  // ---- main stream: propagate ----
-  auto layer_step = [&](int li, const double* F, int rows, int n_mod, int* out_rows_p) -> int {
-    LayerState& L = *m->layers[li];
-    const std::string pfx = mp + std::to_string(li) + "_";
-    const double* z = zs ? zs[li] : nullptr;
-    hipEvent_t fdone = (li == 0 && chain_s != main_s) ? m->ev_factor[bank] : nullptr;   // later layers are stream-ordered behind layer 0
-    hipEvent_t pdone = chain_s != main_s ? m->ev_prep[bank][li] : nullptr;
-    if (!L.is_head) {
-      const int width = L.v.P * L.R;
-      const bool expand = dedup && li == 0;          // N distinct images -> S*N sampled rows
-      const int out_rows = expand ? S * N : rows;
-      DCGP_TRY(ensure_out(m, li, out_rows, width, true));
-      auto& o = m->outs[li];
-      // device RNG: with a shard declared (dcgp_model_set_shard) every element draws at its counter in the un-sharded batch, one
-      // stream per layer -- the step's value is then independent of the number of ranks; otherwise one stream per (layer, rank)
-      RngMap rm;
-      const bool sharded = m->shard_global > 0;
-      if (sharded && (m->shard_global != N || m->shard_lo != 0)) { rm.W = width; rm.Nl = N; rm.Ng = m->shard_global; rm.lo = m->shard_lo; }
-      DCGP_TRY(conv_forward(ctx, L, F, rows, n_mod, expand ? S : 1, (long)N * width, z, seed, (uint32_t)(li + 1 + (sharded ? 0 : 64 * ctx->rank)),
-                            m->jitter, o.sample, m->keep_outputs ? o.mean : nullptr, m->keep_outputs ? o.var : nullptr, pfx,
-                            fdone, pdone, 3, m->keep_state, &rm));
-      *out_rows_p = out_rows;
-    } else {
-      DCGP_TRY(ensure_out(m, li, rows, L.R, true));
-      auto& o = m->outs[li];
-      DCGP_TRY(ensure(ctx, &m->d_kd, &m->kd_cap, (size_t)rows));
-      DCGP_TRY(head_forward(ctx, L, F, rows, n_mod, m->d_kd, o.mean, o.var, pfx, fdone, pdone, 3));
-      if (m->keep_outputs) {
-        // the head's sample is not needed by the ELBO; produce it only on request
-        size_t n = (size_t)rows * L.R;
-        if (z) {
-          DCGP_TRY(reparam_async(ctx, o.mean, o.var, z, n, m->jitter, o.sample));
-        } else {
-          HIP_TRY(ctx, hipMemcpyAsync(o.sample, o.mean, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        }
-      }
-      *out_rows_p = rows;
-    }
-    return DCGP_OK;
-  };
   // sweeps read Z^T / |z|^2 of this bank (a one-launch first layer waits for its G / alpha, recorded behind them on the same stream)
   if (chain_s != main_s && !first_fused) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_sweep[bank], 0));
   const double* F = X;
@@ -334,7 +349,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   for (int li = 0; li < nl; ++li) {
     int out_rows = 0;
     if (li == nl - 1 && join_early && kl_join) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_kl[bank], 0));
-    DCGP_TRY(layer_step(li, F, rows, n_mod, &out_rows));
+    DCGP_TRY(layer_step(li, F, rows, n_mod, &out_rows, (li == 0 && early0) ? 2 : 3));
     if (!m->layers[li]->is_head) F = m->outs[li].sample;
     rows = out_rows;
     n_mod = rows;
