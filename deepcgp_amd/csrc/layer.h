@@ -144,6 +144,7 @@ struct ElboFinish {
   int ngroups = 0;
   double* host_out = nullptr;   // pinned host slot (device-visible address): the four result words are also written there,
                                 // so no copy command follows the launch
+  double host_seq = 0.0;        // written to host_out[4] behind them (system-scope release): the word the host polls for (ticket + 1)
 };
 // RobustMax expectations of every row -> ve_rows, scal[0] = inv_s * their sum, and (fin.nl > 0) scal[40..43] = ELBO, data term,
 // KL, potrf status from the KL pieces at scal[4 + 4 l ..]: one launch (cond.hip)

@@ -93,6 +93,7 @@ struct CombineArgs {
   int ninfo[16];
   int ngroups;
   double* host_out;   // pinned host slot (device-visible address) or nullptr
+  double host_seq;    // completion word behind the four result words (see elbo_forward_collect_impl)
 };
 __global__ void combine_kernel(const double* __restrict__ scal_in, double* __restrict__ out, CombineArgs c) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -114,7 +115,7 @@ __global__ void combine_kernel(const double* __restrict__ scal_in, double* __res
   out[3] = (double)bad;
   if (c.host_out) {
     for (int i = 0; i < 4; ++i) __hip_atomic_store(c.host_out + i, out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(c.host_out + 4, c.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -534,7 +535,8 @@ static void fill_finish(dcgp_model* model, std::vector<FactorGroup>& groups, dou
   for (int l = 0; l < nl; ++l) { fin->M[l] = model->layers[l]->M; fin->R[l] = model->layers[l]->R; fin->white[l] = model->layers[l]->white; }
   fin->ngroups = (int)groups.size();
   for (int g = 0; g < fin->ngroups && g < 16; ++g) { fin->info[g] = groups[g].d_info; fin->ninfo[g] = (int)groups[g].K.size(); }
-  fin->host_out = model->h_ring_dev + 4 * slot;   // the last kernel of the step writes the result words into the pinned slot itself
+  fin->host_out = model->h_ring_dev + 8 * slot;   // the last kernel of the step writes the result words into the pinned slot itself
+  fin->host_seq = (double)(model->enq_seq + 1);   // ... and this step's ticket + 1 behind them
 }
 
 int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
@@ -545,9 +547,10 @@ int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t*
   if (model->enq_seq - model->col_seq >= (uint64_t)dcgp_model::RING)
     return ctx_fail(ctx, DCGP_ERR_ARG, "elbo_forward_enqueue: %d steps in flight, collect the oldest first", dcgp_model::RING);
   if (!model->h_ring) {
-    if (hipHostMalloc((void**)&model->h_ring, dcgp_model::RING * 4 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+    if (hipHostMalloc((void**)&model->h_ring, dcgp_model::RING * 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void**)&model->h_ring_dev, model->h_ring, 0) != hipSuccess)
       return ctx_fail(ctx, DCGP_ERR_ALLOC, "elbo_forward: pinned result slots");
+    memset(model->h_ring, 0, dcgp_model::RING * 8 * sizeof(double));
     for (auto& e : model->ring_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   int rows = 0;
@@ -581,7 +584,7 @@ int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t*
     for (int l = 0; l < nl; ++l) { c.M[l] = fin.M[l]; c.R[l] = fin.R[l]; c.white[l] = fin.white[l]; }
     c.ngroups = fin.ngroups;
     for (int g = 0; g < c.ngroups; ++g) { c.info[g] = fin.info[g]; c.ninfo[g] = fin.ninfo[g]; }
-    c.host_out = fin.host_out;
+    c.host_out = fin.host_out; c.host_seq = fin.host_seq;
     hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, ctx->stream, scal, scal + 40, c);
     LAUNCH_CHECK(ctx);
   }
@@ -603,9 +606,30 @@ int elbo_forward_collect_impl(dcgp_model* model, uint64_t ticket, double* out_ho
   if (ticket != model->col_seq || ticket >= model->enq_seq)
     return ctx_fail(ctx, DCGP_ERR_ARG, "elbo_forward_collect: tickets are collected in the order they were handed out");
   const int slot = (int)(ticket % dcgp_model::RING);
-  HIP_TRY(ctx, hipEventSynchronize(model->ring_ev[slot]));
+  // The step's last kernel writes its four result words and then (system-scope release) ticket + 1 into the pinned slot: the host polls
+  // that word instead of waiting for the event behind the kernel -- the event's signal is another packet for the command processor and a
+  // wake-up through the runtime, several microseconds on a step of 150-800.  The event is still consulted now and then: a failed launch
+  // or a lost device must end the wait.
+  {
+    const volatile double* hv = model->h_ring + 8 * slot;
+    const double want = (double)(ticket + 1);
+    static const bool use_event = getenv("DCGP_SYNC_EVENT") != nullptr;   // A/B switch: the event wait this replaced
+    if (use_event) {
+      HIP_TRY(ctx, hipEventSynchronize(model->ring_ev[slot]));
+    } else {
+      for (unsigned spins = 1; hv[4] != want; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) == 0) {
+          const hipError_t q = hipEventQuery(model->ring_ev[slot]);
+          if (q == hipSuccess) break;                       // complete: coherent host memory already holds the words
+          if (q != hipErrorNotReady) { HIP_TRY(ctx, q); }
+        }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+  }
   ++model->col_seq;
-  const double* h = model->h_ring + 4 * slot;
+  const double* h = model->h_ring + 8 * slot;
   out_host[0] = h[0]; out_host[1] = h[1]; out_host[2] = h[2];
   // the timers resolve their events lazily, once nothing is in flight any more
   if (ctx->timing && ctx->pending.size() > 512 && model->col_seq == model->enq_seq) timing_flush(ctx);   // synchronises every stream of the ctx

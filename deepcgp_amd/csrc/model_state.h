@@ -35,7 +35,7 @@ struct dcgp_model {
   // throughput mode of the forward (dcgp_elbo_forward_enqueue / _collect): results of up to RING steps in flight land in
   // pinned host slots, one event per slot; tickets are handed out and collected in order
   static constexpr int RING = 4;
-  double* h_ring = nullptr;            // RING x 4 pinned doubles: ELBO, data term, KL, potrf status
+  double* h_ring = nullptr;            // RING x 8 pinned doubles: ELBO, data term, KL, potrf status, completion word (ticket + 1)
   double* h_ring_dev = nullptr;        // the same slots as the device addresses them (written by the last kernel of a step)
   hipEvent_t ring_ev[RING] = {};
   uint64_t enq_seq = 0, col_seq = 0;   // tickets handed out / collected

@@ -80,7 +80,7 @@ __device__ __forceinline__ void elbo_assemble(const TailArgs& t, double data) {
   for (int i = 0; i < 4; ++i) scal[40 + i] = res[i];
   if (fin.host_out) {   // straight into the caller's pinned slot: a 32-byte copy command cost 4 us and a gap behind this kernel
     for (int i = 0; i < 4; ++i) __hip_atomic_store(fin.host_out + i, res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(fin.host_out + 4, fin.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // the host polls this word
   }
 }
 
