@@ -1,3 +1,6 @@
+#!/usr/bin/env python
+"""Wall time of every one of 600 consecutive synchronous forward steps of the headline configuration, in windows of 25: how long the part
+takes to reach its steady state after start-up (and after any idle stretch: see tools/bench_overhead.py).  usage (GPU box): python tools/step_series.py"""
 import sys, time, numpy as np
 sys.path.insert(0, ".")
 from deepcgp_amd import device as dev, synthetic as syn
