@@ -163,7 +163,7 @@ def shard_sweep(leg, steps, warmup):
 
 def kuf_measure(leg, ctx, steps):
     """K_uf of layer 0, measured two ways on the bench workload (device-resident inputs, the model's own step):
-      * materialised: the sweep + GEMM route (DCGP_NO_FUSED_LAYER=1, read per call) really writes K_uf [M, N' P] to HBM and reads
+      * materialised: the sweep + GEMM route (ctx option no_fused_layer) really writes K_uf [M, N' P] to HBM and reads
         it back; its sweep launch ("kuf" timer, HIP events on the launch stream, every launch) gives achieved HBM GB/s on the
         algorithmic bytes -- this is `kuf_hbm_gbs`;
       * one-launch route (what `value` runs): K_uf never leaves the chip.  The shader-clock stamps of sampled workgroups give the time
@@ -171,15 +171,12 @@ def kuf_measure(leg, ctx, steps):
         reported beside the true HBM bytes of that phase (images and Z in, nothing out)."""
     from deepcgp_amd import device as dev
     res = {}
-    os.environ["DCGP_NO_FUSED_LAYER"] = "1"
-    try:
+    with ctx.options(no_fused_layer=1):
         # the sweep is enqueued in front of the factorisation chain and runs beside it (two workgroups per CU, the chain's waves at a
-        # higher priority); DCGP_NO_EARLY_SWEEP puts it behind the chain: the launch alone on the chip, which is what the rate is quoted for
+        # higher priority); option no_early_sweep puts it behind the chain: the launch alone on the chip, which is what the rate is quoted for
         n = max(20, min(steps, 60))
-        for key, env in (("sweep_us", "1"), ("sweep_us_beside_the_chain", None)):
-            if env:
-                os.environ["DCGP_NO_EARLY_SWEEP"] = env
-            try:
+        for key, late in (("sweep_us", 1), ("sweep_us_beside_the_chain", 0)):
+            with ctx.options(no_early_sweep=late):
                 for i in range(30):
                     leg.step(i)
                 ctx.timing_enable(3)
@@ -192,10 +189,6 @@ def kuf_measure(leg, ctx, steps):
                 if t[0]:
                     res[key] = 1e3 * t[1] / t[0]
                     res["sweep_launches_sampled"] = t[0]
-            finally:
-                os.environ.pop("DCGP_NO_EARLY_SWEEP", None)
-    finally:
-        del os.environ["DCGP_NO_FUSED_LAYER"]
     for i in range(3):
         leg.step(i)
     # phase stamps of the one-launch layer kernel (csrc/conv_fused.hip CF_TR): [8 sampled workgroups][16 waves][16 stamps]
@@ -248,8 +241,7 @@ def head_only_leg(ctx, grp, S, steps):
     ctx.sync()
     tim = ctx.timing()
     # the sweep alone on the chip (the step above runs it beside the factorisation chain, two workgroups per CU)
-    os.environ["DCGP_HEAD_NO_OVERLAP"] = "1"
-    try:
+    with ctx.options(head_no_overlap=1):
         for i in range(3):
             leg.step(i)
         ctx.timing_reset()
@@ -257,8 +249,6 @@ def head_only_leg(ctx, grp, S, steps):
             leg.step(i)
         ctx.sync()
         tim_alone = ctx.timing()
-    finally:
-        del os.environ["DCGP_HEAD_NO_OVERLAP"]
     ctx.timing_enable(0)
     h = leg.spec["head"]
     rows = 32 * S
@@ -271,7 +261,7 @@ def head_only_leg(ctx, grp, S, steps):
                              "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("head_sweep", "cfg2_mnist_H_M256"),
                              "algorithmic_flops_per_launch": flops, "avg_us": us, "launches_sampled": tim_alone["head_sweep"][0],
                              "avg_us_in_step_beside_the_chain": us_in_step,
-                             "note": HEAD_NOTE + ".  avg_us: the launch alone on the chip (DCGP_HEAD_NO_OVERLAP=1: chain first, then the sweep); the "
+                             "note": HEAD_NOTE + ".  avg_us: the launch alone on the chip (ctx option head_no_overlap: chain first, then the sweep); the "
                                      "head-only step itself (head_only_steps_per_s) runs the sweep beside the factorisation chain on a side stream, two "
                                      "workgroups per CU, where it takes avg_us_in_step_beside_the_chain and the step is the longer of the two"},
            "head_only_kernel_times_us": {k: round(1e3 * v[1] / max(v[0], 1), 2) for k, v in sorted(tim.items())}}
@@ -456,7 +446,7 @@ def main():
             gbs = bytes_kuf / (kuf_raw["sweep_us"] * 1e-6) / 1e9
             o["kuf_hbm_gbs"] = gbs
             o["roofline_kuf"] = {"kernel": "head_units_kernel<.., WRITE> (K_uf sweep of layer 0, materialised [M, N'P] in HBM: the sweep + GEMM route, "
-                                           "DCGP_NO_FUSED_LAYER=1, timed in situ on the bench workload, the launch alone on the chip)",
+                                           "ctx option no_fused_layer, timed in situ on the bench workload, the launch alone on the chip)",
                                  "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                  "traffic": pmc_traffic("kuf", args.config), "algorithmic_bytes_per_launch": bytes_kuf,
                                  "avg_us": kuf_raw["sweep_us"], "avg_us_in_step_beside_the_chain": kuf_raw.get("sweep_us_beside_the_chain"),

@@ -841,7 +841,7 @@ int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_L
   double* Y = d_Linv ? (double*)ws_get(ctx, "chol_Y" + ctx->ws_tag, (size_t)batch * mm * sizeof(double)) : nullptr;
   if (!Lout || (d_Linv && !Y)) return DCGP_ERR_ALLOC;
   // one launch for the whole chain (chol_persist_kernel) where its workgroups are sure to be co-resident
-  static const bool one_launch = getenv("DCGP_CHOL_ONE_LAUNCH") != nullptr;   // A/B switch (see the note above ldg<>)
+  const bool one_launch = ctx->opt.chol_one_launch != 0;   // A/B switch (see the note above ldg<>)
   if (d_Linv && one_launch) {
     const int np = (Mp + NB - 1) / NB;
     int max_tiles = 1;
@@ -877,7 +877,7 @@ int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_L
       return factor_finish_batched(ctx, d_A, batch, Mp, ld);
     }
   }
-  static const bool no_la = getenv("DCGP_CHOL_NO_LOOKAHEAD") != nullptr;   // A/B switch
+  const bool no_la = ctx->opt.chol_no_lookahead != 0;   // A/B switch
   const int np_la = (Mp + NB - 1) / NB;
   double* Xla = nullptr;   // [np][batch][2][NB][NB]: factor and inverse of every diagonal block, handed from launch to launch
   if (d_Linv && !no_la && np_la > 1) {

@@ -27,6 +27,36 @@ struct PendingEvent {
   hipEvent_t start, stop;
 };
 
+// A/B and debugging switches of a ctx.  Filled ONCE, at dcgp_ctx_create, from the environment variable of the same name in upper case with
+// a DCGP_ prefix (so that shell-level experiments keep working), and from then on changed only through dcgp_ctx_set_option: nothing
+// on the step path calls getenv.  Every switch selects between two routes that are both tested, or turns an aid on; none is needed
+// for normal use (DESIGN.md 6a lists them).
+struct DcgpOptions {
+  long no_fused_layer = 0;       // conv layers by the sweep + GEMM route even where the one-launch layer kernel covers them
+  long fused_large = 0;          // the one-launch layer kernel also for M > 256 (narrower strips; measured slower there)
+  long fused_shape = -1;         // force one strip shape of the one-launch layer kernel (-1: chosen from the layer)
+  long kl_side = 0;              // KL terms by their own launches on the side stream instead of inside the tail launch
+  long no_fused_bwd = 0;         // reverse pass of the conditional by GEMM launches instead of the strip kernel
+  long fused_bwd_min_cols = -1;  // strip kernel of the reverse pass from this many columns on (-1: default 4096)
+  long head_unfused = 0;         // the head's conditional by the shared GEMM route instead of its one launch
+  long no_side_stream = 0;       // everything on one stream (counter collection: the profiler serialises dispatches)
+  long cu_partition = 0;         // CU-masked main / side streams for steps in flight (ctx create only)
+  long grad_nofork = 0;          // reverse pass without the side-stream fork of the M x M adjoint chains
+  long chol_one_launch = 0;      // the persistent one-launch factorisation chain
+  long chol_no_lookahead = 0;    // panel launches without the look-ahead workgroup
+  long head_no_overlap = 0;      // head-first model: the factorisation chain in front of the sweep instead of beside it
+  long no_early_sweep = 0;       // the first layer's sweep enqueued behind the chain instead of in front of it
+  long sync_event = 0;           // wait for the step's event instead of polling its completion word
+  long kuf_upw = 0;              // units per wave of the storing sweep (0: chosen by head_units_plan)
+  long head_tail = -1;           // head_units: balance of the launch tail (-1: default; see head_units_plan)
+  long graph = -1;               // synchronous forward step replayed from a captured HIP graph (-1: default)
+  long fused_abl = 0, rb_mixed = 0;   // timing builds only (make EXPERIMENTS=1)
+};
+long* dcgp_option_slot(DcgpOptions* o, const char* name);   // nullptr: no such option (ctx.hip)
+// debugging aid, process-wide, DCGP_POISON_WS read once: fresh device allocations of the library are filled with NaNs;
+// `name` != nullptr additionally applies DCGP_POISON_ONLY (only workspaces whose name contains that string)
+bool dcgp_poison(const char* name = nullptr);
+
 struct ChainEpoch { unsigned epoch = 0; int T = 0, np = 0, batch = 0; };   // launches so far of the one-launch factorisation chain on a sync area
 
 struct dcgp_ctx {
@@ -43,7 +73,8 @@ struct dcgp_ctx {
   bool ev_last_valid = false;
   hipEvent_t ev_fork = nullptr, ev_factor = nullptr, ev_kl = nullptr;
   hipEvent_t ev_prep[8] = {};   // per layer: G / alpha of layer l are ready (side stream)
-  bool no_side = false;            // DCGP_NO_SIDE_STREAM: everything on the main stream (A/B switch; counter-collection runs, where
+  DcgpOptions opt;                 // A/B switches: environment at dcgp_ctx_create, then dcgp_ctx_set_option only
+  bool no_side = false;            // opt.no_side_stream: everything on the main stream (A/B switch; counter-collection runs, where
                                    // the profiler serialises dispatches and cross-stream waits can deadlock it)
   hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;  // fork / join of a short side-stream excursion inside a layer
   std::string err;

@@ -331,11 +331,13 @@ int cond_prep(dcgp_ctx* ctx, GpMats& g, int white, bool have_qsqrt) {
   // run both products a second time just for them (gemm_kl: 280 us at M = 1024).
   const int BM = gemm_row_block(Mp, Mp, R), nrb = (Mp + BM - 1) / BM;
   const int BMa = gemm_row_block(Mp, g.Rp, 1), nrba = (Mp + BMa - 1) / BMa;
-  char nm[64];
-  snprintf(nm, sizeof nm, "prep_tp@%p", (void*)g.G);
+  // named by the model / bank tag of the step (forward_all's ws_tag; empty for the operator entry points) AND the operand's address:
+  // dcgp_model_destroy frees everything carrying its tag, so a later model whose G lands at the same address gets a buffer of its own
+  char nm[128];
+  snprintf(nm, sizeof nm, "prep_tp%s@%p", ctx->ws_tag.c_str(), (void*)g.G);
   g.prep_tp_count = (long)R * nrb * Mp;
   g.prep_tp = have_qsqrt ? (double*)ws_get(ctx, nm, (size_t)g.prep_tp_count * sizeof(double)) : nullptr;
-  snprintf(nm, sizeof nm, "prep_ap@%p", (void*)g.alpha);
+  snprintf(nm, sizeof nm, "prep_ap%s@%p", ctx->ws_tag.c_str(), (void*)g.alpha);
   g.prep_ap_count = (long)nrba * g.Rp;
   g.prep_ap = (double*)ws_get(ctx, nm, (size_t)g.prep_ap_count * sizeof(double));
   if ((have_qsqrt && !g.prep_tp) || !g.prep_ap) return DCGP_ERR_ALLOC;

@@ -198,8 +198,8 @@ __global__ __launch_bounds__(CB_NT) void conv_bwd_fused_kernel(ConvBwdArgs a) {
 
 }  // namespace
 
-bool conv_bwd_fused_ok(const ConvBwdArgs& a) {
-  if (getenv("DCGP_NO_FUSED_BWD")) return false;
+bool conv_bwd_fused_ok(const dcgp_ctx* ctx, const ConvBwdArgs& a) {
+  if (ctx->opt.no_fused_bwd) return false;
   const int Rk = (a.R + 3) & ~3;
   const size_t lds = ((size_t)a.Mp * CB_BN + (size_t)(a.R + Rk + 1) * CB_BN) * sizeof(double);
   return a.Mp >= 16 && a.Mp <= 256 && a.Mp % 16 == 0 && a.R >= 1 && a.R <= 16 && lds <= 160 * 1024 &&
@@ -208,7 +208,7 @@ bool conv_bwd_fused_ok(const ConvBwdArgs& a) {
 
 int conv_bwd_fused(dcgp_ctx* ctx, const ConvBwdArgs& a) {
   if (a.Kc <= 0) return DCGP_OK;
-  if (!conv_bwd_fused_ok(a)) return ctx_fail(ctx, DCGP_ERR_ARG, "conv_bwd_fused: layer shape not supported (M = %d, R = %d)", a.M, a.R);
+  if (!conv_bwd_fused_ok(ctx, a)) return ctx_fail(ctx, DCGP_ERR_ARG, "conv_bwd_fused: layer shape not supported (M = %d, R = %d)", a.M, a.R);
   const int Rk = (a.R + 3) & ~3;
   const size_t lds = ((size_t)a.Mp * CB_BN + (size_t)(a.R + Rk + 1) * CB_BN) * sizeof(double);
   static bool attr[64] = {};   // per device

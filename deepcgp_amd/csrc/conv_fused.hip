@@ -557,13 +557,13 @@ int launch_fused(dcgp_ctx* ctx, const ConvFusedArgs& a, size_t lds) {
 struct FusedPlan { int shape; size_t lds; int lds_main, lds_img; };
 
 // the first instantiated shape (widest strip, most waves) that covers Mp and whose LDS footprint fits
-bool plan_fused(const ConvFusedArgs& a, FusedPlan* p) {
-  const int force = getenv("DCGP_FUSED_SHAPE") ? atoi(getenv("DCGP_FUSED_SHAPE")) : -1;   // A/B experiments
+bool plan_fused(const dcgp_ctx* ctx, const ConvFusedArgs& a, FusedPlan* p) {
+  const int force = (int)ctx->opt.fused_shape;   // A/B experiments (-1: none)
   const int nf = a.Mp / 16;
   if (a.Rp != 16 || a.R > 16 || a.Mp > 1024 || a.Mp % 16) return false;
   // M > 256: the 32- / 16-column strips LDS leaves room for re-fetch the A operands 2 - 4 x as often per MFMA and measure
   // 2 % (M = 384) to 16 % (M = 1024) behind the sweep + 128 x 128-tile GEMM route (87 % of the MFMA peak there); opt-in
-  if (nf > 16 && force < 0 && !getenv("DCGP_FUSED_LARGE")) return false;
+  if (nf > 16 && force < 0 && !ctx->opt.fused_large) return false;
   // Among the shapes that fit, the one whose busiest CU carries the fewest columns: workgroups go round the 256 CUs, a CU works
   // through ceil(strips / 256) strips of BN columns at a rate that does not depend on BN (narrow strips share the CU), so few
   // columns -- a shard of a strongly-scaled batch -- are better cut into narrower strips (4 images x 10 samples x 144 patches:
@@ -603,23 +603,23 @@ extern "C" int dcgp_debug_set_fused_trace(dcgp_ctx* ctx, long long* buf_dev) {
   return DCGP_OK;
 }
 
-bool conv_fused_ok(const ConvFusedArgs& a) {
-  const bool off = getenv("DCGP_NO_FUSED_LAYER") != nullptr;   // A/B switch (read per call: tests flip it): the unfused sweep + GEMM route
+bool conv_fused_ok(const dcgp_ctx* ctx, const ConvFusedArgs& a) {
+  const bool off = ctx->opt.no_fused_layer != 0;   // A/B switch (tests flip it through dcgp_ctx_set_option): the unfused sweep + GEMM route
   FusedPlan p;
-  return !off && plan_fused(a, &p);
+  return !off && plan_fused(ctx, a, &p);
 }
 
 int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a_in) {
   if (a_in.Kc <= 0) return DCGP_OK;
   FusedPlan p;
-  if (!plan_fused(a_in, &p)) return ctx_fail(ctx, DCGP_ERR_ARG, "conv_fused: layer shape not supported (M = %d, R = %d)", a_in.M, a_in.R);
+  if (!plan_fused(ctx, a_in, &p)) return ctx_fail(ctx, DCGP_ERR_ARG, "conv_fused: layer shape not supported (M = %d, R = %d)", a_in.M, a_in.R);
   if ((long)a_in.R * a_in.Mp * a_in.Mp * 8 >= (1L << 31)) return ctx_fail(ctx, DCGP_ERR_ARG, "conv_fused: G exceeds 2 GiB");
   ConvFusedArgs a = a_in;
   a.lds_main = p.lds_main; a.lds_img = p.lds_img;
   a.trace = ctx->fused_trace;
   ScopedTimer t(ctx, "conv_fused");
 #ifdef DCGP_EXPERIMENTS
-  const int abl = getenv("DCGP_FUSED_ABL") ? atoi(getenv("DCGP_FUSED_ABL")) : 0;   // timing build only (make EXPERIMENTS=1): wrong results
+  const int abl = (int)ctx->opt.fused_abl;   // timing build only (make EXPERIMENTS=1): wrong results
   if (abl && p.shape == 0 && a.bk.type == 0) {
     const unsigned grid = (unsigned)((a.Kc + 63) / 64);
 #define CF_ABL(X)                                                                                                                       \

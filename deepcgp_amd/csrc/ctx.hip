@@ -1,4 +1,5 @@
 // Context, memory, error and HIP-event timing plumbing of libdcgp.so.
+#include <cctype>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -13,6 +14,46 @@ int ctx_fail(dcgp_ctx* ctx, int code, const char* fmt, ...) {
   va_end(ap);
   if (ctx) ctx->err = buf;
   return code;
+}
+
+// name -> field of the option block (DcgpOptions, common.h)
+long* dcgp_option_slot(DcgpOptions* o, const char* name) {
+  struct Slot { const char* name; long DcgpOptions::*field; };
+  static const Slot slots[] = {
+      {"no_fused_layer", &DcgpOptions::no_fused_layer}, {"fused_large", &DcgpOptions::fused_large}, {"fused_shape", &DcgpOptions::fused_shape},
+      {"kl_side", &DcgpOptions::kl_side}, {"no_fused_bwd", &DcgpOptions::no_fused_bwd}, {"fused_bwd_min_cols", &DcgpOptions::fused_bwd_min_cols},
+      {"head_unfused", &DcgpOptions::head_unfused}, {"no_side_stream", &DcgpOptions::no_side_stream}, {"cu_partition", &DcgpOptions::cu_partition},
+      {"grad_nofork", &DcgpOptions::grad_nofork}, {"chol_one_launch", &DcgpOptions::chol_one_launch},
+      {"chol_no_lookahead", &DcgpOptions::chol_no_lookahead}, {"head_no_overlap", &DcgpOptions::head_no_overlap},
+      {"no_early_sweep", &DcgpOptions::no_early_sweep}, {"sync_event", &DcgpOptions::sync_event}, {"kuf_upw", &DcgpOptions::kuf_upw},
+      {"head_tail", &DcgpOptions::head_tail}, {"graph", &DcgpOptions::graph},
+      {"fused_abl", &DcgpOptions::fused_abl}, {"rb_mixed", &DcgpOptions::rb_mixed},
+  };
+  for (const Slot& s : slots)
+    if (strcmp(s.name, name) == 0) return &(o->*s.field);
+  return nullptr;
+}
+
+// the environment as the switches' initial values: DCGP_<NAME>; a variable that is set but not a number counts as 1
+static void options_from_env(DcgpOptions* o) {
+  static const char* names[] = {"no_fused_layer", "fused_large", "fused_shape", "kl_side", "no_fused_bwd", "fused_bwd_min_cols", "head_unfused",
+                                "no_side_stream", "cu_partition", "grad_nofork", "chol_one_launch", "chol_no_lookahead", "head_no_overlap",
+                                "no_early_sweep", "sync_event", "kuf_upw", "head_tail", "graph", "fused_abl", "rb_mixed"};
+  for (const char* n : names) {
+    std::string e = "DCGP_";
+    for (const char* c = n; *c; ++c) e += (char)toupper((unsigned char)*c);
+    const char* v = getenv(e.c_str());
+    if (!v) continue;
+    char* end = nullptr;
+    const long x = strtol(v, &end, 10);
+    *dcgp_option_slot(o, n) = (end != v) ? x : 1;
+  }
+}
+
+bool dcgp_poison(const char* name) {
+  static const bool poison = getenv("DCGP_POISON_WS") != nullptr;
+  static const char* only = getenv("DCGP_POISON_ONLY");
+  return poison && (!name || !only || strstr(name, only) != nullptr);
 }
 
 void* ws_get(dcgp_ctx* ctx, const std::string& name, size_t bytes) {
@@ -33,9 +74,7 @@ void* ws_get(dcgp_ctx* ctx, const std::string& name, size_t bytes) {
   }
   // debugging aid: fresh workspaces filled with NaNs (all-ones bit pattern) so that any read of memory a kernel was
   // supposed to have written first shows up in the results (the GPU suite is run this way once per change of the reverse pass)
-  static const bool poison = getenv("DCGP_POISON_WS") != nullptr;
-  static const char* only = getenv("DCGP_POISON_ONLY");   // restrict to workspaces whose name contains this string
-  if (poison && (!only || name.find(only) != std::string::npos)) {
+  if (dcgp_poison(name.c_str())) {
     hipMemset(p, 0xFF, cap);
     hipDeviceSynchronize();   // the ctx streams are non-blocking: the fill must have landed before any kernel writes the buffer
   }
@@ -123,7 +162,8 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return DCGP_ERR_HIP;
   dcgp_ctx* c = new dcgp_ctx();
   c->device = device;
-  c->no_side = getenv("DCGP_NO_SIDE_STREAM") != nullptr;
+  options_from_env(&c->opt);
+  c->no_side = c->opt.no_side_stream != 0;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       side_stream_create(&c->stream2) != hipSuccess || side_stream_create(&c->stream2b) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking) != hipSuccess ||
@@ -147,7 +187,7 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
     // layer (800 us instead of 635) -- more than the undisturbed chain buys.  Without it the chain of step i + 1 finds its CUs in
     // the partial last round and the head of step i (1107 vs 994 steps/s).
     hipDeviceProp_t prop;
-    if (getenv("DCGP_CU_PARTITION") && !c->no_side && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount == 256) {
+    if (c->opt.cu_partition && !c->no_side && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount == 256) {
       uint32_t big[8], small[8];
       for (int w = 0; w < 8; ++w) { big[w] = 0xffffffffu; small[w] = 0u; }
       big[7] = 0x0000ffffu; small[7] = 0xffff0000u;
@@ -238,6 +278,35 @@ int dcgp_memset(dcgp_ctx* ctx, void* dptr, int value, size_t bytes) {
 int dcgp_sync(dcgp_ctx* ctx) {
   if (!ctx) return DCGP_ERR_ARG;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}
+
+int dcgp_workspace_query(dcgp_ctx* ctx, size_t* bytes_out, int* count_out) {
+  if (!ctx) return DCGP_ERR_ARG;
+  size_t total = 0;
+  for (auto& kv : ctx->ws) total += kv.second.second;
+  if (bytes_out) *bytes_out = total;
+  if (count_out) *count_out = (int)ctx->ws.size();
+  return DCGP_OK;
+}
+
+int dcgp_ctx_set_option(dcgp_ctx* ctx, const char* name, long value) {
+  if (!ctx || !name) return DCGP_ERR_ARG;
+  long* slot = dcgp_option_slot(&ctx->opt, name);
+  if (!slot) return ctx_fail(ctx, DCGP_ERR_ARG, "unknown option '%s'", name);
+  if (strcmp(name, "cu_partition") == 0) return ctx_fail(ctx, DCGP_ERR_ARG, "option 'cu_partition' is read at dcgp_ctx_create only (DCGP_CU_PARTITION)");
+  *slot = value;
+  if (strcmp(name, "no_side_stream") == 0) {
+    hipDeviceSynchronize();   // steps in flight were enqueued under the other stream layout
+    ctx->no_side = value != 0;
+  }
+  return DCGP_OK;
+}
+int dcgp_ctx_get_option(dcgp_ctx* ctx, const char* name, long* value_out) {
+  if (!ctx || !name || !value_out) return DCGP_ERR_ARG;
+  long* slot = dcgp_option_slot(&ctx->opt, name);
+  if (!slot) return ctx_fail(ctx, DCGP_ERR_ARG, "unknown option '%s'", name);
+  *value_out = *slot;
   return DCGP_OK;
 }
 

@@ -289,7 +289,7 @@ int launch(dcgp_ctx* ctx, const GemmArgs& a, int* nrb_out) {
   if (red > lds) lds = red;
   GemmArgs k = a;
 #ifdef DCGP_EXPERIMENTS
-  static const bool mixed = getenv("DCGP_RB_MIXED") != nullptr;   // timing build only: Thue-Morse mixed order for launches of many rounds
+  const bool mixed = ctx->opt.rb_mixed != 0;   // timing build only: Thue-Morse mixed order for launches of many rounds
 #else
   constexpr bool mixed = false;
 #endif

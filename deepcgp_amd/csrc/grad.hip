@@ -607,7 +607,7 @@ struct SideScope {
   hipStream_t main_s;
   bool active;
   SideScope(dcgp_ctx* c, hipEvent_t fork_ev) : ctx(c), main_s(c->stream) {
-    static const bool nofork = getenv("DCGP_GRAD_NOFORK") != nullptr;   // A/B switch
+    const bool nofork = c->opt.grad_nofork != 0;   // A/B switch
     active = !nofork && !c->no_side && c->stream2 && c->stream2 != c->stream;
     if (active) {
       if (hipEventRecord(fork_ev, main_s) != hipSuccess || hipStreamWaitEvent(c->stream2, fork_ev, 0) != hipSuccess) active = false;
@@ -801,9 +801,8 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   ConvBwdArgs fb;
   fb.A1 = A1; fb.ld = ld; fb.Kc = (int)Kc; fb.alpha = L.g.alpha; fb.Rp = Rp; fb.Linv = L.g.Linv; fb.gv = gv; fb.gm = gm; fb.gvs = gvs;
   fb.M = M; fb.Mp = Mp; fb.R = R; fb.dKuf = dKuf;
-  const char* min_env = getenv("DCGP_FUSED_BWD_MIN_COLS");   // (tests: the strip kernel at sizes the oracle checks)
-  const long min_cols = min_env ? atol(min_env) : 4096;
-  const bool fused_bwd = L.has_qsqrt && !L.white && Kc >= min_cols && conv_bwd_fused_ok(fb);
+  const long min_cols = ctx->opt.fused_bwd_min_cols >= 0 ? ctx->opt.fused_bwd_min_cols : 4096;   // (tests: the strip kernel at sizes the oracle checks)
+  const bool fused_bwd = L.has_qsqrt && !L.white && Kc >= min_cols && conv_bwd_fused_ok(ctx, fb);
   double* dA1 = fused_bwd ? nullptr : bk.ws("dA1", (size_t)Mp * ld);
   double* dalpha = bk.ws("dalpha", (size_t)Mp * Rp);
   double* dG = bk.ws("dG", (size_t)R * mm);
@@ -831,7 +830,7 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   // dq_sqrt, the first two dL terms) -- long split-k contractions at ~40 % MFMA utilisation.  Main stream: dT, dA1, dK_uf
   // on the tuned kernel.  They share only read-only inputs; the join is in front of the third dL term.
   hipStream_t main_s = ctx->stream;
-  static const bool nofork = getenv("DCGP_GRAD_NOFORK") != nullptr;   // A/B switch
+  const bool nofork = ctx->opt.grad_nofork != 0;   // A/B switch
   const bool fork = !nofork && !ctx->no_side && ctx->stream2 && ctx->stream2 != main_s;
   if (fork) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, main_s));

@@ -125,9 +125,9 @@ struct ConvBwdArgs {
   int M = 0, Mp = 0, R = 0;
   double* dKuf = nullptr;                                 // [Mp][ld]
 };
-bool conv_bwd_fused_ok(const ConvBwdArgs& a);
+bool conv_bwd_fused_ok(const dcgp_ctx* ctx, const ConvBwdArgs& a);
 int conv_bwd_fused(dcgp_ctx* ctx, const ConvBwdArgs& a);
-bool conv_fused_ok(const ConvFusedArgs& a);
+bool conv_fused_ok(const dcgp_ctx* ctx, const ConvFusedArgs& a);
 int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a);
 
 // KL pieces of one layer -> kl4[0..3] = {mahalanobis, logdet_q, logdet_p, trace} (device)

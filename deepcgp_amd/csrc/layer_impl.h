@@ -60,8 +60,7 @@ struct LayerState {
   double* dalloc(size_t n_doubles) {
     void* p = nullptr;
     if (hipMalloc(&p, (n_doubles ? n_doubles : 2) * sizeof(double)) != hipSuccess) return nullptr;
-    static const bool poison = getenv("DCGP_POISON_WS") != nullptr;   // debugging aid, see ws_get (ctx.hip)
-    if (poison) { hipMemset(p, 0xFF, (n_doubles ? n_doubles : 2) * sizeof(double)); hipDeviceSynchronize(); }
+    if (dcgp_poison()) { hipMemset(p, 0xFF, (n_doubles ? n_doubles : 2) * sizeof(double)); hipDeviceSynchronize(); }   // debugging aid, see ws_get (ctx.hip)
     owned.push_back(p);
     return (double*)p;
   }
@@ -203,15 +202,8 @@ struct FactorGroup {
   bool deferred = false;
   int run(dcgp_ctx* ctx, bool defer_finish = false) {
     DCGP_TRY(upload(ctx));
-    static const bool legacy = getenv("DCGP_CHOL_LEGACY") != nullptr;   // A/B: right-looking potrf + recursive trtri
-    deferred = false;
-    if (legacy) {
-      DCGP_TRY(potrf_batched(ctx, dK, nullptr, (int)K.size(), Mp, Mp, d_info));
-      DCGP_TRY(trtri_batched(ctx, dK, dLinv, dLinvT, (int)K.size(), Mp, Mp));
-    } else {
-      DCGP_TRY(factor_inverse_batched(ctx, dK, dLinv, dLinvT, (int)K.size(), Mp, Mp, d_info, defer_finish));
-      deferred = defer_finish;
-    }
+    DCGP_TRY(factor_inverse_batched(ctx, dK, dLinv, dLinvT, (int)K.size(), Mp, Mp, d_info, defer_finish));
+    deferred = defer_finish;
     return DCGP_OK;
   }
   int finish(dcgp_ctx* ctx) {
@@ -248,7 +240,7 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     fa.rep = rep; fa.rep_stride = rep_stride; fa.z = z; fa.seed = seed; fa.stream_id = stream_id; fa.jitter = jitter;
     fa.out_sample = out_sample; fa.out_mean = out_mean; fa.out_var = out_var; fa.idm = L.identity_mean;
     if (rmap) fa.rmap = *rmap;
-    if (conv_fused_ok(fa)) {
+    if (conv_fused_ok(ctx, fa)) {
       if (!(phase & 2)) return DCGP_OK;   // nothing to run ahead of the factorisation: the sweep is part of the one launch
       if (keep_state) {
         fa.Kuf_out = (double*)ws_get(ctx, pfx + "Kuf", (size_t)Mp * ldb * sizeof(double));
@@ -287,7 +279,7 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     a.share_cu = phase == 1;
     if ((phase & 1) || chunked) {
       bool done = false;
-      if (a.bk.type == 0 && !getenv("DCGP_HEAD_OLD_SWEEP")) {   // RBF: the unit sweep in its storing form (head_units.hip)
+      if (a.bk.type == 0) {   // RBF: the unit sweep in its storing form (head_units.hip)
         HeadUnitsArgs h;
         h.X = X; h.n_mod = n_mod; h.N = nr; h.n0 = r0;
         h.H = L.v.H; h.W = L.v.W; h.C = L.v.C; h.f = L.v.f; h.s = L.v.s; h.Wo = L.v.Wo; h.P = P; h.L = L.v.L; h.Lq = L.Lz;
@@ -295,7 +287,7 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
         h.csq = sqrt(1.4426950408889634074) / L.ls; h.log2var = log2(L.variance);
         h.kuf = B; h.sM = ldc; h.sN = P; h.sP = 1;
         h.share_cu = phase == 1;
-        if (getenv("DCGP_KUF_UPW")) h.upw_force = atoi(getenv("DCGP_KUF_UPW"));   // A/B switch
+        h.upw_force = (int)ctx->opt.kuf_upw;   // A/B switch (0: head_units_plan chooses)
         head_units_plan(&h);
         if (head_units_ok(h)) { DCGP_TRY(head_units(ctx, h)); done = true; }
       }
@@ -341,8 +333,8 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   a.w = L.w; a.scale = 1.0 / (double)L.v.P; a.reduce = 1;
   a.in_scale = L.in_scale;
   a.share_cu = phase == 1;
-  static const bool unfused = getenv("DCGP_HEAD_UNFUSED") != nullptr;   // A/B switch
-  if (phase == 3 && L.kernel_type == 0 && a.bk.type == 0 && !L.in_scale && !getenv("DCGP_HEAD_OLD_SWEEP")) {
+  const bool unfused = ctx->opt.head_unfused != 0;   // A/B switch
+  if (phase == 3 && L.kernel_type == 0 && a.bk.type == 0 && !L.in_scale) {
     // ConvKernel head: Kzx and Kdiag as wave-sized units of one launch (head_units.hip), any M
     HeadUnitsArgs h;
     h.X = X; h.n_mod = n_mod; h.N = rows;
@@ -376,7 +368,7 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     }
   }
   if (sweep_mode == 1) return DCGP_OK;   // not the unit-sweep route: nothing is launched ahead
-  if (phase == 3 && L.kernel_type == 0 && a.bk.type == 0 && head_cond_fused_ok(L.g) && !unfused && !getenv("DCGP_HEAD_TWO_SWEEPS")) {
+  if (phase == 3 && L.kernel_type == 0 && a.bk.type == 0 && head_cond_fused_ok(L.g) && !unfused) {
     // ConvKernel head, M <= 256: Kzx and Kdiag in one launch, then the whole conditional in one launch that adds up the Kdiag
     // tile-pair sums itself -- two launches on one stream for the layer
     const double* kdp = nullptr; int kd_n = 1; double kd_scale = 1.0;

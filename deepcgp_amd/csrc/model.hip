@@ -59,7 +59,7 @@ int ensure(dcgp_ctx* ctx, double** p, size_t* cap, size_t n) {
   if (*cap >= n && *p) return DCGP_OK;
   if (*p) { hipDeviceSynchronize(); hipFree(*p); *p = nullptr; }   // steps in flight on any stream may still use it
   if (hipMalloc((void**)p, (n ? n : 2) * sizeof(double)) != hipSuccess) return ctx_fail(ctx, DCGP_ERR_ALLOC, "model: allocation failed");
-  if (getenv("DCGP_POISON_WS")) { hipMemset(*p, 0xFF, (n ? n : 2) * sizeof(double)); hipDeviceSynchronize(); }   // debugging aid, see ws_get
+  if (dcgp_poison()) { hipMemset(*p, 0xFF, (n ? n : 2) * sizeof(double)); hipDeviceSynchronize(); }   // debugging aid, see ws_get
   *cap = n;
   return DCGP_OK;
 }
@@ -74,7 +74,7 @@ int ensure_out(dcgp_model* m, int li, int rows, int width, bool need_mv) {
     if (hipMalloc((void**)&o.sample, n * sizeof(double)) != hipSuccess || hipMalloc((void**)&o.mean, n * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&o.var, n * sizeof(double)) != hipSuccess)
       return ctx_fail(m->ctx, DCGP_ERR_ALLOC, "model: output allocation failed");
-    if (getenv("DCGP_POISON_WS")) {
+    if (dcgp_poison()) {
       hipMemset(o.sample, 0xFF, n * sizeof(double)); hipMemset(o.mean, 0xFF, n * sizeof(double)); hipMemset(o.var, 0xFF, n * sizeof(double));
       hipDeviceSynchronize();
     }
@@ -154,6 +154,11 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   if (!m->has_head) return ctx_fail(ctx, DCGP_ERR_ARG, "model has no head layer");
   const int nl = (int)m->layers.size();
   if (nl > 8) return ctx_fail(ctx, DCGP_ERR_ARG, "at most 8 layers supported");
+  // a local batch that overran its declared shard would draw the noise of the NEXT sample's images (the counters are laid out by the
+  // un-sharded batch): correlated samples, not an error anyone would see
+  if (m->shard_global > 0 && (long)m->shard_lo + N > m->shard_global)
+    return ctx_fail(ctx, DCGP_ERR_ARG, "forward: %d images from image %d on overrun the declared global batch of %d (dcgp_model_set_shard)", N,
+                    m->shard_lo, m->shard_global);
   DCGP_TRY(ensure_events(m));
   const int bank = m->bank ^ 1;
   m->bank = bank;
@@ -176,14 +181,14 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   // (A first layer on the sweep + GEMM route keeps the side stream: its sweep needs Z only and runs beside the chain.)
   // (A model that opens with the head -- the reference's "1-layer" -- has a first kernel that needs Z only: its sweep runs on the main
   // stream beside the chain on the side stream, and the step is the longer of the two instead of their sum.)
-  // (a chain of one or two panels is shorter than the hand-off between streams; DCGP_HEAD_NO_OVERLAP, read per call: A/B switch
+  // (a chain of one or two panels is shorter than the hand-off between streams; option head_no_overlap: A/B switch
   // and how bench.py times the sweep alone on the chip)
-  bool first_fused = !(m->layers[0]->is_head && m->layers[0]->Mp >= 96 && !getenv("DCGP_HEAD_NO_OVERLAP"));
+  bool first_fused = !(m->layers[0]->is_head && m->layers[0]->Mp >= 96 && !ctx->opt.head_no_overlap);
   if (!m->layers[0]->is_head) {
     const LayerState& L0 = *m->layers[0];
     ConvFusedArgs fa;
     fa.Mp = L0.Mp; fa.M = L0.M; fa.R = L0.R; fa.Rp = L0.g.Rp; fa.P = L0.v.P; fa.HWC = L0.v.H * L0.v.W * L0.v.C; fa.Lp = L0.Lp; fa.Lz = L0.Lz;
-    first_fused = conv_fused_ok(fa);
+    first_fused = conv_fused_ok(ctx, fa);
   }
   const hipStream_t chain_s = (pipelined || !first_fused) ? kl_s : main_s;
   // a step on the other main stream than the previous one starts behind it
@@ -257,7 +262,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   // The first layer's sweep needs nothing else: it goes to the main stream NOW, in front of the chain's ~12 launches -- enqueued behind
   // them it started when the host was done with those, 60 us after prepare_all had finished (cfg2 head-only: 0.287 -> 0.24 ms).
   bool early0 = false;
-  if (rc == DCGP_OK && xs && !first_fused && !getenv("DCGP_NO_EARLY_SWEEP")) {
+  if (rc == DCGP_OK && xs && !first_fused && !ctx->opt.no_early_sweep) {
     ctx->stream = main_s;
     if (hipStreamWaitEvent(main_s, m->ev_sweep[bank], 0) != hipSuccess) rc = DCGP_ERR_HIP;
     int out_rows = 0;
@@ -280,7 +285,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   // The KL pieces need nothing but parameter-only state.  Where prep_solve left the sums of squares they are made of (every
   // layer unwhitened, M <= 256, with q_sqrt), one extra workgroup per layer of the tail launch adds them up with the factors'
   // log-determinants: no KL launches, no stream of their own, no fork in front of the first layer and no join (tail_dev.h).
-  bool kl_tail = need_kl && rc == DCGP_OK && nl <= 8 && !getenv("DCGP_KL_SIDE");
+  bool kl_tail = need_kl && rc == DCGP_OK && nl <= 8 && !ctx->opt.kl_side;
   for (int li = 0; li < nl && kl_tail; ++li) {
     const LayerState& L = *m->layers[li];
     kl_tail = !L.white && prep_done[li] && L.has_qsqrt && L.g.klp_valid && (!L.g.Kp || L.g.klpp_valid);
@@ -402,6 +407,9 @@ int dcgp_model_destroy(dcgp_model* model) {
       ++it;
     }
   }
+  for (auto it = ctx->chain_epochs.begin(); it != ctx->chain_epochs.end();)   // sync areas of the one-launch chain: gone with their workspaces
+    it = (it->first.find(tag) != std::string::npos) ? ctx->chain_epochs.erase(it) : std::next(it);
+  if (ctx->ws_tag.find(tag) != std::string::npos) ctx->ws_tag.clear();   // operator calls behind this model must not name scratch after it
   delete model;
   return DCGP_OK;
 }
@@ -571,6 +579,17 @@ int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t*
   ElboFinish fin;
   fill_finish(model, groups_now, scale, slot, &fin);
   const KlTail* klt = model->kl_in_tail[model->bank] ? &model->kl_tail[model->bank] : nullptr;
+  // From here on a kernel that writes this slot's completion word (ticket + 1) may be in flight.  If anything below fails the ticket is
+  // NOT handed out and the next enqueue reuses slot and ticket: the word is cleared, behind a device sync, so that the stale kernel's
+  // write cannot satisfy the retried step's wait early.
+  struct SlotGuard {
+    dcgp_model* m; int slot; bool armed = true;
+    ~SlotGuard() {
+      if (!armed) return;
+      hipDeviceSynchronize();
+      m->h_ring[8 * slot + 4] = 0.0;
+    }
+  } slot_guard{model, slot};
   if (!ctx->comm) {
     // expectations, their sum, the KL pieces where the chain left their ingredients, and the ELBO assembly in one launch
     DCGP_TRY(elbo_tail(ctx, o.mean, o.var, y, rows, N, H.R, model->eps, model->d_ve, inv_s, scal, fin, klt));
@@ -595,6 +614,7 @@ int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t*
     acc.launches += 1;
     acc.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   }
+  slot_guard.armed = false;
   *ticket = model->enq_seq++;
   return DCGP_OK;
 }
@@ -613,16 +633,27 @@ int elbo_forward_collect_impl(dcgp_model* model, uint64_t ticket, double* out_ho
   {
     const volatile double* hv = model->h_ring + 8 * slot;
     const double want = (double)(ticket + 1);
-    static const bool use_event = getenv("DCGP_SYNC_EVENT") != nullptr;   // A/B switch: the event wait this replaced
+    const bool use_event = ctx->opt.sync_event != 0;   // A/B switch: the event wait this replaced
     if (use_event) {
       HIP_TRY(ctx, hipEventSynchronize(model->ring_ev[slot]));
     } else {
+      // bounded spin: a step of this path is 0.15-0.8 ms; one that has not answered after ~65 000 polls (a millisecond or two: the
+      // large configurations, a rank waiting for a slower peer's all-reduce) hands the core back and blocks on the event instead --
+      // eight ranks of a node must not hold eight cores against RCCL's proxy threads
       for (unsigned spins = 1; hv[4] != want; ++spins) {
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        asm volatile("yield");
+#endif
         if ((spins & 0xfff) == 0) {
           const hipError_t q = hipEventQuery(model->ring_ev[slot]);
           if (q == hipSuccess) break;                       // complete: coherent host memory already holds the words
           if (q != hipErrorNotReady) { HIP_TRY(ctx, q); }
+          if (spins >= (1u << 16)) {
+            HIP_TRY(ctx, hipEventSynchronize(model->ring_ev[slot]));
+            break;
+          }
         }
       }
       __atomic_thread_fence(__ATOMIC_ACQUIRE);

@@ -101,7 +101,7 @@ struct NatGradState {   // per layer: fixed buffers + the pointer tables of the 
   double* alloc(size_t n) {
     void* p = nullptr;
     if (hipMalloc(&p, n * sizeof(double)) != hipSuccess) return nullptr;
-    if (getenv("DCGP_POISON_WS")) { hipMemset(p, 0xFF, n * sizeof(double)); hipDeviceSynchronize(); }   // debugging aid, see ws_get
+    if (dcgp_poison()) { hipMemset(p, 0xFF, n * sizeof(double)); hipDeviceSynchronize(); }   // debugging aid, see ws_get
     owned.push_back(p);
     return (double*)p;
   }

@@ -152,7 +152,7 @@ static int kuf_impl(dcgp_ctx* ctx, const double* X, int N, int H, int W, int C, 
   ViewGeom v;
   v.set(H, W, C, f, stride);
   const int Mp = round_up(M, 16), Lp = round_up(v.L, 4);
-  if (bk.type == 0 && !getenv("DCGP_HEAD_OLD_SWEEP")) {   // RBF: the unit sweep in its storing form (head_units.hip)
+  if (bk.type == 0) {   // RBF: the unit sweep in its storing form (head_units.hip)
     HeadUnitsArgs h;
     h.X = X; h.n_mod = N; h.N = N;
     h.H = H; h.W = W; h.C = C; h.f = f; h.s = stride; h.Wo = v.Wo; h.P = v.P; h.L = v.L; h.Lq = sweep_lq(v.L);
@@ -314,7 +314,6 @@ int dcgp_conv_layer_forward(dcgp_ctx* ctx, const double* X, int N, int H, int W,
 // ConvKernel.Kzx / Kdiag through the unit sweep (head_units.hip): what the model-level head runs.  false: shape not covered
 static bool convkernel_units(dcgp_ctx* ctx, const double* X, int N, const ViewGeom& v, const double* Z, int M, double variance,
                              double lengthscale, const double* w, double* out_MN, double* out_N, int* rc) {
-  if (getenv("DCGP_HEAD_OLD_SWEEP")) return false;   // A/B switch: the separate Kzx / Kdiag sweeps of rbf.hip
   HeadUnitsArgs h;
   h.X = X; h.n_mod = N; h.N = N;
   h.H = v.H; h.W = v.W; h.C = v.C; h.f = v.f; h.s = v.s; h.Wo = v.Wo; h.P = v.P; h.L = v.L; h.Lq = sweep_lq(v.L);

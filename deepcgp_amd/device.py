@@ -52,6 +52,9 @@ _SIGS = {
     "dcgp_d2h": [_vp, _vp, _vp, _sz],
     "dcgp_memset": [_vp, _vp, _i, _sz],
     "dcgp_sync": [_vp],
+    "dcgp_workspace_query": [_vp, C.POINTER(_sz), _ip],
+    "dcgp_ctx_set_option": [_vp, C.c_char_p, C.c_long],
+    "dcgp_ctx_get_option": [_vp, C.c_char_p, C.POINTER(C.c_long)],
     "dcgp_timing_enable": [_vp, _i],
     "dcgp_timing_reset": [_vp],
     "dcgp_timing_query": [_vp, C.c_char_p, _ip, _dp],
@@ -217,6 +220,40 @@ class Context:
 
     def sync(self):
         self._check(lib().dcgp_sync(self.handle))
+
+    def workspace_bytes(self):
+        """(bytes, count) of the device workspaces the library itself holds for this ctx (dcgp_workspace_query)."""
+        b, n = _sz(0), C.c_int(0)
+        self._check(lib().dcgp_workspace_query(self.handle, C.byref(b), C.byref(n)))
+        return b.value, n.value
+
+    # A/B switches ------------------------------------------------------------------------------
+    def set_option(self, name, value):
+        """One of the ctx's A/B / debugging switches (csrc/common.h DcgpOptions).  The environment variable
+        DCGP_<NAME> only gives the initial value at ctx creation; the library never reads the environment on the step path."""
+        self._check(lib().dcgp_ctx_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_long(0)
+        self._check(lib().dcgp_ctx_get_option(self.handle, name.encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """``with ctx.options(no_fused_layer=1): ...`` -- switches set for the block, previous values restored behind it."""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self_inner):
+                self_inner.old = {k: ctx.get_option(k) for k in kw}
+                for k, v in kw.items():
+                    ctx.set_option(k, v)
+                return ctx
+
+            def __exit__(self_inner, *exc):
+                for k, v in self_inner.old.items():
+                    ctx.set_option(k, v)
+                return False
+        return _Scope()
 
     # timing ------------------------------------------------------------------------------------
     def timing_enable(self, on=1):

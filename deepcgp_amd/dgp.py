@@ -72,6 +72,11 @@ class DGP_Base:
         self._model = h.value
         for li, l in enumerate(self.layers[:-1]):
             v = l.view
+            if getattr(l, "generic_mean", None) is not None:
+                # the one-call ELBO adds Conv2dMean's centre pixel inside the layer launch (the only mean the reference builds,
+                # conv_gp/models.py:95-99); an arbitrary callable exists at the layer level only
+                raise ValueError("layer %d: the model path takes mean_function None / Zero() / Conv2dMean with its initial filter; "
+                                 "got %r" % (li, l.mean_function))
             keep = [np.ascontiguousarray(a, np.float64) for a in (l.feature.Z, l.Z_prior, l.q_mu, l.q_sqrt)]
             ctx._check(L.dcgp_model_add_conv_layer(
                 self._model, v.input_size[0], v.input_size[1], l.feature_maps_in, v.filter_size, v.stride,

@@ -102,14 +102,21 @@ class HostGroup:
             try:
                 srv.bind((addr, 0))        # the interface the other ranks connect to, not every interface
             except OSError:
+                # MASTER_ADDR does not name a local interface (a hostname the container cannot resolve): the loopback, and the
+                # address actually bound goes into the rendezvous file -- the peers connect to what the file says, so a single-node
+                # job still meets; ranks on other nodes fail on the connect with the address in the message instead of timing out
                 srv.bind(("127.0.0.1", 0))
             srv.listen(self.world)
             srv.settimeout(timeout)
             token = os.urandom(16).hex()
             tmp = path + ".%d.tmp" % os.getpid()
+            try:
+                os.unlink(tmp)             # left by a crashed earlier run whose pid has come round again
+            except OSError:
+                pass
             fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)   # the token is the group's only credential
             with os.fdopen(fd, "w") as fh:
-                json.dump({"port": srv.getsockname()[1], "token": token}, fh)
+                json.dump({"addr": srv.getsockname()[0], "port": srv.getsockname()[1], "token": token}, fh)
             os.replace(tmp, path)          # atomic: a reader sees the old file or the new one, never half of it
             self._path = path
             peers = {}
@@ -131,7 +138,7 @@ class HostGroup:
                 try:
                     with open(path) as fh:
                         info = json.load(fh)
-                    s = socket.create_connection((addr, int(info["port"])), timeout=5.0)
+                    s = socket.create_connection((info.get("addr") or addr, int(info["port"])), timeout=5.0)   # the address rank 0 really bound
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     s.settimeout(timeout)
                     _send_msg(s, json.dumps({"rank": self.rank, "token": info["token"]}).encode())
@@ -142,7 +149,7 @@ class HostGroup:
                 except (OSError, ValueError, KeyError, ConnectionError):
                     pass                   # file not there yet / stale file of an earlier job: look again
                 if time.time() > deadline:
-                    raise TimeoutError("rank %d: no rendezvous with rank 0 through %s" % (self.rank, path))
+                    raise TimeoutError("rank %d: no rendezvous with rank 0 through %s (MASTER_ADDR %s)" % (self.rank, path, addr))
                 time.sleep(0.05)
 
     # every collective = gather to rank 0, combine there, send the result back

@@ -130,8 +130,11 @@ class Layer:
 
 
 class ConvLayer(Layer):
-    """conv_gp/layers.py:52-161.  ``mean_function`` is None / 'zero' (gpflow Zero) or 'conv2d'
-    (Conv2dMean, conv_gp/mean_functions.py:28-41)."""
+    """conv_gp/layers.py:52-161.  ``mean_function``: a ``deepcgp_amd.mean_functions`` object as the reference builds them
+    (``Conv2dMean(filter_size, feature_maps_in, feature_maps_out, stride)`` or ``Zero()``, conv_gp/models.py:95-99), any callable
+    on the NHWC image returning N x num_outputs (or N x H' x W' x gp_count) values, or the aliases None / 'zero' / 'conv2d'.
+    A ``Conv2dMean`` with the filter its constructor built is added inside the layer's own launch; any other callable through
+    its ``__call__`` (the model-level one-call ELBO path takes the former only)."""
 
     def __init__(self, base_kernel, mean_function, feature=None, view=None, white=False, gp_count=1,
                  q_mu=None, q_sqrt=None, **kwargs):
@@ -163,8 +166,42 @@ class ConvLayer(Layer):
 
     @property
     def identity_mean(self):
+        """The mean the layer kernels add themselves: Conv2dMean's centre pixel of input channel 0 into output map 0
+        (conv_gp/mean_functions.py:28-41), geometry equal to the view's."""
         mf = self.mean_function
-        return bool(mf) and (mf == 'conv2d' or getattr(mf, 'is_conv2d_mean', False))
+        if isinstance(mf, str):
+            return mf == 'conv2d'
+        if mf is None or not getattr(mf, 'is_conv2d_mean', False):
+            return False
+        if hasattr(mf, 'has_initial_filter') and not mf.has_initial_filter():
+            return False
+        v = self.view
+        return (getattr(mf, 'filter_size', v.filter_size) == v.filter_size and getattr(mf, 'stride', v.stride) == v.stride and
+                getattr(mf, 'feature_maps_in', v.feature_maps) == v.feature_maps and
+                getattr(mf, 'feature_maps_out', self.gp_count) == self.gp_count)
+
+    @property
+    def generic_mean(self):
+        """A callable mean function the kernels do not add themselves (``mean + self.mean_function(mean_view)``, layers.py:133-134)."""
+        mf = self.mean_function
+        from .mean_functions import Zero
+        if mf is None or isinstance(mf, (str, Zero)) or self.identity_mean:
+            if isinstance(mf, str) and mf not in ('zero', 'conv2d'):
+                raise ValueError("mean_function %r: expected a callable, None, 'zero' or 'conv2d'" % (mf,))
+            return None
+        if not callable(mf):
+            raise ValueError("mean_function must be callable, None, 'zero' or 'conv2d'")
+        return mf
+
+    def _generic_mean_value(self, X4):
+        mf = self.generic_mean
+        if mf is None:
+            return None
+        val = np.asarray(mf(self.view.mean_view(X4, None)), np.float64)
+        N = X4.shape[0]
+        if val.size != N * self.num_outputs:
+            raise ValueError("mean_function returned %s values for %d x %d outputs" % (val.shape, N, self.num_outputs))
+        return val.reshape(N, self.num_outputs)
 
     def conditional_ND(self, ND_X, full_cov=False):
         """mean, var of q(f | m, S), each N x (patch_count * gp_count), HWC column order."""
@@ -191,6 +228,9 @@ class ConvLayer(Layer):
             centre = X4[:, c0:c0 + (Ho - 1) * st + 1:st, c0:c0 + (Wo - 1) * st + 1:st, 0]
             mean = mean.copy()
             mean.reshape(N, v.patch_count, self.gp_count)[:, :, 0] += centre.reshape(N, v.patch_count)
+        extra = self._generic_mean_value(X4)
+        if extra is not None:
+            mean = mean + extra
         return mean, var
 
     def _forward(self, ND_X, z):
@@ -218,7 +258,12 @@ class ConvLayer(Layer):
             dmu.ptr, dsq.ptr, int(self.white), int(self.identity_mean), dz.ptr if dz else None, JITTER,
             ds.ptr if ds else None, dm.ptr, dv.ptr, C.byref(info))
         ctx._check(rc, info)
-        return (ds.numpy() if ds else None), dm.numpy(), dv.numpy()
+        smp, mean, var = (ds.numpy() if ds else None), dm.numpy(), dv.numpy()
+        extra = self._generic_mean_value(ND_X.reshape(N, H, W, self.feature_maps_in))
+        if extra is not None:
+            mean = mean + extra
+            smp = None if smp is None else smp + extra
+        return smp, mean, var
 
     def _forward_composed(self, ND_X, z):
         """conditional_ND as the reference composes it (conv_gp/layers.py:108-135) from the operator-level calls --
@@ -240,6 +285,9 @@ class ConvLayer(Layer):
             centre = X4[:, c0:c0 + (Ho - 1) * st + 1:st, c0:c0 + (Wo - 1) * st + 1:st, 0]
             mean = mean.copy()
             mean.reshape(N, v.patch_count, self.gp_count)[:, :, 0] += centre.reshape(N, v.patch_count)
+        extra = self._generic_mean_value(X4)
+        if extra is not None:
+            mean = mean + extra
         sample = None if z is None else reparameterize(mean, var, np.reshape(z, mean.shape))
         return sample, mean, var
 

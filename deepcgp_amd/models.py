@@ -6,6 +6,7 @@ from .dgp import DGP_Base
 from .kernels import RBF, ArcCosine, ConvKernel, AdditivePatchKernel, PatchInducingFeatures, InducingPoints
 from .layers import ConvLayer, SVGP_Layer
 from .likelihoods import MultiClass
+from .mean_functions import Conv2dMean, IdentityConv2dMean  # noqa: F401  (the names conv_gp/models.py:11 imports)
 from .views import FullView
 
 
@@ -21,7 +22,11 @@ def build_layers_from_spec(spec):
     for c in spec["convs"]:
         view = FullView((c["H"], c["W"]), c["f"], c["C"], c["s"])
         base = ArcCosine(view.patch_length, order=0) if c.get("base", "rbf") == "acos" else RBF(view.patch_length, c["variance"], c["ls"])
-        layer = ConvLayer(base, c.get("mean_function"),
+        mf = c.get("mean_function")
+        if mf == "conv2d":      # --identity-mean: Conv2dMean(filter_size, NHWC[3], feature_map, stride=stride), conv_gp/models.py:95-97
+            mf = Conv2dMean(c["f"], c["C"], c["R"], stride=c["s"])
+            mf.set_trainable(False)                                                            # models.py:100
+        layer = ConvLayer(base, mf,
                           feature=PatchInducingFeatures(c["Z"]), view=view, white=c["white"], gp_count=c["R"],
                           q_mu=c["q_mu"], q_sqrt=c["q_sqrt"])
         layer.Z_prior = np.array(c.get("Z0", c["Z"]), np.float64)

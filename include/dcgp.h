@@ -48,6 +48,16 @@ int dcgp_h2d(dcgp_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int dcgp_d2h(dcgp_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int dcgp_memset(dcgp_ctx* ctx, void* dptr, int value, size_t bytes);
 int dcgp_sync(dcgp_ctx* ctx);
+/* Device memory the library itself holds for this ctx (the named, grow-only workspaces: factor scratch, K_uf / A1 slabs of the
+ * sweep + GEMM route, partial sums) and the number of such workspaces.  SURVEY.md 8(b) planned a dcgp_workspace_query that SIZES
+ * caller-provided workspaces; the library grows its own lazily instead (nothing on the reference side owns scratch memory either:
+ * TensorFlow allocates graph temporaries itself), so the query reports what has been taken so far.                               */
+int dcgp_workspace_query(dcgp_ctx* ctx, size_t* bytes_out, int* count_out);
+/* A/B and debugging switches (csrc/common.h: DcgpOptions).  A ctx reads the environment variable DCGP_<NAME> once, in
+ * dcgp_ctx_create, as the switch's initial value; afterwards only these calls change it -- no getenv on the step path.  Names are
+ * lower case ("no_fused_layer", "kl_side", ...); an unknown name is DCGP_ERR_ARG.                                                 */
+int dcgp_ctx_set_option(dcgp_ctx* ctx, const char* name, long value);
+int dcgp_ctx_get_option(dcgp_ctx* ctx, const char* name, long* value_out);
 
 /* ---- per-kernel HIP-event timing (bench.py's roofline leg) -------------------------------- */
 /* When enabled, the launches of the named kernel families ("kuf", "gemm_cond", "potrf", "trtri",

@@ -178,7 +178,7 @@ def test_device_rng_path(ctx):
 
 def test_kl_pieces_in_the_tail_launch_match_the_kl_launches(ctx):
     """Unwhitened layers with M <= 256 take their KL pieces from the strip sums prep_solve leaves behind, added up by extra
-    workgroups of the tail launch (no KL launches, no side stream); DCGP_KL_SIDE=1 keeps the GEMM + kl_small route on the
+    workgroups of the tail launch (no KL launches, no side stream); the ctx option kl_side keeps the GEMM + kl_small route on the
     side stream.  Same KL to rounding, same data term to the bit, for a conv layer with a frozen-Z prior, and against the oracle."""
     import os
     hwc = (14, 14, 1)
@@ -192,11 +192,8 @@ def test_kl_pieces_in_the_tail_launch_match_the_kl_launches(ctx):
     e, data, kl = model.compute_log_likelihood(X, Y, zs=zs, return_parts=True)
     ref = oracle_model(spec, X, Y).compute_log_likelihood(X, Y, zs=zs)
     assert abs(e - ref) <= RTOL * abs(ref)
-    os.environ["DCGP_KL_SIDE"] = "1"
-    try:
+    with ctx.options(kl_side=1):
         e2, data2, kl2 = model.compute_log_likelihood(X, Y, zs=zs, return_parts=True)
-    finally:
-        del os.environ["DCGP_KL_SIDE"]
     assert data2 == data and abs(kl2 - kl) <= 1e-12 * abs(kl) and abs(e2 - e) <= 1e-12 * abs(e)
     assert abs(model.KL() - kl) <= 1e-10 * abs(kl)                   # the operator API, layer by layer
     tickets = [model.enqueue_log_likelihood(X, Y, zs=zs) for _ in range(3)]
@@ -385,12 +382,9 @@ def test_oversized_operand_slab(ctx):
     X = np.tile(X, (2, 1))[:200]                    # 200 images x 10 samples x 144 patches
     Y = np.tile(Y, 2)[:200]
     model = build_from_spec(spec, X, Y)
-    os.environ["DCGP_FUSED_LARGE"] = "1"          # M > 256 takes the one-launch route on request only
-    try:
+    with ctx.options(fused_large=1):              # M > 256 takes the one-launch route on request only
         e, data, kl = model.compute_log_likelihood(X, Y, seed=0, return_parts=True)
         lo = model.compute_log_likelihood(X[:100], Y[:100], seed=0, return_parts=True)[1]
-    finally:
-        del os.environ["DCGP_FUSED_LARGE"]
     assert np.isfinite([e, data, kl]).all() and data < lo < 0
     e2, data2, kl2 = model.compute_log_likelihood(X, Y, seed=0, return_parts=True)      # default route: chunked
     assert abs(data2 - data) <= 1e-8 * abs(data) and abs(kl2 - kl) <= 1e-10 * abs(kl)
@@ -618,13 +612,9 @@ def test_gradients_match_oracle(ctx, white, additive, idmean):
     import os
     # twice: the launch-per-product reverse pass of the conditional (few columns), then its one-launch strip form
     # (csrc/conv_bwd_fused.hip, taken from 4096 columns on; unwhitened layers with q_sqrt) forced onto these sizes
-    for min_cols in (None, "0"):
-        if min_cols is not None:
-            os.environ["DCGP_FUSED_BWD_MIN_COLS"] = min_cols
-        try:
+    for min_cols in (-1, 0):
+        with ctx.options(fused_bwd_min_cols=min_cols):
             e, grads = model.compute_gradients(X, Y, zs=zs)
-        finally:
-            os.environ.pop("DCGP_FUSED_BWD_MIN_COLS", None)
         assert abs(e - eo) <= RTOL * abs(eo)
         for li, (g, o) in enumerate(zip(grads, go)):
             for name, val in o.items():
@@ -730,13 +720,9 @@ def test_gradients_match_oracle_mnist_geometry(ctx):
     model = build_from_spec(spec, X, Y)
     eo, go = elbo_and_grad(ref, X, Y, zs)
     import os
-    for min_cols in (None, "0"):     # second pass: the strip form of the conditional's reverse pass (M = 136: 9 row fragments, 7 idle waves)
-        if min_cols is not None:
-            os.environ["DCGP_FUSED_BWD_MIN_COLS"] = min_cols
-        try:
+    for min_cols in (-1, 0):     # second pass: the strip form of the conditional's reverse pass (M = 136: 9 row fragments, 7 idle waves)
+        with ctx.options(fused_bwd_min_cols=min_cols):
             e, grads = model.compute_gradients(X, Y, zs=zs)
-        finally:
-            os.environ.pop("DCGP_FUSED_BWD_MIN_COLS", None)
         assert abs(e - eo) <= RTOL * abs(eo)
         for li, (g, o) in enumerate(zip(grads, go)):
             for name, val in o.items():
@@ -965,16 +951,13 @@ def test_gradients_are_bitwise_reproducible_at_full_size(ctx):
     # the conditional's column-wise reverse pass as ONE strip-resident launch (default at this size, csrc/conv_bwd_fused.hip) against
     # its launch-per-product form at the full 46 080 columns: the same gradients to rounding
     import os
-    os.environ["DCGP_NO_FUSED_BWD"] = "1"
-    try:
+    with ctx.options(no_fused_bwd=1):
         for dedup in (False, True):
             model.dedup_layer0 = dedup
             e, g = model.compute_gradients(X, Y, seed=7)
             flat = np.concatenate([np.ravel(v) for gl in g for v in gl.values()])
             assert abs(e - first[dedup][0]) <= 1e-12 * abs(e)
             assert np.abs(flat - first[dedup][1]).max() <= 1e-9 * max(np.abs(flat).max(), 1.0), dedup
-    finally:
-        del os.environ["DCGP_NO_FUSED_BWD"]
     model.close()
 
 
@@ -1021,9 +1004,7 @@ def test_gradients_match_oracle_odd_shapes(ctx, maps, strip_kernel):
     ref = oracle_model(spec, X, Y)
     model = build_from_spec(spec, X, Y)
     eo, go = elbo_and_grad(ref, X, Y, zs)
-    if strip_kernel:
-        os.environ["DCGP_FUSED_BWD_MIN_COLS"] = "0"
-    try:
+    with ctx.options(fused_bwd_min_cols=0 if strip_kernel else -1):
         for dedup in (False, True):
             model.dedup_layer0 = dedup
             e, grads = model.compute_gradients(X, Y, zs=zs)
@@ -1032,8 +1013,6 @@ def test_gradients_match_oracle_odd_shapes(ctx, maps, strip_kernel):
                 for name, val in o.items():
                     err = np.abs(g[name] - val).max()
                     assert err < 1e-7 * np.abs(val).max() or err < 1e-8, (dedup, li, name, err, np.abs(val).max())
-    finally:
-        os.environ.pop("DCGP_FUSED_BWD_MIN_COLS", None)
     model.close()
 
 

@@ -330,7 +330,7 @@ def test_conv_layer(ctx, white, H, W, C, f, s, M, R):
 ])
 def test_fused_conv_layer_matches_the_unfused_route_and_the_oracle(ctx, white, H, W, C, f, s, M, R, N):
     """conv_fused.hip (the whole layer of a column strip in one workgroup) against the sweep + GEMM route it replaces
-    (DCGP_NO_FUSED_LAYER) and against the oracle, over every tile shape the launcher picks."""
+    (option no_fused_layer) and against the oracle, over every tile shape the launcher picks."""
     import os
     from deepcgp_amd.kernels import RBF, PatchInducingFeatures
     from deepcgp_amd.layers import ConvLayer
@@ -342,15 +342,11 @@ def test_fused_conv_layer_matches_the_unfused_route_and_the_oracle(ctx, white, H
     Z *= 1.5
     layer = ConvLayer(RBF(v.patch_length, 5.0, 5.0), None, PatchInducingFeatures(Z), v, white=white, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
     z = rng.standard_normal((N, layer.num_outputs))
-    assert "DCGP_NO_FUSED_LAYER" not in os.environ
-    os.environ["DCGP_FUSED_LARGE"] = "1"        # M > 256 takes the one-launch route on request only
-    try:
+    assert ctx.get_option("no_fused_layer") == 0
+    with ctx.options(fused_large=1):            # M > 256 takes the one-launch route on request only
         smp, mean, var = layer._forward(X, z)
-        os.environ["DCGP_NO_FUSED_LAYER"] = "1"
-        smp_u, mean_u, var_u = layer._forward(X, z)
-    finally:
-        os.environ.pop("DCGP_NO_FUSED_LAYER", None)
-        del os.environ["DCGP_FUSED_LARGE"]
+        with ctx.options(no_fused_layer=1):
+            smp_u, mean_u, var_u = layer._forward(X, z)
     close(mean, mean_u, 1e-11, "mean vs unfused")
     close(var, var_u, 1e-10, "var vs unfused")
     close(smp, smp_u, 1e-10, "sample vs unfused")

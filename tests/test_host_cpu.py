@@ -243,10 +243,46 @@ def test_flat_import_shim():
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r);"
             "from layers import ConvLayer, MultiOutputConvKernel; from kernels import ConvKernel, PatchInducingFeatures, _sample_patches;"
             "from views import FullView; from conditionals import conditional; from models import ModelBuilder; from arguments import default_parser;"
+            "from mean_functions import Conv2dMean, IdentityConv2dMean;"          # conv_gp/models.py:11
+            "import deepcgp_amd.mean_functions as MF; assert Conv2dMean is MF.Conv2dMean and issubclass(Conv2dMean, IdentityConv2dMean);"
             "import deepcgp_amd.layers as L; assert ConvLayer is L.ConvLayer; print(FullView((28, 28), 5, 1).patch_count)"
             % (ROOT, os.path.join(ROOT, "deepcgp_amd", "flat")))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == "576", out.stderr
+
+
+def test_mean_function_objects_without_a_device():
+    """conv_gp/mean_functions.py:6-41 / models.py:95-100: constructor arguments, the two initial filters, set_trainable, and how
+    ConvLayer classifies what it is handed (the kernels add Conv2dMean's centre pixel themselves only while the filter is the
+    initial one and the geometry is the view's)."""
+    from deepcgp_amd.kernels import RBF, PatchInducingFeatures
+    from deepcgp_amd.layers import ConvLayer
+    from deepcgp_amd.mean_functions import Conv2dMean, IdentityConv2dMean, Zero
+    from deepcgp_amd.views import FullView
+    idm = IdentityConv2dMean(5, 3, 4, stride=2)
+    assert idm.conv_filter.shape == (5, 5, 3, 4) and idm.conv_filter.sum() == 12 and np.all(idm.conv_filter[2, 2] == 1.0)
+    cm = Conv2dMean(5, 3, 4, stride=2)
+    assert cm.conv_filter.sum() == 1.0 and cm.conv_filter[2, 2, 0, 0] == 1.0 and cm.has_initial_filter()
+    cm.set_trainable(False)
+    assert cm.trainable is False
+    assert Zero()(np.zeros((3, 7))).shape == (3, 1)
+
+    class Stub(ConvLayer):           # the classification needs no device: skip the prior factorisation
+        def _build_prior_cholesky(self):
+            pass
+    rng = np.random.default_rng(0)
+    view = FullView((9, 9), 5, 3, 2)
+    mk = lambda mf: Stub(RBF(view.patch_length, 1.0, 1.0), mf, PatchInducingFeatures(rng.standard_normal((6, view.patch_length))),   # noqa: E731
+                         view, gp_count=4, q_mu=np.zeros((6, 4)), q_sqrt=np.tile(np.eye(6), (4, 1, 1)))
+    assert mk(cm).identity_mean and mk(cm).generic_mean is None
+    assert mk("conv2d").identity_mean and not mk(None).identity_mean and mk(Zero()).generic_mean is None
+    moved = Conv2dMean(5, 3, 4, stride=2)
+    moved.conv_filter[0, 0, 1, 2] = 0.5
+    assert not mk(moved).identity_mean and mk(moved).generic_mean is moved            # a changed filter goes through __call__
+    assert not mk(Conv2dMean(5, 3, 4, stride=1)).identity_mean                        # another geometry than the view's
+    assert mk(idm).generic_mean is idm
+    with pytest.raises(ValueError):
+        mk("identity").generic_mean
 
 
 def test_kernel_host_classes_validate_without_a_device():
