@@ -48,6 +48,10 @@ struct DcgpOptions {
   long no_early_sweep = 0;       // the first layer's sweep enqueued behind the chain instead of in front of it
   long sync_event = 0;           // wait for the step's event instead of polling its completion word
   long kuf_upw = 0;              // units per wave of the storing sweep (0: chosen by head_units_plan)
+  long kuf_split = -1;           // storing sweep with replicas: column-fragment ranges per row fragment (-1: chosen; 0: one)
+  long kuf_wpg = 0;              // storing sweep: waves per workgroup (0: chosen by head_units_plan; 1, 2, 4)
+  long kuf_stream = 0;           // storing sweep: the streamed-operand kernel also for the patch lengths with a register-resident one
+  long kuf_no_rep = 0;           // storing sweep: evaluate every row, also where rows show the same image (tiled batch)
   long head_tail = -1;           // head_units: balance of the launch tail (-1: default; see head_units_plan)
   long graph = -1;               // synchronous forward step replayed from a captured HIP graph (-1: default)
   long fused_abl = 0, rb_mixed = 0;   // timing builds only (make EXPERIMENTS=1)
@@ -93,6 +97,8 @@ struct dcgp_ctx {
   double* h_scratch = nullptr;   // 64 doubles
   int* h_info = nullptr;         // 16 ints
   long long* fused_trace = nullptr;   // debugging aid (dcgp_debug_set_fused_trace): phase stamps of the one-launch layer kernel
+  std::string sweep_trace_family;     // ... of the launches of this timer family only ("kuf", "kuf_long", "head_sweep")
+  long long* sweep_trace = nullptr; long sweep_trace_wgs = 0;   // debugging aid (dcgp_debug_set_sweep_trace): stamps of every workgroup of the patch sweeps
   // RCCL
   void* comm = nullptr;
   int nranks = 1, rank = 0;
@@ -276,6 +282,11 @@ int head_kdiag(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, i
 // head_units.hip: ConvKernel.Kzx (weighted patch sum) and ConvKernel.Kdiag (partial sums per image) in one launch.
 // RBF base kernel; the operands carry the kernel's scales: ZS = sqrt(c) Z^T with c = log2(e) / lengthscale^2, rows L, L + 1 =
 // (-c |z|^2 / 2 + log2 variance, 1), zero behind (prepare_all writes it beside Z^T).
+// A launch of the unit sweep is a list of segments in dispatch order: workgroups [wg0, next wg0) cover images [img0, ...) with wpi
+// workgroups per image.  kind 0: Kzx row units (one per 16-row fragment of Z); 1: Kdiag chunks of T tiles of the image's patch Gram
+// matrix (C chunks per image); 2: the storing form's row units.  Long units go first, the Kdiag chunks shrink towards the end of the
+// launch so that its tail is a short unit, not a long one (head_units_plan).
+struct HuSeg { int wg0 = 0, img0 = 0, wpi = 1, kind = 0, T = 0, C = 0; };
 struct HeadUnitsArgs {
   const double* X = nullptr; int n_mod = 0, N = 0, n0 = 0; // image of row n is X[(n0 + n) % n_mod] (n0: first image of a chunk; outputs are indexed by the local n)
   int H = 0, W = 0, C = 0, f = 0, s = 0, Wo = 0, P = 0, L = 0, Lq = 0, HWC = 0;
@@ -286,9 +297,22 @@ struct HeadUnitsArgs {
   double* kuf = nullptr; long sM = 0, sN = 0, sP = 0;      // the K_uf sweep instead: kuf[m * sM + n * sN + p * sP] = k(z_m, x_np) (rows M..kzx_rows-1 zeroed)
   int kzx_rows = 0;                                        // rows of kzx / kuf that exist (0: all Mp)
   int share_cu = 0;                                        // leave room on every CU for a workgroup of the factorisation chain (see head_units)
-  double* kd = nullptr;                                    // kd[n * n_kd + i]: Kdiag[n] = sum_i kd[..] / P^2   (nullptr / kzx == nullptr: that half is skipped)
+  double* kd = nullptr;                                    // kd[n * n_kd + i]: Kdiag[n] = sum_i kd[..] / P^2; every slot of an image is written (values or zeros)
   int upw_force = 0;                                       // units per wave (0: chosen by head_units_plan)
-  int nfm = 0, nfp = 0, n_kd = 0, U = 0, u_lo = 0, upw = 1, wpg = 4, wgs_per_img = 0;  // set by head_units_plan (call it with kzx / kd already set)
+  int wpg_force = 0;                                       // storing form: waves per workgroup (0: chosen by head_units_plan)
+  int stream_k = 0;                                        // storing form: the streamed-operand kernel even where a register-resident one exists (A/B)
+  int no_rep = 0;                                          // storing form: evaluate every row even where rows share an image (n_mod < N)
+  long long* trace = nullptr; long trace_wgs = 0;          // debugging aid (tools/sweep_trace.py): [workgroup][wave][8] stamps, first trace_wgs workgroups
+  const char* timer = nullptr;                             // timer family of the launch (nullptr: "kuf" / "head_sweep")
+  int want_kd = 0;                                         // Kdiag partial sums wanted: head_units_plan sizes n_kd, the caller then allocates kd [N][n_kd]
+  int tail_mode = -1;                                      // balance of the launch's tail (-1: default levels; 0: equal Kdiag chunks throughout)
+  int nfm = 0, nfp = 0, n_kd = 0, upw = 1, wpg = 4;        // set by head_units_plan (call it with kzx / want_kd / kuf already set)
+  int nseg = 0; HuSeg seg[6]; long n_wgs = 0;              // the launch's segments and its workgroup count (head_units_plan)
+  int st_split = 1, st_jn = 0, st_hold = 0;                // storing form with replicas: column-fragment ranges per row fragment, fragments per range, hold + replica-outer stores
+  int split_force = -1;                                    // A/B: ranges per row fragment (-1: ceil(nfp / 8); 0: one)
+  int st_jb = 0, st_rb = 0;                                // storing form: byte step per patch fragment (16 sP) and per replica (n_mod sN)
+  int n_base = 0;                                          // rows the launch evaluates: N, or (storing form) the min(N, n_mod) distinct images -- their
+                                                           // values are stored to every row n + r n_mod < N that shows the same image (set by head_units_plan)
   float inv_C = 1.f, inv_f = 1.f, inv_Wo = 1.f, inv_Wr = 1.f;         // reciprocals for the set-up's index splits
 };
 void head_units_plan(HeadUnitsArgs* a);

@@ -23,6 +23,9 @@
 
 namespace {
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kOob = (int)0x80000000u;   // a per-lane buffer offset past every descriptor's num_records (<= 0x7fffffff): the store is dropped
+
 // small-range integer division by a launch-time constant without the ~40-instruction sequence: q = floor((i + 0.5) / d)
 __device__ __forceinline__ int fdiv_small(int i, float inv_d) { return (int)(((float)i + 0.5f) * inv_d); }
 
@@ -39,9 +42,21 @@ __device__ __forceinline__ int fdiv_small(int i, float inv_d) { return (int)(((f
 #define HU_EXPN 4
 #endif
 // WRITE: the K_uf sweep of a conv layer (conv_gp/layers.py:23-32 on views.py:40-44) -- the same row units, every kernel value stored
-// (kuf[m * sM + n * sN + p * sP]) instead of reduced; no Kdiag units.
-template <int NK4, int TL, bool WRITE, int NT>
-__global__ __launch_bounds__(NT, HU_WAVES) void head_units_kernel(HeadUnitsArgs a) {
+// (kuf[m * sM + n * sN + p * sP]) instead of reduced; no Kdiag units.  A pure store kernel reaches 5.3-6.0 TB/s on this part in exactly
+// this tile pattern (tools/store_bw.hip: four 128-byte segments per instruction, rows sM apart, misaligned P included), so what the
+// sweep must not do is spend issue slots beside its stores:
+//   * stores go through ONE buffer descriptor per unit: per-lane offsets (row lrow + 4 v, column lcol) computed once per unit, the
+//     fragment / replica part a scalar offset -- no 64-bit address arithmetic per value; lanes outside the matrix (rows >= kzx_rows,
+//     patches >= P) carry an out-of-range offset and are dropped by the bounds check;
+//   * rows that show the SAME image (propagate() tiles the batch S times: row n shows image (n0 + n) % n_mod) get the same values:
+//     a unit evaluates its tiles once and stores them to every such row (a.n_base < a.N).
+// WMODE 0: the reducing form; 1: the storing form, every tile stored as it is evaluated; 2: the storing form that can also hold a batch
+// of tiles for replica-outer stores (row_pass_hold).  The storing forms run at three / two waves per SIMD (168 / 256 registers, no
+// spill): their stores and a spill reload share the wave's in-order memory counter, so a single reload in the tile loop waits for
+// every store issued before it -- the store queue drained once per tile.
+template <int NK4, int TL, int WMODE, int NT>
+__global__ __launch_bounds__(NT, WMODE == 2 ? 2 : (WMODE == 1 ? 3 : HU_WAVES)) void head_units_kernel(HeadUnitsArgs a) {
+  constexpr bool WRITE = WMODE != 0;
   constexpr int WPG = NT / 64;   // units (waves) per workgroup
   constexpr bool RES = NK4 > 0;
   constexpr int NKR = RES ? NK4 : 1;
@@ -57,51 +72,83 @@ __global__ __launch_bounds__(NT, HU_WAVES) void head_units_kernel(HeadUnitsArgs 
   const char* imgb = reinterpret_cast<const char*>(img);
   const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = blockIdx.x / a.wgs_per_img, bw = blockIdx.x - n * a.wgs_per_img;
+  // this workgroup's segment of the launch (HuSeg, common.h), its image and its place among the image's workgroups
+  int sg = 0;
+#pragma unroll
+  for (int q = 1; q < 6; ++q)
+    if (q < a.nseg && (int)blockIdx.x >= a.seg[q].wg0) sg = q;
+  const int seg_kind = a.seg[sg].kind, seg_T = a.seg[sg].T, seg_C = a.seg[sg].C;
+  const int wloc = (int)blockIdx.x - a.seg[sg].wg0, wpi = a.seg[sg].wpi;
+  const int nloc = wloc / wpi, bw = wloc - nloc * wpi;
+  const int n = a.seg[sg].img0 + nloc;   // storing form: n < a.n_base
   const double* __restrict__ Xn = a.X + (long)((a.n0 + n) % a.n_mod) * HWC;
   auto ldi = [&](int byte_off) { return *reinterpret_cast<const double*>(imgb + byte_off); };
+  // stamps for tools/sweep_trace.py (a.trace == nullptr in normal use: one scalar branch each).  [0] wall clock (100 MHz) at entry,
+  // [1] shader clock at entry, [2] image in LDS, [3] set-up done, [4] first unit done, [5] last unit done, [6] wall clock at exit, [7] units run
+  long long* const tr = (a.trace && blockIdx.x < a.trace_wgs) ? a.trace + ((long)blockIdx.x * WPG + wave) * 8 : nullptr;
+  auto stamp = [&](int k) { if (tr && lane == 0) tr[k] = (long long)clock64(); };
+  if (tr && lane == 0) { tr[0] = (long long)wall_clock64(); tr[7] = 0; }
+  stamp(1);
 
   // ---- set-up, once per workgroup: the scaled image, the offset tables, patch norms from a separable window sum ----
-  for (int i0 = 0; i0 < HWC; i0 += 8 * NT) {   // batches of 8 loads per thread: one memory latency for all of them
-    double t[8];
+  // The image's loads go out first; the tables, which need no pixel, are built under their latency.  (A trace of every workgroup,
+  // tools/sweep_trace.py, showed the set-up at 4.9 us of a 256-thread workgroup's ~20 and 12.5 us of a one-wave workgroup's 26 before
+  // this was reordered and the window sums were given one thread per entry: four threads per entry with two shuffles each is a dependent
+  // chain per iteration, and a 64-thread workgroup walked 42 of them.)
+  {
+    double t[8];   // batches of 8 loads per thread: one memory latency for all of them
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int i = i0 + e * NT + tid;
+      const int i = e * NT + tid;
       t[e] = (i < HWC) ? Xn[i] : 0.0;
     }
+    for (int l = tid; l < a.Lq; l += NT) {
+      const int ll = l < L ? l : 0;
+      const int tq = fdiv_small(ll, a.inv_C), c = ll - tq * a.C;
+      const int kh = fdiv_small(tq, a.inv_f), kw = tq - kh * a.f;
+      koff[l] = ((kh * a.W + kw) * a.C + c) * 8;
+    }
+    for (int p = tid; p < np16; p += NT) {
+      const int q = p < P ? p : 0;                 // patches beyond P repeat the first one (finite values, weight 0)
+      const int oh = fdiv_small(q, a.inv_Wo), ow = q - oh * a.Wo;
+      pbl[p] = (oh * a.s * a.W + ow * a.s) * a.C * 8;
+      wl[p] = (!WRITE && p < P) ? a.w[p] : 0.0;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int i = i0 + e * NT + tid;
+      const int i = e * NT + tid;
       if (i < HWC) img[i] = t[e] * a.csq;
     }
-  }
-  for (int l = tid; l < a.Lq; l += NT) {
-    const int ll = l < L ? l : 0;
-    const int t = fdiv_small(ll, a.inv_C), c = ll - t * a.C;
-    const int kh = fdiv_small(t, a.inv_f), kw = t - kh * a.f;
-    koff[l] = ((kh * a.W + kw) * a.C + c) * 8;
-  }
-  for (int p = tid; p < np16; p += NT) {
-    const int q = p < P ? p : 0;                 // patches beyond P repeat the first one (finite values, weight 0)
-    const int oh = fdiv_small(q, a.inv_Wo), ow = q - oh * a.Wo;
-    pbl[p] = (oh * a.s * a.W + ow * a.s) * a.C * 8;
-    wl[p] = (!WRITE && p < P) ? a.w[p] : 0.0;
+    for (int i0 = 8 * NT; i0 < HWC; i0 += 8 * NT) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = i0 + e * NT + tid;
+        t[e] = (i < HWC) ? Xn[i] : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = i0 + e * NT + tid;
+        if (i < HWC) img[i] = t[e] * a.csq;
+      }
+    }
   }
   __syncthreads();
+  stamp(2);
   {
-    // rs[r][x] = sum over the f*C contiguous elements of image row r that a patch starting at column x covers; 4 threads per entry
+    // rs[r][x] = sum of squares over the f*C contiguous elements of image row r that a patch starting at column x covers: one thread
+    // per entry, its reads independent of each other (four in flight per step)
     const int Wr = a.W - a.f + 1, fC = a.f * a.C;
-    for (int i0 = 0; i0 < a.H * Wr; i0 += NT / 4) {
-      const int i = i0 + (tid >> 2), part = tid & 3;
+    for (int i = tid; i < a.H * Wr; i += NT) {
+      const int r = fdiv_small(i, a.inv_Wr), x = i - r * Wr;
+      const double* src = img + (r * a.W + x) * a.C;
       double acc = 0.0;
-      if (i < a.H * Wr) {
-        const int r = fdiv_small(i, a.inv_Wr), x = i - r * Wr;
-        const double* src = img + (r * a.W + x) * a.C;
-        for (int j = part; j < fC; j += 4) acc = fma(src[j], src[j], acc);
+      int j = 0;
+      for (; j + 4 <= fC; j += 4) {
+        const double v0 = src[j], v1 = src[j + 1], v2 = src[j + 2], v3 = src[j + 3];
+        acc = fma(v0, v0, acc); acc = fma(v1, v1, acc); acc = fma(v2, v2, acc); acc = fma(v3, v3, acc);
       }
-      acc += __shfl_xor(acc, 1);
-      acc += __shfl_xor(acc, 2);
-      if (part == 0 && i < a.H * Wr) rs[i] = acc;
+      for (; j < fC; ++j) acc = fma(src[j], src[j], acc);
+      rs[i] = acc;
     }
     __syncthreads();
     for (int p = tid; p < np16; p += NT) {
@@ -109,7 +156,12 @@ __global__ __launch_bounds__(NT, HU_WAVES) void head_units_kernel(HeadUnitsArgs 
       const int oh = fdiv_small(q, a.inv_Wo), ow = q - oh * a.Wo;
       const double* src = rs + oh * a.s * Wr + ow * a.s;
       double acc = 0.0;
-      for (int kh = 0; kh < a.f; ++kh) acc += src[kh * Wr];
+      int kh = 0;
+      for (; kh + 4 <= a.f; kh += 4) {
+        const double v0 = src[kh * Wr], v1 = src[(kh + 1) * Wr], v2 = src[(kh + 2) * Wr], v3 = src[(kh + 3) * Wr];
+        acc += (v0 + v1) + (v2 + v3);
+      }
+      for (; kh < a.f; ++kh) acc += src[kh * Wr];
       xb[p] = -0.5 * acc;
     }
   }
@@ -118,8 +170,13 @@ __global__ __launch_bounds__(NT, HU_WAVES) void head_units_kernel(HeadUnitsArgs 
   // this wave's unit: rotated by the image so that the empty slots of the last workgroup of an image (U % 4 != 0) do not
   // always fall on the same SIMDs
   // (a workgroup covers WPG * upw consecutive units, wave w the units w, w + WPG, ...: one set-up for upw units per wave)
-  int u = a.u_lo + WPG * a.upw * bw + ((wave + n) & (WPG - 1));
-  if (u >= a.U) return;
+  stamp(3);
+  int u = WPG * a.upw * bw + ((wave + n) & (WPG - 1));
+  const int n_units = seg_kind == 1 ? seg_C : (WRITE ? a.nfm * a.st_split : a.nfm);
+  if (u >= n_units) {
+    if (tr && lane == 0) tr[6] = (long long)wall_clock64();
+    return;
+  }
 
   // The operand slots k = 4 s + lrow behind the patch (k >= L) sit in the last one or two sub-steps (ts = s - sL): the A side
   // (rows) carries (norm + log2 variance, 1) at k = L, L + 1, the B side (columns) (1, norm).  Per lane and tail sub-step:
@@ -148,6 +205,14 @@ __global__ __launch_bounds__(NT, HU_WAVES) void head_units_kernel(HeadUnitsArgs 
     const double t0 = ts ? tB_real[1] : tB_real[0], t1 = ts ? tB_one[1] : tB_one[0], t2 = ts ? tB_nrm[1] : tB_nrm[0];
     return fma(v, t0, fma(nrm, t1, t2));
   };
+
+  // storing form: the unit's buffer descriptor (base: row 16 u of base row n), its per-lane offsets and its replica count
+  __amdgpu_buffer_rsrc_t st_rs = __builtin_amdgcn_make_buffer_rsrc(a.kuf, 0, 0, 0x00020000);
+  int st_voff[4] = {kOob, kOob, kOob, kOob};
+  bool st_zero = false;
+  const int st_nrep = (WRITE && a.n_base < a.N) ? (a.N - 1 - n) / a.n_mod + 1 : 1;
+  const bool st_hold = WMODE == 2 && st_nrep > 1 && a.st_hold;
+  int ur = 0;   // the unit's row fragment (storing form: a unit is a row fragment x one of a.st_split ranges of column fragments)
 
   // NY column fragments starting at fragment j0 against one row fragment: product (operands of the next sub-step requested
   // before the MFMAs of the current one), then 2^t and the weighted row sums.  getA(s): the A operand of sub-step s.
@@ -261,11 +326,28 @@ __global__ __launch_bounds__(NT, HU_WAVES) void head_units_kernel(HeadUnitsArgs 
       if (WRITE) {   // rows m = 16 u + lrow + 4 v, 16 consecutive patches per row: 128-byte segments when sP == 1
 #pragma unroll
         for (int y = 0; y < YE; ++y) {
-          const int pp = 16 * (j0 + y0 + y) + lcol;
+          const int j = j0 + y0 + y;
+          int vo[4];
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int m = 16 * u + lrow + 4 * v;
-            if (m < a.kzx_rows && pp < P) a.kuf[(long)m * a.sM + (long)n * a.sN + (long)pp * a.sP] = m < a.M ? t[4 * y + v] : 0.0;
+          for (int v = 0; v < 4; ++v) vo[v] = st_voff[v];
+          if (j == nfp - 1) {   // the ragged last fragment: patches >= P are dropped
+#pragma unroll
+            for (int v = 0; v < 4; ++v) vo[v] = (16 * j + lcol < P) ? vo[v] : kOob;
+          }
+          if (st_zero) {        // the fragment that holds the padded rows M .. kzx_rows - 1: zeros
+#pragma unroll
+            for (int v = 0; v < 4; ++v) t[4 * y + v] = (16 * ur + lrow + 4 * v < a.M) ? t[4 * y + v] : 0.0;
+          }
+          if (st_hold) {        // several replicas: the values wait in `rdiag` (row_pass_hold's batch of tiles) for the replica-outer stores
+#pragma unroll
+            for (int v = 0; v < 4; ++v) rdiag[4 * (y0 + y) + v] = t[4 * y + v];
+            continue;
+          }
+          int so = j * a.st_jb;
+          for (int r = 0; r < st_nrep; ++r, so += a.st_rb) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, t[4 * y + v]), st_rs, vo[v], so, 0);
           }
         }
         continue;
@@ -286,10 +368,10 @@ __global__ __launch_bounds__(NT, HU_WAVES) void head_units_kernel(HeadUnitsArgs 
   using T3 = std::integral_constant<int, 3>;
   using T4 = std::integral_constant<int, 4>;
 
-  // one row fragment against column fragments [j_lo, nfp): groups of four, then one group of the remaining 1..3.
+  // one row fragment against column fragments [j_lo, j_hi): groups of four, then one group of the remaining 1..3.
   // rdiag != nullptr: receives the share of the first fragment (the diagonal tile of a Kdiag row; rsum must start at zero)
-  auto row_pass = [&](auto&& getA, auto&& getA_raw, int j_lo, double* rdiag, double (&rsum)[4]) {
-    const int nfull = (nfp - j_lo) >> 2, nrem = (nfp - j_lo) & 3;
+  auto row_pass = [&](auto&& getA, auto&& getA_raw, int j_lo, int j_hi, double* rdiag, double (&rsum)[4]) {
+    const int nfull = (j_hi - j_lo) >> 2, nrem = (j_hi - j_lo) & 3;
     int pb[4];
     double bv[4];
     const int ko0 = RES ? kob[0] : koff[lrow];
@@ -305,20 +387,79 @@ __global__ __launch_bounds__(NT, HU_WAVES) void head_units_kernel(HeadUnitsArgs 
     else if (nrem == 3) group(T3{}, getA, getA_raw, j0, -1, 0, rd, rsum, pb, bv);
   };
 
-  for (int uu = 0; uu < a.upw && u < a.U; ++uu, u += WPG) {
-  if (u < a.nfm) {
+  // storing form with replicas: the row fragment's tiles in batches of up to 8, each batch evaluated into registers and then stored
+  // replica by replica, fragment by fragment within a replica -- a row receives 1 KB contiguously.  Tile by tile (each tile to all its
+  // replicas before the next one) a row's 128-byte segments arrive ~one tile time apart, and where P is not a multiple of 16 (13 x 13,
+  // 15 x 15 views) every segment straddles two cache lines whose halves are then written back separately: 4.0 instead of 6.0 TB/s in a
+  // pure store kernel (tools/store_bw.hip, tile_rep_jr against tile_rep).
+  auto row_pass_hold = [&](auto&& getA, auto&& getA_raw, int j_lo, int j_hi) {
+    const int ko0 = RES ? kob[0] : koff[lrow];
+    double dummy[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int jb = j_lo; jb < j_hi; jb += 8) {
+      const int nb = min(8, j_hi - jb), n0 = min(nb, 4), n1 = nb - n0;
+      double keep[32];
+      int pb[4];
+      double bv[4];
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        if (y < n0) { pb[y] = pbl[16 * (jb + y) + lcol]; bv[y] = ldi(pb[y] + ko0); }
+      }
+      if (n0 == 4) group(T4{}, getA, getA_raw, jb, jb + 4, n1, keep, dummy, pb, bv);
+      else if (n0 == 3) group(T3{}, getA, getA_raw, jb, -1, 0, keep, dummy, pb, bv);
+      else if (n0 == 2) group(T2{}, getA, getA_raw, jb, -1, 0, keep, dummy, pb, bv);
+      else group(T1{}, getA, getA_raw, jb, -1, 0, keep, dummy, pb, bv);
+      if (n1 == 4) group(T4{}, getA, getA_raw, jb + 4, -1, 0, keep + 16, dummy, pb, bv);
+      else if (n1 == 3) group(T3{}, getA, getA_raw, jb + 4, -1, 0, keep + 16, dummy, pb, bv);
+      else if (n1 == 2) group(T2{}, getA, getA_raw, jb + 4, -1, 0, keep + 16, dummy, pb, bv);
+      else if (n1 == 1) group(T1{}, getA, getA_raw, jb + 4, -1, 0, keep + 16, dummy, pb, bv);
+      int so_r = jb * a.st_jb;
+      for (int r = 0; r < st_nrep; ++r, so_r += a.st_rb) {
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+          if (y < nb) {
+            const int j = jb + y;
+            int vo[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) vo[v] = st_voff[v];
+            if (j == nfp - 1) {   // the ragged last fragment: patches >= P are dropped
+#pragma unroll
+              for (int v = 0; v < 4; ++v) vo[v] = (16 * j + lcol < P) ? vo[v] : kOob;
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, keep[4 * y + v]), st_rs, vo[v], so_r + y * a.st_jb, 0);
+          }
+        }
+      }
+    }
+  };
+
+  for (int uu = 0; uu < a.upw && u < n_units; ++uu, u += WPG) {
+  if (seg_kind != 1) {
     // ---- Kzx rows 16 u .. 16 u + 15: out[m][n] = scale * sum_p w_p k(z_m, x_p) ----
-    const double* __restrict__ zs = a.ZS + 16 * u + lcol;
+    ur = WRITE ? u / a.st_split : u;
+    const int part = WRITE ? u - ur * a.st_split : 0;
+    const int uj_lo = WRITE ? part * a.st_jn : 0, uj_hi = WRITE ? min(nfp, uj_lo + a.st_jn) : nfp;
+    const double* __restrict__ zs = a.ZS + 16 * ur + lcol;
     double rsum[4] = {0.0, 0.0, 0.0, 0.0};
+    if (WRITE) {
+      st_rs = __builtin_amdgcn_make_buffer_rsrc(a.kuf + ((long)(16 * ur) * a.sM + (long)n * a.sN), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        st_voff[v] = (16 * ur + lrow + 4 * v < a.kzx_rows) ? (int)(((long)(lrow + 4 * v) * a.sM + (long)lcol * a.sP) * 8) : kOob;
+      st_zero = 16 * ur + 16 > a.M;
+    }
     if (RES) {
       double areg[NKR];
 #pragma unroll
       for (int s = 0; s < NKR; ++s) areg[s] = zs[(long)(4 * s + lrow) * a.Mp];
-      row_pass([&](int s) { return areg[s]; }, [&](int s, int) { return areg[RES ? s : 0]; }, 0, nullptr, rsum);
+      if (WMODE == 2 && st_hold) row_pass_hold([&](int s) { return areg[s]; }, [&](int s, int) { return areg[RES ? s : 0]; }, uj_lo, uj_hi);
+      else row_pass([&](int s) { return areg[s]; }, [&](int s, int) { return areg[RES ? s : 0]; }, uj_lo, uj_hi, nullptr, rsum);
     } else {
-      row_pass([&](int s) { return zs[(long)(4 * s + lrow) * a.Mp]; }, [&](int s, int) { return zs[(long)(4 * s + lrow) * a.Mp]; }, 0, nullptr, rsum);
+      if (WMODE == 2 && st_hold) row_pass_hold([&](int s) { return zs[(long)(4 * s + lrow) * a.Mp]; }, [&](int s, int) { return zs[(long)(4 * s + lrow) * a.Mp]; }, uj_lo, uj_hi);
+      else row_pass([&](int s) { return zs[(long)(4 * s + lrow) * a.Mp]; }, [&](int s, int) { return zs[(long)(4 * s + lrow) * a.Mp]; }, uj_lo, uj_hi, nullptr, rsum);
     }
-    if (WRITE) continue;
+    if (!WRITE) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       double s = rsum[v];
@@ -326,20 +467,29 @@ __global__ __launch_bounds__(NT, HU_WAVES) void head_units_kernel(HeadUnitsArgs 
       s += __shfl_xor(s, 2);
       s += __shfl_xor(s, 4);
       s += __shfl_xor(s, 8);
-      const int m = 16 * u + lrow + 4 * v;
+      const int m = 16 * ur + lrow + 4 * v;
       if (lcol == 0 && m < a.kzx_rows) a.kzx[(long)m * a.ldk + n] = m < a.M ? a.kzx_scale * s : 0.0;
     }
+    }
   } else {
-    // ---- Kdiag: fragment rows i and nfp - 1 - i of the patch Gram matrix, tiles on and right of the diagonal ----
-    const int i = u - a.nfm;
+    // ---- Kdiag: chunk u of the image's patch Gram matrix -- tiles on and right of the diagonal (off-diagonal ones count twice), the
+    // fragment rows taken in the order 0, nfp - 1, 1, nfp - 2, ... (a long row, then a short one), the tiles of that list cut into
+    // chunks of seg_T: a chunk is one to three row segments [j_lo, j_hi) whatever its size ----
+    const int ntot = nfp * (nfp + 1) / 2;
+    const int lo = u * seg_T, hi = min(lo + seg_T, ntot);
+    auto row_of = [&](int k) { return (k & 1) ? nfp - 1 - (k >> 1) : (k >> 1); };
+    int k = 0, off = 0;
+    while (k < nfp && off + (nfp - row_of(k)) <= lo) { off += nfp - row_of(k); ++k; }
     double total = 0.0;
-    for (int pass = 0; pass < 2; ++pass) {
-      const int fr = pass == 0 ? i : nfp - 1 - i;
-      if (pass == 1 && fr <= i) break;
+    for (; k < nfp && off < hi; ++k) {
+      const int fr = row_of(k), len = nfp - fr;
+      const int j_lo = fr + max(lo - off, 0), j_hi = fr + min(hi - off, len);
+      off += len;
       const int pr = 16 * fr + lcol;
       const int pa = pbl[pr];
       const double xav = xb[pr] + a.log2var;
       double rsum[4] = {0.0, 0.0, 0.0, 0.0}, rdiag[4] = {0.0, 0.0, 0.0, 0.0};
+      double* rd = j_lo == fr ? rdiag : nullptr;   // the segment opens with the row's diagonal tile
       auto getA_img = [&](int s, int ko) {
         double v = ldi(pa + ko);
         if (s >= sL) v = fixA(v, s, xav);
@@ -349,18 +499,26 @@ __global__ __launch_bounds__(NT, HU_WAVES) void head_units_kernel(HeadUnitsArgs 
         double areg[NKR];
 #pragma unroll
         for (int s = 0; s < NKR; ++s) areg[s] = getA_img(s, kob[s]);
-        row_pass([&](int s) { return areg[s]; }, [&](int s, int) { return areg[RES ? s : 0]; }, fr, rdiag, rsum);
+        row_pass([&](int s) { return areg[s]; }, [&](int s, int) { return areg[RES ? s : 0]; }, j_lo, j_hi, rd, rsum);
       } else {
-        row_pass([&](int s) { return getA_img(s, koff[4 * s + lrow]); }, [&](int, int ko) { return ldi(pa + ko); }, fr, rdiag, rsum);
+        row_pass([&](int s) { return getA_img(s, koff[4 * s + lrow]); }, [&](int, int ko) { return ldi(pa + ko); }, j_lo, j_hi, rd, rsum);
       }
 #pragma unroll
       for (int v = 0; v < 4; ++v) total = fma(wl[16 * fr + lrow + 4 * v], 2.0 * rsum[v] - rdiag[v], total);   // off-diagonal tiles count twice
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) total += __shfl_xor(total, o);
-    if (lane == 0) a.kd[(long)n * a.n_kd + i] = total;
+    // every slot of the image is written by someone: chunk u its own and, where the launch's finest chunks are more numerous than this
+    // segment's (n_kd > seg_C), zeros into the slots u + seg_C, u + 2 seg_C, ...
+    const int slot = u + lane * seg_C;
+    if (slot < a.n_kd) a.kd[(long)n * a.n_kd + slot] = lane == 0 ? total : 0.0;
+  }
+  if (tr) {
+    stamp(uu == 0 ? 4 : 5);
+    if (lane == 0) tr[7] += 1;
   }
   }
+  if (tr && lane == 0) tr[6] = (long long)wall_clock64();
 }
 
 }  // namespace
@@ -371,6 +529,11 @@ static size_t head_units_lds(const HeadUnitsArgs& a) {
 }
 
 bool head_units_ok(const HeadUnitsArgs& a) {
+  if (a.kuf) {
+    // the stores' 32-bit offsets: per lane (15 rows + 15 patches), per fragment + replica (scalar)
+    const long lane_max = (15 * a.sM + 15 * a.sP) * 8, uni_max = ((long)(a.nfp + 1) * 16 * a.sP + (long)a.N * a.sN) * 8;
+    if (lane_max >= (1L << 31) || uni_max >= (1L << 31)) return false;
+  }
   return head_units_lds(a) <= 54 * 1024 && (long)a.Lq * a.Mp * 8 < (1L << 31);
 }
 
@@ -379,35 +542,116 @@ void head_units_plan(HeadUnitsArgs* a) {
   a->HWC = a->H * a->W * a->C;
   a->nfm = a->Mp / 16;
   a->nfp = (a->P + 15) / 16;
-  a->n_kd = (a->nfp + 1) / 2;
-  a->U = (a->kd && !a->kuf) ? a->nfm + a->n_kd : a->nfm;     // no Kdiag output (or the K_uf sweep): the row units only
-  a->u_lo = (a->kzx || a->kuf) ? 0 : a->nfm;                 // no Kzx output: the Kdiag units only
-  // units per wave: the set-up of a workgroup (image, window sums, tables: ~3 us of latency) is as long as a short unit (a 16-row
-  // fragment against the 9 patch fragments of a 12 x 12 view), so such launches put several units behind one set-up -- as many as
-  // leave >= 512 workgroups (two per CU), and never a count between one and two rounds of the 1024 resident slots
-  // waves per workgroup: 4 where the patch fits registers (one set-up for four long units); 2 for long patches on small views
-  // (a 12 x 12 x 10 head input: 18 units of 252 MFMAs per image -- 1600 four-wave workgroups are 1.56 rounds of the resident
-  // slots, 2880 two-wave ones 1.4, and with no empty unit slot: 84 -> 79 us)
-  a->wpg = (a->L == 25 || a->kuf || a->nfp > 8) ? 4 : 2;
-  const int HU_WPG = a->wpg;
-  const int nu = a->U - a->u_lo;
-  a->upw = 1;
-  if (a->upw_force > 0) a->upw = a->upw_force;
-  else
-    for (int k = 4; k > 1; k >>= 1) {
-      const long nwg = (long)a->N * ((nu + HU_WPG * k - 1) / (HU_WPG * k));
-      if (a->nfp <= 16 && nwg >= 512 && nu % (HU_WPG * k) == 0) { a->upw = k; break; }
-    }
-  a->wgs_per_img = (nu + HU_WPG * a->upw - 1) / (HU_WPG * a->upw);
   if (a->kzx_rows <= 0) a->kzx_rows = a->Mp;
   a->inv_C = 1.0f / (float)a->C; a->inv_f = 1.0f / (float)a->f; a->inv_Wo = 1.0f / (float)a->Wo; a->inv_Wr = 1.0f / (float)(a->W - a->f + 1);
+  a->nseg = 0; a->n_wgs = 0; a->n_kd = 0; a->upw = 1; a->n_base = a->N;
+  // waves per workgroup: 4 where the patch fits registers (one set-up for four long units); 2 for long patches on small views
+  // (a 12 x 12 x 10 head input: units of 252 MFMAs, short beside the set-up they sit behind)
+  a->wpg = (a->L == 25 || a->kuf || a->nfp > 8) ? 4 : 2;
+  auto push = [&](int kind, int n_img, int wpi, int T, int C) {
+    if (n_img <= 0 || a->nseg >= 6) return;
+    HuSeg& g = a->seg[a->nseg++];
+    g.wg0 = (int)a->n_wgs; g.img0 = 0; g.wpi = wpi; g.kind = kind; g.T = T; g.C = C;
+    a->n_wgs += (long)n_img * wpi;
+  };
+  if (a->kuf) {
+    // ---- the storing form: row units only ----
+    // rows n, n + n_mod, ... show the same image: evaluated once, stored to each (see the note at the kernel)
+    if (!a->no_rep && a->n_mod > 0 && a->n_mod < a->N) a->n_base = a->n_mod;
+    a->st_jb = (int)(16 * a->sP * 8);
+    a->st_rb = (int)((long)a->n_mod * a->sN * 8);
+    // few units (the distinct images of a tiled batch: 32 x 16 at the headline size): narrower workgroups, so that every CU has one
+    // with replicas a unit is a row fragment x a range of <= 8 column fragments (one batch of row_pass_hold): more, shorter waves -- the
+    // launch ends within a short unit's time of its slowest wave (identical waves finished 27 ... 53 us after their set-up at the CIFAR
+    // first layer: the memory system does not serve them evenly) -- and the stores of a range start after <= 8 tiles, not after all
+    a->st_split = 1; a->st_jn = a->nfp;
+    a->st_hold = a->n_base < a->N && a->sP == 1 && (a->sN % 16) != 0;   // row segments of an image not 128-byte aligned: hold + replica-outer
+    if (a->n_base < a->N && a->split_force != 0) {
+      a->st_split = a->split_force > 0 ? a->split_force : (a->nfp + 7) / 8;
+      if (a->st_split > a->nfp) a->st_split = a->nfp;
+      a->st_jn = (a->nfp + a->st_split - 1) / a->st_split;
+      a->st_split = (a->nfp + a->st_jn - 1) / a->st_jn;
+    }
+    const int nuw = a->nfm * a->st_split;   // units per image
+    const long units = (long)a->n_base * nuw;
+    if (units < 1024) a->wpg = units >= 256 ? 2 : 1;
+    if (a->wpg_force == 1 || a->wpg_force == 2 || a->wpg_force == 4) a->wpg = a->wpg_force;
+    // units per wave: the set-up of a workgroup (image, window sums, tables: ~2.5 us of latency) is as long as a short unit (a 16-row
+    // fragment against the 9 patch fragments of a 12 x 12 view at L = 25: 63 MFMAs), so such launches put several units behind one
+    // set-up -- as many as leave >= 512 workgroups (two per CU); units of a few hundred MFMAs (L = 250) stay one per wave
+    if (a->upw_force > 0) a->upw = a->upw_force;
+    else if (a->st_jn * (a->Lq / 4) < 200 && a->n_base == a->N)
+      for (int k = 4; k > 1; k >>= 1) {
+        const long nwg = (long)a->n_base * ((nuw + a->wpg * k - 1) / (a->wpg * k));
+        if (a->nfp <= 16 && nwg >= 512 && nuw % (a->wpg * k) == 0) { a->upw = k; break; }
+      }
+    push(2, a->n_base, (nuw + a->wpg * a->upw - 1) / (a->wpg * a->upw), 0, 0);
+    return;
+  }
+  // ---- the reducing form: the Kzx row units of every image first, then the Kdiag chunks, shrinking towards the end of the launch ----
+  // A workgroup lives as long as its longest wave, and a wave that shares its SIMD with three others needs ~4 x its own issue time: a
+  // unit of 37 tiles is ~50 us of a ~150 us launch, and workgroups that END at random moments of their last 50 us leave a third of the
+  // chip idle for the final stretch (tools/sweep_trace.py: busy waves over time).  The dispatcher hands out workgroups in id order as
+  // slots free up, so the order of the list is the schedule: long units first, and the last stretch made of chunks of 1/2, 1/4, 1/8 the
+  // size -- each level about half a round of the resident slots -- ends within one short chunk.
+  const int W = a->wpg;
+  if (a->kzx) push(0, a->N, (a->nfm + W - 1) / W, 0, 0);
+  if (a->want_kd || a->kd) {
+    const int ntot = a->nfp * (a->nfp + 1) / 2;
+    // coarse chunks: about one Kzx-sized unit (nfp + 1 tiles) each, their count a multiple of the workgroup's waves where that is possible
+    int C0 = ntot / (a->nfp + 1);
+    if (C0 >= W) C0 = C0 / W * W;
+    if (C0 < 1) C0 = 1;
+    int T0 = (ntot + C0 - 1) / C0;
+    C0 = (ntot + T0 - 1) / T0;
+    int lvT[4] = {T0, 0, 0, 0}, lvC[4] = {C0, 0, 0, 0}, lvN[4] = {a->N, 0, 0, 0}, nlv = 1;
+    const long slots = 1024;   // wave slots the chip holds of this kernel (4 per SIMD)
+    // measured (tools/head_ab.sh): worth 4-5 % on launches of a few rounds of the slots (M = 32 head, the 12 x 12 x 10 heads); from ~10
+    // rounds on (MNIST head at M = 256: 10.6) the extra workgroups' set-ups cost what the sharper end saves, so those keep equal chunks
+    const long rounds = (long)a->N * ((a->kzx ? a->nfm : 0) + C0) / slots;
+    if (a->tail_mode > 0 || (a->tail_mode < 0 && rounds < 8)) {
+      int left = a->N;
+      for (int lv = 1; lv < 4; ++lv) {
+        const int T = (T0 + (1 << lv) - 1) >> lv;
+        if (T < 3 || T == lvT[lv - 1]) break;
+        const int C = (ntot + T - 1) / T;
+        long n = slots / 2 / C;                     // half a round of the slots at this chunk size
+        if (a->tail_mode > 0) n = n * a->tail_mode / 4;   // A/B: tail_mode / 4 of that
+        if (n < 1) n = 1;
+        if (n > left / 2) n = left / 2;             // never more than half of what is left: the coarse levels keep the bulk
+        if (n <= 0) break;
+        lvT[lv] = T; lvC[lv] = C; lvN[lv] = (int)n; left -= (int)n; nlv = lv + 1;
+      }
+      lvN[0] = left;
+    }
+    int img = 0;
+    for (int lv = 0; lv < nlv; ++lv) {
+      const int before = a->nseg;
+      push(1, lvN[lv], (lvC[lv] + W - 1) / W, lvT[lv], lvC[lv]);
+      if (a->nseg > before) { a->seg[before].img0 = img; img += lvN[lv]; }
+      if (lvC[lv] > a->n_kd) a->n_kd = lvC[lv];
+    }
+  }
 }
 
-int head_units(dcgp_ctx* ctx, const HeadUnitsArgs& a) {
+extern "C" int dcgp_debug_set_sweep_trace(dcgp_ctx* ctx, long long* buf_dev, long n_workgroups, const char* family) {
+  if (!ctx) return DCGP_ERR_ARG;
+  ctx->sweep_trace = buf_dev;   // [n_workgroups][waves per workgroup][8] int64; nullptr switches the stamps off
+  ctx->sweep_trace_wgs = buf_dev ? n_workgroups : 0;
+  ctx->sweep_trace_family = family ? family : "";
+  return DCGP_OK;
+}
+
+int head_units(dcgp_ctx* ctx, const HeadUnitsArgs& a_in) {
+  HeadUnitsArgs a = a_in;
+  const char* family = a.timer ? a.timer : (a.kuf ? "kuf" : "head_sweep");
+  if (ctx->sweep_trace && (ctx->sweep_trace_family.empty() || ctx->sweep_trace_family == family)) { a.trace = ctx->sweep_trace; a.trace_wgs = ctx->sweep_trace_wgs; }
   if (a.N <= 0) return DCGP_OK;
+  if (a.want_kd && !a.kd) return ctx_fail(ctx, DCGP_ERR_ARG, "head_units: Kdiag partial sums wanted but no buffer (allocate kd [N][n_kd] behind head_units_plan)");
   if (!head_units_ok(a) || a.n_mod <= 0 || a.Lq != round_up(a.L + 2, 4) || a.Mp % 16)
     return ctx_fail(ctx, DCGP_ERR_ARG, "head_units: unsupported shape (image %d doubles, L = %d, Mp = %d)", a.HWC, a.L, a.Mp);
-  const long nwg = (long)a.N * a.wgs_per_img;
+  const long nwg = a.n_wgs;
+  if (nwg <= 0) return DCGP_OK;
   if (nwg > 0x7fffffffL) return ctx_fail(ctx, DCGP_ERR_ARG, "head_units: too many workgroups");
   size_t lds = head_units_lds(a);
   // Beside the factorisation chain (a head-first model: the sweep needs Z only): a chain workgroup is one wave of 250 VGPRs per SIMD
@@ -415,16 +659,32 @@ int head_units(dcgp_ctx* ctx, const HeadUnitsArgs& a) {
   // workgroups.  Claiming 54 KB per workgroup holds the sweep to two per CU (half the register file stays free; 2 waves per SIMD
   // cost it ~3 %) -- the chain's workgroups then start the moment they are launched.
   if (a.share_cu && lds < 54 * 1024) lds = 54 * 1024;
-  ScopedTimer t(ctx, a.kuf ? "kuf" : "head_sweep");
+  ScopedTimer t(ctx, family);
   if (a.kuf) {
-    if (a.L == 25) hipLaunchKernelGGL((head_units_kernel<7, 1, true, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
-    else hipLaunchKernelGGL((head_units_kernel<0, 0, true, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
+    // patch lengths of the first layers (5 x 5 x 1, 4 x 4 x 1, 4 x 4 x 3: MNIST / CIFAR conv0) with the row operand resident in registers
+#define HU_STORE_W(NK4, TL, WM)                                                                                                          \
+  do {                                                                                                                                     \
+    if (a.wpg == 4) hipLaunchKernelGGL((head_units_kernel<NK4, TL, WM, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);        \
+    else if (a.wpg == 2) hipLaunchKernelGGL((head_units_kernel<NK4, TL, WM, 128>), dim3((unsigned)nwg), dim3(128), lds, ctx->stream, a);   \
+    else hipLaunchKernelGGL((head_units_kernel<NK4, TL, WM, 64>), dim3((unsigned)nwg), dim3(64), lds, ctx->stream, a);                     \
+  } while (0)
+#define HU_STORE(NK4, TL)                     \
+  do {                                        \
+    if (a.st_hold) HU_STORE_W(NK4, TL, 2);    \
+    else HU_STORE_W(NK4, TL, 1);              \
+  } while (0)
+    if (a.L == 25 && !a.stream_k) HU_STORE(7, 1);
+    else if (a.L == 16 && !a.stream_k) HU_STORE(5, 0);
+    else if (a.L == 48 && !a.stream_k) HU_STORE(13, 0);
+    else HU_STORE(0, 0);
+#undef HU_STORE
+#undef HU_STORE_W
   } else if (a.L == 25) {
-    hipLaunchKernelGGL((head_units_kernel<7, 1, false, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);   // 5 x 5 x 1 patches
+    hipLaunchKernelGGL((head_units_kernel<7, 1, 0, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);   // 5 x 5 x 1 patches
   } else if (a.wpg == 4) {
-    hipLaunchKernelGGL((head_units_kernel<0, 0, false, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((head_units_kernel<0, 0, 0, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
   } else {
-    hipLaunchKernelGGL((head_units_kernel<0, 0, false, 128>), dim3((unsigned)nwg), dim3(128), lds, ctx->stream, a);
+    hipLaunchKernelGGL((head_units_kernel<0, 0, 0, 128>), dim3((unsigned)nwg), dim3(128), lds, ctx->stream, a);
   }
   LAUNCH_CHECK(ctx);
   return DCGP_OK;

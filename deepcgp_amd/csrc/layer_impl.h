@@ -288,6 +288,11 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
         h.kuf = B; h.sM = ldc; h.sN = P; h.sP = 1;
         h.share_cu = phase == 1;
         h.upw_force = (int)ctx->opt.kuf_upw;   // A/B switch (0: head_units_plan chooses)
+        h.stream_k = (int)ctx->opt.kuf_stream;
+        h.wpg_force = (int)ctx->opt.kuf_wpg;
+        h.split_force = (int)ctx->opt.kuf_split;
+        h.no_rep = (int)ctx->opt.kuf_no_rep;   // A/B switch: every row evaluated even where rows share an image
+        h.timer = L.v.L > 64 ? "kuf_long" : "kuf";   // long patches (deeper layers, L = 250) are MFMA-bound, short ones HBM-bound: two families
         head_units_plan(&h);
         if (head_units_ok(h)) { DCGP_TRY(head_units(ctx, h)); done = true; }
       }
@@ -343,10 +348,12 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     h.csq = sqrt(1.4426950408889634074) / L.ls; h.log2var = log2(L.variance);
     h.w = L.w; h.kzx = B; h.ldk = ldb; h.kzx_scale = 1.0 / (double)L.v.P;
     h.share_cu = factor_done != nullptr;   // first layer of the model with the chain on another stream: the chain runs beside this launch
-    h.kd = (double*)ws_get(ctx, "kdiag_partial", (size_t)rows * ((L.v.P + 31) / 32) * sizeof(double));
-    if (!h.kd) return DCGP_ERR_ALLOC;
+    h.want_kd = 1;
+    h.tail_mode = (int)ctx->opt.head_tail;
     head_units_plan(&h);
     if (head_units_ok(h)) {
+      h.kd = (double*)ws_get(ctx, "kdiag_partial", (size_t)rows * h.n_kd * sizeof(double));   // [rows][n_kd] partial sums (head_units_plan)
+      if (!h.kd) return DCGP_ERR_ALLOC;
       if (sweep_mode != 2) DCGP_TRY(head_units(ctx, h));
       if (sweep_mode == 1) {
         if (early_done) *early_done = true;

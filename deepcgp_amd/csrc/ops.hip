@@ -321,12 +321,14 @@ static bool convkernel_units(dcgp_ctx* ctx, const double* X, int N, const ViewGe
   h.csq = sqrt(1.4426950408889634074) / lengthscale; h.log2var = log2(variance);
   h.w = w; h.kzx = out_MN; h.ldk = N; h.kzx_rows = M; h.kzx_scale = 1.0 / (double)v.P;
   *rc = DCGP_OK;
-  if (out_N) {
-    h.kd = (double*)ws_get(ctx, "kdiag_partial", (size_t)N * ((v.P + 31) / 32) * sizeof(double));
-    if (!h.kd) { *rc = DCGP_ERR_ALLOC; return true; }
-  }
+  h.want_kd = out_N != nullptr;
+  h.tail_mode = (int)ctx->opt.head_tail;
   head_units_plan(&h);
   if (!head_units_ok(h)) return false;
+  if (out_N) {
+    h.kd = (double*)ws_get(ctx, "kdiag_partial", (size_t)N * h.n_kd * sizeof(double));   // [N][n_kd] partial sums (head_units_plan)
+    if (!h.kd) { *rc = DCGP_ERR_ALLOC; return true; }
+  }
   if (Z) {
     double* ZS = (double*)ws_get(ctx, "op_ZS", (size_t)h.Lq * h.Mp * sizeof(double));
     if (!ZS) { *rc = DCGP_ERR_ALLOC; return true; }

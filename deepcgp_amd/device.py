@@ -103,6 +103,7 @@ _SIGS = {
                           _i, _i, _i, _i, _d, _i, _vp, C.c_long, C.c_long, _vp, C.c_long, C.c_long, _i],
     "dcgp_kmeans": [_vp, _vp, C.c_long, _i, _i, _vp, _i, _d, _vp, _ip],
     "dcgp_debug_set_fused_trace": [_vp, _vp],
+    "dcgp_debug_set_sweep_trace": [_vp, _vp, C.c_long, C.c_char_p],
     "dcgp_comm_unique_id": [C.c_char_p],
     "dcgp_comm_init_rank": [_vp, _i, _i, C.c_char_p],
     "dcgp_comm_destroy": [_vp],

@@ -1,10 +1,5 @@
-for u in 1 2 4; do DCGP_KUF_UPW=$u DCGP_NO_FUSED_LAYER=1 python bench.py --steps 30 --no-cpu-baseline --no-grad-leg --no-extra-legs 2>/dev/null | python -c "
-import json,sys
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('upw $u', round(d['value'],1), d['kernel_times_us'].get('kuf'))"; done
-for u in 1 2 4; do DCGP_KUF_UPW=$u python bench.py --config cfg5_mnist_CH_M1024 --steps 10 --no-cpu-baseline --no-grad-leg --no-extra-legs 2>/dev/null | python -c "
-import json,sys
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('cfg5 upw $u', round(d['value'],2), d['kernel_times_us'].get('kuf'))"; done
+# usage (GPU box): bash tools/kuf_ab.sh   -- the storing sweep under its A/B options, every configuration with a conv layer
+for cfg in cfg2_mnist_CH_M256 cfg3_mnist_3layer_M256 cfg4_cifar_3layer_M384 cfg5_mnist_CH_M1024; do
+for env in "" "DCGP_KUF_SPLIT=0" "DCGP_KUF_SPLIT=3" "DCGP_KUF_SPLIT=4" "DCGP_KUF_WPG=4" "DCGP_KUF_WPG=1"; do
+  echo "== $cfg [$env]"; env $env python tools/sweep_times.py $cfg 2>&1 | grep "kuf "
+done; done

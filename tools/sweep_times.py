@@ -47,17 +47,21 @@ def main():
             ctx.sync()
             tim = ctx.timing()
             ctx.timing_enable(0)
-        if "kuf" in tim and tim["kuf"][0]:
-            # one timer for all conv layers: with several, the per-layer split is not visible here -- report the sum against the summed bytes
-            us = 1e3 * tim["kuf"][1] / n
-            nbytes = 0.0
+        for fam in ("kuf", "kuf_long"):      # short patches (first layers, HBM-bound) / long patches (L = 250, MFMA-bound)
+            if fam not in tim or not tim[fam][0]:
+                continue
+            us = 1e3 * tim[fam][1] / n
+            nbytes = flops = 0.0
             desc = []
             for c in spec["convs"]:
                 P, L = geometry(c)
+                if (L > 64) != (fam == "kuf_long"):
+                    continue
                 nbytes += 8.0 * (rows * c["H"] * c["W"] * c["C"] + c["M"] * L + float(P) * c["M"] * rows)
-                desc.append("P=%d L=%d" % (P, L))
-            print("%-24s kuf        %8.1f us/step  %7.1f MB  %7.0f GB/s  frac %.3f  (%s; %d launches/step)" %
-                  (name, us, nbytes / 1e6, nbytes / us / 1e3, nbytes / us / 1e3 / 8000.0, ", ".join(desc), tim["kuf"][0] // n))
+                flops += float(P) * c["M"] * rows * (2 * L + 4)
+                desc.append("P=%d L=%d M=%d" % (P, L, c["M"]))
+            print("%-24s %-10s %8.1f us/step  %7.1f MB  %7.0f GB/s  frac %.3f  %6.1f TF/s  (%s; %d launches/step)" %
+                  (name, fam, us, nbytes / 1e6, nbytes / us / 1e3, nbytes / us / 1e3 / 8000.0, flops / us / 1e6, ", ".join(desc), tim[fam][0] // n))
         if "head_sweep" in tim and tim["head_sweep"][0]:
             h = spec["head"]
             P, L = geometry(h)
