@@ -39,6 +39,8 @@ from deepcgp_amd.models import build_from_spec                          # noqa: 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix peak (datasheet; the guide lists no fp64 row): 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+PMC_SOURCE = ("profiles/pmc_traffic.json: HBM-side bytes per launch from the COMMITTED rocprofv3 --pmc passes of tools/collect_profiles.sh "
+              "(FETCH_SIZE x 2 + WRITE_SIZE), not re-measured by this run")
 
 
 def pmc_traffic(kernel, config):
@@ -57,9 +59,17 @@ def conv_geometry(c, rows):
 
 
 def cpu_baseline(name, S, batch, budget_s=30.0):
-    """The oracle (NumPy/OpenBLAS fp64 restatement in the reference's operation order) timed on the host."""
+    """The oracle (NumPy/OpenBLAS fp64 restatement in the reference's operation order) timed on the host, as BASELINE.md section 2
+    lays it out: 2 warm-up + >= 5 timed forward ELBO steps of the same workload, median; the BLAS thread count is the best of
+    {8, 32, 64, all cores} (one probing step each -- 256 OpenBLAS threads on a 0.2 s GEMM are slower than 32) and is reported; a
+    1-thread row beside it on a quarter of the batch (the step is linear in the batch: value scaled by 1/4 and labelled).  Bounded
+    at ~budget_s seconds of CPU work whatever the host."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_build import oracle_model
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:                                            # no control over the pool: time it as it comes
+        threadpool_limits = None
     spec, X, Y = syn.make_config(name, S=S)
     X, Y = X[:batch], Y[:batch]
     model = oracle_model(spec, X, Y)
@@ -67,16 +77,50 @@ def cpu_baseline(name, S, batch, budget_s=30.0):
     small = oracle_model(spec, X[:2], Y[:2])
     small.num_samples = 1
     small.compute_log_likelihood(X[:2], Y[:2], rng=rng)          # warm BLAS / page in
-    times = []
-    t_all = time.perf_counter()
-    while len(times) < 3 and (not times or time.perf_counter() - t_all + times[-1] < budget_s):
+
+    def one(m, Xb, Yb):
         t0 = time.perf_counter()
-        model.compute_log_likelihood(X, Y, rng=rng)
-        times.append(time.perf_counter() - t0)
+        m.compute_log_likelihood(Xb, Yb, rng=rng)
+        return time.perf_counter() - t0
+
+    def limited(n):
+        import contextlib
+        return threadpool_limits(limits=n, user_api="blas") if threadpool_limits else contextlib.nullcontext()
+
+    one(model, X, Y)                                             # warm-up 1: first touch of every buffer (several times a steady step)
+    t_begin = time.perf_counter()
+    ncpu = os.cpu_count() or 1
+    probes = {}
+    for n in sorted({min(c, ncpu) for c in (8, 32, 64, ncpu)}):    # one probing step per thread count: warm-ups 2...
+        with limited(n):
+            probes[n] = one(model, X, Y)
+        if time.perf_counter() - t_begin > 0.4 * budget_s:
+            break
+    best = min(probes, key=probes.get)
+    times = []
+    with limited(best):
+        one(model, X, Y)
+        while len(times) < 5 or (len(times) < 9 and time.perf_counter() - t_begin < 0.5 * budget_s):
+            times.append(one(model, X, Y))
+            if time.perf_counter() - t_begin > 0.8 * budget_s and len(times) >= 5:
+                break
     med = float(np.median(times))
-    return {"value": 1.0 / med, "unit": "ELBO steps/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d full forward ELBO steps of the same workload (batch %d, S=%d) with the float64 NumPy/OpenBLAS "
-                      "oracle in the reference's operation order; median %.2f s/step; not TensorFlow" % (len(times), batch, S, med)}
+    q = max(batch // 4, 1)
+    m1 = oracle_model(spec, X[:q], Y[:q])
+    with limited(1):
+        t1 = [one(m1, X[:q], Y[:q]) for _ in range(2)][-1] if threadpool_limits else None
+    out = {"value": 1.0 / med, "unit": "ELBO steps/s", "cores": best, "kind": "port",
+           "threads": best, "host_cores": ncpu, "steps_timed": len(times), "warmup_steps": len(probes) + 2,
+           "thread_probe_s_per_step": {str(k): round(v, 3) for k, v in probes.items()},
+           "sample": "%d full forward ELBO steps of the same workload (batch %d, S=%d) with the float64 NumPy/OpenBLAS oracle in the "
+                     "reference's operation order (materialised K_uf, per-patch triangular solves, dense tensordot), %d BLAS threads "
+                     "(best of %s on %d host cores), after %d warm-up steps; median %.2f s/step; not TensorFlow"
+                     % (len(times), batch, S, best, sorted(probes), ncpu, len(probes) + 2, med)}
+    if t1:
+        out["value_1thread"] = 1.0 / (t1 * batch / q)
+        out["sample_1thread"] = ("1 BLAS thread, second of 2 steps on a quarter of the batch (%d images): %.2f s, scaled by %d (the step is "
+                                 "linear in the batch)" % (q, t1, batch // q))
+    return out
 
 
 class Leg:
@@ -136,29 +180,62 @@ class Leg:
         return float(self.grp.allreduce([dt], "max")[0]), v
 
 
-def shard_sweep(leg, steps, warmup):
+def shard_sweep(leg, steps, warmup, depths=(1, 2)):
     """Strong-scaling preview on ONE GPU: the step on the shard a rank would hold at G = 1, 2, 4, 8 (same parameters, same
-    num_data / global-batch scale).  t(b) = replicated + b * per_image fitted through the end points gives the Amdahl
-    fraction of the step that does not shrink with the shard (factorisation chain, KL, launch + host latency)."""
-    out = {}
+    num_data / global-batch scale), synchronous (`depth` 1) and with two steps in flight (`depth` 2: the parameter-only chain of
+    step i + 1 runs under the data path of step i, so the replicated prefix leaves the critical path).  t(b) = replicated + b *
+    per_image fitted through the end points gives the Amdahl fraction of the step that does not shrink with the shard
+    (factorisation chain, KL, launch + host latency).  The all-reduce of one double is not in these numbers."""
+    res = {}
     B = leg.local_batch
-    for G in (1, 2, 4, 8):
-        b = max(1, -(-B // G))
-        dX, dY = leg.ctx.to_device(leg.Xh[:b]), leg.ctx.to_device(leg.Yh[:b], np.int32)
-        for i in range(60):   # the uploads above left the device idle: past the clock ramp first
-            leg.model.compute_log_likelihood(dX, dY, seed=i, scale=leg.scale)
-        leg.ctx.sync()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            leg.model.compute_log_likelihood(dX, dY, seed=warmup + i, scale=leg.scale)
-        leg.ctx.sync()
-        out[G] = (b, 1e3 * (time.perf_counter() - t0) / steps)
-    (b1, t1), (b8, t8) = out[1], out[8]
-    per_image = (t1 - t8) / max(b1 - b8, 1)
-    replicated = t1 - per_image * b1
-    return {"per_rank_batch_ms": {str(G): {"images": b, "ms_per_step": round(t, 4)} for G, (b, t) in out.items()},
-            "replicated_ms": replicated, "replicated_fraction": replicated / t1,
+    for depth in depths:
+        out = {}
+        for G in (1, 2, 4, 8):
+            b = max(1, -(-B // G))
+            dX, dY = leg.ctx.to_device(leg.Xh[:b]), leg.ctx.to_device(leg.Yh[:b], np.int32)
+
+            def run(first, n):
+                tickets = []
+                for i in range(n):
+                    if depth == 1:
+                        leg.model.compute_log_likelihood(dX, dY, seed=first + i, scale=leg.scale)
+                    else:
+                        tickets.append(leg.model.enqueue_log_likelihood(dX, dY, seed=first + i, scale=leg.scale))
+                        if len(tickets) >= depth:
+                            leg.model.collect_log_likelihood(tickets.pop(0))
+                while tickets:
+                    leg.model.collect_log_likelihood(tickets.pop(0))
+            run(0, 60 if steps >= 60 else max(steps, 10))   # the uploads above left the device idle: past the clock ramp first
+            leg.ctx.sync()
+            t0 = time.perf_counter()
+            run(warmup, steps)
+            leg.ctx.sync()
+            out[G] = (b, 1e3 * (time.perf_counter() - t0) / steps)
+        (b1, t1), (b8, t8) = out[1], out[8]
+        per_image = (t1 - t8) / max(b1 - b8, 1)
+        replicated = t1 - per_image * b1
+        res["synchronous" if depth == 1 else "two_in_flight"] = {
+            "per_rank_batch_ms": {str(G): {"images": b, "ms_per_step": round(t, 4)} for G, (b, t) in out.items()},
+            "replicated_ms": round(replicated, 4), "replicated_fraction": round(replicated / t1, 4),
             "predicted_strong_speedup_excluding_allreduce": {str(G): round(t1 / t, 3) for G, (b, t) in out.items()}}
+    return res
+
+
+def shard_sweep_all(ctx, grp, S, skip, steps=30):
+    """The same preview for every other BASELINE configuration (BASELINE.json assigns cfg3 / cfg4 / cfg5 to 8 GPUs)."""
+    out = {}
+    for name in syn.CONFIGS:
+        if name == skip:
+            continue
+        cfg = syn.CONFIGS[name]
+        try:
+            lg = Leg(ctx, grp, "none", name, S, cfg["batch"], 0, cfg["batch"], False)
+            n = steps if cfg["M"] < 1024 or not cfg["convs"] else max(steps // 3, 8)
+            out[name] = shard_sweep(lg, n, 5)
+            lg.model.close()
+        except Exception as e:                # noqa: BLE001 -- informational
+            out[name] = {"skipped": repr(e)}
+    return out
 
 
 def kuf_measure(leg, ctx, steps):
@@ -189,6 +266,21 @@ def kuf_measure(leg, ctx, steps):
                 if t[0]:
                     res[key] = 1e3 * t[1] / t[0]
                     res["sweep_launches_sampled"] = t[0]
+        # every row evaluated (option kuf_no_rep): what the sweep costs when the rows do NOT repeat images -- layer 0 of this model sees
+        # the batch tiled S times (DGP_Base.propagate), and by default a unit evaluates a tile once and stores it to every row showing
+        # that image; the bytes written are the same
+        with ctx.options(no_early_sweep=1, kuf_no_rep=1):
+            for i in range(10):
+                leg.step(i)
+            ctx.timing_enable(3)
+            ctx.timing_reset()
+            for i in range(n):
+                leg.step(100 + i)
+            leg.barrier()
+            t = ctx.timing().get("kuf", (0, 0.0))
+            ctx.timing_enable(0)
+            if t[0]:
+                res["sweep_us_every_row_evaluated"] = 1e3 * t[1] / t[0]
     for i in range(3):
         leg.step(i)
     # phase stamps of the one-launch layer kernel (csrc/conv_fused.hip CF_TR): [8 sampled workgroups][16 waves][16 stamps]
@@ -258,7 +350,7 @@ def head_only_leg(ctx, grp, S, steps):
     ach = flops / (us * 1e-6) / 1e12
     out = {"head_only_steps_per_s": steps / dt, "head_only_ms_per_step": 1e3 * dt / steps,
            "roofline_head": {"kernel": HEAD_KERNEL, "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("head_sweep", "cfg2_mnist_H_M256"),
+                             "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("head_sweep", "cfg2_mnist_H_M256"), "traffic_source": PMC_SOURCE,
                              "algorithmic_flops_per_launch": flops, "avg_us": us, "launches_sampled": tim_alone["head_sweep"][0],
                              "avg_us_in_step_beside_the_chain": us_in_step,
                              "note": HEAD_NOTE + ".  avg_us: the launch alone on the chip (ctx option head_no_overlap: chain first, then the sweep); the "
@@ -282,6 +374,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grad-leg", action="store_true", help="skip the informational value-and-gradient timing")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the head-only and shard-sweep legs")
+    ap.add_argument("--no-all-configs", action="store_true", help="skip the strong-scaling preview of the other BASELINE configurations")
     ap.add_argument("--profile", action="store_true",
                     help="for rocprofv3 runs: exactly --warmup + --steps steps, none of the extra regions, no CPU baseline")
     ap.add_argument("--comm", type=str, default="rccl", choices=["rccl", "host"],
@@ -445,12 +538,25 @@ def main():
         if "sweep_us" in kuf_raw:
             gbs = bytes_kuf / (kuf_raw["sweep_us"] * 1e-6) / 1e9
             o["kuf_hbm_gbs"] = gbs
-            o["roofline_kuf"] = {"kernel": "head_units_kernel<.., WRITE> (K_uf sweep of layer 0, materialised [M, N'P] in HBM: the sweep + GEMM route, "
+            store_ceiling = informational("store-ceiling", lambda: ctx.measured_store_gbs(rows0, P, M))
+            every = kuf_raw.get("sweep_us_every_row_evaluated")
+            o["roofline_kuf"] = {"kernel": "head_units_kernel<.., storing form> (K_uf sweep of layer 0, materialised [M, N'P] in HBM: the sweep + GEMM route, "
                                            "ctx option no_fused_layer, timed in situ on the bench workload, the launch alone on the chip)",
                                  "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                 "traffic": pmc_traffic("kuf", args.config), "algorithmic_bytes_per_launch": bytes_kuf,
+                                 "traffic": pmc_traffic("kuf", args.config), "traffic_source": PMC_SOURCE,
+                                 "algorithmic_bytes_per_launch": bytes_kuf,
                                  "avg_us": kuf_raw["sweep_us"], "avg_us_in_step_beside_the_chain": kuf_raw.get("sweep_us_beside_the_chain"),
-                                 "launches_sampled": kuf_raw.get("sweep_launches_sampled")}
+                                 "launches_sampled": kuf_raw.get("sweep_launches_sampled"),
+                                 "measured_store_ceiling_gbs": store_ceiling,
+                                 "frac_of_measured_store_ceiling": (gbs / store_ceiling) if store_ceiling else None,
+                                 "rows_sharing_an_image_evaluated_once": True,
+                                 "every_row_evaluated": None if not every else {"avg_us": every, "achieved": bytes_kuf / (every * 1e-6) / 1e9,
+                                                                                  "frac": bytes_kuf / (every * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                                 "note": "every byte of K_uf [M, S*N*P] is written each launch (true bytes = algorithmic bytes).  Layer 0 sees the batch "
+                                         "tiled S times (DGP_Base.propagate), so S rows show each image: a unit evaluates a tile once and stores it to "
+                                         "those S rows; `every_row_evaluated` is the same launch with that switched off (ctx option kuf_no_rep).  "
+                                         "measured_store_ceiling_gbs: a pure store kernel writing the same matrix in the same tile pattern, timed in "
+                                         "this run (csrc/peaks.hip)"}
         if fused and "fused_phase_us_per_strip" in kuf_raw:
             strips = -(-(rows0 * P) // 64)
             rounds = -(-strips // 256)
@@ -467,8 +573,14 @@ def main():
 
     if world == 1 and not args.no_extra_legs:
         extra.update(informational("shard-sweep", lambda: {"strong_scaling_preview": shard_sweep(leg, min(args.steps, 100), args.warmup)}) or {})
+        if not args.no_all_configs:
+            extra.update(informational("shard-sweep-all", lambda: {"strong_scaling_preview_other_configs": shard_sweep_all(ctx, grp, S, args.config)}) or {})
         if args.config.startswith("cfg2"):
             extra.update(informational("head-only", lambda: head_only_leg(ctx, grp, S, min(args.steps, 100))) or {})
+
+    # the fp64 MFMA rate this device sustains right now (csrc/peaks.hip: 4 waves per SIMD of back-to-back v_mfma_f64_16x16x4_f64, ~85 ms),
+    # measured behind everything that is timed -- the ceiling the roofline fractions can also be read against
+    mfma_ceiling = None if args.profile else informational("mfma-ceiling", ctx.measured_mfma_f64_tflops)
 
     if rank == 0:
         value = args.steps / dt
@@ -532,8 +644,9 @@ def main():
                                          ("gemm_tn_kernel<128,128,4,4> (stage 3: T_r = G_r^T A1, fused sum of squares; %d conv-layer launch(es)/step)" % n_conv),
                                "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": (ach / FP64_MFMA_PEAK_TFLOPS) if ach else None,
-                               "traffic": pmc_traffic("conv_fused" if fused else "gemm_cond_s3", args.config),
-                               "measured_mfma_f64_ceiling_tflops": 76.5,
+                               "traffic": pmc_traffic("conv_fused" if fused else "gemm_cond_s3", args.config), "traffic_source": PMC_SOURCE,
+                               "measured_mfma_f64_ceiling_tflops": mfma_ceiling,
+                               "frac_of_measured_ceiling": (ach / mfma_ceiling) if (ach and mfma_ceiling) else None,
                                "algorithmic_flops_per_step": flops_dom, "ms_per_step_in_kernel": per_step_ms,
                                "launches_sampled": t_dom[0], "sampling": "HIP events on the launch stream around every launch of the kernel, in a loop of %d steps behind the timed region" % n_roof,
                                "stage3_only_flops_per_step": flops_s3,
@@ -550,7 +663,7 @@ def main():
             us_h = 1e3 * t_h[1] / t_h[0]
             ach_h = flops_h / (us_h * 1e-6) / 1e12
             out["roofline"] = {"kernel": HEAD_KERNEL, "bound": "mfma", "achieved": ach_h, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach_h / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("head_sweep", args.config),
+                               "frac": ach_h / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("head_sweep", args.config), "traffic_source": PMC_SOURCE,
                                "algorithmic_flops_per_step": flops_h, "ms_per_step_in_kernel": us_h * 1e-3, "launches_sampled": t_h[0], "note": HEAD_NOTE}
         if not args.no_cpu_baseline and not args.profile and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, S, cfg["batch"])

@@ -103,6 +103,8 @@ _SIGS = {
                           _i, _i, _i, _i, _d, _i, _vp, C.c_long, C.c_long, _vp, C.c_long, C.c_long, _i],
     "dcgp_kmeans": [_vp, _vp, C.c_long, _i, _i, _vp, _i, _d, _vp, _ip],
     "dcgp_debug_set_fused_trace": [_vp, _vp],
+    "dcgp_debug_mfma_f64_rate": [_vp, _dp],
+    "dcgp_debug_store_rate": [_vp, _i, _i, _i, _dp],
     "dcgp_debug_set_sweep_trace": [_vp, _vp, C.c_long, C.c_char_p],
     "dcgp_comm_unique_id": [C.c_char_p],
     "dcgp_comm_init_rank": [_vp, _i, _i, C.c_char_p],
@@ -227,6 +229,18 @@ class Context:
         b, n = _sz(0), C.c_int(0)
         self._check(lib().dcgp_workspace_query(self.handle, C.byref(b), C.byref(n)))
         return b.value, n.value
+
+    def measured_mfma_f64_tflops(self):
+        """Sustained v_mfma_f64_16x16x4_f64 rate of this device right now (csrc/peaks.hip; ~85 ms)."""
+        v = C.c_double(0.0)
+        self._check(lib().dcgp_debug_mfma_f64_rate(self.handle, C.byref(v)))
+        return v.value
+
+    def measured_store_gbs(self, N, P, M):
+        """GB/s of a pure store sweep over an [M x N*P] matrix in the K_uf sweep's tile pattern (csrc/peaks.hip)."""
+        v = C.c_double(0.0)
+        self._check(lib().dcgp_debug_store_rate(self.handle, int(N), int(P), int(M), C.byref(v)))
+        return v.value
 
     # A/B switches ------------------------------------------------------------------------------
     def set_option(self, name, value):

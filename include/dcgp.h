@@ -303,6 +303,10 @@ int dcgp_allreduce_sum_f64(dcgp_ctx* ctx, double* buf_dev, int n);
 int dcgp_debug_set_fused_trace(dcgp_ctx* ctx, long long* buf_dev);
 /* The same for the patch sweeps (csrc/head_units.hip; tools/sweep_trace.py): [n_workgroups][waves per workgroup][8] int64 -- wall clock at entry,
  * shader clock at entry / image staged / set-up done / first unit done / last unit done, wall clock at exit, units run.            */
+/* The ceilings bench.py prices kernels against, measured on this device (csrc/peaks.hip): the sustained fp64 MFMA rate (TFLOP/s, 4 waves
+ * per SIMD, ~85 ms) and the rate of a pure store sweep writing an [M x N*P] matrix in the K_uf sweep's tile pattern (GB/s).            */
+int dcgp_debug_mfma_f64_rate(dcgp_ctx* ctx, double* tflops_out);
+int dcgp_debug_store_rate(dcgp_ctx* ctx, int N, int P, int M, double* gbs_out);
 int dcgp_debug_set_sweep_trace(dcgp_ctx* ctx, long long* buf_dev, long n_workgroups, const char* family /* "kuf", "kuf_long", "head_sweep"; NULL: any */);
 
 #ifdef __cplusplus

@@ -378,6 +378,74 @@ def test_conv_layer_identity_mean(ctx):
     np.testing.assert_array_equal(v0, v1)
 
 
+def test_mean_function_objects(ctx):
+    """conv_gp/mean_functions.py:6-41 as objects (constructed at conv_gp/models.py:29-33,95-99): Conv2dMean(...) handed to ConvLayer gives
+    what the 'conv2d' alias and the oracle's Conv2dMean give (the layer launch adds the centre pixel itself); a Conv2dMean with a changed
+    filter, an IdentityConv2dMean and a plain callable go through __call__ (device convolution: dcgp_extract_patches + dcgp_gemm_strided)
+    and are added to mean and sample; the model-level path refuses what it cannot fuse."""
+    from deepcgp_amd.kernels import RBF, PatchInducingFeatures
+    from deepcgp_amd.layers import ConvLayer
+    from deepcgp_amd.mean_functions import Conv2dMean, IdentityConv2dMean, Zero
+    from deepcgp_amd.views import FullView
+    from oracle.mean_functions import Conv2dMean as OConv2dMean
+    rng = np.random.default_rng(33)
+    H, W, C, f, s, M, R, N = 9, 8, 3, 3, 2, 6, 4, 3
+    v = FullView((H, W), f, C, s)
+    X = rng.standard_normal((N, H * W * C))
+    X4 = X.reshape(N, H, W, C)
+    Z, q_mu, q_sqrt = rand_spd_inputs(rng, M, R, v.patch_length, 0.2)
+    mk = lambda mf: ConvLayer(RBF(v.patch_length, 5.0, 5.0), mf, PatchInducingFeatures(Z), v, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)   # noqa: E731
+    m0, v0 = mk(None).conditional_ND(X)
+    # the reference's own object == the alias == the oracle
+    cm = Conv2dMean(f, C, R, stride=s)
+    cm.set_trainable(False)
+    m_obj, v_obj = mk(cm).conditional_ND(X)
+    m_str, _ = mk('conv2d').conditional_ND(X)
+    np.testing.assert_array_equal(m_obj, m_str)
+    np.testing.assert_array_equal(v_obj, v0)
+    close(m_obj, m0 + OConv2dMean(f, C, R, s)(X4), 1e-12, "Conv2dMean object vs oracle")
+    close(cm(X4), OConv2dMean(f, C, R, s)(X4), 1e-13, "Conv2dMean.__call__ on the device")
+    np.testing.assert_array_equal(mk(Zero()).conditional_ND(X)[0], m0)
+    # the device convolution against a NumPy VALID convolution with an arbitrary filter
+    idm = IdentityConv2dMean(f, C, R, stride=s)
+    idm.conv_filter = rng.standard_normal(idm.conv_filter.shape)
+    Ho, Wo = v.out_image_height, v.out_image_width
+    want = np.zeros((N, Ho, Wo, R))
+    for oy in range(Ho):
+        for ox in range(Wo):
+            want[:, oy, ox, :] = np.einsum("nabc,abcr->nr", X4[:, oy * s:oy * s + f, ox * s:ox * s + f, :], idm.conv_filter)
+    close(idm(X4), want, 1e-12, "IdentityConv2dMean conv")
+    # initial filter: the sum over the input channels of the centre pixel, in every output map (what models.identity_conv propagates)
+    c0 = f // 2
+    centre = X4[:, c0:c0 + (Ho - 1) * s + 1:s, c0:c0 + (Wo - 1) * s + 1:s, :].sum(-1)
+    close(IdentityConv2dMean(f, C, R, stride=s)(X4), np.repeat(centre[..., None], R, -1), 1e-13, "identity filter")
+    # anything the launch cannot add itself goes through __call__: mean and sample both move by it
+    z = rng.standard_normal((N, v.patch_count * R))
+    s0, _, _ = mk(None)._forward(X, z)
+    s1, m1, v1 = mk(idm)._forward(X, z)
+    close(m1, m0 + want.reshape(N, -1), 1e-12, "generic mean added")
+    close(s1, s0 + want.reshape(N, -1), 1e-12, "generic mean added to the sample")
+    np.testing.assert_array_equal(v1, v0)
+    moved = Conv2dMean(f, C, R, stride=s)
+    moved.conv_filter = moved.conv_filter * 2.0
+    close(mk(moved).conditional_ND(X)[0], m0 + 2.0 * OConv2dMean(f, C, R, s)(X4), 1e-12, "Conv2dMean with a changed filter")
+    close(mk(lambda img: np.full((img.shape[0], v.patch_count * R), 0.25)).conditional_ND(X)[0], m0 + 0.25, 1e-13, "plain callable")
+    # the one-call model path takes the fused form only
+    from deepcgp_amd.dgp import DGP_Base
+    from deepcgp_amd.kernels import ConvKernel
+    from deepcgp_amd.layers import SVGP_Layer
+    from deepcgp_amd.likelihoods import MultiClass
+    hv = FullView((Ho, Wo, R), 2, R, 1)
+    head = SVGP_Layer(kern=ConvKernel(RBF(hv.patch_length, 1.0, 1.0), hv), num_outputs=10, feature=PatchInducingFeatures(rng.standard_normal((5, hv.patch_length))))
+    Y = rng.integers(0, 10, N)
+    good = DGP_Base(X, Y, likelihood=MultiClass(10), layers=[mk(cm), head], num_samples=2, minibatch_size=None, num_data=N, name="DGP")
+    assert np.isfinite(good.compute_log_likelihood(X, Y, seed=1))
+    good.close()
+    bad = DGP_Base(X, Y, likelihood=MultiClass(10), layers=[mk(idm), head], num_samples=2, minibatch_size=None, num_data=N, name="DGP")
+    with pytest.raises(ValueError):
+        bad.compute_log_likelihood(X, Y, seed=1)
+
+
 @pytest.mark.parametrize("H,W,C,f,s,M", [(8, 8, 1, 3, 1, 4), (12, 12, 10, 5, 1, 8), (28, 28, 1, 5, 1, 32), (9, 9, 10, 5, 1, 20),
                                           (11, 11, 10, 5, 1, 70),
                                           (40, 40, 4, 5, 3, 8)])   # an image past the unit sweep's LDS budget: the one-image-per-workgroup sweeps of rbf.hip take over
