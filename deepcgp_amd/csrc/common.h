@@ -52,6 +52,8 @@ struct DcgpOptions {
   long kuf_wpg = 0;              // storing sweep: waves per workgroup (0: chosen by head_units_plan; 1, 2, 4)
   long kuf_stream = 0;           // storing sweep: the streamed-operand kernel also for the patch lengths with a register-resident one
   long kuf_no_rep = 0;           // storing sweep: evaluate every row, also where rows show the same image (tiled batch)
+  long share_kb = 0;             // patch sweeps beside the factorisation chain: LDS claimed per workgroup in KB (0: default)
+  long sweep_occ = -1;           // patch sweeps: waves per SIMD a launch is held to so that its rounds come out whole (-1: chosen; 0: off)
   long head_tail = -1;           // head_units: balance of the launch tail (-1: default; see head_units_plan)
   long graph = -1;               // synchronous forward step replayed from a captured HIP graph (-1: default)
   long fused_abl = 0, rb_mixed = 0;   // timing builds only (make EXPERIMENTS=1)
@@ -286,7 +288,7 @@ int head_kdiag(dcgp_ctx* ctx, const double* X, int N, int n_mod, int H, int W, i
 // workgroups per image.  kind 0: Kzx row units (one per 16-row fragment of Z); 1: Kdiag chunks of T tiles of the image's patch Gram
 // matrix (C chunks per image); 2: the storing form's row units.  Long units go first, the Kdiag chunks shrink towards the end of the
 // launch so that its tail is a short unit, not a long one (head_units_plan).
-struct HuSeg { int wg0 = 0, img0 = 0, wpi = 1, kind = 0, T = 0, C = 0; };
+struct HuSeg { int wg0 = 0, img0 = 0, wpi = 1, kind = 0, T = 0, C = 0, upw = 1; };   // upw: units a wave runs behind one set-up
 struct HeadUnitsArgs {
   const double* X = nullptr; int n_mod = 0, N = 0, n0 = 0; // image of row n is X[(n0 + n) % n_mod] (n0: first image of a chunk; outputs are indexed by the local n)
   int H = 0, W = 0, C = 0, f = 0, s = 0, Wo = 0, P = 0, L = 0, Lq = 0, HWC = 0;
@@ -305,6 +307,9 @@ struct HeadUnitsArgs {
   long long* trace = nullptr; long trace_wgs = 0;          // debugging aid (tools/sweep_trace.py): [workgroup][wave][8] stamps, first trace_wgs workgroups
   const char* timer = nullptr;                             // timer family of the launch (nullptr: "kuf" / "head_sweep")
   int want_kd = 0;                                         // Kdiag partial sums wanted: head_units_plan sizes n_kd, the caller then allocates kd [N][n_kd]
+  int share_kb = 0;                                        // A/B: LDS claimed per workgroup beside the factorisation chain, KB (0: 54 = two workgroups per CU)
+  int occ_force = -1;                                      // A/B: waves per SIMD the launch is held to through its LDS claim (-1: chosen; 0: no shaping)
+  int occ = 0;                                             // chosen by head_units_plan (0: none)
   int tail_mode = -1;                                      // balance of the launch's tail (-1: default levels; 0: equal Kdiag chunks throughout)
   int nfm = 0, nfp = 0, n_kd = 0, upw = 1, wpg = 4;        // set by head_units_plan (call it with kzx / want_kd / kuf already set)
   int nseg = 0; HuSeg seg[6]; long n_wgs = 0;              // the launch's segments and its workgroup count (head_units_plan)

@@ -19,6 +19,7 @@
 // image load and one pass of patch norms; waves never synchronise after that.  ~11 000 units at the headline size, so
 // the tail of the launch is one unit (~10 us) whatever the image count is relative to 256 CUs.
 #include "common.h"
+#include <cmath>
 #include <type_traits>
 
 namespace {
@@ -171,7 +172,8 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : (WMODE == 1 ? 3 : HU_WAVES)) v
   // always fall on the same SIMDs
   // (a workgroup covers WPG * upw consecutive units, wave w the units w, w + WPG, ...: one set-up for upw units per wave)
   stamp(3);
-  int u = WPG * a.upw * bw + ((wave + n) & (WPG - 1));
+  const int seg_upw = a.seg[sg].upw;
+  int u = WPG * seg_upw * bw + ((wave + n) & (WPG - 1));
   const int n_units = seg_kind == 1 ? seg_C : (WRITE ? a.nfm * a.st_split : a.nfm);
   if (u >= n_units) {
     if (tr && lane == 0) tr[6] = (long long)wall_clock64();
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : (WMODE == 1 ? 3 : HU_WAVES)) v
     }
   };
 
-  for (int uu = 0; uu < a.upw && u < n_units; ++uu, u += WPG) {
+  for (int uu = 0; uu < seg_upw && u < n_units; ++uu, u += WPG) {
   if (seg_kind != 1) {
     // ---- Kzx rows 16 u .. 16 u + 15: out[m][n] = scale * sum_p w_p k(z_m, x_p) ----
     ur = WRITE ? u / a.st_split : u;
@@ -548,11 +550,35 @@ void head_units_plan(HeadUnitsArgs* a) {
   // waves per workgroup: 4 where the patch fits registers (one set-up for four long units); 2 for long patches on small views
   // (a 12 x 12 x 10 head input: units of 252 MFMAs, short beside the set-up they sit behind)
   a->wpg = (a->L == 25 || a->kuf || a->nfp > 8) ? 4 : 2;
-  auto push = [&](int kind, int n_img, int wpi, int T, int C) {
+  auto push = [&](int kind, int n_img, int wpi, int T, int C, int upw = 1) {
     if (n_img <= 0 || a->nseg >= 6) return;
     HuSeg& g = a->seg[a->nseg++];
-    g.wg0 = (int)a->n_wgs; g.img0 = 0; g.wpi = wpi; g.kind = kind; g.T = T; g.C = C;
+    g.wg0 = (int)a->n_wgs; g.img0 = 0; g.wpi = wpi; g.kind = kind; g.T = T; g.C = C; g.upw = upw;
     a->n_wgs += (long)n_img * wpi;
+  };
+  // Occupancy shaping.  Workgroups are handed out as slots free up, so a launch of r = waves / resident slots rounds costs ceil(r)
+  // rounds' worth of time when r is small: 6016 equal units on 4096 slots (4 waves per SIMD) are a full round and then a round at 47 %
+  // occupancy that lasts almost as long (tools/sweep_trace.py: 74 us for 41 us of MFMA work).  Held to 3 waves per SIMD -- by claiming
+  // enough LDS that only so many workgroups fit a CU -- the same launch is 1.96 rounds, both full.  `cap`: what the kernel's register
+  // budget allows; the pipe reaches ~92 / 96 / 98 % of its rate from 2 / 3 / 4 waves per SIMD.
+  auto shape_occupancy = [&](int cap) {
+    // MEASURED AND LEFT OFF (tools/head_ab.sh): every shape got slower held to fewer waves -- 79 -> 101 us at the 12 x 12 x 10 head, 110 ->
+    // 134 us at the CIFAR head, 163 -> 176 us at the MNIST head.  A wave of these sweeps is bound by its own latencies (LDS gathers, the
+    // A operand from L2), not by the pipe, so a SIMD with three waves does less than one with four whatever the round count says.
+    a->occ = 0;
+    if (a->occ_force <= 0) return;
+    if (a->occ_force > 0) { a->occ = a->occ_force < cap ? a->occ_force : 0; return; }
+    const double waves = (double)a->n_wgs * a->wpg;
+    if (waves < 2048.0 || waves / (1024.0 * cap) >= 6.0) return;
+    static const double eff[5] = {0.0, 0.75, 0.92, 0.96, 0.98};
+    double best = 0.0;
+    int best_s = cap;
+    for (int s = cap; s >= 2; --s) {
+      const double r = waves / (1024.0 * s);
+      const double e = r / ceil(r) * eff[s];
+      if (e > best + 0.02) { best = e; best_s = s; }
+    }
+    if (best_s < cap) a->occ = best_s;
   };
   if (a->kuf) {
     // ---- the storing form: row units only ----
@@ -585,7 +611,8 @@ void head_units_plan(HeadUnitsArgs* a) {
         const long nwg = (long)a->n_base * ((nuw + a->wpg * k - 1) / (a->wpg * k));
         if (a->nfp <= 16 && nwg >= 512 && nuw % (a->wpg * k) == 0) { a->upw = k; break; }
       }
-    push(2, a->n_base, (nuw + a->wpg * a->upw - 1) / (a->wpg * a->upw), 0, 0);
+    push(2, a->n_base, (nuw + a->wpg * a->upw - 1) / (a->wpg * a->upw), 0, 0, a->upw);
+    shape_occupancy(a->st_hold ? 2 : 3);
     return;
   }
   // ---- the reducing form: the Kzx row units of every image first, then the Kdiag chunks, shrinking towards the end of the launch ----
@@ -595,7 +622,18 @@ void head_units_plan(HeadUnitsArgs* a) {
   // slots free up, so the order of the list is the schedule: long units first, and the last stretch made of chunks of 1/2, 1/4, 1/8 the
   // size -- each level about half a round of the resident slots -- ends within one short chunk.
   const int W = a->wpg;
-  if (a->kzx) push(0, a->N, (a->nfm + W - 1) / W, 0, 0);
+  // row units of a few dozen MFMAs (a 5 x 5 view of long patches: two column fragments) are shorter than the set-up they sit behind:
+  // two to four per wave
+  int kz_upw = 1;
+  {
+    const int unit_mfma = a->nfp * (a->Lq / 4);
+    if (unit_mfma < 200) {
+      kz_upw = (250 + unit_mfma - 1) / unit_mfma;
+      if (kz_upw > 4) kz_upw = 4;
+      while (kz_upw > 1 && a->nfm % (W * kz_upw)) --kz_upw;
+    }
+  }
+  if (a->kzx) push(0, a->N, (a->nfm + W * kz_upw - 1) / (W * kz_upw), 0, 0, kz_upw);
   if (a->want_kd || a->kd) {
     const int ntot = a->nfp * (a->nfp + 1) / 2;
     // coarse chunks: about one Kzx-sized unit (nfp + 1 tiles) each, their count a multiple of the workgroup's waves where that is possible
@@ -632,6 +670,7 @@ void head_units_plan(HeadUnitsArgs* a) {
       if (lvC[lv] > a->n_kd) a->n_kd = lvC[lv];
     }
   }
+  shape_occupancy(4);
 }
 
 extern "C" int dcgp_debug_set_sweep_trace(dcgp_ctx* ctx, long long* buf_dev, long n_workgroups, const char* family) {
@@ -656,9 +695,18 @@ int head_units(dcgp_ctx* ctx, const HeadUnitsArgs& a_in) {
   size_t lds = head_units_lds(a);
   // Beside the factorisation chain (a head-first model: the sweep needs Z only): a chain workgroup is one wave of 250 VGPRs per SIMD
   // and 50 KB of LDS, and would never find that much free at once on a CU this launch keeps refilling with four 128-register
-  // workgroups.  Claiming 54 KB per workgroup holds the sweep to two per CU (half the register file stays free; 2 waves per SIMD
-  // cost it ~3 %) -- the chain's workgroups then start the moment they are launched.
-  if (a.share_cu && lds < 54 * 1024) lds = 54 * 1024;
+  // workgroups.  Claiming 53 KB per workgroup holds the sweep to THREE per CU: whenever one of them ends -- somewhere on the chip
+  // every ~0.1 us -- that CU has 53 KB and half of every SIMD's registers free, and the chain's high-priority stream takes the slot
+  // before the sweep's backlog does.  (Round 3 claimed 54 KB = two per CU, so that every CU always had room: the sweep ran at two waves
+  // per SIMD, 184 us instead of 171, and the chain no faster -- 157 against 134 us; head-only model 4100 -> 4300 steps/s.  52 KB and
+  // below measured worse again, and with no claim at all the chain starves: 213 us.  ctx option share_kb.)
+  const size_t share_claim = (size_t)(a.share_kb > 0 ? a.share_kb : 53) * 1024;
+  if (a.share_cu && lds < share_claim) lds = share_claim;
+  if (a.occ > 0) {   // occupancy shaping (head_units_plan): exactly 4 occ / wpg workgroups per CU
+    const int per_cu = 4 * a.occ / a.wpg;
+    const size_t claim = (size_t)(160 * 1024 / per_cu) & ~(size_t)255;
+    if (claim <= 64 * 1024 && lds < claim) lds = claim;
+  }
   ScopedTimer t(ctx, family);
   if (a.kuf) {
     // patch lengths of the first layers (5 x 5 x 1, 4 x 4 x 1, 4 x 4 x 3: MNIST / CIFAR conv0) with the row operand resident in registers

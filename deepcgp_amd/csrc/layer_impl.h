@@ -291,6 +291,8 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
         h.stream_k = (int)ctx->opt.kuf_stream;
         h.wpg_force = (int)ctx->opt.kuf_wpg;
         h.split_force = (int)ctx->opt.kuf_split;
+        h.occ_force = (int)ctx->opt.sweep_occ;
+        h.share_kb = (int)ctx->opt.share_kb;
         h.no_rep = (int)ctx->opt.kuf_no_rep;   // A/B switch: every row evaluated even where rows share an image
         h.timer = L.v.L > 64 ? "kuf_long" : "kuf";   // long patches (deeper layers, L = 250) are MFMA-bound, short ones HBM-bound: two families
         head_units_plan(&h);
@@ -350,6 +352,8 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     h.share_cu = factor_done != nullptr;   // first layer of the model with the chain on another stream: the chain runs beside this launch
     h.want_kd = 1;
     h.tail_mode = (int)ctx->opt.head_tail;
+    h.occ_force = (int)ctx->opt.sweep_occ;
+    h.share_kb = (int)ctx->opt.share_kb;
     head_units_plan(&h);
     if (head_units_ok(h)) {
       h.kd = (double*)ws_get(ctx, "kdiag_partial", (size_t)rows * h.n_kd * sizeof(double));   // [rows][n_kd] partial sums (head_units_plan)

@@ -323,6 +323,7 @@ static bool convkernel_units(dcgp_ctx* ctx, const double* X, int N, const ViewGe
   *rc = DCGP_OK;
   h.want_kd = out_N != nullptr;
   h.tail_mode = (int)ctx->opt.head_tail;
+  h.occ_force = (int)ctx->opt.sweep_occ;
   head_units_plan(&h);
   if (!head_units_ok(h)) return false;
   if (out_N) {
