@@ -357,6 +357,32 @@ def test_fused_conv_layer_matches_the_unfused_route_and_the_oracle(ctx, white, H
         close(var, ovar, 1e-9, "var vs oracle")
 
 
+@pytest.mark.parametrize("shape", range(8))
+@pytest.mark.parametrize("M,N", [(70, 3), (256, 2)])
+def test_every_fused_strip_shape(ctx, shape, M, N):
+    """Each instantiated strip shape of the one-launch layer kernel (csrc/conv_fused.hip kShapes: strip width x waves x teams), forced
+    through the ctx option fused_shape, against the sweep + GEMM route on the same inputs -- the launcher's own choice only ever
+    exercises the shapes its cost model picks (shape 7, the 16-wave 32-column strip, is picked for a rank's shard of few columns)."""
+    from deepcgp_amd.kernels import RBF, PatchInducingFeatures
+    from deepcgp_amd.layers import ConvLayer
+    from deepcgp_amd.views import FullView
+    rng = np.random.default_rng(77 + M)
+    H, W, C, f, s, R = 28, 28, 1, 5, 2, 10
+    X = rng.standard_normal((N, H * W * C))
+    v = FullView((H, W), f, C, s)
+    Z, q_mu, q_sqrt = rand_spd_inputs(rng, M, R, v.patch_length, scale=0.05)
+    Z *= 1.5
+    layer = ConvLayer(RBF(v.patch_length, 5.0, 5.0), None, PatchInducingFeatures(Z), v, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
+    z = rng.standard_normal((N, layer.num_outputs))
+    with ctx.options(no_fused_layer=1):
+        smp_u, mean_u, var_u = layer._forward(X, z)
+    with ctx.options(fused_shape=shape):
+        smp, mean, var = layer._forward(X, z)
+    close(mean, mean_u, 1e-11, "mean, shape %d" % shape)
+    close(var, var_u, 1e-10, "var, shape %d" % shape)
+    close(smp, smp_u, 1e-10, "sample, shape %d" % shape)
+
+
 def test_conv_layer_identity_mean(ctx):
     from deepcgp_amd.kernels import RBF, PatchInducingFeatures
     from deepcgp_amd.layers import ConvLayer
