@@ -48,9 +48,17 @@ for fd in sorted(d for d in glob.glob(os.path.join(root, "pmc_%sf_*" % tag)) if 
     fetch, write = per_kernel(fd, "FETCH_SIZE"), per_kernel(wd, "WRITE_SIZE")
     e = {}
     e["conv_fused"] = bytes_of(fetch, write, lambda k, g: k.startswith("conv_fused_kernel"))
-    # head_units_kernel<NK4, TL, WRITE, NT>: WRITE = the storing form (K_uf sweep)
-    e["head_sweep"] = bytes_of(fetch, write, lambda k, g: k.startswith("head_units_kernel") and ", false" in k.split("(")[0])
-    e["kuf"] = bytes_of(fetch, write, lambda k, g: (k.startswith("head_units_kernel") and ", true" in k.split("(")[0]) or k.startswith("patch_rbf_kernel"))
+    # head_units_kernel<NK4, TL, WMODE, NT>: WMODE 0 = the reducing form (head sweep), 1 / 2 = the storing form (K_uf sweep); NK4 > 0 =
+    # the register-resident kernels of the short first-layer patches ("kuf"), NK4 == 0 = streamed operands, long patches ("kuf_long")
+    def hu(k):
+        m = re.match(r"head_units_kernel<\s*(\d+),\s*(\d+),\s*(\w+),", k)
+        if not m:
+            return None
+        wm = {"false": 0, "true": 1}.get(m.group(3))
+        return int(m.group(1)), int(m.group(3)) if wm is None else wm
+    e["head_sweep"] = bytes_of(fetch, write, lambda k, g: hu(k) is not None and hu(k)[1] == 0)
+    e["kuf"] = bytes_of(fetch, write, lambda k, g: (hu(k) is not None and hu(k)[1] != 0 and hu(k)[0] > 0) or k.startswith("patch_rbf_kernel"))
+    e["kuf_long"] = bytes_of(fetch, write, lambda k, g: hu(k) is not None and hu(k)[1] != 0 and hu(k)[0] == 0)
     tn = sorted({g for (k, g) in (set(fetch) | set(write)) if k.startswith("gemm_tn_kernel<128")}, reverse=True)
     if tn:   # the R-batched second product is the largest grid of the 128-row tile kernel, the first product the next one
         e["gemm_cond_s3"] = bytes_of(fetch, write, lambda k, g: k.startswith("gemm_tn_kernel<128") and g == tn[0])
