@@ -314,6 +314,35 @@ def test_full_size_cfg2_vs_oracle(ctx):
     model.close()
 
 
+@pytest.mark.parametrize("hwc,conv,M,N,S", [((13, 13, 1), (4, 1, 3), 24, 5, 3),      # P = 100: ragged last fragment, replica-outer stores
+                                            ((12, 12, 2), (5, 1, 2), 37, 3, 4),      # P = 64 (aligned: direct stores), M not a multiple of 16
+                                            ((28, 28, 1), (5, 2, 10), 256, 4, 10),   # the headline first layer: P = 144, two column ranges
+                                            ((32, 32, 3), (4, 2, 10), 384, 2, 5)])   # the CIFAR first layer: P = 225, L = 48, M > 256
+def test_kuf_sweep_replica_stores_are_exact(ctx, hwc, conv, M, N, S):
+    """The storing sweep evaluates rows that show the same image once (DGP_Base.propagate tiles the batch S times) and stores the tile to
+    every such row -- direct, or replica-outer from held batches where P is not a multiple of 16 (csrc/head_units.hip).  The ELBO and every
+    layer output on the sweep + GEMM route must be BIT-identical with that switched off (ctx option kuf_no_rep), and agree with the oracle."""
+    spec = syn.make_spec(hwc, [conv], (3, 1), M=M, S=S, num_data=900, seed=61, conv_q_sqrt_scale=0.4)
+    X, Y = syn.make_batch(hwc, N, seed=61)
+    zs = syn.make_noise(spec, N, seed=61)
+    model = build_from_spec(spec, X, Y)
+    with ctx.options(no_fused_layer=1):
+        e_rep = model.compute_log_likelihood(X, Y, zs=zs)
+        f_rep = model.propagate(X, S=S, zs=zs)[0][0].copy()
+        with ctx.options(kuf_no_rep=1):
+            e_all = model.compute_log_likelihood(X, Y, zs=zs)
+            f_all = model.propagate(X, S=S, zs=zs)[0][0].copy()
+        for split in (0, 3):                      # other cuts of a row fragment's column fragments
+            with ctx.options(kuf_split=split):
+                assert model.compute_log_likelihood(X, Y, zs=zs) == e_rep
+    assert e_rep == e_all
+    np.testing.assert_array_equal(f_rep, f_all)
+    if M <= 64:
+        ref = oracle_model(spec, X, Y).compute_log_likelihood(X, Y, zs=zs)
+        assert abs(e_rep - ref) <= RTOL * abs(ref)
+    model.close()
+
+
 def test_full_size_cfg1_vs_oracle(ctx):
     """BASELINE configs[0] (the reference's own CPU-runnable case: head only, M = 32, N = 1000, batch 32, S = 10) at its FULL size
     against the oracle: small enough for the NumPy restatement to finish in seconds (320 x 576 x 576 kernel values for Kdiag)."""
