@@ -1,3 +1,6 @@
+// NOTE (round 4): hipcc keeps the accumulators of this loop in AGPRs, and on gfx950 v_mfma_f64_16x16x4_f64 with AGPR accumulators runs at ~105
+// cycles per instruction and SIMD -- 47.7 TFLOP/s over the chip -- where VGPR accumulators give 64 cycles / 77 TFLOP/s.  This tool therefore
+// UNDERSTATES the pipe; the ceiling bench.py quotes comes from csrc/peaks.hip (dcgp_debug_mfma_f64_rate), which pins them to VGPRs.
 // Microbenchmark: sustained v_mfma_f64_16x16x4_f64 rate (the ceiling the conditional GEMM is priced against)
 // and a float4-copy HBM bandwidth ceiling.   hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o /tmp/mfma_peak
 #include <hip/hip_runtime.h>

@@ -1,3 +1,6 @@
+#!/usr/bin/env python
+"""usage (GPU box): python tools/shape_try.py   -- the one-launch conv layer's strip shapes (csrc/conv_fused.hip kShapes, forced through the ctx
+option fused_shape) on a rank's shard of the headline batch: ms per synchronous step and the ELBO (identical for every shape)."""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
