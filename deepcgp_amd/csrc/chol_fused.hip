@@ -884,6 +884,32 @@ int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_L
     Xla = (double*)ws_get(ctx, "chol_Xla" + ctx->ws_tag, (size_t)np_la * batch * 2 * NB * NB * sizeof(double));
     if (!Xla) return DCGP_ERR_ALLOC;
   }
+  // The panel launches of one (matrix group, bank) never change: same pointer tables, same scratch, same grid -- Mp / 32 of them (8 at
+  // M = 256, 32 at M = 1024), ~3.5 us of host time each.  They are captured once into a HIP graph per argument set and replayed with one
+  // call (ctx option chain_graph; the captured kernels and their order are exactly the loop's).  MEASURED AND LEFT OFF: the host's enqueue
+  // time per step falls (317 -> 200 us at M = 1024, 250 -> 205 us at cfg4) but a replay costs ~7 us of DEVICE time that the loop does not
+  // (chain 89.5 -> 97 us at M = 256, 14.4 -> 21 us at M = 32: the graph's own begin / end packets), and the host was never what a step
+  // waits for -- a panel launch is >= 10 us of device time against ~3.5 us to enqueue it.  cfg2 1222 -> 1212 steps/s, cfg1 5800 -> 5500.
+  std::string gkey;
+  const bool use_graph = ctx->opt.chain_graph != 0;   // (the family timer of this function brackets the replay from outside)
+  if (use_graph) {
+    char kb[256];
+    snprintf(kb, sizeof kb, "%p:%p:%p:%d:%d:%d:%p:%p:%p:%p:%d", (const void*)d_A, (const void*)d_Linv, (const void*)d_LinvT, batch, Mp, ld,
+             (void*)d_info, (void*)Lout, (void*)Y, (void*)Xla, (int)no_la);
+    gkey = kb;
+    auto it = ctx->chain_graphs.find(gkey);
+    if (it != ctx->chain_graphs.end()) {
+      HIP_TRY(ctx, hipGraphLaunch(it->second, ctx->stream));
+      if (defer_finish) return DCGP_OK;
+      return factor_finish_batched(ctx, d_A, batch, Mp, ld);
+    }
+    if (ctx->chain_graphs.size() >= 64) {   // models come and go: start over rather than grow without bound
+      for (auto& kv : ctx->chain_graphs) hipGraphExecDestroy(kv.second);
+      ctx->chain_graphs.clear();
+    }
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) gkey.clear();   // no capture: the plain loop
+  }
+  const bool capturing = use_graph && !gkey.empty();
   for (int j = 0; j < Mp; j += NB) {
     RlArgs a;
     a.A = d_A; a.Lout = Lout; a.Y = Y; a.Linv = d_Linv; a.LinvT = d_Linv ? d_LinvT : nullptr; a.Mp = Mp; a.ld = ld; a.j = j; a.info = d_info;
@@ -901,7 +927,18 @@ int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_L
     }
     // gx == 0: last panel of a plain potrf -- only L_jj is left; one workgroup factors and publishes it
     hipLaunchKernelGGL(chol_rl_kernel, dim3(gx > 0 ? gx : 1, batch), dim3(256), 0, ctx->stream, a);
-    LAUNCH_CHECK(ctx);
+    if (!capturing) LAUNCH_CHECK(ctx);
+  }
+  if (capturing) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || !graph)
+      return ctx_fail(ctx, DCGP_ERR_HIP, "factorisation chain: graph capture failed");
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (ei != hipSuccess || !exec) return ctx_fail(ctx, DCGP_ERR_HIP, "factorisation chain: graph instantiation failed: %s", hipGetErrorString(ei));
+    ctx->chain_graphs[gkey] = exec;
+    HIP_TRY(ctx, hipGraphLaunch(exec, ctx->stream));
   }
   if (defer_finish) return DCGP_OK;   // inv(L) is complete; the caller copies the factor back (factor_finish_batched) off its critical path
   return factor_finish_batched(ctx, d_A, batch, Mp, ld);

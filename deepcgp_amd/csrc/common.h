@@ -47,6 +47,7 @@ struct DcgpOptions {
   long head_no_overlap = 0;      // head-first model: the factorisation chain in front of the sweep instead of beside it
   long no_early_sweep = 0;       // the first layer's sweep enqueued behind the chain instead of in front of it
   long sync_event = 0;           // wait for the step's event instead of polling its completion word
+  long chain_graph = 0;          // the factorisation chain's panel launches replayed from a captured HIP graph (measured slower: see chol_fused.hip)
   long kuf_upw = 0;              // units per wave of the storing sweep (0: chosen by head_units_plan)
   long kuf_split = -1;           // storing sweep with replicas: column-fragment ranges per row fragment (-1: chosen; 0: one)
   long kuf_wpg = 0;              // storing sweep: waves per workgroup (0: chosen by head_units_plan; 1, 2, 4)
@@ -55,7 +56,6 @@ struct DcgpOptions {
   long share_kb = 0;             // patch sweeps beside the factorisation chain: LDS claimed per workgroup in KB (0: default)
   long sweep_occ = -1;           // patch sweeps: waves per SIMD a launch is held to so that its rounds come out whole (-1: chosen; 0: off)
   long head_tail = -1;           // head_units: balance of the launch tail (-1: default; see head_units_plan)
-  long graph = -1;               // synchronous forward step replayed from a captured HIP graph (-1: default)
   long fused_abl = 0, rb_mixed = 0;   // timing builds only (make EXPERIMENTS=1)
 };
 long* dcgp_option_slot(DcgpOptions* o, const char* name);   // nullptr: no such option (ctx.hip)
@@ -84,6 +84,7 @@ struct dcgp_ctx {
                                    // the profiler serialises dispatches and cross-stream waits can deadlock it)
   hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;  // fork / join of a short side-stream excursion inside a layer
   std::string err;
+  std::map<std::string, hipGraphExec_t> chain_graphs;   // captured panel-launch sequences of the factorisation chain, by argument set (chol_fused.hip)
   std::map<std::string, ChainEpoch> chain_epochs;   // per sync workspace of chol_persist_kernel (chol_fused.hip)
   std::string ws_tag;   // suffix of the chain's / KL terms' scratch names: steps in flight on the two banks must not share them
   // named, grow-only device workspaces owned by the ctx
