@@ -343,6 +343,33 @@ def test_kuf_sweep_replica_stores_are_exact(ctx, hwc, conv, M, N, S):
     model.close()
 
 
+def test_chain_graph_replay_matches_the_launch_loop(ctx):
+    """ctx option chain_graph: the factorisation chain's panel launches (conv_gp/conditionals.py:29, layers.py:151,156) replayed from a HIP
+    graph captured on first use (csrc/chol_fused.hip; off by default: measured slower).  Same kernels in the same order: the ELBO over several
+    steps -- both banks, the first one capturing, the later ones replaying -- and the gradients are bit-identical to the loop's, for two
+    models alive at once (two argument sets in the cache) and an M whose last panel is ragged."""
+    out = {}
+    for g in (0, 1):
+        with ctx.options(chain_graph=g):
+            vals = []
+            models = []
+            for hwc, convs, head, M in (((13, 13, 2), [(4, 3, 7)], (2, 1), 41), ((12, 12, 1), [], (3, 1), 96)):
+                spec = syn.make_spec(hwc, convs, head, M, S=2, num_data=555, seed=71, conv_q_sqrt_scale=0.3)
+                X, Y = syn.make_batch(hwc, 3, seed=71)
+                zs = syn.make_noise(spec, 3, seed=71)
+                model = build_from_spec(spec, X, Y)
+                models.append(model)
+                for rep in range(4):
+                    vals.append(model.compute_log_likelihood(X, Y, zs=zs))
+                e, grads = model.compute_gradients(X, Y, zs=zs)
+                vals.append(e)
+                vals.append(float(sum(np.sum(np.abs(v)) for gl in grads for v in gl.values())))
+            for m in models:
+                m.close()
+            out[g] = vals
+    assert np.all(np.isfinite(out[1])) and out[0] == out[1], (out[0], out[1])
+
+
 def test_full_size_cfg1_vs_oracle(ctx):
     """BASELINE configs[0] (the reference's own CPU-runnable case: head only, M = 32, N = 1000, batch 32, S = 10) at its FULL size
     against the oracle: small enough for the NumPy restatement to finish in seconds (320 x 576 x 576 kernel values for Kdiag)."""
