@@ -442,7 +442,12 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : (WMODE == 1 ? 3 : HU_WAVES)) v
     ur = WRITE ? u / a.st_split : u;
     const int part = WRITE ? u - ur * a.st_split : 0;
     const int uj_lo = WRITE ? part * a.st_jn : 0, uj_hi = WRITE ? min(nfp, uj_lo + a.st_jn) : nfp;
-    const double* __restrict__ zs = a.ZS + 16 * ur + lcol;
+    // the Z operand through a buffer descriptor: a per-lane offset that is constant for the unit, the sub-step a scalar offset -- no
+    // address arithmetic in the k loop (as plain pointer arithmetic it was 16 VALU instructions per chunk of 16 MFMAs, four of them
+    // quarter-rate 64-bit multiply-adds: ~11 % of the loop's issue slots at L = 250)
+    const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.ZS), 0, a.Lq * a.Mp * 8, 0x00020000);
+    const int zvo = (lrow * a.Mp + 16 * ur + lcol) * 8, zstep = 4 * a.Mp * 8;
+    auto ldz = [&](int sub) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrs, zvo, sub * zstep, 0)); };
     double rsum[4] = {0.0, 0.0, 0.0, 0.0};
     if (WRITE) {
       st_rs = __builtin_amdgcn_make_buffer_rsrc(a.kuf + ((long)(16 * ur) * a.sM + (long)n * a.sN), 0, 0x7fffffff, 0x00020000);
@@ -454,12 +459,12 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : (WMODE == 1 ? 3 : HU_WAVES)) v
     if (RES) {
       double areg[NKR];
 #pragma unroll
-      for (int s = 0; s < NKR; ++s) areg[s] = zs[(long)(4 * s + lrow) * a.Mp];
+      for (int s = 0; s < NKR; ++s) areg[s] = ldz(s);
       if (WMODE == 2 && st_hold) row_pass_hold([&](int s) { return areg[s]; }, [&](int s, int) { return areg[RES ? s : 0]; }, uj_lo, uj_hi);
       else row_pass([&](int s) { return areg[s]; }, [&](int s, int) { return areg[RES ? s : 0]; }, uj_lo, uj_hi, nullptr, rsum);
     } else {
-      if (WMODE == 2 && st_hold) row_pass_hold([&](int s) { return zs[(long)(4 * s + lrow) * a.Mp]; }, [&](int s, int) { return zs[(long)(4 * s + lrow) * a.Mp]; }, uj_lo, uj_hi);
-      else row_pass([&](int s) { return zs[(long)(4 * s + lrow) * a.Mp]; }, [&](int s, int) { return zs[(long)(4 * s + lrow) * a.Mp]; }, uj_lo, uj_hi, nullptr, rsum);
+      if (WMODE == 2 && st_hold) row_pass_hold([&](int s) { return ldz(s); }, [&](int s, int) { return ldz(s); }, uj_lo, uj_hi);
+      else row_pass([&](int s) { return ldz(s); }, [&](int s, int) { return ldz(s); }, uj_lo, uj_hi, nullptr, rsum);
     }
     if (!WRITE) {
 #pragma unroll
