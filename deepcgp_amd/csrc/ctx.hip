@@ -26,7 +26,7 @@ long* dcgp_option_slot(DcgpOptions* o, const char* name) {
       {"grad_nofork", &DcgpOptions::grad_nofork}, {"chol_one_launch", &DcgpOptions::chol_one_launch},
       {"chol_no_lookahead", &DcgpOptions::chol_no_lookahead}, {"head_no_overlap", &DcgpOptions::head_no_overlap},
       {"no_early_sweep", &DcgpOptions::no_early_sweep}, {"sync_event", &DcgpOptions::sync_event}, {"kuf_upw", &DcgpOptions::kuf_upw}, {"chain_graph", &DcgpOptions::chain_graph}, {"kuf_no_rep", &DcgpOptions::kuf_no_rep}, {"kuf_stream", &DcgpOptions::kuf_stream}, {"kuf_wpg", &DcgpOptions::kuf_wpg}, {"kuf_split", &DcgpOptions::kuf_split},
-      {"head_tail", &DcgpOptions::head_tail}, {"sweep_occ", &DcgpOptions::sweep_occ}, {"share_kb", &DcgpOptions::share_kb},
+      {"head_tail", &DcgpOptions::head_tail}, {"sweep_occ", &DcgpOptions::sweep_occ}, {"share_kb", &DcgpOptions::share_kb}, {"head_upw", &DcgpOptions::head_upw},
       {"fused_abl", &DcgpOptions::fused_abl}, {"rb_mixed", &DcgpOptions::rb_mixed},
   };
   for (const Slot& s : slots)
@@ -38,7 +38,7 @@ long* dcgp_option_slot(DcgpOptions* o, const char* name) {
 static void options_from_env(DcgpOptions* o) {
   static const char* names[] = {"no_fused_layer", "fused_large", "fused_shape", "kl_side", "no_fused_bwd", "fused_bwd_min_cols", "head_unfused",
                                 "no_side_stream", "cu_partition", "grad_nofork", "chol_one_launch", "chol_no_lookahead", "head_no_overlap",
-                                "no_early_sweep", "sync_event", "kuf_upw", "chain_graph", "kuf_no_rep", "kuf_stream", "kuf_wpg", "kuf_split", "head_tail", "sweep_occ", "share_kb", "fused_abl", "rb_mixed"};
+                                "no_early_sweep", "sync_event", "kuf_upw", "chain_graph", "kuf_no_rep", "kuf_stream", "kuf_wpg", "kuf_split", "head_tail", "sweep_occ", "share_kb", "head_upw", "fused_abl", "rb_mixed"};
   for (const char* n : names) {
     std::string e = "DCGP_";
     for (const char* c = n; *c; ++c) e += (char)toupper((unsigned char)*c);

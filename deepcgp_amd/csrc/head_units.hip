@@ -637,6 +637,10 @@ void head_units_plan(HeadUnitsArgs* a) {
       if (kz_upw > 4) kz_upw = 4;
       while (kz_upw > 1 && a->nfm % (W * kz_upw)) --kz_upw;
     }
+    // long launches (M = 1024 on long patches: ~20 rounds of the resident slots) halve their set-ups the same way (817 -> 778 us); launches of
+    // a round or two must not (the 12 x 12 x 10 head at M = 256: 74 -> 76 us with two units per wave, 90 with four)
+    if (kz_upw == 1 && unit_mfma < 400 && (long)a->N * a->nfm / W >= 16 * 1024 && a->nfm % (W * 2) == 0) kz_upw = 2;
+    if (a->upw_force > 0) kz_upw = a->upw_force;   // A/B (ctx option head_upw)
   }
   if (a->kzx) push(0, a->N, (a->nfm + W * kz_upw - 1) / (W * kz_upw), 0, 0, kz_upw);
   if (a->want_kd || a->kd) {

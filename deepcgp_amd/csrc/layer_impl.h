@@ -354,6 +354,7 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     h.tail_mode = (int)ctx->opt.head_tail;
     h.occ_force = (int)ctx->opt.sweep_occ;
     h.share_kb = (int)ctx->opt.share_kb;
+    h.upw_force = (int)ctx->opt.head_upw;
     head_units_plan(&h);
     if (head_units_ok(h)) {
       h.kd = (double*)ws_get(ctx, "kdiag_partial", (size_t)rows * h.n_kd * sizeof(double));   // [rows][n_kd] partial sums (head_units_plan)
