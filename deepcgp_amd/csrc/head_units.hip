@@ -97,9 +97,12 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : (WMODE == 1 ? 3 : HU_WAVES)) v
   // this was reordered and the window sums were given one thread per entry: four threads per entry with two shuffles each is a dependent
   // chain per iteration, and a 64-thread workgroup walked 42 of them.)
   {
-    double t[8];   // batches of 8 loads per thread: one memory latency for all of them
+    // batches of IB loads per thread: one memory latency for all of them (16 for the narrow workgroups, so that a 12 x 12 x 10 image is one
+    // batch of a two-wave workgroup as well: its second batch was a second full latency, ~1.5 us of a ~6 us set-up)
+    constexpr int IB = NT <= 128 ? 16 : 8;
+    double t[IB];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < IB; ++e) {
       const int i = e * NT + tid;
       t[e] = (i < HWC) ? Xn[i] : 0.0;
     }
@@ -116,18 +119,18 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : (WMODE == 1 ? 3 : HU_WAVES)) v
       wl[p] = (!WRITE && p < P) ? a.w[p] : 0.0;
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < IB; ++e) {
       const int i = e * NT + tid;
       if (i < HWC) img[i] = t[e] * a.csq;
     }
-    for (int i0 = 8 * NT; i0 < HWC; i0 += 8 * NT) {
+    for (int i0 = IB * NT; i0 < HWC; i0 += IB * NT) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < IB; ++e) {
         const int i = i0 + e * NT + tid;
         t[e] = (i < HWC) ? Xn[i] : 0.0;
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < IB; ++e) {
         const int i = i0 + e * NT + tid;
         if (i < HWC) img[i] = t[e] * a.csq;
       }
