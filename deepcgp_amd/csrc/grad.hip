@@ -596,6 +596,7 @@ struct Bk {   // per-backward bookkeeping
   dcgp_ctx* ctx;
   std::string pfx;   // workspace prefix of the layer being processed
   int slot_v = 0, slot_l = 0, slot_b = 0;
+  bool side_pending = false;   // a layer left the end of its reverse pass on the side stream: model_backward joins once, at the end
   double klw = 1.0;   // weight of the (replicated) KL term on this rank: 1 / number of batch shards
   double* ws(const char* name, size_t n_doubles) { return (double*)ws_get(ctx, pfx + "g_" + name, (n_doubles ? n_doubles : 1) * sizeof(double)); }
 };
@@ -606,11 +607,12 @@ struct SideScope {
   dcgp_ctx* ctx;
   hipStream_t main_s;
   bool active;
-  SideScope(dcgp_ctx* c, hipEvent_t fork_ev) : ctx(c), main_s(c->stream) {
+  // recorded: fork_ev already marks the fork point on the main stream (the side work is enqueued later than the point it may start at)
+  SideScope(dcgp_ctx* c, hipEvent_t fork_ev, bool recorded = false) : ctx(c), main_s(c->stream) {
     const bool nofork = c->opt.grad_nofork != 0;   // A/B switch
     active = !nofork && !c->no_side && c->stream2 && c->stream2 != c->stream;
     if (active) {
-      if (hipEventRecord(fork_ev, main_s) != hipSuccess || hipStreamWaitEvent(c->stream2, fork_ev, 0) != hipSuccess) active = false;
+      if ((!recorded && hipEventRecord(fork_ev, main_s) != hipSuccess) || hipStreamWaitEvent(c->stream2, fork_ev, 0) != hipSuccess) active = false;
       else c->stream = c->stream2;
     }
   }
@@ -832,11 +834,10 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   hipStream_t main_s = ctx->stream;
   const bool nofork = ctx->opt.grad_nofork != 0;   // A/B switch
   const bool fork = !nofork && !ctx->no_side && ctx->stream2 && ctx->stream2 != main_s;
-  if (fork) {
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, main_s));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_aux, 0));
-    ctx->stream = ctx->stream2;
-  }
+  // (the fork point is marked here; the side chain is ENQUEUED behind the main chain: one host thread feeds both streams at ~5 us a launch, and
+  // with few columns -- the head -- the main chain's launches are as short as that: fed second, it sat idle while the host was busy with the side
+  // chain's fourteen launches)
+  if (fork) HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, main_s));
   auto side_chain = [&]() -> int {
     // d alpha = A1 gm
     DCGP_TRY(gemm_gen(ctx, mk(A1, ld, 1, gm, R, 1, dalpha, Rp, M, R, (int)Kc)));
@@ -888,12 +889,19 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
     }
     return DCGP_OK;
   };
-  int rc_side = side_chain();
-  if (fork) {
-    if (rc_side == DCGP_OK && hipEventRecord(ctx->ev_aux2, ctx->stream2) != hipSuccess) rc_side = DCGP_ERR_HIP;
-    ctx->stream = main_s;
-  }
-  if (rc_side != DCGP_OK) { if (fork) hipStreamSynchronize(ctx->stream2); return rc_side; }
+  auto run_side = [&]() -> int {
+    if (fork) {
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_aux, 0));
+      ctx->stream = ctx->stream2;
+    }
+    int rc_side = side_chain();
+    if (fork) {
+      if (rc_side == DCGP_OK && hipEventRecord(ctx->ev_aux2, ctx->stream2) != hipSuccess) rc_side = DCGP_ERR_HIP;
+      ctx->stream = main_s;
+      if (rc_side != DCGP_OK) hipStreamSynchronize(ctx->stream2);
+    }
+    return rc_side;
+  };
   // main chain
   if (fused_bwd) {
     DCGP_TRY(conv_bwd_fused(ctx, fb));
@@ -953,6 +961,7 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
       DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dA1, ld, 1, dKuf, ld, M, (int)Kc, M)));
     }
   }
+  DCGP_TRY(run_side());
   if (fork) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux2, 0));   // join: dL's first terms, dq_mu, dq_sqrt are done
   GenGemm l3 = mk(dKuf, ld, 1, A1, 1, ld, dL, Mp, M, M, (int)Kc);
   l3.alpha = -1.0; l3.lower_only = 1; l3.accumulate = 1;
@@ -1044,15 +1053,21 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   // patch-kernel adjoint on the main stream; both add into dZ, so the main one collects its part in a scratch first
   double* dzp = bk.ws("dz_patch", (size_t)M * Ld);
   NEED(dzp);
-  bool forked;
-  {
-    SideScope side(ctx, ctx->ev_fork);
-    forked = side.active;
+  // (fork point here; the side chain is enqueued behind the main stream's launches below -- see head_backward)
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  auto side_tail = [&](bool* forked) -> int {
+    SideScope side(ctx, ctx->ev_fork, true);
+    *forked = side.active;
     DCGP_TRY(add_scalar(bk, L, 0, gvs, Kc, 1.0));                  // Knn = variance on every column
     DCGP_TRY(kuu_backward(bk, L, L.Z, S, Mp, true));
     DCGP_TRY(kl_backward(bk, L, nullptr));
-    DCGP_TRY(side.done(ctx->ev_kl));
-  }
+    if (side.active) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux, 0));   // (the side stream: behind the main stream's part of the layer)
+    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(Ld), M), dim3(256), 0, ctx->stream, dzp, (long)Ld, L.gZ, (long)Ld, M, Ld, 1.0, 1);
+    LAUNCH_CHECK(ctx);
+    DCGP_TRY(end_layer(bk, L));
+    bk.side_pending = bk.side_pending || side.active;
+    return side.done(ctx->ev_kl);
+  };
   HIP_TRY(ctx, hipMemsetAsync(dzp, 0, (size_t)M * Ld * sizeof(double), ctx->stream));
   hipLaunchKernelGGL(im2col_kernel, dim3(blocks_for(Kc * Ld)), dim3(256), 0, ctx->stream, Xin, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s,
                      L.v.Wo, P, Ld, Kc, Xcol);
@@ -1108,10 +1123,13 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
       LAUNCH_CHECK(ctx);
     }
   }
-  if (forked) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_kl, 0));   // join
-  hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(Ld), M), dim3(256), 0, ctx->stream, dzp, (long)Ld, L.gZ, (long)Ld, M, Ld, 1.0, 1);
-  LAUNCH_CHECK(ctx);
-  return end_layer(bk, L);
+  // The main stream's part of this layer ends here (dX is out).  Everything that is left -- the M x M tail, adding the patch part of dZ,
+  // the scalar sums -- yields this layer's own parameter gradients only: it stays on the side stream, and the main stream goes straight on
+  // to the layer below instead of waiting for it (model_backward joins once, at the end of the step)
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));
+  bool forked = false;
+  DCGP_TRY(side_tail(&forked));
+  return DCGP_OK;
 }
 
 // Dense head backward: gpflow RBF(D, ARD=True) on the flattened features (--last-kernel rbf, conv_gp/models.py:160-168).
@@ -1185,14 +1203,9 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   // as in conv_backward: KL + Gram adjoints on the side stream, the patch-kernel adjoints (K_zx, K_diag) on the main one
   double* dzp = bk.ws("dz_patch", (size_t)M * Ld);
   NEED(dzp);
-  bool forked;
-  {
-    SideScope side(ctx, ctx->ev_fork);
-    forked = side.active;
-    if (!L.white) DCGP_TRY(kl_backward(bk, L, S)); else DCGP_TRY(kl_backward(bk, L, nullptr));
-    DCGP_TRY(kuu_backward(bk, L, L.Z, S, Mp, true));
-    DCGP_TRY(side.done(ctx->ev_kl));
-  }
+  // the fork point of the side chain (KL + Gram adjoints: they need S only); the chain itself is ENQUEUED behind the patch-kernel adjoints
+  // below -- what the previous layer's reverse pass waits for is dX, and one host thread feeding two streams of 5-10 us launches starved the main one
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(dzp, 0, (size_t)M * Ld * sizeof(double), ctx->stream));
   // every patch response again: Kfull[m][n * P + p] = k(Z_m, x_np)
   PatchRbfArgs a;
@@ -1255,10 +1268,21 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
                        L.v.Wo, Ld, dXin);
     LAUNCH_CHECK(ctx);
   }
-  if (forked) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_kl, 0));   // join
-  hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(Ld), M), dim3(256), 0, ctx->stream, dzp, (long)Ld, L.gZ, (long)Ld, M, Ld, 1.0, 1);
-  LAUNCH_CHECK(ctx);
-  return end_layer(bk, L);
+  // the main stream's part of the head ends here (dX is out); the rest yields the head's own parameter gradients and stays on the side stream
+  // (see conv_backward)
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));
+  {
+    SideScope side(ctx, ctx->ev_fork, true);
+    if (!L.white) DCGP_TRY(kl_backward(bk, L, S)); else DCGP_TRY(kl_backward(bk, L, nullptr));
+    DCGP_TRY(kuu_backward(bk, L, L.Z, S, Mp, true));
+    if (side.active) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux, 0));
+    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(Ld), M), dim3(256), 0, ctx->stream, dzp, (long)Ld, L.gZ, (long)Ld, M, Ld, 1.0, 1);
+    LAUNCH_CHECK(ctx);
+    DCGP_TRY(end_layer(bk, L));
+    bk.side_pending = bk.side_pending || side.active;
+    DCGP_TRY(side.done(ctx->ev_kl));
+  }
+  return DCGP_OK;
 }
 
 }  // namespace
@@ -1325,6 +1349,7 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
       LAUNCH_CHECK(ctx);
     }
   }
+  if (bk.side_pending) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_kl, 0));   // the one join of the step: every layer's side-stream tail
   if (ctx->comm)   // one in-stream all-reduce per layer over its contiguous gradient block (RCCL over xGMI)
     for (auto& l : m->layers) {
       const size_t n = l->grad_block_count();
