@@ -404,6 +404,37 @@ def test_conv_layer_identity_mean(ctx):
     np.testing.assert_array_equal(v0, v1)
 
 
+def test_ctx_options_and_workspace_query(ctx):
+    """dcgp_ctx_set_option / dcgp_ctx_get_option (the A/B switches live in the ctx: nothing on the step path reads the environment),
+    the scoped form, unknown names, the creation-only switch; dcgp_workspace_query reports what the library holds for the ctx."""
+    from deepcgp_amd import device as dev
+    assert ctx.get_option("no_fused_layer") == 0 and ctx.get_option("fused_shape") == -1
+    with ctx.options(no_fused_layer=1, kuf_split=3):
+        assert ctx.get_option("no_fused_layer") == 1 and ctx.get_option("kuf_split") == 3
+        with ctx.options(no_fused_layer=0):
+            assert ctx.get_option("no_fused_layer") == 0
+        assert ctx.get_option("no_fused_layer") == 1
+    assert ctx.get_option("no_fused_layer") == 0 and ctx.get_option("kuf_split") == -1
+    with pytest.raises(dev.DcgpError):
+        ctx.set_option("no_such_switch", 1)
+    with pytest.raises(dev.DcgpError):
+        ctx.get_option("no_such_switch")
+    with pytest.raises(dev.DcgpError):
+        ctx.set_option("cu_partition", 1)          # read at dcgp_ctx_create only
+    before, n_before = ctx.workspace_bytes()
+    rng = np.random.default_rng(3)
+    from deepcgp_amd.kernels import RBF, ConvKernel
+    from deepcgp_amd.views import FullView
+    v = FullView((10, 10, 2), 3, 2, 1)
+    ConvKernel(RBF(v.patch_length, 1.0, 1.0), v).Kzx(rng.standard_normal((7, v.patch_length)), rng.standard_normal((3, 200)))
+    after, n_after = ctx.workspace_bytes()
+    assert after >= before and n_after >= n_before and after > 0 and n_after > 0
+    # the measured ceilings bench.py quotes (csrc/peaks.hip): sane magnitudes on an MI355X
+    tf = ctx.measured_mfma_f64_tflops()
+    gbs = ctx.measured_store_gbs(64, 144, 256)
+    assert 40.0 < tf < 90.0 and 500.0 < gbs < 9000.0, (tf, gbs)
+
+
 def test_mean_function_objects(ctx):
     """conv_gp/mean_functions.py:6-41 as objects (constructed at conv_gp/models.py:29-33,95-99): Conv2dMean(...) handed to ConvLayer gives
     what the 'conv2d' alias and the oracle's Conv2dMean give (the layer launch adds the centre pixel itself); a Conv2dMean with a changed
