@@ -1,4 +1,4 @@
-// conv_bwd_fused.hip -- the reverse pass of the conditional's column-wise part for ONE 64-column strip in ONE workgroup
+// conv_bwd_fused.hip -- the reverse pass of the conditional's column-wise part for ONE strip of 16 FN columns in ONE workgroup
 // (the adjoint of conv_gp/conditionals.py:31-65 with respect to K_uf, given d mean and d var of layers.py:128-134).
 //
 // With A1 = inv(L) K_uf, T_r = G_r^T A1, var_r = Knn - sum_m A1^2 + sum_m T_r^2 and mean_r = alpha_r^T A1, the adjoint is
@@ -15,21 +15,26 @@
 // registers two k-tiles ahead, wave w owning the 16 rows of fragment w for all r (dense S_r: every wave carries the same
 // R * Mp/16 k-tiles), no barrier inside the k loops.  dA1 leaves the registers once, into the strip, as the B operand of
 // the closing triangular product; HBM traffic is the strip of A1 in and the strip of dK_uf out.
+// Strip width: 64 columns (FN = 4) where that still gives the chip a round of workgroups; the de-duplicated first layer of a
+// training step has a tenth of the columns (4608 at the headline size: 72 strips of 64 on 256 CUs, 332 us) and takes 32-column
+// strips -- twice the workgroups on half the MFMA chain each, the S_r stream (L2) per workgroup unchanged.
 #include "layer.h"
 
 namespace {
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-constexpr int CB_BN = 64, CB_FN = 4, CB_NT = 1024, CB_D = 2;
+constexpr int CB_NT = 1024, CB_D = 2;
 
+template <int CB_FN>
 __global__ __launch_bounds__(CB_NT) void conv_bwd_fused_kernel(ConvBwdArgs a) {
+  constexpr int CB_BN = 16 * CB_FN, CB_SH = CB_FN == 4 ? 6 : (CB_FN == 2 ? 5 : 4);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int Mp = a.Mp, nf = Mp >> 4, R = a.R, Rk = (R + 3) & ~3;
   const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool live = wave < nf;
   const int fw = live ? wave : nf - 1;                  // idle waves shadow the last fragment (loads in range, results dropped)
-  double* strip = smem;                                 // [Mp][64], 16-column groups XOR-swizzled by (row & 3)
+  double* strip = smem;                                 // [Mp][BN], 16-column groups XOR-swizzled by (row & (FN - 1))
   double* gvl = strip + (long)Mp * CB_BN;               // [R][64]   2 gv[j][r]
   double* gml = gvl + R * CB_BN;                        // [Rk][64]  gm[j][r], zero rows beyond R
   double* gsl = gml + Rk * CB_BN;                       // [64]      -2 gvs[j]
@@ -40,13 +45,13 @@ __global__ __launch_bounds__(CB_NT) void conv_bwd_fused_kernel(ConvBwdArgs a) {
     double t[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int idx = i0 + e * CB_NT + tid, m = idx >> 6, c = idx & 63;
+      const int idx = i0 + e * CB_NT + tid, m = idx >> CB_SH, c = idx & (CB_BN - 1);
       t[e] = (idx < Mp * CB_BN && j0 + c < a.Kc) ? a.A1[(long)m * a.ld + j0 + c] : 0.0;
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int idx = i0 + e * CB_NT + tid, m = idx >> 6, c = idx & 63;
-      if (idx < Mp * CB_BN) strip[m * CB_BN + ((((c >> 4) ^ (m & 3)) << 4) | (c & 15))] = t[e];
+      const int idx = i0 + e * CB_NT + tid, m = idx >> CB_SH, c = idx & (CB_BN - 1);
+      if (idx < Mp * CB_BN) strip[m * CB_BN + ((((c >> 4) ^ (m & (CB_FN - 1))) << 4) | (c & 15))] = t[e];
     }
   }
   for (int idx = tid; idx < Rk * CB_BN; idx += CB_NT) {
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(CB_NT) void conv_bwd_fused_kernel(ConvBwdArgs a) {
 
   int bsw[CB_FN];   // element (row k, column y*16 + lcol) with k & 3 == lrow lives at k * 64 + bsw[y]
 #pragma unroll
-  for (int y = 0; y < CB_FN; ++y) bsw[y] = ((y ^ lrow) << 4) + lcol;
+  for (int y = 0; y < CB_FN; ++y) bsw[y] = ((y ^ (lrow & (CB_FN - 1))) << 4) + lcol;
   unsigned voff[4];   // lane (lrow, lcol) of k-substep q of a k-tile needs Wt[16 kt + 4q + lrow][16 f + lcol]
 #pragma unroll
   for (int q = 0; q < 4; ++q) voff[q] = (unsigned)(((4 * q + lrow) * Mp + lcol) * 8);
@@ -198,10 +203,16 @@ __global__ __launch_bounds__(CB_NT) void conv_bwd_fused_kernel(ConvBwdArgs a) {
 
 }  // namespace
 
+// strip width in 16-column fragments: 4 while that fills a round of the chip, else 2
+static int strip_frags(const dcgp_ctx* ctx, const ConvBwdArgs& a) {
+  if (ctx->opt.fused_bwd_frags == 4 || ctx->opt.fused_bwd_frags == 2 || ctx->opt.fused_bwd_frags == 1) return ctx->opt.fused_bwd_frags;   // A/B switch
+  return (a.Kc + 63) / 64 >= 200 ? 4 : 2;
+}
+
 bool conv_bwd_fused_ok(const dcgp_ctx* ctx, const ConvBwdArgs& a) {
   if (ctx->opt.no_fused_bwd) return false;
   const int Rk = (a.R + 3) & ~3;
-  const size_t lds = ((size_t)a.Mp * CB_BN + (size_t)(a.R + Rk + 1) * CB_BN) * sizeof(double);
+  const size_t lds = ((size_t)a.Mp * 64 + (size_t)(a.R + Rk + 1) * 64) * sizeof(double);
   return a.Mp >= 16 && a.Mp <= 256 && a.Mp % 16 == 0 && a.R >= 1 && a.R <= 16 && lds <= 160 * 1024 &&
          (long)a.R * a.Mp * a.Mp * 8 < (1L << 31);
 }
@@ -209,16 +220,21 @@ bool conv_bwd_fused_ok(const dcgp_ctx* ctx, const ConvBwdArgs& a) {
 int conv_bwd_fused(dcgp_ctx* ctx, const ConvBwdArgs& a) {
   if (a.Kc <= 0) return DCGP_OK;
   if (!conv_bwd_fused_ok(ctx, a)) return ctx_fail(ctx, DCGP_ERR_ARG, "conv_bwd_fused: layer shape not supported (M = %d, R = %d)", a.M, a.R);
-  const int Rk = (a.R + 3) & ~3;
-  const size_t lds = ((size_t)a.Mp * CB_BN + (size_t)(a.R + Rk + 1) * CB_BN) * sizeof(double);
+  const int Rk = (a.R + 3) & ~3, fn = strip_frags(ctx, a), bn = 16 * fn;
+  const size_t lds = ((size_t)a.Mp * bn + (size_t)(a.R + Rk + 1) * bn) * sizeof(double);
   static bool attr[64] = {};   // per device
   const int dv = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
   if (!attr[dv]) {
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)conv_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)conv_bwd_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)conv_bwd_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)conv_bwd_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr[dv] = true;
   }
   ScopedTimer t(ctx, "conv_bwd_fused");
-  hipLaunchKernelGGL(conv_bwd_fused_kernel, dim3((unsigned)((a.Kc + CB_BN - 1) / CB_BN)), dim3(CB_NT), lds, ctx->stream, a);
+  const dim3 grid((unsigned)((a.Kc + bn - 1) / bn));
+  if (fn == 4) hipLaunchKernelGGL(conv_bwd_fused_kernel<4>, grid, dim3(CB_NT), lds, ctx->stream, a);
+  else if (fn == 2) hipLaunchKernelGGL(conv_bwd_fused_kernel<2>, grid, dim3(CB_NT), lds, ctx->stream, a);
+  else hipLaunchKernelGGL(conv_bwd_fused_kernel<1>, grid, dim3(CB_NT), lds, ctx->stream, a);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }

@@ -17,36 +17,38 @@ int ctx_fail(dcgp_ctx* ctx, int code, const char* fmt, ...) {
 }
 
 // name -> field of the option block (DcgpOptions, common.h)
+namespace {
+struct OptSlot { const char* name; long DcgpOptions::*field; };
+const OptSlot kOptSlots[] = {
+    {"no_fused_layer", &DcgpOptions::no_fused_layer}, {"fused_large", &DcgpOptions::fused_large}, {"fused_shape", &DcgpOptions::fused_shape},
+    {"kl_side", &DcgpOptions::kl_side}, {"no_fused_bwd", &DcgpOptions::no_fused_bwd}, {"fused_bwd_min_cols", &DcgpOptions::fused_bwd_min_cols},
+    {"fused_bwd_frags", &DcgpOptions::fused_bwd_frags}, {"grad_late_kl", &DcgpOptions::grad_late_kl},
+    {"head_unfused", &DcgpOptions::head_unfused}, {"no_side_stream", &DcgpOptions::no_side_stream}, {"cu_partition", &DcgpOptions::cu_partition},
+    {"grad_nofork", &DcgpOptions::grad_nofork}, {"chol_one_launch", &DcgpOptions::chol_one_launch},
+    {"chol_no_lookahead", &DcgpOptions::chol_no_lookahead}, {"head_no_overlap", &DcgpOptions::head_no_overlap},
+    {"no_early_sweep", &DcgpOptions::no_early_sweep}, {"sync_event", &DcgpOptions::sync_event}, {"kuf_upw", &DcgpOptions::kuf_upw},
+    {"chain_graph", &DcgpOptions::chain_graph}, {"kuf_no_rep", &DcgpOptions::kuf_no_rep}, {"kuf_stream", &DcgpOptions::kuf_stream},
+    {"kuf_wpg", &DcgpOptions::kuf_wpg}, {"kuf_split", &DcgpOptions::kuf_split}, {"head_tail", &DcgpOptions::head_tail},
+    {"sweep_occ", &DcgpOptions::sweep_occ}, {"share_kb", &DcgpOptions::share_kb}, {"head_upw", &DcgpOptions::head_upw},
+    {"fused_abl", &DcgpOptions::fused_abl}, {"rb_mixed", &DcgpOptions::rb_mixed},
+};
+}  // namespace
 long* dcgp_option_slot(DcgpOptions* o, const char* name) {
-  struct Slot { const char* name; long DcgpOptions::*field; };
-  static const Slot slots[] = {
-      {"no_fused_layer", &DcgpOptions::no_fused_layer}, {"fused_large", &DcgpOptions::fused_large}, {"fused_shape", &DcgpOptions::fused_shape},
-      {"kl_side", &DcgpOptions::kl_side}, {"no_fused_bwd", &DcgpOptions::no_fused_bwd}, {"fused_bwd_min_cols", &DcgpOptions::fused_bwd_min_cols},
-      {"head_unfused", &DcgpOptions::head_unfused}, {"no_side_stream", &DcgpOptions::no_side_stream}, {"cu_partition", &DcgpOptions::cu_partition},
-      {"grad_nofork", &DcgpOptions::grad_nofork}, {"chol_one_launch", &DcgpOptions::chol_one_launch},
-      {"chol_no_lookahead", &DcgpOptions::chol_no_lookahead}, {"head_no_overlap", &DcgpOptions::head_no_overlap},
-      {"no_early_sweep", &DcgpOptions::no_early_sweep}, {"sync_event", &DcgpOptions::sync_event}, {"kuf_upw", &DcgpOptions::kuf_upw}, {"chain_graph", &DcgpOptions::chain_graph}, {"kuf_no_rep", &DcgpOptions::kuf_no_rep}, {"kuf_stream", &DcgpOptions::kuf_stream}, {"kuf_wpg", &DcgpOptions::kuf_wpg}, {"kuf_split", &DcgpOptions::kuf_split},
-      {"head_tail", &DcgpOptions::head_tail}, {"sweep_occ", &DcgpOptions::sweep_occ}, {"share_kb", &DcgpOptions::share_kb}, {"head_upw", &DcgpOptions::head_upw},
-      {"fused_abl", &DcgpOptions::fused_abl}, {"rb_mixed", &DcgpOptions::rb_mixed},
-  };
-  for (const Slot& s : slots)
+  for (const OptSlot& s : kOptSlots)
     if (strcmp(s.name, name) == 0) return &(o->*s.field);
   return nullptr;
 }
 
 // the environment as the switches' initial values: DCGP_<NAME>; a variable that is set but not a number counts as 1
 static void options_from_env(DcgpOptions* o) {
-  static const char* names[] = {"no_fused_layer", "fused_large", "fused_shape", "kl_side", "no_fused_bwd", "fused_bwd_min_cols", "head_unfused",
-                                "no_side_stream", "cu_partition", "grad_nofork", "chol_one_launch", "chol_no_lookahead", "head_no_overlap",
-                                "no_early_sweep", "sync_event", "kuf_upw", "chain_graph", "kuf_no_rep", "kuf_stream", "kuf_wpg", "kuf_split", "head_tail", "sweep_occ", "share_kb", "head_upw", "fused_abl", "rb_mixed"};
-  for (const char* n : names) {
+  for (const OptSlot& s : kOptSlots) {
     std::string e = "DCGP_";
-    for (const char* c = n; *c; ++c) e += (char)toupper((unsigned char)*c);
+    for (const char* c = s.name; *c; ++c) e += (char)toupper((unsigned char)*c);
     const char* v = getenv(e.c_str());
     if (!v) continue;
     char* end = nullptr;
     const long x = strtol(v, &end, 10);
-    *dcgp_option_slot(o, n) = (end != v) ? x : 1;
+    o->*s.field = (end != v) ? x : 1;
   }
 }
 

@@ -596,6 +596,7 @@ struct Bk {   // per-backward bookkeeping
   dcgp_ctx* ctx;
   std::string pfx;   // workspace prefix of the layer being processed
   int slot_v = 0, slot_l = 0, slot_b = 0;
+  bool kl_early = false;       // the layer being processed had its kl_products beside the forward pass (grad_kl_early)
   bool side_pending = false;   // a layer left the end of its reverse pass on the side stream: model_backward joins once, at the end
   double klw = 1.0;   // weight of the (replicated) KL term on this rank: 1 / number of batch shards
   double* ws(const char* name, size_t n_doubles) { return (double*)ws_get(ctx, pfx + "g_" + name, (n_doubles ? n_doubles : 1) * sizeof(double)); }
@@ -658,36 +659,47 @@ int add_scalars(Bk& bk, LayerState& L, std::initializer_list<ScalarPart> parts) 
   return reduce_sum_multi(bk.ctx, j, k);
 }
 
+// the hyper-parameter partial sums a Gram backward left in its scratch (`tag`) -> the layer's scalar slots
+int kuu_scalars(Bk& bk, LayerState& L, const char* tag) {
+  const std::string t(tag);
+  const int M = L.M;
+  if (L.base_type == 1) DCGP_TRY(add_scalar(bk, L, 2, bk.ws((t + "_pb").c_str(), M), M, 1.0));
+  return add_scalars(bk, L, {{0, bk.ws((t + "_pv").c_str(), M), M, 1.0}, {1, bk.ws((t + "_pl").c_str(), M), M, 1.0}});
+}
+
 // RBF Gram backward from S = d ELBO / dK (unsymmetrised).  dZ accumulates into L.gZ when Zsrc is the live Z (want_dz).
-int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, long lds, bool want_dz, double* dz_out = nullptr) {
+// tag: prefix of its scratch; defer_scalars: leave the hyper-parameter partial sums there (kuu_scalars adds them later -- the scalar
+// slots of a layer are zeroed at the start of its reverse pass, and the KL half of a frozen prior runs before that)
+int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, long lds, bool want_dz, double* dz_out = nullptr,
+                 const char* tag = "kuu", bool defer_scalars = false) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Ld = L.v.L;
   const double inv_l2 = 1.0 / (L.ls * L.ls), inv_l3 = inv_l2 / L.ls;
+  const std::string t(tag);
   double *Es = nullptr, *rs = nullptr;
-  double* pv = bk.ws("kuu_pv", M);
-  double* pl = bk.ws("kuu_pl", M);
+  double* pv = bk.ws((t + "_pv").c_str(), M);
+  double* pl = bk.ws((t + "_pl").c_str(), M);
   NEED(pv); NEED(pl);
-  if (want_dz) { Es = bk.ws("kuu_Es", (size_t)M * M); rs = bk.ws("kuu_rs", M); NEED(Es); NEED(rs); }
+  if (want_dz) { Es = bk.ws((t + "_Es").c_str(), (size_t)M * M); rs = bk.ws((t + "_rs").c_str(), M); NEED(Es); NEED(rs); }
   double cz = inv_l2;      // factor of the dZ combination: 1 / l^2 (RBF) or the weight variance (ArcCosine)
   if (L.base_type == 1) {
-    double* pb = bk.ws("kuu_pb", M);
-    double* znv = bk.ws("kuu_zn", M);
+    double* pb = bk.ws((t + "_pb").c_str(), M);
+    double* znv = bk.ws((t + "_zn").c_str(), M);
     NEED(pb); NEED(znv);
     hipLaunchKernelGGL(rownorm_kernel, dim3(blocks_for(M)), dim3(256), 0, ctx->stream, Zsrc, (long)M, Ld, znv);
     LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(acos_kuu_backward_kernel, dim3(M), dim3(256), 0, ctx->stream, Zsrc, znv, M, Ld, S, lds, L.variance, L.acos_w, L.acos_b,
                        Es, (long)M, rs, pv, pl, pb);
     LAUNCH_CHECK(ctx);
-    DCGP_TRY(add_scalar(bk, L, 2, pb, M, 1.0));
     cz = L.acos_w;
   } else {
     hipLaunchKernelGGL(kuu_backward_kernel, dim3(M), dim3(256), 0, ctx->stream, Zsrc, Zsrc == L.Z ? L.ZT : nullptr, L.Mp, M, Ld, S, lds, L.variance,
                        inv_l2, inv_l3, Es, (long)M, rs, pv, pl);
     LAUNCH_CHECK(ctx);
   }
-  DCGP_TRY(add_scalars(bk, L, {{0, pv, M, 1.0}, {1, pl, M, 1.0}}));
+  if (!defer_scalars) DCGP_TRY(kuu_scalars(bk, L, tag));
   if (want_dz) {
-    double* EX = bk.ws("kuu_EX", (size_t)M * Ld);
+    double* EX = bk.ws((t + "_EX").c_str(), (size_t)M * Ld);
     NEED(EX);
     DCGP_TRY(gemm_gen(ctx, mk(Es, M, 1, Zsrc, Ld, 1, EX, Ld, M, Ld, M)));
     hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for((long)M * Ld)), dim3(256), 0, ctx->stream, EX, rs, Zsrc, (long)M, Ld, cz, 1,
@@ -732,9 +744,52 @@ int patch_backward(Bk& bk, LayerState& L, const double* E, long ld, long Kc, con
   return DCGP_OK;
 }
 
-// KL backward of one layer (ELBO = ... - KL).  Returns with -dKL/dK_prior ADDED to Sacc [M x M, ld Mp] when Sacc != null
-// (head: the prior shares the live Z), otherwise pushed through the Gram backward on the frozen Z0 (conv layers).
-int kl_backward(Bk& bk, LayerState& L, double* Sacc) {
+// KL backward of one layer (ELBO = ... - KL), in two halves.
+// kl_products: everything that is a product of parameter-only matrices -- inv(K) q_mu, inv(K) Lq_r, -dKL/dK_prior -- into scratch.  The last one
+// goes into `Sacc` [M x M, ld Mp] (head: the prior shares the live Z; s_first: Sacc is written, otherwise added to) or, Sacc == null, through
+// the Gram backward on the frozen Z0 (conv layers), whose partial sums stay in scratch.  Nothing here reads the step's data or writes a
+// gradient buffer: grad_kl_early runs it beside the FORWARD pass, where the side stream is idle -- at the end of a layer's reverse pass
+// (fourteen short launches) it was the tail of the whole step.
+// kl_apply: adds the pieces to dq_mu / dq_sqrt and the scalar slots (a whitened layer has no products: its KL adjoint is q_mu and Lq themselves).
+int kl_products(Bk& bk, LayerState& L, double* Sacc, bool s_first) {
+  dcgp_ctx* ctx = bk.ctx;
+  if (L.white) return DCGP_OK;
+  const int M = L.M, Mp = L.Mp, R = L.R, Rp = L.g.Rp;
+  const long mm = (long)Mp * Mp;
+  const double kw = bk.klw;
+  const double* Lpinv = L.g.Kp ? L.g.Lpinv : L.g.Linv;
+  double* a1 = bk.ws("kl_a1", (size_t)Mp * Rp);
+  double* Kimu = bk.ws("kl_Kimu", (size_t)Mp * Rp);
+  double* Wm = bk.ws("kl_W", (size_t)R * mm);
+  double* KiL = bk.ws("kl_KiL", (size_t)R * mm);
+  NEED(a1); NEED(Kimu); NEED(Wm); NEED(KiL);
+  DCGP_TRY(gemm_gen(ctx, mk(Lpinv, Mp, 1, L.q_mu, R, 1, a1, Rp, M, R, M)));
+  DCGP_TRY(gemm_gen(ctx, mk(Lpinv, 1, Mp, a1, Rp, 1, Kimu, Rp, M, R, M)));
+  GenGemm g1 = mk(Lpinv, Mp, 1, L.g.Lq, Mp, 1, Wm, Mp, M, M, M);
+  g1.batch = R; g1.b_bs = mm; g1.c_bs = mm;
+  DCGP_TRY(gemm_gen(ctx, g1));
+  const long Rm = (long)R * Mp;
+  HIP_TRY(ctx, hipMemsetAsync(KiL, 0, (size_t)R * mm * sizeof(double), ctx->stream));
+  GenGemm g2 = mk(Lpinv, 1, Mp, Wm, Mp, 1, KiL, Rm, M, M, M);        // inv(K) Lq_r, stored [i][r][k]
+  g2.batch = R; g2.b_bs = mm; g2.c_bs = Mp;
+  DCGP_TRY(gemm_gen(ctx, g2));
+  // -dKL/dK = -1/2 [R inv(K) - (inv(K) q_mu)(inv(K) q_mu)^T - sum_r (inv(K) Lq_r)(inv(K) Lq_r)^T]
+  double* Sk = Sacc;
+  int acc = s_first ? 0 : 1;
+  if (!Sk) { Sk = bk.ws("kl_S", (size_t)mm); NEED(Sk); acc = 0; }
+  GenGemm g3 = mk(Lpinv, 1, Mp, Lpinv, Mp, 1, Sk, Mp, M, M, M);
+  g3.alpha = -0.5 * R * kw; g3.accumulate = acc;
+  DCGP_TRY(gemm_gen(ctx, g3));
+  GenGemm g4 = mk(Kimu, Rp, 1, Kimu, 1, Rp, Sk, Mp, M, M, R);
+  g4.alpha = 0.5 * kw; g4.accumulate = 1;
+  DCGP_TRY(gemm_gen(ctx, g4));
+  GenGemm g5 = mk(KiL, Rm, 1, KiL, 1, Rm, Sk, Mp, M, M, (int)Rm);     // all r at once, stacked along k
+  g5.alpha = 0.5 * kw; g5.accumulate = 1;
+  DCGP_TRY(gemm_gen(ctx, g5));
+  if (!Sacc) DCGP_TRY(kuu_backward(bk, L, L.Z0, Sk, Mp, false, nullptr, "klz", true));   // frozen Z0: hyper-parameters only
+  return DCGP_OK;
+}
+int kl_apply(Bk& bk, LayerState& L, bool frozen_prior) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Mp = L.Mp, R = L.R, Rp = L.g.Rp;
   const long mm = (long)Mp * Mp;
@@ -746,41 +801,16 @@ int kl_backward(Bk& bk, LayerState& L, double* Sacc) {
                        (long)M * M, M, -kw, 1);
     LAUNCH_CHECK(ctx);
   } else {
-    const double* Lpinv = L.g.Kp ? L.g.Lpinv : L.g.Linv;
-    double* a1 = bk.ws("kl_a1", (size_t)Mp * Rp);
-    double* Kimu = bk.ws("kl_Kimu", (size_t)Mp * Rp);
-    double* Wm = bk.ws("kl_W", (size_t)R * mm);
-    double* KiL = bk.ws("kl_KiL", (size_t)R * mm);
-    NEED(a1); NEED(Kimu); NEED(Wm); NEED(KiL);
-    DCGP_TRY(gemm_gen(ctx, mk(Lpinv, Mp, 1, L.q_mu, R, 1, a1, Rp, M, R, M)));
-    DCGP_TRY(gemm_gen(ctx, mk(Lpinv, 1, Mp, a1, Rp, 1, Kimu, Rp, M, R, M)));
+    const long Rm = (long)R * Mp;
+    const double* Kimu = bk.ws("kl_Kimu", (size_t)Mp * Rp);
+    const double* KiL = bk.ws("kl_KiL", (size_t)R * mm);
+    NEED(Kimu); NEED(KiL);
     hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(R), M), dim3(256), 0, ctx->stream, Kimu, (long)Rp, L.gq_mu, (long)R, M, R, -kw, 1);
     LAUNCH_CHECK(ctx);
-    GenGemm g1 = mk(Lpinv, Mp, 1, L.g.Lq, Mp, 1, Wm, Mp, M, M, M);
-    g1.batch = R; g1.b_bs = mm; g1.c_bs = mm;
-    DCGP_TRY(gemm_gen(ctx, g1));
-    const long Rm = (long)R * Mp;
-    HIP_TRY(ctx, hipMemsetAsync(KiL, 0, (size_t)R * mm * sizeof(double), ctx->stream));
-    GenGemm g2 = mk(Lpinv, 1, Mp, Wm, Mp, 1, KiL, Rm, M, M, M);        // inv(K) Lq_r, stored [i][r][k]
-    g2.batch = R; g2.b_bs = mm; g2.c_bs = Mp;
-    DCGP_TRY(gemm_gen(ctx, g2));
     hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, KiL, Rm, (long)Mp, L.gq_sqrt, (long)M,
                        (long)M * M, M, -kw, 1);
     LAUNCH_CHECK(ctx);
-    // -dKL/dK = -1/2 [R inv(K) - (inv(K) q_mu)(inv(K) q_mu)^T - sum_r (inv(K) Lq_r)(inv(K) Lq_r)^T]
-    double* Sk = Sacc;
-    int acc = 1;
-    if (!Sk) { Sk = bk.ws("kl_S", (size_t)mm); NEED(Sk); acc = 0; }
-    GenGemm g3 = mk(Lpinv, 1, Mp, Lpinv, Mp, 1, Sk, Mp, M, M, M);
-    g3.alpha = -0.5 * R * kw; g3.accumulate = acc;
-    DCGP_TRY(gemm_gen(ctx, g3));
-    GenGemm g4 = mk(Kimu, Rp, 1, Kimu, 1, Rp, Sk, Mp, M, M, R);
-    g4.alpha = 0.5 * kw; g4.accumulate = 1;
-    DCGP_TRY(gemm_gen(ctx, g4));
-    GenGemm g5 = mk(KiL, Rm, 1, KiL, 1, Rm, Sk, Mp, M, M, (int)Rm);     // all r at once, stacked along k
-    g5.alpha = 0.5 * kw; g5.accumulate = 1;
-    DCGP_TRY(gemm_gen(ctx, g5));
-    if (!Sacc) DCGP_TRY(kuu_backward(bk, L, L.Z0, Sk, Mp, false));   // frozen Z0: hyper-parameters only
+    if (frozen_prior) DCGP_TRY(kuu_scalars(bk, L, "klz"));
   }
   hipLaunchKernelGGL(kl_diag_kernel, dim3(blocks_for((long)M * R)), dim3(256), 0, ctx->stream, L.gq_sqrt, L.g.Lq, M, Mp, R, kw);
   LAUNCH_CHECK(ctx);
@@ -790,8 +820,9 @@ int kl_backward(Bk& bk, LayerState& L, double* Sacc) {
 // The conditional's backward shared by conv layers and the head.  Kuf, A1: [Mp x ld] with Kc live columns;
 // gm, gv: [Kc][R].  Leaves dKuf in `dKuf` [M x ld], writes L.gq_mu / L.gq_sqrt (overwrites), and S = d ELBO / dKuu
 // (data part) in `S` [M x M, ld Mp]; gvs [Kc] = sum_r gv (= d ELBO / d Knn).
+// s_acc: S already holds the KL part of d ELBO / dKuu (kl_products ran first): add to it.
 int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, const double* gm, const double* gv, double* dKuf, double* S,
-                  double* gvs) {
+                  double* gvs, bool s_acc = false) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Mp = L.Mp, R = L.R, Rp = L.g.Rp;
   const long mm = (long)Mp * Mp;
@@ -828,64 +859,61 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
     DCGP_TRY(gemm_gen(ctx, sg));
     fb.S = Sgg;
   }
-  // Two independent chains from here.  Side stream: everything that ends in an M x M result (d alpha, W_r -> dG_r ->
-  // dq_sqrt, the first two dL terms) -- long split-k contractions at ~40 % MFMA utilisation.  Main stream: dT, dA1, dK_uf
-  // on the tuned kernel.  They share only read-only inputs; the join is in front of the third dL term.
+  // Two independent chains from here.  Side stream: the M x M results that cost a long contraction over the columns and the chain behind
+  // them (W_r -> dG_r -> dq_sqrt, the dq_sqrt term of dL) -- split-k products at ~40 % MFMA utilisation.  Main stream: dT, dA1, dK_uf on
+  // the tuned kernel, then the short chain d alpha -> dq_mu.  They share only read-only inputs; the join is in front of dL's other terms.
+  // (d alpha used to open the side chain: beside the strip kernel its 288 small workgroups took 108 us instead of 8, in front of W_r)
   hipStream_t main_s = ctx->stream;
   const bool nofork = ctx->opt.grad_nofork != 0;   // A/B switch
-  const bool fork = !nofork && !ctx->no_side && ctx->stream2 && ctx->stream2 != main_s;
+  const bool fork = !nofork && !ctx->no_side && ctx->stream2 && ctx->stream2 != main_s && L.has_qsqrt;
   // (the fork point is marked here; the side chain is ENQUEUED behind the main chain: one host thread feeds both streams at ~5 us a launch, and
   // with few columns -- the head -- the main chain's launches are as short as that: fed second, it sat idle while the host was busy with the side
-  // chain's fourteen launches)
+  // chain's launches)
   if (fork) HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, main_s));
   auto side_chain = [&]() -> int {
-    // d alpha = A1 gm
-    DCGP_TRY(gemm_gen(ctx, mk(A1, ld, 1, gm, R, 1, dalpha, Rp, M, R, (int)Kc)));
-    if (L.has_qsqrt) {
-      // dG_r = tril(A1 dT_r^T) = tril(W_r G_r),  W_r = 2 A1 diag(gv_r) A1^T (symmetric).  Both operands of the long
-      // contraction are then A1 itself (94 MB at the headline size: it stays in the 256 MB Infinity Cache across the R
-      // batches, where the R x larger dT would stream from HBM); lower tiles only, mirrored afterwards.
-      double* Wr = bk.ws("Wr", (size_t)R * mm);
-      NEED(Wr);
-      GenGemm w = mk(A1, ld, 1, A1, 1, ld, Wr, Mp, M, M, (int)Kc);
-      // (the k scaling reads gv [Kc][R] in place, stride R: a transposed copy used to cost 290 us of scattered 8-byte stores per step)
-      w.batch = R; w.c_bs = mm; w.lower_only = 1; w.alpha = 2.0; w.kscale = gv; w.ks_s = R; w.ks_bs = 1;
-      DCGP_TRY(gemm_gen(ctx, w));
-      hipLaunchKernelGGL(mirror_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Wr, (long)Mp, mm, M);
+    if (!L.has_qsqrt) return DCGP_OK;
+    // dG_r = tril(A1 dT_r^T) = tril(W_r G_r),  W_r = 2 A1 diag(gv_r) A1^T (symmetric).  Both operands of the long
+    // contraction are then A1 itself (94 MB at the headline size: it stays in the 256 MB Infinity Cache across the R
+    // batches, where the R x larger dT would stream from HBM); lower tiles only, mirrored afterwards.
+    double* Wr = bk.ws("Wr", (size_t)R * mm);
+    NEED(Wr);
+    GenGemm w = mk(A1, ld, 1, A1, 1, ld, Wr, Mp, M, M, (int)Kc);
+    // (the k scaling reads gv [Kc][R] in place, stride R: a transposed copy used to cost 290 us of scattered 8-byte stores per step)
+    w.batch = R; w.c_bs = mm; w.lower_only = 1; w.alpha = 2.0; w.kscale = gv; w.ks_s = R; w.ks_bs = 1;
+    DCGP_TRY(gemm_gen(ctx, w));
+    hipLaunchKernelGGL(mirror_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Wr, (long)Mp, mm, M);
+    LAUNCH_CHECK(ctx);
+    GenGemm d = mk(Wr, Mp, 1, g.G, Mp, 1, dG, Mp, M, M, M);
+    d.batch = R; d.a_bs = mm; d.b_bs = mm; d.c_bs = mm; d.lower_only = 1;
+    DCGP_TRY(gemm_gen(ctx, d));
+    if (L.white) {
+      hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, dG, (long)Mp, mm, L.gq_sqrt, (long)M,
+                         (long)M * M, M, 1.0, 0);
       LAUNCH_CHECK(ctx);
-      GenGemm d = mk(Wr, Mp, 1, g.G, Mp, 1, dG, Mp, M, M, M);
-      d.batch = R; d.a_bs = mm; d.b_bs = mm; d.c_bs = mm; d.lower_only = 1;
-      DCGP_TRY(gemm_gen(ctx, d));
+    } else {
+      double* Bm = bk.ws("Bm", (size_t)R * mm);                      // B_r = inv(L)^T dG_r, stored [i][r][k]
+      NEED(Bm);
+      HIP_TRY(ctx, hipMemsetAsync(Bm, 0, (size_t)R * mm * sizeof(double), ctx->stream));
+      GenGemm b = mk(g.Linv, 1, Mp, dG, Mp, 1, Bm, Rm, M, M, M);
+      b.batch = R; b.b_bs = mm; b.c_bs = Mp;
+      DCGP_TRY(gemm_gen(ctx, b));
+      hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Bm, Rm, (long)Mp, L.gq_sqrt, (long)M,
+                         (long)M * M, M, 1.0, 0);
+      LAUNCH_CHECK(ctx);
+      GenGemm l2 = mk(Bm, Rm, 1, GT, Mp, 1, dL, Mp, M, M, (int)Rm);   // dL = -tril(sum_r B_r G_r^T), stacked along k: the first of dL's terms
+      l2.alpha = -1.0; l2.lower_only = 1;
+      DCGP_TRY(gemm_gen(ctx, l2));
     }
+    return DCGP_OK;
+  };
+  // d alpha = A1 gm;  dq_mu = d alpha (whitened) or inv(L)^T d alpha
+  auto alpha_chain = [&]() -> int {
+    DCGP_TRY(gemm_gen(ctx, mk(A1, ld, 1, gm, R, 1, dalpha, Rp, M, R, (int)Kc)));
     if (L.white) {
       hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(R), M), dim3(256), 0, ctx->stream, dalpha, (long)Rp, L.gq_mu, (long)R, M, R, 1.0, 0);
       LAUNCH_CHECK(ctx);
-      if (L.has_qsqrt) {
-        hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, dG, (long)Mp, mm, L.gq_sqrt, (long)M,
-                           (long)M * M, M, 1.0, 0);
-        LAUNCH_CHECK(ctx);
-      }
-      HIP_TRY(ctx, hipMemsetAsync(dL, 0, mm * sizeof(double), ctx->stream));
     } else {
-      // dq_mu = inv(L)^T d alpha;  dL = -tril(dq_mu alpha^T)
       DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dalpha, Rp, 1, L.gq_mu, R, M, R, M)));
-      GenGemm l1 = mk(L.gq_mu, R, 1, g.alpha, 1, Rp, dL, Mp, M, M, R);
-      l1.alpha = -1.0; l1.lower_only = 1;
-      DCGP_TRY(gemm_gen(ctx, l1));
-      if (L.has_qsqrt) {
-        double* Bm = bk.ws("Bm", (size_t)R * mm);                      // B_r = inv(L)^T dG_r, stored [i][r][k]
-        NEED(Bm);
-        HIP_TRY(ctx, hipMemsetAsync(Bm, 0, (size_t)R * mm * sizeof(double), ctx->stream));
-        GenGemm b = mk(g.Linv, 1, Mp, dG, Mp, 1, Bm, Rm, M, M, M);
-        b.batch = R; b.b_bs = mm; b.c_bs = Mp;
-        DCGP_TRY(gemm_gen(ctx, b));
-        hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Bm, Rm, (long)Mp, L.gq_sqrt, (long)M,
-                           (long)M * M, M, 1.0, 0);
-        LAUNCH_CHECK(ctx);
-        GenGemm l2 = mk(Bm, Rm, 1, GT, Mp, 1, dL, Mp, M, M, (int)Rm);   // dL -= tril(sum_r B_r G_r^T), stacked along k
-        l2.alpha = -1.0; l2.lower_only = 1; l2.accumulate = 1;
-        DCGP_TRY(gemm_gen(ctx, l2));
-      }
     }
     return DCGP_OK;
   };
@@ -961,10 +989,19 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
       DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dA1, ld, 1, dKuf, ld, M, (int)Kc, M)));
     }
   }
+  DCGP_TRY(alpha_chain());
   DCGP_TRY(run_side());
-  if (fork) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux2, 0));   // join: dL's first terms, dq_mu, dq_sqrt are done
+  if (fork) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux2, 0));   // join: dq_sqrt and its term of dL are done
+  // dL = -tril(sum_r B_r G_r^T [side chain, unwhitened with q_sqrt] + dq_mu alpha^T [unwhitened] + dKuf A1^T)
+  int dl_acc = (!L.white && L.has_qsqrt) ? 1 : 0;
+  if (!L.white) {
+    GenGemm l1 = mk(L.gq_mu, R, 1, g.alpha, 1, Rp, dL, Mp, M, M, R);
+    l1.alpha = -1.0; l1.lower_only = 1; l1.accumulate = dl_acc;
+    DCGP_TRY(gemm_gen(ctx, l1));
+    dl_acc = 1;
+  }
   GenGemm l3 = mk(dKuf, ld, 1, A1, 1, ld, dL, Mp, M, M, (int)Kc);
-  l3.alpha = -1.0; l3.lower_only = 1; l3.accumulate = 1;
+  l3.alpha = -1.0; l3.lower_only = 1; l3.accumulate = dl_acc;
   DCGP_TRY(gemm_gen(ctx, l3));
   // Cholesky adjoint: S = inv(L)^T Phi(L^T dL) inv(L)
   double* Lc = bk.ws("Lc", (size_t)mm);
@@ -977,7 +1014,9 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   hipLaunchKernelGGL(phi_kernel, dim3(blocks_for(M), M), dim3(256), 0, ctx->stream, Pm, (long)Mp, M);
   LAUNCH_CHECK(ctx);
   DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, Pm, Mp, 1, S1, Mp, M, M, M)));
-  DCGP_TRY(gemm_gen(ctx, mk(S1, Mp, 1, g.Linv, Mp, 1, S, Mp, M, M, M)));
+  GenGemm sf = mk(S1, Mp, 1, g.Linv, Mp, 1, S, Mp, M, M, M);
+  sf.accumulate = s_acc ? 1 : 0;
+  DCGP_TRY(gemm_gen(ctx, sf));
   return DCGP_OK;
 }
 
@@ -1060,7 +1099,8 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
     *forked = side.active;
     DCGP_TRY(add_scalar(bk, L, 0, gvs, Kc, 1.0));                  // Knn = variance on every column
     DCGP_TRY(kuu_backward(bk, L, L.Z, S, Mp, true));
-    DCGP_TRY(kl_backward(bk, L, nullptr));
+    if (!bk.kl_early) DCGP_TRY(kl_products(bk, L, nullptr, false));
+    DCGP_TRY(kl_apply(bk, L, true));
     if (side.active) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux, 0));   // (the side stream: behind the main stream's part of the layer)
     hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(Ld), M), dim3(256), 0, ctx->stream, dzp, (long)Ld, L.gZ, (long)Ld, M, Ld, 1.0, 1);
     LAUNCH_CHECK(ctx);
@@ -1157,8 +1197,9 @@ int dense_head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int 
   NEED(A1); NEED(dKzx); NEED(S); NEED(gkd); NEED(cs); NEED(Zs); NEED(Xs); NEED(dZs); NEED(dXs);
   if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(A1 + (size_t)M * ld, 0, (size_t)(Mp - M) * ld * sizeof(double), ctx->stream));
   DCGP_TRY(gemm_gen(ctx, mk(L.g.Linv, Mp, 1, Kzx, ld, 1, A1, ld, M, rows, M)));
-  DCGP_TRY(cond_backward(bk, L, A1, ld, rows, gm, gv, dKzx, S, gkd));
-  DCGP_TRY(kl_backward(bk, L, L.white ? nullptr : S));
+  DCGP_TRY(cond_backward(bk, L, A1, ld, rows, gm, gv, dKzx, S, gkd, bk.kl_early && !L.white));
+  if (!bk.kl_early) DCGP_TRY(kl_products(bk, L, L.white ? nullptr : S, false));
+  DCGP_TRY(kl_apply(bk, L, false));
   DCGP_TRY(add_scalar(bk, L, 0, gkd, rows, 1.0));             // Kdiag = variance
   hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks_for((long)M * D)), dim3(256), 0, ctx->stream, L.Z, M, (long)M, D, L.in_scale, Zs);
   LAUNCH_CHECK(ctx);
@@ -1199,7 +1240,7 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   NEED(A1); NEED(dKzx); NEED(S); NEED(gkd); NEED(Kfull); NEED(E); NEED(cs); NEED(raw); NEED(Xcol); NEED(dXcol);
   if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(A1 + (size_t)M * ld, 0, (size_t)(Mp - M) * ld * sizeof(double), ctx->stream));   // padded rows: operands of gemm_tn
   DCGP_TRY(gemm_gen(ctx, mk(L.g.Linv, Mp, 1, Kzx, ld, 1, A1, ld, M, rows, M)));      // the fused forward keeps A1 on chip
-  DCGP_TRY(cond_backward(bk, L, A1, ld, rows, gm, gv, dKzx, S, gkd));
+  DCGP_TRY(cond_backward(bk, L, A1, ld, rows, gm, gv, dKzx, S, gkd, bk.kl_early && !L.white));
   // as in conv_backward: KL + Gram adjoints on the side stream, the patch-kernel adjoints (K_zx, K_diag) on the main one
   double* dzp = bk.ws("dz_patch", (size_t)M * Ld);
   NEED(dzp);
@@ -1273,7 +1314,8 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));
   {
     SideScope side(ctx, ctx->ev_fork, true);
-    if (!L.white) DCGP_TRY(kl_backward(bk, L, S)); else DCGP_TRY(kl_backward(bk, L, nullptr));
+    if (!bk.kl_early) DCGP_TRY(kl_products(bk, L, L.white ? nullptr : S, false));
+    DCGP_TRY(kl_apply(bk, L, false));
     DCGP_TRY(kuu_backward(bk, L, L.Z, S, Mp, true));
     if (side.active) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux, 0));
     hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(Ld), M), dim3(256), 0, ctx->stream, dzp, (long)Ld, L.gZ, (long)Ld, M, Ld, 1.0, 1);
@@ -1287,6 +1329,45 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
 
 }  // namespace
 
+static double kl_weight(const dcgp_model* m) {
+  // the data term is summed over the batch shards (ranks); the KL term is replicated, so each shard carries 1 / shards of it
+  const int shards = m->grad_shards > 0 ? m->grad_shards : (m->ctx->comm ? m->ctx->nranks : 1);
+  return 1.0 / shards;
+}
+
+// Called by the forward pass of a training step (forward_all, model.hip): the KL adjoint's products of every unwhitened layer go to the
+// side stream, beside the layers of the forward pass (see model_state.h for the two calls).
+int grad_kl_early(dcgp_model* m, bool enqueue, bool wait_fork) {
+  dcgp_ctx* ctx = m->ctx;
+  const int nl = (int)m->layers.size();
+  for (bool& f : m->kl_early) f = false;
+  const bool side = !ctx->opt.grad_nofork && !ctx->no_side && ctx->stream2;
+  if (ctx->opt.grad_late_kl || !side || nl > 8) return DCGP_OK;
+  if (!enqueue) return 1;
+  Bk bk;
+  bk.m = m; bk.ctx = ctx; bk.klw = kl_weight(m);
+  hipStream_t saved = ctx->stream;
+  if (wait_fork) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+  ctx->stream = ctx->stream2;
+  const std::string mp = "m" + std::to_string(m->id) + "_";
+  int rc = DCGP_OK;
+  for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
+    LayerState& L = *m->layers[li];
+    if (L.white) continue;
+    bk.pfx = mp + std::to_string(li) + "_";
+    double* Sacc = nullptr;
+    if (L.is_head) {   // the head's prior shares the live Z: its part of d ELBO / dKuu opens the buffer cond_backward adds to
+      Sacc = bk.ws("S", (size_t)L.Mp * L.Mp);
+      if (!Sacc) { rc = DCGP_ERR_ALLOC; break; }
+    }
+    rc = kl_products(bk, L, Sacc, true);
+    if (rc == DCGP_OK) m->kl_early[li] = true;
+  }
+  ctx->stream = saved;
+  if (rc != DCGP_OK) { hipStreamSynchronize(ctx->stream2); for (bool& f : m->kl_early) f = false; }
+  return rc;
+}
+
 int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, double scale, int dedup_layer0) {
   dcgp_ctx* ctx = m->ctx;
   const int nl = (int)m->layers.size(), S = m->S;
@@ -1298,9 +1379,7 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
   if (!gh) return DCGP_ERR_ALLOC;
   Bk bk;
   bk.m = m; bk.ctx = ctx;
-  // the data term is summed over the batch shards (ranks); the KL term is replicated, so each shard carries 1 / shards of it
-  const int shards = m->grad_shards > 0 ? m->grad_shards : (ctx->comm ? ctx->nranks : 1);
-  bk.klw = 1.0 / shards;
+  bk.klw = kl_weight(m);
   const std::string mp = "m" + std::to_string(m->id) + "_";
   LayerState& H = *m->layers[nl - 1];
   auto& oh = m->outs[nl - 1];
@@ -1316,6 +1395,8 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
   for (int li = nl - 1; li >= 0; --li) {
     LayerState& L = *m->layers[li];
     bk.pfx = mp + std::to_string(li) + "_";
+    bk.kl_early = li < 8 && m->kl_early[li];
+    if (li < 8) m->kl_early[li] = false;
     const double* Xin = li == 0 ? X : m->outs[li - 1].sample;
     int rows_l = m->outs[li].rows;                  // rows entering == rows leaving ...
     // ... except for a de-duplicated first conv layer: propagate() tiles the batch S times, so layer 0 saw S identical
@@ -1368,10 +1449,30 @@ int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, 
   const bool keep = model->keep_outputs;
   model->keep_outputs = true;   // the reverse pass reads every layer's (sample, mean, var)
   model->keep_state = true;     // ... and K_uf / A1 of every conv layer
-  int rc = elbo_forward_impl(model, X, y, N, scale, z_per_layer_host, seed, dedup_layer0, out_host, info_host);
+  model->grad_follows = true;   // ... and marks where the parameter-only part of the reverse pass may start (grad_kl_early)
+  // The forward pass is ENQUEUED, the reverse pass behind it, and only then is the forward's result collected: the host does not wait for
+  // the ELBO before it feeds the ~110 launches of the reverse pass (a failed factorisation is reported all the same; the reverse pass then
+  // ran on NaNs, which nothing reads).
+  uint64_t ticket = 0;
+  if (info_host) *info_host = 0;
+  int rc = model->enq_seq != model->col_seq ? ctx_fail(ctx, DCGP_ERR_ARG, "elbo_grad: enqueued steps are still to be collected")
+                                             : elbo_forward_enqueue_impl(model, X, y, N, scale, z_per_layer_host, seed, dedup_layer0, &ticket);
+  const bool enqueued = rc == DCGP_OK;
+  if (rc == DCGP_OK && model->gkl_state) rc = grad_kl_early(model, true, model->gkl_state == 2);
   if (rc == DCGP_OK) rc = model_backward(model, X, y, N, scale, dedup_layer0);
+  if (enqueued) {
+    const int rc_f = elbo_forward_collect_impl(model, ticket, out_host, info_host);
+    if (rc == DCGP_OK) rc = rc_f;
+  }
   model->keep_outputs = keep;
   model->keep_state = false;
+  model->grad_follows = false;
+  model->gkl_state = 0;
+  if (rc != DCGP_OK) {
+    for (bool& f : model->kl_early) f = false;
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
+  }
   DCGP_TRY(rc);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return DCGP_OK;

@@ -343,6 +343,14 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     hipStreamSynchronize(chain_s);
     return rc;
   }
+  // A training step: the parameter-only part of the reverse pass (grad.hip, grad_kl_early) may start HERE on the side stream -- the point is
+  // marked, its thirty launches are enqueued by dcgp_elbo_grad behind the whole forward pass (in front of the layers below the host kept
+  // the first layer waiting for 170 us, in front of the tail launch the end of the forward pass for 60)
+  m->gkl_state = 0;
+  if (m->grad_follows && !pipelined && grad_kl_early(m, false, false) == 1) {
+    m->gkl_state = chain_s != ctx->stream2 ? 2 : 1;
+    if (m->gkl_state == 2) HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, chain_s));
+  }
 
   // sweeps read Z^T / |z|^2 of this bank (a one-launch first layer waits for its G / alpha, recorded behind them on the same stream)
   if (chain_s != main_s && !first_fused) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_sweep[bank], 0));

@@ -11,6 +11,9 @@ struct dcgp_model {
   bool has_head = false;
   bool keep_outputs = false;
   bool keep_state = false;   // the forward leaves K_uf / A1 of every conv layer in HBM (set around the forward of dcgp_elbo_grad)
+  bool grad_follows = false; // set around the forward of dcgp_elbo_grad: forward_all hands the parameter-only part of the reverse pass to the side stream
+  int gkl_state = 0;         // forward_all of such a step: 0 nothing to hand over, 1 the side stream itself holds the parameter-only chain, 2 it waits for ctx->ev_fork
+  bool kl_early[8] = {};     // per layer: grad_kl_early enqueued its kl_products for the step in flight (consumed by model_backward)
   int adam_t = 0;        // Adam steps taken on this model's moment buffers (bias correction; dcgp_model_adam_step with t = 0)
   int shard_lo = 0, shard_global = 0;   // this rank's first image and the global batch (dcgp_model_set_shard): device-RNG counters
   int grad_shards = 0;   // KL gradient weight 1 / shards; 0 = number of ranks of the ctx's communicator (1 without one)
@@ -67,3 +70,6 @@ int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t*
 int elbo_forward_collect_impl(dcgp_model* model, uint64_t ticket, double* out_host, int* info_host);
 // grad.hip: reverse pass over the state the forward left behind; fills every layer's gradient buffers
 int model_backward(dcgp_model* model, const double* X, const int32_t* y, int N, double scale, int dedup_layer0);
+// enqueue == false: 1 if a training step's forward should hand the KL adjoint's products to the side stream, else 0;
+// enqueue == true: do it (wait_fork: behind ctx->ev_fork, recorded where the parameter-only chain ended)
+int grad_kl_early(dcgp_model* model, bool enqueue, bool wait_fork);
