@@ -188,7 +188,7 @@ __global__ __launch_bounds__(1024) void reduce_sum_kernel(const double* __restri
   if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 
-// up to four independent sums in one launch (one workgroup each; the same summation order as reduce_sum_kernel)
+// up to REDUCE_JOBS_MAX independent sums in one launch (one workgroup each; the same summation order as reduce_sum_kernel)
 __global__ __launch_bounds__(1024) void reduce_sum_multi_kernel(ReduceJobs j) {
   __shared__ double red[1024];
   const int k = blockIdx.x;
@@ -299,7 +299,7 @@ int reduce_sum(dcgp_ctx* ctx, const double* in, long n, double scale, double* ou
 
 int reduce_sum_multi(dcgp_ctx* ctx, const ReduceJobs& jobs, int count) {
   if (count <= 0) return DCGP_OK;
-  if (count > 4) return ctx_fail(ctx, DCGP_ERR_ARG, "reduce_sum_multi: at most 4 sums per launch");
+  if (count > REDUCE_JOBS_MAX) return ctx_fail(ctx, DCGP_ERR_ARG, "reduce_sum_multi: at most %d sums per launch", REDUCE_JOBS_MAX);
   hipLaunchKernelGGL(reduce_sum_multi_kernel, dim3(count), dim3(1024), 0, ctx->stream, jobs);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 4) void gemm_gen_kernel(GenGem
         if (i >= g.M || j >= g.N) continue;
         double v = acc[fi][fj][q];
         if (!split) {
+          if (g.sub_v) v -= g.sub_v[(long)b * g.sv_bs + i] * g.sub_x[(long)b * g.sx_bs + (long)i * g.sx_rs + j];
           v *= g.alpha;
           if (g.colscale) v *= g.colscale[(long)j * g.cs_s + (long)b * g.cs_bs];
           if (g.lower_only && j > i) v = 0.0;
@@ -182,6 +183,7 @@ __global__ void splitk_reduce_kernel(GenGemm g, int ksplit, const double* part) 
     for (int u = 0; u < 8; ++u) v += t[u];
   }
   for (; s < ksplit; ++s) v += part[(long)s * total + idx];
+  if (g.sub_v) v -= g.sub_v[(long)b * g.sv_bs + i] * g.sub_x[(long)b * g.sx_bs + (long)i * g.sx_rs + j];
   v *= g.alpha;
   if (g.colscale) v *= g.colscale[(long)j * g.cs_s + (long)b * g.cs_bs];
   if (g.lower_only && j > i) v = 0.0;

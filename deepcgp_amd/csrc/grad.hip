@@ -232,15 +232,20 @@ __global__ __launch_bounds__(256) void kuu_backward_kernel(const double* __restr
 
 // ---- patch kernels backward -------------------------------------------------------------------------------------
 // Xcol[c][l], c = n * P + p, l = (kh * f + kw) * C + ch  (FullView.extract_patches, conv_gp/views.py:46-54)
-__global__ void im2col_kernel(const double* __restrict__ X, int n_mod, int H, int W, int C, int f, int s, int Wo, int P, int L, long Kc,
-                              double* __restrict__ Xcol) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Kc * L) return;
-  const long c = idx / L;
-  const int l = (int)(idx % L);
-  const int n = (int)(c / P), p = (int)(c % P);
-  const int oh = p / Wo, ow = p % Wo, ch = l % C, kw = (l / C) % f, kh = l / (C * f);
-  Xcol[idx] = X[(((long)(n % n_mod) * H + oh * s + kh) * W + ow * s + kw) * C + ch];
+// rpb patches per 256-thread block, thread (r, l): 32-bit index arithmetic only (one thread per element with 64-bit divisions: 26 us for the
+// head's 41 MB at the headline size)
+__global__ __launch_bounds__(256) void im2col_kernel(const double* __restrict__ X, int n_mod, int H, int W, int C, int f, int s, int Wo, int P,
+                                                     int L, int Kc, int rpb, double* __restrict__ Xcol) {
+  for (int l0 = 0; l0 < L; l0 += 256) {   // L > 256: the block takes one patch, in passes
+    const int t = threadIdx.x + l0;
+    const int r = L >= 256 ? 0 : t / L, l = L >= 256 ? t : t - r * L;
+    const int c = blockIdx.x * rpb + r;
+    if (r >= rpb || l >= L || c >= Kc) continue;
+    const int n = c / P, p = c - n * P;
+    const int oh = p / Wo, ow = p - oh * Wo;
+    const int q = l / C, ch = l - q * C, kh = q / f, kw = q - kh * f;
+    Xcol[(long)c * L + l] = X[(((long)(n % n_mod) * H + oh * s + kh) * W + ow * s + kw) * C + ch];
+  }
 }
 
 // dX[n][h][w][ch] = sum over the patches that contain the pixel (adjoint of extract_patches; gather, no atomics)
@@ -315,6 +320,16 @@ __global__ __launch_bounds__(256) void e_form_kernel(const double* __restrict__ 
   }
 }
 
+// the same for two arrays at once (e_form: column sums of E and of dK o K)
+__global__ void sum_chunks2_kernel(const double* __restrict__ pa, const double* __restrict__ pb, int chunks, long n, double* __restrict__ oa,
+                                   double* __restrict__ ob) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double a = 0.0, b = 0.0;
+  for (int ch = 0; ch < chunks; ++ch) { a += pa[(long)ch * n + i]; b += pb[(long)ch * n + i]; }
+  oa[i] = a;
+  ob[i] = b;
+}
 // out[i] = sum_ch part[ch][i]
 __global__ void sum_chunks_kernel(const double* __restrict__ part, int chunks, long n, double* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -334,16 +349,6 @@ __global__ __launch_bounds__(256) void rowsum_big_kernel(const double* __restric
   for (long c = c0 + threadIdx.x; c < c1; c += 256) s += A[m * ld + c];
   const double r = block_sum_256(s, red);
   if (threadIdx.x == 0) part[(long)blockIdx.y * M + m] = r;
-}
-
-// dst[i][l] (+)= alpha * (P[i][l] - v[i] * X[i][l])
-__global__ void axmy_kernel(const double* __restrict__ Pm, const double* __restrict__ v, const double* __restrict__ X, long rows, int L,
-                            double alpha, int accumulate, double* __restrict__ dst) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * L) return;
-  const long i = idx / L;
-  const double val = alpha * (Pm[idx] - v[i] * X[idx]);
-  dst[idx] = accumulate ? dst[idx] + val : val;
 }
 
 // out[p] (+)= scale * sum_n raw[n * P + p]: one block per p
@@ -596,6 +601,10 @@ struct Bk {   // per-backward bookkeeping
   dcgp_ctx* ctx;
   std::string pfx;   // workspace prefix of the layer being processed
   int slot_v = 0, slot_l = 0, slot_b = 0;
+  // hyper-parameter partial sums of the layer being processed: collected here, reduced into the layer's scalar slots by ONE launch at the end of
+  // its reverse pass (end_layer; they feed nothing else, and each used to be a 5 us launch in the middle of the data path)
+  struct PendingSum { const double* in; long n; double scale; double* out; };
+  std::vector<PendingSum> pending;
   bool kl_early = false;       // the layer being processed had its kl_products beside the forward pass (grad_kl_early)
   bool side_pending = false;   // a layer left the end of its reverse pass on the side stream: model_backward joins once, at the end
   double klw = 1.0;   // weight of the (replicated) KL term on this rank: 1 / number of batch shards
@@ -635,28 +644,40 @@ GenGemm mk(const double* A, long ars, long acs, const double* B, long brs, long 
 
 #define NEED(p) do { if (!(p)) return DCGP_ERR_ALLOC; } while (0)
 
-// add scale * sum(part[0..n)) to the next slot of the layer: which = 0 variance, 1 lengthscale | acos weight variance, 2 acos bias variance
+// scale * sum(part[0..n)) goes to the next slot of the layer: which = 0 variance, 1 lengthscale | acos weight variance, 2 acos bias variance
 int add_scalar(Bk& bk, LayerState& L, int which, const double* part, long n, double scale) {
   int& s = which == 0 ? bk.slot_v : (which == 1 ? bk.slot_l : bk.slot_b);
   if (s >= 16) return ctx_fail(bk.ctx, DCGP_ERR_ARG, "grad: out of scalar slots");
-  DCGP_TRY(reduce_sum(bk.ctx, part, n, scale, L.gslots + (which == 0 ? VAR_SLOT : (which == 1 ? LS_SLOT : P2_SLOT)) + s));
+  bk.pending.push_back({part, n, scale, L.gslots + (which == 0 ? VAR_SLOT : (which == 1 ? LS_SLOT : P2_SLOT)) + s});
   ++s;
   return DCGP_OK;
 }
-
-// several hyper-parameter partial sums in one launch
 struct ScalarPart { int which; const double* part; long n; double scale; };
 int add_scalars(Bk& bk, LayerState& L, std::initializer_list<ScalarPart> parts) {
-  ReduceJobs j{};
-  int k = 0;
-  for (const ScalarPart& p : parts) {
-    int& s = p.which == 0 ? bk.slot_v : (p.which == 1 ? bk.slot_l : bk.slot_b);
-    if (s >= 16 || k >= 4) return ctx_fail(bk.ctx, DCGP_ERR_ARG, "grad: out of scalar slots");
-    j.in[k] = p.part; j.n[k] = p.n; j.scale[k] = p.scale;
-    j.out[k] = L.gslots + (p.which == 0 ? VAR_SLOT : (p.which == 1 ? LS_SLOT : P2_SLOT)) + s;
-    ++s; ++k;
+  for (const ScalarPart& p : parts) DCGP_TRY(add_scalar(bk, L, p.which, p.part, p.n, p.scale));
+  return DCGP_OK;
+}
+int flush_scalars(Bk& bk) {
+  for (size_t i = 0; i < bk.pending.size(); i += REDUCE_JOBS_MAX) {
+    ReduceJobs j{};
+    int k = 0;
+    for (; k < REDUCE_JOBS_MAX && i + k < bk.pending.size(); ++k) {
+      const Bk::PendingSum& p = bk.pending[i + k];
+      j.in[k] = p.in; j.n[k] = p.n; j.scale[k] = p.scale; j.out[k] = p.out;
+    }
+    DCGP_TRY(reduce_sum_multi(bk.ctx, j, k));
   }
-  return reduce_sum_multi(bk.ctx, j, k);
+  bk.pending.clear();
+  return DCGP_OK;
+}
+
+int im2col(dcgp_ctx* ctx, const LayerState& L, const double* Xin, int n_mod, long Kc, double* Xcol) {
+  const int Ld = L.v.L, rpb = Ld >= 256 ? 1 : 256 / Ld;
+  if (Kc > 0x7fffffffL) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: too many patch columns");
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((Kc + rpb - 1) / rpb)), dim3(256), 0, ctx->stream, Xin, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s,
+                     L.v.Wo, L.v.P, Ld, (int)Kc, rpb, Xcol);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
 }
 
 // the hyper-parameter partial sums a Gram backward left in its scratch (`tag`) -> the layer's scalar slots
@@ -699,12 +720,10 @@ int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, lon
   }
   if (!defer_scalars) DCGP_TRY(kuu_scalars(bk, L, tag));
   if (want_dz) {
-    double* EX = bk.ws((t + "_EX").c_str(), (size_t)M * Ld);
-    NEED(EX);
-    DCGP_TRY(gemm_gen(ctx, mk(Es, M, 1, Zsrc, Ld, 1, EX, Ld, M, Ld, M)));
-    hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for((long)M * Ld)), dim3(256), 0, ctx->stream, EX, rs, Zsrc, (long)M, Ld, cz, 1,
-                       dz_out ? dz_out : L.gZ);
-    LAUNCH_CHECK(ctx);
+    // dZ += cz (Es Z - rs o Z): the correction rides in the product's epilogue
+    GenGemm e = mk(Es, M, 1, Zsrc, Ld, 1, dz_out ? dz_out : L.gZ, Ld, M, Ld, M);
+    e.alpha = cz; e.accumulate = 1; e.sub_v = rs; e.sub_x = Zsrc; e.sx_rs = Ld;
+    DCGP_TRY(gemm_gen(ctx, e));
   }
   return DCGP_OK;
 }
@@ -717,8 +736,7 @@ int patch_backward(Bk& bk, LayerState& L, const double* E, long ld, long Kc, con
   const int M = L.M, Ld = L.v.L;
   const double inv_l2 = cz != 0.0 ? cz : 1.0 / (L.ls * L.ls);   // cz: the ArcCosine adjoint passes its weight variance (and its own row vector)
   double* rs = rs_in ? const_cast<double*>(rs_in) : bk.ws("pb_rs", M);
-  double* EX = bk.ws("pb_EX", (size_t)M * Ld);
-  NEED(rs); NEED(EX);
+  NEED(rs);
   if (!rs_in) {
     const int chunks = (int)std::min<long>(32, (Kc + 4095) / 4096);
     const long cpc = round_up_l((Kc + chunks - 1) / chunks, 256);
@@ -729,17 +747,16 @@ int patch_backward(Bk& bk, LayerState& L, const double* E, long ld, long Kc, con
     hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks_for(M)), dim3(256), 0, ctx->stream, rsp, chunks, (long)M, rs);
     LAUNCH_CHECK(ctx);
   }
-  DCGP_TRY(gemm_gen(ctx, mk(E, ld, 1, Xcol, Ld, 1, EX, Ld, M, Ld, (int)Kc)));
   const double* Zp = Zuse ? Zuse : L.Z;
-  hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for((long)M * Ld)), dim3(256), 0, ctx->stream, EX, rs, Zp, (long)M, Ld, inv_l2, 1,
-                     dz_out ? dz_out : L.gZ);
-  LAUNCH_CHECK(ctx);
-  if (dXcol) {
-    double* EtZ = bk.ws("pb_EtZ", (size_t)Kc * Ld);
-    NEED(EtZ);
-    DCGP_TRY(gemm_gen(ctx, mk(E, 1, ld, Zp, Ld, 1, EtZ, Ld, (int)Kc, Ld, M)));
-    hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for(Kc * Ld)), dim3(256), 0, ctx->stream, EtZ, cs, Xcol, Kc, Ld, inv_l2, dx_accumulate, dXcol);
-    LAUNCH_CHECK(ctx);
+  {   // dZ += (E Xcol - rs o Z) / l^2: one product over the columns (split along k), the correction in its epilogue
+    GenGemm e = mk(E, ld, 1, Xcol, Ld, 1, dz_out ? dz_out : L.gZ, Ld, M, Ld, (int)Kc);
+    e.alpha = inv_l2; e.accumulate = 1; e.sub_v = rs; e.sub_x = Zp; e.sx_rs = Ld;
+    DCGP_TRY(gemm_gen(ctx, e));
+  }
+  if (dXcol) {   // dXcol (+)= (E^T Z - cs o Xcol) / l^2
+    GenGemm e = mk(E, 1, ld, Zp, Ld, 1, dXcol, Ld, (int)Kc, Ld, M);
+    e.alpha = inv_l2; e.accumulate = dx_accumulate; e.sub_v = cs; e.sub_x = Xcol; e.sx_rs = Ld;
+    DCGP_TRY(gemm_gen(ctx, e));
   }
   return DCGP_OK;
 }
@@ -1039,12 +1056,9 @@ int e_form(Bk& bk, LayerState& L, const double* dK, long lddk, int pdiv, const d
                      1.0 / L.variance, 2.0 * L.ls * L.ls, csp, rawp, pv, pl);
   LAUNCH_CHECK(ctx);
   if (chunks > 1) {
-    hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, csp, chunks, Kc, cs);
+    if (raw) hipLaunchKernelGGL(sum_chunks2_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, csp, rawp, chunks, Kc, cs, raw);
+    else hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, csp, chunks, Kc, cs);
     LAUNCH_CHECK(ctx);
-    if (raw) {
-      hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, rawp, chunks, Kc, raw);
-      LAUNCH_CHECK(ctx);
-    }
   }
   DCGP_TRY(add_scalars(bk, L, {{0, pv, (long)nb * chunks, 1.0 / L.variance}, {1, pl, (long)nb * chunks, 1.0 / (L.ls * L.ls * L.ls)}}));
   return DCGP_OK;
@@ -1053,6 +1067,7 @@ int e_form(Bk& bk, LayerState& L, const double* dK, long lddk, int pdiv, const d
 int begin_layer(Bk& bk, LayerState& L) {
   DCGP_TRY(L.ensure_grads());
   bk.slot_v = bk.slot_l = bk.slot_b = 0;
+  bk.pending.clear();
   HIP_TRY(bk.ctx, hipMemsetAsync(L.gslots, 0, 48 * sizeof(double), bk.ctx->stream));
   if (L.grad_block_count() * sizeof(double) <= (8u << 20)) {   // a small block ([Z | q_mu | q_sqrt | w | gscal | gard], contiguous): one fill
     HIP_TRY(bk.ctx, hipMemsetAsync(L.gZ, 0, L.grad_block_count() * sizeof(double), bk.ctx->stream));
@@ -1064,6 +1079,7 @@ int begin_layer(Bk& bk, LayerState& L) {
   return DCGP_OK;
 }
 int end_layer(Bk& bk, LayerState& L) {
+  DCGP_TRY(flush_scalars(bk));
   hipLaunchKernelGGL(scal_finish_kernel, dim3(1), dim3(64), 0, bk.ctx->stream, L.gslots, L.gscal);
   LAUNCH_CHECK(bk.ctx);
   return DCGP_OK;
@@ -1109,9 +1125,7 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
     return side.done(ctx->ev_kl);
   };
   HIP_TRY(ctx, hipMemsetAsync(dzp, 0, (size_t)M * Ld * sizeof(double), ctx->stream));
-  hipLaunchKernelGGL(im2col_kernel, dim3(blocks_for(Kc * Ld)), dim3(256), 0, ctx->stream, Xin, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s,
-                     L.v.Wo, P, Ld, Kc, Xcol);
-  LAUNCH_CHECK(ctx);
+  DCGP_TRY(im2col(ctx, L, Xin, n_mod, Kc, Xcol));
   double* dXcol = nullptr;
   if (dXin) { dXcol = bk.ws("dXcol", (size_t)Kc * Ld); NEED(dXcol); }
   if (L.base_type == 1) {   // ArcCosine(order 0): F1 over dKuf, F2 beside it, the RBF machinery on (F1, rowsum(F2) / Q, colsum(F2) / A, w)
@@ -1256,9 +1270,7 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   a.bk = L.base();
   a.out = Kfull; a.sM = ldf; a.sN = P; a.sP = 1;
   DCGP_TRY(patch_rbf(ctx, a, "grad_head_kfull"));
-  hipLaunchKernelGGL(im2col_kernel, dim3(blocks_for(Kc * Ld)), dim3(256), 0, ctx->stream, Xin, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s,
-                     L.v.Wo, P, Ld, Kc, Xcol);
-  LAUNCH_CHECK(ctx);
+  DCGP_TRY(im2col(ctx, L, Xin, n_mod, Kc, Xcol));
   // Kzx[m][n] = 1/P sum_p w_p k(Z_m, x_np)
   DCGP_TRY(e_form(bk, L, dKzx, ld, P, L.w, 1.0 / P, Kfull, ldf, E, ldf, Kc, cs, raw));
   hipLaunchKernelGGL(strided_sum_kernel, dim3(P), dim3(256), 0, ctx->stream, raw, rows, P, 1.0 / P, 1, L.gw);
@@ -1272,8 +1284,7 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
     double* dwn = bk.ws("kd_dwn", (size_t)rows * P);
     double* pv = bk.ws("kd_pv", (size_t)rows * P);
     double* pl = bk.ws("kd_pl", (size_t)rows * P);
-    double* EXn = bk.ws("kd_EX", (size_t)Kc * Ld);
-    NEED(Gm); NEED(norms); NEED(dwn); NEED(pv); NEED(pl); NEED(EXn);
+    NEED(Gm); NEED(norms); NEED(dwn); NEED(pv); NEED(pl);
     GenGemm gg = mk(Xcol, Ld, 1, Xcol, 1, Ld, Gm, P, P, P, Ld);     // per image: X_n X_n^T
     gg.batch = rows; gg.a_bs = (long)P * Ld; gg.b_bs = (long)P * Ld; gg.c_bs = (long)P * P;
     DCGP_TRY(gemm_gen(ctx, gg));
@@ -1285,12 +1296,11 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
     hipLaunchKernelGGL(strided_sum_kernel, dim3(P), dim3(256), 0, ctx->stream, dwn, rows, P, 1.0, 1, L.gw);
     LAUNCH_CHECK(ctx);
     if (dXin) {
-      GenGemm ge = mk(Gm, P, 1, Xcol, Ld, 1, EXn, Ld, P, Ld, P);    // E_n X_n
+      // d x_p += 2 (E_n X_n - rowsum(E_n) o X_n)_p / l^2   (E symmetric), per image
+      GenGemm ge = mk(Gm, P, 1, Xcol, Ld, 1, dXcol, Ld, P, Ld, P);
       ge.batch = rows; ge.a_bs = (long)P * P; ge.b_bs = (long)P * Ld; ge.c_bs = (long)P * Ld;
+      ge.alpha = 2.0 * inv_l2; ge.accumulate = 1; ge.sub_v = pv; ge.sv_bs = P; ge.sub_x = Xcol; ge.sx_rs = Ld; ge.sx_bs = (long)P * Ld;
       DCGP_TRY(gemm_gen(ctx, ge));
-      // d x_p += 2 (E X - rowsum(E) o X)_p / l^2   (E symmetric)
-      hipLaunchKernelGGL(axmy_kernel, dim3(blocks_for(Kc * Ld)), dim3(256), 0, ctx->stream, EXn, pv, Xcol, Kc, Ld, 2.0 * inv_l2, 1, dXcol);
-      LAUNCH_CHECK(ctx);
     }
   } else {
     // AdditivePatchKernel.Kdiag = mean_p w_p variance (conv_gp/kernels.py:53-61)

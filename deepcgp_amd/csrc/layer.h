@@ -167,5 +167,6 @@ const double* gauss_hermite_table(dcgp_ctx* ctx);   // [40]: 20 nodes then 20 we
 
 // deterministic single-block sum of n doubles, scaled: out[0] = scale * sum
 int reduce_sum(dcgp_ctx* ctx, const double* in, long n, double scale, double* out);
-struct ReduceJobs { const double* in[4]; long n[4]; double scale[4]; double* out[4]; };
+constexpr int REDUCE_JOBS_MAX = 12;
+struct ReduceJobs { const double* in[REDUCE_JOBS_MAX]; long n[REDUCE_JOBS_MAX]; double scale[REDUCE_JOBS_MAX]; double* out[REDUCE_JOBS_MAX]; };
 int reduce_sum_multi(dcgp_ctx* ctx, const ReduceJobs& jobs, int count);   // out[k][0] = scale[k] * sum(in[k][0..n[k])), one launch
