@@ -85,6 +85,9 @@ struct dcgp_ctx {
   DcgpOptions opt;                 // A/B switches: environment at dcgp_ctx_create, then dcgp_ctx_set_option only
   bool no_side = false;            // opt.no_side_stream: everything on the main stream (A/B switch; counter-collection runs, where
                                    // the profiler serialises dispatches and cross-stream waits can deadlock it)
+  // training step, the part of the reverse pass that runs beside the forward pass on stream_aux (grad_kl_early): ev_kl2 behind the zero fills and
+  // parameter-only operands, ev_kl3 behind the KL adjoint's products
+  hipEvent_t ev_kl2 = nullptr, ev_kl3 = nullptr;
   hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;  // fork / join of a short side-stream excursion inside a layer
   std::string err;
   std::map<std::string, hipGraphExec_t> chain_graphs;   // captured panel-launch sequences of the factorisation chain, by argument set (chol_fused.hip)

@@ -172,6 +172,8 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_factor, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_kl2, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_kl3, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_aux2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_kl, hipEventDisableTiming) != hipSuccess) {
     delete c;
@@ -227,6 +229,8 @@ int dcgp_ctx_destroy(dcgp_ctx* ctx) {
   hipEventDestroy(ctx->ev_fork);
   hipEventDestroy(ctx->ev_factor);
   hipEventDestroy(ctx->ev_aux);
+  hipEventDestroy(ctx->ev_kl2);
+  hipEventDestroy(ctx->ev_kl3);
   hipEventDestroy(ctx->ev_aux2);
   for (auto& e : ctx->ev_prep)
     if (e) hipEventDestroy(e);

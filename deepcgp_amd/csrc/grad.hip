@@ -19,6 +19,7 @@
 // (d alpha, W_r -> dG_r -> dq_sqrt, first dL terms) runs on the side stream (cond_backward).  No atomics anywhere: the
 // gradients are reproducible run to run.  The oracle for this file is oracle/grad.py.
 #include <algorithm>
+#include <chrono>
 #include <initializer_list>
 
 #include "model_state.h"
@@ -605,6 +606,7 @@ struct Bk {   // per-backward bookkeeping
   // its reverse pass (end_layer; they feed nothing else, and each used to be a 5 us launch in the middle of the data path)
   struct PendingSum { const double* in; long n; double scale; double* out; };
   std::vector<PendingSum> pending;
+  int prep = 0;                // the layer being processed: bit 0 fills + GT + Lc, bit 1 S_r done beside the forward pass (grad_kl_early)
   bool kl_early = false;       // the layer being processed had its kl_products beside the forward pass (grad_kl_early)
   bool side_pending = false;   // a layer left the end of its reverse pass on the side stream: model_backward joins once, at the end
   double klw = 1.0;   // weight of the (replicated) KL term on this rank: 1 / number of batch shards
@@ -808,6 +810,7 @@ int kl_products(Bk& bk, LayerState& L, double* Sacc, bool s_first) {
 }
 int kl_apply(Bk& bk, LayerState& L, bool frozen_prior) {
   dcgp_ctx* ctx = bk.ctx;
+  if (bk.kl_early) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_kl3, 0));   // the products came from the auxiliary stream
   const int M = L.M, Mp = L.Mp, R = L.R, Rp = L.g.Rp;
   const long mm = (long)Mp * Mp;
   const double kw = bk.klw;
@@ -830,6 +833,34 @@ int kl_apply(Bk& bk, LayerState& L, bool frozen_prior) {
     if (frozen_prior) DCGP_TRY(kuu_scalars(bk, L, "klz"));
   }
   hipLaunchKernelGGL(kl_diag_kernel, dim3(blocks_for((long)M * R)), dim3(256), 0, ctx->stream, L.gq_sqrt, L.g.Lq, M, Mp, R, kw);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
+// Parameter-only operands of cond_backward: sgg == false: G^T stacked along k (GT) and the lower triangle of the factor (Lc);
+// sgg == true: S_r = G_r G_r^T, the strip kernel's operand.
+int param_operands(Bk& bk, LayerState& L, bool sgg) {
+  dcgp_ctx* ctx = bk.ctx;
+  const int M = L.M, Mp = L.Mp, R = L.R;
+  const long mm = (long)Mp * Mp;
+  const GpMats& g = L.g;
+  if (sgg) {
+    double* Sgg = bk.ws("Sgg", (size_t)R * mm);
+    NEED(Sgg);
+    if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(Sgg, 0, (size_t)R * mm * sizeof(double), ctx->stream));
+    GenGemm sg = mk(g.G, Mp, 1, g.G, 1, Mp, Sgg, Mp, M, M, M);
+    sg.batch = R; sg.a_bs = mm; sg.b_bs = mm; sg.c_bs = mm;
+    return gemm_gen(ctx, sg);
+  }
+  if (L.has_qsqrt) {
+    double* GT = bk.ws("GT", (size_t)R * mm);
+    NEED(GT);
+    hipLaunchKernelGGL(restack_transpose_kernel, dim3(blocks_for(R * mm)), dim3(256), 0, ctx->stream, g.G, Mp, R, GT);
+    LAUNCH_CHECK(ctx);
+  }
+  double* Lc = bk.ws("Lc", (size_t)mm);
+  NEED(Lc);
+  hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, 1), dim3(256), 0, ctx->stream, g.K, (long)Mp, 0L, Lc, (long)Mp, 0L, M, 1.0, 0);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }
@@ -864,17 +895,13 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   if (L.has_qsqrt) {
     GT = bk.ws("GT", (size_t)R * mm);
     NEED(GT);
-    hipLaunchKernelGGL(restack_transpose_kernel, dim3(blocks_for(R * mm)), dim3(256), 0, ctx->stream, g.G, Mp, R, GT);
-    LAUNCH_CHECK(ctx);
   }
+  // (parameter-only operands: G^T stacked, S_r = G_r G_r^T, the factor's lower triangle -- already there when grad_kl_early prepared them)
+  if (!(bk.prep & 1)) DCGP_TRY(param_operands(bk, L, false));
   if (fused_bwd) {
-    double* Sgg = bk.ws("Sgg", (size_t)R * mm);
-    NEED(Sgg);
-    if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(Sgg, 0, (size_t)R * mm * sizeof(double), ctx->stream));
-    GenGemm sg = mk(g.G, Mp, 1, g.G, 1, Mp, Sgg, Mp, M, M, M);   // S_r = G_r G_r^T
-    sg.batch = R; sg.a_bs = mm; sg.b_bs = mm; sg.c_bs = mm;
-    DCGP_TRY(gemm_gen(ctx, sg));
-    fb.S = Sgg;
+    if (!(bk.prep & 2)) DCGP_TRY(param_operands(bk, L, true));
+    fb.S = bk.ws("Sgg", (size_t)R * mm);
+    NEED(fb.S);
   }
   // Two independent chains from here.  Side stream: the M x M results that cost a long contraction over the columns and the chain behind
   // them (W_r -> dG_r -> dq_sqrt, the dq_sqrt term of dL) -- split-k products at ~40 % MFMA utilisation.  Main stream: dT, dA1, dK_uf on
@@ -1025,13 +1052,12 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   double* Pm = bk.ws("Pm", (size_t)mm);
   double* S1 = bk.ws("S1", (size_t)mm);
   NEED(Lc); NEED(Pm); NEED(S1);
-  hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, 1), dim3(256), 0, ctx->stream, g.K, (long)Mp, 0L, Lc, (long)Mp, 0L, M, 1.0, 0);
-  LAUNCH_CHECK(ctx);
   DCGP_TRY(gemm_gen(ctx, mk(Lc, 1, Mp, dL, Mp, 1, Pm, Mp, M, M, M)));
   hipLaunchKernelGGL(phi_kernel, dim3(blocks_for(M), M), dim3(256), 0, ctx->stream, Pm, (long)Mp, M);
   LAUNCH_CHECK(ctx);
   DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, Pm, Mp, 1, S1, Mp, M, M, M)));
   GenGemm sf = mk(S1, Mp, 1, g.Linv, Mp, 1, S, Mp, M, M, M);
+  if (s_acc) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_kl3, 0));   // S holds the KL part, written on the auxiliary stream
   sf.accumulate = s_acc ? 1 : 0;
   DCGP_TRY(gemm_gen(ctx, sf));
   return DCGP_OK;
@@ -1064,10 +1090,14 @@ int e_form(Bk& bk, LayerState& L, const double* dK, long lddk, int pdiv, const d
   return DCGP_OK;
 }
 
-int begin_layer(Bk& bk, LayerState& L) {
+// the zero fills in front of a layer's reverse pass: scalar slots, gradient block, the scratch its patch adjoint collects dZ in
+int layer_fills(Bk& bk, LayerState& L) {
   DCGP_TRY(L.ensure_grads());
-  bk.slot_v = bk.slot_l = bk.slot_b = 0;
-  bk.pending.clear();
+  if (!L.in_scale) {
+    double* dzp = bk.ws("dz_patch", (size_t)L.M * L.v.L);
+    NEED(dzp);
+    HIP_TRY(bk.ctx, hipMemsetAsync(dzp, 0, (size_t)L.M * L.v.L * sizeof(double), bk.ctx->stream));
+  }
   HIP_TRY(bk.ctx, hipMemsetAsync(L.gslots, 0, 48 * sizeof(double), bk.ctx->stream));
   if (L.grad_block_count() * sizeof(double) <= (8u << 20)) {   // a small block ([Z | q_mu | q_sqrt | w | gscal | gard], contiguous): one fill
     HIP_TRY(bk.ctx, hipMemsetAsync(L.gZ, 0, L.grad_block_count() * sizeof(double), bk.ctx->stream));
@@ -1077,6 +1107,12 @@ int begin_layer(Bk& bk, LayerState& L) {
   HIP_TRY(bk.ctx, hipMemsetAsync(L.gw, 0, ((size_t)L.v.P + 3 + (L.is_head ? (size_t)L.v.L : 0)) * sizeof(double), bk.ctx->stream));   // gw, gscal, gard
   if (!L.has_qsqrt) HIP_TRY(bk.ctx, hipMemsetAsync(L.gq_sqrt, 0, (size_t)L.R * L.M * L.M * sizeof(double), bk.ctx->stream));
   return DCGP_OK;
+}
+int begin_layer(Bk& bk, LayerState& L) {
+  bk.slot_v = bk.slot_l = bk.slot_b = 0;
+  bk.pending.clear();
+  if (bk.prep & 1) return DCGP_OK;   // grad_kl_early ran the fills beside the forward pass
+  return layer_fills(bk, L);
 }
 int end_layer(Bk& bk, LayerState& L) {
   DCGP_TRY(flush_scalars(bk));
@@ -1124,7 +1160,6 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
     bk.side_pending = bk.side_pending || side.active;
     return side.done(ctx->ev_kl);
   };
-  HIP_TRY(ctx, hipMemsetAsync(dzp, 0, (size_t)M * Ld * sizeof(double), ctx->stream));
   DCGP_TRY(im2col(ctx, L, Xin, n_mod, Kc, Xcol));
   double* dXcol = nullptr;
   if (dXin) { dXcol = bk.ws("dXcol", (size_t)Kc * Ld); NEED(dXcol); }
@@ -1261,7 +1296,6 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   // the fork point of the side chain (KL + Gram adjoints: they need S only); the chain itself is ENQUEUED behind the patch-kernel adjoints
   // below -- what the previous layer's reverse pass waits for is dX, and one host thread feeding two streams of 5-10 us launches starved the main one
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(dzp, 0, (size_t)M * Ld * sizeof(double), ctx->stream));
   // every patch response again: Kfull[m][n * P + p] = k(Z_m, x_np)
   PatchRbfArgs a;
   a.X = Xin; a.N = rows; a.n_mod = n_mod;
@@ -1351,16 +1385,36 @@ int grad_kl_early(dcgp_model* m, bool enqueue, bool wait_fork) {
   dcgp_ctx* ctx = m->ctx;
   const int nl = (int)m->layers.size();
   for (bool& f : m->kl_early) f = false;
-  const bool side = !ctx->opt.grad_nofork && !ctx->no_side && ctx->stream2;
+  for (int& f : m->prep_early) f = 0;
+  const bool side = !ctx->opt.grad_nofork && !ctx->no_side && ctx->stream2 && ctx->stream_aux;
   if (ctx->opt.grad_late_kl || !side || nl > 8) return DCGP_OK;
   if (!enqueue) return 1;
   Bk bk;
   bk.m = m; bk.ctx = ctx; bk.klw = kl_weight(m);
   hipStream_t saved = ctx->stream;
-  if (wait_fork) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-  ctx->stream = ctx->stream2;
+  // a stream of its own: on the side stream these ~40 launches (slow beside the forward pass's kernels) were still in front of the head's side
+  // chain when the reverse pass got there
+  hipStream_t es = ctx->stream_aux;
+  if (wait_fork) HIP_TRY(ctx, hipStreamWaitEvent(es, ctx->ev_fork, 0));
+  ctx->stream = es;
   const std::string mp = "m" + std::to_string(m->id) + "_";
   int rc = DCGP_OK;
+  // first what the main stream's part of the reverse pass reads: zero fills and the parameter-only operands of every layer's conditional
+  // (model_backward waits for ctx->ev_kl2 -- long past by then), the last layer first
+  for (int li = nl - 1; li >= 0 && rc == DCGP_OK; --li) {
+    LayerState& L = *m->layers[li];
+    bk.pfx = mp + std::to_string(li) + "_";
+    rc = layer_fills(bk, L);
+    if (rc == DCGP_OK) rc = param_operands(bk, L, false);
+    if (rc == DCGP_OK) m->prep_early[li] = 1;
+    ConvBwdArgs fb;
+    fb.M = L.M; fb.Mp = L.Mp; fb.R = L.R;
+    if (rc == DCGP_OK && !L.is_head && L.has_qsqrt && !L.white && conv_bwd_fused_ok(ctx, fb)) {
+      rc = param_operands(bk, L, true);
+      if (rc == DCGP_OK) m->prep_early[li] |= 2;
+    }
+  }
+  if (rc == DCGP_OK && hipEventRecord(ctx->ev_kl2, es) != hipSuccess) rc = DCGP_ERR_HIP;
   for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
     LayerState& L = *m->layers[li];
     if (L.white) continue;
@@ -1373,8 +1427,9 @@ int grad_kl_early(dcgp_model* m, bool enqueue, bool wait_fork) {
     rc = kl_products(bk, L, Sacc, true);
     if (rc == DCGP_OK) m->kl_early[li] = true;
   }
+  if (rc == DCGP_OK && hipEventRecord(ctx->ev_kl3, es) != hipSuccess) rc = DCGP_ERR_HIP;
   ctx->stream = saved;
-  if (rc != DCGP_OK) { hipStreamSynchronize(ctx->stream2); for (bool& f : m->kl_early) f = false; }
+  if (rc != DCGP_OK) { hipStreamSynchronize(es); for (bool& f : m->kl_early) f = false; for (int& f : m->prep_early) f = 0; }
   return rc;
 }
 
@@ -1387,6 +1442,9 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
   }
   const double* gh = gauss_hermite_table(ctx);
   if (!gh) return DCGP_ERR_ALLOC;
+  bool prepped = false;
+  for (int f : m->prep_early) prepped = prepped || f != 0;
+  if (prepped) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_kl2, 0));   // fills and parameter-only operands from the side stream (grad_kl_early)
   Bk bk;
   bk.m = m; bk.ctx = ctx;
   bk.klw = kl_weight(m);
@@ -1406,7 +1464,8 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
     LayerState& L = *m->layers[li];
     bk.pfx = mp + std::to_string(li) + "_";
     bk.kl_early = li < 8 && m->kl_early[li];
-    if (li < 8) m->kl_early[li] = false;
+    bk.prep = li < 8 ? m->prep_early[li] : 0;
+    if (li < 8) { m->kl_early[li] = false; m->prep_early[li] = 0; }
     const double* Xin = li == 0 ? X : m->outs[li - 1].sample;
     int rows_l = m->outs[li].rows;                  // rows entering == rows leaving ...
     // ... except for a de-duplicated first conv layer: propagate() tiles the batch S times, so layer 0 saw S identical
@@ -1465,11 +1524,17 @@ int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, 
   // ran on NaNs, which nothing reads).
   uint64_t ticket = 0;
   if (info_host) *info_host = 0;
+  const auto host_t0 = std::chrono::steady_clock::now();
   int rc = model->enq_seq != model->col_seq ? ctx_fail(ctx, DCGP_ERR_ARG, "elbo_grad: enqueued steps are still to be collected")
                                              : elbo_forward_enqueue_impl(model, X, y, N, scale, z_per_layer_host, seed, dedup_layer0, &ticket);
   const bool enqueued = rc == DCGP_OK;
   if (rc == DCGP_OK && model->gkl_state) rc = grad_kl_early(model, true, model->gkl_state == 2);
   if (rc == DCGP_OK) rc = model_backward(model, X, y, N, scale, dedup_layer0);
+  if (ctx->timing) {   // host time to enqueue the whole step, forward pass included (reported beside the kernel timers)
+    auto& acc = ctx->tim["grad_host_enqueue"];
+    acc.launches += 1;
+    acc.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+  }
   if (enqueued) {
     const int rc_f = elbo_forward_collect_impl(model, ticket, out_host, info_host);
     if (rc == DCGP_OK) rc = rc_f;
@@ -1480,8 +1545,10 @@ int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, 
   model->gkl_state = 0;
   if (rc != DCGP_OK) {
     for (bool& f : model->kl_early) f = false;
+    for (int& f : model->prep_early) f = 0;
     hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream_aux) hipStreamSynchronize(ctx->stream_aux);
   }
   DCGP_TRY(rc);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

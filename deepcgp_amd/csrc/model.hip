@@ -343,14 +343,15 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     hipStreamSynchronize(chain_s);
     return rc;
   }
-  // A training step: the parameter-only part of the reverse pass (grad.hip, grad_kl_early) may start HERE on the side stream -- the point is
-  // marked, its thirty launches are enqueued by dcgp_elbo_grad behind the whole forward pass (in front of the layers below the host kept
-  // the first layer waiting for 170 us, in front of the tail launch the end of the forward pass for 60)
-  m->gkl_state = 0;
-  if (m->grad_follows && !pipelined && grad_kl_early(m, false, false) == 1) {
-    m->gkl_state = chain_s != ctx->stream2 ? 2 : 1;
-    if (m->gkl_state == 2) HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, chain_s));
-  }
+  // A training step: the parameter-only part of the reverse pass (grad.hip, grad_kl_early) runs beside the forward pass on the auxiliary
+  // stream.  Its start is marked behind the FIRST layer (below): that layer's launch fills the chip at the full batch, and forty short
+  // launches squeezed in between its rounds cost it more than they gained.  They are enqueued by dcgp_elbo_grad behind the whole forward
+  // pass (in front of the layers below the host kept the first layer waiting for 170 us, in front of the tail launch the end of the
+  // forward pass for 60).
+  m->gkl_state = (m->grad_follows && !pipelined && grad_kl_early(m, false, false) == 1) ? 2 : 0;
+  // (a first layer of a few thousand patch columns -- the de-duplicated batch -- leaves half the chip idle: there the mark is here, behind the chain)
+  const bool mark_behind_first = (long)rows0 * m->layers[0]->v.P >= 8192;
+  if (m->gkl_state && !mark_behind_first) HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, chain_s));
 
   // sweeps read Z^T / |z|^2 of this bank (a one-launch first layer waits for its G / alpha, recorded behind them on the same stream)
   if (chain_s != main_s && !first_fused) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_sweep[bank], 0));
@@ -364,6 +365,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     int out_rows = 0;
     if (li == nl - 1 && join_early && kl_join) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_kl[bank], 0));
     DCGP_TRY(layer_step(li, F, rows, n_mod, &out_rows, (li == 0 && early0) ? 2 : 3));
+    if (li == 0 && m->gkl_state && mark_behind_first) HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_s));   // (the chain's results are ordered in front of this layer)
     if (!m->layers[li]->is_head) F = m->outs[li].sample;
     rows = out_rows;
     n_mod = rows;

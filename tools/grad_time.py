@@ -24,3 +24,12 @@ for i in range(steps):
     model.compute_gradients(dX, dY, seed=i, fetch=False)
 ctx.sync()
 print("%s: value+grad %.3f ms/step" % (name, 1e3 * (time.perf_counter() - t0) / steps))
+if os.environ.get("DCGP_GRAD_HOST"):   # host time to enqueue a step (timers on: a few more events per step)
+    ctx.timing_enable(1); ctx.timing_reset()
+    for i in range(steps):
+        model.compute_gradients(dX, dY, seed=i, fetch=False)
+    ctx.sync()
+    t = ctx.timing()
+    for k in ("grad_host_enqueue", "host_enqueue"):
+        if k in t:
+            print("  %s: %.1f us/step" % (k, 1e3 * t[k][1] / max(1, t[k][0])))
