@@ -158,6 +158,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 4) void gemm_gen_kernel(GenGem
           v *= g.alpha;
           if (g.colscale) v *= g.colscale[(long)j * g.cs_s + (long)b * g.cs_bs];
           if (g.lower_only && j > i) v = 0.0;
+          if (g.phi) v = j < i ? v : (j == i ? 0.5 * v : 0.0);
           if (g.accumulate) v += C[(long)i * c_rs + j];
         }
         C[(long)i * c_rs + j] = v;
@@ -187,6 +188,7 @@ __global__ void splitk_reduce_kernel(GenGemm g, int ksplit, const double* part) 
   v *= g.alpha;
   if (g.colscale) v *= g.colscale[(long)j * g.cs_s + (long)b * g.cs_bs];
   if (g.lower_only && j > i) v = 0.0;
+  if (g.phi) v = j < i ? v : (j == i ? 0.5 * v : 0.0);
   double* c = g.C + (long)b * g.c_bs + (long)i * g.c_rs + j;
   if (g.accumulate) v += *c;
   *c = v;

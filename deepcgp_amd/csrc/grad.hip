@@ -174,14 +174,6 @@ __global__ void mirror_lower_kernel(double* __restrict__ A, long ld, long bs, in
   A[b * bs + i * ld + j] = A[b * bs + j * ld + i];
 }
 
-// Phi: keep the lower triangle, halve the diagonal (in place)
-__global__ void phi_kernel(double* __restrict__ P, long ld, int M) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-  if (j >= M) return;
-  double v = P[i * ld + j];
-  P[i * ld + j] = j < i ? v : (j == i ? 0.5 * v : 0.0);
-}
-
 // gq_sqrt[r][i][i] += 1 / Lq[r][i][i]   (- d/dLq of -1/2 log det(Lq Lq^T))
 __global__ void kl_diag_kernel(double* __restrict__ gq, const double* __restrict__ Lq, int M, int Mp, int R, double kw) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -233,19 +225,23 @@ __global__ __launch_bounds__(256) void kuu_backward_kernel(const double* __restr
 
 // ---- patch kernels backward -------------------------------------------------------------------------------------
 // Xcol[c][l], c = n * P + p, l = (kh * f + kw) * C + ch  (FullView.extract_patches, conv_gp/views.py:46-54)
-// rpb patches per 256-thread block, thread (r, l): 32-bit index arithmetic only (one thread per element with 64-bit divisions: 26 us for the
-// head's 41 MB at the headline size)
-__global__ __launch_bounds__(256) void im2col_kernel(const double* __restrict__ X, int n_mod, int H, int W, int C, int f, int s, int Wo, int P,
-                                                     int L, int Kc, int rpb, double* __restrict__ Xcol) {
-  for (int l0 = 0; l0 < L; l0 += 256) {   // L > 256: the block takes one patch, in passes
-    const int t = threadIdx.x + l0;
-    const int r = L >= 256 ? 0 : t / L, l = L >= 256 ? t : t - r * L;
-    const int c = blockIdx.x * rpb + r;
-    if (r >= rpb || l >= L || c >= Kc) continue;
-    const int n = c / P, p = c - n * P;
-    const int oh = p / Wo, ow = p - oh * Wo;
-    const int q = l / C, ch = l - q * C, kh = q / f, kw = q - kh * f;
-    Xcol[(long)c * L + l] = X[(((long)(n % n_mod) * H + oh * s + kh) * W + ow * s + kw) * C + ch];
+// A patch row (kh fixed) is ONE contiguous run of f C doubles of the image, and so is its place in Xcol: block (n, oh) copies the
+// Wo f runs of its patch row -- thread (run slot, j): no division inside the loop.  (One thread per element with 64-bit index
+// arithmetic: 26 us for the head's 41 MB at the headline size; one 250-element patch per block: 28.)
+__global__ __launch_bounds__(256) void im2col_kernel(const double* __restrict__ X, int n_mod, int H, int W, int C, int f, int s, int Ho, int Wo,
+                                                     int L, double* __restrict__ Xcol) {
+  const int fc = f * C, n = blockIdx.x / Ho, oh = blockIdx.x - n * Ho;
+  const int per = fc >= 256 ? 1 : 256 / fc;               // runs in flight per pass
+  const int slot = fc >= 256 ? 0 : threadIdx.x / fc, j0 = fc >= 256 ? threadIdx.x : threadIdx.x - slot * fc;
+  if (slot >= per) return;
+  const double* __restrict__ img = X + (long)(n % n_mod) * H * W * C;
+  double* __restrict__ out = Xcol + ((long)n * Ho * Wo + (long)oh * Wo) * L;
+  const int runs = Wo * f;                                 // run r = ow * f + kh
+  for (int r = slot; r < runs; r += per) {
+    const int ow = r / f, kh = r - ow * f;
+    const double* __restrict__ src = img + ((long)(oh * s + kh) * W + ow * s) * C;
+    double* __restrict__ dst = out + (long)ow * L + kh * fc;
+    for (int j = j0; j < fc; j += 256) dst[j] = src[j];
   }
 }
 
@@ -674,10 +670,10 @@ int flush_scalars(Bk& bk) {
 }
 
 int im2col(dcgp_ctx* ctx, const LayerState& L, const double* Xin, int n_mod, long Kc, double* Xcol) {
-  const int Ld = L.v.L, rpb = Ld >= 256 ? 1 : 256 / Ld;
-  if (Kc > 0x7fffffffL) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: too many patch columns");
-  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((Kc + rpb - 1) / rpb)), dim3(256), 0, ctx->stream, Xin, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s,
-                     L.v.Wo, L.v.P, Ld, (int)Kc, rpb, Xcol);
+  const long rows = Kc / L.v.P;
+  if (rows * L.v.Ho > 0x7fffffffL) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: too many patch rows");
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)(rows * L.v.Ho)), dim3(256), 0, ctx->stream, Xin, n_mod, L.v.H, L.v.W, L.v.C, L.v.f, L.v.s,
+                     L.v.Ho, L.v.Wo, L.v.L, Xcol);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }
@@ -1052,9 +1048,9 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   double* Pm = bk.ws("Pm", (size_t)mm);
   double* S1 = bk.ws("S1", (size_t)mm);
   NEED(Lc); NEED(Pm); NEED(S1);
-  DCGP_TRY(gemm_gen(ctx, mk(Lc, 1, Mp, dL, Mp, 1, Pm, Mp, M, M, M)));
-  hipLaunchKernelGGL(phi_kernel, dim3(blocks_for(M), M), dim3(256), 0, ctx->stream, Pm, (long)Mp, M);
-  LAUNCH_CHECK(ctx);
+  GenGemm ph = mk(Lc, 1, Mp, dL, Mp, 1, Pm, Mp, M, M, M);
+  ph.phi = 1;   // Phi(L^T dL) in the product's epilogue
+  DCGP_TRY(gemm_gen(ctx, ph));
   DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, Pm, Mp, 1, S1, Mp, M, M, M)));
   GenGemm sf = mk(S1, Mp, 1, g.Linv, Mp, 1, S, Mp, M, M, M);
   if (s_acc) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_kl3, 0));   // S holds the KL part, written on the auxiliary stream
