@@ -203,10 +203,10 @@ __global__ __launch_bounds__(CB_NT) void conv_bwd_fused_kernel(ConvBwdArgs a) {
 
 }  // namespace
 
-// strip width in 16-column fragments: 4 while that fills a round of the chip, else 2
+// strip width in 16-column fragments: 4 while that fills a round of the chip, 2 for a few thousand columns, 1 for a few hundred (the head)
 static int strip_frags(const dcgp_ctx* ctx, const ConvBwdArgs& a) {
   if (ctx->opt.fused_bwd_frags == 4 || ctx->opt.fused_bwd_frags == 2 || ctx->opt.fused_bwd_frags == 1) return ctx->opt.fused_bwd_frags;   // A/B switch
-  return (a.Kc + 63) / 64 >= 200 ? 4 : 2;
+  return (a.Kc + 63) / 64 >= 200 ? 4 : ((a.Kc + 31) / 32 >= 64 ? 2 : 1);
 }
 
 bool conv_bwd_fused_ok(const dcgp_ctx* ctx, const ConvBwdArgs& a) {

@@ -18,6 +18,7 @@ struct GenGemm {
   const double* sub_v = nullptr; long sv_bs = 0;               // sub_v_b[i] = sub_v[b * sv_bs + i]
   const double* sub_x = nullptr; long sx_rs = 0, sx_bs = 0;    // sub_x_b(i, j) = sub_x[b * sx_bs + i * sx_rs + j]
   int lower_only = 0;      // entries with j > i are written as 0 (before accumulation)
+  int mirror = 0;          // with lower_only on a square result: the strictly lower entries are also stored transposed (a symmetric product, computed once)
   int phi = 0;             // Murray's Phi on the result (before accumulation): strictly lower part kept, diagonal halved, the rest zero
   int lower_compact = 0;   // set by the launcher: the grid enumerates the tiles on / below the diagonal only
 };

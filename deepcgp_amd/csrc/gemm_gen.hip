@@ -49,6 +49,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 4) void gemm_gen_kernel(GenGem
   double* C = split ? part + ((long)sp * g.batch + b) * (long)g.M * g.N : g.C + (long)b * g.c_bs;
   const long c_rs = split ? g.N : g.c_rs;
   if (g.lower_only && j0 > i0 + GT - 1) {   // rectangular grid (direct store): the tile above the diagonal is defined as zero
+    if (g.mirror) return;                   // ... or is the mirror image of a tile below it, stored by that tile's workgroup
     for (int e = t; e < GT * GT; e += NT) {
       const int i = i0 + e / GT, j = j0 + e % GT;
       if (i < g.M && j < g.N) C[(long)i * c_rs + j] = 0.0;
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 4) void gemm_gen_kernel(GenGem
       for (int q = 0; q < 4; ++q) {
         const int i = i0 + wm + fi * 16 + (lane >> 4) + 4 * q, j = j0 + wn + fj * 16 + (lane & 15);
         if (i >= g.M || j >= g.N) continue;
+        if (g.mirror && j > i) continue;   // written by the thread that holds (j, i)
         double v = acc[fi][fj][q];
         if (!split) {
           if (g.sub_v) v -= g.sub_v[(long)b * g.sv_bs + i] * g.sub_x[(long)b * g.sx_bs + (long)i * g.sx_rs + j];
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 4) void gemm_gen_kernel(GenGem
           if (g.lower_only && j > i) v = 0.0;
           if (g.phi) v = j < i ? v : (j == i ? 0.5 * v : 0.0);
           if (g.accumulate) v += C[(long)i * c_rs + j];
+          if (g.mirror && j < i) C[(long)j * c_rs + i] = v;
         }
         C[(long)i * c_rs + j] = v;
       }
@@ -172,6 +175,7 @@ __global__ void splitk_reduce_kernel(GenGemm g, int ksplit, const double* part) 
   const int b = (int)(idx / per);
   const long e = idx % per;
   const int i = (int)(e / g.N), j = (int)(e % g.N);
+  if (g.mirror && j > i) return;   // written by the thread that holds (j, i)
   double v = 0.0;
   // batches of 8 partials requested together, added in the same fixed order (a rolled loop waited one memory latency per partial:
   // 150-330 us for the 25-50 partials of the W_r contraction)
@@ -192,6 +196,7 @@ __global__ void splitk_reduce_kernel(GenGemm g, int ksplit, const double* part) 
   double* c = g.C + (long)b * g.c_bs + (long)i * g.c_rs + j;
   if (g.accumulate) v += *c;
   *c = v;
+  if (g.mirror && j < i) g.C[(long)b * g.c_bs + (long)j * g.c_rs + i] = v;
 }
 
 }  // namespace

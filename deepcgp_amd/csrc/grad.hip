@@ -118,6 +118,24 @@ __global__ void sample_backward_kernel(const double* __restrict__ dF, const doub
   gv[i] = d * (sample[i] - mean[i]) / (2.0 * (var[i] + jitter));
 }
 
+// the same for a de-duplicated first layer, whose S samples share one conditional: the S gradients arriving per element add up
+// (gm[i] = sum_s of the kernel above at s * n + i, in the order s = 0, 1, ...)
+__global__ void sample_backward_dedup_kernel(const double* __restrict__ dF, const double* __restrict__ sample, const double* __restrict__ mean,
+                                             const double* __restrict__ var, double jitter, int S, long n, double* __restrict__ gm,
+                                             double* __restrict__ gv) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double sa = 0.0, sb = 0.0;
+  for (int s = 0; s < S; ++s) {
+    const long k = (long)s * n + i;
+    const double d = dF[k];
+    sa += d;
+    sb += d * (sample[k] - mean[k]) / (2.0 * (var[k] + jitter));
+  }
+  gm[i] = sa;
+  gv[i] = sb;
+}
+
 // out[i] = sum_s in[s * n + i]: the S samples of a de-duplicated first layer share one conditional
 __global__ void reduce_replicas_kernel(const double* __restrict__ a, const double* __restrict__ b, int S, long n, double* __restrict__ oa,
                                        double* __restrict__ ob) {
@@ -165,13 +183,6 @@ __global__ void copy2d_kernel(const double* __restrict__ src, long lds, double* 
   const double v = alpha * src[i * lds + j];
   double* d = dst + i * ldd + j;
   *d = accumulate ? *d + v : v;
-}
-
-// A_b[i][j] = A_b[j][i] for j > i
-__global__ void mirror_lower_kernel(double* __restrict__ A, long ld, long bs, int M) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
-  if (j >= M || j <= i) return;
-  A[b * bs + i * ld + j] = A[b * bs + j * ld + i];
 }
 
 // gq_sqrt[r][i][i] += 1 / Lq[r][i][i]   (- d/dLq of -1/2 log det(Lq Lq^T))
@@ -784,7 +795,7 @@ int kl_products(Bk& bk, LayerState& L, double* Sacc, bool s_first) {
   g1.batch = R; g1.b_bs = mm; g1.c_bs = mm;
   DCGP_TRY(gemm_gen(ctx, g1));
   const long Rm = (long)R * Mp;
-  HIP_TRY(ctx, hipMemsetAsync(KiL, 0, (size_t)R * mm * sizeof(double), ctx->stream));
+  if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(KiL, 0, (size_t)R * mm * sizeof(double), ctx->stream));   // (the padded k of the stacked product below)
   GenGemm g2 = mk(Lpinv, 1, Mp, Wm, Mp, 1, KiL, Rm, M, M, M);        // inv(K) Lq_r, stored [i][r][k]
   g2.batch = R; g2.b_bs = mm; g2.c_bs = Mp;
   DCGP_TRY(gemm_gen(ctx, g2));
@@ -919,10 +930,8 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
     NEED(Wr);
     GenGemm w = mk(A1, ld, 1, A1, 1, ld, Wr, Mp, M, M, (int)Kc);
     // (the k scaling reads gv [Kc][R] in place, stride R: a transposed copy used to cost 290 us of scattered 8-byte stores per step)
-    w.batch = R; w.c_bs = mm; w.lower_only = 1; w.alpha = 2.0; w.kscale = gv; w.ks_s = R; w.ks_bs = 1;
+    w.batch = R; w.c_bs = mm; w.lower_only = 1; w.mirror = 1; w.alpha = 2.0; w.kscale = gv; w.ks_s = R; w.ks_bs = 1;
     DCGP_TRY(gemm_gen(ctx, w));
-    hipLaunchKernelGGL(mirror_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Wr, (long)Mp, mm, M);
-    LAUNCH_CHECK(ctx);
     GenGemm d = mk(Wr, Mp, 1, g.G, Mp, 1, dG, Mp, M, M, M);
     d.batch = R; d.a_bs = mm; d.b_bs = mm; d.c_bs = mm; d.lower_only = 1;
     DCGP_TRY(gemm_gen(ctx, d));
@@ -933,7 +942,7 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
     } else {
       double* Bm = bk.ws("Bm", (size_t)R * mm);                      // B_r = inv(L)^T dG_r, stored [i][r][k]
       NEED(Bm);
-      HIP_TRY(ctx, hipMemsetAsync(Bm, 0, (size_t)R * mm * sizeof(double), ctx->stream));
+      if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(Bm, 0, (size_t)R * mm * sizeof(double), ctx->stream));   // (the padded k of the stacked product below)
       GenGemm b = mk(g.Linv, 1, Mp, dG, Mp, 1, Bm, Rm, M, M, M);
       b.batch = R; b.b_bs = mm; b.c_bs = Mp;
       DCGP_TRY(gemm_gen(ctx, b));
@@ -1456,6 +1465,7 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
   hipLaunchKernelGGL(robustmax_grad_kernel, dim3((rows + RM_ROWS - 1) / RM_ROWS), dim3(256), 0, ctx->stream, oh.mean, oh.var, y, rows, N, H.R,
                      m->eps, gh, weight, gm, gv);
   LAUNCH_CHECK(ctx);
+  bool dedup_done = false;   // layer 0's (dmean, dvar) already summed over the S replicas
   for (int li = nl - 1; li >= 0; --li) {
     LayerState& L = *m->layers[li];
     bk.pfx = mp + std::to_string(li) + "_";
@@ -1468,13 +1478,15 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
     // copies; the forward evaluated its conditional on the N distinct images and drew S samples from it.  The S
     // gradients arriving per image add up, and the conditional's reverse pass runs on N rows instead of S N (exact).
     if (li == 0 && dedup_layer0 && !L.is_head && rows_l == S * N && S > 1) {
-      const long n = (long)N * L.v.P * L.R;
-      double* gm0 = (double*)ws_get(ctx, bk.pfx + "g_gm_dedup", (size_t)n * sizeof(double));
-      double* gv0 = (double*)ws_get(ctx, bk.pfx + "g_gv_dedup", (size_t)n * sizeof(double));
-      NEED(gm0); NEED(gv0);
-      hipLaunchKernelGGL(reduce_replicas_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, gm, gv, S, n, gm0, gv0);
-      LAUNCH_CHECK(ctx);
-      gm = gm0; gv = gv0;
+      if (!dedup_done) {   // (the head-less case: the gradients came from the likelihood, not from a layer above)
+        const long n = (long)N * L.v.P * L.R;
+        double* gm0 = (double*)ws_get(ctx, bk.pfx + "g_gm_dedup", (size_t)n * sizeof(double));
+        double* gv0 = (double*)ws_get(ctx, bk.pfx + "g_gv_dedup", (size_t)n * sizeof(double));
+        NEED(gm0); NEED(gv0);
+        hipLaunchKernelGGL(reduce_replicas_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, gm, gv, S, n, gm0, gv0);
+        LAUNCH_CHECK(ctx);
+        gm = gm0; gv = gv0;
+      }
       rows_l = N;
     }
     const int n_mod = li == 0 ? N : rows_l;
@@ -1491,7 +1503,15 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
       gm = (double*)ws_get(ctx, mp + std::to_string(li - 1) + "_g_gm", (size_t)n * sizeof(double));
       gv = (double*)ws_get(ctx, mp + std::to_string(li - 1) + "_g_gv", (size_t)n * sizeof(double));
       NEED(gm); NEED(gv);
-      hipLaunchKernelGGL(sample_backward_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, dXin, o.sample, o.mean, o.var, m->jitter, n, gm, gv);
+      LayerState& Lb = *m->layers[li - 1];
+      if (li - 1 == 0 && dedup_layer0 && !Lb.is_head && o.rows == S * N && S > 1) {   // S gradients per element of the shared conditional: summed here
+        const long n0 = (long)N * o.width;
+        hipLaunchKernelGGL(sample_backward_dedup_kernel, dim3(blocks_for(n0)), dim3(256), 0, ctx->stream, dXin, o.sample, o.mean, o.var, m->jitter, S, n0,
+                           gm, gv);
+        dedup_done = true;
+      } else {
+        hipLaunchKernelGGL(sample_backward_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, dXin, o.sample, o.mean, o.var, m->jitter, n, gm, gv);
+      }
       LAUNCH_CHECK(ctx);
     }
   }
