@@ -174,6 +174,8 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
       hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_kl2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_kl3, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_g[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_g[1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_g[2], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_g[3], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_aux2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_kl, hipEventDisableTiming) != hipSuccess) {
     delete c;
@@ -231,6 +233,7 @@ int dcgp_ctx_destroy(dcgp_ctx* ctx) {
   hipEventDestroy(ctx->ev_aux);
   hipEventDestroy(ctx->ev_kl2);
   hipEventDestroy(ctx->ev_kl3);
+  for (hipEvent_t e : ctx->ev_g) hipEventDestroy(e);
   hipEventDestroy(ctx->ev_aux2);
   for (auto& e : ctx->ev_prep)
     if (e) hipEventDestroy(e);

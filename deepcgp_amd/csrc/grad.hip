@@ -450,8 +450,8 @@ __global__ void rownorm_kernel(const double* __restrict__ X, long rows, int L, d
   for (int l = 0; l < L; ++l) { const double v = X[c * L + l]; s += v * v; }
   out[c] = s;
 }
-// one thread per column c and row chunk (blockIdx.y): F1 over dK (in place), F2, csp[chunk][c] = sum_m F2 / A_c, block partials
-__global__ __launch_bounds__(256) void acos_e_form_kernel(double* __restrict__ dKF1, long ld, const double* __restrict__ K, double* __restrict__ F2,
+// one thread per column c and row chunk (blockIdx.y): F1 (beside dK: the chain stream still reads dK), F2, csp[chunk][c] = sum_m F2 / A_c, block partials
+__global__ __launch_bounds__(256) void acos_e_form_kernel(const double* __restrict__ dK, double* __restrict__ F1, long ld, const double* __restrict__ K, double* __restrict__ F2,
                                                           int M, int rows_per_chunk, long Kc, double variance, double w, double b,
                                                           const double* __restrict__ zn, const double* __restrict__ xn, double* __restrict__ csp,
                                                           double* __restrict__ pv, double* __restrict__ pw, double* __restrict__ pb) {
@@ -462,13 +462,13 @@ __global__ __launch_bounds__(256) void acos_e_form_kernel(double* __restrict__ d
   if (c < Kc) {
     const double a2 = xn[c], A = w * a2 + b;
     for (int m = m0; m < m1; ++m) {
-      const double k = K[m * ld + c], dk = dKF1[m * ld + c];
+      const double k = K[m * ld + c], dk = dK[m * ld + c];
       const double theta = 3.14159265358979323846 * (1.0 - k / variance);
       const double sn = sin(theta), cc = (cos(theta) - 1e-15) / (1.0 - 2e-15);
       const double F = sn > 1e-12 ? dk * variance * 0.31830988618379067154 * (1.0 - 2e-15) / sn : 0.0;
       const double q2 = zn[m], Q = w * q2 + b, rt = sqrt(Q * A);
       const double f1 = F / rt, f2 = F * cc;
-      dKF1[m * ld + c] = f1;
+      F1[m * ld + c] = f1;
       F2[m * ld + c] = f2;
       sv += dk * k;
       sw += f1 * (cc * rt - b) / w - 0.5 * f2 * (a2 / A + q2 / Q);
@@ -620,29 +620,29 @@ struct Bk {   // per-backward bookkeeping
   double* ws(const char* name, size_t n_doubles) { return (double*)ws_get(ctx, pfx + "g_" + name, (n_doubles ? n_doubles : 1) * sizeof(double)); }
 };
 
-// Runs the launches issued in its lifetime on the side stream, ordered behind what the main stream holds at construction;
-// done() records `done_ev` (wait for it on the main stream to join).  Restores ctx->stream on every exit path.
-struct SideScope {
+// The three streams of a layer's reverse pass.  main: the data path (the column-wise adjoint, the patch-kernel adjoint, dX for the layer
+// below).  chain: the M x M chain of the conditional (W_r -> dG_r -> dq_sqrt -> dL -> Cholesky adjoint -> S).  tail: what needs S -- the Gram
+// adjoint of K_uu, the KL pieces, the scalar sums, dZ.  Nothing on chain or tail feeds the layer below: the main stream never waits for
+// them inside a step (model_backward joins once, at the end).  Option grad_nofork / no side stream: all three are the main stream.
+struct Lanes { hipStream_t main, chain, tail; bool forked; };
+Lanes lanes_of(dcgp_ctx* c) {
+  Lanes l;
+  l.main = c->stream;
+  l.forked = !c->opt.grad_nofork && !c->no_side && c->stream2 && c->stream2 != c->stream;
+  l.chain = l.forked ? c->stream2 : c->stream;
+  l.tail = l.forked ? (c->stream_aux ? c->stream_aux : c->stream2) : c->stream;
+  return l;
+}
+// launches issued in its lifetime go to `s`, behind `after` (an event already recorded on another stream) when s is not the current stream
+struct OnStream {
   dcgp_ctx* ctx;
-  hipStream_t main_s;
-  bool active;
-  // recorded: fork_ev already marks the fork point on the main stream (the side work is enqueued later than the point it may start at)
-  SideScope(dcgp_ctx* c, hipEvent_t fork_ev, bool recorded = false) : ctx(c), main_s(c->stream) {
-    const bool nofork = c->opt.grad_nofork != 0;   // A/B switch
-    active = !nofork && !c->no_side && c->stream2 && c->stream2 != c->stream;
-    if (active) {
-      if ((!recorded && hipEventRecord(fork_ev, main_s) != hipSuccess) || hipStreamWaitEvent(c->stream2, fork_ev, 0) != hipSuccess) active = false;
-      else c->stream = c->stream2;
-    }
+  hipStream_t saved;
+  bool ok = true;
+  OnStream(dcgp_ctx* c, hipStream_t s, hipEvent_t after) : ctx(c), saved(c->stream) {
+    if (s != saved && after && hipStreamWaitEvent(s, after, 0) != hipSuccess) ok = false;
+    c->stream = s;
   }
-  int done(hipEvent_t done_ev) {
-    if (!active) return DCGP_OK;
-    const hipError_t e = hipEventRecord(done_ev, ctx->stream2);
-    ctx->stream = main_s;
-    active = false;
-    return e == hipSuccess ? DCGP_OK : ctx_fail(ctx, DCGP_ERR_HIP, "grad: event record failed");
-  }
-  ~SideScope() { if (active) { hipStreamSynchronize(ctx->stream2); ctx->stream = main_s; } }
+  ~OnStream() { ctx->stream = saved; }
 };
 
 GenGemm mk(const double* A, long ars, long acs, const double* B, long brs, long bcs, double* C, long crs, int M, int N, int K) {
@@ -872,16 +872,18 @@ int param_operands(Bk& bk, LayerState& L, bool sgg) {
   return DCGP_OK;
 }
 
-// The conditional's backward shared by conv layers and the head.  Kuf, A1: [Mp x ld] with Kc live columns;
-// gm, gv: [Kc][R].  Leaves dKuf in `dKuf` [M x ld], writes L.gq_mu / L.gq_sqrt (overwrites), and S = d ELBO / dKuu
-// (data part) in `S` [M x M, ld Mp]; gvs [Kc] = sum_r gv (= d ELBO / d Knn).
-// s_acc: S already holds the KL part of d ELBO / dKuu (kl_products ran first): add to it.
-int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, const double* gm, const double* gv, double* dKuf, double* S,
-                  double* gvs, bool s_acc = false) {
+// The conditional's backward shared by conv layers and the head, in two calls.  Kuf, A1: [Mp x ld] with Kc live columns; gm, gv: [Kc][R].
+// cond_backward_main (main stream): dKuf [M x ld], gvs [Kc] = sum_r gv (= d ELBO / d Knn), dq_mu; enqueues the chain's first part (W_r -> dG_r
+//   -> dq_sqrt and its term of dL) on the chain stream behind ev_g[0] and marks its own end with ev_g[1].
+// cond_backward_finish (chain stream, behind ev_g[1]): dL's other terms and the Cholesky adjoint, S = d ELBO / dKuu (data part) [M x M, ld Mp];
+//   s_acc: S already holds the KL part (kl_products ran first): add to it.  Marks its end with ev_g[2].
+int cond_backward_main(Bk& bk, const Lanes& ln, LayerState& L, const double* A1, long ld, long Kc, const double* gm, const double* gv, double* dKuf,
+                       double* gvs) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Mp = L.Mp, R = L.R, Rp = L.g.Rp;
   const long mm = (long)Mp * Mp;
   const GpMats& g = L.g;
+  if (ln.forked) HIP_TRY(ctx, hipEventRecord(ctx->ev_g[0], ln.main));   // A1 and gv are there: the chain may start
   hipLaunchKernelGGL(rowsum_small_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, gv, Kc, R, gvs);
   LAUNCH_CHECK(ctx);
   // The column-wise part of the adjoint -- dT, dA1, dK_uf -- in one strip-resident launch where the shape allows and there are
@@ -910,76 +912,8 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
     fb.S = bk.ws("Sgg", (size_t)R * mm);
     NEED(fb.S);
   }
-  // Two independent chains from here.  Side stream: the M x M results that cost a long contraction over the columns and the chain behind
-  // them (W_r -> dG_r -> dq_sqrt, the dq_sqrt term of dL) -- split-k products at ~40 % MFMA utilisation.  Main stream: dT, dA1, dK_uf on
-  // the tuned kernel, then the short chain d alpha -> dq_mu.  They share only read-only inputs; the join is in front of dL's other terms.
-  // (d alpha used to open the side chain: beside the strip kernel its 288 small workgroups took 108 us instead of 8, in front of W_r)
-  hipStream_t main_s = ctx->stream;
-  const bool nofork = ctx->opt.grad_nofork != 0;   // A/B switch
-  const bool fork = !nofork && !ctx->no_side && ctx->stream2 && ctx->stream2 != main_s && L.has_qsqrt;
-  // (the fork point is marked here; the side chain is ENQUEUED behind the main chain: one host thread feeds both streams at ~5 us a launch, and
-  // with few columns -- the head -- the main chain's launches are as short as that: fed second, it sat idle while the host was busy with the side
-  // chain's launches)
-  if (fork) HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, main_s));
-  auto side_chain = [&]() -> int {
-    if (!L.has_qsqrt) return DCGP_OK;
-    // dG_r = tril(A1 dT_r^T) = tril(W_r G_r),  W_r = 2 A1 diag(gv_r) A1^T (symmetric).  Both operands of the long
-    // contraction are then A1 itself (94 MB at the headline size: it stays in the 256 MB Infinity Cache across the R
-    // batches, where the R x larger dT would stream from HBM); lower tiles only, mirrored afterwards.
-    double* Wr = bk.ws("Wr", (size_t)R * mm);
-    NEED(Wr);
-    GenGemm w = mk(A1, ld, 1, A1, 1, ld, Wr, Mp, M, M, (int)Kc);
-    // (the k scaling reads gv [Kc][R] in place, stride R: a transposed copy used to cost 290 us of scattered 8-byte stores per step)
-    w.batch = R; w.c_bs = mm; w.lower_only = 1; w.mirror = 1; w.alpha = 2.0; w.kscale = gv; w.ks_s = R; w.ks_bs = 1;
-    DCGP_TRY(gemm_gen(ctx, w));
-    GenGemm d = mk(Wr, Mp, 1, g.G, Mp, 1, dG, Mp, M, M, M);
-    d.batch = R; d.a_bs = mm; d.b_bs = mm; d.c_bs = mm; d.lower_only = 1;
-    DCGP_TRY(gemm_gen(ctx, d));
-    if (L.white) {
-      hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, dG, (long)Mp, mm, L.gq_sqrt, (long)M,
-                         (long)M * M, M, 1.0, 0);
-      LAUNCH_CHECK(ctx);
-    } else {
-      double* Bm = bk.ws("Bm", (size_t)R * mm);                      // B_r = inv(L)^T dG_r, stored [i][r][k]
-      NEED(Bm);
-      if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(Bm, 0, (size_t)R * mm * sizeof(double), ctx->stream));   // (the padded k of the stacked product below)
-      GenGemm b = mk(g.Linv, 1, Mp, dG, Mp, 1, Bm, Rm, M, M, M);
-      b.batch = R; b.b_bs = mm; b.c_bs = Mp;
-      DCGP_TRY(gemm_gen(ctx, b));
-      hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Bm, Rm, (long)Mp, L.gq_sqrt, (long)M,
-                         (long)M * M, M, 1.0, 0);
-      LAUNCH_CHECK(ctx);
-      GenGemm l2 = mk(Bm, Rm, 1, GT, Mp, 1, dL, Mp, M, M, (int)Rm);   // dL = -tril(sum_r B_r G_r^T), stacked along k: the first of dL's terms
-      l2.alpha = -1.0; l2.lower_only = 1;
-      DCGP_TRY(gemm_gen(ctx, l2));
-    }
-    return DCGP_OK;
-  };
-  // d alpha = A1 gm;  dq_mu = d alpha (whitened) or inv(L)^T d alpha
-  auto alpha_chain = [&]() -> int {
-    DCGP_TRY(gemm_gen(ctx, mk(A1, ld, 1, gm, R, 1, dalpha, Rp, M, R, (int)Kc)));
-    if (L.white) {
-      hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(R), M), dim3(256), 0, ctx->stream, dalpha, (long)Rp, L.gq_mu, (long)R, M, R, 1.0, 0);
-      LAUNCH_CHECK(ctx);
-    } else {
-      DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dalpha, Rp, 1, L.gq_mu, R, M, R, M)));
-    }
-    return DCGP_OK;
-  };
-  auto run_side = [&]() -> int {
-    if (fork) {
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_aux, 0));
-      ctx->stream = ctx->stream2;
-    }
-    int rc_side = side_chain();
-    if (fork) {
-      if (rc_side == DCGP_OK && hipEventRecord(ctx->ev_aux2, ctx->stream2) != hipSuccess) rc_side = DCGP_ERR_HIP;
-      ctx->stream = main_s;
-      if (rc_side != DCGP_OK) hipStreamSynchronize(ctx->stream2);
-    }
-    return rc_side;
-  };
-  // main chain
+  if (!(bk.prep & 1) && ln.forked) HIP_TRY(ctx, hipEventRecord(ctx->ev_g[0], ln.main));   // (the chain reads G^T: behind the launch that made it)
+  // main stream: dT, dA1, dK_uf on the tuned kernels ...
   if (fused_bwd) {
     DCGP_TRY(conv_bwd_fused(ctx, fb));
   } else {
@@ -1026,7 +960,7 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
     }
     hipLaunchKernelGGL(dA1_fix_kernel, dim3(blocks_for(Kc), M), dim3(256), 0, ctx->stream, dA1, A1, gvs, M, Kc, ld);
     LAUNCH_CHECK(ctx);
-    // dKuf = inv(L)^T dA1;  dL -= tril(dKuf A1^T)
+    // dKuf = inv(L)^T dA1
     if ((long)Mp * ld * 8 < (1L << 31)) {   // inv(L) row-major IS the k-major operand of inv(L)^T; upper-triangular product
       GemmArgs a;
       a.Wt = g.Linv; a.ldw = Mp;
@@ -1038,10 +972,68 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
       DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dA1, ld, 1, dKuf, ld, M, (int)Kc, M)));
     }
   }
-  DCGP_TRY(alpha_chain());
-  DCGP_TRY(run_side());
-  if (fork) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux2, 0));   // join: dq_sqrt and its term of dL are done
-  // dL = -tril(sum_r B_r G_r^T [side chain, unwhitened with q_sqrt] + dq_mu alpha^T [unwhitened] + dKuf A1^T)
+  // ... then d alpha = A1 gm and dq_mu = d alpha (whitened) or inv(L)^T d alpha.  (d alpha used to open the chain: beside the strip kernel
+  // its 288 small workgroups took 108 us instead of 8, in front of W_r.)
+  DCGP_TRY(gemm_gen(ctx, mk(A1, ld, 1, gm, R, 1, dalpha, Rp, M, R, (int)Kc)));
+  if (L.white) {
+    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(R), M), dim3(256), 0, ctx->stream, dalpha, (long)Rp, L.gq_mu, (long)R, M, R, 1.0, 0);
+    LAUNCH_CHECK(ctx);
+  } else {
+    DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dalpha, Rp, 1, L.gq_mu, R, M, R, M)));
+  }
+  if (ln.forked) HIP_TRY(ctx, hipEventRecord(ctx->ev_g[1], ln.main));   // dK_uf and dq_mu are there
+  // The chain's first part, ENQUEUED behind the launches above (one host thread feeds the streams at ~4 us a launch; with few columns -- the
+  // head -- the main stream's launches are as short as that: fed second, it sat idle while the host was busy with the chain's).
+  if (L.has_qsqrt) {
+    OnStream on(ctx, ln.chain, ctx->ev_g[0]);
+    if (!on.ok) return ctx_fail(ctx, DCGP_ERR_HIP, "grad: stream wait failed");
+    // dG_r = tril(A1 dT_r^T) = tril(W_r G_r),  W_r = 2 A1 diag(gv_r) A1^T (symmetric).  Both operands of the long
+    // contraction are then A1 itself (94 MB at the headline size: it stays in the 256 MB Infinity Cache across the R
+    // batches, where the R x larger dT would stream from HBM); lower tiles only, stored to both triangles.
+    double* Wr = bk.ws("Wr", (size_t)R * mm);
+    NEED(Wr);
+    GenGemm w = mk(A1, ld, 1, A1, 1, ld, Wr, Mp, M, M, (int)Kc);
+    // (the k scaling reads gv [Kc][R] in place, stride R: a transposed copy used to cost 290 us of scattered 8-byte stores per step)
+    w.batch = R; w.c_bs = mm; w.lower_only = 1; w.mirror = 1; w.alpha = 2.0; w.kscale = gv; w.ks_s = R; w.ks_bs = 1;
+    DCGP_TRY(gemm_gen(ctx, w));
+    GenGemm d = mk(Wr, Mp, 1, g.G, Mp, 1, dG, Mp, M, M, M);
+    d.batch = R; d.a_bs = mm; d.b_bs = mm; d.c_bs = mm; d.lower_only = 1;
+    DCGP_TRY(gemm_gen(ctx, d));
+    if (L.white) {
+      hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, dG, (long)Mp, mm, L.gq_sqrt, (long)M,
+                         (long)M * M, M, 1.0, 0);
+      LAUNCH_CHECK(ctx);
+    } else {
+      double* Bm = bk.ws("Bm", (size_t)R * mm);                      // B_r = inv(L)^T dG_r, stored [i][r][k]
+      NEED(Bm);
+      if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(Bm, 0, (size_t)R * mm * sizeof(double), ctx->stream));   // (the padded k of the stacked product below)
+      GenGemm b = mk(g.Linv, 1, Mp, dG, Mp, 1, Bm, Rm, M, M, M);
+      b.batch = R; b.b_bs = mm; b.c_bs = Mp;
+      DCGP_TRY(gemm_gen(ctx, b));
+      hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Bm, Rm, (long)Mp, L.gq_sqrt, (long)M,
+                         (long)M * M, M, 1.0, 0);
+      LAUNCH_CHECK(ctx);
+      GenGemm l2 = mk(Bm, Rm, 1, GT, Mp, 1, dL, Mp, M, M, (int)Rm);   // dL = -tril(sum_r B_r G_r^T), stacked along k: the first of dL's terms
+      l2.alpha = -1.0; l2.lower_only = 1;
+      DCGP_TRY(gemm_gen(ctx, l2));
+    }
+  }
+  return DCGP_OK;
+}
+
+int cond_backward_finish(Bk& bk, const Lanes& ln, LayerState& L, const double* A1, long ld, long Kc, const double* dKuf, double* S, bool s_acc) {
+  dcgp_ctx* ctx = bk.ctx;
+  const int M = L.M, Mp = L.Mp, R = L.R, Rp = L.g.Rp;
+  const long mm = (long)Mp * Mp;
+  const GpMats& g = L.g;
+  OnStream on(ctx, ln.chain, ctx->ev_g[1]);
+  if (!on.ok) return ctx_fail(ctx, DCGP_ERR_HIP, "grad: stream wait failed");
+  double* dL = bk.ws("dL", (size_t)mm);
+  double* Lc = bk.ws("Lc", (size_t)mm);
+  double* Pm = bk.ws("Pm", (size_t)mm);
+  double* S1 = bk.ws("S1", (size_t)mm);
+  NEED(dL); NEED(Lc); NEED(Pm); NEED(S1);
+  // dL = -tril(sum_r B_r G_r^T [the chain's first part, unwhitened with q_sqrt] + dq_mu alpha^T [unwhitened] + dKuf A1^T)
   int dl_acc = (!L.white && L.has_qsqrt) ? 1 : 0;
   if (!L.white) {
     GenGemm l1 = mk(L.gq_mu, R, 1, g.alpha, 1, Rp, dL, Mp, M, M, R);
@@ -1053,10 +1045,6 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   l3.alpha = -1.0; l3.lower_only = 1; l3.accumulate = dl_acc;
   DCGP_TRY(gemm_gen(ctx, l3));
   // Cholesky adjoint: S = inv(L)^T Phi(L^T dL) inv(L)
-  double* Lc = bk.ws("Lc", (size_t)mm);
-  double* Pm = bk.ws("Pm", (size_t)mm);
-  double* S1 = bk.ws("S1", (size_t)mm);
-  NEED(Lc); NEED(Pm); NEED(S1);
   GenGemm ph = mk(Lc, 1, Mp, dL, Mp, 1, Pm, Mp, M, M, M);
   ph.phi = 1;   // Phi(L^T dL) in the product's epilogue
   DCGP_TRY(gemm_gen(ctx, ph));
@@ -1065,6 +1053,7 @@ int cond_backward(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, con
   if (s_acc) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_kl3, 0));   // S holds the KL part, written on the auxiliary stream
   sf.accumulate = s_acc ? 1 : 0;
   DCGP_TRY(gemm_gen(ctx, sf));
+  if (ln.forked) HIP_TRY(ctx, hipEventRecord(ctx->ev_g[2], ctx->stream));
   return DCGP_OK;
 }
 
@@ -1126,11 +1115,34 @@ int end_layer(Bk& bk, LayerState& L) {
   return DCGP_OK;
 }
 
+// what is left of a layer once S = d ELBO / dKuu is there, on the tail stream: Gram adjoint of K_uu, KL pieces, the patch adjoint's part of
+// dZ (dzp, from the main stream: behind ev_g[3]), the scalar sums.  kd: d ELBO / d Knn per column (conv layers) or null.
+int layer_tail(Bk& bk, const Lanes& ln, LayerState& L, const double* S, const double* dzp, const double* kd, long n_kd, bool frozen_prior) {
+  dcgp_ctx* ctx = bk.ctx;
+  const int M = L.M, Ld = L.v.L;
+  OnStream on(ctx, ln.tail, ctx->ev_g[2]);
+  if (!on.ok) return ctx_fail(ctx, DCGP_ERR_HIP, "grad: stream wait failed");
+  if (kd) DCGP_TRY(add_scalar(bk, L, 0, kd, n_kd, 1.0));          // Knn = variance on every column
+  if (!bk.kl_early) DCGP_TRY(kl_products(bk, L, frozen_prior || L.white ? nullptr : const_cast<double*>(S), false));
+  DCGP_TRY(kl_apply(bk, L, frozen_prior));
+  DCGP_TRY(kuu_backward(bk, L, L.Z, S, L.Mp, true));
+  if (ln.forked) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_g[3], 0));   // behind the main stream's part of the layer
+  hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(Ld), M), dim3(256), 0, ctx->stream, dzp, (long)Ld, L.gZ, (long)Ld, M, Ld, 1.0, 1);
+  LAUNCH_CHECK(ctx);
+  DCGP_TRY(end_layer(bk, L));
+  if (ln.forked) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_kl, ctx->stream));
+    bk.side_pending = true;
+  }
+  return DCGP_OK;
+}
+
 // ConvLayer backward.  Xin: the layer's input images ([n_mod, H, W, C], row n reads image n % n_mod); gm / gv [rows * P][R].
 int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod, const double* gm, const double* gv, double* dXin) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Mp = L.Mp, P = L.v.P, Ld = L.v.L;
   const long Kc = (long)rows * P, ld = col_ld(Kc);
+  const Lanes ln = lanes_of(ctx);
   DCGP_TRY(begin_layer(bk, L));
   // forward leftovers (conv_forward / cond_core workspaces)
   auto itB = ctx->ws.find(bk.pfx + "Kuf"), itA = ctx->ws.find(bk.pfx + "A1");
@@ -1139,36 +1151,20 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   const double* Kuf = (const double*)itB->second.first;
   const double* A1 = (const double*)itA->second.first;
   double* dKuf = bk.ws("dKuf", (size_t)Mp * ld);
+  double* E = bk.ws("E", (size_t)Mp * ld);       // (not over dK_uf: the chain stream still reads that)
   double* S = bk.ws("S", (size_t)Mp * Mp);
   double* gvs = bk.ws("gvs", Kc);
   double* cs = bk.ws("cs", Kc);
   double* Xcol = bk.ws("Xcol", (size_t)Kc * Ld);
-  NEED(dKuf); NEED(S); NEED(gvs); NEED(cs); NEED(Xcol);
-  DCGP_TRY(cond_backward(bk, L, A1, ld, Kc, gm, gv, dKuf, S, gvs));
-  // two independent tails: the M x M one (Gram adjoint of K_uu, KL adjoint: ~25 small launches) on the side stream, the
-  // patch-kernel adjoint on the main stream; both add into dZ, so the main one collects its part in a scratch first
   double* dzp = bk.ws("dz_patch", (size_t)M * Ld);
-  NEED(dzp);
-  // (fork point here; the side chain is enqueued behind the main stream's launches below -- see head_backward)
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-  auto side_tail = [&](bool* forked) -> int {
-    SideScope side(ctx, ctx->ev_fork, true);
-    *forked = side.active;
-    DCGP_TRY(add_scalar(bk, L, 0, gvs, Kc, 1.0));                  // Knn = variance on every column
-    DCGP_TRY(kuu_backward(bk, L, L.Z, S, Mp, true));
-    if (!bk.kl_early) DCGP_TRY(kl_products(bk, L, nullptr, false));
-    DCGP_TRY(kl_apply(bk, L, true));
-    if (side.active) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux, 0));   // (the side stream: behind the main stream's part of the layer)
-    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(Ld), M), dim3(256), 0, ctx->stream, dzp, (long)Ld, L.gZ, (long)Ld, M, Ld, 1.0, 1);
-    LAUNCH_CHECK(ctx);
-    DCGP_TRY(end_layer(bk, L));
-    bk.side_pending = bk.side_pending || side.active;
-    return side.done(ctx->ev_kl);
-  };
+  NEED(dKuf); NEED(E); NEED(S); NEED(gvs); NEED(cs); NEED(Xcol); NEED(dzp);
+  // main stream: the column-wise adjoint of the conditional, then the patch-kernel adjoint -> dX.  The M x M chain behind the conditional
+  // runs beside them on the chain stream, what needs its result on the tail stream (Lanes).
+  DCGP_TRY(cond_backward_main(bk, ln, L, A1, ld, Kc, gm, gv, dKuf, gvs));
   DCGP_TRY(im2col(ctx, L, Xin, n_mod, Kc, Xcol));
   double* dXcol = nullptr;
   if (dXin) { dXcol = bk.ws("dXcol", (size_t)Kc * Ld); NEED(dXcol); }
-  if (L.base_type == 1) {   // ArcCosine(order 0): F1 over dKuf, F2 beside it, the RBF machinery on (F1, rowsum(F2) / Q, colsum(F2) / A, w)
+  if (L.base_type == 1) {   // ArcCosine(order 0): F1, F2 beside it, the RBF machinery on (F1, rowsum(F2) / Q, colsum(F2) / A, w)
     const unsigned nb = blocks_for(Kc);
     int chunks = (int)std::min<long>(16, std::max<long>(1, 2048 / nb));
     chunks = std::min(chunks, (M + 15) / 16);
@@ -1185,7 +1181,7 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
     NEED(F2); NEED(xn); NEED(csp); NEED(pv); NEED(pw); NEED(pb); NEED(rs2); NEED(rsp);
     hipLaunchKernelGGL(rownorm_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, Xcol, Kc, Ld, xn);
     LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(acos_e_form_kernel, dim3(nb, chunks), dim3(256), 0, ctx->stream, dKuf, ld, Kuf, F2, M, rpc, Kc, L.variance, L.acos_w, L.acos_b,
+    hipLaunchKernelGGL(acos_e_form_kernel, dim3(nb, chunks), dim3(256), 0, ctx->stream, dKuf, E, ld, Kuf, F2, M, rpc, Kc, L.variance, L.acos_w, L.acos_b,
                        L.zn, xn, csp, pv, pw, pb);
     LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks_for(Kc)), dim3(256), 0, ctx->stream, csp, chunks, Kc, cs);
@@ -1201,10 +1197,10 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
       hipLaunchKernelGGL(acos_divide_kernel, dim3(blocks_for(M)), dim3(256), 0, ctx->stream, rs2, L.zn, M, L.acos_w, L.acos_b);
       LAUNCH_CHECK(ctx);
     }
-    DCGP_TRY(patch_backward(bk, L, dKuf, ld, Kc, cs, Xcol, dXcol, 0, nullptr, dzp, rs2, L.acos_w));
+    DCGP_TRY(patch_backward(bk, L, E, ld, Kc, cs, Xcol, dXcol, 0, nullptr, dzp, rs2, L.acos_w));
   } else {
-    DCGP_TRY(e_form(bk, L, dKuf, ld, 1, nullptr, 1.0, Kuf, ld, dKuf, ld, Kc, cs, nullptr));   // E over dKuf
-    DCGP_TRY(patch_backward(bk, L, dKuf, ld, Kc, cs, Xcol, dXcol, 0, nullptr, dzp));
+    DCGP_TRY(e_form(bk, L, dKuf, ld, 1, nullptr, 1.0, Kuf, ld, E, ld, Kc, cs, nullptr));
+    DCGP_TRY(patch_backward(bk, L, E, ld, Kc, cs, Xcol, dXcol, 0, nullptr, dzp));
   }
   if (dXin) {
     const long n = (long)rows * L.v.H * L.v.W * L.v.C;
@@ -1217,13 +1213,10 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
       LAUNCH_CHECK(ctx);
     }
   }
-  // The main stream's part of this layer ends here (dX is out).  Everything that is left -- the M x M tail, adding the patch part of dZ,
-  // the scalar sums -- yields this layer's own parameter gradients only: it stays on the side stream, and the main stream goes straight on
-  // to the layer below instead of waiting for it (model_backward joins once, at the end of the step)
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));
-  bool forked = false;
-  DCGP_TRY(side_tail(&forked));
-  return DCGP_OK;
+  // The main stream's part of this layer ends here (dX is out): it goes straight on to the layer below.
+  if (ln.forked) HIP_TRY(ctx, hipEventRecord(ctx->ev_g[3], ctx->stream));
+  DCGP_TRY(cond_backward_finish(bk, ln, L, A1, ld, Kc, dKuf, S, false));
+  return layer_tail(bk, ln, L, S, dzp, gvs, Kc, true);
 }
 
 // Dense head backward: gpflow RBF(D, ARD=True) on the flattened features (--last-kernel rbf, conv_gp/models.py:160-168).
@@ -1251,7 +1244,10 @@ int dense_head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int 
   NEED(A1); NEED(dKzx); NEED(S); NEED(gkd); NEED(cs); NEED(Zs); NEED(Xs); NEED(dZs); NEED(dXs);
   if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(A1 + (size_t)M * ld, 0, (size_t)(Mp - M) * ld * sizeof(double), ctx->stream));
   DCGP_TRY(gemm_gen(ctx, mk(L.g.Linv, Mp, 1, Kzx, ld, 1, A1, ld, M, rows, M)));
-  DCGP_TRY(cond_backward(bk, L, A1, ld, rows, gm, gv, dKzx, S, gkd, bk.kl_early && !L.white));
+  Lanes ln = lanes_of(ctx);
+  ln.forked = false; ln.chain = ln.tail = ln.main;   // (a few hundred columns, one patch: everything in line on the main stream)
+  DCGP_TRY(cond_backward_main(bk, ln, L, A1, ld, rows, gm, gv, dKzx, gkd));
+  DCGP_TRY(cond_backward_finish(bk, ln, L, A1, ld, rows, dKzx, S, bk.kl_early && !L.white));
   if (!bk.kl_early) DCGP_TRY(kl_products(bk, L, L.white ? nullptr : S, false));
   DCGP_TRY(kl_apply(bk, L, false));
   DCGP_TRY(add_scalar(bk, L, 0, gkd, rows, 1.0));             // Kdiag = variance
@@ -1294,13 +1290,12 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   NEED(A1); NEED(dKzx); NEED(S); NEED(gkd); NEED(Kfull); NEED(E); NEED(cs); NEED(raw); NEED(Xcol); NEED(dXcol);
   if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(A1 + (size_t)M * ld, 0, (size_t)(Mp - M) * ld * sizeof(double), ctx->stream));   // padded rows: operands of gemm_tn
   DCGP_TRY(gemm_gen(ctx, mk(L.g.Linv, Mp, 1, Kzx, ld, 1, A1, ld, M, rows, M)));      // the fused forward keeps A1 on chip
-  DCGP_TRY(cond_backward(bk, L, A1, ld, rows, gm, gv, dKzx, S, gkd, bk.kl_early && !L.white));
-  // as in conv_backward: KL + Gram adjoints on the side stream, the patch-kernel adjoints (K_zx, K_diag) on the main one
+  const Lanes ln = lanes_of(ctx);
+  // as in conv_backward: the conditional's column-wise adjoint and the patch-kernel adjoints (K_zx, K_diag) on the main stream, the M x M
+  // chain and what needs S beside them
+  DCGP_TRY(cond_backward_main(bk, ln, L, A1, ld, rows, gm, gv, dKzx, gkd));
   double* dzp = bk.ws("dz_patch", (size_t)M * Ld);
   NEED(dzp);
-  // the fork point of the side chain (KL + Gram adjoints: they need S only); the chain itself is ENQUEUED behind the patch-kernel adjoints
-  // below -- what the previous layer's reverse pass waits for is dX, and one host thread feeding two streams of 5-10 us launches starved the main one
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   // every patch response again: Kfull[m][n * P + p] = k(Z_m, x_np)
   PatchRbfArgs a;
   a.X = Xin; a.N = rows; a.n_mod = n_mod;
@@ -1358,22 +1353,10 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
                        L.v.Wo, Ld, dXin);
     LAUNCH_CHECK(ctx);
   }
-  // the main stream's part of the head ends here (dX is out); the rest yields the head's own parameter gradients and stays on the side stream
-  // (see conv_backward)
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));
-  {
-    SideScope side(ctx, ctx->ev_fork, true);
-    if (!bk.kl_early) DCGP_TRY(kl_products(bk, L, L.white ? nullptr : S, false));
-    DCGP_TRY(kl_apply(bk, L, false));
-    DCGP_TRY(kuu_backward(bk, L, L.Z, S, Mp, true));
-    if (side.active) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux, 0));
-    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(Ld), M), dim3(256), 0, ctx->stream, dzp, (long)Ld, L.gZ, (long)Ld, M, Ld, 1.0, 1);
-    LAUNCH_CHECK(ctx);
-    DCGP_TRY(end_layer(bk, L));
-    bk.side_pending = bk.side_pending || side.active;
-    DCGP_TRY(side.done(ctx->ev_kl));
-  }
-  return DCGP_OK;
+  // the main stream's part of the head ends here (dX is out): it goes on to the layer below (see conv_backward)
+  if (ln.forked) HIP_TRY(ctx, hipEventRecord(ctx->ev_g[3], ctx->stream));
+  DCGP_TRY(cond_backward_finish(bk, ln, L, A1, ld, rows, dKzx, S, bk.kl_early && !L.white));
+  return layer_tail(bk, ln, L, S, dzp, nullptr, 0, false);
 }
 
 }  // namespace
