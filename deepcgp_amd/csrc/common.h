@@ -89,8 +89,8 @@ struct dcgp_ctx {
   // parameter-only operands, ev_kl3 behind the KL adjoint's products
   hipEvent_t ev_kl2 = nullptr, ev_kl3 = nullptr;
   // reverse pass of a layer (grad.hip, Lanes): [0] main -> chain: the conditional's operands are there, [1] main -> chain: dK_uf and dq_mu,
-  // [2] chain -> tail: S = d ELBO / dK_uu, [3] main -> tail: the patch adjoint's part of dZ and the partial sums
-  hipEvent_t ev_g[4] = {};
+  // [2] chain -> tail: S = d ELBO / dK_uu, [3] main -> tail: the patch adjoint's part of dZ and the partial sums, [4] chain -> tail: dq_sqrt
+  hipEvent_t ev_g[5] = {};
   hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;  // fork / join of a short side-stream excursion inside a layer
   std::string err;
   std::map<std::string, hipGraphExec_t> chain_graphs;   // captured panel-launch sequences of the factorisation chain, by argument set (chol_fused.hip)

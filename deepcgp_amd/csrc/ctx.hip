@@ -176,6 +176,7 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
       hipEventCreateWithFlags(&c->ev_kl3, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_g[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_g[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_g[2], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_g[3], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_g[4], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_aux2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_kl, hipEventDisableTiming) != hipSuccess) {
     delete c;

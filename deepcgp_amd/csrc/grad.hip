@@ -613,6 +613,7 @@ struct Bk {   // per-backward bookkeeping
   // its reverse pass (end_layer; they feed nothing else, and each used to be a 5 us launch in the middle of the data path)
   struct PendingSum { const double* in; long n; double scale; double* out; };
   std::vector<PendingSum> pending;
+  bool last_layer = false;     // the layer being processed is the last one of the reverse pass (layer 0)
   int prep = 0;                // the layer being processed: bit 0 fills + GT + Lc, bit 1 S_r done beside the forward pass (grad_kl_early)
   bool kl_early = false;       // the layer being processed had its kl_products beside the forward pass (grad_kl_early)
   bool side_pending = false;   // a layer left the end of its reverse pass on the side stream: model_backward joins once, at the end
@@ -700,8 +701,9 @@ int kuu_scalars(Bk& bk, LayerState& L, const char* tag) {
 // RBF Gram backward from S = d ELBO / dK (unsymmetrised).  dZ accumulates into L.gZ when Zsrc is the live Z (want_dz).
 // tag: prefix of its scratch; defer_scalars: leave the hyper-parameter partial sums there (kuu_scalars adds them later -- the scalar
 // slots of a layer are zeroed at the start of its reverse pass, and the KL half of a frozen prior runs before that)
+// dz_after: the product that adds into dZ is enqueued behind this event (the patch adjoint adds into the same dZ on another stream)
 int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, long lds, bool want_dz, double* dz_out = nullptr,
-                 const char* tag = "kuu", bool defer_scalars = false) {
+                 const char* tag = "kuu", bool defer_scalars = false, hipEvent_t dz_after = nullptr) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Ld = L.v.L;
   const double inv_l2 = 1.0 / (L.ls * L.ls), inv_l3 = inv_l2 / L.ls;
@@ -730,6 +732,7 @@ int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, lon
   if (!defer_scalars) DCGP_TRY(kuu_scalars(bk, L, tag));
   if (want_dz) {
     // dZ += cz (Es Z - rs o Z): the correction rides in the product's epilogue
+    if (dz_after) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, dz_after, 0));
     GenGemm e = mk(Es, M, 1, Zsrc, Ld, 1, dz_out ? dz_out : L.gZ, Ld, M, Ld, M);
     e.alpha = cz; e.accumulate = 1; e.sub_v = rs; e.sub_x = Zsrc; e.sx_rs = Ld;
     DCGP_TRY(gemm_gen(ctx, e));
@@ -872,13 +875,28 @@ int param_operands(Bk& bk, LayerState& L, bool sgg) {
   return DCGP_OK;
 }
 
+// The terms of dL that do not come out of the chain:  dL = -tril(dq_mu alpha^T) [unwhitened; the first writer of dL],  dL (+)= -tril(dKuf A1^T).
+// The first one is ALWAYS formed on the main stream, right behind dq_mu: the tail stream adds the KL part into dq_mu as soon as ev_g[1] is past.
+int dl_term_mu(Bk& bk, LayerState& L, double* dL) {
+  GenGemm l1 = mk(L.gq_mu, L.R, 1, L.g.alpha, 1, L.g.Rp, dL, L.Mp, L.M, L.M, L.R);
+  l1.alpha = -1.0; l1.lower_only = 1;
+  return gemm_gen(bk.ctx, l1);
+}
+int dl_term_kuf(Bk& bk, LayerState& L, const double* A1, long ld, long Kc, const double* dKuf, double* dL) {
+  GenGemm l3 = mk(dKuf, ld, 1, A1, 1, ld, dL, L.Mp, L.M, L.M, (int)Kc);
+  l3.alpha = -1.0; l3.lower_only = 1; l3.accumulate = L.white ? 0 : 1;   // (whitened: the only term)
+  return gemm_gen(bk.ctx, l3);
+}
+
 // The conditional's backward shared by conv layers and the head, in two calls.  Kuf, A1: [Mp x ld] with Kc live columns; gm, gv: [Kc][R].
 // cond_backward_main (main stream): dKuf [M x ld], gvs [Kc] = sum_r gv (= d ELBO / d Knn), dq_mu; enqueues the chain's first part (W_r -> dG_r
 //   -> dq_sqrt and its term of dL) on the chain stream behind ev_g[0] and marks its own end with ev_g[1].
 // cond_backward_finish (chain stream, behind ev_g[1]): dL's other terms and the Cholesky adjoint, S = d ELBO / dKuu (data part) [M x M, ld Mp];
 //   s_acc: S already holds the KL part (kl_products ran first): add to it.  Marks its end with ev_g[2].
+// dl_on_main: dL's term from dK_uf is formed on the main stream as well (the last layer of the reverse pass: nothing follows it there, and the
+// chain is what the step ends on).
 int cond_backward_main(Bk& bk, const Lanes& ln, LayerState& L, const double* A1, long ld, long Kc, const double* gm, const double* gv, double* dKuf,
-                       double* gvs) {
+                       double* gvs, bool dl_on_main) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Mp = L.Mp, R = L.R, Rp = L.g.Rp;
   const long mm = (long)Mp * Mp;
@@ -981,7 +999,9 @@ int cond_backward_main(Bk& bk, const Lanes& ln, LayerState& L, const double* A1,
   } else {
     DCGP_TRY(gemm_gen(ctx, mk(g.Linv, 1, Mp, dalpha, Rp, 1, L.gq_mu, R, M, R, M)));
   }
-  if (ln.forked) HIP_TRY(ctx, hipEventRecord(ctx->ev_g[1], ln.main));   // dK_uf and dq_mu are there
+  if (!L.white) DCGP_TRY(dl_term_mu(bk, L, dL));
+  if (dl_on_main) DCGP_TRY(dl_term_kuf(bk, L, A1, ld, Kc, dKuf, dL));
+  if (ln.forked) HIP_TRY(ctx, hipEventRecord(ctx->ev_g[1], ln.main));   // dK_uf, dq_mu and dL's first term(s) are there
   // The chain's first part, ENQUEUED behind the launches above (one host thread feeds the streams at ~4 us a launch; with few columns -- the
   // head -- the main stream's launches are as short as that: fed second, it sat idle while the host was busy with the chain's).
   if (L.has_qsqrt) {
@@ -1013,17 +1033,20 @@ int cond_backward_main(Bk& bk, const Lanes& ln, LayerState& L, const double* A1,
       hipLaunchKernelGGL(mask_lower_kernel, dim3(blocks_for(M), M, R), dim3(256), 0, ctx->stream, Bm, Rm, (long)Mp, L.gq_sqrt, (long)M,
                          (long)M * M, M, 1.0, 0);
       LAUNCH_CHECK(ctx);
-      GenGemm l2 = mk(Bm, Rm, 1, GT, Mp, 1, dL, Mp, M, M, (int)Rm);   // dL = -tril(sum_r B_r G_r^T), stacked along k: the first of dL's terms
-      l2.alpha = -1.0; l2.lower_only = 1;
+      if (ln.forked) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_g[1], 0));   // (dL's first writer is on the main stream)
+      GenGemm l2 = mk(Bm, Rm, 1, GT, Mp, 1, dL, Mp, M, M, (int)Rm);   // dL -= tril(sum_r B_r G_r^T), stacked along k
+      l2.alpha = -1.0; l2.lower_only = 1; l2.accumulate = 1;
       DCGP_TRY(gemm_gen(ctx, l2));
     }
+    if (ln.forked) HIP_TRY(ctx, hipEventRecord(ctx->ev_g[4], ctx->stream));   // dq_sqrt is there
   }
   return DCGP_OK;
 }
 
-int cond_backward_finish(Bk& bk, const Lanes& ln, LayerState& L, const double* A1, long ld, long Kc, const double* dKuf, double* S, bool s_acc) {
+int cond_backward_finish(Bk& bk, const Lanes& ln, LayerState& L, const double* A1, long ld, long Kc, const double* dKuf, double* S, bool s_acc,
+                         bool dl_on_main) {
   dcgp_ctx* ctx = bk.ctx;
-  const int M = L.M, Mp = L.Mp, R = L.R, Rp = L.g.Rp;
+  const int M = L.M, Mp = L.Mp;
   const long mm = (long)Mp * Mp;
   const GpMats& g = L.g;
   OnStream on(ctx, ln.chain, ctx->ev_g[1]);
@@ -1033,17 +1056,8 @@ int cond_backward_finish(Bk& bk, const Lanes& ln, LayerState& L, const double* A
   double* Pm = bk.ws("Pm", (size_t)mm);
   double* S1 = bk.ws("S1", (size_t)mm);
   NEED(dL); NEED(Lc); NEED(Pm); NEED(S1);
-  // dL = -tril(sum_r B_r G_r^T [the chain's first part, unwhitened with q_sqrt] + dq_mu alpha^T [unwhitened] + dKuf A1^T)
-  int dl_acc = (!L.white && L.has_qsqrt) ? 1 : 0;
-  if (!L.white) {
-    GenGemm l1 = mk(L.gq_mu, R, 1, g.alpha, 1, Rp, dL, Mp, M, M, R);
-    l1.alpha = -1.0; l1.lower_only = 1; l1.accumulate = dl_acc;
-    DCGP_TRY(gemm_gen(ctx, l1));
-    dl_acc = 1;
-  }
-  GenGemm l3 = mk(dKuf, ld, 1, A1, 1, ld, dL, Mp, M, M, (int)Kc);
-  l3.alpha = -1.0; l3.lower_only = 1; l3.accumulate = dl_acc;
-  DCGP_TRY(gemm_gen(ctx, l3));
+  // dL = -tril(dq_mu alpha^T [main stream, unwhitened] + sum_r B_r G_r^T [the chain's first part, unwhitened with q_sqrt] + dKuf A1^T)
+  if (!dl_on_main) DCGP_TRY(dl_term_kuf(bk, L, A1, ld, Kc, dKuf, dL));
   // Cholesky adjoint: S = inv(L)^T Phi(L^T dL) inv(L)
   GenGemm ph = mk(Lc, 1, Mp, dL, Mp, 1, Pm, Mp, M, M, M);
   ph.phi = 1;   // Phi(L^T dL) in the product's epilogue
@@ -1084,14 +1098,9 @@ int e_form(Bk& bk, LayerState& L, const double* dK, long lddk, int pdiv, const d
   return DCGP_OK;
 }
 
-// the zero fills in front of a layer's reverse pass: scalar slots, gradient block, the scratch its patch adjoint collects dZ in
+// the zero fills in front of a layer's reverse pass: scalar slots, gradient block
 int layer_fills(Bk& bk, LayerState& L) {
   DCGP_TRY(L.ensure_grads());
-  if (!L.in_scale) {
-    double* dzp = bk.ws("dz_patch", (size_t)L.M * L.v.L);
-    NEED(dzp);
-    HIP_TRY(bk.ctx, hipMemsetAsync(dzp, 0, (size_t)L.M * L.v.L * sizeof(double), bk.ctx->stream));
-  }
   HIP_TRY(bk.ctx, hipMemsetAsync(L.gslots, 0, 48 * sizeof(double), bk.ctx->stream));
   if (L.grad_block_count() * sizeof(double) <= (8u << 20)) {   // a small block ([Z | q_mu | q_sqrt | w | gscal | gard], contiguous): one fill
     HIP_TRY(bk.ctx, hipMemsetAsync(L.gZ, 0, L.grad_block_count() * sizeof(double), bk.ctx->stream));
@@ -1115,20 +1124,26 @@ int end_layer(Bk& bk, LayerState& L) {
   return DCGP_OK;
 }
 
-// what is left of a layer once S = d ELBO / dKuu is there, on the tail stream: Gram adjoint of K_uu, KL pieces, the patch adjoint's part of
-// dZ (dzp, from the main stream: behind ev_g[3]), the scalar sums.  kd: d ELBO / d Knn per column (conv layers) or null.
-int layer_tail(Bk& bk, const Lanes& ln, LayerState& L, const double* S, const double* dzp, const double* kd, long n_kd, bool frozen_prior) {
+// What is left of a layer, on the tail stream.  Behind the conditional's own dq_mu / dq_sqrt (ev_g[1], ev_g[4]): the KL pieces.  Behind
+// S = d ELBO / dKuu (ev_g[2]): the Gram adjoint of K_uu, whose product adds into the dZ the main stream's patch adjoint adds into (behind
+// ev_g[3]).  Last the layer's scalar sums.  kd: d ELBO / d Knn per column (conv layers) or null.
+int layer_tail(Bk& bk, const Lanes& ln, LayerState& L, const double* S, const double* kd, long n_kd, bool frozen_prior) {
   dcgp_ctx* ctx = bk.ctx;
-  const int M = L.M, Ld = L.v.L;
-  OnStream on(ctx, ln.tail, ctx->ev_g[2]);
+  OnStream on(ctx, ln.tail, ctx->ev_g[1]);
   if (!on.ok) return ctx_fail(ctx, DCGP_ERR_HIP, "grad: stream wait failed");
   if (kd) DCGP_TRY(add_scalar(bk, L, 0, kd, n_kd, 1.0));          // Knn = variance on every column
-  if (!bk.kl_early) DCGP_TRY(kl_products(bk, L, frozen_prior || L.white ? nullptr : const_cast<double*>(S), false));
-  DCGP_TRY(kl_apply(bk, L, frozen_prior));
-  DCGP_TRY(kuu_backward(bk, L, L.Z, S, L.Mp, true));
-  if (ln.forked) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_g[3], 0));   // behind the main stream's part of the layer
-  hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for(Ld), M), dim3(256), 0, ctx->stream, dzp, (long)Ld, L.gZ, (long)Ld, M, Ld, 1.0, 1);
-  LAUNCH_CHECK(ctx);
+  const bool kl_first = bk.kl_early || frozen_prior || L.white;   // (otherwise the KL products add into S: behind it)
+  if (ln.forked && L.has_qsqrt) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_g[4], 0));
+  if (kl_first) {
+    if (!bk.kl_early) DCGP_TRY(kl_products(bk, L, nullptr, false));
+    DCGP_TRY(kl_apply(bk, L, frozen_prior));
+  }
+  if (ln.forked) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_g[2], 0));
+  if (!kl_first) {
+    DCGP_TRY(kl_products(bk, L, const_cast<double*>(S), false));
+    DCGP_TRY(kl_apply(bk, L, frozen_prior));
+  }
+  DCGP_TRY(kuu_backward(bk, L, L.Z, S, L.Mp, true, nullptr, "kuu", false, ln.forked ? ctx->ev_g[3] : nullptr));
   DCGP_TRY(end_layer(bk, L));
   if (ln.forked) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_kl, ctx->stream));
@@ -1156,11 +1171,10 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   double* gvs = bk.ws("gvs", Kc);
   double* cs = bk.ws("cs", Kc);
   double* Xcol = bk.ws("Xcol", (size_t)Kc * Ld);
-  double* dzp = bk.ws("dz_patch", (size_t)M * Ld);
-  NEED(dKuf); NEED(E); NEED(S); NEED(gvs); NEED(cs); NEED(Xcol); NEED(dzp);
+  NEED(dKuf); NEED(E); NEED(S); NEED(gvs); NEED(cs); NEED(Xcol);
   // main stream: the column-wise adjoint of the conditional, then the patch-kernel adjoint -> dX.  The M x M chain behind the conditional
   // runs beside them on the chain stream, what needs its result on the tail stream (Lanes).
-  DCGP_TRY(cond_backward_main(bk, ln, L, A1, ld, Kc, gm, gv, dKuf, gvs));
+  DCGP_TRY(cond_backward_main(bk, ln, L, A1, ld, Kc, gm, gv, dKuf, gvs, bk.last_layer && ln.forked));
   DCGP_TRY(im2col(ctx, L, Xin, n_mod, Kc, Xcol));
   double* dXcol = nullptr;
   if (dXin) { dXcol = bk.ws("dXcol", (size_t)Kc * Ld); NEED(dXcol); }
@@ -1197,10 +1211,10 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
       hipLaunchKernelGGL(acos_divide_kernel, dim3(blocks_for(M)), dim3(256), 0, ctx->stream, rs2, L.zn, M, L.acos_w, L.acos_b);
       LAUNCH_CHECK(ctx);
     }
-    DCGP_TRY(patch_backward(bk, L, E, ld, Kc, cs, Xcol, dXcol, 0, nullptr, dzp, rs2, L.acos_w));
+    DCGP_TRY(patch_backward(bk, L, E, ld, Kc, cs, Xcol, dXcol, 0, nullptr, nullptr, rs2, L.acos_w));
   } else {
     DCGP_TRY(e_form(bk, L, dKuf, ld, 1, nullptr, 1.0, Kuf, ld, E, ld, Kc, cs, nullptr));
-    DCGP_TRY(patch_backward(bk, L, E, ld, Kc, cs, Xcol, dXcol, 0, nullptr, dzp));
+    DCGP_TRY(patch_backward(bk, L, E, ld, Kc, cs, Xcol, dXcol, 0));
   }
   if (dXin) {
     const long n = (long)rows * L.v.H * L.v.W * L.v.C;
@@ -1215,8 +1229,8 @@ int conv_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   }
   // The main stream's part of this layer ends here (dX is out): it goes straight on to the layer below.
   if (ln.forked) HIP_TRY(ctx, hipEventRecord(ctx->ev_g[3], ctx->stream));
-  DCGP_TRY(cond_backward_finish(bk, ln, L, A1, ld, Kc, dKuf, S, false));
-  return layer_tail(bk, ln, L, S, dzp, gvs, Kc, true);
+  DCGP_TRY(cond_backward_finish(bk, ln, L, A1, ld, Kc, dKuf, S, false, bk.last_layer && ln.forked));
+  return layer_tail(bk, ln, L, S, gvs, Kc, true);
 }
 
 // Dense head backward: gpflow RBF(D, ARD=True) on the flattened features (--last-kernel rbf, conv_gp/models.py:160-168).
@@ -1246,8 +1260,8 @@ int dense_head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int 
   DCGP_TRY(gemm_gen(ctx, mk(L.g.Linv, Mp, 1, Kzx, ld, 1, A1, ld, M, rows, M)));
   Lanes ln = lanes_of(ctx);
   ln.forked = false; ln.chain = ln.tail = ln.main;   // (a few hundred columns, one patch: everything in line on the main stream)
-  DCGP_TRY(cond_backward_main(bk, ln, L, A1, ld, rows, gm, gv, dKzx, gkd));
-  DCGP_TRY(cond_backward_finish(bk, ln, L, A1, ld, rows, dKzx, S, bk.kl_early && !L.white));
+  DCGP_TRY(cond_backward_main(bk, ln, L, A1, ld, rows, gm, gv, dKzx, gkd, false));
+  DCGP_TRY(cond_backward_finish(bk, ln, L, A1, ld, rows, dKzx, S, bk.kl_early && !L.white, false));
   if (!bk.kl_early) DCGP_TRY(kl_products(bk, L, L.white ? nullptr : S, false));
   DCGP_TRY(kl_apply(bk, L, false));
   DCGP_TRY(add_scalar(bk, L, 0, gkd, rows, 1.0));             // Kdiag = variance
@@ -1293,9 +1307,7 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   const Lanes ln = lanes_of(ctx);
   // as in conv_backward: the conditional's column-wise adjoint and the patch-kernel adjoints (K_zx, K_diag) on the main stream, the M x M
   // chain and what needs S beside them
-  DCGP_TRY(cond_backward_main(bk, ln, L, A1, ld, rows, gm, gv, dKzx, gkd));
-  double* dzp = bk.ws("dz_patch", (size_t)M * Ld);
-  NEED(dzp);
+  DCGP_TRY(cond_backward_main(bk, ln, L, A1, ld, rows, gm, gv, dKzx, gkd, bk.last_layer && ln.forked));
   // every patch response again: Kfull[m][n * P + p] = k(Z_m, x_np)
   PatchRbfArgs a;
   a.X = Xin; a.N = rows; a.n_mod = n_mod;
@@ -1309,7 +1321,7 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   DCGP_TRY(e_form(bk, L, dKzx, ld, P, L.w, 1.0 / P, Kfull, ldf, E, ldf, Kc, cs, raw));
   hipLaunchKernelGGL(strided_sum_kernel, dim3(P), dim3(256), 0, ctx->stream, raw, rows, P, 1.0 / P, 1, L.gw);
   LAUNCH_CHECK(ctx);
-  DCGP_TRY(patch_backward(bk, L, E, ldf, Kc, cs, Xcol, dXin ? dXcol : nullptr, 0, nullptr, dzp));
+  DCGP_TRY(patch_backward(bk, L, E, ldf, Kc, cs, Xcol, dXin ? dXcol : nullptr, 0));
   // Kdiag
   if (L.kernel_type == 0) {
     const double inv_l2 = 1.0 / (L.ls * L.ls);
@@ -1355,8 +1367,8 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   }
   // the main stream's part of the head ends here (dX is out): it goes on to the layer below (see conv_backward)
   if (ln.forked) HIP_TRY(ctx, hipEventRecord(ctx->ev_g[3], ctx->stream));
-  DCGP_TRY(cond_backward_finish(bk, ln, L, A1, ld, rows, dKzx, S, bk.kl_early && !L.white));
-  return layer_tail(bk, ln, L, S, dzp, nullptr, 0, false);
+  DCGP_TRY(cond_backward_finish(bk, ln, L, A1, ld, rows, dKzx, S, bk.kl_early && !L.white, bk.last_layer && ln.forked));
+  return layer_tail(bk, ln, L, S, nullptr, 0, false);
 }
 
 }  // namespace
@@ -1452,6 +1464,7 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
   for (int li = nl - 1; li >= 0; --li) {
     LayerState& L = *m->layers[li];
     bk.pfx = mp + std::to_string(li) + "_";
+    bk.last_layer = li == 0;
     bk.kl_early = li < 8 && m->kl_early[li];
     bk.prep = li < 8 ? m->prep_early[li] : 0;
     if (li < 8) { m->kl_early[li] = false; m->prep_early[li] = 0; }

@@ -693,6 +693,43 @@ def test_gradients_match_oracle(ctx, white, additive, idmean):
     model.close()
 
 
+@pytest.mark.parametrize("head_kernel,white", [("conv", False), ("rbf", False), ("conv", True)])
+def test_gradients_repeat_in_steady_state(ctx, head_kernel, white):
+    """The reverse pass runs on three streams (csrc/grad.hip, Lanes) beside work that started during the forward pass; every
+    buffer two of them touch is ordered by an event.  A missing one shows up only once nothing allocates any more: forty
+    steps back to back, alternating the two forms of the conditional's reverse pass, must give the same bits as the first
+    two -- and the same numbers as the single-stream order (option grad_nofork)."""
+    hwc, N, S = (14, 14, 1), 3, 2
+    spec = syn.make_spec(hwc, [(3, 1, 3), (4, 2, 2)], (3, 1), 20, S=S, num_data=500, seed=9, white=white, conv_q_sqrt_scale=0.3,
+                         variance=2.0, ls=1.5, head_kernel=head_kernel)
+    X, Y = syn.make_batch(hwc, N, seed=9)
+    zs = syn.make_noise(spec, N, seed=9)
+    model = build_from_spec(spec, X, Y)
+    first = {}
+    for it in range(40):
+        mc = 0 if it % 2 else -1
+        with ctx.options(fused_bwd_min_cols=mc):
+            e, grads = model.compute_gradients(X, Y, zs=zs)
+        if mc not in first:
+            first[mc] = (e, grads)
+            continue
+        e0, g0 = first[mc]
+        assert e == e0
+        for li, (g, o) in enumerate(zip(grads, g0)):
+            for name in o:
+                assert np.array_equal(g[name], o[name]), (it, li, name, np.abs(g[name] - o[name]).max())
+    for mc in (-1, 0):
+        with ctx.options(fused_bwd_min_cols=mc, grad_nofork=1):
+            e, grads = model.compute_gradients(X, Y, zs=zs)
+        e0, g0 = first[mc]
+        assert abs(e - e0) <= 1e-12 * abs(e0)
+        for li, (g, o) in enumerate(zip(grads, g0)):
+            for name in o:
+                err = np.abs(g[name] - o[name]).max()
+                assert err <= 1e-9 * max(1.0, np.abs(o[name]).max()), (mc, li, name, err)
+    model.close()
+
+
 def _softplus_inv(x):
     return np.log(np.expm1(x - 1e-6))
 
