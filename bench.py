@@ -511,9 +511,8 @@ def main():
                 cg(i)
             g["value_and_grad_ms"] = 1e3 * leg.timed(args.warmup, n_g, cg)[0] / n_g
 
-            def train_step(i):
-                cg(i)
-                model.adam_step(1e-9)     # lr small enough to leave the benchmark state essentially where it was
+            def train_step(i):   # value, gradient and the Adam update: one device call (dcgp_model_train_step_adam)
+                model.train_step(leg.dX, leg.dY, 1e-9, seed=i, scale=leg.scale)     # lr small enough to leave the benchmark state essentially where it was
             g["train_step_ms_value_grad_adam"] = 1e3 * leg.timed(args.warmup, n_g, train_step)[0] / n_g
             if cfg["convs"] and not args.dedup_layer0:
                 model.dedup_layer0 = True

@@ -561,46 +561,66 @@ __global__ __launch_bounds__(256) void ard_finish_kernel(const double* __restric
   const double r = block_sum_256(acc, red);
   if (t == 0) gard[d] = -sd * r;
 }
-__global__ void reciprocal_kernel(const double* __restrict__ in, int n, double* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = 1.0 / in[i];
-}
-
 // ---- optimiser ---------------------------------------------------------------------------------------------------
-// tf.train.AdamOptimizer on gpflow's unconstrained variables, ascending the ELBO.  transform 0: identity;
+// tf.train.AdamOptimizer / GradientDescentOptimizer on gpflow's unconstrained variables, ascending the ELBO.  transform 0: identity;
 // 1: gpflow transforms.positive (x = softplus(u) + 1e-6): the parameter is held constrained, moved through u.
-__global__ void adam_kernel(double* __restrict__ p, const double* __restrict__ g, double* __restrict__ m, double* __restrict__ v, long n,
-                            double lr_t, double b1, double b2, double eps, int transform) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double x = p[i], gr = -g[i];                       // minimise -ELBO
-  double u = x;
-  if (transform == 1) {
-    const double y = x - 1e-6;
-    u = y > 35.0 ? y : log(expm1(y));               // softplus^-1
-    gr *= -expm1(-y);                                // dx/du = sigmoid(u) = 1 - exp(-y)
-  }
-  const double mi = b1 * m[i] + (1.0 - b1) * gr;
-  const double vi = b2 * v[i] + (1.0 - b2) * gr * gr;
-  m[i] = mi;
-  v[i] = vi;
-  u -= lr_t * mi / (sqrt(vi) + eps);
-  p[i] = transform == 1 ? (u > 35.0 ? u : log1p(exp(u))) + 1e-6 : u;
-}
-
-// plain gradient ascent on the ELBO in the unconstrained space (tf.train.GradientDescentOptimizer on -ELBO)
-__global__ void sgd_kernel(double* __restrict__ p, const double* __restrict__ g, long n, double lr, int transform) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double x = p[i], gr = g[i];
-  if (transform == 1) {
-    const double y = x - 1e-6;
-    double u = y > 35.0 ? y : log(expm1(y));
-    u += lr * gr * -expm1(-y);
-    p[i] = (u > 35.0 ? u : log1p(exp(u))) + 1e-6;
+// ONE launch for every parameter group of every layer (a launch per group: ten 5 us launches and 2 x layers small copies on a 1.5 ms
+// step): block b works on group g with first_block[g] <= b < first_block[g + 1].  A layer's kernel hyper-parameters live on the host
+// (they are launch arguments of the forward pass): their current values arrive as arguments, the updated ones go to the device copy
+// and straight into a pinned host slot.
+struct OptGroup {
+  double* p; const double* g; double* m; double* v;   // parameter, gradient, Adam moments (unused by SGD)
+  double* recip;                                      // != null: 1 / p is kept here as well (the dense head's staging scale)
+  long n;
+  int transform, hyp_layer;                           // hyp_layer >= 0: p is that layer's {variance, p1, p2} triple
+};
+constexpr int OPT_GROUPS_MAX = 48;
+struct OptArgs {
+  OptGroup grp[OPT_GROUPS_MAX];
+  int first_block[OPT_GROUPS_MAX + 1];
+  int ng, sgd;
+  double lr, b1, b2, eps;            // lr: Adam's bias-corrected step size, or the plain SGD rate
+  double hyp_in[8][3];
+  double* host_out;                  // [8][3] pinned
+  const double* status;              // != null: a non-zero word there (the step's factorisation failed) leaves every parameter untouched
+};
+__global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
+  if (a.status && *a.status != 0.0) return;
+  int gi = 0;
+  while (gi + 1 < a.ng && (int)blockIdx.x >= a.first_block[gi + 1]) ++gi;
+  const OptGroup& G = a.grp[gi];
+  const long i = (long)((int)blockIdx.x - a.first_block[gi]) * 256 + threadIdx.x;
+  if (i >= G.n) return;
+  const double x = G.hyp_layer >= 0 ? a.hyp_in[G.hyp_layer][i] : G.p[i];
+  double out;
+  if (a.sgd) {   // plain gradient ascent on the ELBO in the unconstrained space
+    const double gr = G.g[i];
+    if (G.transform == 1) {
+      const double y = x - 1e-6;
+      double u = y > 35.0 ? y : log(expm1(y));
+      u += a.lr * gr * -expm1(-y);
+      out = (u > 35.0 ? u : log1p(exp(u))) + 1e-6;
+    } else {
+      out = x + a.lr * gr;
+    }
   } else {
-    p[i] = x + lr * gr;
+    double gr = -G.g[i];                               // minimise -ELBO
+    double u = x;
+    if (G.transform == 1) {
+      const double y = x - 1e-6;
+      u = y > 35.0 ? y : log(expm1(y));               // softplus^-1
+      gr *= -expm1(-y);                                // dx/du = sigmoid(u) = 1 - exp(-y)
+    }
+    const double mi = a.b1 * G.m[i] + (1.0 - a.b1) * gr;
+    const double vi = a.b2 * G.v[i] + (1.0 - a.b2) * gr * gr;
+    G.m[i] = mi;
+    G.v[i] = vi;
+    u -= a.lr * mi / (sqrt(vi) + a.eps);
+    out = G.transform == 1 ? (u > 35.0 ? u : log1p(exp(u))) + 1e-6 : u;
   }
+  G.p[i] = out;
+  if (G.recip) G.recip[i] = 1.0 / out;
+  if (G.hyp_layer >= 0) a.host_out[3 * G.hyp_layer + i] = out;
 }
 
 // ---- host helpers ------------------------------------------------------------------------------------------------
@@ -1523,9 +1543,15 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
 
 extern "C" {
 
-int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, double scale, const double* const* z_per_layer_host,
-                   uint64_t seed, int dedup_layer0, double* out_host, int* info_host) {
-  if (!model || !X || !y || N <= 0 || !out_host) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "elbo_grad: bad args") : DCGP_ERR_ARG;
+}  // extern "C"
+
+// Adam step enqueued behind the reverse pass (dcgp_model_train_step_adam): lr is the bias-corrected rate
+struct AdamReq { double lr_t, beta1, beta2, eps; };
+static int opt_enqueue(dcgp_model* model, const char* who, bool sgd, double lr, double beta1, double beta2, double eps, const double* status);
+static int opt_readback(dcgp_model* model);
+
+static int elbo_grad_run(dcgp_model* model, const double* X, const int32_t* y, int N, double scale, const double* const* z_per_layer_host,
+                         uint64_t seed, int dedup_layer0, double* out_host, int* info_host, const AdamReq* adam) {
   dcgp_ctx* ctx = model->ctx;
   const bool keep = model->keep_outputs;
   model->keep_outputs = true;   // the reverse pass reads every layer's (sample, mean, var)
@@ -1542,6 +1568,9 @@ int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, 
   const bool enqueued = rc == DCGP_OK;
   if (rc == DCGP_OK && model->gkl_state) rc = grad_kl_early(model, true, model->gkl_state == 2);
   if (rc == DCGP_OK) rc = model_backward(model, X, y, N, scale, dedup_layer0);
+  // (the update reads the step's factorisation status word on the device: a failed step leaves the parameters as they were)
+  if (rc == DCGP_OK && adam)
+    rc = opt_enqueue(model, "train_step_adam", false, adam->lr_t, adam->beta1, adam->beta2, adam->eps, model->d_scal + 64 * model->bank + 43);
   if (ctx->timing) {   // host time to enqueue the whole step, forward pass included (reported beside the kernel timers)
     auto& acc = ctx->tim["grad_host_enqueue"];
     acc.launches += 1;
@@ -1564,6 +1593,34 @@ int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, 
   }
   DCGP_TRY(rc);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (adam) DCGP_TRY(opt_readback(model));
+  return DCGP_OK;
+}
+
+extern "C" {
+
+int dcgp_elbo_grad(dcgp_model* model, const double* X, const int32_t* y, int N, double scale, const double* const* z_per_layer_host,
+                   uint64_t seed, int dedup_layer0, double* out_host, int* info_host) {
+  if (!model || !X || !y || N <= 0 || !out_host) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "elbo_grad: bad args") : DCGP_ERR_ARG;
+  return elbo_grad_run(model, X, y, N, scale, z_per_layer_host, seed, dedup_layer0, out_host, info_host, nullptr);
+}
+
+// One training step in one call: value, gradient and the Adam update (dcgp_model_adam_step's arguments; t == 0: the model's own step
+// count), enqueued back to back with one wait at the end -- what session.run(minimise_op) is to the reference (conv_gp/experiment.py:84-108).
+// A step whose factorisation fails returns DCGP_ERR_NOT_PD and leaves parameters, moments and step count untouched.
+int dcgp_model_train_step_adam(dcgp_model* model, const double* X, const int32_t* y, int N, double scale, const double* const* z_per_layer_host,
+                               uint64_t seed, int dedup_layer0, double lr, double beta1, double beta2, double eps, int t, double* out_host,
+                               int* info_host) {
+  if (!model || !X || !y || N <= 0 || !out_host) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "train_step_adam: bad args") : DCGP_ERR_ARG;
+  if (t < 0 || !(lr > 0) || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1) || !(eps > 0))
+    return ctx_fail(model->ctx, DCGP_ERR_ARG, "train_step_adam: bad optimiser arguments");
+  const int t_use = t == 0 ? model->adam_t + 1 : t;
+  AdamReq a;
+  a.lr_t = lr * sqrt(1.0 - pow(beta2, (double)t_use)) / (1.0 - pow(beta1, (double)t_use));
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  for (auto& l : model->layers) DCGP_TRY(l->ensure_grads());   // (the optimiser's group table is built before the first reverse pass has run)
+  DCGP_TRY(elbo_grad_run(model, X, y, N, scale, z_per_layer_host, seed, dedup_layer0, out_host, info_host, &a));
+  model->adam_t = t_use;
   return DCGP_OK;
 }
 
@@ -1614,85 +1671,78 @@ int dcgp_model_grad_block(dcgp_model* model, int layer, double** block_dev, size
   return DCGP_OK;
 }
 
-int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta2, double eps, int t) {
-  if (!model || t < 0 || !(lr > 0) || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1) || !(eps > 0))
-    return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "adam_step: bad arguments") : DCGP_ERR_ARG;
+// one optimiser step over every trainable group of the model (sgd: plain ascent, otherwise Adam with the bias-corrected rate lr)
+static int opt_readback(dcgp_model* model);
+static int opt_enqueue(dcgp_model* model, const char* who, bool sgd, double lr, double beta1, double beta2, double eps, const double* status);
+static int opt_step(dcgp_model* model, const char* who, bool sgd, double lr, double beta1, double beta2, double eps) {
+  DCGP_TRY(opt_enqueue(model, who, sgd, lr, beta1, beta2, eps, nullptr));
+  HIP_TRY(model->ctx, hipStreamSynchronize(model->ctx->stream));
+  return opt_readback(model);
+}
+// the launch alone, behind whatever the stream holds (status: see OptArgs)
+static int opt_enqueue(dcgp_model* model, const char* who, bool sgd, double lr, double beta1, double beta2, double eps, const double* status) {
   dcgp_ctx* ctx = model->ctx;
-  // t == 0: the model's own count of Adam steps since its moment buffers were created (they start at zero with it) --
-  // what tf.train.AdamOptimizer's beta powers do for a freshly built optimiser, whatever global_step a checkpoint carried
-  if (t == 0) t = ++model->adam_t; else model->adam_t = t;
-  const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
-  auto run = [&](double* p, const double* g, double* const* mv, long n, int transform) -> int {
+  const int nl = (int)model->layers.size();
+  if (nl > 8) return ctx_fail(ctx, DCGP_ERR_ARG, "%s: at most 8 layers", who);
+  OptArgs a{};
+  a.sgd = sgd ? 1 : 0; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.status = status;
+  double* h = ctx->h_scratch;   // 64 pinned doubles: {variance, p1, p2} per layer
+  if (hipHostGetDevicePointer((void**)&a.host_out, h, 0) != hipSuccess) return ctx_fail(ctx, DCGP_ERR_HIP, "%s: pinned slot not mapped", who);
+  int nb = 0;
+  auto add = [&](double* p, const double* g, double* const* mv, long n, int transform, int hyp_layer, double* recip) -> int {
     if (n <= 0) return DCGP_OK;
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, p, g, mv[0], mv[1], n, lr_t, beta1, beta2, eps, transform);
-    LAUNCH_CHECK(ctx);
+    if (a.ng >= OPT_GROUPS_MAX) return ctx_fail(ctx, DCGP_ERR_ARG, "%s: too many parameter groups", who);
+    OptGroup& G = a.grp[a.ng];
+    G.p = p; G.g = g; G.m = mv[0]; G.v = mv[1]; G.recip = recip; G.n = n; G.transform = transform; G.hyp_layer = hyp_layer;
+    a.first_block[a.ng++] = nb;
+    nb += (int)blocks_for(n);
     return DCGP_OK;
   };
-  const int nl = (int)model->layers.size();
-  double* h = ctx->h_scratch;   // 64 pinned doubles: {variance, p1, p2} per layer (at most 8 layers)
   for (int li = 0; li < nl; ++li) {
     LayerState& L = *model->layers[li];
-    if (!L.gZ) return ctx_fail(ctx, DCGP_ERR_ARG, "adam_step: call dcgp_elbo_grad first");
-    DCGP_TRY(L.ensure_adam());
-    h[3 * li] = L.variance; h[3 * li + 1] = L.base_type == 1 ? L.acos_w : L.ls; h[3 * li + 2] = L.base_type == 1 ? L.acos_b : 1.0;
-    HIP_TRY(ctx, hipMemcpyAsync(L.hyp, h + 3 * li, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if (!(L.frozen & 1u)) DCGP_TRY(run(L.Z, L.gZ, L.aZ, (long)L.M * L.v.L, 0));
-    if (!(L.frozen & 2u)) DCGP_TRY(run(L.q_mu, L.gq_mu, L.aq_mu, (long)L.M * L.R, 0));
-    if (L.has_qsqrt && !(L.frozen & 4u)) DCGP_TRY(run(L.q_sqrt, L.gq_sqrt, L.aq_sqrt, (long)L.R * L.M * L.M, 0));   // upper triangle: zero gradient, zero step
-    if (L.is_head && L.w && !(L.frozen & 8u)) DCGP_TRY(run(L.w, L.gw, L.aw, (long)L.v.P, 0));
-    if (!(L.frozen & 16u)) DCGP_TRY(run(L.hyp, L.gscal, L.ahyp, 3, 1));
-    if (L.ard && !(L.frozen & 16u)) {   // dense head: per-dimension lengthscales, then refresh the staging scale 1 / l
-      DCGP_TRY(run(L.ard, L.gard, L.aard, (long)L.v.L, 1));
-      hipLaunchKernelGGL(reciprocal_kernel, dim3(blocks_for(L.v.L)), dim3(256), 0, ctx->stream, L.ard, L.v.L, L.in_scale);
-      LAUNCH_CHECK(ctx);
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(h + 3 * li, L.hyp, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (!L.gZ) return ctx_fail(ctx, DCGP_ERR_ARG, "%s: call dcgp_elbo_grad first", who);
+    DCGP_TRY(L.ensure_adam());   // (SGD: for the device copy of the hyper-parameters)
+    a.hyp_in[li][0] = L.variance; a.hyp_in[li][1] = L.base_type == 1 ? L.acos_w : L.ls; a.hyp_in[li][2] = L.base_type == 1 ? L.acos_b : 1.0;
+    if (!(L.frozen & 1u)) DCGP_TRY(add(L.Z, L.gZ, L.aZ, (long)L.M * L.v.L, 0, -1, nullptr));
+    if (!(L.frozen & 2u)) DCGP_TRY(add(L.q_mu, L.gq_mu, L.aq_mu, (long)L.M * L.R, 0, -1, nullptr));
+    if (L.has_qsqrt && !(L.frozen & 4u)) DCGP_TRY(add(L.q_sqrt, L.gq_sqrt, L.aq_sqrt, (long)L.R * L.M * L.M, 0, -1, nullptr));   // upper triangle: zero gradient, zero step
+    if (L.is_head && L.w && !(L.frozen & 8u)) DCGP_TRY(add(L.w, L.gw, L.aw, (long)L.v.P, 0, -1, nullptr));
+    if (!(L.frozen & 16u)) DCGP_TRY(add(L.hyp, L.gscal, L.ahyp, 3, 1, li, nullptr));
+    if (L.ard && !(L.frozen & 16u)) DCGP_TRY(add(L.ard, L.gard, L.aard, (long)L.v.L, 1, -1, L.in_scale));   // dense head: per-dimension lengthscales and the staging scale 1 / l
   }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  a.first_block[a.ng] = nb;
+  if (nb > 0) {
+    hipLaunchKernelGGL(opt_step_kernel, dim3(nb), dim3(256), 0, ctx->stream, a);
+    LAUNCH_CHECK(ctx);
+  }
+  return DCGP_OK;
+}
+// the updated kernel hyper-parameters back into the host-side layer state (the stream must have been synchronised)
+static int opt_readback(dcgp_model* model) {
+  const double* h = model->ctx->h_scratch;
+  const int nl = (int)model->layers.size();
   for (int li = 0; li < nl; ++li) {
     LayerState& L = *model->layers[li];
+    if (L.frozen & 16u) continue;
     L.variance = h[3 * li];
     if (L.base_type == 1) { L.acos_w = h[3 * li + 1]; L.acos_b = h[3 * li + 2]; } else L.ls = h[3 * li + 1];
   }
   return DCGP_OK;
 }
 
+int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta2, double eps, int t) {
+  if (!model || t < 0 || !(lr > 0) || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1) || !(eps > 0))
+    return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "adam_step: bad arguments") : DCGP_ERR_ARG;
+  // t == 0: the model's own count of Adam steps since its moment buffers were created (they start at zero with it) --
+  // what tf.train.AdamOptimizer's beta powers do for a freshly built optimiser, whatever global_step a checkpoint carried
+  if (t == 0) t = ++model->adam_t; else model->adam_t = t;
+  const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
+  return opt_step(model, "adam_step", false, lr_t, beta1, beta2, eps);
+}
+
 int dcgp_model_sgd_step(dcgp_model* model, double lr) {
   if (!model || !(lr > 0)) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "sgd_step: bad arguments") : DCGP_ERR_ARG;
-  dcgp_ctx* ctx = model->ctx;
-  auto run = [&](double* p, const double* g, long n, int transform) -> int {
-    if (n <= 0) return DCGP_OK;
-    hipLaunchKernelGGL(sgd_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, p, g, n, lr, transform);
-    LAUNCH_CHECK(ctx);
-    return DCGP_OK;
-  };
-  const int nl = (int)model->layers.size();
-  double* h = ctx->h_scratch;
-  for (int li = 0; li < nl; ++li) {
-    LayerState& L = *model->layers[li];
-    if (!L.gZ) return ctx_fail(ctx, DCGP_ERR_ARG, "sgd_step: call dcgp_elbo_grad first");
-    DCGP_TRY(L.ensure_adam());   // for the device copy of the hyper-parameters
-    h[3 * li] = L.variance; h[3 * li + 1] = L.base_type == 1 ? L.acos_w : L.ls; h[3 * li + 2] = L.base_type == 1 ? L.acos_b : 1.0;
-    HIP_TRY(ctx, hipMemcpyAsync(L.hyp, h + 3 * li, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if (!(L.frozen & 1u)) DCGP_TRY(run(L.Z, L.gZ, (long)L.M * L.v.L, 0));
-    if (!(L.frozen & 2u)) DCGP_TRY(run(L.q_mu, L.gq_mu, (long)L.M * L.R, 0));
-    if (L.has_qsqrt && !(L.frozen & 4u)) DCGP_TRY(run(L.q_sqrt, L.gq_sqrt, (long)L.R * L.M * L.M, 0));
-    if (L.is_head && L.w && !(L.frozen & 8u)) DCGP_TRY(run(L.w, L.gw, (long)L.v.P, 0));
-    if (!(L.frozen & 16u)) DCGP_TRY(run(L.hyp, L.gscal, 3, 1));
-    if (L.ard && !(L.frozen & 16u)) {
-      DCGP_TRY(run(L.ard, L.gard, (long)L.v.L, 1));
-      hipLaunchKernelGGL(reciprocal_kernel, dim3(blocks_for(L.v.L)), dim3(256), 0, ctx->stream, L.ard, L.v.L, L.in_scale);
-      LAUNCH_CHECK(ctx);
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(h + 3 * li, L.hyp, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  for (int li = 0; li < nl; ++li) {
-    LayerState& L = *model->layers[li];
-    L.variance = h[3 * li];
-    if (L.base_type == 1) { L.acos_w = h[3 * li + 1]; L.acos_b = h[3 * li + 2]; } else L.ls = h[3 * li + 1];
-  }
-  return DCGP_OK;
+  return opt_step(model, "sgd_step", true, lr, 0.0, 0.0, 0.0);
 }
 
 int dcgp_model_set_trainable(dcgp_model* model, int layer, const char* which, int on) {

@@ -90,6 +90,7 @@ _SIGS = {
     "dcgp_elbo_grad": [_vp, _vp, _vp, _i, _d, C.POINTER(_vp), _u64, _i, C.POINTER(_d), _ip],
     "dcgp_model_get_grad": [_vp, _i, C.c_char_p, _vp, C.c_size_t],
     "dcgp_model_adam_step": [_vp, _d, _d, _d, _d, _i],
+    "dcgp_model_train_step_adam": [_vp, _vp, _vp, _i, _d, C.POINTER(_vp), _u64, _i, _d, _d, _d, _d, _i, C.POINTER(_d), _ip],
     "dcgp_model_get_param": [_vp, _i, C.c_char_p, _vp, C.c_size_t],
     "dcgp_model_set_grad_shards": [_vp, _i],
     "dcgp_model_set_shard": [_vp, _i, _i],

@@ -279,6 +279,26 @@ class DGP_Base:
         moves; ``pull_parameters`` refreshes the Python-side values."""
         self._ctx._check(dev.lib().dcgp_model_adam_step(self._model, float(lr), float(beta1), float(beta2), float(epsilon), int(t or 0)))
 
+    def train_step(self, X, Y, lr, zs=None, seed=0, scale=None, t=None, beta1=0.9, beta2=0.999, epsilon=1e-8, shards=None):
+        """One training step in one call -- ``compute_gradients`` and ``adam_step`` enqueued back to back with a single wait
+        at the end (dcgp_model_train_step_adam): the optimiser's ``minimize`` step of conv_gp/experiment.py:84-108.  Returns the
+        step's ELBO (evaluated before the update, as TensorFlow's fetch of the objective beside the train op would be).  A step whose
+        K_uu is not positive definite raises and leaves every parameter as it was."""
+        self._build()
+        ctx, L = self._ctx, dev.lib()
+        dX = ctx.as_device(np.reshape(X, (np.shape(X)[0], -1)) if not isinstance(X, dev.DeviceArray) else X)
+        dY = ctx.as_device(np.reshape(Y, (-1,)) if not isinstance(Y, dev.DeviceArray) else Y, np.int32)
+        N = dX.shape[0]
+        if scale is None:
+            scale = self._default_scale(N)
+        arr, keep = self._z_table(zs, N, self.num_samples)
+        out = (C.c_double * 3)()
+        info = C.c_int(0)
+        ctx._check(L.dcgp_model_set_grad_shards(self._model, int(shards or 0)))
+        ctx._check(L.dcgp_model_train_step_adam(self._model, dX.ptr, dY.ptr, N, float(scale), arr, int(seed), int(self.dedup_layer0),
+                                                float(lr), float(beta1), float(beta2), float(epsilon), int(t or 0), out, C.byref(info)), info)
+        return out[0]
+
     def sgd_step(self, lr):
         """Plain gradient ascent step in the unconstrained space (the "SGD" branch, conv_gp/experiment.py:100-103)."""
         self._ctx._check(dev.lib().dcgp_model_sgd_step(self._model, float(lr)))

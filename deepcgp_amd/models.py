@@ -77,7 +77,7 @@ def train(model, steps, lr=0.01, lr_decay_steps=50000, global_step=0, seed=0, ca
           max_retries=5, dedup_layer0=True):
     """The reference's optimisation loop (conv_gp/experiment.py:84-108 + gpflow.actions.Loop at :44).  Every step draws a
     minibatch and evaluates the ELBO and its gradient on the device (``compute_gradients``), then
-      "Adam":    one device Adam step on every parameter;
+      "Adam":    one device Adam step on every parameter (value, gradient and update in ONE call, ``train_step``);
       "SGD":     one plain gradient step;
       "NatGrad": a natural-gradient step on every layer's (q_mu, q_sqrt) (``DGP_Base.natgrad_step``, step size from
                  ``natgrad_gamma``), then -- as the reference's loop does, with the variational parameters switched to
@@ -105,6 +105,12 @@ def train(model, steps, lr=0.01, lr_decay_steps=50000, global_step=0, seed=0, ca
     for i in range(int(steps)):
         idx = rng.choice(n, size=bs, replace=False)
         step = global_step + i
+        if optimizer == "Adam":      # value, gradient and update in one device call (dcgp_model_train_step_adam)
+            elbo = model.train_step(model.X[idx], model.Y[idx], learning_rate(lr, step, lr_decay_steps), seed=seed + step)
+            history.append(elbo)
+            if callback is not None:
+                callback(step + 1, elbo)
+            continue
         elbo, _ = model.compute_gradients(model.X[idx], model.Y[idx], seed=seed + step, fetch=False)
         if optimizer == "NatGrad":
             # a step that leaves the positive-definite cone is retried with gamma scaled by 0.2, at most max_retries

@@ -242,6 +242,13 @@ int dcgp_model_grad_block(dcgp_model* model, int layer, double** block_dev, size
  * own count of steps taken since its (zero-initialised) moment buffers were created -- a freshly built optimiser
  * restarts its beta powers whatever global_step a loaded checkpoint carries (experiment.py:84-89). */
 int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta2, double eps, int t);
+/* One training step in one call -- dcgp_elbo_grad and dcgp_model_adam_step enqueued back to back with a single wait at the end: what
+ * session.run(minimise_op) is to the reference (conv_gp/experiment.py:84-108).  Arguments: those of the two calls.  A step whose
+ * factorisation fails returns DCGP_ERR_NOT_PD and leaves parameters, moments and step count as they were (the update reads the step's
+ * status word on the device). */
+int dcgp_model_train_step_adam(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
+                               const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, double lr, double beta1,
+                               double beta2, double eps, int t, double* out_host, int* info_host);
 /* Plain gradient ascent in the same unconstrained space (gpflow.train.GradientDescentOptimizer, the "SGD" branch
  * at conv_gp/experiment.py:100-103). */
 int dcgp_model_sgd_step(dcgp_model* model, double lr);

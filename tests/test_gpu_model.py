@@ -734,10 +734,11 @@ def _softplus_inv(x):
     return np.log(np.expm1(x - 1e-6))
 
 
-@pytest.mark.parametrize("head_kernel", ["conv", "rbf", "conv+acos"])
-def test_adam_steps_match_numpy_on_oracle_gradients(ctx, head_kernel):
-    """Three device Adam steps (dcgp_model_adam_step) against tf.train.AdamOptimizer's update written out in numpy
-    on the ORACLE's gradients, in gpflow's unconstrained space (softplus + 1e-6 for variance / lengthscales)."""
+@pytest.mark.parametrize("head_kernel,one_call", [("conv", False), ("rbf", False), ("conv+acos", False), ("conv", True), ("rbf", True)])
+def test_adam_steps_match_numpy_on_oracle_gradients(ctx, head_kernel, one_call):
+    """Three device Adam steps (dcgp_model_adam_step, or the one-call training step dcgp_model_train_step_adam) against
+    tf.train.AdamOptimizer's update written out in numpy on the ORACLE's gradients, in gpflow's unconstrained space
+    (softplus + 1e-6 for variance / lengthscales)."""
     from oracle.grad import elbo_and_grad
     from oracle_build import oracle_param_handles
     hwc, N, S, lr = (12, 12, 1), 3, 2, 0.05
@@ -754,8 +755,11 @@ def test_adam_steps_match_numpy_on_oracle_gradients(ctx, head_kernel):
     b1, b2, eps = 0.9, 0.999, 1e-8
     for t in range(1, 4):
         zs = syn.make_noise(spec, N, seed=100 + t)
-        e, _ = model.compute_gradients(X, Y, zs=zs, fetch=False)
-        model.adam_step(lr, t)
+        if one_call:
+            e = model.train_step(X, Y, lr, zs=zs, t=t)
+        else:
+            e, _ = model.compute_gradients(X, Y, zs=zs, fetch=False)
+            model.adam_step(lr, t)
         eo, go = elbo_and_grad(ref, X, Y, zs)
         assert abs(e - eo) <= 1e-8 * abs(eo)
         lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
@@ -875,7 +879,24 @@ def test_training_entry_points_fail_loudly(ctx):
     assert L.dcgp_model_get_grad(model._model, 0, b"q_mu", buf.ctypes.data, 3) != 0      # wrong count
     assert L.dcgp_model_get_grad(model._model, 0, b"w", buf.ctypes.data, 3) != 0         # conv layers have no patch weights
     assert L.dcgp_model_get_param(model._model, 7, b"Z", buf.ctypes.data, 3) != 0        # no such layer
+    with pytest.raises(dev.DcgpError):            # the one-call step checks the optimiser's arguments before anything is enqueued
+        model.train_step(X, Y, -1.0)
     model.close()
+    # a training step whose K_uu is not positive definite (two identical inducing patches, a variance that swallows the jitter) raises --
+    # and the update, already enqueued behind the reverse pass, has left every parameter and the step count where they were
+    spec = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), 8, S=2, num_data=100, seed=2, conv_q_sqrt_scale=0.3, variance=1e15)
+    spec["convs"][0]["Z"] = np.array(spec["convs"][0]["Z"])
+    spec["convs"][0]["Z"][1] = spec["convs"][0]["Z"][0]
+    bad = build_from_spec(spec, X, Y)
+    bad._build()
+    bad.pull_parameters()
+    before = [(np.array(l.feature.Z), np.array(l.q_mu), np.array(l.q_sqrt)) for l in bad.layers]
+    with pytest.raises(dev.DcgpError):
+        bad.train_step(X, Y, 0.05)
+    bad.pull_parameters()
+    for (z0, m0, s0), l in zip(before, bad.layers):
+        assert np.array_equal(l.feature.Z, z0) and np.array_equal(l.q_mu, m0) and np.array_equal(l.q_sqrt, s0)
+    bad.close()
 
 
 def test_gradient_properties_at_full_baseline_size(ctx):
