@@ -24,6 +24,13 @@ for i in range(steps):
     model.compute_gradients(dX, dY, seed=i, fetch=False)
 ctx.sync()
 print("%s: value+grad %.3f ms/step" % (name, 1e3 * (time.perf_counter() - t0) / steps))
+if os.environ.get("DCGP_TRAIN", "1") != "0":   # the one-call training step: value, gradient and the Adam update (dcgp_model_train_step_adam)
+    for i in range(2):
+        model.train_step(dX, dY, 1e-9, seed=i)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        model.train_step(dX, dY, 1e-9, seed=i)
+    print("%s: training step (value + gradient + Adam, one call) %.3f ms/step" % (name, 1e3 * (time.perf_counter() - t0) / steps))
 if os.environ.get("DCGP_GRAD_HOST"):   # host time to enqueue a step (timers on: a few more events per step)
     ctx.timing_enable(1); ctx.timing_reset()
     for i in range(steps):
