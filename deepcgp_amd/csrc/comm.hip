@@ -3,6 +3,9 @@
 // per-GPU data term; KL terms are replicated and computed redundantly.
 // librccl is dlopen()ed on first use so that libdcgp.so loads on hosts without it.
 #include <dlfcn.h>
+#include <unistd.h>
+
+#include <cstdio>
 
 #include "layer_impl.h"
 
@@ -51,6 +54,24 @@ bool rccl_load() {
   return true;
 }
 
+// RCCL announces itself with printf ("RCCL version : ...", four lines) the first time a communicator is set up.  A library must not write
+// to its host's stdout (bench.py's contract is ONE JSON line there, and C stdio flushes the banner at exit, BEHIND that line): while an
+// RCCL set-up call runs, file descriptor 1 points at stderr.
+struct StdoutToStderr {
+  int saved = -1;
+  StdoutToStderr() {
+    fflush(stdout);
+    saved = dup(1);
+    if (saved >= 0 && dup2(2, 1) < 0) { close(saved); saved = -1; }
+  }
+  ~StdoutToStderr() {
+    if (saved < 0) return;
+    fflush(stdout);
+    dup2(saved, 1);
+    close(saved);
+  }
+};
+
 constexpr int kNcclFloat64 = 8;   // ncclDouble
 constexpr int kNcclSum = 0;       // ncclSum
 
@@ -71,6 +92,7 @@ int dcgp_comm_unique_id(unsigned char* out_128bytes) {
   if (!out_128bytes) return DCGP_ERR_ARG;
   if (!rccl_load()) return DCGP_ERR_RCCL;
   UniqueId id;
+  StdoutToStderr quiet;
   if (g_rccl.get_unique_id(&id) != 0) return DCGP_ERR_RCCL;
   memcpy(out_128bytes, id.internal, 128);
   return DCGP_OK;
@@ -85,7 +107,11 @@ int dcgp_comm_init_rank(dcgp_ctx* ctx, int nranks, int rank, const unsigned char
   UniqueId id;
   memcpy(id.internal, id_128bytes, 128);
   void* comm = nullptr;
-  int rc = g_rccl.comm_init_rank(&comm, nranks, id, rank);
+  int rc;
+  {
+    StdoutToStderr quiet;
+    rc = g_rccl.comm_init_rank(&comm, nranks, id, rank);
+  }
   if (rc != 0)
     return ctx_fail(ctx, DCGP_ERR_RCCL, "ncclCommInitRank failed: %s",
                     g_rccl.get_error_string ? g_rccl.get_error_string(rc) : "?");
