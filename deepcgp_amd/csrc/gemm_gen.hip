@@ -302,3 +302,25 @@ extern "C" int dcgp_gemm_strided(dcgp_ctx* ctx, const double* A, long a_rs, long
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return DCGP_OK;
 }
+
+// the same with the epilogue hooks of the kernel adjoints: C_b(i, j) (+)= alpha (sum_k ... - sub_v_b[i] sub_x_b(i, j)), flags bit 0: lower_only,
+// bit 1: mirror (the strictly lower entries also stored transposed), bit 2: phi (strictly lower part kept, diagonal halved, rest zero)
+extern "C" int dcgp_gemm_strided_ex(dcgp_ctx* ctx, const double* A, long a_rs, long a_cs, long a_bs, const double* B, long b_rs, long b_cs,
+                                    long b_bs, double* C, long c_rs, long c_bs, int M, int N, int K, int batch, double alpha, int accumulate,
+                                    const double* sub_v, long sv_bs, const double* sub_x, long sx_rs, long sx_bs, int flags) {
+  if (!ctx) return DCGP_ERR_ARG;
+  if (!A || !B || !C || M < 0 || N < 0 || K < 0 || batch < 0 || c_rs < N || ((sub_v != nullptr) != (sub_x != nullptr)))
+    return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_strided_ex: bad arguments");
+  if ((flags & 3) && M != N) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_strided_ex: lower_only / mirror need a square result");
+  if ((flags & 2) && !(flags & 1)) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_strided_ex: mirror goes with lower_only");
+  GenGemm g;
+  g.A = A; g.a_rs = a_rs; g.a_cs = a_cs; g.a_bs = a_bs;
+  g.B = B; g.b_rs = b_rs; g.b_cs = b_cs; g.b_bs = b_bs;
+  g.C = C; g.c_rs = c_rs; g.c_bs = c_bs;
+  g.M = M; g.N = N; g.K = K; g.batch = batch; g.alpha = alpha; g.accumulate = accumulate;
+  g.sub_v = sub_v; g.sv_bs = sv_bs; g.sub_x = sub_x; g.sx_rs = sx_rs; g.sx_bs = sx_bs;
+  g.lower_only = flags & 1; g.mirror = (flags >> 1) & 1; g.phi = (flags >> 2) & 1;
+  DCGP_TRY(gemm_gen(ctx, g));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DCGP_OK;
+}

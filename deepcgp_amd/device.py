@@ -102,6 +102,8 @@ _SIGS = {
     "dcgp_model_layer_output": [_vp, _i, _vp, _vp, _vp, _ip, _ip],
     "dcgp_gemm_strided": [_vp, _vp, C.c_long, C.c_long, C.c_long, _vp, C.c_long, C.c_long, C.c_long, _vp, C.c_long, C.c_long,
                           _i, _i, _i, _i, _d, _i, _vp, C.c_long, C.c_long, _vp, C.c_long, C.c_long, _i],
+    "dcgp_gemm_strided_ex": [_vp, _vp, C.c_long, C.c_long, C.c_long, _vp, C.c_long, C.c_long, C.c_long, _vp, C.c_long, C.c_long,
+                             _i, _i, _i, _i, _d, _i, _vp, C.c_long, _vp, C.c_long, C.c_long, _i],
     "dcgp_kmeans": [_vp, _vp, C.c_long, _i, _i, _vp, _i, _d, _vp, _ip],
     "dcgp_debug_set_fused_trace": [_vp, _vp],
     "dcgp_debug_mfma_f64_rate": [_vp, _dp],

@@ -287,6 +287,15 @@ int dcgp_gemm_strided(dcgp_ctx* ctx, const double* A, long a_rs, long a_cs, long
                       long b_cs, long b_bs, double* C, long c_rs, long c_bs, int M, int N, int K, int batch,
                       double alpha, int accumulate, const double* colscale, long cs_s, long cs_bs,
                       const double* kscale, long ks_s, long ks_bs, int lower_only);
+/* The same product with the epilogues of the kernel adjoints (dZ = (E X - rowsum(E) o Z) / l^2 and its kin, Murray's Phi of the Cholesky
+ * adjoint, symmetric products computed on the lower tiles only):
+ *   C_b(i, j) (+)= alpha * (sum_k A_b(i, k) B_b(k, j) - sub_v[b sv_bs + i] * sub_x[b sx_bs + i sx_rs + j])      (sub_v, sub_x: both or neither)
+ * flags bit 0: lower_only; bit 1 (with bit 0): mirror -- entries below the diagonal are also stored transposed, nothing else is written
+ * above it; bit 2: phi -- the strictly lower part is kept, the diagonal halved, the rest written as zero. */
+int dcgp_gemm_strided_ex(dcgp_ctx* ctx, const double* A, long a_rs, long a_cs, long a_bs, const double* B, long b_rs,
+                         long b_cs, long b_bs, double* C, long c_rs, long c_bs, int M, int N, int K, int batch,
+                         double alpha, int accumulate, const double* sub_v, long sv_bs, const double* sub_x, long sx_rs,
+                         long sx_bs, int flags);
 
 /* ---- initialisation ---------------------------------------------------------------------------------------------- */
 /* Lloyd's k-means of n points [n, d] (device) into k centres [k, d] (device): the inducing-patch initialisation of

@@ -768,3 +768,46 @@ def test_strided_gemm_layouts_edges_and_epilogues(ctx, mode):
     run(20, 7, 5000, kscale=True)                               # split-k, 64-tile kernel
     run(130, 130, 4100, batch=2, lower=True, alpha=2.0)         # split-k, 128-tile kernel, compact grid
     run(256, 25, 9000, accumulate=True)                         # tall contraction into a narrow result
+
+
+def test_strided_gemm_adjoint_epilogues(ctx):
+    """dcgp_gemm_strided_ex: the row-scaled correction (E X - rowsum(E) o Z), Murray's Phi and the mirrored store of a symmetric
+    product, direct store and split-k, batches, accumulation -- against NumPy."""
+    from deepcgp_amd import device as dev
+    L = dev.lib()
+    rng = np.random.default_rng(2)
+
+    def run(M, N, K, batch=1, alpha=1.0, accumulate=False, sub=False, flags=0, sym=False):
+        A = rng.standard_normal((batch, M, K))
+        B = np.transpose(A, (0, 2, 1)).copy() if sym else rng.standard_normal((batch, K, N))
+        C0 = rng.standard_normal((batch, M, N + 2))
+        v = rng.standard_normal((batch, M))
+        Xs = rng.standard_normal((batch, M, N + 1))                # sx_rs > N
+        dA, dB, dC, dv, dX = (ctx.to_device(a) for a in (A, B, C0, v, Xs))
+        ctx._check(L.dcgp_gemm_strided_ex(ctx.handle, dA.ptr, K, 1, M * K, dB.ptr, N, 1, K * N, dC.ptr, N + 2, M * (N + 2), M, N, K, batch,
+                                          alpha, int(accumulate), dv.ptr if sub else None, M, dX.ptr if sub else None, N + 1, M * (N + 1), flags))
+        out = dC.numpy()
+        for b in range(batch):
+            want = A[b] @ B[b]
+            if sub:
+                want = want - v[b][:, None] * Xs[b][:, :N]
+            want = alpha * want
+            if flags & 4:
+                want = np.tril(want, -1) + 0.5 * np.diag(np.diag(want))
+            elif flags & 2:
+                want = np.tril(want) + np.tril(want, -1).T          # the lower triangle, mirrored (== want when the product is symmetric)
+            elif flags & 1:
+                want = np.tril(want)
+            if accumulate:
+                want = want + C0[b][:, :N]
+            err = np.abs(out[b][:, :N] - want).max()
+            assert err <= 1e-11 * max(np.abs(want).max(), 1.0) * max(K, 1) ** 0.5, (M, N, K, batch, flags, err)
+            assert np.array_equal(out[b][:, N:], C0[b][:, N:])
+    run(37, 53, 19, batch=2, alpha=0.7, sub=True)
+    run(256, 25, 9000, accumulate=True, sub=True)               # split-k: the correction in the reduction's epilogue
+    run(70, 70, 33, batch=3, flags=4)                           # Phi, direct store
+    run(40, 40, 3000, flags=4, alpha=-1.0)                      # Phi behind split-k (32-tile kernel)
+    run(96, 96, 40, batch=2, flags=3, sym=True)                 # mirrored store, rectangular grid
+    run(130, 130, 4100, batch=2, flags=3, sym=True, alpha=2.0)  # mirrored store, split-k, 128-tile kernel, compact grid
+    with pytest.raises(dev.DcgpError):
+        run(8, 9, 4, flags=1)                                    # lower_only needs a square result
