@@ -15,9 +15,13 @@
 //
 // The R M^2 K products that fit the forward's tuned kernel run on it (gemm.hip: dT with a column-scaled store, dA1 as one
 // launch with the R blocks stacked along k, dK_uf); everything else goes through gemm_gen (strided MFMA GEMM, deterministic
-// split-k) and elementwise / reduction kernels.  Main stream = the data path; the M x M-result chain of each conditional
-// (d alpha, W_r -> dG_r -> dq_sqrt, first dL terms) runs on the side stream (cond_backward).  No atomics anywhere: the
-// gradients are reproducible run to run.  The oracle for this file is oracle/grad.py.
+// split-k, the adjoints' corrections in its epilogue) and elementwise / reduction kernels.
+// Scheduling (Lanes, below): the main stream carries the data path only -- the column-wise adjoint of each conditional, the patch-kernel
+// adjoint, dX for the layer below; the conditional's M x M chain (W_r -> dG_r -> dq_sqrt -> dL -> Cholesky adjoint -> S) runs on a second
+// stream, what needs S (Gram adjoint of K_uu, scalar sums) and the KL pieces on a third; zero fills, parameter-only operands and the KL
+// adjoint's products are enqueued beside the FORWARD pass (grad_kl_early).  Every buffer two streams touch is ordered by an event; the main
+// stream joins the others once, at the end of the step.  No atomics anywhere: the gradients are reproducible run to run
+// (tests: test_gradients_repeat_in_steady_state).  The oracle for this file is oracle/grad.py.
 #include <algorithm>
 #include <chrono>
 #include <initializer_list>
