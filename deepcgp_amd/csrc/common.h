@@ -39,6 +39,7 @@ struct DcgpOptions {
   long no_fused_bwd = 0;         // reverse pass of the conditional by GEMM launches instead of the strip kernel
   long fused_bwd_min_cols = -1;  // strip kernel of the reverse pass from this many columns on (-1: default 4096)
   long fused_bwd_frags = 0;      // strip width of that kernel in 16-column fragments (0: chosen from the column count; 4, 2, 1)
+  long gemm_tile = 0;            // gemm_gen: force the 32 / 64 / 128 output tile (0: chosen from the shape)
   long grad_late_kl = 0;         // reverse pass: the KL adjoint at the end of each layer instead of beside the forward pass
   long head_unfused = 0;         // the head's conditional by the shared GEMM route instead of its one launch
   long no_side_stream = 0;       // everything on one stream (counter collection: the profiler serialises dispatches)

@@ -274,6 +274,9 @@ int gemm_gen(dcgp_ctx* ctx, const GenGemm& g) {
 #else
   constexpr long big_fill = 512, small_wgs = 256;
 #endif
+  if (ctx->opt.gemm_tile == 32) return gemm_gen_launch<32, 256, 16>(ctx, g, 1024);     // A/B switch
+  if (ctx->opt.gemm_tile == 64) return gemm_gen_launch<64, 256, 32>(ctx, g, 1024);
+  if (ctx->opt.gemm_tile == 128) return gemm_gen_launch<128, 1024, 32>(ctx, g, 512);
   const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch / (g.lower_only ? 2 : 1);
   if (g.M >= 128 && g.N >= 128 && g.K >= 4096 && tiles128 * (g.K / 512) >= big_fill) return gemm_gen_launch<128, 1024, 32>(ctx, g, 512);
   // the M x M x M products of the Cholesky / KL adjoint chains would launch a few dozen 64-tile workgroups on 256 CUs and
