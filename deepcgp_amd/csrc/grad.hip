@@ -425,11 +425,6 @@ __global__ void kdiag_norms_kernel(const double* __restrict__ Gm, int P, long n_
   norms[idx] = Gm[(n * P + p) * P + p];
 }
 
-__global__ void fill_kernel(double* __restrict__ p, long n, double v) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
-
 __global__ void scal_finish_kernel(const double* __restrict__ slots, double* __restrict__ gscal) {
   if (threadIdx.x || blockIdx.x) return;
   double a = 0.0, b = 0.0, c = 0.0;
