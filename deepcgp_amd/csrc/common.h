@@ -40,6 +40,7 @@ struct DcgpOptions {
   long fused_bwd_min_cols = -1;  // strip kernel of the reverse pass from this many columns on (-1: default 4096)
   long fused_bwd_frags = 0;      // strip width of that kernel in 16-column fragments (0: chosen from the column count; 4, 2, 1)
   long gemm_tile = 0;            // gemm_gen: force the 32 / 64 / 128 output tile (0: chosen from the shape)
+  long grad_no_keep_k = 0;       // training step: the head's patch responses evaluated again by the reverse pass instead of kept by the forward sweep
   long grad_late_kl = 0;         // reverse pass: the KL adjoint at the end of each layer instead of beside the forward pass
   long head_unfused = 0;         // the head's conditional by the shared GEMM route instead of its one launch
   long no_side_stream = 0;       // everything on one stream (counter collection: the profiler serialises dispatches)
@@ -309,6 +310,9 @@ struct HeadUnitsArgs {
   double* kzx = nullptr; long ldk = 0; double kzx_scale = 1.0;   // kzx[m * ldk + n] = kzx_scale * sum_p w_p k(z_m, x_np), rows M..Mp-1 zeroed
   double* kuf = nullptr; long sM = 0, sN = 0, sP = 0;      // the K_uf sweep instead: kuf[m * sM + n * sN + p * sP] = k(z_m, x_np) (rows M..kzx_rows-1 zeroed)
   int kzx_rows = 0;                                        // rows of kzx / kuf that exist (0: all Mp)
+  // reducing form of a training step: every kernel value of the Kzx units is ALSO stored, kfull[m * kf_sM + n * kf_sN + p] = k(z_m, x_np), m < M
+  // (the reverse pass needs them all again: conv_gp/kernels.py:117-133 differentiated; recomputing them was a 57 us launch at the headline size)
+  double* kfull = nullptr; long kf_sM = 0, kf_sN = 0;
   int share_cu = 0;                                        // leave room on every CU for a workgroup of the factorisation chain (see head_units)
   double* kd = nullptr;                                    // kd[n * n_kd + i]: Kdiag[n] = sum_i kd[..] / P^2; every slot of an image is written (values or zeros)
   int upw_force = 0;                                       // units per wave (0: chosen by head_units_plan)

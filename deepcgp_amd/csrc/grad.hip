@@ -320,7 +320,11 @@ __global__ __launch_bounds__(256) void e_form_kernel(const double* __restrict__ 
       E[m * lde + c] = e;
       sr += r;
       sc += e;
-      if (k > 0.0) sd -= e * two_l2 * log(k * inv_var);
+      // d^2 = -2 l^2 log(k / variance).  A response so small that k / variance is a denormal or rounds to zero (the unit sweep's 2^t keeps
+      // denormals where the launch-per-tile sweep flushed them: log -> -inf against e -> 0 would make the lengthscale gradient NaN) weighs
+      // less than 1e-300: skipped
+      const double q = k * inv_var;
+      if (q >= 2.2250738585072014e-308) sd -= e * two_l2 * log(q);
     }
     csp[(long)blockIdx.y * Kc + c] = sc;
     if (rawp) rawp[(long)blockIdx.y * Kc + c] = sr;
@@ -1327,14 +1331,19 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   // as in conv_backward: the conditional's column-wise adjoint and the patch-kernel adjoints (K_zx, K_diag) on the main stream, the M x M
   // chain and what needs S beside them
   DCGP_TRY(cond_backward_main(bk, ln, L, A1, ld, rows, gm, gv, dKzx, gkd, bk.last_layer && ln.forked));
-  // every patch response again: Kfull[m][n * P + p] = k(Z_m, x_np)
-  PatchRbfArgs a;
-  a.X = Xin; a.N = rows; a.n_mod = n_mod;
-  a.H = L.v.H; a.W = L.v.W; a.C = L.v.C; a.f = L.v.f; a.s = L.v.s; a.Ho = L.v.Ho; a.Wo = L.v.Wo; a.P = P; a.L = Ld;
-  a.ZT = L.ZT; a.zn = L.zn; a.M = M; a.Mp = Mp; a.Lp = L.Lp;
-  a.bk = L.base();
-  a.out = Kfull; a.sM = ldf; a.sN = P; a.sP = 1;
-  DCGP_TRY(patch_rbf(ctx, a, "grad_head_kfull"));
+  // every patch response, Kfull[m][n * P + p] = k(Z_m, x_np): kept by the forward pass's sweep where that was the unit sweep (head_forward,
+  // keep_k), evaluated again otherwise
+  if (L.kfull_ready) {
+    L.kfull_ready = false;
+  } else {
+    PatchRbfArgs a;
+    a.X = Xin; a.N = rows; a.n_mod = n_mod;
+    a.H = L.v.H; a.W = L.v.W; a.C = L.v.C; a.f = L.v.f; a.s = L.v.s; a.Ho = L.v.Ho; a.Wo = L.v.Wo; a.P = P; a.L = Ld;
+    a.ZT = L.ZT; a.zn = L.zn; a.M = M; a.Mp = Mp; a.Lp = L.Lp;
+    a.bk = L.base();
+    a.out = Kfull; a.sM = ldf; a.sN = P; a.sP = 1;
+    DCGP_TRY(patch_rbf(ctx, a, "grad_head_kfull"));
+  }
   DCGP_TRY(im2col(ctx, L, Xin, n_mod, Kc, Xcol));
   // Kzx[m][n] = 1/P sum_p w_p k(Z_m, x_np)
   DCGP_TRY(e_form(bk, L, dKzx, ld, P, L.w, 1.0 / P, Kfull, ldf, E, ldf, Kc, cs, raw));

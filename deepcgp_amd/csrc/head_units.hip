@@ -51,13 +51,15 @@ __device__ __forceinline__ int fdiv_small(int i, float inv_d) { return (int)(((f
 //     patches >= P) carry an out-of-range offset and are dropped by the bounds check;
 //   * rows that show the SAME image (propagate() tiles the batch S times: row n shows image (n0 + n) % n_mod) get the same values:
 //     a unit evaluates its tiles once and stores them to every such row (a.n_base < a.N).
+// WMODE 3: the reducing form that also stores every kernel value of its Kzx units (a.kfull: the head of a training step).
 // WMODE 0: the reducing form; 1: the storing form, every tile stored as it is evaluated; 2: the storing form that can also hold a batch
 // of tiles for replica-outer stores (row_pass_hold).  The storing forms run at three / two waves per SIMD (168 / 256 registers, no
 // spill): their stores and a spill reload share the wave's in-order memory counter, so a single reload in the tile loop waits for
 // every store issued before it -- the store queue drained once per tile.
 template <int NK4, int TL, int WMODE, int NT>
-__global__ __launch_bounds__(NT, WMODE == 2 ? 2 : (WMODE == 1 ? 3 : HU_WAVES)) void head_units_kernel(HeadUnitsArgs a) {
-  constexpr bool WRITE = WMODE != 0;
+__global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 3 : HU_WAVES)) void head_units_kernel(HeadUnitsArgs a) {
+  constexpr bool WRITE = WMODE == 1 || WMODE == 2;
+  constexpr bool KEEP = WMODE == 3;
   constexpr int WPG = NT / 64;   // units (waves) per workgroup
   constexpr bool RES = NK4 > 0;
   constexpr int NKR = RES ? NK4 : 1;
@@ -357,6 +359,16 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : (WMODE == 1 ? 3 : HU_WAVES)) v
         }
         continue;
       }
+      if (KEEP && seg_kind != 1) {   // Kzx unit of a training step: the values go out as well (128-byte segments, a fragment = 16 consecutive patches)
+#pragma unroll
+        for (int y = 0; y < YE; ++y) {
+          const int j = j0 + y0 + y;
+          const bool in = j < nfp - 1 || 16 * j + lcol < P;   // the ragged last fragment: patches >= P are dropped
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, t[4 * y + v]), st_rs, in ? st_voff[v] : kOob, j * 128, 0);
+        }
+      }
 #pragma unroll
       for (int y = 0; y < YE; ++y) {
 #pragma unroll
@@ -459,6 +471,11 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : (WMODE == 1 ? 3 : HU_WAVES)) v
         st_voff[v] = (16 * ur + lrow + 4 * v < a.kzx_rows) ? (int)(((long)(lrow + 4 * v) * a.sM + (long)lcol * a.sP) * 8) : kOob;
       st_zero = 16 * ur + 16 > a.M;
     }
+    if (KEEP) {   // the unit's 16 rows of the image's P kernel values each: the descriptor's base is (row 16 u, image n)
+      st_rs = __builtin_amdgcn_make_buffer_rsrc(a.kfull + ((long)(16 * ur) * a.kf_sM + (long)n * a.kf_sN), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) st_voff[v] = (16 * ur + lrow + 4 * v < a.M) ? (int)(((long)(lrow + 4 * v) * a.kf_sM + lcol) * 8) : kOob;
+    }
     if (RES) {
       double areg[NKR];
 #pragma unroll
@@ -544,6 +561,7 @@ bool head_units_ok(const HeadUnitsArgs& a) {
     const long lane_max = (15 * a.sM + 15 * a.sP) * 8, uni_max = ((long)(a.nfp + 1) * 16 * a.sP + (long)a.N * a.sN) * 8;
     if (lane_max >= (1L << 31) || uni_max >= (1L << 31)) return false;
   }
+  if (a.kfull && (15 * a.kf_sM + 15) * 8 + (long)(a.nfp + 1) * 128 >= (1L << 31)) return false;
   return head_units_lds(a) <= 54 * 1024 && (long)a.Lq * a.Mp * 8 < (1L << 31);
 }
 
@@ -739,6 +757,10 @@ int head_units(dcgp_ctx* ctx, const HeadUnitsArgs& a_in) {
     else HU_STORE(0, 0);
 #undef HU_STORE
 #undef HU_STORE_W
+  } else if (a.kfull) {   // a training step's head: the reducing form that also leaves every kernel value behind
+    if (a.L == 25) hipLaunchKernelGGL((head_units_kernel<7, 1, 3, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
+    else if (a.wpg == 4) hipLaunchKernelGGL((head_units_kernel<0, 0, 3, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((head_units_kernel<0, 0, 3, 128>), dim3((unsigned)nwg), dim3(128), lds, ctx->stream, a);
   } else if (a.L == 25) {
     hipLaunchKernelGGL((head_units_kernel<7, 1, 0, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);   // 5 x 5 x 1 patches
   } else if (a.wpg == 4) {

@@ -16,6 +16,7 @@ int allreduce_sum_f64_async(dcgp_ctx* ctx, double* buf_dev, int n);
 struct LayerState {
   dcgp_ctx* ctx = nullptr;
   bool is_head = false;
+  bool kfull_ready = false;   // head: the forward pass of a training step left every patch response in "<pfx>g_Kfull" (head_forward, keep_k)
   ViewGeom v;
   int M = 0, Mp = 0, R = 0, Lp = 0;
   int white = 0, identity_mean = 0, kernel_type = 0;
@@ -322,7 +323,10 @@ static inline int conv_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
 // SVGP head: Kzx / Kdiag from the conv kernel, then the shared conditional
 static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, int rows, int n_mod, double* kd, double* out_mean,
                  double* out_var, const std::string& pfx, hipEvent_t factor_done = nullptr,
-                               hipEvent_t prep_done = nullptr, int phase = 3, int sweep_mode = 0, bool* early_done = nullptr) {
+                               hipEvent_t prep_done = nullptr, int phase = 3, int sweep_mode = 0, bool* early_done = nullptr,
+                               bool keep_k = false) {
+  // keep_k (a training step): the unit sweep also leaves every patch response in the "<pfx>g_Kfull" workspace [Mp][col_ld(rows P)] and sets
+  // L.kfull_ready (the reverse pass would otherwise evaluate them all again)
   // sweep_mode (the unit-sweep route only): 1 = the sweep launch alone (it needs Z only: the model enqueues it in front of the long
   // factorisation chain so that the host still enqueueing the chain does not hold it up; *early_done tells whether anything was launched),
   // 2 = everything behind a sweep launched that way, 0 = both
@@ -355,8 +359,18 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     h.occ_force = (int)ctx->opt.sweep_occ;
     h.share_kb = (int)ctx->opt.share_kb;
     h.upw_force = (int)ctx->opt.head_upw;
+    // (long patches only: a value of a 5 x 5 x 1 patch costs 7 MFMAs to evaluate again -- less than the sweep loses by storing it; head-only MNIST
+    // model 0.64 -> 0.67 ms with the values kept, conv + head at L = 250 1.50 -> 1.43)
+    if (keep_k && !ctx->opt.grad_no_keep_k && L.v.L >= 64) {
+      const long ldf = col_ld((long)rows * L.v.P);
+      h.kfull = (double*)ws_get(ctx, pfx + "g_Kfull", (size_t)Mp * ldf * sizeof(double));
+      if (!h.kfull) return DCGP_ERR_ALLOC;
+      h.kf_sM = ldf; h.kf_sN = L.v.P;
+    }
     head_units_plan(&h);
+    if (h.kfull && !head_units_ok(h)) { h.kfull = nullptr; head_units_plan(&h); }   // (offsets past 32 bits: the reverse pass recomputes)
     if (head_units_ok(h)) {
+      if (sweep_mode != 2) L.kfull_ready = h.kfull != nullptr;
       h.kd = (double*)ws_get(ctx, "kdiag_partial", (size_t)rows * h.n_kd * sizeof(double));   // [rows][n_kd] partial sums (head_units_plan)
       if (!h.kd) return DCGP_ERR_ALLOC;
       if (sweep_mode != 2) DCGP_TRY(head_units(ctx, h));

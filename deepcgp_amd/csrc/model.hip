@@ -224,7 +224,8 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       auto& o = m->outs[li];
       DCGP_TRY(ensure(ctx, &m->d_kd, &m->kd_cap, (size_t)rows));
       DCGP_TRY(head_forward(ctx, L, F, rows, n_mod, m->d_kd, o.mean, o.var, pfx, fdone, pdone, 3,
-                            phase == 1 ? 1 : (phase == 2 && early_head ? 2 : 0), phase == 1 ? &early_head : nullptr));
+                            phase == 1 ? 1 : (phase == 2 && early_head ? 2 : 0), phase == 1 ? &early_head : nullptr,
+                            m->keep_state && m->grad_follows));
       if (phase == 1) { *out_rows_p = rows; return DCGP_OK; }
       if (m->keep_outputs) {
         // the head's sample is not needed by the ELBO; produce it only on request

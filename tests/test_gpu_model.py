@@ -730,6 +730,46 @@ def test_gradients_repeat_in_steady_state(ctx, head_kernel, white):
     model.close()
 
 
+@pytest.mark.parametrize("hwc,convs,M,N", [((9, 9, 10), [], 32, 6), ((12, 12, 10), [], 48, 5), ((14, 14, 1), [(4, 1, 10)], 32, 4),
+                                           ((9, 9, 10), [], 256, 40)])
+def test_kept_patch_responses_match_recomputed(ctx, hwc, convs, M, N):
+    """A training step's forward sweep of a long-patch head also stores every patch response k(z_m, x_np) for the reverse pass
+    (head_units_kernel<..., 3, ...>, conv_gp/kernels.py:117-133 differentiated); option grad_no_keep_k makes the reverse pass
+    evaluate them again (patch_rbf).  Same ELBO bits, gradients equal to rounding -- ragged patch counts (25, 64, 49) included."""
+    spec = syn.make_spec(hwc, convs, (5, 1), M, S=2, num_data=500, seed=3)
+    X, Y = syn.make_batch(hwc, N, seed=3)
+    model = build_from_spec(spec, X, Y)
+    res = {}
+    for nk in (1, 0):
+        with ctx.options(grad_no_keep_k=nk):
+            res[nk] = model.compute_gradients(X, Y, seed=5)
+    (e1, g1), (e0, g0) = res[1], res[0]
+    assert e0 == e1
+    for li, (a, b) in enumerate(zip(g0, g1)):
+        for k in a:
+            assert np.all(np.isfinite(a[k])) and np.all(np.isfinite(b[k])), (li, k)
+            assert np.abs(a[k] - b[k]).max() <= 1e-9 * max(1.0, np.abs(b[k]).max()), (li, k)
+    model.close()
+
+
+def test_gradients_finite_and_repeatable_at_cfg3_size(ctx):
+    """BASELINE configs[2] at full size: three layers, 640 rows, a head of 25 patches of 250 elements -- far-apart patch pairs whose
+    kernel values are denormals (a NaN lengthscale gradient once: 0 x log 0 in the kernel adjoint).  Finite, and the same bits twice."""
+    cfg = syn.CONFIGS["cfg3_mnist_3layer_M256"]
+    spec = syn.make_spec(cfg["hwc"], cfg["convs"], cfg["head"], cfg["M"], S=10, num_data=cfg["num_data"], seed=1)
+    X, Y = syn.make_batch(cfg["hwc"], cfg["batch"], seed=1)
+    model = build_from_spec(spec, X, Y)
+    model.dedup_layer0 = True
+    e0, g0 = model.compute_gradients(X, Y, seed=3)
+    e1, g1 = model.compute_gradients(X, Y, seed=3)
+    assert np.isfinite(e0) and e0 == e1
+    for li, (a, b) in enumerate(zip(g0, g1)):
+        for k in a:
+            assert np.all(np.isfinite(a[k])), (li, k)
+            assert np.array_equal(a[k], b[k]), (li, k)
+    model.close()
+
+
 def _softplus_inv(x):
     return np.log(np.expm1(x - 1e-6))
 
