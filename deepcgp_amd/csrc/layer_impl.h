@@ -332,6 +332,7 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   // 2 = everything behind a sweep launched that way, 0 = both
   const int Mp = L.Mp;
   const long ldb = col_ld(rows);
+  if (sweep_mode != 2) L.kfull_ready = false;   // (set below by the one route that keeps the patch responses)
   double* B = (double*)ws_get(ctx, pfx + "Kzx", (size_t)Mp * ldb * sizeof(double));
   if (!B) return DCGP_ERR_ALLOC;
   if ((phase & 1) && sweep_mode != 2 && Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));
