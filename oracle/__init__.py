@@ -35,6 +35,9 @@ needs the reference -- but it does pin the FORMULAS recalled in SURVEY App. A:
     predict_mean_and_var
   conditional(), SVGP_Layer     torch.linalg dense closed form k - k^T K^-1 k + k^T K^-1 S K^-1 k, both whitenings; KL against K_uu
   reparameterize, ELBO assembly torch algebra; sum_n mean_s E * num_data / N - sum_l KL_l from those pieces
+  the hand-written reverse pass   torch autograd (CPU, float64) of an independently written textbook forward -- unfold patches,
+    (oracle/grad.py), and the       cholesky_solve, Gaussian closed-form KL, RobustMax quadrature -- ELBO to 1e-10, every gradient entry of
+    whole forward value             every layer to 1e-9, both whitenings (``tests/test_oracle_autograd.py``; finite differences reach 1e-4)
 and the stack as a whole learns real images (sklearn load_digits: 0.97 / 0.99 test
 accuracy after 500 Adam steps; ``tests/test_gpu_model.py::test_learns_real_digits``).
 """

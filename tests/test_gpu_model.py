@@ -770,6 +770,33 @@ def test_gradients_finite_and_repeatable_at_cfg3_size(ctx):
     model.close()
 
 
+@pytest.mark.parametrize("white", [False, True])
+def test_device_gradient_matches_torch_autograd(ctx, white):
+    """dcgp_elbo_grad against PyTorch autograd (CPU, float64) of the independently written textbook forward in
+    tests/test_oracle_autograd.py -- third-party differentiation of a forward that shares no code with oracle/ or csrc/."""
+    torch = pytest.importorskip("torch")
+    from test_oracle_autograd import _torch_elbo
+    hwc, N, S = (10, 10, 1), 3, 2
+    spec = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), 7, S=S, num_data=200, seed=11, white=white, conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5)
+    rng = np.random.default_rng(11)
+    spec["head"]["w"] = 0.5 + rng.random(spec["head"]["w"].shape)
+    X, Y = syn.make_batch(hwc, N, seed=11)
+    zs = syn.make_noise(spec, N, seed=11)
+    model = build_from_spec(spec, X, Y)
+    e, grads = model.compute_gradients(X, Y, zs=zs)
+    e_t, leaves = _torch_elbo(spec, X, Y, zs)
+    assert abs(e - e_t.item()) <= 1e-9 * abs(e)
+    flat = [(li, k, t) for li, p in enumerate(leaves) for k, t in p.items()]
+    tg = torch.autograd.grad(e_t, [t for _, _, t in flat])
+    for (li, name, _), g in zip(flat, tg):
+        want, got = g.numpy(), np.asarray(grads[li][name], np.float64)
+        if name == "q_sqrt":
+            want, got = np.tril(want), np.tril(got)
+        err = np.abs(got - want).max()
+        assert err <= 1e-7 * max(1.0, np.abs(want).max()), (li, name, err)
+    model.close()
+
+
 def _softplus_inv(x):
     return np.log(np.expm1(x - 1e-6))
 
