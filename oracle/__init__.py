@@ -37,7 +37,10 @@ needs the reference -- but it does pin the FORMULAS recalled in SURVEY App. A:
   reparameterize, ELBO assembly torch algebra; sum_n mean_s E * num_data / N - sum_l KL_l from those pieces
   the hand-written reverse pass   torch autograd (CPU, float64) of an independently written textbook forward -- unfold patches,
     (oracle/grad.py), and the       cholesky_solve, Gaussian closed-form KL, RobustMax quadrature -- ELBO to 1e-10, every gradient entry of
-    whole forward value             every layer to 1e-9, both whitenings (``tests/test_oracle_autograd.py``; finite differences reach 1e-4)
+    whole forward value             every layer to 1e-9: conv / additive / dense RBF(ARD) heads, Conv2dMean, three layers with a stride-2 first one, both
+    whitenings (``tests/test_oracle_autograd.py``; finite differences reach 1e-4).  The DEVICE value and gradients are compared with
+    the same autograd directly in ``tests/test_gpu_model.py::test_device_gradient_matches_torch_autograd`` /
+    ``test_device_elbo_matches_torch_forward_mnist_geometry``
 and the stack as a whole learns real images (sklearn load_digits: 0.97 / 0.99 test
 accuracy after 500 Adam steps; ``tests/test_gpu_model.py::test_learns_real_digits``).
 """

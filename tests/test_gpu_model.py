@@ -770,16 +770,25 @@ def test_gradients_finite_and_repeatable_at_cfg3_size(ctx):
     model.close()
 
 
-@pytest.mark.parametrize("white", [False, True])
-def test_device_gradient_matches_torch_autograd(ctx, white):
+@pytest.mark.parametrize("white,variant", [(False, "conv"), (True, "conv"), (False, "three_layers_stride2"), (False, "additive"), (False, "dense_ard"),
+                                           (True, "dense_ard"), (False, "conv2d_mean")])
+def test_device_gradient_matches_torch_autograd(ctx, white, variant):
     """dcgp_elbo_grad against PyTorch autograd (CPU, float64) of the independently written textbook forward in
-    tests/test_oracle_autograd.py -- third-party differentiation of a forward that shares no code with oracle/ or csrc/."""
+    tests/test_oracle_autograd.py -- third-party differentiation of a forward that shares no code with oracle/ or csrc/: conv head, additive
+    head, dense RBF(ARD) head, Conv2dMean, three layers with a stride-2 first layer, both whitenings."""
     torch = pytest.importorskip("torch")
     from test_oracle_autograd import _torch_elbo
-    hwc, N, S = (10, 10, 1), 3, 2
-    spec = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), 7, S=S, num_data=200, seed=11, white=white, conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5)
+    hwc, N, S = ((14, 14, 1) if variant == "three_layers_stride2" else (10, 10, 1)), 3, 2
+    convs = [(4, 2, 2), (3, 1, 2)] if variant == "three_layers_stride2" else [(3, 1, 2)]
+    spec = syn.make_spec(hwc, convs, (3, 1), 7, S=S, num_data=200, seed=11, white=white, conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5,
+                         head_kernel="rbf" if variant == "dense_ard" else "conv")
     rng = np.random.default_rng(11)
-    spec["head"]["w"] = 0.5 + rng.random(spec["head"]["w"].shape)
+    if variant != "dense_ard":
+        spec["head"]["w"] = 0.5 + rng.random(spec["head"]["w"].shape)
+    if variant == "additive":
+        spec["head"]["kernel"] = "add"
+    if variant == "conv2d_mean":
+        spec["convs"][0]["mean_function"] = "conv2d"
     X, Y = syn.make_batch(hwc, N, seed=11)
     zs = syn.make_noise(spec, N, seed=11)
     model = build_from_spec(spec, X, Y)
@@ -793,7 +802,23 @@ def test_device_gradient_matches_torch_autograd(ctx, white):
         if name == "q_sqrt":
             want, got = np.tril(want), np.tril(got)
         err = np.abs(got - want).max()
-        assert err <= 1e-7 * max(1.0, np.abs(want).max()), (li, name, err)
+        assert err <= 1e-7 * max(1.0, np.abs(want).max()), (variant, li, name, err)
+    model.close()
+
+
+def test_device_elbo_matches_torch_forward_mnist_geometry(ctx):
+    """The forward ELBO at the headline geometry (28 x 28 x 1, 5 x 5 stride-2 conv layer with 10 maps, 5 x 5 conv head; M = 64, 6 images,
+    S = 3) against the torch textbook forward of tests/test_oracle_autograd.py -- a forward that shares no code with oracle/ or csrc/."""
+    pytest.importorskip("torch")
+    from test_oracle_autograd import _torch_elbo
+    hwc, N, S = (28, 28, 1), 6, 3
+    spec = syn.make_spec(hwc, [(5, 2, 10)], (5, 1), 64, S=S, num_data=60000, seed=17, conv_q_sqrt_scale=0.2)
+    X, Y = syn.make_batch(hwc, N, seed=17)
+    zs = syn.make_noise(spec, N, seed=17)
+    model = build_from_spec(spec, X, Y)
+    e = model.compute_log_likelihood(X, Y, zs=zs)
+    e_t, _ = _torch_elbo(spec, X, Y, zs)
+    assert abs(e - e_t.item()) <= 1e-9 * abs(e), (e, e_t.item())
     model.close()
 
 

@@ -78,7 +78,8 @@ def _robustmax_ve(mu, var, y, eps=1e-3, n_gh=20):
 
 
 def _torch_elbo(spec, X, Y, zs):
-    """ELBO of the conv layers + conv head of `spec` and the leaf tensors it depends on, [{name: tensor}] per layer."""
+    """ELBO of the conv layers + head (ConvKernel, AdditivePatchKernel or dense RBF(ARD)) of `spec` and the leaf tensors it depends on,
+    [{name: tensor}] per layer."""
     leaves = []
     S, N = spec["S"], X.shape[0]
     F = torch.tensor(np.tile(X[None], [S, 1, 1]).reshape(S * N, -1), dtype=T)
@@ -98,24 +99,37 @@ def _torch_elbo(spec, X, Y, zs):
         kff = p["variance"] * torch.ones(cols.shape[0], dtype=T)
         mean, var = _conditional(Kuu, Kuf, kff, p["q_mu"], p["q_sqrt"], c["white"])          # [SNP, R]
         mean, var = mean.reshape(S * N, P * R), var.reshape(S * N, P * R)                    # output index p * R + r (layers.py:128-131)
+        if c.get("mean_function") == "conv2d":   # Conv2dMean (mean_functions.py:28-41): output map 0 of a patch = the centre pixel of input channel 0
+            centre = pt.reshape(S * N, P, c["f"], c["f"], c["C"])[:, :, c["f"] // 2, c["f"] // 2, 0]
+            mean = mean + torch.cat([centre[:, :, None], torch.zeros(S * N, P, R - 1, dtype=T)], 2).reshape(S * N, P * R)
         z = torch.tensor(np.asarray(zs[li]).reshape(S * N, P * R), dtype=T)
         F = mean + z * torch.sqrt(var + JITTER)
         Z0 = torch.tensor(np.array(c["Z0"], np.float64), dtype=T)                             # the prior's inducing patches are frozen (layers.py:149-152)
         Kp = None if c["white"] else _rbf(Z0, Z0, p["variance"], p["lengthscales"]) + JITTER * torch.eye(M, dtype=T)
         kl = kl + _gauss_kl(p["q_mu"], p["q_sqrt"], Kp)
     h = spec["head"]
-    p = dict(Z=leaf(h["Z"]), q_mu=leaf(h["q_mu"]), q_sqrt=leaf(h["q_sqrt"]), variance=leaf(h["variance"]), lengthscales=leaf(h["ls"]),
-             patch_weights=leaf(h["w"]))
-    leaves.append(p)
     M = h["M"]
-    pt = _patches(F.reshape(S * N, h["H"], h["W"], h["C"]), h["f"], h["s"])                  # [SN, P, L]
-    P = pt.shape[1]
-    w = p["patch_weights"]
-    Kall = _rbf(p["Z"], pt.reshape(S * N * P, -1), p["variance"], p["lengthscales"]).reshape(M, S * N, P)
-    Kzx = (Kall * w[None, None, :]).sum(2) / P                                               # kernels.py:117-133
-    Kpp = p["variance"] * torch.exp(-0.5 * torch.cdist(pt / p["lengthscales"], pt / p["lengthscales"], compute_mode="donot_use_mm_for_euclid_dist") ** 2)
-    kdiag = torch.einsum("npq,p,q->n", Kpp, w, w) / P ** 2                                   # kernels.py:106-115
-    Kuu = _rbf(p["Z"], p["Z"], p["variance"], p["lengthscales"]) + JITTER * torch.eye(M, dtype=T)
+    if h.get("kernel", "conv") == "rbf":   # dense head: gpflow RBF(ARD=True) on the flattened features (models.py:160-168)
+        p = dict(Z=leaf(h["Z"]), q_mu=leaf(h["q_mu"]), q_sqrt=leaf(h["q_sqrt"]), variance=leaf(h["variance"]), lengthscales=leaf(h["ls_ard"]))
+        leaves.append(p)
+        Kuu = _rbf(p["Z"], p["Z"], p["variance"], p["lengthscales"][None, :]) + JITTER * torch.eye(M, dtype=T)
+        Kzx = _rbf(p["Z"], F, p["variance"], p["lengthscales"][None, :])
+        kdiag = p["variance"] * torch.ones(F.shape[0], dtype=T)
+    else:
+        p = dict(Z=leaf(h["Z"]), q_mu=leaf(h["q_mu"]), q_sqrt=leaf(h["q_sqrt"]), variance=leaf(h["variance"]), lengthscales=leaf(h["ls"]),
+                 patch_weights=leaf(h["w"]))
+        leaves.append(p)
+        pt = _patches(F.reshape(S * N, h["H"], h["W"], h["C"]), h["f"], h["s"])                  # [SN, P, L]
+        P = pt.shape[1]
+        w = p["patch_weights"]
+        Kall = _rbf(p["Z"], pt.reshape(S * N * P, -1), p["variance"], p["lengthscales"]).reshape(M, S * N, P)
+        Kzx = (Kall * w[None, None, :]).sum(2) / P                                               # kernels.py:63-74 / :117-133
+        if h.get("kernel", "conv") == "add":   # AdditivePatchKernel.Kdiag (kernels.py:53-61): mean_p w_p k(x_p, x_p)
+            kdiag = p["variance"] * w.mean() * torch.ones(S * N, dtype=T)
+        else:                                  # ConvKernel.Kdiag (kernels.py:106-115): all patch pairs of an image
+            Kpp = p["variance"] * torch.exp(-0.5 * torch.cdist(pt / p["lengthscales"], pt / p["lengthscales"], compute_mode="donot_use_mm_for_euclid_dist") ** 2)
+            kdiag = torch.einsum("npq,p,q->n", Kpp, w, w) / P ** 2
+        Kuu = _rbf(p["Z"], p["Z"], p["variance"], p["lengthscales"]) + JITTER * torch.eye(M, dtype=T)
     mean, var = _conditional(Kuu, Kzx, kdiag, p["q_mu"], p["q_sqrt"], h["white"])
     kl = kl + _gauss_kl(p["q_mu"], p["q_sqrt"], None if h["white"] else Kuu)                  # the head's prior shares the live Z
     y = torch.tensor(np.tile(np.asarray(Y).reshape(1, N), [S, 1]).reshape(S * N), dtype=torch.long)
@@ -123,17 +137,29 @@ def _torch_elbo(spec, X, Y, zs):
     return ve * (spec["num_data"] / N) - kl, leaves
 
 
-@pytest.mark.parametrize("white", [False, True])
-def test_hand_written_gradient_matches_torch_autograd(white):
+@pytest.mark.parametrize("white,variant", [(False, "conv"), (True, "conv"), (False, "three_layers_stride2"), (False, "additive"), (False, "dense_ard"),
+                                           (True, "dense_ard"), (False, "conv2d_mean")])
+def test_hand_written_gradient_matches_torch_autograd(white, variant):
     from oracle.grad import elbo_and_grad
-    hwc, N, S = (10, 10, 1), 3, 2
-    spec = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), 7, S=S, num_data=200, seed=11, white=white, conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5)
+    hwc, N, S = ((14, 14, 1) if variant == "three_layers_stride2" else (10, 10, 1)), 3, 2
+    convs = [(4, 2, 2), (3, 1, 2)] if variant == "three_layers_stride2" else [(3, 1, 2)]
+    spec = syn.make_spec(hwc, convs, (3, 1), 7, S=S, num_data=200, seed=11, white=white, conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5,
+                         head_kernel="rbf" if variant == "dense_ard" else "conv")
     rng = np.random.default_rng(11)
-    spec["head"]["w"] = 0.5 + rng.random(spec["head"]["w"].shape)
+    if variant != "dense_ard":
+        spec["head"]["w"] = 0.5 + rng.random(spec["head"]["w"].shape)
+    if variant == "additive":
+        spec["head"]["kernel"] = "add"
+    if variant == "conv2d_mean":
+        spec["convs"][0]["mean_function"] = "conv2d"
     spec["convs"][0]["Z0"] = spec["convs"][0]["Z"] + 0.05 * rng.standard_normal(spec["convs"][0]["Z"].shape)   # prior patches != live patches
     X, Y = syn.make_batch(hwc, N, seed=11)
     zs = syn.make_noise(spec, N, seed=11)
     ref = oracle_model(spec, X, Y)
+    if variant == "additive":
+        from oracle.kernels import AdditivePatchKernel
+        k = ref.layers[-1].kern
+        ref.layers[-1].kern = AdditivePatchKernel(k.base_kernel, k.view, k.patch_weights)
     e_oracle, g_oracle = elbo_and_grad(ref, X, Y, zs)
     e_torch, leaves = _torch_elbo(spec, X, Y, zs)
     assert abs(e_torch.item() - e_oracle) <= 1e-10 * abs(e_oracle)
@@ -146,4 +172,4 @@ def test_hand_written_gradient_matches_torch_autograd(white):
             got = np.tril(got)                      # only the lower triangle is a parameter
             want = np.tril(want)
         err = np.abs(got - want).max()
-        assert err <= 1e-9 * max(1.0, np.abs(want).max()), (li, name, err, np.abs(want).max())
+        assert err <= 1e-9 * max(1.0, np.abs(want).max()), (variant, li, name, err, np.abs(want).max())
