@@ -1328,7 +1328,9 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   double* dXcol = bk.ws("dXcol", (size_t)Kc * Ld);
   NEED(A1); NEED(dKzx); NEED(S); NEED(gkd); NEED(Kfull); NEED(E); NEED(cs); NEED(raw); NEED(Xcol); NEED(dXcol);
   if (Mp > M) HIP_TRY(ctx, hipMemsetAsync(A1 + (size_t)M * ld, 0, (size_t)(Mp - M) * ld * sizeof(double), ctx->stream));   // padded rows: operands of gemm_tn
-  DCGP_TRY(gemm_gen(ctx, mk(L.g.Linv, Mp, 1, Kzx, ld, 1, A1, ld, M, rows, M)));      // the fused forward keeps A1 on chip
+  // A1 = inv(L) Kzx: left behind by the forward pass's one-launch conditional in a training step (head_forward, keep_k), formed here otherwise
+  if (L.a1h_ready) L.a1h_ready = false;
+  else DCGP_TRY(gemm_gen(ctx, mk(L.g.Linv, Mp, 1, Kzx, ld, 1, A1, ld, M, rows, M)));
   const Lanes ln = lanes_of(ctx);
   // as in conv_backward: the conditional's column-wise adjoint and the patch-kernel adjoints (K_zx, K_diag) on the main stream, the M x M
   // chain and what needs S beside them

@@ -32,6 +32,8 @@ struct HeadCondArgs {
   int kd_n; double kd_scale;
   int Mp, R;
   double *out_mean, *out_var;              // [Kc][R]
+  double* A1_out; long lda1;               // != null: A1 = inv(L) Kzx [M][lda1] is left behind as well (a training step's reverse pass reads it)
+  int M;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -119,6 +121,11 @@ __global__ __launch_bounds__(1024, 4) void head_cond_kernel(HeadCondArgs a) {
   if (live) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) Bt[(i0 + lrow + 4 * v) * HC_BN + lcol] = acc[v];
+    if (a.A1_out && r == 0 && j0 + lcol < a.Kc) {   // (every output's workgroup of the strip holds the same A1: the first one stores it)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (i0 + lrow + 4 * v < a.M) a.A1_out[(long)(i0 + lrow + 4 * v) * a.lda1 + j0 + lcol] = acc[v];
+    }
   }
   __syncthreads();   // A1 published
   // ---- stage 3: T_r = G_r^T A1, upper-triangular W: k-tiles wave .. nt-1 ----
@@ -267,7 +274,7 @@ bool head_cond_fused_ok(const GpMats& g) { return g.Mp <= HC_MP && g.Mp % HC_BK 
 
 // mean / var [Kc][R] of the conditional at Kc columns whose Kzx is B [Mp][ldb]; G / alpha from cond_prep
 int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, bool have_qsqrt, const double* kd,
-                    double* out_mean, double* out_var, int kd_n, double kd_scale) {
+                    double* out_mean, double* out_var, int kd_n, double kd_scale, double* A1_out, long lda1) {
   if (Kc <= 0) return DCGP_OK;
   if (!head_cond_fused_ok(g) || (long)g.Mp * ldb * 8 >= (1L << 31))
     return ctx_fail(ctx, DCGP_ERR_ARG, "head_cond_fused: M = %d not supported", g.Mp);
@@ -277,6 +284,7 @@ int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, i
   a.LinvT = g.LinvT; a.G = have_qsqrt ? g.G : nullptr; a.alpha = g.alpha; a.Rp = g.Rp;
   a.kd = kd; a.kd_n = kd_n; a.kd_scale = kd_scale; a.Mp = g.Mp; a.R = g.R;
   a.out_mean = out_mean; a.out_var = out_var;
+  a.A1_out = A1_out; a.lda1 = lda1; a.M = g.M;
   hipLaunchKernelGGL(head_cond_kernel, dim3((Kc + HC_BN - 1) / HC_BN, g.R), dim3(1024), 0, ctx->stream, a);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;

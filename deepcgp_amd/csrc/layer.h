@@ -68,7 +68,7 @@ int cond_core(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc,
 // head_cond.hip: the whole conditional of a few-column problem in one launch (M <= 256): mean / var [Kc][R]
 bool head_cond_fused_ok(const GpMats& g);
 int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, bool have_qsqrt, const double* kd,
-                    double* out_mean, double* out_var, int kd_n = 1, double kd_scale = 1.0);   // Knn[j] = kd_scale * sum_{i < kd_n} kd[j * kd_n + i]
+                    double* out_mean, double* out_var, int kd_n = 1, double kd_scale = 1.0, double* A1_out = nullptr, long lda1 = 0);   // Knn[j] = kd_scale * sum_{i < kd_n} kd[j * kd_n + i]
 
 // head_cond.hip: G / alpha of every layer in one launch; done[i] = false where layer i still needs cond_prep
 int prep_solve_all(dcgp_ctx* ctx, GpMats* const* gs, const int* white, const bool* have_qsqrt, int nl, bool* done);

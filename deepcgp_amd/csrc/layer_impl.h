@@ -16,6 +16,7 @@ int allreduce_sum_f64_async(dcgp_ctx* ctx, double* buf_dev, int n);
 struct LayerState {
   dcgp_ctx* ctx = nullptr;
   bool is_head = false;
+  bool a1h_ready = false;     // head: the forward pass of a training step left A1 = inv(L) Kzx in "<pfx>g_A1h" (head_forward, keep_k)
   bool kfull_ready = false;   // head: the forward pass of a training step left every patch response in "<pfx>g_Kfull" (head_forward, keep_k)
   ViewGeom v;
   int M = 0, Mp = 0, R = 0, Lp = 0;
@@ -333,6 +334,12 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
   const int Mp = L.Mp;
   const long ldb = col_ld(rows);
   if (sweep_mode != 2) L.kfull_ready = false;   // (set below by the one route that keeps the patch responses)
+  if (sweep_mode != 1) L.a1h_ready = false;     // (set below where the one-launch conditional leaves A1 behind)
+  double* a1_out = nullptr;
+  if (keep_k && sweep_mode != 1 && !ctx->opt.grad_no_keep_k && head_cond_fused_ok(L.g) && !ctx->opt.head_unfused) {
+    a1_out = (double*)ws_get(ctx, pfx + "g_A1h", (size_t)Mp * ldb * sizeof(double));
+    if (!a1_out) return DCGP_ERR_ALLOC;
+  }
   double* B = (double*)ws_get(ctx, pfx + "Kzx", (size_t)Mp * ldb * sizeof(double));
   if (!B) return DCGP_ERR_ALLOC;
   if ((phase & 1) && sweep_mode != 2 && Mp > L.M) HIP_TRY(ctx, hipMemsetAsync(B + (size_t)L.M * ldb, 0, (size_t)(Mp - L.M) * ldb * sizeof(double), ctx->stream));
@@ -382,8 +389,10 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
       const double kd_scale = 1.0 / ((double)L.v.P * (double)L.v.P);
       if (prep_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, prep_done, 0));
       else if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
-      if (head_cond_fused_ok(L.g) && !unfused)
-        return head_cond_fused(ctx, L.g, B, ldb, rows, L.has_qsqrt, h.kd, out_mean, out_var, h.n_kd, kd_scale);
+      if (head_cond_fused_ok(L.g) && !unfused) {
+        L.a1h_ready = a1_out != nullptr;
+        return head_cond_fused(ctx, L.g, B, ldb, rows, L.has_qsqrt, h.kd, out_mean, out_var, h.n_kd, kd_scale, a1_out, ldb);
+      }
       DCGP_TRY(kdiag_reduce(ctx, h.kd, h.n_kd, rows, kd_scale, kd));
       CondScratch sc;
       DCGP_TRY(cond_core(ctx, L.g, B, ldb, rows, L.white, L.has_qsqrt, pfx.c_str(), &sc, nullptr, true));
@@ -402,7 +411,8 @@ static inline int head_forward(dcgp_ctx* ctx, LayerState& L, const double* X, in
     DCGP_TRY(head_sweep(ctx, a, L.w, &kdp, &kd_n, &kd_scale));
     if (prep_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, prep_done, 0));
     else if (factor_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, factor_done, 0));
-    return head_cond_fused(ctx, L.g, B, ldb, rows, L.has_qsqrt, kdp, out_mean, out_var, kd_n, kd_scale);
+    L.a1h_ready = a1_out != nullptr;
+    return head_cond_fused(ctx, L.g, B, ldb, rows, L.has_qsqrt, kdp, out_mean, out_var, kd_n, kd_scale, a1_out, ldb);
   }
   bool kd_on_side = false;
   if (phase & 1) {
