@@ -40,7 +40,8 @@ needs the reference -- but it does pin the FORMULAS recalled in SURVEY App. A:
     whole forward value             every layer to 1e-9: conv / additive / dense RBF(ARD) heads, Conv2dMean, three layers with a stride-2 first one, both
     whitenings (``tests/test_oracle_autograd.py``; finite differences reach 1e-4).  The DEVICE value and gradients are compared with
     the same autograd directly in ``tests/test_gpu_model.py::test_device_gradient_matches_torch_autograd`` /
-    ``test_device_elbo_matches_torch_forward_mnist_geometry``
+    ``test_device_elbo_matches_torch_forward_mnist_geometry``, and at the FULL size of BASELINE configs[0..3] in
+    ``test_full_size_cfg1_vs_torch_forward`` / ``test_full_size_baseline_configs_vs_torch_forward`` (1e-9)
 and the stack as a whole learns real images (sklearn load_digits: 0.97 / 0.99 test
 accuracy after 500 Adam steps; ``tests/test_gpu_model.py::test_learns_real_digits``).
 """

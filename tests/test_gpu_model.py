@@ -383,6 +383,38 @@ def test_full_size_cfg1_vs_oracle(ctx):
     model.close()
 
 
+def test_full_size_cfg1_vs_torch_forward(ctx):
+    """The same configuration at full size against the independently written torch forward of tests/test_oracle_autograd.py (float64, CPU):
+    BASELINE configs[0] is the one configuration the reference itself runs on a CPU, and this is the check of the device path at that size
+    that owes nothing to oracle/."""
+    pytest.importorskip("torch")
+    from test_oracle_autograd import _torch_elbo
+    spec, X, Y = syn.make_config("cfg1_mnist_H_M32")
+    zs = syn.make_noise(spec, X.shape[0], seed=5)
+    model = build_from_spec(spec, X, Y)
+    e = model.compute_log_likelihood(X, Y, zs=zs)
+    e_t, _ = _torch_elbo(spec, X, Y, zs)
+    assert abs(e - e_t.item()) <= 1e-9 * abs(e), (e, e_t.item())
+    model.close()
+
+
+@pytest.mark.parametrize("name", ["cfg2_mnist_H_M256", "cfg2_mnist_CH_M256", "cfg3_mnist_3layer_M256", "cfg4_cifar_3layer_M384"])
+def test_full_size_baseline_configs_vs_torch_forward(ctx, name):
+    """BASELINE configs[1] -- the configuration the metric is quoted on, in both readings of "1-layer": M = 256, batch 32, S = 10, 46080 patch
+    columns through the conv layer -- and configs[2], [3] (three layers, batch 64 / CIFAR M = 384) at FULL size against the same torch forward
+    (2-5 s of CPU each; configs[4] at M = 1024 would take minutes and stays with the oracle on a reduced batch)."""
+    torch = pytest.importorskip("torch")
+    from test_oracle_autograd import _torch_elbo
+    spec, X, Y = syn.make_config(name)
+    zs = syn.make_noise(spec, X.shape[0], seed=6)
+    model = build_from_spec(spec, X, Y)
+    e = model.compute_log_likelihood(X, Y, zs=zs)
+    with torch.no_grad():
+        e_t, _ = _torch_elbo(spec, X, Y, zs)
+    assert abs(e - e_t.item()) <= 1e-9 * abs(e), (e, e_t.item())
+    model.close()
+
+
 BIG = ["cfg3_mnist_3layer_M256", "cfg4_cifar_3layer_M384", "cfg5_mnist_H_M1024", "cfg5_mnist_CH_M1024"]
 
 
