@@ -415,6 +415,29 @@ def test_full_size_baseline_configs_vs_torch_forward(ctx, name):
     model.close()
 
 
+@pytest.mark.parametrize("name", ["cfg2_mnist_H_M256", "cfg2_mnist_CH_M256"])
+def test_full_size_cfg2_gradient_vs_torch_autograd(ctx, name):
+    """The training step's gradient at the FULL size of the configuration the metric is quoted on against PyTorch autograd of the torch forward:
+    every parameter group of every layer (relative to the group's largest entry)."""
+    torch = pytest.importorskip("torch")
+    from test_oracle_autograd import _torch_elbo
+    spec, X, Y = syn.make_config(name)
+    zs = syn.make_noise(spec, X.shape[0], seed=6)
+    model = build_from_spec(spec, X, Y)
+    e, grads = model.compute_gradients(X, Y, zs=zs)
+    e_t, leaves = _torch_elbo(spec, X, Y, zs)
+    assert abs(e - e_t.item()) <= 1e-9 * abs(e)
+    flat = [(li, k, t) for li, p in enumerate(leaves) for k, t in p.items()]
+    tg = torch.autograd.grad(e_t, [t for _, _, t in flat])
+    for (li, gname, _), g in zip(flat, tg):
+        want, got = g.numpy(), np.asarray(grads[li][gname], np.float64)
+        if gname == "q_sqrt":
+            want, got = np.tril(want), np.tril(got)
+        err = np.abs(got - want).max()
+        assert err <= 1e-7 * max(1.0, np.abs(want).max()), (name, li, gname, err, np.abs(want).max())
+    model.close()
+
+
 BIG = ["cfg3_mnist_3layer_M256", "cfg4_cifar_3layer_M384", "cfg5_mnist_H_M1024", "cfg5_mnist_CH_M1024"]
 
 
