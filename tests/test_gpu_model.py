@@ -383,6 +383,28 @@ def test_full_size_cfg1_vs_oracle(ctx):
     model.close()
 
 
+def test_propagate_and_predict_y_vs_torch_forward(ctx):
+    """DGP_Base.propagate (the head's marginals of every sample) and predict_y (RobustMax class probabilities, conv_gp/utils/log.py:62-66)
+    against the torch forward: 28 x 28 geometry, conv layer + head, M = 48."""
+    torch = pytest.importorskip("torch")
+    from test_oracle_autograd import _torch_elbo, _robustmax_predict
+    hwc, N, S = (28, 28, 1), 5, 3
+    spec = syn.make_spec(hwc, [(5, 2, 10)], (5, 1), 48, S=S, num_data=60000, seed=23, conv_q_sqrt_scale=0.2)
+    X, Y = syn.make_batch(hwc, N, seed=23)
+    zs = syn.make_noise(spec, N, seed=23)
+    model = build_from_spec(spec, X, Y)
+    with torch.no_grad():
+        _, _, mean_t, var_t = _torch_elbo(spec, X, Y, zs, want_head=True)
+        p_t = _robustmax_predict(mean_t.reshape(S * N, -1), var_t.reshape(S * N, -1)).reshape(S, N, -1).numpy()
+    Fs, Fmeans, Fvars = model.propagate(X, S=S, zs=zs)
+    assert np.abs(Fmeans[-1] - mean_t.numpy()).max() <= 1e-9 * max(1.0, np.abs(mean_t.numpy()).max())
+    assert np.abs(Fvars[-1] - var_t.numpy()).max() <= 1e-9 * max(1.0, np.abs(var_t.numpy()).max())
+    ps, pv = model.predict_y(X, S, zs=zs)
+    assert np.abs(ps - p_t).max() <= 1e-10
+    assert np.abs(ps.sum(-1) - 1.0).max() < 2e-3          # RobustMax probabilities of the K classes sum to ~1 (quadrature + epsilon)
+    model.close()
+
+
 def test_full_size_cfg1_vs_torch_forward(ctx):
     """The same configuration at full size against the independently written torch forward of tests/test_oracle_autograd.py (float64, CPU):
     BASELINE configs[0] is the one configuration the reference itself runs on a CPU, and this is the check of the device path at that size

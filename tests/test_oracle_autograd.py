@@ -77,7 +77,20 @@ def _robustmax_ve(mu, var, y, eps=1e-3, n_gh=20):
     return p * math.log(1.0 - eps) + (1.0 - p) * math.log(eps / (K - 1.0))
 
 
-def _torch_elbo(spec, X, Y, zs):
+def _robustmax_predict(mu, var, eps=1e-3):
+    """class probabilities of gpflow's MultiClass.predict_mean_and_var: p_k = P(f_k largest) (1 - eps) + (1 - P) eps / (K - 1)."""
+    n, K = mu.shape
+    cols = []
+    for k in range(K):
+        y = torch.full((n,), k, dtype=torch.long)
+        ve = _robustmax_ve(mu, var, y, eps)                      # p log(1 - eps) + (1 - p) log(eps / (K - 1)) -> p
+        a, b = math.log(1.0 - eps), math.log(eps / (K - 1.0))
+        p = (ve - b) / (a - b)
+        cols.append(p * (1.0 - eps) + (1.0 - p) * eps / (K - 1.0))
+    return torch.stack(cols, 1)
+
+
+def _torch_elbo(spec, X, Y, zs, want_head=False):
     """ELBO of the conv layers + head (ConvKernel, AdditivePatchKernel or dense RBF(ARD)) of `spec` and the leaf tensors it depends on,
     [{name: tensor}] per layer."""
     leaves = []
@@ -134,6 +147,8 @@ def _torch_elbo(spec, X, Y, zs):
     kl = kl + _gauss_kl(p["q_mu"], p["q_sqrt"], None if h["white"] else Kuu)                  # the head's prior shares the live Z
     y = torch.tensor(np.tile(np.asarray(Y).reshape(1, N), [S, 1]).reshape(S * N), dtype=torch.long)
     ve = _robustmax_ve(mean, var, y).reshape(S, N).mean(0).sum()
+    if want_head:   # the last layer's marginals [S, N, R] as well (DGP_Base.propagate / predict_y)
+        return ve * (spec["num_data"] / N) - kl, leaves, mean.reshape(S, N, -1), var.reshape(S, N, -1)
     return ve * (spec["num_data"] / N) - kl, leaves
 
 
