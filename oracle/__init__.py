@@ -41,7 +41,8 @@ needs the reference -- but it does pin the FORMULAS recalled in SURVEY App. A:
     whitenings (``tests/test_oracle_autograd.py``; finite differences reach 1e-4).  The DEVICE value and gradients are compared with
     the same autograd directly in ``tests/test_gpu_model.py::test_device_gradient_matches_torch_autograd`` /
     ``test_device_elbo_matches_torch_forward_mnist_geometry``, and at the FULL size of BASELINE configs[0..3] in
-    ``test_full_size_cfg1_vs_torch_forward`` / ``test_full_size_baseline_configs_vs_torch_forward`` (1e-9); the gradient of the
+    ``test_full_size_cfg1_vs_torch_forward`` / ``test_full_size_baseline_configs_vs_torch_forward`` (1e-9), configs[4] (M = 1024) on a
+    reduced batch in ``test_cfg5_reduced_batch_vs_torch_forward``; the gradient of the
     headline configuration at full size against autograd in ``test_full_size_cfg2_gradient_vs_torch_autograd`` (1e-7)
 and the stack as a whole learns real images (sklearn load_digits: 0.97 / 0.99 test
 accuracy after 500 Adam steps; ``tests/test_gpu_model.py::test_learns_real_digits``).

@@ -460,6 +460,23 @@ def test_full_size_cfg2_gradient_vs_torch_autograd(ctx, name):
     model.close()
 
 
+@pytest.mark.parametrize("name", ["cfg5_mnist_H_M1024", "cfg5_mnist_CH_M1024"])
+def test_cfg5_reduced_batch_vs_torch_forward(ctx, name):
+    """BASELINE configs[4] (M = 1024: the 32-panel factorisation chain, the GEMM route of the conditional) on a reduced batch (4 images, S = 2)
+    against the torch forward -- at its full batch that forward would take minutes of CPU."""
+    torch = pytest.importorskip("torch")
+    from test_oracle_autograd import _torch_elbo
+    spec, X, Y = syn.make_config(name, S=2)
+    X, Y = X[:4], Y[:4]
+    zs = syn.make_noise(spec, 4, seed=8)
+    model = build_from_spec(spec, X, Y)
+    e = model.compute_log_likelihood(X, Y, zs=zs)
+    with torch.no_grad():
+        e_t, _ = _torch_elbo(spec, X, Y, zs)
+    assert abs(e - e_t.item()) <= 1e-9 * abs(e), (e, e_t.item())
+    model.close()
+
+
 BIG = ["cfg3_mnist_3layer_M256", "cfg4_cifar_3layer_M384", "cfg5_mnist_H_M1024", "cfg5_mnist_CH_M1024"]
 
 
