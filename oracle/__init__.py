@@ -38,7 +38,7 @@ needs the reference -- but it does pin the FORMULAS recalled in SURVEY App. A:
   the hand-written reverse pass   torch autograd (CPU, float64) of an independently written textbook forward -- unfold patches,
     (oracle/grad.py), and the       cholesky_solve, Gaussian closed-form KL, RobustMax quadrature -- ELBO to 1e-10, every gradient entry of
     whole forward value             every layer to 1e-9: conv / additive / dense RBF(ARD) heads, Conv2dMean, three layers with a stride-2 first one, both
-    whitenings (``tests/test_oracle_autograd.py``; finite differences reach 1e-4).  The DEVICE value and gradients are compared with
+    whitenings; the ArcCosine(order 0) conv layers' ELBO value as well (``tests/test_oracle_autograd.py``; finite differences reach 1e-4).  The DEVICE value and gradients are compared with
     the same autograd directly in ``tests/test_gpu_model.py::test_device_gradient_matches_torch_autograd`` /
     ``test_device_elbo_matches_torch_forward_mnist_geometry``, and at the FULL size of BASELINE configs[0..3] in
     ``test_full_size_cfg1_vs_torch_forward`` / ``test_full_size_baseline_configs_vs_torch_forward`` (1e-9), configs[4] (M = 1024) on a

@@ -405,6 +405,23 @@ def test_propagate_and_predict_y_vs_torch_forward(ctx):
     model.close()
 
 
+@pytest.mark.parametrize("white", [False, True])
+def test_arccosine_model_vs_torch_forward(ctx, white):
+    """ArcCosine(order 0) conv layers (--base-kernel acos, conv_gp/models.py:118-119) on the device against the torch forward, MNIST geometry."""
+    torch = pytest.importorskip("torch")
+    from test_oracle_autograd import _torch_elbo
+    hwc, N, S = (28, 28, 1), 4, 2
+    spec = syn.make_spec(hwc, [(5, 2, 4)], (5, 1), 40, S=S, num_data=60000, seed=29, white=white, conv_q_sqrt_scale=0.2, base_kernel="acos")
+    X, Y = syn.make_batch(hwc, N, seed=29)
+    zs = syn.make_noise(spec, N, seed=29)
+    model = build_from_spec(spec, X, Y)
+    e = model.compute_log_likelihood(X, Y, zs=zs)
+    with torch.no_grad():
+        e_t, _ = _torch_elbo(spec, X, Y, zs)
+    assert abs(e - e_t.item()) <= 1e-9 * abs(e), (e, e_t.item())
+    model.close()
+
+
 def test_full_size_cfg1_vs_torch_forward(ctx):
     """The same configuration at full size against the independently written torch forward of tests/test_oracle_autograd.py (float64, CPU):
     BASELINE configs[0] is the one configuration the reference itself runs on a CPU, and this is the check of the device path at that size

@@ -34,6 +34,15 @@ def _rbf(A, B, variance, ls):
     return variance * torch.exp(-0.5 * torch.cdist(A / ls, B / ls, compute_mode="donot_use_mm_for_euclid_dist") ** 2)
 
 
+def _acos0(A, B, variance, wv, bv):
+    """gpflow ArcCosine(order 0): variance / pi * (pi - theta), theta = acos(1e-15 + (1 - 2e-15) cos), <x, z> = wv x.z + bv."""
+    num = wv * (A @ B.T) + bv
+    da = torch.sqrt(wv * (A * A).sum(1) + bv)
+    db = torch.sqrt(wv * (B * B).sum(1) + bv)
+    theta = torch.acos(1e-15 + (1.0 - 2e-15) * num / da[:, None] / db[None, :])
+    return variance * (math.pi - theta) / math.pi
+
+
 def _conditional(Kuu, Kuf, kff, q_mu, q_sqrt, white):
     """columns c of Kuf [M, C]; returns mean [C, R], var [C, R] of q(f_c) for the R outputs (full_cov = False)."""
     M = Kuu.shape[0]
@@ -107,8 +116,14 @@ def _torch_elbo(spec, X, Y, zs, want_head=False):
         pt = _patches(F.reshape(S * N, c["H"], c["W"], c["C"]), c["f"], c["s"])               # [SN, P, L]
         P = pt.shape[1]
         cols = pt.reshape(S * N * P, -1)                                                     # column (n, p)
-        Kuu = _rbf(p["Z"], p["Z"], p["variance"], p["lengthscales"]) + JITTER * torch.eye(M, dtype=T)
-        Kuf = _rbf(p["Z"], cols, p["variance"], p["lengthscales"])
+        if c.get("base", "rbf") == "acos":   # ArcCosine(order 0) base kernel with gpflow's default hyper-parameters (value only: see the test below)
+            one = torch.ones((), dtype=T)
+            kern = lambda A, B: _acos0(A, B, one, one, one)                                  # noqa: E731
+            p["variance"] = one
+        else:
+            kern = lambda A, B: _rbf(A, B, p["variance"], p["lengthscales"])                   # noqa: E731
+        Kuu = kern(p["Z"], p["Z"]) + JITTER * torch.eye(M, dtype=T)
+        Kuf = kern(p["Z"], cols)
         kff = p["variance"] * torch.ones(cols.shape[0], dtype=T)
         mean, var = _conditional(Kuu, Kuf, kff, p["q_mu"], p["q_sqrt"], c["white"])          # [SNP, R]
         mean, var = mean.reshape(S * N, P * R), var.reshape(S * N, P * R)                    # output index p * R + r (layers.py:128-131)
@@ -118,7 +133,7 @@ def _torch_elbo(spec, X, Y, zs, want_head=False):
         z = torch.tensor(np.asarray(zs[li]).reshape(S * N, P * R), dtype=T)
         F = mean + z * torch.sqrt(var + JITTER)
         Z0 = torch.tensor(np.array(c["Z0"], np.float64), dtype=T)                             # the prior's inducing patches are frozen (layers.py:149-152)
-        Kp = None if c["white"] else _rbf(Z0, Z0, p["variance"], p["lengthscales"]) + JITTER * torch.eye(M, dtype=T)
+        Kp = None if c["white"] else kern(Z0, Z0) + JITTER * torch.eye(M, dtype=T)
         kl = kl + _gauss_kl(p["q_mu"], p["q_sqrt"], Kp)
     h = spec["head"]
     M = h["M"]
@@ -188,3 +203,18 @@ def test_hand_written_gradient_matches_torch_autograd(white, variant):
             want = np.tril(want)
         err = np.abs(got - want).max()
         assert err <= 1e-9 * max(1.0, np.abs(want).max()), (variant, li, name, err, np.abs(want).max())
+
+
+@pytest.mark.parametrize("white", [False, True])
+def test_arccosine_forward_matches_torch(white):
+    """ArcCosine(order 0) conv layers (--base-kernel acos): the oracle's ELBO against the torch forward.  Value only: the oracle's gradient skips the
+    coincident points of K_uu on purpose (acos' slope at 1 - 1e-15 is ~2e7 and would only amplify rounding; oracle/grad.py), autograd does not."""
+    hwc, N, S = (10, 10, 1), 3, 2
+    spec = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), 7, S=S, num_data=200, seed=13, white=white, conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5, base_kernel="acos")
+    X, Y = syn.make_batch(hwc, N, seed=13)
+    zs = syn.make_noise(spec, N, seed=13)
+    ref = oracle_model(spec, X, Y)
+    with torch.no_grad():
+        e_t, _ = _torch_elbo(spec, X, Y, zs)
+    e_o = ref.compute_log_likelihood(X, Y, zs=zs)
+    assert abs(e_t.item() - e_o) <= 1e-9 * abs(e_o), (e_t.item(), e_o)
