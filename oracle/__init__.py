@@ -33,7 +33,8 @@ needs the reference -- but it does pin the FORMULAS recalled in SURVEY App. A:
   RobustMax prob_is_largest,    Monte-Carlo orthant probabilities / E_q[log p(y|f)] / class
     variational_expectations,     probabilities, 1e6 draws
     predict_mean_and_var
-  conditional(), SVGP_Layer     torch.linalg dense closed form k - k^T K^-1 k + k^T K^-1 S K^-1 k, both whitenings; KL against K_uu
+  conditional(), SVGP_Layer     torch.linalg dense closed form k - k^T K^-1 k + k^T K^-1 S K^-1 k, both whitenings, full_cov=True (per-patch N x N
+                                covariance) included; KL against K_uu
   reparameterize, ELBO assembly torch algebra; sum_n mean_s E * num_data / N - sum_l KL_l from those pieces
   the hand-written reverse pass   torch autograd (CPU, float64) of an independently written textbook forward -- unfold patches,
     (oracle/grad.py), and the       cholesky_solve, Gaussian closed-form KL, RobustMax quadrature -- ELBO to 1e-10, every gradient entry of

@@ -170,6 +170,35 @@ def test_conv_conditional_against_torch_closed_form(white):
 
 
 @pytest.mark.parametrize("white", [False, True])
+def test_conv_conditional_full_cov_against_torch_closed_form(white):
+    """conditional(full_cov=True) (conv_gp/conditionals.py:36-38,62-63 in the per-patch form its comments declare): for every patch and output the
+    N x N covariance  K_ff - K_fu K^-1 K_uf + K_fu K^-1 S K^-1 K_uf  by dense torch.linalg solves; its diagonal is the full_cov=False variance."""
+    rng = np.random.default_rng(15 + white)
+    P, M, N, R = 2, 6, 5, 2
+    Z = rng.standard_normal((M, 4))
+    Xp = rng.standard_normal((P, N, 4))
+    k = RBF(4, 1.3, 1.6)
+    Kmm = k.K(Z) + JITTER * np.eye(M)
+    Kmn = np.stack([k.K(Z, Xp[p]) for p in range(P)])
+    Kff = np.stack([k.K(Xp[p]) for p in range(P)])
+    q_mu = rng.standard_normal((M, R))
+    q_sqrt = np.stack([np.linalg.cholesky(_spd(rng, M)) for _ in range(R)]) * 0.4
+    mean, var = conditional(Kmn, Kmm, Kff, q_mu, full_cov=True, q_sqrt=q_sqrt, white=white)
+    assert mean.shape == (N, P, R) and var.shape == (R, P, N, N)
+    _, var_diag = conditional(Kmn, Kmm, np.stack([k.Kdiag(Xp[p]) for p in range(P)]), q_mu, q_sqrt=q_sqrt, white=white)
+    Kt, St = T(Kmm), T(q_sqrt).tril() @ T(q_sqrt).tril().transpose(-1, -2)
+    if white:
+        Lt = torch.linalg.cholesky(Kt)
+        St = Lt @ St @ Lt.T
+    for p in range(P):
+        B = torch.linalg.solve(Kt, T(Kmn[p]))                                   # K^-1 K_uf
+        for r in range(R):
+            want = T(Kff[p]) - T(Kmn[p]).T @ B + B.T @ St[r] @ B
+            np.testing.assert_allclose(var[r, p], want.numpy(), rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(np.diag(var[r, p]), var_diag[r, p], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("white", [False, True])
 def test_svgp_layer_against_torch_closed_form(white):
     """SVGP_Layer.conditional_ND (models.py:192-198) with the ConvKernel: Kuu = Kzz + jitter I, Kuf = Kzx, Kdiag; KL against K_uu."""
     from torch.distributions import MultivariateNormal, kl_divergence
