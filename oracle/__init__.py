@@ -36,6 +36,7 @@ needs the reference -- but it does pin the FORMULAS recalled in SURVEY App. A:
   conditional(), SVGP_Layer     torch.linalg dense closed form k - k^T K^-1 k + k^T K^-1 S K^-1 k, both whitenings, full_cov=True (per-patch N x N
                                 covariance) included; KL against K_uu
   reparameterize, ELBO assembly torch algebra; sum_n mean_s E * num_data / N - sum_l KL_l from those pieces
+  NatGrad step (natgrad_ref)    theta <- theta + gamma dL/d eta with dL/d eta by torch autograd through eta -> (mu, S) -> chol(S)
   the hand-written reverse pass   torch autograd (CPU, float64) of an independently written textbook forward -- unfold patches,
     (oracle/grad.py), and the       cholesky_solve, Gaussian closed-form KL, RobustMax quadrature -- ELBO to 1e-10, every gradient entry of
     whole forward value             every layer to 1e-9: conv / additive / dense RBF(ARD) heads, Conv2dMean, three layers with a stride-2 first one, both

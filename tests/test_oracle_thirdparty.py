@@ -246,3 +246,43 @@ def test_reparameterize_and_elbo_assembly_against_torch():
     ve = MultiClass(10).variational_expectations(m1, v1, np.tile(Y, S)).reshape(S, N)
     want_elbo = ve.mean(0).sum() * 123.0 / N - sum(l.KL() for l in model.layers)
     assert abs(elbo - want_elbo) <= 1e-12 * abs(want_elbo), (elbo, want_elbo)
+
+
+def test_natgrad_reference_against_torch_autograd():
+    """The natural-gradient step the device NatGrad is checked against (tests/natgrad_ref.py, Salimbeni et al. 2018: theta <- theta + gamma dL/d eta
+    in natural / expectation parameters) with dL/d eta taken by torch autograd through eta -> (mu, S) -> chol(S), for an arbitrary smooth objective
+    of (mu, tril(L)) -- the reference's step uses the gradients with respect to (mu, L) and the Cholesky adjoint written out by hand."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from natgrad_ref import natgrad_reference
+    rng = np.random.default_rng(31)
+    M, R, gamma = 5, 2, 0.07
+    mu = rng.standard_normal((M, R))
+    Lq = np.stack([np.linalg.cholesky(_spd(rng, M)) for _ in range(R)])
+    a, Bm, Cm = rng.standard_normal((M, R)), _spd(rng, M), rng.standard_normal((R, M, M))
+
+    def objective(mu_t, L_t):   # any smooth function of (mu, lower triangle of L)
+        Ll = L_t.tril()
+        return (T(a) * mu_t).sum() - 0.5 * torch.einsum("mr,mk,kr->", mu_t, T(Bm), mu_t) + (T(Cm) * Ll).sum() \
+            + torch.log(torch.diagonal(Ll, dim1=1, dim2=2) ** 2).sum() - 0.3 * (Ll @ Ll.transpose(1, 2)).diagonal(dim1=1, dim2=2).sum()
+
+    mu_t, L_t = T(mu).requires_grad_(True), T(Lq).requires_grad_(True)
+    g_mu, g_L = torch.autograd.grad(objective(mu_t, L_t), [mu_t, L_t])
+    new_mu, new_L = natgrad_reference(mu, Lq, g_mu.numpy(), np.tril(g_L.numpy()), gamma)
+    for r in range(R):
+        S = Lq[r] @ Lq[r].T
+        eta1 = T(mu[:, r]).requires_grad_(True)
+        eta2 = T(S + np.outer(mu[:, r], mu[:, r])).requires_grad_(True)
+        m_of = eta1
+        S_of = 0.5 * (eta2 + eta2.T) - torch.outer(eta1, eta1)
+        L_of = torch.linalg.cholesky(S_of)
+        mu_all = torch.stack([m_of if q == r else T(mu[:, q]) for q in range(R)], 1)
+        L_all = torch.stack([L_of if q == r else T(Lq[q]) for q in range(R)], 0)
+        d1, d2 = torch.autograd.grad(objective(mu_all, L_all), [eta1, eta2])
+        Sinv = np.linalg.inv(S)
+        theta1 = Sinv @ mu[:, r] + gamma * d1.numpy()
+        theta2 = -0.5 * Sinv + gamma * d2.numpy()
+        S_new = np.linalg.inv(-2.0 * theta2)
+        np.testing.assert_allclose(new_mu[:, r], S_new @ theta1, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(new_L[r] @ new_L[r].T, S_new, rtol=1e-9, atol=1e-11)
