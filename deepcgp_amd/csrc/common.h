@@ -35,6 +35,7 @@ struct DcgpOptions {
   long no_fused_layer = 0;       // conv layers by the sweep + GEMM route even where the one-launch layer kernel covers them
   long fused_large = 0;          // the one-launch layer kernel also for M > 256 (narrower strips; measured slower there)
   long fused_shape = -1;         // force one strip shape of the one-launch layer kernel (-1: chosen from the layer)
+  long fused_split = -1;         // strips of the layer kernel's partial last round shared by this many workgroups (-1: chosen, 0 / 1: never)
   long kl_side = 0;              // KL terms by their own launches on the side stream instead of inside the tail launch
   long no_fused_bwd = 0;         // reverse pass of the conditional by GEMM launches instead of the strip kernel
   long fused_bwd_min_cols = -1;  // strip kernel of the reverse pass from this many columns on (-1: default 4096)
@@ -72,6 +73,7 @@ struct ChainEpoch { unsigned epoch = 0; int T = 0, np = 0, batch = 0; };   // la
 
 struct dcgp_ctx {
   int device = 0;
+  int n_cus = 256;   // compute units of the device (set at dcgp_ctx_create)
   hipStream_t stream = nullptr;    // the stream launches go to (temporarily swapped to stream2 for the side branch)
   hipStream_t stream2 = nullptr;   // side stream: factorisation chain + KL terms
   // CU partition for steps in flight (dcgp_elbo_forward_enqueue): the data path of step i on 30 CUs of every XCD, the

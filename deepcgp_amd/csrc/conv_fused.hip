@@ -62,7 +62,15 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
   double* aux = smem + a.lds_main;                       // images of the strip; after phase 1: [TW][BN] partial sums of A1^2
   double* xn = aux + a.lds_img;                          // [BN] |x_p|^2
   int* koff = reinterpret_cast<int*>(xn + BN);           // [Lp]
-  const int j0 = blockIdx.x * BN;
+  // strips of the launch's partial last round are shared by SQ workgroups: each runs phases 0 - 2 and the outputs r = sq, sq + SQ, ...
+  int sidx = blockIdx.x, sq = 0, SQ = 1;
+  if (sidx >= a.split_first) {
+    const int t = sidx - a.split_first;
+    SQ = a.split_q;
+    sidx = a.split_first + t / SQ;
+    sq = t - (sidx - a.split_first) * SQ;
+  }
+  const int j0 = sidx * BN;
   const int jmax = a.Kc - 1;
   CF_TR(0)
   if (a.trace && lane == 0 && blockIdx.x % 90 == 0 && blockIdx.x / 90 < 8) a.trace[((blockIdx.x / 90) * 16 + wave) * 16 + 10] = (long long)wall_clock64();
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
       if (j <= jmax) out[(long)m * a.ldk + j] = strip[m * BN + ((((c >> 4) ^ (m & (FN - 1))) << 4) | (c & 15))];
     }
   };
-  if (a.Kuf_out) store_strip(a.Kuf_out);
+  if (a.Kuf_out && sq == 0) store_strip(a.Kuf_out);
 
   // ---- the A-operand stream ---------------------------------------------------------------------------------------
   // lane (lrow, lcol) of k-substep q of k-tile kt needs Wt[kt*16 + 4q + lrow][16 f + lcol]: per-lane byte offset voff[q],
@@ -336,9 +344,9 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
   }
   __syncthreads();   // A1 published
   CF_TR(5)
-  if (a.A1_out) store_strip(a.A1_out);
+  if (a.A1_out && sq == 0) store_strip(a.A1_out);
 
-  // ---- phase 3: T_r = G_r^T A1 for r = sp, sp + NS, ... (upper-triangular W: fragment f needs k-tiles f .. nf-1): one flat
+  // ---- phase 3: T_r = G_r^T A1 for r = r0, r0 + rstep, ... (r0 = sp, rstep = NS for a whole strip) (upper-triangular W: fragment f needs k-tiles f .. nf-1): one flat
   // stream over (r, fragment, k-tile), all FN column fragments.  s2 of this wave's i-th output is parked in the lanes with
   // lrow == (i & 3) of keep[i >> 2][.]
   constexpr int KEEP = (16 / NS + 3) / 4;
@@ -372,7 +380,8 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
     ldb(kt_next, 0, b0);
     mf(w[3], b1);
   };
-  const int nr = (R - sp + NS - 1) / NS;   // outputs of this team
+  const int r0 = sq + SQ * sp, rstep = SQ * NS;
+  const int nr = r0 < R ? (R - 1 - r0) / rstep + 1 : 0;   // outputs of this team
   if (a.G && nfw > 0 && nr > 0) {
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.G), 0, R * Mp * Mp * 8, 0x00020000);
     int steps_per_r = 0;
@@ -380,14 +389,14 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
     const int total = nr * steps_per_r;
     // load cursor / compute cursor over the flat sequence of (r, fragment c, k-tile); the load cursor stops on the last tile
     const int f0 = frag_of(wm, TW, 0);
-    int lr = sp, lc = 0, lf = f0, lk = f0, lleft = total - 1;
+    int lr = r0, lc = 0, lf = f0, lk = f0, lleft = total - 1;
     int ci = 0, cc = 0, ck = f0, cleft = total - 1;
     auto lsoff = [&]() { return ((lr * Mp + lk * 16) * Mp + 16 * lf) * 8; };
     auto ladv = [&]() {
       if (lleft > 0) {
         --lleft;
         if (++lk >= nf) {
-          if (++lc == nfw) { lc = 0; lr += NS; }
+          if (++lc == nfw) { lc = 0; lr += rstep; }
           lf = frag_of(wm, TW, lc);
           lk = lf;
         }
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
     const int c = y * 16 + lcol;
 #pragma unroll
     for (int i = 0; i < KEEP; ++i) {
-      const int r = sp + NS * (4 * i + lrow);
+      const int r = r0 + rstep * (4 * i + lrow);
       if (r < R) s2p[(wm * R + r) * BN + c] = keep[i][y];
     }
   }
@@ -500,7 +509,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
   for (int idx = tid; idx < BN * R; idx += NT) {
     const int c = idx / R, r = idx - c * R;
     const int j = j0 + c;
-    if (j > jmax) continue;
+    if (j > jmax || (SQ > 1 && r % SQ != sq)) continue;
     double s1 = 0.0, s2 = 0.0, m = 0.0;
     for (int w = 0; w < TW; ++w) {
       s1 += s1p[w * BN + c];
@@ -541,7 +550,8 @@ constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 template <int FN, int NS, int MAXF, int NT>
 int launch_fused(dcgp_ctx* ctx, const ConvFusedArgs& a, size_t lds) {
   const int BN = FN * 16;
-  const unsigned grid = (unsigned)((a.Kc + BN - 1) / BN);
+  const long strips = ((long)a.Kc + BN - 1) / BN;
+  const unsigned grid = (unsigned)(a.split_q > 1 ? a.split_first + (strips - a.split_first) * a.split_q : strips);
   static bool attr_done[64] = {};   // per device: a second ctx on another device of this process needs the opt-in too
   const int dv = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
   if (!attr_done[dv]) {   // more than 64 KB of dynamic LDS needs the opt-in
@@ -555,7 +565,32 @@ int launch_fused(dcgp_ctx* ctx, const ConvFusedArgs& a, size_t lds) {
   return DCGP_OK;
 }
 
-struct FusedPlan { int shape; size_t lds; int lds_main, lds_img; };
+struct FusedPlan { int shape; size_t lds; int lds_main, lds_img; int split_q; };
+
+// The partial last round.  A 1024-thread strip owns its CU, so `strips` workgroups take ceil(strips / CUs) strip times and the last round
+// leaves CUs idle.  Where they are enough, its strips are shared by Q workgroups each: every one of them runs the sweep and the first product
+// (~0.11 of a strip, `kFront`) and the outputs r = q, q + Q, ... of the R-batched product, whose teams take them in turn -- a part costs
+// kFront + (1 - kFront) * (outputs of its busiest team) / (outputs of a whole strip's busiest team).  Returns the last round's cost in strip
+// times (1 unshared) and the Q to use.  Measured on shards of the headline batch (tools/shape_try.py): 90 strips of 64 columns 198 -> 118 us
+// with Q = 2, 360 strips of 32 columns on 16 waves 215 -> 174 us; the full batch (720 strips, 208 in the last round) has no CUs to share with.
+double last_round(const dcgp_ctx* ctx, const FusedShape& sh, long strips, int R, bool has_g, int* q_out) {
+  *q_out = 1;
+  const long want = ctx->opt.fused_split;
+  const int slots = ctx->n_cus > 0 ? ctx->n_cus : 256;
+  const long rem = strips % slots;
+  if (rem == 0) return 0.0;
+  if (want == 0 || want == 1 || sh.NT != 1024 || !has_g || R < 2) return 1.0;
+  constexpr double kFront = 0.11;
+  const int whole = (R + sh.NS - 1) / sh.NS;
+  const long qmax = slots / rem < R ? slots / rem : R;
+  double best = 0.9;   // a split must save a tenth of a strip time to be worth its extra sweeps
+  for (int q = 2; q <= qmax; ++q) {
+    const int part = ((R + q - 1) / q + sh.NS - 1) / sh.NS;
+    const double cost = kFront + (1.0 - kFront) * part / whole;
+    if ((want > 1 && q <= want) || (want < 0 && cost < best - 1e-9)) { best = cost; *q_out = q; }
+  }
+  return *q_out > 1 ? best : 1.0;
+}
 
 // the first instantiated shape (widest strip, most waves) that covers Mp and whose LDS footprint fits
 bool plan_fused(const dcgp_ctx* ctx, const ConvFusedArgs& a, FusedPlan* p) {
@@ -590,11 +625,14 @@ bool plan_fused(const dcgp_ctx* ctx, const ConvFusedArgs& a, FusedPlan* p) {
     // shape 7 (32 columns on 16 waves, the outputs split over two teams): a strip's latency is what a launch of one round costs, and
     // the second team shortens it (a 4-image shard of the headline batch: 0.297 -> 0.290 ms per step); over several rounds the eight-wave
     // form's two strips per CU do better (8 images: 0.398 against 0.384)
-    if (i == 7 && force < 0 && strips > 256) continue;
-    const double cost = (double)((strips + 255) / 256) * BN * (i == 7 ? 0.97 : (sh.FN == 4 ? 1.0 : (sh.FN == 2 ? 1.03 : 1.06)));
+    if (i == 7 && force < 0 && strips > 512) continue;
+    int q = 1;
+    const int slots = ctx->n_cus > 0 ? ctx->n_cus : 256;
+    const double rounds = sh.NT == 1024 ? (double)(strips / slots) + last_round(ctx, sh, strips, a.R, a.G != nullptr, &q) : (double)((strips + 255) / 256);
+    const double cost = rounds * BN * (i == 7 ? 0.97 : (sh.FN == 4 ? 1.0 : (sh.FN == 2 ? 1.03 : 1.12)));
     if (found && cost >= best) continue;
     found = true; best = cost;
-    p->shape = i; p->lds = (size_t)bytes; p->lds_main = (int)main_d; p->lds_img = (int)img_d;
+    p->shape = i; p->lds = (size_t)bytes; p->lds_main = (int)main_d; p->lds_img = (int)img_d; p->split_q = q;
   }
   return found;
 }
@@ -622,6 +660,11 @@ int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a_in) {
   ConvFusedArgs a = a_in;
   a.lds_main = p.lds_main; a.lds_img = p.lds_img;
   a.trace = ctx->fused_trace;
+  if (p.split_q > 1 && !a.trace) {
+    const long strips = ((long)a.Kc + kShapes[p.shape].FN * 16 - 1) / (kShapes[p.shape].FN * 16);
+    a.split_q = p.split_q;
+    a.split_first = (int)(strips - strips % (ctx->n_cus > 0 ? ctx->n_cus : 256));
+  }
   ScopedTimer t(ctx, "conv_fused");
 #ifdef DCGP_EXPERIMENTS
   const int abl = (int)ctx->opt.fused_abl;   // timing build only (make EXPERIMENTS=1): wrong results

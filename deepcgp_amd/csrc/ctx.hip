@@ -20,7 +20,7 @@ int ctx_fail(dcgp_ctx* ctx, int code, const char* fmt, ...) {
 namespace {
 struct OptSlot { const char* name; long DcgpOptions::*field; };
 const OptSlot kOptSlots[] = {
-    {"no_fused_layer", &DcgpOptions::no_fused_layer}, {"fused_large", &DcgpOptions::fused_large}, {"fused_shape", &DcgpOptions::fused_shape},
+    {"no_fused_layer", &DcgpOptions::no_fused_layer}, {"fused_large", &DcgpOptions::fused_large}, {"fused_shape", &DcgpOptions::fused_shape}, {"fused_split", &DcgpOptions::fused_split},
     {"kl_side", &DcgpOptions::kl_side}, {"no_fused_bwd", &DcgpOptions::no_fused_bwd}, {"fused_bwd_min_cols", &DcgpOptions::fused_bwd_min_cols},
     {"fused_bwd_frags", &DcgpOptions::fused_bwd_frags}, {"grad_late_kl", &DcgpOptions::grad_late_kl}, {"gemm_tile", &DcgpOptions::gemm_tile}, {"grad_no_keep_k", &DcgpOptions::grad_no_keep_k},
     {"head_unfused", &DcgpOptions::head_unfused}, {"no_side_stream", &DcgpOptions::no_side_stream}, {"cu_partition", &DcgpOptions::cu_partition},
@@ -164,6 +164,10 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return DCGP_ERR_HIP;
   dcgp_ctx* c = new dcgp_ctx();
   c->device = device;
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cus = ncu;
+  }
   options_from_env(&c->opt);
   c->no_side = c->opt.no_side_stream != 0;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||

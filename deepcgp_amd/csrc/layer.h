@@ -113,6 +113,7 @@ struct ConvFusedArgs {
   int idm = 0;
   double *Kuf_out = nullptr, *A1_out = nullptr; long ldk = 0;   // training step: k-major [Mp][ldk] copies for the reverse pass
   int lds_main = 0, lds_img = 0;                           // set by the launcher
+  int split_first = 1 << 30, split_q = 1;                  // set by the launcher: strips >= split_first are shared by split_q workgroups (outputs r = q, q + split_q, ...)
   long long* trace = nullptr;                              // debugging aid: phase timestamps (dcgp_debug_set_fused_trace)
 };
 // the reverse pass of the same strip (conv_bwd_fused.hip): dK_uf = inv(L)^T [sum_r (S_r A1) o (2 gv_r) + alpha gm^T - 2 A1 o gvs]

@@ -383,6 +383,33 @@ def test_every_fused_strip_shape(ctx, shape, M, N):
     close(smp, smp_u, 1e-10, "sample, shape %d" % shape)
 
 
+@pytest.mark.parametrize("shape", [0, 7])
+@pytest.mark.parametrize("split", [2, 3, 4, 7])
+@pytest.mark.parametrize("M,N,R", [(70, 3, 10), (256, 2, 10), (96, 2, 3)])
+def test_fused_strip_shared_by_workgroups(ctx, shape, split, M, N, R):
+    """The strips of the layer kernel's partial last round are shared by `fused_split` workgroups (each runs the sweep and the first product
+    and the outputs r = q, q + Q, ... of the R-batched product): every output is computed by the same instructions on the same operands as
+    in the whole-strip launch, so the result is bit-identical."""
+    from deepcgp_amd.kernels import RBF, PatchInducingFeatures
+    from deepcgp_amd.layers import ConvLayer
+    from deepcgp_amd.views import FullView
+    rng = np.random.default_rng(5 + M + split)
+    H, W, C, f, s = 28, 28, 1, 5, 2
+    X = rng.standard_normal((N, H * W * C))
+    v = FullView((H, W), f, C, s)
+    Z, q_mu, q_sqrt = rand_spd_inputs(rng, M, R, v.patch_length, scale=0.05)
+    Z *= 1.5
+    layer = ConvLayer(RBF(v.patch_length, 5.0, 5.0), None, PatchInducingFeatures(Z), v, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
+    z = rng.standard_normal((N, layer.num_outputs))
+    with ctx.options(fused_shape=shape, fused_split=0):
+        smp_w, mean_w, var_w = layer._forward(X, z)
+    with ctx.options(fused_shape=shape, fused_split=split):
+        smp, mean, var = layer._forward(X, z)
+    np.testing.assert_array_equal(mean, mean_w)
+    np.testing.assert_array_equal(var, var_w)
+    np.testing.assert_array_equal(smp, smp_w)
+
+
 def test_conv_layer_identity_mean(ctx):
     from deepcgp_amd.kernels import RBF, PatchInducingFeatures
     from deepcgp_amd.layers import ConvLayer
