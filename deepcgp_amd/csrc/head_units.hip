@@ -63,6 +63,11 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
   constexpr int WPG = NT / 64;   // units (waves) per workgroup
   constexpr bool RES = NK4 > 0;
   constexpr int NKR = RES ? NK4 : 1;
+  // L = 25 (<7, 1>): the k slots are dealt so that lane group lrow walks the CONTIGUOUS patch elements 5 lrow .. 5 lrow + 4 in sub-steps 0 .. 4
+  // (f * C is 5 or 25: five consecutive elements never straddle a patch row), then elements 20 + lrow (sub-step 5) and 24 / the norm slots
+  // (sub-step 6, as before).  The gathers of sub-steps 1 .. 4 are then `ds_read_b64 ... offset: 8 s` on the address of sub-step 0 -- no
+  // address arithmetic: 16 of the ~90 VALU instructions of a tile.  The Z operand is read in the same order (ldz below).
+  constexpr bool PERM = NK4 == 7 && TL == 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int HWC = a.HWC, L = a.L, nk4 = RES ? NK4 : a.Lq >> 2, nfp = a.nfp, P = a.P, np16 = nfp * 16;
   const int HWCe = (HWC + 1) & ~1;
@@ -200,8 +205,16 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
   int kob[NKR];   // RES: byte offsets of this lane's patch elements, all sub-steps (0 for the slots behind the patch)
   if (RES) {
 #pragma unroll
-    for (int s = 0; s < NKR; ++s) kob[s] = koff[4 * s + lrow];
+    for (int s = 0; s < NKR; ++s) kob[s] = (PERM && s < 5) ? koff[5 * lrow] + 8 * s : koff[4 * s + lrow];
   }
+  const int kd5 = PERM ? kob[NKR > 5 ? 5 : 0] - kob[0] : 0, kd6 = PERM ? kob[NKR > 6 ? 6 : 0] - kob[0] : 0;
+  // pbx(fragment): the LDS byte address of this lane's sub-step-0 element of its patch (PERM: kob[0] folded in); ld0 / ldB: the gathers
+  auto pbx = [&](int frag) { const int p0 = pbl[16 * frag + lcol]; return PERM ? p0 + kob[0] : p0; };
+  auto ld0 = [&](int pbv) { return PERM ? ldi(pbv) : ldi(pbv + (RES ? kob[0] : koff[lrow])); };
+  auto ldB = [&](int pbv, int s) {   // RES only; s is a compile-time constant after unrolling
+    if (PERM) return s < 5 ? ldi(pbv + 8 * s) : ldi(pbv + (s == 5 ? kd5 : kd6));
+    return ldi(pbv + kob[RES ? s : 0]);
+  };
   auto fixB = [&](double v, int s, double nrm) {   // s >= sL (wave-uniform test at the call site)
     const int ts = s - sL;
     const double t0 = ts ? tB_real[1] : tB_real[0], t1 = ts ? tB_nrm[1] : tB_nrm[0], t2 = ts ? tB_one[1] : tB_one[0];
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
         double bn[NY];
         if (s + 1 < NKR) {
 #pragma unroll
-          for (int y = 0; y < NY; ++y) bn[y] = ldi(pb[y] + kob[s + 1]);
+          for (int y = 0; y < NY; ++y) bn[y] = ldB(pb[y], s + 1);
         }
         HU_SB1;
         const double av = getA(s);
@@ -312,12 +325,11 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
 #pragma unroll
     for (int y = 0; y < NY; ++y) wc[y] = WRITE ? 0.0 : wl[16 * (j0 + y) + lcol];
     if (nyn > 0) {
-      const int ko0 = RES ? kob[0] : koff[lrow];
 #pragma unroll
       for (int y = 0; y < 4; ++y) {
         if (y < nyn) {
-          pb[y] = pbl[16 * (next_j0 + y) + lcol];
-          bv[y] = ldi(pb[y] + ko0);
+          pb[y] = pbx(next_j0 + y);
+          bv[y] = ld0(pb[y]);
         }
       }
     }
@@ -391,11 +403,10 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
     const int nfull = (j_hi - j_lo) >> 2, nrem = (j_hi - j_lo) & 3;
     int pb[4];
     double bv[4];
-    const int ko0 = RES ? kob[0] : koff[lrow];
     int j0 = j_lo;
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
-      if (y < (nfull ? 4 : nrem)) { pb[y] = pbl[16 * (j0 + y) + lcol]; bv[y] = ldi(pb[y] + ko0); }
+      if (y < (nfull ? 4 : nrem)) { pb[y] = pbx(j0 + y); bv[y] = ld0(pb[y]); }
     }
     for (int g = 0; g < nfull; ++g, j0 += 4) group(T4{}, getA, getA_raw, j0, j0 + 4, g + 1 < nfull ? 4 : nrem, g == 0 ? rdiag : nullptr, rsum, pb, bv);
     double* rd = nfull == 0 ? rdiag : nullptr;
@@ -410,7 +421,6 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
   // 15 x 15 views) every segment straddles two cache lines whose halves are then written back separately: 4.0 instead of 6.0 TB/s in a
   // pure store kernel (tools/store_bw.hip, tile_rep_jr against tile_rep).
   auto row_pass_hold = [&](auto&& getA, auto&& getA_raw, int j_lo, int j_hi) {
-    const int ko0 = RES ? kob[0] : koff[lrow];
     double dummy[4] = {0.0, 0.0, 0.0, 0.0};
     for (int jb = j_lo; jb < j_hi; jb += 8) {
       const int nb = min(8, j_hi - jb), n0 = min(nb, 4), n1 = nb - n0;
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
       double bv[4];
 #pragma unroll
       for (int y = 0; y < 4; ++y) {
-        if (y < n0) { pb[y] = pbl[16 * (jb + y) + lcol]; bv[y] = ldi(pb[y] + ko0); }
+        if (y < n0) { pb[y] = pbx(jb + y); bv[y] = ld0(pb[y]); }
       }
       if (n0 == 4) group(T4{}, getA, getA_raw, jb, jb + 4, n1, keep, dummy, pb, bv);
       else if (n0 == 3) group(T3{}, getA, getA_raw, jb, -1, 0, keep, dummy, pb, bv);
@@ -462,7 +472,11 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
     // quarter-rate 64-bit multiply-adds: ~11 % of the loop's issue slots at L = 250)
     const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.ZS), 0, a.Lq * a.Mp * 8, 0x00020000);
     const int zvo = (lrow * a.Mp + 16 * ur + lcol) * 8, zstep = 4 * a.Mp * 8;
-    auto ldz = [&](int sub) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrs, zvo, sub * zstep, 0)); };
+    const int zvp = (5 * lrow * a.Mp + 16 * ur + lcol) * 8;   // PERM: rows 5 lrow + s of ZS in sub-steps 0 .. 4
+    auto ldz = [&](int sub) {
+      if (PERM && sub < 5) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrs, zvp, sub * a.Mp * 8, 0));
+      return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrs, zvo, sub * zstep, 0));
+    };
     double rsum[4] = {0.0, 0.0, 0.0, 0.0};
     if (WRITE) {
       st_rs = __builtin_amdgcn_make_buffer_rsrc(a.kuf + ((long)(16 * ur) * a.sM + (long)n * a.sN), 0, 0x7fffffff, 0x00020000);
