@@ -63,11 +63,13 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
   constexpr int WPG = NT / 64;   // units (waves) per workgroup
   constexpr bool RES = NK4 > 0;
   constexpr int NKR = RES ? NK4 : 1;
-  // L = 25 (<7, 1>): the k slots are dealt so that lane group lrow walks the CONTIGUOUS patch elements 5 lrow .. 5 lrow + 4 in sub-steps 0 .. 4
-  // (f * C is 5 or 25: five consecutive elements never straddle a patch row), then elements 20 + lrow (sub-step 5) and 24 / the norm slots
-  // (sub-step 6, as before).  The gathers of sub-steps 1 .. 4 are then `ds_read_b64 ... offset: 8 s` on the address of sub-step 0 -- no
-  // address arithmetic: 16 of the ~90 VALU instructions of a tile.  The Z operand is read in the same order (ldz below).
-  constexpr bool PERM = NK4 == 7 && TL == 1;
+  // Register-resident forms: the k slots are dealt so that lane group lrow walks RL CONTIGUOUS patch elements RL lrow .. RL lrow + RL - 1 in
+  // sub-steps 0 .. RL - 1 (L = 25: RL = 5, f * C is 5 or 25; L = 16: RL = 4; L = 48: RL = 12 -- RL consecutive elements never straddle a patch
+  // row), then what is left in the old order (L = 25: elements 20 + lrow in sub-step 5, 24 and the norm slots in sub-step 6).  The gathers of
+  // sub-steps 1 .. RL - 1 are then `ds_read_b64 ... offset: 8 s` on the address of sub-step 0 -- no address arithmetic (L = 25: 16 of the ~90
+  // VALU instructions of a tile).  The Z operand is read in the same order (ldz below).
+  constexpr int RL = (NK4 == 7 && TL == 1) ? 5 : ((NK4 == 5 && TL == 0) ? 4 : ((NK4 == 13 && TL == 0) ? 12 : 0));
+  constexpr bool PERM = RL > 0;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int HWC = a.HWC, L = a.L, nk4 = RES ? NK4 : a.Lq >> 2, nfp = a.nfp, P = a.P, np16 = nfp * 16;
   const int HWCe = (HWC + 1) & ~1;
@@ -205,14 +207,19 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
   int kob[NKR];   // RES: byte offsets of this lane's patch elements, all sub-steps (0 for the slots behind the patch)
   if (RES) {
 #pragma unroll
-    for (int s = 0; s < NKR; ++s) kob[s] = (PERM && s < 5) ? koff[5 * lrow] + 8 * s : koff[4 * s + lrow];
+    for (int s = 0; s < NKR; ++s) kob[s] = (PERM && s < RL) ? koff[RL * lrow] + 8 * s : koff[4 * s + lrow];
   }
-  const int kd5 = PERM ? kob[NKR > 5 ? 5 : 0] - kob[0] : 0, kd6 = PERM ? kob[NKR > 6 ? 6 : 0] - kob[0] : 0;
+  int kdel[2] = {0, 0};   // PERM: the one or two sub-steps behind the runs, relative to sub-step 0
+  if (PERM) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) kdel[q] = RL + q < NKR ? kob[RL + q < NKR ? RL + q : 0] - kob[0] : 0;
+  }
+  static_assert(!PERM || NKR - RL <= 2, "at most two sub-steps behind the runs");
   // pbx(fragment): the LDS byte address of this lane's sub-step-0 element of its patch (PERM: kob[0] folded in); ld0 / ldB: the gathers
   auto pbx = [&](int frag) { const int p0 = pbl[16 * frag + lcol]; return PERM ? p0 + kob[0] : p0; };
   auto ld0 = [&](int pbv) { return PERM ? ldi(pbv) : ldi(pbv + (RES ? kob[0] : koff[lrow])); };
   auto ldB = [&](int pbv, int s) {   // RES only; s is a compile-time constant after unrolling
-    if (PERM) return s < 5 ? ldi(pbv + 8 * s) : ldi(pbv + (s == 5 ? kd5 : kd6));
+    if (PERM) return s < RL ? ldi(pbv + 8 * s) : ldi(pbv + kdel[s - RL < 1 ? 0 : 1]);
     return ldi(pbv + kob[RES ? s : 0]);
   };
   auto fixB = [&](double v, int s, double nrm) {   // s >= sL (wave-uniform test at the call site)
@@ -472,9 +479,9 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
     // quarter-rate 64-bit multiply-adds: ~11 % of the loop's issue slots at L = 250)
     const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.ZS), 0, a.Lq * a.Mp * 8, 0x00020000);
     const int zvo = (lrow * a.Mp + 16 * ur + lcol) * 8, zstep = 4 * a.Mp * 8;
-    const int zvp = (5 * lrow * a.Mp + 16 * ur + lcol) * 8;   // PERM: rows 5 lrow + s of ZS in sub-steps 0 .. 4
+    const int zvp = (RL * lrow * a.Mp + 16 * ur + lcol) * 8;   // PERM: rows RL lrow + s of ZS in sub-steps 0 .. RL - 1
     auto ldz = [&](int sub) {
-      if (PERM && sub < 5) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrs, zvp, sub * a.Mp * 8, 0));
+      if (PERM && sub < RL) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrs, zvp, sub * a.Mp * 8, 0));
       return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrs, zvo, sub * zstep, 0));
     };
     double rsum[4] = {0.0, 0.0, 0.0, 0.0};
