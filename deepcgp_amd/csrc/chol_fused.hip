@@ -30,24 +30,14 @@ __device__ long long g_chol_trace[64 * 32];
 
 namespace {
 
-// factor + inverse of a diagonal block held in LDS: two 16-column panels + MFMA block work (chol_dev.h); DCGP_POTRF32 (compile time):
-// the single 32-column recurrence it replaced
-__device__ __forceinline__ int potrf_inv32(double (*D)[NB + 1], double (*Xs)[NB + 1], double (&col)[2 * NB], double (*Tp)[17], int lane) {
-#ifdef DCGP_POTRF32
-  double v[NB];
-#pragma unroll
-  for (int c = 0; c < NB; ++c) v[c] = (lane < NB) ? D[lane][c] : ((c == lane - NB) ? 1.0 : 0.0);
-  const int fail = wave_potrf_inv32(v, lane, col);
-  if (lane < NB) {
-#pragma unroll
-    for (int c = 0; c < NB; ++c) D[lane][c] = (c <= lane) ? v[c] : 0.0;
-  } else {
-#pragma unroll
-    for (int r = 0; r < NB; ++r) Xs[r][lane - NB] = v[r];
-  }
-  return fail;
+// factor + inverse of a diagonal block held in LDS (chol_dev.h): two 16 x 16 blocks in the halves layout + MFMA block work (round 5;
+// tools/diag_bench.hip: 3.6 us against 5.1 for the two 16-column panels of round 3, DCGP_POTRF_PANELS at compile time).  col: 96 doubles.
+constexpr int COL_N = 96;
+__device__ __forceinline__ int potrf_inv32(double (*D)[NB + 1], double (*Xs)[NB + 1], double (&col)[COL_N], double (*Tp)[17], int lane) {
+#ifdef DCGP_POTRF_PANELS
+  return wave_potrf_inv32_2x16(D, Xs, reinterpret_cast<double (&)[64]>(col), Tp, lane);
 #else
-  return wave_potrf_inv32_2x16(D, Xs, col, Tp, lane);
+  return potrf_inv32_halves<NB + 1>(D, Xs, col, Tp, lane);
 #endif
 }
 
@@ -150,7 +140,7 @@ __device__ __forceinline__ void panel_store(double (*U)[NB + 1], int wm, int wn,
 
 __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   __shared__ double D[NB][NB + 1];
-  __shared__ double col[2 * NB];
+  __shared__ __attribute__((aligned(16))) double col[COL_N];
   __shared__ double Ui[64][NB + 1];
   __shared__ double UcTs[64 * (NB + 1)];   // trailing tiles: second panel row block; inverse tiles: the Y tile
   __shared__ double Xs[NB][NB + 1];   // inv(L_jj)
@@ -674,7 +664,7 @@ __device__ __forceinline__ void pc_tile(const RlArgs& a, int b, int bx, int j, i
 
 struct PcLds {
   double D[NB][NB + 1];
-  double col[2 * NB];
+  __attribute__((aligned(16))) double col[COL_N];
   double Ui[64][NB + 1];
   double UcTs[64 * (NB + 1)];
   double Xs[NB][NB + 1];
@@ -684,7 +674,7 @@ struct PcLds {
 template <int SC>
 __device__ __forceinline__ void pc_run(const PcArgs& p, const int b, const int role, PcLds& sh) {
   double (&D)[NB][NB + 1] = sh.D;
-  double (&col)[2 * NB] = sh.col;
+  double (&col)[COL_N] = sh.col;
   double (*Ui)[NB + 1] = sh.Ui;
   double* UcTs = sh.UcTs;
   double (*Xs)[NB + 1] = sh.Xs;

@@ -3,6 +3,7 @@
 // per-GPU data term; KL terms are replicated and computed redundantly.
 // librccl is dlopen()ed on first use so that libdcgp.so loads on hosts without it.
 #include <dlfcn.h>
+#include <mutex>
 #include <unistd.h>
 
 #include <cstdio>
@@ -57,8 +58,12 @@ bool rccl_load() {
 // RCCL announces itself with printf ("RCCL version : ...", four lines) the first time a communicator is set up.  A library must not write
 // to its host's stdout (bench.py's contract is ONE JSON line there, and C stdio flushes the banner at exit, BEHIND that line): while an
 // RCCL set-up call runs, file descriptor 1 points at stderr.
+// Side effect, documented in include/dcgp.h: for the duration of the set-up call OTHER host threads' writes to fd 1 land on stderr too.
+// The swap is serialised process-wide (two contexts initialising concurrently would otherwise restore each other's descriptor).
+std::mutex g_fd_mutex;
 struct StdoutToStderr {
   int saved = -1;
+  std::lock_guard<std::mutex> lock{g_fd_mutex};
   StdoutToStderr() {
     fflush(stdout);
     saved = dup(1);

@@ -1427,7 +1427,11 @@ int grad_kl_early(dcgp_model* m, bool enqueue, bool wait_fork) {
   // a stream of its own: on the side stream these ~40 launches (slow beside the forward pass's kernels) were still in front of the head's side
   // chain when the reverse pass got there
   hipStream_t es = ctx->stream_aux;
-  if (wait_fork) HIP_TRY(ctx, hipStreamWaitEvent(es, ctx->ev_fork, 0));
+  if (wait_fork) {
+    HIP_TRY(ctx, hipStreamWaitEvent(es, ctx->ev_fork, 0));
+    // (the mark may sit on the main stream behind layer 0 while G / alpha of the later layers are still being written on the chain's stream)
+    for (int li = 0; li < m->gkl_prep_wait && li < nl; ++li) HIP_TRY(ctx, hipStreamWaitEvent(es, m->ev_prep[m->bank][li], 0));
+  }
   ctx->stream = es;
   const std::string mp = "m" + std::to_string(m->id) + "_";
   int rc = DCGP_OK;

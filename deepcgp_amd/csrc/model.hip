@@ -155,8 +155,10 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   const int nl = (int)m->layers.size();
   if (nl > 8) return ctx_fail(ctx, DCGP_ERR_ARG, "at most 8 layers supported");
   // a local batch that overran its declared shard would draw the noise of the NEXT sample's images (the counters are laid out by the
-  // un-sharded batch): correlated samples, not an error anyone would see
-  if (m->shard_global > 0 && (long)m->shard_lo + N > m->shard_global)
+  // un-sharded batch): correlated samples, not an error anyone would see.  Only the ELBO / gradient paths (need_kl) are bound by the
+  // declared training shard: propagate / predict_y take any batch (an AccuracyLogger's batches on rank 3 of 4), their counter layout
+  // does not matter
+  if (need_kl && m->shard_global > 0 && (long)m->shard_lo + N > m->shard_global)
     return ctx_fail(ctx, DCGP_ERR_ARG, "forward: %d images from image %d on overrun the declared global batch of %d (dcgp_model_set_shard)", N,
                     m->shard_lo, m->shard_global);
   DCGP_TRY(ensure_events(m));
@@ -353,6 +355,9 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   // (a first layer of a few thousand patch columns -- the de-duplicated batch -- leaves half the chip idle: there the mark is here, behind the chain)
   const bool mark_behind_first = (long)rows0 * m->layers[0]->v.P >= 8192;
   if (m->gkl_state && !mark_behind_first) HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, chain_s));
+  // with the chain on a side stream a mark on the MAIN stream orders layer 0's operands only: grad_kl_early also waits for the G / alpha
+  // of the other layers (cond_prep of whitened / M > 256 layers runs behind ev_prep[0] on that stream)
+  m->gkl_prep_wait = (m->gkl_state && mark_behind_first && chain_s != main_s) ? nl : 0;
 
   // sweeps read Z^T / |z|^2 of this bank (a one-launch first layer waits for its G / alpha, recorded behind them on the same stream)
   if (chain_s != main_s && !first_fused) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_sweep[bank], 0));

@@ -13,6 +13,7 @@ struct dcgp_model {
   bool keep_state = false;   // the forward leaves K_uf / A1 of every conv layer in HBM (set around the forward of dcgp_elbo_grad)
   bool grad_follows = false; // set around the forward of dcgp_elbo_grad: forward_all hands the parameter-only part of the reverse pass to the side stream
   int gkl_state = 0;         // forward_all of such a step: 0 nothing to hand over, 1 the side stream itself holds the parameter-only chain, 2 it waits for ctx->ev_fork
+  int gkl_prep_wait = 0;     // forward_all: grad_kl_early must also wait for ev_prep[bank][0 .. gkl_prep_wait) (chain on a side stream, mark on the main stream)
   int prep_early[8] = {};    // per layer: bit 0 its zero fills, G^T and the factor's lower triangle, bit 1 S_r = G_r G_r^T were enqueued by grad_kl_early
   bool kl_early[8] = {};     // per layer: grad_kl_early enqueued its kl_products for the step in flight (consumed by model_backward)
   int adam_t = 0;        // Adam steps taken on this model's moment buffers (bias correction; dcgp_model_adam_step with t = 0)

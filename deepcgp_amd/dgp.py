@@ -62,9 +62,21 @@ class DGP_Base:
     def _ptr(self, a):
         return np.ascontiguousarray(a, np.float64).ctypes.data
 
+    def _check_means(self):
+        """Every model-level call: the mean functions the device model was built with must still be the ones on the layers (a
+        Conv2dMean whose conv_filter was changed afterwards would run as the centre-pixel mean at the model level and through its
+        generic __call__ at the layer level -- a silent disagreement)."""
+        for li, l in enumerate(self.layers[:-1]):
+            now = (bool(l.identity_mean), getattr(l, "generic_mean", None) is not None)
+            if now != self._built_means[li]:
+                raise ValueError("layer %d: mean function changed after the device model was built (identity_mean %r -> %r, generic "
+                                 "%r -> %r); build a new model" % (li, self._built_means[li][0], now[0], self._built_means[li][1], now[1]))
+
     def _build(self):
         if self._model is not None:
+            self._check_means()
             return
+        self._built_means = [(bool(l.identity_mean), getattr(l, "generic_mean", None) is not None) for l in self.layers[:-1]]
         ctx = self._ctx = dev.get_context()
         L = dev.lib()
         h = C.c_void_p()

@@ -66,3 +66,12 @@ class FullView(View):
     def extract_patches_PNL(self, NHWC_X):
         """patch_count x N x patch_length (conv_gp/views.py:40-44)."""
         return self._extract(NHWC_X, True)
+
+
+class RandomPartialView(View):
+    """Name kept so that ``from views import FullView, RandomPartialView`` (conv_gp/models.py:10) resolves under the flat shim.
+    The view itself (a random subset of patches, conv_gp/views.py:70-124) is outside this build's scope: it is
+    never constructed by ``ModelBuilder``'s flags; constructing it says so."""
+
+    def __init__(self, input_size, filter_size, feature_maps, patch_count):
+        raise NotImplementedError("RandomPartialView is out of scope of the MI355X path (no reference flag selects it); use FullView")

@@ -306,6 +306,9 @@ int dcgp_kmeans(dcgp_ctx* ctx, const double* X, long n, int d, int k, const int3
                 double tol, double* centers, int* iters_out);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------ */
+/* Side effect of the two set-up calls below: RCCL prints a version banner to stdout the first time; while the call runs the process's
+ * file descriptor 1 points at stderr (so for that window other host threads' stdout lands there too).  The swap is serialised
+ * process-wide. */
 int dcgp_comm_unique_id(unsigned char* out_128bytes);
 int dcgp_comm_init_rank(dcgp_ctx* ctx, int nranks, int rank, const unsigned char* id_128bytes);
 int dcgp_comm_destroy(dcgp_ctx* ctx);

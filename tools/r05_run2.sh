@@ -1,0 +1,3 @@
+export TMPDIR=/tmp; mkdir -p gpurun_out
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I deepcgp_amd/csrc -I tools tools/diag_bench.hip -o /tmp/diag_bench 2>/dev/null && /tmp/diag_bench > gpurun_out/r05_diag_bench.txt 2>&1
+cat gpurun_out/r05_diag_bench.txt
