@@ -22,8 +22,8 @@ using namespace chol_dev;
 #ifdef CHOL_TRACE
 __device__ long long g_chol_trace[64 * 32];
 #define TR(k)                                                                                              \
-  if (tid == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                    \
-    g_chol_trace[(a.j / NB) * 32 + (blockIdx.x == 0 ? 0 : 16) + (k)] = wall_clock64();
+  if (tid == 0 && b == 0 && (bx == 0 || bx == a.gx_trace - 1))                                             \
+    g_chol_trace[(a.j / NB) * 32 + (bx == 0 ? 0 : 16) + (k)] = wall_clock64();
 #else
 #define TR(k)
 #endif
@@ -58,6 +58,23 @@ struct RlArgs {
   const double* Xin = nullptr;
   double* Xnext = nullptr;
   int la_idx = -1;
+  // Right-hand sides riding the chain (round 5): G_r = inv(L) Lq_r and alpha = inv(L) q_mu -- the conditional's small operands, one launch
+  // of their own until now (prep_solve, 13 us behind the last panel) -- by block forward substitution ONE PANEL BEHIND the factorisation:
+  // launch jp applies panel p = jp - 1, whose rows of L (Lout) and inverse diagonal block (Xall slot p) the previous launch left in memory;
+  // the last launch also applies the last panel.  Workgroups [rhs_base, ...) of a launch: (right-hand side q, 32-column tile ct, row tile rt).
+  const ChainRhs* rhs = nullptr;   // per matrix of the batch
+  const double* Xall = nullptr;    // [np][batch][2][NB][NB]: factor and inverse of every diagonal block (slot 0 written by launch 0's first workgroup)
+  double* Xself = nullptr;         // launch 0: where its first workgroup leaves block 0 (slot 0 of Xall)
+  int rhs_base = 0, rhs_p = -1, rhs_last = 0, rhs_nt = 0, rhs_nq = 0, rhs_tpw = 1, batch = 0, np = 0;
+  // XCD isolation (iso_per > 0: 1-D grid).  Workgroup i of a launch runs on XCD i % 8.  fp64 MFMAs of ANY wave hold a SIMD for 64 cycles
+  // during which no other wave's VALU instruction issues there -- wave priorities do not help -- and the look-ahead workgroup's
+  // recurrence is one issue-bound wave: with the right-hand sides' ~700 workgroups in the launch, three to a CU, every panel launch took
+  // 1.3 us longer.  So the look-ahead workgroups of all matrices sit alone on one XCD and every other tile on the seven others (right-hand
+  // sides first: the longest).  Which XCD: workgroups of XCD 7 start 0.7 us before those of XCD 0 (stamps of the first instruction: a launch's
+  // look-ahead workgroups ended +8.2-8.9 us after its first workgroup on XCD 7, +9.0-10.5 on XCD 0 or 3).
+  int iso_per = 0;
+  int gx_trace = 0;
+
 };
 
 // Accesses to data another workgroup of the SAME launch wrote or will read (chol_persist_kernel) are relaxed atomics of agent
@@ -138,6 +155,196 @@ __device__ __forceinline__ void panel_store(double (*U)[NB + 1], int wm, int wn,
     for (int v = 0; v < 4; ++v) U[wm * 32 + x * 16 + lrow + 4 * v][wn * 16 + lcol] = p[x][v];
 }
 
+
+// ---- right-hand sides riding the chain (RlArgs::rhs): workgroup `idx` of the launch's right-hand-side part ----
+// Item (q, ct, g): right-hand side q (q < R: Lq_q, lower triangular; q == R: q_mu), columns [32 ct, 32 ct + 32), row group g.  Every item forms
+// Ynew = inv(L_pp) Y_p (the 32 x 32 block of the lagged panel p: 8 MFMAs a wave, cheaper than waiting for another workgroup); group 0 stores
+// it (final rows of G_q / alpha) and its sum of squares; group g then updates the 64-row tiles 2g and 2g + 1 below, Y -= L[rows, p] Ynew.
+// (Two row tiles per workgroup: with one, a launch carried ~700 workgroups against 672-768 resident slots, and the few that had to wait for
+// a slot made every panel launch 1.4 us longer; the dispatcher also needs ~10 ns per workgroup.)  In the LAST launch the row tile that holds the
+// last panel's rows goes on to make them final with the inverse block this launch was handed, and one more item per right-hand side
+// (ct == p + 1: the diagonal block of Lq, first touched by the last panel) does only that.  Values a panel touches first come from the
+// right-hand side itself, later ones from the scratch Yw.  The item on the diagonal also writes the structural zeros to the right of its
+// final rows, so G needs no clearing.
+__device__ __forceinline__ void rhs_tile(const RlArgs& a, const int b, const int idx, double (*D)[NB + 1], double (*Xs)[NB + 1], double (&col)[COL_N],
+                                         double (*Tp)[17], double (*Ui)[NB + 1], double* UcTs) {
+  double (*Ts)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(UcTs);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane >> 4, lcol = lane & 15;
+  const ChainRhs d = a.rhs[b];
+  const int Mp = a.Mp, ld = a.ld, np = a.np, p = a.rhs_p;
+  // decode: R blocks of rhs_nq items (Lq_q), then alpha's
+  const int tpw = a.rhs_tpw, ng = a.rhs_nt > 0 ? (a.rhs_nt + tpw - 1) / tpw : 1;   // row tiles per workgroup (1 or 2), row groups
+  int q, ct, g;
+  bool final_only = false;
+  if (idx < d.R * a.rhs_nq) {
+    q = idx / a.rhs_nq;
+    const int rem = idx % a.rhs_nq;
+    if (p >= 0 && rem < (p + 1) * ng) { ct = rem / ng; g = rem % ng; }
+    else { ct = p + 1; g = 0; final_only = true; }                     // (only enumerated in the last launch)
+  } else {
+    const int rem = idx - d.R * a.rhs_nq;
+    q = d.R; ct = 0; g = rem;
+    if (p < 0) { if (rem != 0 || !a.rhs_last) return; final_only = true; }
+    else if (rem >= ng) return;
+  }
+  const bool is_alpha = q == d.R;
+  const double* __restrict__ B = is_alpha ? d.qmu : (d.Lq ? d.Lq + (long)q * Mp * ld : nullptr);
+  if (!B) return;
+  const int ldb = is_alpha ? d.Rp : ld, ncol = is_alpha ? d.Rp : Mp, c0 = ct * 32;
+  if (c0 >= ncol) return;
+  const bool lagged = !final_only;
+  const int j = 32 * (p < 0 ? 0 : p);
+  double* __restrict__ Yq = d.Yw + (long)(is_alpha ? d.R : q) * Mp * ld;          // (alpha's scratch behind the R matrices; its rows are ldb wide)
+  double* __restrict__ Cq = is_alpha ? d.alpha : (d.G ? d.G + (long)q * Mp * ld : nullptr);
+  double* __restrict__ sq = d.sums + (long)q * (np * (np + 1) / 2);
+  const double* __restrict__ Lout = a.Lout + (long)b * Mp * ld;
+  const int jl = 32 * (np - 1), nbl = Mp - jl;                                     // the last panel
+  const int r0[2] = {j + 32 + 64 * tpw * g, j + 32 + 64 * tpw * g + 64};            // this group's row tiles
+  const bool live[2] = {lagged && r0[0] < Mp, lagged && tpw == 2 && r0[1] < Mp};
+  const bool cont = live[0] && a.rhs_last && g == 0;                               // the first row tile holds the last panel's rows (r0 == jl)
+  const bool have_x = a.Xin != nullptr;
+
+  // ---- every global read, in one latency ----
+  double tx[NB * NB / 256], tl[NB * NB / 256], tt[NB * NB / 256], tu[2][64 * NB / 256], old[2][2][4];
+#pragma unroll
+  for (int e = 0; e < NB * NB / 256; ++e) { tx[e] = 0.0; tl[e] = 0.0; }
+  if (lagged) {
+    const double* __restrict__ xp = a.Xall + ((long)p * a.batch + b) * 2 * NB * NB + NB * NB;
+#pragma unroll
+    for (int e = 0; e < NB * NB / 256; ++e) tx[e] = xp[tid + e * 256];
+  }
+  if ((cont || final_only) && have_x) {
+    const double* __restrict__ xl = a.Xin + (long)b * 2 * NB * NB + NB * NB;
+#pragma unroll
+    for (int e = 0; e < NB * NB / 256; ++e) tl[e] = xl[tid + e * 256];
+  }
+  {
+    const bool first = final_only || (is_alpha ? p == 0 : ct == p);
+    const double* __restrict__ src = first ? B : Yq;
+    const int jr = final_only ? jl : j;
+#pragma unroll
+    for (int e = 0; e < NB * NB / 256; ++e) {
+      const int i2 = tid + e * 256, qr = i2 >> 5, c = i2 & 31;
+      tt[e] = (jr + qr < Mp && c0 + c < ncol) ? src[(long)(jr + qr) * ldb + c0 + c] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int i = r0[t] + 16 * wave + lrow + 4 * v, gc = c0 + 16 * y + lcol;
+          old[t][y][v] = (live[t] && i < Mp && gc < ncol) ? src[(long)i * ldb + gc] : 0.0;
+        }
+#pragma unroll
+      for (int e = 0; e < 64 * NB / 256; ++e) {
+        const int i2 = tid + e * 256, i = i2 / NB, c = i2 % NB;
+        tu[t][e] = (live[t] && r0[t] + i < Mp) ? Lout[(long)(r0[t] + i) * ld + j + c] : 0.0;
+      }
+    }
+  }
+  if (final_only && !have_x) load_diag(a.A[b], ld, 0, min(NB, Mp), D, tid);   // one-panel matrix: this launch factors it, every workgroup for itself
+  else {
+#pragma unroll
+    for (int e = 0; e < NB * NB / 256; ++e) { const int i2 = tid + e * 256; D[i2 / NB][i2 % NB] = tx[e]; }
+  }
+  if (have_x) {
+#pragma unroll
+    for (int e = 0; e < NB * NB / 256; ++e) { const int i2 = tid + e * 256; Xs[i2 / NB][i2 % NB] = tl[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < NB * NB / 256; ++e) { const int i2 = tid + e * 256; Ts[i2 >> 5][i2 & 31] = tt[e]; }
+  if (live[0]) {
+#pragma unroll
+    for (int e = 0; e < 64 * NB / 256; ++e) { const int i2 = tid + e * 256; Ui[i2 / NB][i2 % NB] = tu[0][e]; }
+  }
+  __syncthreads();
+  if (final_only && !have_x) {
+    if (tid < 64) potrf_inv32(D, Xs, col, Tp, tid);
+    __syncthreads();
+  }
+
+  // Ts (32 x 32) <- Xm Ts: wave w owns the 16 x 16 block (w >> 1, w & 1)
+  auto ynew = [&](const double (*Xm)[NB + 1]) {
+    const int bm = wave >> 1, bn = wave & 1;
+    d4 y = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < NB; kk += 4) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Xm[bm * 16 + lcol][kk + lrow], Ts[kk + lrow][bn * 16 + lcol], y, 0, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Ts[bm * 16 + lrow + 4 * v][bn * 16 + lcol] = y[v];
+    __syncthreads();
+  };
+  // rows [jr, jr + nbr) of the result are final: store, zeros to the right of a diagonal tile, sum of squares -> slot
+  auto finish = [&](int jr, int nbr, int pc) {
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < NB * NB / 256; ++e) {
+      const int i2 = tid + e * 256, qr = i2 >> 5, c = i2 & 31;
+      if (qr < nbr && c0 + c < ncol) {
+        const double x = Ts[qr][c];
+        s = fma(x, x, s);
+        if (Cq) Cq[(long)(jr + qr) * ldb + c0 + c] = x;
+      }
+    }
+    if (Cq && !is_alpha && ct == pc) {
+      const int z0 = 32 * (pc + 1), zw = Mp - z0;
+      for (int i2 = tid; i2 < nbr * zw; i2 += 256) Cq[(long)(jr + i2 / zw) * ldb + z0 + i2 % zw] = 0.0;
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    if (lane == 0) col[wave] = s;
+    __syncthreads();
+    if (tid == 0) sq[is_alpha ? pc : pc * (pc + 1) / 2 + ct] = (col[0] + col[1]) + (col[2] + col[3]);
+  };
+
+  if (final_only) {
+    ynew(Xs);
+    finish(jl, nbl, np - 1);
+    return;
+  }
+  ynew(D);
+  if (g == 0) finish(j, NB, p);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (!live[t]) break;
+    if (t == 1) {   // the second tile's rows of L waited in registers
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 64 * NB / 256; ++e) { const int i2 = tid + e * 256; Ui[i2 / NB][i2 % NB] = tu[1][e]; }
+      __syncthreads();
+    }
+    d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int kk = 0; kk < NB; kk += 4) {
+      const double av = Ui[16 * wave + lcol][kk + lrow];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Ts[kk + lrow][16 * y + lcol], acc[y], 0, 0, 0);
+    }
+    if (t == 0 && cont) {
+      // the last panel's rows, updated through panel p: final with this launch's inverse block
+      __syncthreads();
+      if (wave < 2) {
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) Ts[16 * wave + lrow + 4 * v][16 * y + lcol] = old[0][y][v] - acc[y][v];
+      }
+      __syncthreads();
+      ynew(Xs);
+      finish(jl, nbl, np - 1);
+      return;
+    }
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int i = r0[t] + 16 * wave + lrow + 4 * v, gc = c0 + 16 * y + lcol;
+        if (i < Mp && gc < ncol) Yq[(long)i * ldb + gc] = old[t][y][v] - acc[y][v];
+      }
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   __shared__ double D[NB][NB + 1];
   __shared__ __attribute__((aligned(16))) double col[COL_N];
@@ -150,8 +357,34 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   static_assert(NB * 65 <= 64 * (NB + 1), "Y tile fits the shared slot");
   // the chain is latency: when it shares CUs with a throughput kernel (the head sweep of a head-first model, the previous step's layer
   // kernel with steps in flight) its waves go first in the issue arbitration
-  __builtin_amdgcn_s_setprio(3);
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the look-ahead workgroup is the launch's critical path and issue-bound: the other workgroups of the chain sharing its SIMDs yield to it)
+  int b = blockIdx.y, bx = blockIdx.x;
+  if (a.iso_per > 0) {
+    const int lin = blockIdx.x, slot = lin >> 3;
+    const int xcd = (lin + 1) & 7;   // (XCD 7 reads as 0: see iso_per)
+    if (xcd == 0) {
+      if (slot >= a.batch || a.la_idx < 0) return;
+      b = slot; bx = a.la_idx;
+    } else {
+      // the right-hand sides first (the longest workgroups beside the look-ahead ones), then the trailing / inverse tiles
+      const int item = slot * 7 + xcd - 1, nla = a.la_idx >= 0 ? 1 : 0;
+      const int rhs_per = a.rhs ? a.iso_per + nla - a.rhs_base : 0, chain_per = a.iso_per - rhs_per;
+      if (item < a.batch * rhs_per) { b = item / rhs_per; bx = a.rhs_base + item % rhs_per; }
+      else {
+        const int it = item - a.batch * rhs_per;
+        if (it >= a.batch * chain_per) return;
+        b = it / chain_per; bx = it % chain_per;
+        if (nla && bx >= a.la_idx) ++bx;
+      }
+    }
+  }
+  if (bx == a.la_idx) __builtin_amdgcn_s_setprio(3);
+  else __builtin_amdgcn_s_setprio(2);
+  if (a.rhs && bx >= a.rhs_base) {   // a right-hand side riding the chain
+    rhs_tile(a, b, bx - a.rhs_base, D, Xs, col, Tp, Ui, UcTs);
+    return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, lrow = lane >> 4, lcol = lane & 15;
   const int Mp = a.Mp, ld = a.ld, j = a.j, nb = min(NB, Mp - j);
   double* __restrict__ A = a.A[b];
@@ -162,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   // ---- prologue: every global read of this workgroup is issued here, in one latency ----
   TR(0)
   const bool have_x = a.Xin != nullptr;
-  const bool is_la = (int)blockIdx.x == a.la_idx;
+  const bool is_la = bx == a.la_idx;
   if (have_x) {   // factor and inverse of this panel's diagonal block: left by the previous launch's look-ahead workgroup
     const double* __restrict__ xin = a.Xin + (long)b * 2 * NB * NB;
     double t[2 * NB * NB / 256];
@@ -177,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
     load_diag(A, ld, j, nb, D, tid);
   }
   const bool only_diag = a.nT == 0 && a.nct == 0 && !is_la;
-  const bool is_trailing = (int)blockIdx.x < a.nT;
+  const bool is_trailing = bx < a.nT;
   int ti = 0, tc = 0, rt = -1, ct = 0;
   double old[2][2][4];   // values the final read-modify-write subtracts from
 #pragma unroll
@@ -198,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
       if (r < nbn && c < nbn && c <= r) la_d[e] = A[(long)(jn + r) * ld + jn + c];
     }
   } else if (is_trailing) {
-    int pair = blockIdx.x;
+    int pair = bx;
     while (pair >= a.nt - tc) {   // column-major enumeration of the lower triangle: tc <= ti
       pair -= a.nt - tc;
       ++tc;
@@ -217,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
           if (i < Mp && jj < Mp && jj <= i) old[x][y][v] = A[(long)i * ld + jj];
         }
   } else {
-    const int yy = blockIdx.x - a.nT;
+    const int yy = bx - a.nT;
     rt = yy / a.nct - 1;   // -1: the panel's own row block, else row tile below
     ct = yy % a.nct;
     const int c0 = ct * 64;
@@ -257,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
     const int fail = potrf_inv32(D, Xs, col, Tp, tid);
     fail_j = fail;
     // (with a look-ahead workgroup in the launch it is the one writer of the status word: it sees this panel's failure too)
-    if (tid == 0 && blockIdx.x == 0 && a.la_idx < 0 && (j == 0 || (fail && a.info[b] == 0))) a.info[b] = fail ? j + fail : 0;
+    if (tid == 0 && bx == 0 && a.la_idx < 0 && (j == 0 || (fail && a.info[b] == 0))) a.info[b] = fail ? j + fail : 0;
   }
   __syncthreads();
   TR(2)
@@ -316,10 +549,14 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
     TR(5)
     return;
   }
-  if (blockIdx.x == 0 && !have_x) {   // publish L_jj (final; with Xin the previous launch's look-ahead workgroup already has)
+  if (bx == 0 && !have_x) {   // publish L_jj (final; with Xin the previous launch's look-ahead workgroup already has)
     for (int idx = tid; idx < nb * nb; idx += 256) {
       const int r = idx / nb, c = idx % nb;
       Lout[(long)(j + r) * ld + j + c] = D[r][c];
+    }
+    if (a.Xself) {   // ... and block 0 with its inverse where the right-hand sides of the next launch read them
+      double* __restrict__ xs = a.Xself + (long)b * 2 * NB * NB;
+      for (int idx = tid; idx < NB * NB; idx += 256) { xs[idx] = D[idx / NB][idx % NB]; xs[NB * NB + idx] = Xs[idx / NB][idx % NB]; }
     }
   }
   if (only_diag) return;
@@ -822,9 +1059,15 @@ __global__ void chol_finish_kernel(double* const* __restrict__ Ap, const double*
 }  // namespace
 
 // Cholesky factor in place (strict upper triangle zeroed) and, when d_Linv != nullptr, inv(L) (+ its transpose).
+// right-hand sides ride the plain panel-per-launch chain with its look-ahead (the A/B routes -- one launch, no look-ahead, captured graph -- do not carry them)
+bool chain_can_ride(const dcgp_ctx* ctx, int Mp) {
+  return Mp <= kChainRhsMaxMp && !ctx->opt.chol_one_launch && !ctx->opt.chol_no_lookahead && !ctx->opt.chain_graph && !ctx->opt.no_rhs_ride;
+}
+
 int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_Linv, double* const* d_LinvT, int batch,
-                           int Mp, int ld, int* d_info, bool defer_finish) {
+                           int Mp, int ld, int* d_info, bool defer_finish, const ChainRhs* d_rhs, int max_R) {
   if (batch <= 0) return DCGP_OK;
+  if (d_rhs && (!d_Linv || !chain_can_ride(ctx, Mp))) return ctx_fail(ctx, DCGP_ERR_ARG, "factorisation chain: right-hand sides cannot ride this route");
   ScopedTimer t(ctx, "factor_chain");
   const size_t mm = (size_t)Mp * ld;
   double* Lout = (double*)ws_get(ctx, "chol_Lout" + ctx->ws_tag, (size_t)batch * mm * sizeof(double));
@@ -909,13 +1152,37 @@ int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_L
     a.nct = d_Linv ? (min(j + NB, Mp) + 63) / 64 : 0;
     const int nY = d_Linv ? (1 + a.nt) * a.nct : 0;
     int gx = a.nT + nY;
+    const int jp = j / NB;
     if (Xla) {
-      const int jp = j / NB;
       const size_t slot = (size_t)batch * 2 * NB * NB;
       if (jp > 0) a.Xin = Xla + (size_t)jp * slot;
       if (jp + 1 < np_la) { a.Xnext = Xla + (size_t)(jp + 1) * slot; a.la_idx = gx; ++gx; }
     }
+    if (d_rhs) {   // the right-hand sides: panel jp - 1 here, and the last panel too in the last launch
+      const bool last = jp == np_la - 1;
+      a.batch = batch; a.np = np_la; a.Xall = Xla;
+      if (jp == 0 && Xla) a.Xself = Xla;
+      if (jp > 0 || last) {
+        a.rhs = d_rhs; a.rhs_p = jp - 1; a.rhs_last = last ? 1 : 0;
+        const int below_p = jp > 0 ? Mp - NB * jp : 0;                 // rows below the lagged panel
+        a.rhs_nt = below_p > 0 ? (below_p + 63) / 64 : 0;
+        // one 64-row tile per workgroup while the launch stays inside the resident slots (~400 beside the chain's own tiles), else two
+        const long w1 = (long)batch * (max_R * jp + 1) * (a.rhs_nt > 0 ? a.rhs_nt : 1);
+        a.rhs_tpw = w1 > 400 ? 2 : 1;
+        const int ng = a.rhs_nt > 0 ? (a.rhs_nt + a.rhs_tpw - 1) / a.rhs_tpw : 1;   // row groups (rhs_tile)
+        a.rhs_nq = jp * ng + (last ? 1 : 0);                           // items per Lq_q: (column tile <= jp - 1, group), + the last panel's diagonal tile
+        a.rhs_base = gx > 0 ? gx : 1;
+        gx = a.rhs_base + max_R * a.rhs_nq + (jp > 0 ? ng : 1);        // ... + alpha's
+      }
+    }
     // gx == 0: last panel of a plain potrf -- only L_jj is left; one workgroup factors and publishes it
+    a.gx_trace = gx > 0 ? gx : 1;
+    if (Xla && !ctx->opt.chain_no_iso) {   // the look-ahead workgroups alone on one XCD (RlArgs::iso_per)
+      a.batch = batch;
+      a.iso_per = (gx > 0 ? gx : 1) - (a.la_idx >= 0 ? 1 : 0);
+      const int items = batch * a.iso_per, slots = (items + 6) / 7;
+      hipLaunchKernelGGL(chol_rl_kernel, dim3(8 * (slots > batch ? slots : batch)), dim3(256), 0, ctx->stream, a);
+    } else
     hipLaunchKernelGGL(chol_rl_kernel, dim3(gx > 0 ? gx : 1, batch), dim3(256), 0, ctx->stream, a);
     if (!capturing) LAUNCH_CHECK(ctx);
   }

@@ -53,6 +53,8 @@ struct DcgpOptions {
   long no_early_sweep = 0;       // the first layer's sweep enqueued behind the chain instead of in front of it
   long sync_event = 0;           // wait for the step's event instead of polling its completion word
   long chain_graph = 0;          // the factorisation chain's panel launches replayed from a captured HIP graph (measured slower: see chol_fused.hip)
+  long chain_no_iso = 0;         // chain launches that carry right-hand sides: no XCD isolation of the look-ahead workgroups (A/B)
+  long no_rhs_ride = 0;          // G / alpha by their own launch behind the chain (prep_solve) instead of riding its panel launches
   long kuf_upw = 0;              // units per wave of the storing sweep (0: chosen by head_units_plan)
   long kuf_split = -1;           // storing sweep with replicas: column-fragment ranges per row fragment (-1: chosen; 0: one)
   long kuf_wpg = 0;              // storing sweep: waves per workgroup (0: chosen by head_units_plan; 1, 2, 4)
@@ -352,9 +354,20 @@ int potrf_batched(dcgp_ctx* ctx, double* const* d_ptrs, double** h_ptrs, int bat
                   int* d_info);   // d_info[b] = 0 or 1-based failing column
 int trtri_batched(dcgp_ctx* ctx, double* const* d_L, double* const* d_Linv, double* const* d_LinvT,
                   int batch, int Mp, int ld);
-// left-looking fused Cholesky (+ inverse of the factor when d_Linv != nullptr): one launch per 32-wide panel
+// Right-hand sides that ride the factorisation chain of one matrix (chol_fused.hip): G_r = inv(L) Lq_r (r < R; Lq lower triangular,
+// [R][Mp][Mp]) and alpha = inv(L) q_mu ([Mp][Rp], Rp = 16) by block forward substitution inside the panel launches.  G / alpha ==
+// nullptr: only the sums of squares are kept (the KL's trace / Mahalanobis terms with a prior factor).  sums: [(R + 1)][ns],
+// ns = np (np + 1) / 2, np = ceil(Mp / 32): slot p (p + 1) / 2 + ct of row r holds the 32 x 32 block (rows of panel p, column tile
+// ct <= p) of G_r, row R slot p the panel's rows of alpha.  Yw: scratch [R][Mp][Mp] + [Mp][Rp] (the rows not yet final).
+// Lq == nullptr && qmu == nullptr: nothing rides on this matrix.
+struct ChainRhs { const double* Lq; const double* qmu; double* G; double* alpha; double* sums; double* Yw; int R, Rp; };
+inline int chain_rhs_slots(int Mp) { const int np = (Mp + 31) / 32; return np * (np + 1) / 2; }
+constexpr int kChainRhsMaxMp = 256;   // beyond: the substitution's workgroups outgrow a panel launch (the generic GEMM route takes those layers)
+// left-looking fused Cholesky (+ inverse of the factor when d_Linv != nullptr): one launch per 32-wide panel.
+// d_rhs != nullptr (device array, one entry per matrix; max_R = the largest R among them): right-hand sides ride the chain.
 int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_Linv, double* const* d_LinvT, int batch,
-                           int Mp, int ld, int* d_info, bool defer_finish = false);
+                           int Mp, int ld, int* d_info, bool defer_finish = false, const ChainRhs* d_rhs = nullptr, int max_R = 0);
 int factor_finish_batched(dcgp_ctx* ctx, double* const* d_A, int batch, int Mp, int ld);
+bool chain_can_ride(const dcgp_ctx* ctx, int Mp);   // right-hand sides may ride the chain of a matrix of this size under the ctx's options
 int pad_copy(dcgp_ctx* ctx, const double* src, int rows, int cols, int lds, double* dst, int ldd, int rows_p,
              int cols_p, int mode, int batch, long src_batch, long dst_batch);   // mode 0 full, 1 lower-tri, 2: +I on pad diag

@@ -427,9 +427,9 @@ int kl_layer(dcgp_ctx* ctx, const GpMats& g, const double* Lp, const double* Lpi
   const double* sums = (g.klp && g.klp_valid && LpinvT == g.LinvT) ? g.klp : ((g.klpp && g.klpp_valid && LpinvT == g.LpinvT) ? g.klpp : nullptr);
   if (!white && sums) {
     // prep_solve left the sums of squares of inv(Lp) Lq_r and inv(Lp) q_mu (Lp = L for a layer without a prior of its own)
-    const int ns = Mp / 16;
+    const int ns = g.kl_ns > 0 ? g.kl_ns : Mp / 16;
     tp = const_cast<double*>(sums); tp_count = (long)R * ns;
-    ap = tp + (long)R * ns; ap_count = 1;
+    ap = tp + (long)R * ns; ap_count = g.kl_ns > 0 ? g.kl_nsa : 1;
   } else if (!white && g.prep_sums_valid && LpinvT == g.LinvT) {
     tp = g.prep_tp; tp_count = g.prep_tp_count;   // cond_prep's products left them (same launch stream: ordered behind them)
     ap = g.prep_ap; ap_count = g.prep_ap_count;

@@ -27,7 +27,7 @@ const OptSlot kOptSlots[] = {
     {"grad_nofork", &DcgpOptions::grad_nofork}, {"chol_one_launch", &DcgpOptions::chol_one_launch},
     {"chol_no_lookahead", &DcgpOptions::chol_no_lookahead}, {"head_no_overlap", &DcgpOptions::head_no_overlap},
     {"no_early_sweep", &DcgpOptions::no_early_sweep}, {"sync_event", &DcgpOptions::sync_event}, {"kuf_upw", &DcgpOptions::kuf_upw},
-    {"chain_graph", &DcgpOptions::chain_graph}, {"kuf_no_rep", &DcgpOptions::kuf_no_rep}, {"kuf_stream", &DcgpOptions::kuf_stream},
+    {"chain_graph", &DcgpOptions::chain_graph}, {"no_rhs_ride", &DcgpOptions::no_rhs_ride}, {"chain_no_iso", &DcgpOptions::chain_no_iso}, {"kuf_no_rep", &DcgpOptions::kuf_no_rep}, {"kuf_stream", &DcgpOptions::kuf_stream},
     {"kuf_wpg", &DcgpOptions::kuf_wpg}, {"kuf_split", &DcgpOptions::kuf_split}, {"head_tail", &DcgpOptions::head_tail},
     {"sweep_occ", &DcgpOptions::sweep_occ}, {"share_kb", &DcgpOptions::share_kb}, {"head_upw", &DcgpOptions::head_upw},
     {"fused_abl", &DcgpOptions::fused_abl}, {"rb_mixed", &DcgpOptions::rb_mixed},

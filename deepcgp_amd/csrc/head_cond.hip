@@ -291,18 +291,20 @@ int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, i
 }
 
 // G / alpha of up to 8 layers in one launch (replaces cond_prep for unwhitened layers with M <= 256)
-int prep_solve_all(dcgp_ctx* ctx, GpMats* const* gs, const int* white, const bool* have_qsqrt, int nl, bool* done) {
+int prep_solve_all(dcgp_ctx* ctx, GpMats* const* gs, const int* white, const bool* have_qsqrt, int nl, bool* done, const bool* skip) {
   PrepSolveArgs a;
   int any = 0, maxMp = 0, maxR = 0, ne = nl < 8 ? nl : 8;
   for (int i = 0; i < nl && i < 8; ++i) {
     const GpMats& g = *gs[i];
     PrepSolveLayer& l = a.l[i];
+    if (skip && skip[i]) { l.active = 0; continue; }   // G / alpha of this layer rode the factorisation chain (its flags are the caller's)
     l.active = (!white[i] && head_cond_fused_ok(g) && g.Rp == HC_BN) ? 1 : 0;
     done[i] = l.active != 0;
     l.LinvT = g.LinvT; l.Lq = have_qsqrt[i] ? g.Lq : nullptr; l.qmu = g.qmu; l.G = g.G; l.alpha = g.alpha;
     l.klp = (l.active && have_qsqrt[i]) ? g.klp : nullptr;
     gs[i]->klp_valid = l.klp != nullptr;
     gs[i]->klpp_valid = false;
+    gs[i]->kl_ns = gs[i]->kl_nsa = 0;
     l.Mp = g.Mp; l.R = g.R; l.Rp = g.Rp;
     if (l.active) { any = 1; maxMp = g.Mp > maxMp ? g.Mp : maxMp; maxR = g.R > maxR ? g.R : maxR; }
   }

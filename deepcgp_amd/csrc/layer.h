@@ -32,6 +32,8 @@ struct GpMats {
   double* klpp = nullptr;   // the same sums with the PRIOR factor inv(Lp) in place of inv(L) (layers with a prior Kuu(Z0)): nothing
                             // but the sums is kept of those products
   bool klpp_valid = false;
+  int kl_ns = 0, kl_nsa = 0;   // layout of klp / klpp: 0 = prep_solve's 16-column strips ([(R + 1)][Mp / 16], one alpha entry); else [(R + 1)][kl_ns] with
+                               // kl_nsa alpha entries (the right-hand sides rode the factorisation chain: chain_rhs_slots)
   // M > 256 (cond_prep's generic GEMMs): the same column sums of squares, per row block, from the G / alpha products' epilogues
   double* prep_tp = nullptr; long prep_tp_count = 0;   // [R][nrb][Mp] sums of squares of G
   double* prep_ap = nullptr; long prep_ap_count = 0;   // [nrb][Rp] of alpha
@@ -71,7 +73,7 @@ int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, i
                     double* out_mean, double* out_var, int kd_n = 1, double kd_scale = 1.0, double* A1_out = nullptr, long lda1 = 0);   // Knn[j] = kd_scale * sum_{i < kd_n} kd[j * kd_n + i]
 
 // head_cond.hip: G / alpha of every layer in one launch; done[i] = false where layer i still needs cond_prep
-int prep_solve_all(dcgp_ctx* ctx, GpMats* const* gs, const int* white, const bool* have_qsqrt, int nl, bool* done);
+int prep_solve_all(dcgp_ctx* ctx, GpMats* const* gs, const int* white, const bool* have_qsqrt, int nl, bool* done, const bool* skip = nullptr);
 
 struct FinalizeArgs {
   const double* s1p = nullptr; int nrb1 = 0;
@@ -155,7 +157,8 @@ struct TailArgs;   // tail_dev.h
 struct KlTailLayer {
   const double* Lfac = nullptr; long ldf = 0;   // the KL prior's Cholesky factor (diagonal read: log-determinant)
   const double* Lq = nullptr;                   // [R][Mp][Mp] (diagonal read)
-  const double* sums = nullptr;                 // [(R + 1)][Mp / 16] strip sums (GpMats::klp / klpp)
+  const double* sums = nullptr;                 // [(R + 1)][ns] partial sums of squares (GpMats::klp / klpp): rows r < R all ns, row R the first nsa
+  int ns = 0, nsa = 0;                          // 0: prep_solve's layout (ns = Mp / 16 strips, nsa = 1)
   int M = 0, Mp = 0, R = 0;
 };
 struct KlTail { int nl = 0; KlTailLayer l[8]; };

@@ -89,16 +89,18 @@ struct LayerState {
       if (!p) return ctx_fail(c, DCGP_ERR_ALLOC, "layer: device allocation failed");
     return DCGP_OK;
   }
+  // partial sums of squares per output: 16-column strips (prep_solve) or the chain's (panel, column tile) blocks, whichever is more
+  static size_t kl_slots(int Mp) { const int a = Mp / 16 + 1, c = chain_rhs_slots(Mp); return (size_t)(a > c ? a : c); }
   void alloc_bank(int b) {
     GpMats& q = gbank[b];
     q.M = M; q.Mp = Mp; q.R = R; q.Rp = round_up(R, 16);
     const size_t mm = (size_t)Mp * Mp;
     q.K = dalloc(mm); q.Linv = dalloc(mm); q.LinvT = dalloc(mm);
-    if (!is_head && !white && need_prior_) { q.Kp = dalloc(mm); q.Lpinv = dalloc(mm); q.LpinvT = dalloc(mm); q.klpp = dalloc((size_t)(R + 1) * (Mp / 16 + 1)); }
+    if (!is_head && !white && need_prior_) { q.Kp = dalloc(mm); q.Lpinv = dalloc(mm); q.LpinvT = dalloc(mm); q.klpp = dalloc((size_t)(R + 1) * kl_slots(Mp)); }
     q.Lq = dalloc((size_t)R * mm);
     q.qmu = dalloc((size_t)Mp * q.Rp);
     if (white) { q.G = q.Lq; q.alpha = q.qmu; }
-    else { q.G = dalloc((size_t)R * mm); q.alpha = dalloc((size_t)Mp * q.Rp); q.klp = dalloc((size_t)(R + 1) * (Mp / 16 + 1)); }
+    else { q.G = dalloc((size_t)R * mm); q.alpha = dalloc((size_t)Mp * q.Rp); q.klp = dalloc((size_t)(R + 1) * kl_slots(Mp)); }
     ZTb[b] = dalloc((size_t)Lp * Mp);
     znb[b] = dalloc(Mp);
     ZSb[b] = dalloc((size_t)Lz * Mp);
@@ -180,12 +182,20 @@ struct FactorGroup {
   double **dK = nullptr, **dLinv = nullptr, **dLinvT = nullptr;
   int* d_info = nullptr;
   bool uploaded = false;
+  // right-hand sides riding the chain (ChainRhs, common.h): one entry per matrix, Yw filled in by upload()
+  std::vector<ChainRhs> rhs;
+  ChainRhs* d_rhs = nullptr;
+  double* d_yw = nullptr;
+  int max_R = 0;
+  bool ride = false;   // some matrix of the group carries right-hand sides
   void release() {
     if (dK) hipFree(dK);
     if (dLinv) hipFree(dLinv);
     if (dLinvT) hipFree(dLinvT);
     if (d_info) hipFree(d_info);
-    dK = dLinv = dLinvT = nullptr; d_info = nullptr; uploaded = false;
+    if (d_rhs) hipFree(d_rhs);
+    if (d_yw) hipFree(d_yw);
+    dK = dLinv = dLinvT = nullptr; d_info = nullptr; d_rhs = nullptr; d_yw = nullptr; uploaded = false;
   }
   int upload(dcgp_ctx* ctx) {
     if (uploaded) return DCGP_OK;
@@ -196,15 +206,30 @@ struct FactorGroup {
     HIP_TRY(ctx, hipMemcpy(dK, K.data(), n * sizeof(double*), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dLinv, Linv.data(), n * sizeof(double*), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(dLinvT, LinvT.data(), n * sizeof(double*), hipMemcpyHostToDevice));
+    if (ride) {
+      size_t total = 0;
+      for (auto& r : rhs) total += (r.Lq || r.qmu) ? (size_t)r.R * Mp * Mp + (size_t)Mp * r.Rp : 0;
+      if (hipMalloc((void**)&d_yw, (total ? total : 2) * sizeof(double)) != hipSuccess || hipMalloc((void**)&d_rhs, n * sizeof(ChainRhs)) != hipSuccess)
+        return ctx_fail(ctx, DCGP_ERR_ALLOC, "factor group: allocation failed");
+      if (dcgp_poison()) { hipMemset(d_yw, 0xFF, (total ? total : 2) * sizeof(double)); hipDeviceSynchronize(); }
+      size_t off = 0;
+      for (auto& r : rhs) {
+        r.Yw = d_yw + off;
+        off += (r.Lq || r.qmu) ? (size_t)r.R * Mp * Mp + (size_t)Mp * r.Rp : 0;
+      }
+      HIP_TRY(ctx, hipMemcpy(d_rhs, rhs.data(), n * sizeof(ChainRhs), hipMemcpyHostToDevice));
+    }
     uploaded = true;
     return DCGP_OK;
   }
   // defer_finish: inv(L) and its transpose are complete on return, the factor itself is copied back over K by finish() --
   // only the KL terms (and the reverse pass) read it, so the copy need not sit in front of the first layer
   bool deferred = false;
+  bool rode = false;   // the most recent run() carried the right-hand sides (the ctx's options may rule it out from one step to the next)
   int run(dcgp_ctx* ctx, bool defer_finish = false) {
     DCGP_TRY(upload(ctx));
-    DCGP_TRY(factor_inverse_batched(ctx, dK, dLinv, dLinvT, (int)K.size(), Mp, Mp, d_info, defer_finish));
+    rode = ride && chain_can_ride(ctx, Mp);
+    DCGP_TRY(factor_inverse_batched(ctx, dK, dLinv, dLinvT, (int)K.size(), Mp, Mp, d_info, defer_finish, rode ? d_rhs : nullptr, max_R));
     deferred = defer_finish;
     return DCGP_OK;
   }

@@ -27,16 +27,25 @@ int build_groups(dcgp_model* m, int bank) {   // the layers must be on `bank` (u
   auto& groups = m->groups[bank];
   for (auto& gr : groups) gr.release();
   groups.clear();
-  auto add = [&](int Mp, double* K, double* Linv, double* LinvT) {
+  auto add = [&](int Mp, double* K, double* Linv, double* LinvT, const ChainRhs& r) {
+    FactorGroup* g = nullptr;
     for (auto& gr : groups)
-      if (gr.Mp == Mp) { gr.K.push_back(K); gr.Linv.push_back(Linv); gr.LinvT.push_back(LinvT); return; }
-    FactorGroup gr;
-    gr.Mp = Mp; gr.K.push_back(K); gr.Linv.push_back(Linv); gr.LinvT.push_back(LinvT);
-    groups.push_back(gr);
+      if (gr.Mp == Mp) g = &gr;
+    if (!g) { groups.emplace_back(); g = &groups.back(); g->Mp = Mp; }
+    g->K.push_back(K); g->Linv.push_back(Linv); g->LinvT.push_back(LinvT); g->rhs.push_back(r);
+    if (r.Lq || r.qmu) { g->ride = true; g->max_R = r.R > g->max_R ? r.R : g->max_R; }
   };
+  // G = inv(L) Lq and alpha = inv(L) q_mu ride the chain (chol_fused.hip) where a layer is unwhitened and small enough; with a prior
+  // Kuu(Z0) the same right-hand sides ride its chain for the KL's sums of squares
   for (auto& l : m->layers) {
-    add(l->Mp, l->g.K, l->g.Linv, l->g.LinvT);
-    if (l->g.Kp) add(l->Mp, l->g.Kp, l->g.Lpinv, l->g.LpinvT);
+    const GpMats& g = l->g;
+    const bool rides = !l->white && g.Mp <= kChainRhsMaxMp && g.Rp <= 32 && g.G && g.alpha && g.klp;
+    ChainRhs live{}, prior{};
+    live.R = prior.R = g.R; live.Rp = prior.Rp = g.Rp;
+    if (rides) { live.Lq = l->has_qsqrt ? g.Lq : nullptr; live.qmu = g.qmu; live.G = g.G; live.alpha = g.alpha; live.sums = g.klp; }
+    if (rides && g.Kp && g.klpp && l->has_qsqrt) { prior.Lq = g.Lq; prior.qmu = g.qmu; prior.sums = g.klpp; }
+    add(l->Mp, g.K, g.Linv, g.LinvT, live);
+    if (g.Kp) add(l->Mp, g.Kp, g.Lpinv, g.LpinvT, prior);
   }
   m->groups_built[bank] = true;
   return DCGP_OK;
@@ -279,11 +288,28 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     if (rc == DCGP_OK) rc = gr.run(ctx, defer);
   if (rc == DCGP_OK && xs && hipEventRecord(m->ev_factor[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
   // G_r = inv(L) Lq_r and alpha = inv(L) q_mu of every layer (cond_prep): gate the second conditional GEMM
-  bool prep_done[8] = {};
-  if (rc == DCGP_OK) {   // every layer the one-launch route covers (unwhitened, M <= 256, <= 16 outputs): head_cond.hip
+  bool prep_done[8] = {}, rode[8] = {};
+  int kl_ns[8] = {}, kl_nsa[8] = {};
+  for (int li = 0; li < nl && rc == DCGP_OK; ++li) {   // layers whose right-hand sides rode the chain (build_groups): nothing left to do
+    LayerState& L = *m->layers[li];
+    bool live_sums = false, prior_sums = false;
+    for (auto& gr : m->groups[bank]) {
+      if (!gr.rode) continue;
+      for (size_t i = 0; i < gr.K.size(); ++i) {
+        if (gr.K[i] == L.g.K && (gr.rhs[i].Lq || gr.rhs[i].qmu)) { rode[li] = true; live_sums = gr.rhs[i].Lq != nullptr; }
+        if (L.g.Kp && gr.K[i] == L.g.Kp && gr.rhs[i].Lq) prior_sums = true;
+      }
+    }
+    if (!rode[li]) continue;
+    prep_done[li] = true;
+    L.g.klp_valid = live_sums; L.g.klpp_valid = prior_sums;
+    kl_ns[li] = chain_rhs_slots(L.Mp); kl_nsa[li] = (L.Mp + 31) / 32;
+    L.g.kl_ns = kl_ns[li]; L.g.kl_nsa = kl_nsa[li];
+  }
+  if (rc == DCGP_OK) {   // every other layer the one-launch route covers (unwhitened, M <= 256, <= 16 outputs): head_cond.hip
     GpMats* gs[8]; int wh[8]; bool hq[8];
     for (int li = 0; li < nl; ++li) { gs[li] = &m->layers[li]->g; wh[li] = m->layers[li]->white; hq[li] = m->layers[li]->has_qsqrt; }
-    rc = prep_solve_all(ctx, gs, wh, hq, nl, prep_done);
+    rc = prep_solve_all(ctx, gs, wh, hq, nl, prep_done, rode);
   }
   // The KL pieces need nothing but parameter-only state.  Where prep_solve left the sums of squares they are made of (every
   // layer unwhitened, M <= 256, with q_sqrt), one extra workgroup per layer of the tail launch adds them up with the factors'
@@ -315,6 +341,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
         q.Lfac = lout + idx * (long)L.Mp * L.Mp;
       }
       q.Lq = L.g.Lq; q.sums = L.g.Kp ? L.g.klpp : L.g.klp; q.M = L.M; q.Mp = L.Mp; q.R = L.R;
+      q.ns = kl_ns[li]; q.nsa = kl_nsa[li];
     }
   }
   const bool side_kl = need_kl && !kl_tail;

@@ -37,8 +37,8 @@ __device__ __forceinline__ double robustmax_logp(double p, double eps, int K) {
 // One workgroup (256 threads): the four KL pieces of a layer -- {Mahalanobis, log det q, log det prior, trace}, the layout
 // kl_small_kernel (cond.hip) leaves -- from the strip sums of prep_solve and the diagonals of the factors.
 __device__ __forceinline__ void kl_pieces_block(const KlTailLayer& L, double* __restrict__ kl4, double* red /* [4][256] LDS */) {
-  const int tid = threadIdx.x, ns = L.Mp / 16;
-  double ldq = 0.0, ldp = 0.0, tr = 0.0;
+  const int tid = threadIdx.x, ns = L.ns > 0 ? L.ns : L.Mp / 16, nsa = L.ns > 0 ? L.nsa : 1;
+  double ldq = 0.0, ldp = 0.0, tr = 0.0, mh = 0.0;
   for (int idx = tid; idx < L.M * L.R; idx += 256) {
     const int i = idx % L.M, r = idx / L.M;
     const double d = L.Lq[((long)r * L.Mp + i) * L.Mp + i];
@@ -49,7 +49,8 @@ __device__ __forceinline__ void kl_pieces_block(const KlTailLayer& L, double* __
     ldp += log(d * d);
   }
   for (int i = tid; i < L.R * ns; i += 256) tr += L.sums[i];
-  red[tid] = tid == 0 ? L.sums[(long)L.R * ns] : 0.0; red[256 + tid] = ldq; red[512 + tid] = ldp; red[768 + tid] = tr;
+  for (int i = tid; i < nsa; i += 256) mh += L.sums[(long)L.R * ns + i];
+  red[tid] = mh; red[256 + tid] = ldq; red[512 + tid] = ldp; red[768 + tid] = tr;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (tid < o)

@@ -349,8 +349,9 @@ def test_chain_graph_replay_matches_the_launch_loop(ctx):
     steps -- both banks, the first one capturing, the later ones replaying -- and the gradients are bit-identical to the loop's, for two
     models alive at once (two argument sets in the cache) and an M whose last panel is ragged."""
     out = {}
-    for g in (0, 1):
-        with ctx.options(chain_graph=g):
+    for g in (0, 1, 2):   # 0: the launch loop, 1: the replayed graph -- both with G / alpha by their own launch (a graph does not carry the
+        # right-hand sides that otherwise ride the chain, ctx option no_rhs_ride) -- 2: the loop with them riding (the default route)
+        with ctx.options(chain_graph=1 if g == 1 else 0, no_rhs_ride=0 if g == 2 else 1):
             vals = []
             models = []
             for hwc, convs, head, M in (((13, 13, 2), [(4, 3, 7)], (2, 1), 41), ((12, 12, 1), [], (3, 1), 96)):
@@ -368,6 +369,8 @@ def test_chain_graph_replay_matches_the_launch_loop(ctx):
                 m.close()
             out[g] = vals
     assert np.all(np.isfinite(out[1])) and out[0] == out[1], (out[0], out[1])
+    # the riding right-hand sides sum the same products in another order: equal to rounding
+    np.testing.assert_allclose(out[2], out[0], rtol=1e-11, atol=0)
 
 
 def test_full_size_cfg1_vs_oracle(ctx):
