@@ -116,6 +116,30 @@ def cpu_baseline(name, S, batch, budget_s=30.0):
                      "reference's operation order (materialised K_uf, per-patch triangular solves, dense tensordot), %d BLAS threads "
                      "(best of %s on %d host cores), after %d warm-up steps; median %.2f s/step; not TensorFlow"
                      % (len(times), batch, S, best, sorted(probes), ncpu, len(probes) + 2, med)}
+    # the same arithmetic batched the way a CPU likes it (oracle/fast_cpu.py: ONE triangular solve over all K columns, ONE (R M) x M x K
+    # GEMM instead of the reference's loop of 2 P solves + tensordot): what a tuned CPU implementation would reach, beside the
+    # reference-order row above
+    try:
+        from oracle import fast_cpu
+        fb = {}
+        for n in sorted(probes):
+            with limited(n):
+                fast_cpu.elbo(spec, X, Y, rng=rng)
+                t0 = time.perf_counter(); fast_cpu.elbo(spec, X, Y, rng=rng); fb[n] = time.perf_counter() - t0
+            if time.perf_counter() - t_begin > 1.3 * budget_s:
+                break
+        nb = min(fb, key=fb.get)
+        with limited(nb):
+            ft = []
+            while len(ft) < 5 and (len(ft) < 3 or time.perf_counter() - t_begin < 1.6 * budget_s):
+                t0 = time.perf_counter(); fast_cpu.elbo(spec, X, Y, rng=rng); ft.append(time.perf_counter() - t0)
+        out["best_cpu"] = {"value": 1.0 / float(np.median(ft)), "unit": "ELBO steps/s", "cores": nb, "kind": "port",
+                           "thread_probe_s_per_step": {str(k): round(v, 3) for k, v in fb.items()},
+                           "sample": "%d steps of the same workload, oracle/fast_cpu.py (batched: one trsm over all K columns, one (R M) x M x K GEMM; "
+                                     "equal to the reference-order oracle to 1e-10, tests/test_oracle_cpu.py), %d BLAS threads; median %.3f s/step"
+                                     % (len(ft), nb, float(np.median(ft)))}
+    except Exception as exc:                                       # a baseline row must never break the bench line
+        out["best_cpu"] = {"error": repr(exc)}
     if t1:
         out["value_1thread"] = 1.0 / (t1 * batch / q)
         out["sample_1thread"] = ("1 BLAS thread, second of 2 steps on a quarter of the batch (%d images): %.2f s, scaled by %d (the step is "
@@ -522,6 +546,35 @@ def main():
                     g["train_step_ms_with_exact_layer0_dedup"] = 1e3 * leg.timed(args.warmup, n_g, train_step)[0] / n_g
                 finally:
                     model.dedup_layer0 = False
+            # roofline of the reverse pass's two chip-filling product kernels (first conv layer, tiled batch): conv_bwd_fused
+            # (dK_uf = inv(L)^T [sum_r (S_r A1) o 2 gv_r + ...]: R dense M x M x K products + one triangular) and the symmetric
+            # W_r = 2 A1 diag(gv_r) A1^T contraction (R x the lower half of M x M x K), timed by HIP events on their own streams in a
+            # loop of their own; they overlap in the step (different streams), so the sum of their times is an upper bound of their share
+            if cfg["convs"]:
+                ctx.timing_enable(1)
+                ctx.timing_reset()
+                for i in range(min(n_g, 6)):
+                    cg(1000 + i)
+                leg.barrier()
+                tim = ctx.timing()
+                ctx.timing_enable(0)
+                c0 = cfg["convs"][0]
+                P0 = ((cfg["hwc"][0] - c0[0]) // c0[1] + 1) * ((cfg["hwc"][1] - c0[0]) // c0[1] + 1)
+                Kc, M, R = leg.local_batch * S * P0, cfg["M"], c0[2]
+                f_bwd = (2.0 * R + 1.0) * M * M * Kc          # dense S_r products 2 M^2 K each, the closing triangular product M^2 K
+                f_wr = 1.0 * R * M * M * Kc                   # symmetric: M^2 K per output
+                tb, tw = tim.get("conv_bwd_fused"), tim.get("grad_wr")
+                if tb and tw and tb[0] and tw[0]:
+                    us_b, us_w = 1e3 * tb[1] / tb[0], 1e3 * tw[1] / tw[0]
+                    ach = (f_bwd + f_wr) / ((us_b + us_w) * 1e-6) / 1e12
+                    g["roofline_train"] = {"kernel": "conv_bwd_fused_kernel + gemm_gen (W_r contraction): the reverse pass's products of the first conv layer",
+                                           "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                                           "traffic": None, "algorithmic_flops": f_bwd + f_wr,
+                                           "conv_bwd_fused": {"avg_us": us_b, "flops": f_bwd, "tflops": f_bwd / us_b / 1e6},
+                                           "w_r_contraction": {"avg_us": us_w, "flops": f_wr, "tflops": f_wr / us_w / 1e6},
+                                           "launches_sampled": int(tb[0]),
+                                           "note": "flops: (2 R + 1) M^2 K + R M^2 K (symmetric / triangular products counted as M^2 per column, as SURVEY 8(d) "
+                                                   "counts the forward's); times: HIP events around each launch on its own stream, the two overlap in the step"}
             return g
         grad = informational("gradient", grad_leg) or {}
 
@@ -612,6 +665,10 @@ def main():
             "value_and_grad_ms": grad.get("value_and_grad_ms"),
             "train_step_ms_value_grad_adam": grad.get("train_step_ms_value_grad_adam"),
             "train_step_ms_with_exact_layer0_dedup": grad.get("train_step_ms_with_exact_layer0_dedup"),
+            # the training step as a first-class number: value + gradient + Adam update in ONE device call (conv_gp/experiment.py:84-108)
+            "train_steps_per_s": (1e3 / grad["train_step_ms_value_grad_adam"]) if grad.get("train_step_ms_value_grad_adam") else None,
+            "train_steps_per_s_with_exact_layer0_dedup": (1e3 / grad["train_step_ms_with_exact_layer0_dedup"]) if grad.get("train_step_ms_with_exact_layer0_dedup") else None,
+            "roofline_train": grad.get("roofline_train"),
         }
         out.update(extra)
         # ---- roofline of the dominant kernel -------------------------------------------------------------------------

@@ -18,6 +18,8 @@ typedef int (*fn_get_unique_id)(UniqueId*);
 typedef int (*fn_comm_init_rank)(void** comm, int nranks, UniqueId id, int rank);
 typedef int (*fn_comm_destroy)(void* comm);
 typedef int (*fn_all_reduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t s);
+typedef int (*fn_reduce_scatter)(const void* send, void* recv, size_t recvcount, int dtype, int op, void* comm, hipStream_t s);
+typedef int (*fn_all_gather)(const void* send, void* recv, size_t sendcount, int dtype, void* comm, hipStream_t s);
 typedef const char* (*fn_get_error_string)(int);
 typedef int (*fn_comm_count)(void* comm, int* count);
 
@@ -27,6 +29,8 @@ struct Rccl {
   fn_comm_init_rank comm_init_rank = nullptr;
   fn_comm_destroy comm_destroy = nullptr;
   fn_all_reduce all_reduce = nullptr;
+  fn_reduce_scatter reduce_scatter = nullptr;
+  fn_all_gather all_gather = nullptr;
   fn_get_error_string get_error_string = nullptr;
   fn_comm_count comm_count = nullptr;
 };
@@ -45,6 +49,8 @@ bool rccl_load() {
   g_rccl.comm_init_rank = (fn_comm_init_rank)dlsym(h, "ncclCommInitRank");
   g_rccl.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
   g_rccl.all_reduce = (fn_all_reduce)dlsym(h, "ncclAllReduce");
+  g_rccl.reduce_scatter = (fn_reduce_scatter)dlsym(h, "ncclReduceScatter");
+  g_rccl.all_gather = (fn_all_gather)dlsym(h, "ncclAllGather");
   g_rccl.get_error_string = (fn_get_error_string)dlsym(h, "ncclGetErrorString");
   g_rccl.comm_count = (fn_comm_count)dlsym(h, "ncclCommCount");
   if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce) {
@@ -91,7 +97,33 @@ int allreduce_sum_f64_async(dcgp_ctx* ctx, double* buf_dev, int n) {
   return DCGP_OK;
 }
 
+// In-place reduce-scatter of a block of nranks * shard doubles: this rank's shard [rank * shard, (rank + 1) * shard) ends up summed over the
+// ranks (the rest of the block is left as it was).  In-place all-gather: every rank's shard of the block to every rank.
+int reduce_scatter_sum_f64_async(dcgp_ctx* ctx, double* block_dev, size_t shard) {
+  if (!ctx->comm || !g_rccl.reduce_scatter) return ctx_fail(ctx, DCGP_ERR_RCCL, "reduce_scatter: no communicator on this ctx (or librccl without ncclReduceScatter)");
+  const int rc = g_rccl.reduce_scatter(block_dev, block_dev + (size_t)ctx->rank * shard, shard, kNcclFloat64, kNcclSum, ctx->comm, ctx->stream);
+  if (rc != 0) return ctx_fail(ctx, DCGP_ERR_RCCL, "ncclReduceScatter failed: %s", g_rccl.get_error_string ? g_rccl.get_error_string(rc) : "?");
+  return DCGP_OK;
+}
+int all_gather_f64_async(dcgp_ctx* ctx, double* block_dev, size_t shard) {
+  if (!ctx->comm || !g_rccl.all_gather) return ctx_fail(ctx, DCGP_ERR_RCCL, "all_gather: no communicator on this ctx (or librccl without ncclAllGather)");
+  const int rc = g_rccl.all_gather(block_dev + (size_t)ctx->rank * shard, block_dev, shard, kNcclFloat64, ctx->comm, ctx->stream);
+  if (rc != 0) return ctx_fail(ctx, DCGP_ERR_RCCL, "ncclAllGather failed: %s", g_rccl.get_error_string ? g_rccl.get_error_string(rc) : "?");
+  return DCGP_OK;
+}
+
 extern "C" {
+
+// Contiguous shards of a block of n values over nranks ranks, every shard the same length ceil(n / nranks) (the collectives want equal
+// counts: the block is padded to nranks * shard): rank r holds [r * shard, min((r + 1) * shard, n)).  deepcgp_amd/dist.py: grad_shard_range.
+int dcgp_shard_range(long n, int nranks, int rank, long* lo, long* hi, long* shard) {
+  if (n < 0 || nranks <= 0 || rank < 0 || rank >= nranks || !lo || !hi) return DCGP_ERR_ARG;
+  const long sh = (n + nranks - 1) / nranks;
+  *lo = (long)rank * sh < n ? (long)rank * sh : n;
+  *hi = (long)(rank + 1) * sh < n ? (long)(rank + 1) * sh : n;
+  if (shard) *shard = sh;
+  return DCGP_OK;
+}
 
 int dcgp_comm_unique_id(unsigned char* out_128bytes) {
   if (!out_128bytes) return DCGP_ERR_ARG;

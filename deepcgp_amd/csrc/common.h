@@ -367,6 +367,8 @@ constexpr int kChainRhsMaxMp = 256;   // beyond: the substitution's workgroups o
 // d_rhs != nullptr (device array, one entry per matrix; max_R = the largest R among them): right-hand sides ride the chain.
 int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_Linv, double* const* d_LinvT, int batch,
                            int Mp, int ld, int* d_info, bool defer_finish = false, const ChainRhs* d_rhs = nullptr, int max_R = 0);
+int reduce_scatter_sum_f64_async(dcgp_ctx* ctx, double* block_dev, size_t shard);   // comm.hip (in place, this rank's shard)
+int all_gather_f64_async(dcgp_ctx* ctx, double* block_dev, size_t shard);
 int factor_finish_batched(dcgp_ctx* ctx, double* const* d_A, int batch, int Mp, int ld);
 bool chain_can_ride(const dcgp_ctx* ctx, int Mp);   // right-hand sides may ride the chain of a matrix of this size under the ctx's options
 int pad_copy(dcgp_ctx* ctx, const double* src, int rows, int cols, int lds, double* dst, int ldd, int rows_p,

@@ -576,6 +576,8 @@ struct OptGroup {
   double* recip;                                      // != null: 1 / p is kept here as well (the dense head's staging scale)
   long n;
   int transform, hyp_layer;                           // hyp_layer >= 0: p is that layer's {variance, p1, p2} triple
+  // sharded step (OptArgs::sharded): the group's offset in its layer's gradient block, the layer, and whether it only passes through
+  long off; int layer, frozen;
 };
 constexpr int OPT_GROUPS_MAX = 48;
 struct OptArgs {
@@ -586,6 +588,12 @@ struct OptArgs {
   double hyp_in[8][3];
   double* host_out;                  // [8][3] pinned
   const double* status;              // != null: a non-zero word there (the step's factorisation failed) leaves every parameter untouched
+  // Sharded step (dcgp_model_set_grad_exchange 1): only the elements whose position in the layer's block lies in [sh_lo, sh_hi) are updated --
+  // the gradient there is this rank's reduce-scattered sum -- and every value of the range, updated or frozen, also goes to stage[layer]
+  // (the block's layout), which the all-gather then completes.  stage_only: the parameter arrays are left alone (the debug entry's other ranks).
+  int sharded, stage_only;
+  long sh_lo[8], sh_hi[8];
+  double* stage[8];
 };
 __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
   if (a.status && *a.status != 0.0) return;
@@ -594,9 +602,12 @@ __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
   const OptGroup& G = a.grp[gi];
   const long i = (long)((int)blockIdx.x - a.first_block[gi]) * 256 + threadIdx.x;
   if (i >= G.n) return;
+  if (a.sharded && (G.off + i < a.sh_lo[G.layer] || G.off + i >= a.sh_hi[G.layer])) return;
   const double x = G.hyp_layer >= 0 ? a.hyp_in[G.hyp_layer][i] : G.p[i];
   double out;
-  if (a.sgd) {   // plain gradient ascent on the ELBO in the unconstrained space
+  if (G.frozen) {
+    out = x;
+  } else if (a.sgd) {   // plain gradient ascent on the ELBO in the unconstrained space
     const double gr = G.g[i];
     if (G.transform == 1) {
       const double y = x - 1e-6;
@@ -621,6 +632,22 @@ __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
     u -= a.lr * mi / (sqrt(vi) + a.eps);
     out = G.transform == 1 ? (u > 35.0 ? u : log1p(exp(u))) + 1e-6 : u;
   }
+  if (a.sharded) a.stage[G.layer][G.off + i] = out;
+  if (G.frozen || a.stage_only) return;
+  G.p[i] = out;
+  if (G.recip) G.recip[i] = 1.0 / out;
+  if (G.hyp_layer >= 0) a.host_out[3 * G.hyp_layer + i] = out;
+}
+// behind the all-gather: the other ranks' shards of the staged block into this rank's parameter arrays
+__global__ __launch_bounds__(256) void opt_unstage_kernel(OptArgs a) {
+  if (a.status && *a.status != 0.0) return;
+  int gi = 0;
+  while (gi + 1 < a.ng && (int)blockIdx.x >= a.first_block[gi + 1]) ++gi;
+  const OptGroup& G = a.grp[gi];
+  const long i = (long)((int)blockIdx.x - a.first_block[gi]) * 256 + threadIdx.x;
+  if (i >= G.n || G.frozen) return;
+  if (G.off + i >= a.sh_lo[G.layer] && G.off + i < a.sh_hi[G.layer]) return;   // this rank's own shard: already in place
+  const double out = a.stage[G.layer][G.off + i];
   G.p[i] = out;
   if (G.recip) G.recip[i] = 1.0 / out;
   if (G.hyp_layer >= 0) a.host_out[3 * G.hyp_layer + i] = out;
@@ -1040,7 +1067,10 @@ int cond_backward_main(Bk& bk, const Lanes& ln, LayerState& L, const double* A1,
     GenGemm w = mk(A1, ld, 1, A1, 1, ld, Wr, Mp, M, M, (int)Kc);
     // (the k scaling reads gv [Kc][R] in place, stride R: a transposed copy used to cost 290 us of scattered 8-byte stores per step)
     w.batch = R; w.c_bs = mm; w.lower_only = 1; w.mirror = 1; w.alpha = 2.0; w.kscale = gv; w.ks_s = R; w.ks_bs = 1;
-    DCGP_TRY(gemm_gen(ctx, w));
+    {
+      ScopedTimer t(ctx, L.is_head ? "grad_wr_head" : "grad_wr");   // (bench.py: roofline_train)
+      DCGP_TRY(gemm_gen(ctx, w));
+    }
     GenGemm d = mk(Wr, Mp, 1, g.G, Mp, 1, dG, Mp, M, M, M);
     d.batch = R; d.a_bs = mm; d.b_bs = mm; d.c_bs = mm; d.lower_only = 1;
     DCGP_TRY(gemm_gen(ctx, d));
@@ -1548,12 +1578,26 @@ int model_backward(dcgp_model* m, const double* X, const int32_t* y, int N, doub
     }
   }
   if (bk.side_pending) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_kl, 0));   // the one join of the step: every layer's side-stream tail
-  if (ctx->comm)   // one in-stream all-reduce per layer over its contiguous gradient block (RCCL over xGMI)
+  m->grad_scattered = false;
+  if (ctx->comm) {
+    // One in-stream collective per layer over its contiguous gradient block (RCCL over xGMI).  A training step in exchange mode 1: a
+    // reduce-scatter -- this rank's shard of the block summed over the ranks, 1 / ranks of an all-reduce's receive volume -- followed (opt_enqueue)
+    // by the update of that shard alone and an all-gather of the parameters; otherwise the all-reduce every rank follows with the full update.
+    const bool scatter = m->grad_exchange == 1 && m->adam_follows && ctx->nranks > 1;
     for (auto& l : m->layers) {
       const size_t n = l->grad_block_count();
-      if (n > 0x7fffffffUL) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: gradient block too large for one all-reduce");
-      DCGP_TRY(allreduce_sum_f64_async(ctx, l->gZ, (int)n));
+      if (n > 0x7fffffffUL) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: gradient block too large for one collective");
+      if (scatter) {
+        long lo, hi, sh;
+        DCGP_TRY(dcgp_shard_range((long)n, ctx->nranks, ctx->rank, &lo, &hi, &sh));
+        if ((size_t)sh * ctx->nranks > n + LayerState::kGradBlockPad) return ctx_fail(ctx, DCGP_ERR_ARG, "grad: more ranks than the gradient block is padded for");
+        DCGP_TRY(reduce_scatter_sum_f64_async(ctx, l->gZ, (size_t)sh));
+      } else {
+        DCGP_TRY(allreduce_sum_f64_async(ctx, l->gZ, (int)n));
+      }
     }
+    m->grad_scattered = scatter;
+  }
   return DCGP_OK;
 }
 
@@ -1563,7 +1607,7 @@ extern "C" {
 
 // Adam step enqueued behind the reverse pass (dcgp_model_train_step_adam): lr is the bias-corrected rate
 struct AdamReq { double lr_t, beta1, beta2, eps; };
-static int opt_enqueue(dcgp_model* model, const char* who, bool sgd, double lr, double beta1, double beta2, double eps, const double* status);
+static int opt_enqueue(dcgp_model* model, const char* who, bool sgd, double lr, double beta1, double beta2, double eps, const double* status, int vranks);
 static int opt_readback(dcgp_model* model);
 
 static int elbo_grad_run(dcgp_model* model, const double* X, const int32_t* y, int N, double scale, const double* const* z_per_layer_host,
@@ -1572,6 +1616,7 @@ static int elbo_grad_run(dcgp_model* model, const double* X, const int32_t* y, i
   const bool keep = model->keep_outputs;
   model->keep_outputs = true;   // the reverse pass reads every layer's (sample, mean, var)
   model->keep_state = true;     // ... and K_uf / A1 of every conv layer
+  model->adam_follows = adam != nullptr;
   model->grad_follows = true;   // ... and marks where the parameter-only part of the reverse pass may start (grad_kl_early)
   // The forward pass is ENQUEUED, the reverse pass behind it, and only then is the forward's result collected: the host does not wait for
   // the ELBO before it feeds the ~110 launches of the reverse pass (a failed factorisation is reported all the same; the reverse pass then
@@ -1586,7 +1631,7 @@ static int elbo_grad_run(dcgp_model* model, const double* X, const int32_t* y, i
   if (rc == DCGP_OK) rc = model_backward(model, X, y, N, scale, dedup_layer0);
   // (the update reads the step's factorisation status word on the device: a failed step leaves the parameters as they were)
   if (rc == DCGP_OK && adam)
-    rc = opt_enqueue(model, "train_step_adam", false, adam->lr_t, adam->beta1, adam->beta2, adam->eps, model->d_scal + 64 * model->bank + 43);
+    rc = opt_enqueue(model, "train_step_adam", false, adam->lr_t, adam->beta1, adam->beta2, adam->eps, model->d_scal + 64 * model->bank + 43, 0);
   if (ctx->timing) {   // host time to enqueue the whole step, forward pass included (reported beside the kernel timers)
     auto& acc = ctx->tim["grad_host_enqueue"];
     acc.launches += 1;
@@ -1689,48 +1734,77 @@ int dcgp_model_grad_block(dcgp_model* model, int layer, double** block_dev, size
 
 // one optimiser step over every trainable group of the model (sgd: plain ascent, otherwise Adam with the bias-corrected rate lr)
 static int opt_readback(dcgp_model* model);
-static int opt_enqueue(dcgp_model* model, const char* who, bool sgd, double lr, double beta1, double beta2, double eps, const double* status);
-static int opt_step(dcgp_model* model, const char* who, bool sgd, double lr, double beta1, double beta2, double eps) {
-  DCGP_TRY(opt_enqueue(model, who, sgd, lr, beta1, beta2, eps, nullptr));
+static int opt_enqueue(dcgp_model* model, const char* who, bool sgd, double lr, double beta1, double beta2, double eps, const double* status, int vranks);
+static int opt_step(dcgp_model* model, const char* who, bool sgd, double lr, double beta1, double beta2, double eps, int vranks = 0) {
+  DCGP_TRY(opt_enqueue(model, who, sgd, lr, beta1, beta2, eps, nullptr, vranks));
   HIP_TRY(model->ctx, hipStreamSynchronize(model->ctx->stream));
   return opt_readback(model);
 }
-// the launch alone, behind whatever the stream holds (status: see OptArgs)
-static int opt_enqueue(dcgp_model* model, const char* who, bool sgd, double lr, double beta1, double beta2, double eps, const double* status) {
+// the launch alone, behind whatever the stream holds (status: see OptArgs).
+// vranks > 0 (debugging aid, dcgp_model_debug_sharded_adam): the sharded step of `vranks` ranks played on this one GPU from rank 0's point of
+// view -- its own shard for real, the others' into the staging block only, then the unstage pass.
+static int opt_enqueue(dcgp_model* model, const char* who, bool sgd, double lr, double beta1, double beta2, double eps, const double* status, int vranks = 0) {
   dcgp_ctx* ctx = model->ctx;
   const int nl = (int)model->layers.size();
   if (nl > 8) return ctx_fail(ctx, DCGP_ERR_ARG, "%s: at most 8 layers", who);
+  const bool comm_sharded = ctx->comm && ctx->nranks > 1 && model->grad_exchange == 1 && model->grad_scattered;
+  const bool sharded = comm_sharded || vranks > 0;
+  const int nranks = vranks > 0 ? vranks : ctx->nranks, rank = vranks > 0 ? 0 : ctx->rank;
   OptArgs a{};
   a.sgd = sgd ? 1 : 0; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.status = status;
+  a.sharded = sharded ? 1 : 0;
   double* h = ctx->h_scratch;   // 64 pinned doubles: {variance, p1, p2} per layer
   if (hipHostGetDevicePointer((void**)&a.host_out, h, 0) != hipSuccess) return ctx_fail(ctx, DCGP_ERR_HIP, "%s: pinned slot not mapped", who);
-  int nb = 0;
-  auto add = [&](double* p, const double* g, double* const* mv, long n, int transform, int hyp_layer, double* recip) -> int {
-    if (n <= 0) return DCGP_OK;
+  int nb = 0, cur_layer = 0;
+  const double* blk0 = nullptr;
+  auto add = [&](double* p, const double* g, double* const* mv, long n, int transform, int hyp_layer, double* recip, bool frozen) -> int {
+    if (n <= 0 || (frozen && !sharded)) return DCGP_OK;
     if (a.ng >= OPT_GROUPS_MAX) return ctx_fail(ctx, DCGP_ERR_ARG, "%s: too many parameter groups", who);
     OptGroup& G = a.grp[a.ng];
     G.p = p; G.g = g; G.m = mv[0]; G.v = mv[1]; G.recip = recip; G.n = n; G.transform = transform; G.hyp_layer = hyp_layer;
+    G.off = (long)(g - blk0); G.layer = cur_layer; G.frozen = frozen ? 1 : 0;
     a.first_block[a.ng++] = nb;
     nb += (int)blocks_for(n);
     return DCGP_OK;
   };
+  long shard[8] = {};
   for (int li = 0; li < nl; ++li) {
     LayerState& L = *model->layers[li];
     if (!L.gZ) return ctx_fail(ctx, DCGP_ERR_ARG, "%s: call dcgp_elbo_grad first", who);
     DCGP_TRY(L.ensure_adam());   // (SGD: for the device copy of the hyper-parameters)
+    cur_layer = li; blk0 = L.gZ;
+    if (sharded) {
+      DCGP_TRY(L.ensure_stage());
+      if (nranks - 1 > (int)LayerState::kGradBlockPad) return ctx_fail(ctx, DCGP_ERR_ARG, "%s: more ranks than the gradient block is padded for", who);
+      DCGP_TRY(dcgp_shard_range((long)L.grad_block_count(), nranks, rank, &a.sh_lo[li], &a.sh_hi[li], &shard[li]));
+      a.stage[li] = L.pstage;
+    }
     a.hyp_in[li][0] = L.variance; a.hyp_in[li][1] = L.base_type == 1 ? L.acos_w : L.ls; a.hyp_in[li][2] = L.base_type == 1 ? L.acos_b : 1.0;
-    if (!(L.frozen & 1u)) DCGP_TRY(add(L.Z, L.gZ, L.aZ, (long)L.M * L.v.L, 0, -1, nullptr));
-    if (!(L.frozen & 2u)) DCGP_TRY(add(L.q_mu, L.gq_mu, L.aq_mu, (long)L.M * L.R, 0, -1, nullptr));
-    if (L.has_qsqrt && !(L.frozen & 4u)) DCGP_TRY(add(L.q_sqrt, L.gq_sqrt, L.aq_sqrt, (long)L.R * L.M * L.M, 0, -1, nullptr));   // upper triangle: zero gradient, zero step
-    if (L.is_head && L.w && !(L.frozen & 8u)) DCGP_TRY(add(L.w, L.gw, L.aw, (long)L.v.P, 0, -1, nullptr));
-    if (!(L.frozen & 16u)) DCGP_TRY(add(L.hyp, L.gscal, L.ahyp, 3, 1, li, nullptr));
-    if (L.ard && !(L.frozen & 16u)) DCGP_TRY(add(L.ard, L.gard, L.aard, (long)L.v.L, 1, -1, L.in_scale));   // dense head: per-dimension lengthscales and the staging scale 1 / l
+    DCGP_TRY(add(L.Z, L.gZ, L.aZ, (long)L.M * L.v.L, 0, -1, nullptr, (L.frozen & 1u) != 0));
+    DCGP_TRY(add(L.q_mu, L.gq_mu, L.aq_mu, (long)L.M * L.R, 0, -1, nullptr, (L.frozen & 2u) != 0));
+    if (L.has_qsqrt) DCGP_TRY(add(L.q_sqrt, L.gq_sqrt, L.aq_sqrt, (long)L.R * L.M * L.M, 0, -1, nullptr, (L.frozen & 4u) != 0));   // upper triangle: zero gradient, zero step
+    if (L.is_head && L.w) DCGP_TRY(add(L.w, L.gw, L.aw, (long)L.v.P, 0, -1, nullptr, (L.frozen & 8u) != 0));
+    DCGP_TRY(add(L.hyp, L.gscal, L.ahyp, 3, 1, li, nullptr, (L.frozen & 16u) != 0));
+    if (L.ard) DCGP_TRY(add(L.ard, L.gard, L.aard, (long)L.v.L, 1, -1, L.in_scale, (L.frozen & 16u) != 0));   // dense head: per-dimension lengthscales and the staging scale 1 / l
   }
   a.first_block[a.ng] = nb;
-  if (nb > 0) {
-    hipLaunchKernelGGL(opt_step_kernel, dim3(nb), dim3(256), 0, ctx->stream, a);
-    LAUNCH_CHECK(ctx);
+  if (nb <= 0) return DCGP_OK;
+  hipLaunchKernelGGL(opt_step_kernel, dim3(nb), dim3(256), 0, ctx->stream, a);
+  LAUNCH_CHECK(ctx);
+  if (!sharded) return DCGP_OK;
+  if (vranks > 0) {   // the other ranks' shards: into the staging block only
+    for (int r = 1; r < vranks; ++r) {
+      OptArgs b = a;
+      b.stage_only = 1;
+      for (int li = 0; li < nl; ++li) DCGP_TRY(dcgp_shard_range((long)model->layers[li]->grad_block_count(), vranks, r, &b.sh_lo[li], &b.sh_hi[li], nullptr));
+      hipLaunchKernelGGL(opt_step_kernel, dim3(nb), dim3(256), 0, ctx->stream, b);
+      LAUNCH_CHECK(ctx);
+    }
+  } else {
+    for (int li = 0; li < nl; ++li) DCGP_TRY(all_gather_f64_async(ctx, model->layers[li]->pstage, (size_t)shard[li]));
   }
+  hipLaunchKernelGGL(opt_unstage_kernel, dim3(nb), dim3(256), 0, ctx->stream, a);
+  LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }
 // the updated kernel hyper-parameters back into the host-side layer state (the stream must have been synchronised)
@@ -1754,6 +1828,25 @@ int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta
   if (t == 0) t = ++model->adam_t; else model->adam_t = t;
   const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
   return opt_step(model, "adam_step", false, lr_t, beta1, beta2, eps);
+}
+
+// Multi-rank training step: how the ranks exchange a step's gradient (0: all-reduce, every rank updates everything; 1: reduce-scatter, each rank
+// updates its shard of every layer's parameter block, all-gather of the parameters -- SURVEY section 5).  Applies to dcgp_model_train_step_adam;
+// dcgp_elbo_grad alone always all-reduces (its caller wants the whole gradient).
+int dcgp_model_set_grad_exchange(dcgp_model* model, int mode) {
+  if (!model || (mode != 0 && mode != 1)) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "set_grad_exchange: mode 0 or 1") : DCGP_ERR_ARG;
+  model->grad_exchange = mode;
+  return DCGP_OK;
+}
+// Debugging aid: one Adam step (dcgp_model_adam_step's arguments) taken the way `ranks` ranks would take it in exchange mode 1, played on this one
+// GPU from rank 0's point of view -- shard 0 updated in place, the other shards through the staging block and the unstage pass.  The gradient must be
+// the complete one (dcgp_elbo_grad).  Parameters and moments come out bit-identical to dcgp_model_adam_step's (tests/test_gpu_model.py).
+int dcgp_model_debug_sharded_adam(dcgp_model* model, int ranks, double lr, double beta1, double beta2, double eps, int t) {
+  if (!model || ranks < 1 || t < 0 || !(lr > 0) || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1) || !(eps > 0))
+    return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "debug_sharded_adam: bad arguments") : DCGP_ERR_ARG;
+  if (t == 0) t = ++model->adam_t; else model->adam_t = t;
+  const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
+  return opt_step(model, "debug_sharded_adam", false, lr_t, beta1, beta2, eps, ranks);
 }
 
 int dcgp_model_sgd_step(dcgp_model* model, double lr) {

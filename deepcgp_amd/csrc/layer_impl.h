@@ -116,10 +116,17 @@ struct LayerState {
     return DCGP_OK;
   }
   // one contiguous block per layer [gZ | gq_mu | gq_sqrt | gw | gscal] so that a single all-reduce covers the layer
+  static constexpr size_t kGradBlockPad = 64;   // ranks - 1 at most
+  double* pstage = nullptr;                     // [grad_block_count() + pad]: the layer's parameters in the gradient block's layout (sharded optimiser step)
+  int ensure_stage() {
+    if (pstage) return DCGP_OK;
+    pstage = dalloc(grad_block_count() + kGradBlockPad);
+    return pstage ? DCGP_OK : ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: staging allocation failed");
+  }
   size_t grad_block_count() const { return (size_t)M * v.L + (size_t)M * R + (size_t)R * M * M + (size_t)v.P + 3 + (is_head ? (size_t)v.L : 0); }
   int ensure_grads() {
     if (gZ) return DCGP_OK;
-    double* blk = dalloc(grad_block_count());
+    double* blk = dalloc(grad_block_count() + kGradBlockPad);   // (padding: the sharded exchange rounds the block up to ranks x shard)
     gslots = dalloc(48);
     if (!blk || !gslots) return ctx_fail(ctx, DCGP_ERR_ALLOC, "layer: gradient allocation failed");
     gZ = blk; gq_mu = gZ + (size_t)M * v.L; gq_sqrt = gq_mu + (size_t)M * R; gw = gq_sqrt + (size_t)R * M * M; gscal = gw + v.P;

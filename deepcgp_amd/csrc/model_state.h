@@ -18,6 +18,9 @@ struct dcgp_model {
   bool kl_early[8] = {};     // per layer: grad_kl_early enqueued its kl_products for the step in flight (consumed by model_backward)
   int adam_t = 0;        // Adam steps taken on this model's moment buffers (bias correction; dcgp_model_adam_step with t = 0)
   int shard_lo = 0, shard_global = 0;   // this rank's first image and the global batch (dcgp_model_set_shard): device-RNG counters
+  int grad_exchange = 0; // multi-rank training step (dcgp_model_train_step_adam): 0 all-reduce of every layer's gradient block + the full update on every rank,
+                         // 1 reduce-scatter -> Adam on this rank's shard -> all-gather of the parameters (dcgp_model_set_grad_exchange)
+  bool adam_follows = false, grad_scattered = false;   // the step in flight ends in the optimiser update / its gradient blocks hold this rank's shard only
   int grad_shards = 0;   // KL gradient weight 1 / shards; 0 = number of ranks of the ctx's communicator (1 without one)
   // two banks of parameter-only state (LayerState::use_bank): factor groups, events and ELBO scalars follow the bank
   std::vector<FactorGroup> groups[2];

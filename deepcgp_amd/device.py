@@ -96,6 +96,9 @@ _SIGS = {
     "dcgp_model_set_shard": [_vp, _i, _i],
     "dcgp_model_grad_block": [_vp, _i, C.POINTER(_vp), C.POINTER(C.c_size_t)],
     "dcgp_model_sgd_step": [_vp, _d],
+    "dcgp_model_set_grad_exchange": [_vp, _i],
+    "dcgp_model_debug_sharded_adam": [_vp, _i, _d, _d, _d, _d, _i],
+    "dcgp_shard_range": [C.c_long, _i, _i, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)],
     "dcgp_model_set_trainable": [_vp, _i, C.c_char_p, _i],
     "dcgp_model_natgrad_step": [_vp, _d, _ip],
     "dcgp_model_predict_y": [_vp, _vp, _i, _i, C.POINTER(_vp), _u64, _vp, _vp, _ip],

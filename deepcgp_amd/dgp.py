@@ -311,6 +311,17 @@ class DGP_Base:
                                                 float(lr), float(beta1), float(beta2), float(epsilon), int(t or 0), out, C.byref(info)), info)
         return out[0]
 
+    def set_grad_exchange(self, mode):
+        """Multi-rank ``train_step``: 0 = all-reduce of the gradient blocks, every rank updates everything; 1 = reduce-scatter, Adam on this
+        rank's shard of every layer's parameter block, all-gather of the parameters (dcgp_model_set_grad_exchange; dist.sharded_adam_step is
+        the same three steps on host arrays)."""
+        self._build()
+        self._ctx._check(dev.lib().dcgp_model_set_grad_exchange(self._model, int(mode)))
+
+    def debug_sharded_adam(self, ranks, lr, t=None, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        """Debugging aid: ``adam_step`` taken the way ``ranks`` ranks take it in exchange mode 1, played on this one GPU (bit-identical)."""
+        self._ctx._check(dev.lib().dcgp_model_debug_sharded_adam(self._model, int(ranks), float(lr), float(beta1), float(beta2), float(epsilon), int(t or 0)))
+
     def sgd_step(self, lr):
         """Plain gradient ascent step in the unconstrained space (the "SGD" branch, conv_gp/experiment.py:100-103)."""
         self._ctx._check(dev.lib().dcgp_model_sgd_step(self._model, float(lr)))

@@ -35,6 +35,39 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def grad_shard_range(n, world, rank):
+    """Shards of a block of n values over `world` ranks as the sharded optimiser step cuts it (dcgp_shard_range, include/dcgp.h): every
+    shard ceil(n / world) long -- RCCL's reduce-scatter / all-gather want equal counts, the block is padded to world * shard --, rank r
+    holds [lo, hi) = [r * shard, min((r + 1) * shard, n)).  Returns (lo, hi, shard)."""
+    if world <= 0 or not (0 <= rank < world) or n < 0:
+        raise ValueError("bad n/world/rank: %d/%d/%d" % (n, world, rank))
+    sh = -(-int(n) // int(world))
+    return min(rank * sh, n), min((rank + 1) * sh, n), sh
+
+
+def adam_update(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer's update of plain (untransformed) values ASCENDING the objective whose gradient is g, in place on (p, m, v):
+    the arithmetic of opt_step_kernel (csrc/grad.hip) for transform-0 groups, for the host-side mirror of the sharded step."""
+    gr = -g
+    m *= beta1; m += (1.0 - beta1) * gr
+    v *= beta2; v += (1.0 - beta2) * gr * gr
+    p -= lr_t * m / (np.sqrt(v) + eps)
+
+
+def sharded_adam_step(group, block_p, block_g_local, m, v, lr_t, **kw):
+    """The multi-rank optimiser step of exchange mode 1 (dcgp_model_set_grad_exchange) on host arrays over a HostGroup: reduce-scatter of the
+    rank-local gradient block, Adam on this rank's shard of the parameter block, all-gather of the parameters.  Returns the updated block
+    (every rank the same).  The device runs the same three steps with ncclReduceScatter / opt_step_kernel / ncclAllGather."""
+    n = block_p.size
+    lo, hi, sh = grad_shard_range(n, group.world, group.rank)
+    g_mine = group.reduce_scatter_sum(block_g_local)
+    p_mine = block_p[lo:hi].copy()
+    adam_update(p_mine, g_mine[:hi - lo], m[lo:hi], v[lo:hi], lr_t, **kw)
+    stage = np.zeros(sh)
+    stage[:hi - lo] = p_mine
+    return group.all_gather(stage)[:n]
+
+
 def shard_batch(X, Y, zs, rank, world):
     """This rank's images, labels and noise (z is indexed [S, image, D], so a shard sees exactly the
     rows it would see in the full batch -> results are independent of the number of ranks)."""
@@ -177,6 +210,34 @@ class HostGroup:
 
         def combine(parts):
             return np.ascontiguousarray(fn(np.stack([np.frombuffer(p, np.float64) for p in parts]), axis=0)).tobytes()
+        return np.frombuffer(self._exchange(v.tobytes(), combine), np.float64).copy()
+
+    def reduce_scatter_sum(self, values):
+        """Sum over the ranks of equally long float vectors, cut into `world` equal shards (the vector padded with zeros to world * shard,
+        shard = ceil(n / world)): returns this rank's shard.  Fixed rank order: reproducible.  The host counterpart of ncclReduceScatter on a
+        layer's gradient block (grad_shard_range)."""
+        v = np.ascontiguousarray(np.atleast_1d(values), np.float64)
+        sh = -(-v.size // max(self.world, 1))
+
+        def combine(parts):
+            tot = np.zeros(sh * max(self.world, 1))
+            for p in parts:
+                a = np.frombuffer(p, np.float64)
+                if a.size != v.size:
+                    raise ValueError("reduce_scatter_sum: ranks sent %d and %d values" % (v.size, a.size))
+                tot[:a.size] += a
+            return tot.tobytes()
+        full = np.frombuffer(self._exchange(v.tobytes(), combine), np.float64)
+        return full[self.rank * sh:(self.rank + 1) * sh].copy()
+
+    def all_gather(self, shard):
+        """Every rank's (equally long) float vector, concatenated in rank order, to every rank: the host counterpart of ncclAllGather."""
+        v = np.ascontiguousarray(np.atleast_1d(shard), np.float64)
+
+        def combine(parts):
+            if any(len(p) != len(parts[0]) for p in parts):
+                raise ValueError("all_gather: ranks sent shards of different lengths")
+            return b"".join(parts)
         return np.frombuffer(self._exchange(v.tobytes(), combine), np.float64).copy()
 
     def barrier(self):

@@ -249,6 +249,20 @@ int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta
 int dcgp_model_train_step_adam(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
                                const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, double lr, double beta1,
                                double beta2, double eps, int t, double* out_host, int* info_host);
+/* Multi-rank training step (one process per GPU, dcgp_comm_init_rank): how a step's gradient is exchanged inside dcgp_model_train_step_adam.
+ * 0 (default): ncclAllReduce of every layer's gradient block, every rank then updates every parameter.  1: ncclReduceScatter of the block
+ * (each rank receives the sum of its shard only -- dcgp_shard_range), Adam on that shard of the layer's parameter block, ncclAllGather
+ * of the updated parameters: half the bytes on the links of an all-reduce + nothing, and 1 / ranks of the optimiser arithmetic per rank
+ * (the counterpart of nothing in the reference, which is single-device).  Frozen groups (dcgp_model_set_trainable)
+ * pass through unchanged.  dcgp_elbo_grad on its own always all-reduces: its caller reads whole gradients. */
+int dcgp_model_set_grad_exchange(dcgp_model* model, int mode);
+/* Shards of a block of n values over nranks ranks: every shard ceil(n / nranks) long (the collectives want equal counts), rank r holds
+ * [lo, hi) = [r * shard, min((r + 1) * shard, n)).  deepcgp_amd/dist.py grad_shard_range is the same arithmetic on the host. */
+int dcgp_shard_range(long n, int nranks, int rank, long* lo, long* hi, long* shard /* may be NULL */);
+/* Debugging aid: one Adam step taken the way `ranks` ranks take it in exchange mode 1, played on this one GPU from rank 0's point of view
+ * (shard 0 in place, the others through the staging block and the unstage pass).  Needs the complete gradient (dcgp_elbo_grad).  Bit-identical
+ * to dcgp_model_adam_step. */
+int dcgp_model_debug_sharded_adam(dcgp_model* model, int ranks, double lr, double beta1, double beta2, double eps, int t);
 /* Plain gradient ascent in the same unconstrained space (gpflow.train.GradientDescentOptimizer, the "SGD" branch
  * at conv_gp/experiment.py:100-103). */
 int dcgp_model_sgd_step(dcgp_model* model, double lr);

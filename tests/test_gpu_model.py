@@ -14,7 +14,7 @@ from golden.make_golden import unflatten_spec
 
 pytestmark = pytest.mark.gpu
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "g[0-9]*.npz")))   # (ops_*.npz: tests/test_golden_ops.py)
 RTOL = 1e-9          # fp64 end to end; the north star's bar is 1e-4
 
 
@@ -1471,3 +1471,66 @@ def test_learns_real_digits(ctx, variant):
     assert accs[0] < 0.3, accs                     # untrained: chance level (0.1)
     assert accs[-1] >= 0.93, accs
     assert elbos[1] < elbos[2] < elbos[3], elbos   # mean minibatch ELBO of steps 1-250 < 251-500 < 501-750
+
+
+def _all_params(model):
+    model.pull_parameters()
+    out = []
+    for li, l in enumerate(model.layers):
+        head = li == len(model.layers) - 1
+        kern = (l.kern.base_kernel if hasattr(l.kern, "base_kernel") else l.kern) if head else l.base_kernel
+        out += [np.array(l.feature.Z), np.array(l.q_mu), np.array(l.q_sqrt), np.array(kern.variance), np.array(kern.lengthscales)]
+        if head and hasattr(l.kern, "patch_weights"):
+            out.append(np.array(l.kern.patch_weights))
+    return out
+
+
+@pytest.mark.parametrize("head_kernel", ["conv", "rbf"])
+@pytest.mark.parametrize("ranks", [1, 2, 3, 8])
+def test_sharded_adam_step_equals_the_full_step(ctx, head_kernel, ranks):
+    """Exchange mode 1 of the multi-rank training step (dcgp_model_set_grad_exchange; SURVEY section 5: reduce-scatter -> Adam on the rank's
+    shard -> all-gather of the parameters), its device part played on one GPU: dcgp_model_debug_sharded_adam updates shard 0 of every
+    layer's parameter block in place and takes the other `ranks - 1` shards through the staging block and the unstage pass -- the block cut
+    as dcgp_shard_range cuts it, across group boundaries, with a frozen group passing through -- and must land on exactly the parameters
+    two plain dcgp_model_adam_step calls give (conv_gp/experiment.py:104-107's optimiser)."""
+    hwc, N = (12, 12, 1), 3
+    spec = syn.make_spec(hwc, [(3, 1, 2)], (3, 1), 11, S=2, num_data=200, seed=4, conv_q_sqrt_scale=0.3, variance=2.0, ls=1.5, head_kernel=head_kernel)
+    X, Y = syn.make_batch(hwc, N, seed=4)
+    res = []
+    for sharded in (False, True):
+        model = build_from_spec(spec, X, Y)
+        model.set_trainable(0, "q_mu", False)          # a frozen group in the middle of layer 0's block
+        for t in (1, 2):
+            model.compute_gradients(X, Y, zs=syn.make_noise(spec, N, seed=50 + t), fetch=False)
+            if sharded:
+                model.debug_sharded_adam(ranks, 0.05, t)
+            else:
+                model.adam_step(0.05, t)
+        res.append(_all_params(model))
+        e_after = model.compute_log_likelihood(X, Y, zs=syn.make_noise(spec, N, seed=60))
+        res[-1].append(np.array(e_after))
+        model.close()
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_rccl_single_rank_reduce_scatter_path(ctx):
+    """Exchange mode 1 under a 1-rank RCCL communicator: the training step is the plain one (one rank owns every shard), and switching
+    the mode back and forth changes nothing."""
+    from deepcgp_amd import device as dev
+    hwc = (12, 12, 1)
+    spec = syn.make_spec(hwc, [(3, 2, 4)], (3, 1), M=10, S=2, num_data=500, seed=5, conv_q_sqrt_scale=0.3)
+    X, Y = syn.make_batch(hwc, 4, seed=5)
+    outs = []
+    for mode in (0, 1):
+        model = build_from_spec(spec, X, Y)
+        ctx.comm_init(1, 0, dev.comm_unique_id())
+        try:
+            model.set_grad_exchange(mode)
+            es = [model.train_step(X, Y, 0.03, zs=syn.make_noise(spec, 4, seed=70 + t), t=t) for t in (1, 2, 3)]
+        finally:
+            dev.lib().dcgp_comm_destroy(ctx.handle)
+        outs.append(_all_params(model) + [np.array(es)])
+        model.close()
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)

@@ -332,3 +332,24 @@ def test_optimiser_schedules_match_the_reference_formulas():
     assert abs(natgrad_gamma(5000, 0.001) - (50 * 1e-3 + 0.001)) < 1e-15
     assert abs(natgrad_gamma(5000, 0.001, steps_back=2) - (50 * 1e-3 + 0.001) * 0.04) < 1e-15
     assert natgrad_gamma(10 ** 9) == 1.0
+
+
+def test_shard_range_of_the_library_equals_the_host_arithmetic():
+    """dcgp_shard_range (the cut of a layer's parameter block in exchange mode 1 of the multi-rank training step; pure host arithmetic, no
+    device needed) == deepcgp_amd.dist.grad_shard_range; the shards tile the block, are equally long up to the last, and world * shard
+    covers it with at most world - 1 values of padding (the gradient blocks carry 64)."""
+    import ctypes as C
+    from deepcgp_amd import device as dev
+    from deepcgp_amd.dist import grad_shard_range
+    L = dev.lib()
+    for n in (0, 1, 2, 7, 8, 9, 1000, 1001, 65536 * 10 + 2819):
+        for world in (1, 2, 3, 8, 64):
+            prev = 0
+            for r in range(world):
+                lo, hi, sh = C.c_long(), C.c_long(), C.c_long()
+                assert L.dcgp_shard_range(n, world, r, C.byref(lo), C.byref(hi), C.byref(sh)) == 0
+                assert (lo.value, hi.value, sh.value) == grad_shard_range(n, world, r)
+                assert lo.value == prev and hi.value - lo.value <= sh.value
+                prev = hi.value
+            assert prev == n and sh.value * world - n <= max(world - 1, 0)
+    assert L.dcgp_shard_range(10, 4, 4, C.byref(lo), C.byref(hi), None) != 0       # rank out of range

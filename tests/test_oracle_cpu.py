@@ -17,7 +17,7 @@ from oracle.dgp import SVGP_Layer
 from oracle_build import oracle_model
 from golden.make_golden import unflatten_spec
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "g[0-9]*.npz")))   # (ops_*.npz: tests/test_golden_ops.py)
 
 
 def test_reference_test_shape_facts():
@@ -354,3 +354,19 @@ def test_oracle_full_cov_branch_agrees_with_the_marginal_path_and_the_closed_for
     m2, v2 = layer.conditional_ND(X, full_cov=True)
     assert v2.shape == (4, 4, layer.num_outputs) and np.allclose(m1, m2)
     assert np.allclose(np.einsum("nnd->nd", v2), v1, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("hwc,convs,head,M,white", [((12, 12, 1), [(3, 2, 4)], (3, 1), 24, False), ((14, 14, 2), [(4, 2, 3), (3, 1, 2)], (3, 1), 17, False),
+                                                     ((10, 10, 1), [(3, 1, 3)], (3, 1), 9, True), ((12, 12, 1), [], (5, 1), 20, False)])
+def test_batched_best_cpu_form_equals_the_reference_order_oracle(hwc, convs, head, M, white):
+    """oracle/fast_cpu.py (bench.py's `cpu_baseline.best_cpu` row: one triangular solve over all K columns, one (R M) x M x K GEMM) is the
+    same ELBO as the oracle in the reference's operation order (conv_gp/conditionals.py:29-65 under map_fn)."""
+    from deepcgp_amd import synthetic as syn
+    from oracle import fast_cpu
+    spec = syn.make_spec(hwc, convs, head, M, S=3, num_data=500, seed=5, white=white, conv_q_sqrt_scale=0.3)
+    X, Y = syn.make_batch(hwc, 5, seed=5)
+    zs = syn.make_noise(spec, 5, seed=5)
+    m = oracle_model(spec, X, Y)
+    want = (m.compute_log_likelihood(X, Y, zs=zs), m.data_term(X, Y, zs=zs), m.KL())
+    got = fast_cpu.elbo(spec, X, Y, zs=zs)
+    np.testing.assert_allclose(got, want, rtol=1e-10)
