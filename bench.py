@@ -147,6 +147,86 @@ def cpu_baseline(name, S, batch, budget_s=30.0):
     return out
 
 
+def dry_run(args, rank, world, local_rank):
+    """`bench.py --gpus N --dry-run [--inject ...]`: the multi-rank set-up of main() and nothing else, with faults on request, so that the
+    first real 8-GPU run cannot hang silently.  Every wait is bounded (DCGP_HOSTGROUP_TIMEOUT seconds, default 120; the dry run uses 20);
+    a rank that cannot go on says why on stderr and exits non-zero -- spawn_ranks / the launcher then stops the others.  Rank 0 prints one
+    JSON line: which communication path the ranks agreed on and what each step of the walk took."""
+    faults = {}
+    for f in filter(None, args.inject.split(",")):
+        k, _, v = f.partition(":")
+        faults.setdefault(k, []).append(float(v) if k == "late_id" else int(v))
+    t0 = time.perf_counter()
+    events = []
+
+    def mark(what):
+        events.append({"step": what, "t_s": round(time.perf_counter() - t0, 3)})
+    if rank in faults.get("die_before_init", []):
+        print("rank %d: injected fault: dying before the rendezvous" % rank, file=sys.stderr)
+        return 7
+    os.environ.setdefault("DCGP_HOSTGROUP_TIMEOUT", "20")
+    try:
+        grp = HostGroup(rank, world)
+    except (TimeoutError, OSError) as exc:
+        print("rank %d: rendezvous failed: %r" % (rank, exc), file=sys.stderr)
+        return 3
+    mark("host group of %d ranks met" % world)
+    try:
+        n_dev = dev.device_count()
+    except Exception:                                   # noqa: BLE001 -- no library / no GPU: the walk is simulated
+        n_dev = 0
+    ctx = None
+    if n_dev > 0:
+        ctx = dev.Context(local_rank if n_dev > local_rank else local_rank % n_dev)
+    comm, rccl_ranks, ok = "host", 0, 1
+    try:
+        if rank in faults.get("no_rccl", []):
+            raise RuntimeError("injected fault: librccl could not be loaded")
+        if rank == 0:
+            for d in faults.get("late_id", []):
+                time.sleep(d)
+            uid = dev.comm_unique_id() if ctx is not None else bytes(range(128))
+        else:
+            uid = bytes(128)
+        uid = grp.broadcast_bytes(uid)
+        mark("RCCL id broadcast (%d bytes)" % len(uid))
+        if rank in faults.get("init_fail", []):
+            raise RuntimeError("injected fault: ncclCommInitRank failed")
+        if ctx is not None:
+            ctx.comm_init(world, rank, uid)         # (two ranks on one device: RCCL refuses -- the real failure path)
+        mark("dcgp_comm_init_rank")
+    except Exception as exc:                            # noqa: BLE001 -- any failure must reach the collective vote below
+        ok = 0
+        print("rank %d: RCCL init failed (%s); voting for the host all-reduce" % (rank, exc), file=sys.stderr)
+        if rank in faults.get("no_rccl", []):
+            grp.broadcast_bytes(b"")                    # (keep the group's exchanges in step: the others are in the id broadcast)
+    try:
+        agreed = int(grp.allreduce([ok], "min")[0])
+        mark("vote: %s" % ("RCCL on every rank" if agreed else "some rank without RCCL -> host all-reduce on all"))
+        if agreed:
+            comm = "rccl"
+            rccl_ranks = ctx.comm_count() if ctx is not None else world
+        elif ctx is not None:
+            ctx.comm_destroy()
+        # one data-term-sized exchange on the agreed path (the host path is the group itself; the device path needs a GPU)
+        total = float(grp.allreduce([float(rank + 1)], "sum")[0])
+        assert total == world * (world + 1) / 2
+        if comm == "rccl" and ctx is not None:
+            buf = ctx.to_device(np.array([float(rank + 1)]))
+            ctx.allreduce_sum(buf)
+            assert float(buf.numpy()[0]) == total
+        mark("one all-reduce on the agreed path")
+        grp.barrier()
+        grp.close()
+    except Exception as exc:                            # noqa: BLE001
+        print("rank %d: dry run failed behind the vote: %r" % (rank, exc), file=sys.stderr)
+        return 4
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "comm": comm, "ranks_seen_by_rccl": rccl_ranks, "devices_visible": n_dev,
+                          "simulated_device_calls": ctx is None, "faults": args.inject, "events": events}))
+    return 0
+
+
 class Leg:
     """One sharded workload on this rank: the model, its device-resident shard and the step function."""
 
@@ -401,6 +481,13 @@ def main():
     ap.add_argument("--no-all-configs", action="store_true", help="skip the strong-scaling preview of the other BASELINE configurations")
     ap.add_argument("--profile", action="store_true",
                     help="for rocprofv3 runs: exactly --warmup + --steps steps, none of the extra regions, no CPU baseline")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="N > 1 readiness check: walk the multi-rank set-up only -- rendezvous of the host group, broadcast of the RCCL id, "
+                         "dcgp_comm_init_rank on every rank, the collective vote and the host-join fallback -- print one JSON line and exit; "
+                         "no model, no timing.  Without a GPU the device calls are simulated (the control flow is what is walked)")
+    ap.add_argument("--inject", type=str, default="",
+                    help="--dry-run only, comma-separated faults: die_before_init:R (rank R exits before the rendezvous), late_id:SECONDS "
+                         "(rank 0 draws the id late), no_rccl:R (librccl missing on rank R), init_fail:R (ncclCommInitRank fails on rank R)")
     ap.add_argument("--comm", type=str, default="rccl", choices=["rccl", "host"],
                     help="N > 1: rccl = in-stream ncclAllReduce inside dcgp_elbo_forward (default); host = host-group "
                          "all-reduce of the per-rank data term (debug / fallback when RCCL cannot initialise)")
@@ -416,6 +503,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    if args.dry_run:
+        raise SystemExit(dry_run(args, rank, world, local_rank))
     grp = HostGroup(rank, world)
     n_dev = dev.device_count()
     ctx = dev.Context(local_rank if n_dev > local_rank else local_rank % max(n_dev, 1))

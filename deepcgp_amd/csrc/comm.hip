@@ -112,7 +112,39 @@ int all_gather_f64_async(dcgp_ctx* ctx, double* block_dev, size_t shard) {
   return DCGP_OK;
 }
 
+// debugging aid (dcgp_debug_comm_gate): holds the comm stream until the host opens the gate -- or ~4 s have passed: a test must not hang a GPU
+__global__ void comm_gate_kernel(const int* gate) {
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 && wall_clock64() - t0 < 400000000LL) __builtin_amdgcn_s_sleep(32);
+}
+int comm_gate_wait(dcgp_ctx* ctx) {
+  int* dgate = nullptr;
+  if (hipHostGetDevicePointer((void**)&dgate, ctx->comm_gate, 0) != hipSuccess) return ctx_fail(ctx, DCGP_ERR_HIP, "comm gate not mapped");
+  hipLaunchKernelGGL(comm_gate_kernel, dim3(1), dim3(1), 0, ctx->stream, dgate);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
 extern "C" {
+
+// Debugging aid for the test that the data term's all-reduce of a step in flight does not hold up the next step (tests/test_gpu_model.py):
+// closed != 0: every all-reduce enqueued on the comm stream from now on first waits for the gate; closed == 0: opens it (and removes it).
+// main_idle_out (may be NULL): bit 0 -- the ctx's main stream has nothing left to do right now (hipStreamQuery), bit 1 -- nor has the comm stream.
+int dcgp_debug_comm_gate(dcgp_ctx* ctx, int closed, int* main_idle_out) {
+  if (!ctx) return DCGP_ERR_ARG;
+  if (closed && !ctx->comm_gate) {
+    if (hipHostMalloc((void**)&ctx->comm_gate, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return ctx_fail(ctx, DCGP_ERR_ALLOC, "comm gate");
+    *ctx->comm_gate = 0;
+  } else if (!closed && ctx->comm_gate) {
+    __atomic_store_n(ctx->comm_gate, 1, __ATOMIC_SEQ_CST);
+    if (ctx->stream_comm) hipStreamSynchronize(ctx->stream_comm);
+    hipHostFree(ctx->comm_gate);
+    ctx->comm_gate = nullptr;
+  }
+  if (main_idle_out)
+    *main_idle_out = (hipStreamQuery(ctx->stream) == hipSuccess ? 1 : 0) | ((!ctx->stream_comm || hipStreamQuery(ctx->stream_comm) == hipSuccess) ? 2 : 0);
+  return DCGP_OK;
+}
 
 // Contiguous shards of a block of n values over nranks ranks, every shard the same length ceil(n / nranks) (the collectives want equal
 // counts: the block is padded to nranks * shard): rank r holds [r * shard, min((r + 1) * shard, n)).  deepcgp_amd/dist.py: grad_shard_range.

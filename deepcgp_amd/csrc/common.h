@@ -54,6 +54,7 @@ struct DcgpOptions {
   long sync_event = 0;           // wait for the step's event instead of polling its completion word
   long chain_graph = 0;          // the factorisation chain's panel launches replayed from a captured HIP graph (measured slower: see chol_fused.hip)
   long chain_no_iso = 0;         // chain launches that carry right-hand sides: no XCD isolation of the look-ahead workgroups (A/B)
+  long comm_inline = 0;          // multi-rank steps in flight: the data term's all-reduce in the main stream instead of the comm stream (A/B)
   long no_rhs_ride = 0;          // G / alpha by their own launch behind the chain (prep_solve) instead of riding its panel launches
   long kuf_upw = 0;              // units per wave of the storing sweep (0: chosen by head_units_plan)
   long kuf_split = -1;           // storing sweep with replicas: column-fragment ranges per row fragment (-1: chosen; 0: one)
@@ -82,6 +83,10 @@ struct dcgp_ctx {
   // parameter-only chain of step i + 1 on the other 2 (hipExtStreamCreateWithCUMask; nullptr when the device is not 8 x 32 CUs)
   hipStream_t stream2b = nullptr;  // second side stream: the chain of a step enqueued while the previous one is in flight (bank 1)
   hipStream_t stream_aux = nullptr;   // short excursions beside the main stream inside a layer (the head's Kdiag)
+  hipStream_t stream_comm = nullptr;  // created on first use: the data term's all-reduce + ELBO assembly of a step kept in flight / followed by its reverse
+                                      // pass, so that the next step's (or the reverse pass's) kernels on the main stream do not queue behind the collective
+  hipEvent_t ev_comm[4] = {};         // main -> comm stream, one per result-ring slot
+  int* comm_gate = nullptr;           // debugging aid (dcgp_debug_comm_gate): pinned word; != null: the comm stream's work waits for it to become non-zero
   hipStream_t stream_m = nullptr, stream2_m = nullptr;
   hipStream_t last_main = nullptr;             // main stream of the most recent forward step ...
   hipEvent_t ev_last = nullptr;                // ... and the event marking the end of that step on it (not owned; a step on the other main stream waits for it)
@@ -367,6 +372,7 @@ constexpr int kChainRhsMaxMp = 256;   // beyond: the substitution's workgroups o
 // d_rhs != nullptr (device array, one entry per matrix; max_R = the largest R among them): right-hand sides ride the chain.
 int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_Linv, double* const* d_LinvT, int batch,
                            int Mp, int ld, int* d_info, bool defer_finish = false, const ChainRhs* d_rhs = nullptr, int max_R = 0);
+int comm_gate_wait(dcgp_ctx* ctx);   // comm.hip (debugging aid)
 int reduce_scatter_sum_f64_async(dcgp_ctx* ctx, double* block_dev, size_t shard);   // comm.hip (in place, this rank's shard)
 int all_gather_f64_async(dcgp_ctx* ctx, double* block_dev, size_t shard);
 int factor_finish_batched(dcgp_ctx* ctx, double* const* d_A, int batch, int Mp, int ld);

@@ -27,7 +27,7 @@ const OptSlot kOptSlots[] = {
     {"grad_nofork", &DcgpOptions::grad_nofork}, {"chol_one_launch", &DcgpOptions::chol_one_launch},
     {"chol_no_lookahead", &DcgpOptions::chol_no_lookahead}, {"head_no_overlap", &DcgpOptions::head_no_overlap},
     {"no_early_sweep", &DcgpOptions::no_early_sweep}, {"sync_event", &DcgpOptions::sync_event}, {"kuf_upw", &DcgpOptions::kuf_upw},
-    {"chain_graph", &DcgpOptions::chain_graph}, {"no_rhs_ride", &DcgpOptions::no_rhs_ride}, {"chain_no_iso", &DcgpOptions::chain_no_iso}, {"kuf_no_rep", &DcgpOptions::kuf_no_rep}, {"kuf_stream", &DcgpOptions::kuf_stream},
+    {"chain_graph", &DcgpOptions::chain_graph}, {"no_rhs_ride", &DcgpOptions::no_rhs_ride}, {"comm_inline", &DcgpOptions::comm_inline}, {"chain_no_iso", &DcgpOptions::chain_no_iso}, {"kuf_no_rep", &DcgpOptions::kuf_no_rep}, {"kuf_stream", &DcgpOptions::kuf_stream},
     {"kuf_wpg", &DcgpOptions::kuf_wpg}, {"kuf_split", &DcgpOptions::kuf_split}, {"head_tail", &DcgpOptions::head_tail},
     {"sweep_occ", &DcgpOptions::sweep_occ}, {"share_kb", &DcgpOptions::share_kb}, {"head_upw", &DcgpOptions::head_upw},
     {"fused_abl", &DcgpOptions::fused_abl}, {"rb_mixed", &DcgpOptions::rb_mixed},
@@ -233,6 +233,8 @@ int dcgp_ctx_destroy(dcgp_ctx* ctx) {
   for (auto e : ctx->event_pool) hipEventDestroy(e);
   hipHostFree(ctx->h_scratch);
   hipHostFree(ctx->h_info);
+  if (ctx->comm_gate) hipHostFree(ctx->comm_gate);
+  if (ctx->stream_comm) { hipStreamDestroy(ctx->stream_comm); for (auto e : ctx->ev_comm) if (e) hipEventDestroy(e); }
   hipEventDestroy(ctx->ev_fork);
   hipEventDestroy(ctx->ev_factor);
   hipEventDestroy(ctx->ev_aux);

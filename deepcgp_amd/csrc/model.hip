@@ -640,6 +640,22 @@ int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t*
     // multi-GPU: the data term is summed over the ranks between the reduction and the assembly
     ElboFinish none;
     DCGP_TRY(elbo_tail(ctx, o.mean, o.var, y, rows, N, H.R, model->eps, model->d_ve, inv_s, scal, none, klt));
+    // A step kept in flight: collective and assembly go to the comm stream behind one event, and the main stream is free for the next step's
+    // data path at once -- in stream, a 1-double ncclAllReduce (~20 us of latency over xGMI, more when a rank is late) sat in front of the next
+    // step's layer kernel.  What it reads (scal of this bank, the chain's status words) stays untouched until the bank's next writer, which
+    // waits for this step's ring event (forward_all: done_ev).  (Not for a training step: its gradient collectives follow on the main stream,
+    // and one communicator's collectives stay on one stream.)
+    const bool side_comm = pipelined && !model->grad_follows && !ctx->no_side && !ctx->opt.comm_inline;
+    if (side_comm) {
+      if (!ctx->stream_comm) {
+        if (hipStreamCreateWithFlags(&ctx->stream_comm, hipStreamNonBlocking) != hipSuccess) return ctx_fail(ctx, DCGP_ERR_HIP, "comm stream");
+        for (auto& e : ctx->ev_comm) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      }
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_comm[slot], ctx->stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_comm, ctx->ev_comm[slot], 0));
+      ctx->stream = ctx->stream_comm;   // (the StreamGuard above restores the caller's stream)
+      if (ctx->comm_gate) DCGP_TRY(comm_gate_wait(ctx));
+    }
     DCGP_TRY(allreduce_sum_f64_async(ctx, scal, 1));
     CombineArgs c;
     c.nl = nl; c.scale = scale;

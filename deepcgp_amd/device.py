@@ -109,6 +109,7 @@ _SIGS = {
                              _i, _i, _i, _i, _d, _i, _vp, C.c_long, _vp, C.c_long, C.c_long, _i],
     "dcgp_kmeans": [_vp, _vp, C.c_long, _i, _i, _vp, _i, _d, _vp, _ip],
     "dcgp_debug_set_fused_trace": [_vp, _vp],
+    "dcgp_debug_comm_gate": [_vp, _i, _ip],
     "dcgp_debug_mfma_f64_rate": [_vp, _dp],
     "dcgp_debug_store_rate": [_vp, _i, _i, _i, _dp],
     "dcgp_debug_set_sweep_trace": [_vp, _vp, C.c_long, C.c_char_p],

@@ -122,7 +122,9 @@ def rendezvous_file():
 class HostGroup:
     """Star-topology host process group: ``broadcast_bytes``, ``allreduce`` (small float vectors), ``barrier``."""
 
-    def __init__(self, rank, world, addr=None, path=None, timeout=120.0):
+    def __init__(self, rank, world, addr=None, path=None, timeout=None):
+        if timeout is None:
+            timeout = float(os.environ.get("DCGP_HOSTGROUP_TIMEOUT", "120"))   # every wait of the group is bounded by it
         self.rank, self.world = int(rank), int(world)
         self._peers, self._sock, self._path = [], None, None
         if self.world <= 1:

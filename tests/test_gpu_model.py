@@ -1534,3 +1534,49 @@ def test_rccl_single_rank_reduce_scatter_path(ctx):
         model.close()
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
+
+
+def test_allreduce_of_a_step_in_flight_does_not_hold_up_the_next_step(ctx):
+    """SURVEY 8(e) / the review's item 6c, on one GPU with a 1-rank RCCL communicator: with steps kept in flight the data term's
+    ncclAllReduce + ELBO assembly of step i run on the comm stream, so step i + 1's kernels on the main stream do not queue behind the
+    collective.  Causal check: the comm stream is GATED (dcgp_debug_comm_gate) -- step 0's all-reduce cannot run -- two steps are enqueued,
+    and the main stream must drain all the same (both data paths done) while neither result is there; the gate opens, both results
+    arrive and equal the ungated ones.  With the collective in the main stream (ctx option comm_inline) the same schedule cannot drain."""
+    import ctypes as C
+    import time
+    from deepcgp_amd import device as dev
+    hwc = (12, 12, 1)
+    spec = syn.make_spec(hwc, [(3, 2, 4)], (3, 1), M=10, S=2, num_data=500, seed=5, conv_q_sqrt_scale=0.3)
+    X, Y = syn.make_batch(hwc, 4, seed=5)
+    zs = syn.make_noise(spec, 4, seed=5)
+    model = build_from_spec(spec, X, Y)
+    L = dev.lib()
+    idle = C.c_int(0)
+
+    def main_idle_within(seconds):
+        t0 = time.time()
+        while time.time() - t0 < seconds:
+            ctx._check(L.dcgp_debug_comm_gate(ctx.handle, 1, C.byref(idle)))
+            if idle.value & 1:
+                return True
+            time.sleep(0.01)
+        return False
+    ctx.comm_init(1, 0, dev.comm_unique_id())
+    try:
+        want = [model.collect_log_likelihood(model.enqueue_log_likelihood(X, Y, zs=zs, seed=s)) for s in (1, 2)]
+        ctx._check(L.dcgp_debug_comm_gate(ctx.handle, 1, None))                    # close the gate
+        tickets = [model.enqueue_log_likelihood(X, Y, zs=zs, seed=s) for s in (1, 2)]
+        assert main_idle_within(2.0), "the main stream waits for the gated all-reduce: the collective is not on the comm stream"
+        assert not (idle.value & 2)                                                # ... while the comm stream still sits at the gate: no result yet
+        ctx._check(L.dcgp_debug_comm_gate(ctx.handle, 0, None))                    # open it
+        assert [model.collect_log_likelihood(t) for t in tickets] == want
+        with ctx.options(comm_inline=1):                                           # the A/B: collective in the main stream
+            ctx._check(L.dcgp_debug_comm_gate(ctx.handle, 1, None))
+            tickets = [model.enqueue_log_likelihood(X, Y, zs=zs, seed=s) for s in (1, 2)]
+            assert main_idle_within(1.0) and (idle.value & 2)      # nothing went to the comm stream: the whole step drains by itself
+            ctx._check(L.dcgp_debug_comm_gate(ctx.handle, 0, None))
+            assert [model.collect_log_likelihood(t) for t in tickets] == want
+    finally:
+        L.dcgp_debug_comm_gate(ctx.handle, 0, None)
+        L.dcgp_comm_destroy(ctx.handle)
+    model.close()

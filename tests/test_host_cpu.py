@@ -353,3 +353,36 @@ def test_shard_range_of_the_library_equals_the_host_arithmetic():
                 prev = hi.value
             assert prev == n and sh.value * world - n <= max(world - 1, 0)
     assert L.dcgp_shard_range(10, 4, 4, C.byref(lo), C.byref(hi), None) != 0       # rank out of range
+
+
+def _dry(args, timeout=90, launcher=False):
+    import json as _json
+    import time as _time
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("DCGP_RDZV_FILE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", args[1], "--master-addr", "127.0.0.1",
+               "--master-port", "29741", os.path.join(ROOT, "bench.py")] + args
+    t0 = _time.time()
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out.returncode, (_json.loads(lines[-1]) if lines else None), out.stderr, _time.time() - t0
+
+
+def test_bench_dry_run_walks_the_multi_rank_set_up_and_its_failure_paths():
+    """`bench.py --gpus N --dry-run` (no GPU here: device calls simulated, the control flow is the product's): rendezvous, RCCL id broadcast,
+    dcgp_comm_init_rank, the collective vote, one all-reduce on the agreed path -- and with injected faults the run either agrees on the
+    host fallback or ends with a non-zero status in bounded time; nothing hangs."""
+    rc, line, err, _ = _dry(["--gpus", "3", "--dry-run"])
+    assert rc == 0 and line["dry_run"] and line["comm"] == "rccl" and line["n_gpus"] == 3 and len(line["events"]) == 5, (rc, line, err)
+    for fault in ("no_rccl:1", "no_rccl:0", "init_fail:2"):                      # one rank without RCCL: every rank falls back together
+        rc, line, err, _ = _dry(["--gpus", "3", "--dry-run", "--inject", fault])
+        assert rc == 0 and line["comm"] == "host" and line["ranks_seen_by_rccl"] == 0, (fault, rc, line, err)
+        assert "voting for the host all-reduce" in err
+    rc, line, err, dt = _dry(["--gpus", "2", "--dry-run", "--inject", "late_id:1.5"])      # the id arrives late: the others wait for it
+    assert rc == 0 and line["comm"] == "rccl" and line["events"][1]["t_s"] >= 1.5, (rc, line, err)
+    rc, line, err, dt = _dry(["--gpus", "3", "--dry-run", "--inject", "die_before_init:1"])   # a rank dies before the rendezvous
+    assert rc == 7 and line is None and dt < 40, (rc, line, err, dt)
+    rc, line, err, _ = _dry(["--gpus", "2", "--dry-run", "--inject", "init_fail:1"], launcher=True, timeout=180)   # the driver's launcher
+    assert rc == 0 and line["comm"] == "host", (rc, line, err)
