@@ -395,6 +395,134 @@ __device__ __forceinline__ int potrf_inv32_halves(double (*D)[LD], double (*Xs)[
   return fail;
 }
 
+
+// The whole workgroup (4 waves) on the 32 x 32 block (round 5).  Wave 0 runs the two 16 x 16 recurrences (halves layout) and the block products
+// between them in LDL^T form -- UNSCALED columns: L = Lt diag(y), inv(L) = diag(y) Xt, y = 1 / sqrt(piv), r = 1 / piv = y^2 -- so that no
+// square root, no broadcast of y and no scaling pass sits on its path:  Pt = A21 Xt11^T,  A22 -= (Pt diag(r1)) Pt^T,
+// Xt21 = -Xt22 ((Pt diag(r1)) Xt11).  The other waves do what is off that path while it runs: zero the upper-right block of the inverse,
+// T = (Pt diag(r1)) Xt11, the scalings of L11 / inv(L)11 (then L21, L22), each behind one of two workgroup barriers.  (tools/diag_bench.hip: the
+// one-wave form spent 5200 of its 9300 cycles outside the two recurrences -- y through an LDS line, 16 multiplies and 32 stores per block, three
+// LDS round trips of block products.)  Call with all 256 threads; ends without a barrier (callers synchronise before reading D / Xs).
+// D: lower triangle of the block on entry (zero above), L on return; Xs: inv(L); line: 96 doubles, 16-byte aligned; T: 16 x 17; sc: 64 doubles.
+// Returns (wave 0) 0 or the 1-based column of the first non-positive pivot.
+template <int LD>
+__device__ __forceinline__ int potrf_inv32_wg(double (*D)[LD], double (*Xs)[LD], double* line, double (*T)[17], double* sc, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, lrow = lane >> 4, lcol = lane & 15;
+  const int h = lane >> 5, i = lane & 31;
+  int fail = 0;
+  double* r1 = sc, *y1 = sc + 16, *y2 = sc + 48;
+  if (wave == 0) {
+    double x[8], lc[16], pv;
+    {
+      const int rr = i < 16 ? i : 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = 2 * k + h;
+        const double a = (c <= rr) ? D[rr][c] : D[c][rr];
+        x[k] = i < 16 ? a : (i - 16 == c ? 1.0 : 0.0);
+      }
+    }
+    block16_halves(x, lc, pv, lane, line);
+    {
+      const unsigned long long bad = __ballot(lane < 16 && !(pv > 0.0));
+      if (bad) fail = __ffsll((long long)bad);
+      if (lane < 16) {
+        r1[lane] = rcp_nr(pv);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) D[lane][c] = lc[c];              // Lt11 raw (the scaling pass zeroes above the diagonal)
+      } else if (lane < 32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Xs[r][lane - 16] = lc[r];        // Xt11 raw (exact zeros above the diagonal)
+      }
+    }
+    DCGP_WAVE_LDS_SYNC();
+    {
+      d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[16 + lcol][4 * s + lrow], Xs[lcol][4 * s + lrow], acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) D[16 + lrow + 4 * q][lcol] = acc[q];   // Pt
+    }
+  } else {
+    for (int e = tid - 64; e < 256; e += 192) Xs[e >> 4][16 + (e & 15)] = 0.0;   // the inverse's upper-right block
+  }
+  __syncthreads();   // B1: Lt11, Xt11, r1, Pt are there
+  if (wave == 0) {
+    {
+      d4 a2 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double a = D[16 + lcol][4 * s + lrow];
+        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a * r1[4 * s + lrow], a, a2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) D[16 + lrow + 4 * q][16 + lcol] -= a2[q];
+    }
+    DCGP_WAVE_LDS_SYNC();
+    double x[8], lc[16], pv;
+    {
+      const int rr = i < 16 ? i : 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = 2 * k + h;
+        const double a = (c <= rr) ? D[16 + rr][16 + c] : D[16 + c][16 + rr];
+        x[k] = i < 16 ? a : (i - 16 == c ? 1.0 : 0.0);
+      }
+    }
+    block16_halves(x, lc, pv, lane, line);
+    {
+      const unsigned long long bad = __ballot(lane < 16 && !(pv > 0.0));
+      if (bad && fail == 0) fail = 16 + __ffsll((long long)bad);
+      if (lane < 16) {
+        y2[lane] = rsqrt_nr(pv);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) D[16 + lane][16 + c] = lc[c];
+      } else if (lane < 32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Xs[16 + r][lane] = lc[r];
+      }
+    }
+  } else if (wave == 1) {
+    // T = (Pt diag(r1)) Xt11, then y1 and inv(L)11 = diag(y1) Xt11 in place (nobody reads Xt11 any more)
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[16 + lcol][4 * s + lrow] * r1[4 * s + lrow], Xs[4 * s + lrow][lcol], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T[lrow + 4 * q][lcol] = acc[q];
+    if (lane < 16) { const double r = r1[lane]; y1[lane] = r * rsqrt_nr(r); }
+    DCGP_WAVE_LDS_SYNC();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Xs[lrow + 4 * q][lcol] *= y1[lrow + 4 * q];
+  } else if (wave == 2) {
+    // L11 = Lt11 diag(y1), zero above the diagonal
+    const double r = r1[lcol], yc = r * rsqrt_nr(r);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int rw = lrow + 4 * q; D[rw][lcol] = lcol <= rw ? D[rw][lcol] * yc : 0.0; }
+  }
+  __syncthreads();   // B2: block 2's raw results, T, y1, y2
+  if (wave == 0) {
+    d4 xx = d4{0.0, 0.0, 0.0, 0.0};
+    double yv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) yv[q] = y2[lrow + 4 * q];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xx = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[16 + lcol][16 + 4 * s + lrow], T[4 * s + lrow][lcol], xx, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      Xs[16 + lrow + 4 * q][lcol] = -xx[q] * yv[q];                     // inv(L)21 = -diag(y2) Xt22 T
+      Xs[16 + lrow + 4 * q][16 + lcol] *= yv[q];                        // inv(L)22 = diag(y2) Xt22 (this wave's own reads of Xt22 are done)
+    }
+  } else if (wave == 1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) D[16 + lrow + 4 * q][lcol] *= y1[lcol];                                  // L21 = Pt diag(y1)
+  } else if (wave == 2) {
+    const double yc = y2[lcol];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int rw = lrow + 4 * q; D[16 + rw][16 + lcol] = lcol <= rw ? D[16 + rw][16 + lcol] * yc : 0.0; }   // L22
+  }
+  return fail;
+}
+
 // Column c of inv(L) for a 32x32 lower-triangular L held in LDS (D) with its reciprocal diagonal (Dr):
 // forward substitution, the row of L being read as broadcast loads once per step.
 __device__ __forceinline__ void lane_trtri32(const double (*D)[NB + 1], const double* Dr, int c, double (&x)[NB]) {

@@ -167,7 +167,7 @@ __device__ __forceinline__ void panel_store(double (*U)[NB + 1], int wm, int wn,
 // right-hand side itself, later ones from the scratch Yw.  The item on the diagonal also writes the structural zeros to the right of its
 // final rows, so G needs no clearing.
 __device__ __forceinline__ void rhs_tile(const RlArgs& a, const int b, const int idx, double (*D)[NB + 1], double (*Xs)[NB + 1], double (&col)[COL_N],
-                                         double (*Tp)[17], double (*Ui)[NB + 1], double* UcTs) {
+                                         double (*Tp)[17], double (*Ui)[NB + 1], double* UcTs, double* sc) {
   double (*Ts)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(UcTs);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane >> 4, lcol = lane & 15;
   const ChainRhs d = a.rhs[b];
@@ -260,7 +260,7 @@ __device__ __forceinline__ void rhs_tile(const RlArgs& a, const int b, const int
   }
   __syncthreads();
   if (final_only && !have_x) {
-    if (tid < 64) potrf_inv32(D, Xs, col, Tp, tid);
+    potrf_inv32_wg<NB + 1>(D, Xs, col, Tp, sc, tid);
     __syncthreads();
   }
 
@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   __shared__ double Ui[64][NB + 1];
   __shared__ double UcTs[64 * (NB + 1)];   // trailing tiles: second panel row block; inverse tiles: the Y tile
   __shared__ double Xs[NB][NB + 1];   // inv(L_jj)
-  __shared__ double Tp[16][17];       // scratch of the two-panel factorisation
+  __shared__ double Tp[16][17];       // scratch of the diagonal block's factorisation
+  __shared__ double sc[64];           // ... (reciprocal pivots and scalings)
   double (*Uc)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(UcTs);
   double (*Ts)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(UcTs);   // [NB][65]: old Y rows, then new
   static_assert(NB * 65 <= 64 * (NB + 1), "Y tile fits the shared slot");
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   if (bx == a.la_idx) __builtin_amdgcn_s_setprio(3);
   else __builtin_amdgcn_s_setprio(2);
   if (a.rhs && bx >= a.rhs_base) {   // a right-hand side riding the chain
-    rhs_tile(a, b, bx - a.rhs_base, D, Xs, col, Tp, Ui, UcTs);
+    rhs_tile(a, b, bx - a.rhs_base, D, Xs, col, Tp, Ui, UcTs, sc);
     return;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -486,9 +487,9 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   TR(1)
   // ---- L_jj and inv(L_jj): one wavefront (unless the previous launch left them) ----
   int fail_j = 0;
-  if (!have_x && tid < 64) {
-    const int fail = potrf_inv32(D, Xs, col, Tp, tid);
-    fail_j = fail;
+  if (!have_x) {
+    const int fail = potrf_inv32_wg<NB + 1>(D, Xs, col, Tp, sc, tid);   // (all four waves; the status is wave 0's)
+    if (tid < 64) fail_j = fail;
     // (with a look-ahead workgroup in the launch it is the one writer of the status word: it sees this panel's failure too)
     if (tid == 0 && bx == 0 && a.la_idx < 0 && (j == 0 || (fail && a.info[b] == 0))) a.info[b] = fail ? j + fail : 0;
   }
@@ -528,8 +529,7 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
     }
     __syncthreads();
     TR(3)
-    int fail = 0;
-    if (tid < 64) fail = potrf_inv32(D, Xs, col, Tp, tid);
+    const int fail = potrf_inv32_wg<NB + 1>(D, Xs, col, Tp, sc, tid);
     __syncthreads();
     TR(4)
 #pragma unroll

@@ -1,6 +1,4 @@
 // Microbenchmark of the 32 x 32 diagonal-block factor + inverse variants (one wavefront of a 256-thread workgroup).
-__device__ long long g_stamp[16];
-#define DIAG_STAMP(k) if (lane == 0) g_stamp[k] = clock64();
 #include "diag_variants.h"
 #include <cstdio>
 #include <cmath>
@@ -12,12 +10,17 @@ __global__ __launch_bounds__(256, 2) void kb(const double* __restrict__ Ain, dou
   __shared__ double Xs[NB][NB + 1];
   __shared__ __attribute__((aligned(16))) double col[96];
   __shared__ double T[16][17];
+  __shared__ double sc[64];
   const int tid = threadIdx.x;
   long long tot = 0, wtot = 0; int fail = 0;
   for (int rep = 0; rep < reps; ++rep) {
     for (int idx = tid; idx < NB * NB; idx += 256) D[idx / NB][idx % NB] = (idx % NB <= idx / NB) ? Ain[idx] : ((idx % NB == idx / NB) ? 1.0 : 0.0);
     __syncthreads();
-    if (tid < 64) {
+    if constexpr (MODE == 5) {
+      const long long c0 = clock64(), w0 = wall_clock64();
+      const int f = potrf_inv32_wg<NB + 1>(D, Xs, col, T, sc, tid);
+      if (tid < 64) { fail = f; tot += clock64() - c0; wtot += wall_clock64() - w0; }
+    } else if (tid < 64) {
       const long long c0 = clock64(), w0 = wall_clock64();
       if constexpr (MODE == 9) fail = wave_potrf_inv32_2x16(D, Xs, reinterpret_cast<double (&)[64]>(col), T, tid);
       else if constexpr (MODE == 2) fail = potrf_inv32_halves<NB + 1>(D, Xs, col, T, tid);
@@ -58,10 +61,6 @@ int main() {
   run("existing 2x16 (LDS line)", kb<9>);
   run("new, LDS line cleaned", kb<1>);
   run("halves layout", kb<2>);
-  {
-    long long st[16]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamp), sizeof st);
-    printf("halves, cycles per phase (last repetition): fill %lld | block 1 %lld | finish %lld | L21 + A22 update %lld | fill %lld | block 2 %lld | finish %lld | X21 %lld\n",
-           st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6], st[8] - st[7]);
-  }
+  run("whole workgroup, LDL^T glue", kb<5>);
   return 0;
 }
