@@ -640,13 +640,17 @@ def main():
             # W_r = 2 A1 diag(gv_r) A1^T contraction (R x the lower half of M x M x K), timed by HIP events on their own streams in a
             # loop of their own; they overlap in the step (different streams), so the sum of their times is an upper bound of their share
             if cfg["convs"]:
-                ctx.timing_enable(1)
-                ctx.timing_reset()
-                for i in range(min(n_g, 6)):
-                    cg(1000 + i)
-                leg.barrier()
-                tim = ctx.timing()
-                ctx.timing_enable(0)
+                # (ctx option grad_nofork: the reverse pass on ONE stream, so that each of the two kernels is timed alone on the chip -- in the
+                # step proper they run beside each other on two streams and share it, which is what train_step_ms measures)
+                with ctx.options(grad_nofork=1):
+                    cg(999)
+                    ctx.timing_enable(1)
+                    ctx.timing_reset()
+                    for i in range(min(n_g, 6)):
+                        cg(1000 + i)
+                    leg.barrier()
+                    tim = ctx.timing()
+                    ctx.timing_enable(0)
                 c0 = cfg["convs"][0]
                 P0 = ((cfg["hwc"][0] - c0[0]) // c0[1] + 1) * ((cfg["hwc"][1] - c0[0]) // c0[1] + 1)
                 Kc, M, R = leg.local_batch * S * P0, cfg["M"], c0[2]
@@ -663,7 +667,8 @@ def main():
                                            "w_r_contraction": {"avg_us": us_w, "flops": f_wr, "tflops": f_wr / us_w / 1e6},
                                            "launches_sampled": int(tb[0]),
                                            "note": "flops: (2 R + 1) M^2 K + R M^2 K (symmetric / triangular products counted as M^2 per column, as SURVEY 8(d) "
-                                                   "counts the forward's); times: HIP events around each launch on its own stream, the two overlap in the step"}
+                                                   "counts the forward's); times: HIP events around each launch with the reverse pass on one stream (ctx option "
+                                                   "grad_nofork), i.e. each kernel alone on the chip; in the step they overlap on two streams"}
             return g
         grad = informational("gradient", grad_leg) or {}
 

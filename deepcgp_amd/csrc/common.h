@@ -106,6 +106,9 @@ struct dcgp_ctx {
   std::string err;
   std::map<std::string, hipGraphExec_t> chain_graphs;   // captured panel-launch sequences of the factorisation chain, by argument set (chol_fused.hip)
   std::map<std::string, ChainEpoch> chain_epochs;   // per sync workspace of chol_persist_kernel (chol_fused.hip)
+  bool chain_alone = true;   // the factorisation chain about to run has the chip to itself (forward_all: synchronous step, chain on the main stream).  Beside a
+                             // patch sweep or the previous step's layer kernel its extra workgroups -- the riding right-hand sides -- and the look-ahead
+                             // workgroups' confinement to one XCD cost more than they save (head-only model 4250 -> 4200 / 3190 steps/s)
   std::string ws_tag;   // suffix of the chain's / KL terms' scratch names: steps in flight on the two banks must not share them
   // named, grow-only device workspaces owned by the ctx
   std::map<std::string, std::pair<void*, size_t>> ws;
