@@ -1061,7 +1061,7 @@ __global__ void chol_finish_kernel(double* const* __restrict__ Ap, const double*
 // Cholesky factor in place (strict upper triangle zeroed) and, when d_Linv != nullptr, inv(L) (+ its transpose).
 // right-hand sides ride the plain panel-per-launch chain with its look-ahead (the A/B routes -- one launch, no look-ahead, captured graph -- do not carry them)
 bool chain_can_ride(const dcgp_ctx* ctx, int Mp) {
-  return ctx->chain_alone && Mp <= kChainRhsMaxMp && !ctx->opt.chol_one_launch && !ctx->opt.chol_no_lookahead && !ctx->opt.chain_graph && !ctx->opt.no_rhs_ride;
+  return ctx->chain_ride_ok && Mp <= kChainRhsMaxMp && !ctx->opt.chol_one_launch && !ctx->opt.chol_no_lookahead && !ctx->opt.chain_graph && !ctx->opt.no_rhs_ride;
 }
 
 int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_Linv, double* const* d_LinvT, int batch,

@@ -106,9 +106,11 @@ struct dcgp_ctx {
   std::string err;
   std::map<std::string, hipGraphExec_t> chain_graphs;   // captured panel-launch sequences of the factorisation chain, by argument set (chol_fused.hip)
   std::map<std::string, ChainEpoch> chain_epochs;   // per sync workspace of chol_persist_kernel (chol_fused.hip)
-  bool chain_alone = true;   // the factorisation chain about to run has the chip to itself (forward_all: synchronous step, chain on the main stream).  Beside a
-                             // patch sweep or the previous step's layer kernel its extra workgroups -- the riding right-hand sides -- and the look-ahead
-                             // workgroups' confinement to one XCD cost more than they save (head-only model 4250 -> 4200 / 3190 steps/s)
+  bool chain_alone = true;   // the factorisation chain about to run has the chip to itself (forward_all: synchronous step, chain on the main stream): the
+                             // look-ahead workgroups are then confined to one XCD.  Beside a patch sweep or the previous step's layer kernel that
+                             // confinement costs more than it saves (head-only model 4250 -> 3190 steps/s without the riding right-hand sides)
+  bool chain_ride_ok = true; // right-hand sides may ride the chain about to run: not beside a patch sweep (a head-first model: 4250 -> 4200 steps/s).
+                             // A property of the model, not of the step's mode: synchronous and in-flight steps take the same route (bit-identical)
   std::string ws_tag;   // suffix of the chain's / KL terms' scratch names: steps in flight on the two banks must not share them
   // named, grow-only device workspaces owned by the ctx
   std::map<std::string, std::pair<void*, size_t>> ws;

@@ -285,9 +285,10 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   // with a single factor group its "chol_Lout" scratch stays untouched until the deferred copy runs on the KL stream
   const bool defer = m->groups[bank].size() == 1 && need_kl && !m->keep_state;
   ctx->chain_alone = chain_s == main_s && !pipelined;
+  ctx->chain_ride_ok = first_fused;
   for (auto& gr : m->groups[bank])
     if (rc == DCGP_OK) rc = gr.run(ctx, defer);
-  ctx->chain_alone = true;
+  ctx->chain_alone = ctx->chain_ride_ok = true;
   if (rc == DCGP_OK && xs && hipEventRecord(m->ev_factor[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
   // G_r = inv(L) Lq_r and alpha = inv(L) q_mu of every layer (cond_prep): gate the second conditional GEMM
   bool prep_done[8] = {}, rode[8] = {};
