@@ -262,12 +262,12 @@ __device__ __forceinline__ int wave_potrf_inv32_2x16(double (*D)[NB + 1], double
 // =====================================================================================================================
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
-// line: 96 doubles of LDS, 16-byte aligned: [0,16) rows in de-interleaved order ((i & 1) * 8 + (i >> 1)), [16,32) unit vectors, [32,96) sink
+// line: 48 doubles of LDS, 16-byte aligned: [0,16) rows in de-interleaved order ((i & 1) * 8 + (i >> 1)), [16,32) unit vectors, [32,48) sink
 __device__ __forceinline__ void block16_halves(double (&x)[8], double (&lc)[16], double& pv, int lane, double* line) {
   const int h = lane >> 5, i = lane & 31;
   const int pi = i < 16 ? ((i & 1) * 8 + (i >> 1)) : i;
-  double* const w_even = line + (h == 0 ? pi : 32 + lane);
-  double* const w_odd = line + (h == 1 ? pi : 32 + lane);
+  double* const w_even = line + (h == 0 ? pi : 32 + (lane & 15));   // (the sink: 16 slots the non-owner lanes scribble on)
+  double* const w_odd = line + (h == 1 ? pi : 32 + (lane & 15));
   const double* const rd_u = line + h * 8;
   const double* const rd_x = line + pi;
   double u[8];
@@ -356,7 +356,7 @@ __device__ __forceinline__ int potrf_inv32_halves(double (*D)[LD], double (*Xs)[
     const unsigned long long bad = __ballot(lane < 16 && !(pv > 0.0));
     if (bad && fail == 0) fail = o + __ffsll((long long)bad);
     const double y = rsqrt_nr(pv);
-    line[lane] = y;                       // lanes >= 16 write junk beyond the 16 entries read back
+    if (lane < 16) line[lane] = y;
     double ys[16];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const dbl2 p = *reinterpret_cast<const dbl2*>(line + 2 * j); ys[2 * j] = p[0]; ys[2 * j + 1] = p[1]; }
@@ -403,7 +403,7 @@ __device__ __forceinline__ int potrf_inv32_halves(double (*D)[LD], double (*Xs)[
 // T = (Pt diag(r1)) Xt11, the scalings of L11 / inv(L)11 (then L21, L22), each behind one of two workgroup barriers.  (tools/diag_bench.hip: the
 // one-wave form spent 5200 of its 9300 cycles outside the two recurrences -- y through an LDS line, 16 multiplies and 32 stores per block, three
 // LDS round trips of block products.)  Call with all 256 threads; ends without a barrier (callers synchronise before reading D / Xs).
-// D: lower triangle of the block on entry (zero above), L on return; Xs: inv(L); line: 96 doubles, 16-byte aligned; T: 16 x 17; sc: 64 doubles.
+// D: lower triangle of the block on entry (zero above), L on return; Xs: inv(L); line: 48 doubles, 16-byte aligned; T: 16 x 17; sc: 64 doubles.
 // Returns (wave 0) 0 or the 1-based column of the first non-positive pivot.
 template <int LD>
 __device__ __forceinline__ int potrf_inv32_wg(double (*D)[LD], double (*Xs)[LD], double* line, double (*T)[17], double* sc, int tid) {

@@ -31,8 +31,15 @@ __device__ long long g_chol_trace[64 * 32];
 namespace {
 
 // factor + inverse of a diagonal block held in LDS (chol_dev.h): two 16 x 16 blocks in the halves layout + MFMA block work (round 5;
-// tools/diag_bench.hip: 3.6 us against 5.1 for the two 16-column panels of round 3, DCGP_POTRF_PANELS at compile time).  col: 96 doubles.
-constexpr int COL_N = 96;
+// tools/diag_bench.hip: 3.6 us against 5.1 for the two 16-column panels of round 3, DCGP_POTRF_PANELS at compile time).  col: 48 doubles.
+// (LDS of chol_rl_kernel is a budget: beside a patch sweep -- which claims 53 KB per workgroup so that a chain workgroup fits the moment one of its
+// three per CU ends, head_units.hip -- a kernel of 54144 bytes ran the head-only model's chain at 150 us and its sweep at 178, one of 53760 at 108 and
+// 168: 4250 -> 4350 steps/s, 4500 -> 4780 in flight.  The line's sink is therefore 16 slots, not one per lane.)
+#ifdef DCGP_POTRF_PANELS
+constexpr int COL_N = 64;
+#else
+constexpr int COL_N = 48;
+#endif
 __device__ __forceinline__ int potrf_inv32(double (*D)[NB + 1], double (*Xs)[NB + 1], double (&col)[COL_N], double (*Tp)[17], int lane) {
 #ifdef DCGP_POTRF_PANELS
   return wave_potrf_inv32_2x16(D, Xs, reinterpret_cast<double (&)[64]>(col), Tp, lane);
@@ -485,53 +492,59 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
   }
   __syncthreads();
   TR(1)
-  // ---- L_jj and inv(L_jj): one wavefront (unless the previous launch left them) ----
-  int fail_j = 0;
-  if (!have_x) {
-    const int fail = potrf_inv32_wg<NB + 1>(D, Xs, col, Tp, sc, tid);   // (all four waves; the status is wave 0's)
-    if (tid < 64) fail_j = fail;
-    // (with a look-ahead workgroup in the launch it is the one writer of the status word: it sees this panel's failure too)
-    if (tid == 0 && bx == 0 && a.la_idx < 0 && (j == 0 || (fail && a.info[b] == 0))) a.info[b] = fail ? j + fail : 0;
-  }
-  __syncthreads();
-  TR(2)
-  if (is_la) {
-    // ---- the next diagonal block: P = U inv(L_jj)^T, D_next = A[jn,jn] - P P^T, its factor and inverse -> Lout, Xnext ----
-    double (*U)[NB + 1] = Ui;
-    double (*Pm)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(UcTs);
-    double* __restrict__ xn = a.Xnext + (long)b * 2 * NB * NB;
+  // ---- L_jj and inv(L_jj) (unless the previous launch left them); the look-ahead workgroup then the NEXT diagonal block too ----
+  // ONE call site of the block routine for both (a loop of up to two passes): inlined twice, its ~1500 straight-line instructions made the kernel
+  // large enough to evict a co-running sweep's code and its own (head-only model: sweep 168 -> 177 us, chain 141 -> 152 beside each other).
+  int fail_j = 0, fail_n = 0;
+  double* __restrict__ xn = is_la ? a.Xnext + (long)b * 2 * NB * NB : nullptr;
+  for (int pass = have_x ? 1 : 0; pass < (is_la ? 2 : 1); ++pass) {
+    if (pass == 1) {
+      // ---- the next diagonal block: P = U inv(L_jj)^T, D_next = A[jn,jn] - P P^T ----
+      double (*U)[NB + 1] = Ui;
+      double (*Pm)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(UcTs);
 #pragma unroll
-    for (int e = 0; e < NB * NB / 256; ++e) { const int idx = tid + e * 256; U[idx / NB][idx % NB] = la_u[e]; }
-    __syncthreads();
-    const int bm = wave >> 1, bn = wave & 1;
-    {
-      d4 pacc = d4{0.0, 0.0, 0.0, 0.0};
+      for (int e = 0; e < NB * NB / 256; ++e) { const int idx = tid + e * 256; U[idx / NB][idx % NB] = la_u[e]; }
+      __syncthreads();
+      const int bm = wave >> 1, bn = wave & 1;
+      {
+        d4 pacc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int kk = 0; kk < NB; kk += 4)
-        pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(U[bm * 16 + lcol][kk + lrow], Xs[bn * 16 + lcol][kk + lrow], pacc, 0, 0, 0);
+        for (int kk = 0; kk < NB; kk += 4)
+          pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(U[bm * 16 + lcol][kk + lrow], Xs[bn * 16 + lcol][kk + lrow], pacc, 0, 0, 0);
 #pragma unroll
-      for (int v = 0; v < 4; ++v) Pm[bm * 16 + lrow + 4 * v][bn * 16 + lcol] = pacc[v];
-    }
-    __syncthreads();   // (also: everyone is done with D = L_jj, which the first workgroup of the launch publishes from its own copy)
-#pragma unroll
-    for (int e = 0; e < NB * NB / 256; ++e) { const int idx = tid + e * 256; D[idx / NB][idx % NB] = la_d[e]; }
-    __syncthreads();
-    {
-      d4 dacc = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < NB; kk += 4)
-        dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pm[bm * 16 + lcol][kk + lrow], Pm[bn * 16 + lcol][kk + lrow], dacc, 0, 0, 0);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int r = bm * 16 + lrow + 4 * v, c = bn * 16 + lcol;
-        if (c <= r && r < nbn) D[r][c] -= dacc[v];
+        for (int v = 0; v < 4; ++v) Pm[bm * 16 + lrow + 4 * v][bn * 16 + lcol] = pacc[v];
       }
+      __syncthreads();   // (also: everyone is done with D = L_jj, which the first workgroup of the launch publishes from its own copy)
+#pragma unroll
+      for (int e = 0; e < NB * NB / 256; ++e) { const int idx = tid + e * 256; D[idx / NB][idx % NB] = la_d[e]; }
+      __syncthreads();
+      {
+        d4 dacc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < NB; kk += 4)
+          dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pm[bm * 16 + lcol][kk + lrow], Pm[bn * 16 + lcol][kk + lrow], dacc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int r = bm * 16 + lrow + 4 * v, c = bn * 16 + lcol;
+          if (c <= r && r < nbn) D[r][c] -= dacc[v];
+        }
+      }
+      __syncthreads();
+      TR(3)
     }
+    const int fail = potrf_inv32_wg<NB + 1>(D, Xs, col, Tp, sc, tid);   // (all four waves; the status is wave 0's)
     __syncthreads();
-    TR(3)
-    const int fail = potrf_inv32_wg<NB + 1>(D, Xs, col, Tp, sc, tid);
-    __syncthreads();
-    TR(4)
+    if (pass == 0) {
+      TR(2)
+      if (tid < 64) fail_j = fail;
+      // (with a look-ahead workgroup in the launch it is the one writer of the status word: it sees this panel's failure too)
+      if (tid == 0 && bx == 0 && a.la_idx < 0 && (j == 0 || (fail && a.info[b] == 0))) a.info[b] = fail ? j + fail : 0;
+    } else {
+      TR(4)
+      if (tid < 64) fail_n = fail;
+    }
+  }
+  if (is_la) {
 #pragma unroll
     for (int e = 0; e < NB * NB / 256; ++e) {
       const int idx = tid + e * 256, r = idx / NB, c = idx % NB;
@@ -539,12 +552,10 @@ __global__ __launch_bounds__(256, 2) void chol_rl_kernel(RlArgs a) {
       xn[NB * NB + idx] = Xs[r][c];
       if (r < nbn && c < nbn) Lout[(long)(jn + r) * ld + jn + c] = D[r][c];
     }
-    {
-      if (tid == 0) {   // status word: first failing column of the chain so far (launch 0 initialises it)
-        const int mine = fail_j ? j + fail_j : (fail ? jn + fail : 0);
-        if (j == 0) a.info[b] = mine;
-        else if (mine && a.info[b] == 0) a.info[b] = mine;
-      }
+    if (tid == 0) {   // status word: first failing column of the chain so far (launch 0 initialises it)
+      const int mine = fail_j ? j + fail_j : (fail_n ? jn + fail_n : 0);
+      if (j == 0) a.info[b] = mine;
+      else if (mine && a.info[b] == 0) a.info[b] = mine;
     }
     TR(5)
     return;
