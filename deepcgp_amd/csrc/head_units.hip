@@ -97,7 +97,13 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
   // [1] shader clock at entry, [2] image in LDS, [3] set-up done, [4] first unit done, [5] last unit done, [6] wall clock at exit, [7] units run
   long long* const tr = (a.trace && blockIdx.x < a.trace_wgs) ? a.trace + ((long)blockIdx.x * WPG + wave) * 8 : nullptr;
   auto stamp = [&](int k) { if (tr && lane == 0) tr[k] = (long long)clock64(); };
-  if (tr && lane == 0) { tr[0] = (long long)wall_clock64(); tr[7] = 0; }
+  if (tr && lane == 0) {   // [7]: units run in the low word, (XCC_ID << 16 | HW_ID[15:0]) -- where the wave sits -- in the high word
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    tr[0] = (long long)wall_clock64();
+    tr[7] = (long long)(((xcc & 0xf) << 16) | (hwid & 0xffff)) << 32;
+  }
   stamp(1);
 
   // ---- set-up, once per workgroup: the scaled image, the offset tables, patch norms from a separable window sum ----
@@ -299,7 +305,11 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
           double bn[NY];
           const int kon = q < 3 ? kc[q + 1] : kn[0];   // sub-step s + q + 1 <= sL exists
 #pragma unroll
+#ifdef HU_ABL_NOB
+          for (int y = 0; y < NY; ++y) bn[y] = (double)(lane + y + kon) * 1e-3;   // timing experiment (wrong results): no B gathers
+#else
           for (int y = 0; y < NY; ++y) bn[y] = ldi(pb[y] + kon);
+#endif
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int y = 0; y < NY; ++y) acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[q], bv[y], acc[y], 0, 0, 0);
@@ -481,6 +491,9 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
     const int zvo = (lrow * a.Mp + 16 * ur + lcol) * 8, zstep = 4 * a.Mp * 8;
     const int zvp = (RL * lrow * a.Mp + 16 * ur + lcol) * 8;   // PERM: rows RL lrow + s of ZS in sub-steps 0 .. RL - 1
     auto ldz = [&](int sub) {
+#ifdef HU_ABL_NOA
+      return (double)(lane + sub) * 1e-3;   // timing experiment (tools/r05_abl.sh; wrong results): no A-operand loads
+#endif
       if (PERM && sub < RL) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrs, zvp, sub * a.Mp * 8, 0));
       return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zrs, zvo, sub * zstep, 0));
     };
@@ -609,6 +622,13 @@ void head_units_plan(HeadUnitsArgs* a) {
   // enough LDS that only so many workgroups fit a CU -- the same launch is 1.96 rounds, both full.  `cap`: what the kernel's register
   // budget allows; the pipe reaches ~92 / 96 / 98 % of its rate from 2 / 3 / 4 waves per SIMD.
   auto shape_occupancy = [&](int cap) {
+    // Round 5 looked at where the thin second round goes (tools/sweep_trace.py now records every wave's HW_ID; tools/r05_abl.sh): its waves
+    // ARE spread evenly (896 SIMDs with two of them, 128 with one at the 12 x 12 x 10 head); a unit of 252 MFMAs = 7.2 us of issue takes a
+    // wave 12.9 us alone on its SIMD and 17.9 us beside one other, and exactly as long with its A loads, its B gathers or both removed --
+    // one wave issues an fp64 MFMA every ~96 cycles, not 64, so a SIMD needs three to four waves whatever they wait for.  Two plans that
+    // keep the launch to ONE round (every image's units dealt evenly to the workgroups that fit the chip at once, two to three units per
+    // wave behind one set-up; the Kdiag chunks as second units, or alone on a wave) measured 76 - 78 us against 70: a Kdiag chunk -- two row
+    // passes, one of them a single tile wide -- takes a wave 50 - 67 us beside three others and is the launch's last wave either way.
     // MEASURED AND LEFT OFF (tools/head_ab.sh): every shape got slower held to fewer waves -- 79 -> 101 us at the 12 x 12 x 10 head, 110 ->
     // 134 us at the CIFAR head, 163 -> 176 us at the MNIST head.  A wave of these sweeps is bound by its own latencies (LDS gathers, the
     // A operand from L2), not by the pipe, so a SIMD with three waves does less than one with four whatever the round count says.

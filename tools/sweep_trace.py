@@ -31,9 +31,14 @@ with ctx.options(no_fused_layer=1, no_early_sweep=1, head_no_overlap=1, **{k: in
     model.compute_log_likelihood(dX, dY, seed=99)
     ctx.sync()
     dev.lib().dcgp_debug_set_sweep_trace(ctx.handle, None, 0, None)
-t = buf.numpy().astype(np.float64)
+raw = buf.numpy()
+where = (raw[:, 7] >> 32) & 0xfffff      # XCC_ID << 16 | HW_ID[15:0] of the wave
+raw = raw.copy()
+raw[:, 7] &= 0xffffffff
+t = raw.astype(np.float64)
 live = t[:, 0] > 0
 t = t[live]
+where = where[live]
 if not len(t):
     raise SystemExit("no stamps: family %r was not launched" % family)
 w0, w1 = t[:, 0].min(), t[:, 6].max()
@@ -65,4 +70,39 @@ if ran.any():
 edges = np.linspace(0, span_us, 21)
 print("busy waves over time (20 slices of %.1f us): %s" % (span_us / 20, " ".join(
     "%d" % int(((start < hi) & (end > lo)).sum()) for lo, hi in zip(edges[:-1], edges[1:]))))
+# placement: waves per SIMD among those that start late (the launch's second round), and how long their unit takes against the number of
+# late waves that share the SIMD
+simd = (where >> 16) * 4096 + ((where >> 8) & 0xff) * 16 + ((where >> 4) & 3)     # (XCC, SE/SH/CU, SIMD)
+late = start > 0.4 * span_us
+if late.any() and ran.any():
+    ids, cnt = np.unique(simd[late], return_counts=True)
+    n_simd = len(np.unique(simd))
+    hist = dict(zip(*np.unique(cnt, return_counts=True)))
+    hist[0] = n_simd - len(ids)
+    print("late waves (start > 40 %% of the span): %d on %d SIMDs seen; SIMDs by number of late waves: %s" % (late.sum(), n_simd, dict(sorted(hist.items()))))
+    per = dict(zip(ids, cnt))
+    k = np.array([per[s] for s in simd[late]])
+    unit = (t[late, 4] - t[late, 3]) / ghz / 1e3
+    for c in sorted(set(k)):
+        sel = (k == c) & (t[late, 7] > 0)
+        if sel.any():
+            print("  late waves on a SIMD with %d of them: %d, first unit median %.1f us (min %.1f max %.1f)" % (c, sel.sum(), np.median(unit[sel]), unit[sel].min(), unit[sel].max()))
+if os.environ.get("SWEEP_PLACE"):
+    # where the launch's first-round workgroups sit: (workgroup, wave) -> SIMD, for the first CUs seen
+    idx = np.nonzero(live)[0]
+    wg, wv = idx // WAVES, idx % WAVES
+    cu = (where >> 16) * 4096 + ((where >> 8) & 0xff)
+    sid = (where >> 4) & 3
+    early = start < 0.2 * span_us
+    for c in np.unique(cu)[:3]:
+        sel = early & (cu == c)
+        order = np.argsort(wg[sel] * WAVES + wv[sel])
+        print("CU %05x first-round (workgroup.wave:SIMD): %s" % (c, " ".join("%d.%d:%d" % (a, b, d) for a, b, d in zip(wg[sel][order], wv[sel][order], sid[sel][order]))))
+    # how often do the two waves of a workgroup sit on SIMDs (0,1) / (2,3) / other pairs
+    pairs = {}
+    for w in np.unique(wg[early]):
+        m = early & (wg == w)
+        key = tuple(sid[m][np.argsort(wv[m])])
+        pairs[key] = pairs.get(key, 0) + 1
+    print("SIMDs of a workgroup's waves (first round): %s" % dict(sorted(pairs.items(), key=lambda kv: -kv[1])[:12]))
 model.close()
