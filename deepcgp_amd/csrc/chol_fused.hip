@@ -1154,6 +1154,15 @@ int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_L
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) gkey.clear();   // no capture: the plain loop
   }
   const bool capturing = use_graph && !gkey.empty();
+  // whatever leaves this function between here and hipStreamEndCapture must not leave the stream capturing (every later launch on it would fail)
+  struct CaptureGuard {
+    hipStream_t s; bool open;
+    ~CaptureGuard() {
+      if (!open) return;
+      hipGraph_t g = nullptr;
+      if (hipStreamEndCapture(s, &g) == hipSuccess && g) hipGraphDestroy(g);
+    }
+  } guard{ctx->stream, capturing};
   for (int j = 0; j < Mp; j += NB) {
     RlArgs a;
     a.A = d_A; a.Lout = Lout; a.Y = Y; a.Linv = d_Linv; a.LinvT = d_Linv ? d_LinvT : nullptr; a.Mp = Mp; a.ld = ld; a.j = j; a.info = d_info;
@@ -1200,6 +1209,7 @@ int factor_inverse_batched(dcgp_ctx* ctx, double* const* d_A, double* const* d_L
   if (capturing) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    guard.open = false;
     if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || !graph)
       return ctx_fail(ctx, DCGP_ERR_HIP, "factorisation chain: graph capture failed");
     const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
