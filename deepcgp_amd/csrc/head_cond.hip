@@ -41,7 +41,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(1024, 4) void head_cond_kernel(HeadCondArgs a) {
   __shared__ __attribute__((aligned(16))) double Bt[HC_MP * HC_BN];   // [k][16]: Kzx strip, then A1
-  __shared__ double red[3 * 16 * 16];
+  __shared__ double red[4 * 16 * 16];
 
   const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,6 +59,15 @@ __global__ __launch_bounds__(1024, 4) void head_cond_kernel(HeadCondArgs a) {
       const_cast<double*>(s3 ? a.G + (long)r * Mp * Mp : a.LinvT), 0, Mp * Mp * 8, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
 
+  // Knn of the strip's 16 columns: the sum of each column's kd_n partial sums (the sweep's Kdiag chunks: up to ~100 per column where the
+  // launch's tail was cut fine), 64 threads per column, their loads in flight under the strip's DMA.  (Sixteen threads walking kd_n values
+  // each at the very end of the kernel were 12 of its 28 us at the M = 32 head.)
+  double knn_part = 0.0;
+  {
+    const int c = tid & 15, sl = tid >> 4, j = j0 + c;
+    if (j < a.Kc)
+      for (int i = sl; i < a.kd_n; i += 64) knn_part += a.kd[(long)j * a.kd_n + i];
+  }
   double al[4];                          // alpha[row][r] of this lane's four accumulator rows
 #pragma unroll
   for (int v = 0; v < 4; ++v) al[v] = live ? a.alpha[(long)(i0 + lrow + 4 * v) * a.Rp + r] : 0.0;
@@ -139,10 +148,12 @@ __global__ __launch_bounds__(1024, 4) void head_cond_kernel(HeadCondArgs a) {
   s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
   mu += __shfl_xor(mu, 16); mu += __shfl_xor(mu, 32);
   s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+  knn_part += __shfl_xor(knn_part, 16); knn_part += __shfl_xor(knn_part, 32);   // (lane & 15 is the column: the wave's four slices)
   if (lrow == 0) {
     red[(0 * 16 + wave) * 16 + lcol] = s1;
     red[(1 * 16 + wave) * 16 + lcol] = mu;
     red[(2 * 16 + wave) * 16 + lcol] = s2;
+    red[(3 * 16 + wave) * 16 + lcol] = knn_part;
   }
   __syncthreads();
   if (tid < HC_BN) {
@@ -157,7 +168,8 @@ __global__ __launch_bounds__(1024, 4) void head_cond_kernel(HeadCondArgs a) {
     if (j < a.Kc) {
       a.out_mean[(long)j * a.R + r] = tm;
       double knn = 0.0;
-      for (int i = 0; i < a.kd_n; ++i) knn += a.kd[(long)j * a.kd_n + i];
+#pragma unroll
+      for (int w = 0; w < 16; ++w) knn += red[(3 * 16 + w) * 16 + tid];
       a.out_var[(long)j * a.R + r] = knn * a.kd_scale - t1 + t2;
     }
   }
