@@ -61,6 +61,7 @@ struct DcgpOptions {
   long kuf_wpg = 0;              // storing sweep: waves per workgroup (0: chosen by head_units_plan; 1, 2, 4)
   long kuf_stream = 0;           // storing sweep: the streamed-operand kernel also for the patch lengths with a register-resident one
   long kuf_no_rep = 0;           // storing sweep: evaluate every row, also where rows show the same image (tiled batch)
+  long no_syrk = 0;              // reverse pass: W_r = 2 A1 diag(gv_r) A1^T through the general GEMM instead of its own kernel (A/B)
   long head_upw = 0;             // reducing sweep: Kzx row units per wave (0: chosen by head_units_plan)
   long share_kb = 0;             // patch sweeps beside the factorisation chain: LDS claimed per workgroup in KB (0: default)
   long sweep_occ = -1;           // patch sweeps: waves per SIMD a launch is held to so that its rounds come out whole (-1: chosen; 0: off)

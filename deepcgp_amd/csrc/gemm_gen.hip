@@ -199,6 +199,129 @@ __global__ void splitk_reduce_kernel(GenGemm g, int ksplit, const double* part) 
   if (g.mirror && j < i) g.C[(long)b * g.c_bs + (long)j * g.c_rs + i] = v;
 }
 
+
+// ---- C_b = alpha A diag(kscale_b) A^T for ONE long, k-contiguous A of at most 256 rows (the reverse pass's W_r = 2 A1 diag(gv_r) A1^T: K = every
+// patch column of the batch, R outputs) -------------------------------------------------------------------------------------------------
+// Both operands are the same matrix, so a workgroup stages ONE [256][32] chunk of A per step (the general kernel stages two 128-row tiles per 16
+// columns and meets at a barrier every 16 MFMAs of a wave) and owns the WHOLE lower triangle of one output for its share of the columns: 36 blocks
+// of 32 x 32 on 12 waves, three blocks a wave (the general kernel's three 128 x 128 tiles compute 48 such blocks), 96 MFMAs of a wave between two
+// barriers, the column scale applied to the B fragment as it leaves LDS.  grid (k ranges, outputs): the ranges are chosen so that the launch is one
+// workgroup per CU; the partial sums meet in splitk_reduce_kernel (fixed order, both triangles stored).
+constexpr int SY_ROWS = 256, SY_KC = 32, SY_LD = SY_KC + 1, SY_NT = 768;
+// the 36 blocks on and below the diagonal of the 8 x 8 grid, row by row; wave w owns entries 3 w .. 3 w + 2.  A kernel ARGUMENT: as a constant table
+// the compiler specialised the whole kernel per wave (twelve copies of the loop, 400 KB of code)
+struct SyBlocks { unsigned char b[36][2]; };
+static SyBlocks sy_blocks_host() {
+  SyBlocks t;
+  int n = 0;
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j <= i; ++j) { t.b[n][0] = (unsigned char)i; t.b[n][1] = (unsigned char)j; ++n; }
+  return t;
+}
+
+__global__ __launch_bounds__(SY_NT) void syrk_kscale_kernel(GenGemm g, int kchunk, double* __restrict__ part, SyBlocks tab) {
+  extern __shared__ __attribute__((aligned(16))) double sy_smem[];
+  double* As = sy_smem;                            // [2][SY_ROWS][SY_LD]
+  double* ks = sy_smem + 2 * SY_ROWS * SY_LD;      // [2][SY_KC]
+  const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sp = blockIdx.x, b = blockIdx.y;
+  const int kbeg = sp * kchunk, kend = min(g.K, kbeg + kchunk);
+  const int nk = (kend - kbeg + SY_KC - 1) / SY_KC;
+  const double* __restrict__ A = g.A + (long)b * g.a_bs;
+  const double* __restrict__ sc = g.kscale + (long)b * g.ks_bs;
+  // this thread's 16-byte pieces of a chunk: piece idx = tid + e * SY_NT covers row idx >> 4, columns 2 (idx & 15), 2 (idx & 15) + 1.  Through a buffer
+  // descriptor: a 32-bit per-piece offset that never changes, the chunk a scalar offset; rows >= M and whatever lies behind the matrix read as zero
+  constexpr int NP = (SY_ROWS * SY_KC / 2 + SY_NT - 1) / SY_NT;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A), 0, (int)min((long)g.M * g.a_rs * 8, 0x7fffffffL), 0x00020000);
+  int poff[NP];
+#pragma unroll
+  for (int e = 0; e < NP; ++e) {
+    const int idx = tid + e * SY_NT, row = idx >> 4;
+    poff[e] = (idx < SY_ROWS * SY_KC / 2 && row < g.M) ? (int)(((long)row * g.a_rs + 2 * (idx & 15)) * 8) : (int)0x80000000u;
+  }
+  double2 ra[NP];
+  double rk = 0.0;
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ars, poff[e], k0 * 8, 0);
+      __builtin_memcpy(&ra[e], &v, 16);
+      const int k = k0 + 2 * ((tid + e * SY_NT) & 15);   // columns >= kend belong to the next range (or to nobody): their scale is zero, but 0 x NaN is not
+      if (k >= kend) ra[e].x = 0.0;
+      if (k + 1 >= kend) ra[e].y = 0.0;
+    }
+    if (tid < SY_KC) rk = k0 + tid < kend ? sc[(long)(k0 + tid) * g.ks_s] : 0.0;
+  };
+  auto stage = [&](int buf) {
+    double* dst = As + buf * SY_ROWS * SY_LD;
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      const int idx = tid + e * SY_NT, row = idx >> 4, c = 2 * (idx & 15);
+      if (idx < SY_ROWS * SY_KC / 2) { dst[row * SY_LD + c] = ra[e].x; dst[row * SY_LD + c + 1] = ra[e].y; }
+    }
+    if (tid < SY_KC) ks[buf * SY_KC + tid] = rk;
+  };
+  int bi[3], bj[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) { bi[t] = tab.b[3 * wave + t][0]; bj[t] = tab.b[3 * wave + t][1]; }
+  d4 acc[3][2][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) acc[t][x][y] = d4{0.0, 0.0, 0.0, 0.0};
+  if (nk > 0) {
+    fetch(kbeg);
+    stage(0);
+    __syncthreads();
+  }
+  for (int it = 0; it < nk; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < nk) fetch(kbeg + (it + 1) * SY_KC);
+    const double* Ac = As + cur * SY_ROWS * SY_LD + lcol * SY_LD + lrow;
+    const double* kc = ks + cur * SY_KC + lrow;
+    // (one k-step's twelve fragments at a time: left to itself the scheduler hoists every LDS read of the chunk -- 96 of them -- and spills)
+#pragma unroll
+    for (int kk = 0; kk < SY_KC; kk += 4) {
+      const double kv = kc[kk];
+      double a0[3], a1[3], b0[3], b1[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        a0[t] = Ac[(32 * bi[t]) * SY_LD + kk]; a1[t] = Ac[(32 * bi[t] + 16) * SY_LD + kk];
+        b0[t] = Ac[(32 * bj[t]) * SY_LD + kk]; b1[t] = Ac[(32 * bj[t] + 16) * SY_LD + kk];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        b0[t] *= kv; b1[t] *= kv;
+        acc[t][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b0[t], acc[t][0][0], 0, 0, 0);
+        acc[t][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b1[t], acc[t][0][1], 0, 0, 0);
+        acc[t][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b0[t], acc[t][1][0], 0, 0, 0);
+        acc[t][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b1[t], acc[t][1][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (it + 1 < nk) stage(cur ^ 1);   // (the other buffer was last read before the previous barrier)
+    __syncthreads();
+  }
+  // partial sums in splitk_reduce_kernel's layout: part[(sp * batch + b) * M * N + i * N + j], entries on and below the diagonal only
+  double* __restrict__ out = part + ((long)sp * g.batch + b) * (long)g.M * g.N;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = 32 * bi[t] + 16 * x + lrow + 4 * q, j = 32 * bj[t] + 16 * y + lcol;
+          if (i < g.M && j <= i) out[(long)i * g.N + j] = acc[t][x][y][q];
+        }
+}
+
 }  // namespace
 
 template <int GT, int NT, int WT>
@@ -261,9 +384,41 @@ static int gemm_gen_launch(dcgp_ctx* ctx, const GenGemm& g, int slots_per_round)
   return DCGP_OK;
 }
 
+// the symmetric long contraction of the reverse pass on its own kernel (syrk_kscale_kernel): A diag(kscale) A^T, k contiguous, <= 256 rows
+static bool syrk_applies(const dcgp_ctx* ctx, const GenGemm& g) {
+  return !ctx->opt.no_syrk && g.A == g.B && g.a_bs == g.b_bs && g.a_cs == 1 && g.b_rs == 1 && g.a_rs == g.b_cs && g.M == g.N && g.M <= SY_ROWS &&
+         g.M > 128 && g.K >= 8192 && g.lower_only && g.mirror && g.kscale && !g.colscale && !g.sub_v && !g.phi && (g.a_rs & 1) == 0 &&
+         (g.a_bs & 1) == 0 && (uintptr_t)g.A % 16 == 0 && g.batch <= 64 && (long)g.M * g.a_rs * 8 < 0x7fffffffL;
+}
+static int syrk_launch(dcgp_ctx* ctx, const GenGemm& g) {
+  const int cus = ctx->n_cus > 0 ? ctx->n_cus : 256;
+  int ksplit = cus / g.batch;   // one workgroup per CU, no second round
+  if (ksplit < 1) ksplit = 1;
+  if (ksplit > g.K / 256) ksplit = g.K / 256;
+  const int kchunk = round_up((g.K + ksplit - 1) / ksplit, SY_KC);
+  ksplit = (g.K + kchunk - 1) / kchunk;
+  char pname[48];
+  snprintf(pname, sizeof pname, "gemm_gen_part@%p", (void*)ctx->stream);
+  double* part = (double*)ws_get(ctx, pname, (size_t)ksplit * g.batch * g.M * g.N * sizeof(double));
+  if (!part) return DCGP_ERR_ALLOC;
+  const size_t lds = (size_t)(2 * SY_ROWS * SY_LD + 2 * SY_KC) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)syrk_kscale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(syrk_kscale_kernel, dim3(ksplit, g.batch), dim3(SY_NT), lds, ctx->stream, g, kchunk, part, sy_blocks_host());
+  LAUNCH_CHECK(ctx);
+  const long total = (long)g.M * g.N * g.batch;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, g, ksplit, part);
+  LAUNCH_CHECK(ctx);
+  return DCGP_OK;
+}
+
 int gemm_gen(dcgp_ctx* ctx, const GenGemm& g) {
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return DCGP_OK;
   if (!g.A || !g.B || !g.C || g.K < 0) return ctx_fail(ctx, DCGP_ERR_ARG, "gemm_gen: bad arguments");
+  if (syrk_applies(ctx, g)) return syrk_launch(ctx, g);
   // 256 CUs; 4 co-resident 64-tile workgroups per CU (40 KB LDS each), 2 of the 128-tile ones (72 KB, 1024 threads)
   // the 1024-thread 128-tile (twice the flop per operand byte) pays off where it can fill its 512 slots, split included:
   // the tiled batch's contractions (K = 46080 columns at the headline size), M = 1024.  With a few thousand columns and

@@ -480,6 +480,24 @@ def test_full_size_cfg2_gradient_vs_torch_autograd(ctx, name):
     model.close()
 
 
+def test_symmetric_contraction_kernel_equals_the_general_gemm(ctx):
+    """W_r = 2 A1 diag(gv_r) A1^T of the tiled conv layer's reverse pass (K = 46 080 columns at the headline size) runs on its own kernel
+    (csrc/gemm_gen.hip: syrk_kscale_kernel); ctx option no_syrk sends it through the general GEMM.  Every gradient must agree to rounding --
+    the two sum the columns in different orders."""
+    spec, X, Y = syn.make_config("cfg2_mnist_CH_M256")
+    zs = syn.make_noise(spec, X.shape[0], seed=11)
+    model = build_from_spec(spec, X, Y)
+    e1, g1 = model.compute_gradients(X, Y, zs=zs)
+    with ctx.options(no_syrk=1):
+        e0, g0 = model.compute_gradients(X, Y, zs=zs)
+    assert e0 == e1
+    for li, (a, b) in enumerate(zip(g1, g0)):
+        for k in a:
+            x, y = np.asarray(a[k], np.float64), np.asarray(b[k], np.float64)
+            assert np.abs(x - y).max() <= 1e-11 * max(1.0, np.abs(y).max()), (li, k, np.abs(x - y).max(), np.abs(y).max())
+    model.close()
+
+
 @pytest.mark.parametrize("name", ["cfg5_mnist_H_M1024", "cfg5_mnist_CH_M1024"])
 def test_cfg5_reduced_batch_vs_torch_forward(ctx, name):
     """BASELINE configs[4] (M = 1024: the 32-panel factorisation chain, the GEMM route of the conditional) on a reduced batch (4 images, S = 2)
