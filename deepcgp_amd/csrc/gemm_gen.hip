@@ -241,27 +241,31 @@ __global__ __launch_bounds__(SY_NT) void syrk_kscale_kernel(GenGemm g, int kchun
     const int idx = tid + e * SY_NT, row = idx >> 4;
     poff[e] = (idx < SY_ROWS * SY_KC / 2 && row < g.M) ? (int)(((long)row * g.a_rs + 2 * (idx & 15)) * 8) : (int)0x80000000u;
   }
-  double2 ra[NP];
+  // pieces [0, NP / 2) travel in the first half of a step, the rest in the second: half the staging registers (a chunk's 24 of them were what spilled)
+  constexpr int NH = NP / 2;
+  static_assert(NP % 2 == 0, "two halves");
+  double2 ra[NH];
   double rk = 0.0;
-  auto fetch = [&](int k0) {
+  auto fetch = [&](int k0, int half) {
 #pragma unroll
-    for (int e = 0; e < NP; ++e) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ars, poff[e], k0 * 8, 0);
-      __builtin_memcpy(&ra[e], &v, 16);
+    for (int h = 0; h < NH; ++h) {
+      const int e = half * NH + h;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ars, poff[half ? NH + h : h], k0 * 8, 0);
+      __builtin_memcpy(&ra[h], &v, 16);
       const int k = k0 + 2 * ((tid + e * SY_NT) & 15);   // columns >= kend belong to the next range (or to nobody): their scale is zero, but 0 x NaN is not
-      if (k >= kend) ra[e].x = 0.0;
-      if (k + 1 >= kend) ra[e].y = 0.0;
+      if (k >= kend) ra[h].x = 0.0;
+      if (k + 1 >= kend) ra[h].y = 0.0;
     }
-    if (tid < SY_KC) rk = k0 + tid < kend ? sc[(long)(k0 + tid) * g.ks_s] : 0.0;
+    if (half == 0 && tid < SY_KC) rk = k0 + tid < kend ? sc[(long)(k0 + tid) * g.ks_s] : 0.0;
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](int buf, int half) {
     double* dst = As + buf * SY_ROWS * SY_LD;
 #pragma unroll
-    for (int e = 0; e < NP; ++e) {
-      const int idx = tid + e * SY_NT, row = idx >> 4, c = 2 * (idx & 15);
-      if (idx < SY_ROWS * SY_KC / 2) { dst[row * SY_LD + c] = ra[e].x; dst[row * SY_LD + c + 1] = ra[e].y; }
+    for (int h = 0; h < NH; ++h) {
+      const int idx = tid + (half * NH + h) * SY_NT, row = idx >> 4, c = 2 * (idx & 15);
+      if (idx < SY_ROWS * SY_KC / 2) { dst[row * SY_LD + c] = ra[h].x; dst[row * SY_LD + c + 1] = ra[h].y; }
     }
-    if (tid < SY_KC) ks[buf * SY_KC + tid] = rk;
+    if (half == 0 && tid < SY_KC) ks[buf * SY_KC + tid] = rk;
   };
   int bi[3], bj[3];
 #pragma unroll
@@ -274,37 +278,45 @@ __global__ __launch_bounds__(SY_NT) void syrk_kscale_kernel(GenGemm g, int kchun
 #pragma unroll
       for (int y = 0; y < 2; ++y) acc[t][x][y] = d4{0.0, 0.0, 0.0, 0.0};
   if (nk > 0) {
-    fetch(kbeg);
-    stage(0);
+    fetch(kbeg, 0); stage(0, 0);
+    fetch(kbeg, 1); stage(0, 1);
     __syncthreads();
   }
   for (int it = 0; it < nk; ++it) {
     const int cur = it & 1;
-    if (it + 1 < nk) fetch(kbeg + (it + 1) * SY_KC);
+    const bool more = it + 1 < nk;
     const double* Ac = As + cur * SY_ROWS * SY_LD + lcol * SY_LD + lrow;
     const double* kc = ks + cur * SY_KC + lrow;
     // (one k-step's twelve fragments at a time: left to itself the scheduler hoists every LDS read of the chunk -- 96 of them -- and spills)
+    auto ksteps = [&](int k_lo) {
 #pragma unroll
-    for (int kk = 0; kk < SY_KC; kk += 4) {
-      const double kv = kc[kk];
-      double a0[3], a1[3], b0[3], b1[3];
+      for (int kk = k_lo; kk < k_lo + SY_KC / 2; kk += 4) {
+        const double kv = kc[kk];
+        double a0[3], a1[3], b0[3], b1[3];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        a0[t] = Ac[(32 * bi[t]) * SY_LD + kk]; a1[t] = Ac[(32 * bi[t] + 16) * SY_LD + kk];
-        b0[t] = Ac[(32 * bj[t]) * SY_LD + kk]; b1[t] = Ac[(32 * bj[t] + 16) * SY_LD + kk];
+        for (int t = 0; t < 3; ++t) {
+          a0[t] = Ac[(32 * bi[t]) * SY_LD + kk]; a1[t] = Ac[(32 * bi[t] + 16) * SY_LD + kk];
+          b0[t] = Ac[(32 * bj[t]) * SY_LD + kk]; b1[t] = Ac[(32 * bj[t] + 16) * SY_LD + kk];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          b0[t] *= kv; b1[t] *= kv;
+          acc[t][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b0[t], acc[t][0][0], 0, 0, 0);
+          acc[t][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b1[t], acc[t][0][1], 0, 0, 0);
+          acc[t][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b0[t], acc[t][1][0], 0, 0, 0);
+          acc[t][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b1[t], acc[t][1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        b0[t] *= kv; b1[t] *= kv;
-        acc[t][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b0[t], acc[t][0][0], 0, 0, 0);
-        acc[t][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b1[t], acc[t][0][1], 0, 0, 0);
-        acc[t][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b0[t], acc[t][1][0], 0, 0, 0);
-        acc[t][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b1[t], acc[t][1][1], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (it + 1 < nk) stage(cur ^ 1);   // (the other buffer was last read before the previous barrier)
+    };
+    // the next chunk goes into the other buffer (last read before the previous barrier) in two halves, each requested before half of this chunk's
+    // products and written behind them
+    if (more) fetch(kbeg + (it + 1) * SY_KC, 0);
+    ksteps(0);
+    if (more) { stage(cur ^ 1, 0); fetch(kbeg + (it + 1) * SY_KC, 1); }
+    ksteps(SY_KC / 2);
+    if (more) stage(cur ^ 1, 1);
     __syncthreads();
   }
   // partial sums in splitk_reduce_kernel's layout: part[(sp * batch + b) * M * N + i * N + j], entries on and below the diagonal only
