@@ -429,13 +429,14 @@ __global__ void kdiag_norms_kernel(const double* __restrict__ Gm, int P, long n_
   norms[idx] = Gm[(n * P + p) * P + p];
 }
 
+// the layer's three scalar gradients from their 16 slots each: lanes 16 q .. 16 q + 15 hold the slots of sum q (one load per lane -- one thread
+// walking the 48 slots took ~50 us of a step's tail stream: a load, a wait and an add 48 times over)
 __global__ void scal_finish_kernel(const double* __restrict__ slots, double* __restrict__ gscal) {
-  if (threadIdx.x || blockIdx.x) return;
-  double a = 0.0, b = 0.0, c = 0.0;
-  for (int i = 0; i < 16; ++i) { a += slots[VAR_SLOT + i]; b += slots[LS_SLOT + i]; c += slots[P2_SLOT + i]; }
-  gscal[0] = a;
-  gscal[1] = b;
-  gscal[2] = c;
+  if (blockIdx.x) return;
+  const int lane = threadIdx.x, q = lane >> 4, i = lane & 15;
+  double v = q < 3 ? slots[(q == 0 ? VAR_SLOT : (q == 1 ? LS_SLOT : P2_SLOT)) + i] : 0.0;
+  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+  if (q < 3 && i == 0) gscal[q] = v;
 }
 
 // ---- ArcCosine(order 0) base kernel (--base-kernel acos, conv layers) ------------------------------------------------
