@@ -61,6 +61,7 @@ struct DcgpOptions {
   long kuf_wpg = 0;              // storing sweep: waves per workgroup (0: chosen by head_units_plan; 1, 2, 4)
   long kuf_stream = 0;           // storing sweep: the streamed-operand kernel also for the patch lengths with a register-resident one
   long kuf_no_rep = 0;           // storing sweep: evaluate every row, also where rows show the same image (tiled batch)
+  long grad_dz_main = 0;         // reverse pass of the head: the patch adjoint's dZ product on the main stream instead of the tail stream (A/B)
   long no_syrk = 0;              // reverse pass: W_r = 2 A1 diag(gv_r) A1^T through the general GEMM instead of its own kernel (A/B)
   long head_upw = 0;             // reducing sweep: Kzx row units per wave (0: chosen by head_units_plan)
   long share_kb = 0;             // patch sweeps beside the factorisation chain: LDS claimed per workgroup in KB (0: default)
@@ -102,7 +103,7 @@ struct dcgp_ctx {
   hipEvent_t ev_kl2 = nullptr, ev_kl3 = nullptr;
   // reverse pass of a layer (grad.hip, Lanes): [0] main -> chain: the conditional's operands are there, [1] main -> chain: dK_uf and dq_mu,
   // [2] chain -> tail: S = d ELBO / dK_uu, [3] main -> tail: the patch adjoint's part of dZ and the partial sums, [4] chain -> tail: dq_sqrt
-  hipEvent_t ev_g[5] = {};
+  hipEvent_t ev_g[6] = {};
   hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;  // fork / join of a short side-stream excursion inside a layer
   std::string err;
   std::map<std::string, hipGraphExec_t> chain_graphs;   // captured panel-launch sequences of the factorisation chain, by argument set (chol_fused.hip)

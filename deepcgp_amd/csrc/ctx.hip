@@ -29,7 +29,7 @@ const OptSlot kOptSlots[] = {
     {"no_early_sweep", &DcgpOptions::no_early_sweep}, {"sync_event", &DcgpOptions::sync_event}, {"kuf_upw", &DcgpOptions::kuf_upw},
     {"chain_graph", &DcgpOptions::chain_graph}, {"no_rhs_ride", &DcgpOptions::no_rhs_ride}, {"comm_inline", &DcgpOptions::comm_inline}, {"chain_no_iso", &DcgpOptions::chain_no_iso}, {"kuf_no_rep", &DcgpOptions::kuf_no_rep}, {"kuf_stream", &DcgpOptions::kuf_stream},
     {"kuf_wpg", &DcgpOptions::kuf_wpg}, {"kuf_split", &DcgpOptions::kuf_split}, {"head_tail", &DcgpOptions::head_tail},
-    {"sweep_occ", &DcgpOptions::sweep_occ}, {"share_kb", &DcgpOptions::share_kb}, {"head_upw", &DcgpOptions::head_upw}, {"no_syrk", &DcgpOptions::no_syrk},
+    {"sweep_occ", &DcgpOptions::sweep_occ}, {"share_kb", &DcgpOptions::share_kb}, {"head_upw", &DcgpOptions::head_upw}, {"no_syrk", &DcgpOptions::no_syrk}, {"grad_dz_main", &DcgpOptions::grad_dz_main},
     {"fused_abl", &DcgpOptions::fused_abl}, {"rb_mixed", &DcgpOptions::rb_mixed},
 };
 }  // namespace
@@ -180,7 +180,7 @@ int dcgp_ctx_create(int device, dcgp_ctx** out) {
       hipEventCreateWithFlags(&c->ev_kl3, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_g[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_g[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_g[2], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_g[3], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_g[4], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_g[4], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_g[5], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_aux2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_kl, hipEventDisableTiming) != hipSuccess) {
     delete c;

@@ -793,8 +793,12 @@ int kuu_backward(Bk& bk, LayerState& L, const double* Zsrc, const double* S, lon
 
 // Patch-kernel backward: E [M x Kc] (ld) = d ELBO / dKfull o Kfull is ready, cs = its column sums.
 // dZ += (E Xcol - rowsum(E) o Z) / l^2;  dXcol (=|+=) (E^T Z - cs o Xcol) / l^2 when requested.
+// dz_lanes (the head): the dZ product goes to the TAIL stream, behind an event recorded here -- nothing on the main stream reads dZ, the tail stream is
+// idle at this point of the head's reverse pass and adds its own term into the same dZ later (kuu_backward: in stream order behind this one), and the two
+// long products of the patch adjoint (73 + 86 us at the headline size, neither of them bound by the matrix pipe) then run beside each other
 int patch_backward(Bk& bk, LayerState& L, const double* E, long ld, long Kc, const double* cs, const double* Xcol, double* dXcol,
-                   int dx_accumulate, const double* Zuse = nullptr, double* dz_out = nullptr, const double* rs_in = nullptr, double cz = 0.0) {
+                   int dx_accumulate, const double* Zuse = nullptr, double* dz_out = nullptr, const double* rs_in = nullptr, double cz = 0.0,
+                   const Lanes* dz_lanes = nullptr) {
   dcgp_ctx* ctx = bk.ctx;
   const int M = L.M, Ld = L.v.L;
   const double inv_l2 = cz != 0.0 ? cz : 1.0 / (L.ls * L.ls);   // cz: the ArcCosine adjoint passes its weight variance (and its own row vector)
@@ -814,7 +818,14 @@ int patch_backward(Bk& bk, LayerState& L, const double* E, long ld, long Kc, con
   {   // dZ += (E Xcol - rs o Z) / l^2: one product over the columns (split along k), the correction in its epilogue
     GenGemm e = mk(E, ld, 1, Xcol, Ld, 1, dz_out ? dz_out : L.gZ, Ld, M, Ld, (int)Kc);
     e.alpha = inv_l2; e.accumulate = 1; e.sub_v = rs; e.sub_x = Zp; e.sx_rs = Ld;
-    DCGP_TRY(gemm_gen(ctx, e));
+    if (dz_lanes && dz_lanes->forked && !dz_out && !ctx->opt.grad_dz_main) {
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_g[5], ctx->stream));   // E, Xcol, rs are there
+      OnStream on(ctx, dz_lanes->tail, ctx->ev_g[5]);
+      if (!on.ok) return ctx_fail(ctx, DCGP_ERR_HIP, "grad: stream wait failed");
+      DCGP_TRY(gemm_gen(ctx, e));
+    } else {
+      DCGP_TRY(gemm_gen(ctx, e));
+    }
   }
   if (dXcol) {   // dXcol (+)= (E^T Z - cs o Xcol) / l^2
     GenGemm e = mk(E, 1, ld, Zp, Ld, 1, dXcol, Ld, (int)Kc, Ld, M);
@@ -1384,7 +1395,7 @@ int head_backward(Bk& bk, LayerState& L, const double* Xin, int rows, int n_mod,
   DCGP_TRY(e_form(bk, L, dKzx, ld, P, L.w, 1.0 / P, Kfull, ldf, E, ldf, Kc, cs, raw));
   hipLaunchKernelGGL(strided_sum_kernel, dim3(P), dim3(256), 0, ctx->stream, raw, rows, P, 1.0 / P, 1, L.gw);
   LAUNCH_CHECK(ctx);
-  DCGP_TRY(patch_backward(bk, L, E, ldf, Kc, cs, Xcol, dXin ? dXcol : nullptr, 0));
+  DCGP_TRY(patch_backward(bk, L, E, ldf, Kc, cs, Xcol, dXin ? dXcol : nullptr, 0, nullptr, nullptr, nullptr, 0.0, &ln));
   // Kdiag
   if (L.kernel_type == 0) {
     const double inv_l2 = 1.0 / (L.ls * L.ls);
