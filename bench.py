@@ -660,7 +660,7 @@ def main():
                 if tb and tw and tb[0] and tw[0]:
                     us_b, us_w = 1e3 * tb[1] / tb[0], 1e3 * tw[1] / tw[0]
                     ach = (f_bwd + f_wr) / ((us_b + us_w) * 1e-6) / 1e12
-                    g["roofline_train"] = {"kernel": "conv_bwd_fused_kernel + gemm_gen (W_r contraction): the reverse pass's products of the first conv layer",
+                    g["roofline_train"] = {"kernel": "conv_bwd_fused_kernel + syrk_kscale_kernel (W_r = 2 A1 diag(gv_r) A1^T, with its split-k reduction): the reverse pass's products of the first conv layer",
                                            "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                                            "traffic": None, "algorithmic_flops": f_bwd + f_wr,
                                            "conv_bwd_fused": {"avg_us": us_b, "flops": f_bwd, "tflops": f_bwd / us_b / 1e6},
