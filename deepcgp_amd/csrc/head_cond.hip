@@ -18,7 +18,8 @@
 
 namespace {
 
-constexpr int HC_MP = 256;             // largest padded M handled (16 waves x one 16-row fragment)
+constexpr int HC_MP = 512;             // largest padded M handled by head_cond_kernel (16 waves x two 16-row fragments)
+constexpr int PS_MP = 256;             // ... by prep_solve_kernel (16 waves x one fragment)
 constexpr int HC_BK = 16;
 constexpr int HC_BN = 16;
 constexpr int HC_D = 3;                // W k-tiles in flight per wave beside the one being multiplied
@@ -39,17 +40,21 @@ struct HeadCondArgs {
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+// Row fragments: nf = Mp / 16 <= 32.  Wave w < ceil(nf / 2) owns fragments w and nf - 1 - w (one where they meet): w + 1 and nf - w live k-tiles in
+// the lower-triangular stage, nf - w and w + 1 in the upper-triangular one -- nf + 1 per stage for every wave; the other waves only help with the loads
+// and the reductions.  (M <= 256 ran one fragment per wave, wave w's k-tiles graded 1 .. 16; M = 384 went through four launches of the GEMM route.)
 __global__ __launch_bounds__(1024, 4) void head_cond_kernel(HeadCondArgs a) {
-  __shared__ __attribute__((aligned(16))) double Bt[HC_MP * HC_BN];   // [k][16]: Kzx strip, then A1
-  __shared__ double red[4 * 16 * 16];
+  extern __shared__ __attribute__((aligned(16))) double hc_smem[];
+  double* Bt = hc_smem;                       // [Mp][16]: Kzx strip, then A1
+  double* red = hc_smem + a.Mp * HC_BN;       // [4][16][16]
 
   const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j0 = blockIdx.x * HC_BN, r = blockIdx.y;
-  const int Mp = a.Mp, nt = Mp / HC_BK;                  // k-tiles per stage
+  const int Mp = a.Mp, nt = Mp / HC_BK;                  // k-tiles per stage = row fragments
   const bool s3 = a.G != nullptr;
-  const int i0 = wave * 16;                              // this wave's rows
-  const bool live = i0 < Mp;
+  const int fr[2] = {wave, nt - 1 - wave};
+  const int nfr = fr[0] < fr[1] ? 2 : (fr[0] == fr[1] ? 1 : 0);   // fragments of this wave
 
   const __amdgpu_buffer_rsrc_t brs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.B), 0, (int)((long)Mp * a.ldb * 8), 0x00020000);
@@ -68,45 +73,45 @@ __global__ __launch_bounds__(1024, 4) void head_cond_kernel(HeadCondArgs a) {
     if (j < a.Kc)
       for (int i = sl; i < a.kd_n; i += 64) knn_part += a.kd[(long)j * a.kd_n + i];
   }
-  double al[4];                          // alpha[row][r] of this lane's four accumulator rows
+  double al[2][4];                       // alpha[row][r] of this lane's accumulator rows
 #pragma unroll
-  for (int v = 0; v < 4; ++v) al[v] = live ? a.alpha[(long)(i0 + lrow + 4 * v) * a.Rp + r] : 0.0;
-  // Kzx strip by LDS-DMA: wave-instruction q covers rows 8q..8q+7 (8 lanes x 16 B per row); 2 per wave
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) al[c][v] = c < nfr ? a.alpha[(long)(16 * fr[c] + lrow + 4 * v) * a.Rp + r] : 0.0;
+  // Kzx strip by LDS-DMA: wave-instruction q covers rows 8q..8q+7 (8 lanes x 16 B per row); Mp / 128 per wave
   {
     const int rl = lane >> 3, cl = (lane & 7) * 2;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int q = wave * 2 + h, row = q * 8 + rl;
+    for (int q = wave; q * 8 < Mp; q += 16) {
+      const int row = q * 8 + rl;
       const unsigned off = (row < Mp) ? (unsigned)(((long)row * a.ldb + j0 + cl) * 8) : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_ptr)(Bt + q * 8 * HC_BN), 16, (int)off, 0, 0, 0);
     }
   }
 
-  // A operand straight from global memory: lane (lrow, lcol) of k-substep q needs W^T[kt*16 + 4q + lrow][i0 + lcol].
-  // Each wave streams ONLY its 16 columns and only its live k-tiles, HC_D tiles ahead in registers -- no LDS staging
-  // and no barrier in the k loop (the B operand is the resident strip).
+  // A operand straight from global memory: lane (lrow, lcol) of k-substep q needs W^T[kt*16 + 4q + lrow][16 f + lcol].
+  // Each wave streams ONLY the 16 columns of the fragment in hand and only its live k-tiles, HC_D tiles ahead in registers -- no LDS staging
+  // and no barrier in the k loop (the B operand is the resident strip).  Per-lane byte offset woff[q]; fragment and k-tile are a scalar offset.
   unsigned woff[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) woff[q] = live ? (unsigned)(((4 * q + lrow) * Mp + i0 + lcol) * 8) : OOB;
-  auto ldw = [&](const __amdgpu_buffer_rsrc_t& rs, int kt, double (&dst)[4]) {
-    const int so = kt * HC_BK * Mp * 8;
+  for (int q = 0; q < 4; ++q) woff[q] = (unsigned)(((4 * q + lrow) * Mp + lcol) * 8);
+  auto ldw = [&](const __amdgpu_buffer_rsrc_t& rs, int f, int kt, double (&dst)[4]) {
+    const int so = (kt * HC_BK * Mp + 16 * f) * 8;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)woff[q], so, 0);
       __builtin_memcpy(&dst[q], &v, 8);
     }
   };
-  d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-  // tiles [lo, hi) of one stage, prefetch distance HC_D (loads past the end re-read the last tile: static counts)
-  auto stage = [&](const __amdgpu_buffer_rsrc_t& rs, int lo, int hi) {
+  // tiles [lo, hi) of one stage of fragment f into acc, prefetch distance HC_D (loads past the end re-read the last tile: static counts)
+  auto stage = [&](const __amdgpu_buffer_rsrc_t& rs, int f, int lo, int hi, d4& acc) {
     double wb[HC_D + 1][4];
 #pragma unroll
-    for (int u = 0; u < HC_D; ++u) ldw(rs, min(lo + u, hi - 1), wb[u]);
+    for (int u = 0; u < HC_D; ++u) ldw(rs, f, min(lo + u, hi - 1), wb[u]);
     for (int kt = lo; kt < hi; kt += HC_D + 1) {
 #pragma unroll
       for (int u = 0; u <= HC_D; ++u) {
         if (kt + u < hi) {
-          ldw(rs, min(kt + u + HC_D, hi - 1), wb[(u + HC_D) % (HC_D + 1)]);
+          ldw(rs, f, min(kt + u + HC_D, hi - 1), wb[(u + HC_D) % (HC_D + 1)]);
           const double* b = Bt + (kt + u) * HC_BK * HC_BN + lcol;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
@@ -118,31 +123,43 @@ __global__ __launch_bounds__(1024, 4) void head_cond_kernel(HeadCondArgs a) {
 
   __syncthreads();   // Kzx strip resident (drains the DMA queue)
   double s1 = 0.0, mu = 0.0, s2 = 0.0;   // per-lane partials for column lcol
-  // ---- stage 1: A1 = inv(L) Kzx, lower-triangular W: k-tiles 0 .. wave ----
-  if (live) stage(lrs, 0, wave + 1);
+  d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+  // ---- stage 1: A1 = inv(L) Kzx, lower-triangular W: fragment f needs k-tiles 0 .. f ----
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const double x = live ? acc[v] : 0.0;
-    s1 = fma(x, x, s1);
-    mu = fma(al[v], x, mu);
-  }
+  for (int c = 0; c < 2; ++c)
+    if (c < nfr) stage(lrs, fr[c], 0, fr[c] + 1, acc[c]);
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const double x = c < nfr ? acc[c][v] : 0.0;
+      s1 = fma(x, x, s1);
+      mu = fma(al[c][v], x, mu);
+    }
   __syncthreads();   // every wave is done reading the Kzx strip
-  if (live) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) Bt[(i0 + lrow + 4 * v) * HC_BN + lcol] = acc[v];
-    if (a.A1_out && r == 0 && j0 + lcol < a.Kc) {   // (every output's workgroup of the strip holds the same A1: the first one stores it)
+  for (int c = 0; c < 2; ++c) {
+    if (c < nfr) {
+      const int i0 = 16 * fr[c];
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        if (i0 + lrow + 4 * v < a.M) a.A1_out[(long)(i0 + lrow + 4 * v) * a.lda1 + j0 + lcol] = acc[v];
+      for (int v = 0; v < 4; ++v) Bt[(i0 + lrow + 4 * v) * HC_BN + lcol] = acc[c][v];
+      if (a.A1_out && r == 0 && j0 + lcol < a.Kc) {   // (every output's workgroup of the strip holds the same A1: the first one stores it)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (i0 + lrow + 4 * v < a.M) a.A1_out[(long)(i0 + lrow + 4 * v) * a.lda1 + j0 + lcol] = acc[c][v];
+      }
     }
   }
   __syncthreads();   // A1 published
-  // ---- stage 3: T_r = G_r^T A1, upper-triangular W: k-tiles wave .. nt-1 ----
+  // ---- stage 3: T_r = G_r^T A1, upper-triangular W: fragment f needs k-tiles f .. nt-1 ----
   if (s3) {
-    acc = d4{0.0, 0.0, 0.0, 0.0};
-    if (live) stage(grs, wave, nt);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) s2 = fma(acc[v], acc[v], s2);
+    for (int c = 0; c < 2; ++c) {
+      acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+      if (c < nfr) stage(grs, fr[c], fr[c], nt, acc[c]);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) s2 = fma(acc[c][v], acc[c][v], s2);
+    }
   }
   // ---- reduce over the 4 row groups of a wave, then over the waves ----
   s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
@@ -184,12 +201,12 @@ __global__ __launch_bounds__(1024, 4) void head_cond_kernel(HeadCondArgs a) {
 // y == R: q_mu (x == 0 only).  The generic route was two latency-bound GEMM launches per layer (17 + 31 us at cfg2).
 struct PrepSolveLayer {
   const double* LinvT; const double* Lq; const double* qmu; double* G; double* alpha; double* klp;
-  int Mp, R, Rp, active;   // active == 0: whitened layer (G / alpha alias Lq / q_mu) or larger than HC_MP
+  int Mp, R, Rp, active;   // active == 0: whitened layer (G / alpha alias Lq / q_mu) or larger than PS_MP
 };
 struct PrepSolveArgs { PrepSolveLayer l[16]; };   // layers, then the prior-factor entries (G == nullptr: sums only)
 
 __global__ __launch_bounds__(1024, 4) void prep_solve_kernel(PrepSolveArgs args) {
-  __shared__ __attribute__((aligned(16))) double Bt[HC_MP * HC_BN];   // [k][16]
+  __shared__ __attribute__((aligned(16))) double Bt[PS_MP * HC_BN];   // [k][16]
   __shared__ double ssq[16];
   // Heaviest strips first.  Strip s of a triangular right-hand side costs (16 - s)(17 - s) / 2 k-tiles -- 136 for strip 0, 1 for strip 15 --
   // and the launch is 1.4 rounds of the resident slots: in grid order (strips fastest) the second round still held strip-0 workgroups,
@@ -283,6 +300,7 @@ __global__ __launch_bounds__(1024, 4) void prep_solve_kernel(PrepSolveArgs args)
 }  // namespace
 
 bool head_cond_fused_ok(const GpMats& g) { return g.Mp <= HC_MP && g.Mp % HC_BK == 0; }
+static bool prep_solve_ok(const GpMats& g) { return g.Mp <= PS_MP && g.Mp % HC_BK == 0; }
 
 // mean / var [Kc][R] of the conditional at Kc columns whose Kzx is B [Mp][ldb]; G / alpha from cond_prep
 int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, int Kc, bool have_qsqrt, const double* kd,
@@ -297,7 +315,13 @@ int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, i
   a.kd = kd; a.kd_n = kd_n; a.kd_scale = kd_scale; a.Mp = g.Mp; a.R = g.R;
   a.out_mean = out_mean; a.out_var = out_var;
   a.A1_out = A1_out; a.lda1 = lda1; a.M = g.M;
-  hipLaunchKernelGGL(head_cond_kernel, dim3((Kc + HC_BN - 1) / HC_BN, g.R), dim3(1024), 0, ctx->stream, a);
+  const size_t lds = (size_t)(g.Mp * HC_BN + 4 * 16 * 16) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {   // (72 KB at Mp = 512)
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)head_cond_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (HC_MP * HC_BN + 4 * 16 * 16) * 8));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(head_cond_kernel, dim3((Kc + HC_BN - 1) / HC_BN, g.R), dim3(1024), lds, ctx->stream, a);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }
@@ -310,7 +334,7 @@ int prep_solve_all(dcgp_ctx* ctx, GpMats* const* gs, const int* white, const boo
     const GpMats& g = *gs[i];
     PrepSolveLayer& l = a.l[i];
     if (skip && skip[i]) { l.active = 0; continue; }   // G / alpha of this layer rode the factorisation chain (its flags are the caller's)
-    l.active = (!white[i] && head_cond_fused_ok(g) && g.Rp == HC_BN) ? 1 : 0;
+    l.active = (!white[i] && prep_solve_ok(g) && g.Rp == HC_BN) ? 1 : 0;
     done[i] = l.active != 0;
     l.LinvT = g.LinvT; l.Lq = have_qsqrt[i] ? g.Lq : nullptr; l.qmu = g.qmu; l.G = g.G; l.alpha = g.alpha;
     l.klp = (l.active && have_qsqrt[i]) ? g.klp : nullptr;

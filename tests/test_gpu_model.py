@@ -1331,12 +1331,19 @@ def test_model_destroy_releases_its_workspaces(ctx):
     m = build_from_spec(spec, X, Y)
     m.compute_gradients(X, Y, fetch=False)
     m.close()
+    def three_models():
+        for _ in range(3):
+            m = build_from_spec(spec, X, Y)
+            m.compute_gradients(X, Y, fetch=False)
+            m.close()
+        return free_bytes()
     base = free_bytes()
-    for _ in range(3):
-        m = build_from_spec(spec, X, Y)
-        m.compute_gradients(X, Y, fetch=False)
-        m.close()
-    assert base - free_bytes() < 8 * 1024 * 1024, (base, free_bytes())
+    f1 = three_models()
+    f2 = three_models()
+    # a leak grows with every model (a training step's workspaces are tens of MB); a one-off allocation of the runtime's (a code object loaded late,
+    # a pool grown once: seen once in a dozen full runs as 8+ MB between `base` and the first three models) does not
+    assert f1 - f2 < 8 * 1024 * 1024, (base, f1, f2)
+    assert base - f2 < 64 * 1024 * 1024, (base, f1, f2)
 
 
 @pytest.mark.parametrize("maps,strip_kernel", [(17, False), (13, True), (1, True)])
