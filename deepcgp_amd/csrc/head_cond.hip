@@ -1,14 +1,14 @@
 // head_cond.hip -- the whole conditional of a FEW-column problem (the head: one column per image, a few hundred in
-// all) in ONE launch, for M <= 256.
+// all) in ONE launch, for M <= 512 (round 5: two row fragments per wave).
 //
 // The generic route is four dependent launches -- A1 = inv(L) Kzx (+ sum of squares), T_r = G_r^T A1 (+ sum of
 // squares), mean = alpha^T A1, finalize -- of 13-17 us each at cfg2, every one of them nothing but a serial chain of
 // 16 k-steps that each wait a full memory latency: ~75 us with the gaps, at the very end of the step where nothing
 // can hide it.  Here a workgroup owns (16 columns, one output r) and runs both triangular products back to back:
-//     * the 16-column strip of Kzx is LDS-resident ([k][16], 32 KB), and A1 overwrites it in place when stage 1 ends;
-//     * wave w owns rows 16w..16w+15 and streams ONLY its own 16 columns of the W operands (inv(L)^T, then G_r) from
-//       global memory straight into MFMA A registers, three k-tiles ahead, and only its live k-tiles: w+1 in the
-//       lower-triangular stage, 16-w in the upper-triangular one -- no LDS staging, no barrier inside a k loop.
+//     * the 16-column strip of Kzx is LDS-resident ([k][16], 32 KB at M = 256), and A1 overwrites it in place when stage 1 ends;
+//     * wave w owns the row fragments w and nf - 1 - w (nf = M / 16 <= 32) and streams ONLY the 16 columns of the fragment in hand of the
+//       W operands (inv(L)^T, then G_r) from global memory straight into MFMA A registers, three k-tiles ahead, and only its live
+//       k-tiles: nf + 1 per stage for every wave -- no LDS staging, no barrier inside a k loop.
 //       (A first version staged whole W k-tiles through an LDS ring for all waves: 2 tiles = 64 KB in flight per CU
 //       against ~1.7 us of latency is 32 GB/s -- 27 us for the 1 MB a workgroup streams.);
 //     * sum_m A1^2, alpha_r^T A1 and sum_m T_r^2 are reduced from the accumulators, and mean / var leave the kernel
