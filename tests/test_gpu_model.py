@@ -480,11 +480,17 @@ def test_full_size_cfg2_gradient_vs_torch_autograd(ctx, name):
     model.close()
 
 
-def test_symmetric_contraction_kernel_equals_the_general_gemm(ctx):
+@pytest.mark.parametrize("M", [256, 200, 129])
+def test_symmetric_contraction_kernel_equals_the_general_gemm(ctx, M):
     """W_r = 2 A1 diag(gv_r) A1^T of the tiled conv layer's reverse pass (K = 46 080 columns at the headline size) runs on its own kernel
     (csrc/gemm_gen.hip: syrk_kscale_kernel); ctx option no_syrk sends it through the general GEMM.  Every gradient must agree to rounding --
-    the two sum the columns in different orders."""
-    spec, X, Y = syn.make_config("cfg2_mnist_CH_M256")
+    the two sum the columns in different orders.  M = 200 / 129: rows the kernel's 256-row chunk pads with zeros, a ragged last block."""
+    if M == 256:
+        spec, X, Y = syn.make_config("cfg2_mnist_CH_M256")
+    else:
+        hwc = (28, 28, 1)
+        spec = syn.make_spec(hwc, [(5, 2, 10)], (5, 1), M, S=10, num_data=60000, seed=5 + M, conv_q_sqrt_scale=0.3)
+        X, Y = syn.make_batch(hwc, 8, seed=M)      # 8 x 10 x 144 = 11 520 columns: past the kernel's threshold
     zs = syn.make_noise(spec, X.shape[0], seed=11)
     model = build_from_spec(spec, X, Y)
     e1, g1 = model.compute_gradients(X, Y, zs=zs)

@@ -600,13 +600,15 @@ def test_head_unit_sweep_exp_accuracy(ctx):
     assert abs(got[0] - 1.0) <= 2.3e-16
 
 
-@pytest.mark.parametrize("white", [False, True])
-def test_svgp_head(ctx, white):
+@pytest.mark.parametrize("white,M", [(False, 24), (True, 24), (False, 300), (False, 500), (True, 264)])
+def test_svgp_head(ctx, white, M):
+    """M = 300 / 500 / 264: the one-launch head conditional with TWO row fragments per wave (M > 256: nf = 19 -- an odd count, the middle fragment
+    alone on its wave -- 32 with padded rows, 17), on 23 columns (a ragged second strip)."""
     from deepcgp_amd.kernels import RBF, ConvKernel, PatchInducingFeatures
     from deepcgp_amd.layers import SVGP_Layer
     from deepcgp_amd.views import FullView
     rng = np.random.default_rng(9)
-    H, W, C, f, s, M, R, N = 12, 12, 10, 5, 1, 24, 10, 7
+    H, W, C, f, s, R, N = 12, 12, 10, 5, 1, 10, 7 if M == 24 else 23
     X = rng.standard_normal((N, H * W * C))
     v, ov = FullView((H, W, C), f, C, s), OFullView((H, W, C), f, C, s)
     w = rng.random(v.patch_count) + 0.5
