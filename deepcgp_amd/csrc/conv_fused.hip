@@ -36,10 +36,9 @@ __device__ __forceinline__ void set_prio(int p) {   // s_setprio takes an immedi
 }
 __device__ __forceinline__ int frag_of(int w, int W, int c) { return (c >> 1) * 2 * W + ((c & 1) ? 2 * W - 1 - w : w); }
 
-// phase timestamps for tools/fused_trace.py: [workgroup][wave][16] shader-clock ticks, first 8 workgroups of every 90th
-#define CF_TR(k)                                                                                              \
-  if (a.trace && lane == 0 && blockIdx.x % 90 == 0 && blockIdx.x / 90 < 8)                                   \
-    a.trace[((blockIdx.x / 90) * 16 + wave) * 16 + (k)] = (long long)__builtin_readcyclecounter();
+// phase timestamps for tools/fused_trace.py: [8 sampled workgroups][4 strips of a persistent workgroup][wave][16] shader-clock ticks
+#define CF_TR(k) \
+  if (tr_slot >= 0 && lane == 0) a.trace[(tr_slot * 16 + wave) * 16 + (k)] = (long long)__builtin_readcyclecounter();
 
 // FN: 16-column fragments per strip.  NS: the W = NT/64 waves form NS teams of TW = W/NS; the row fragments are dealt to the
 // TW members of a team (boustrophedon), and the teams split the rest of the work: the columns of the strip in the sweep and in
@@ -49,32 +48,55 @@ __device__ __forceinline__ int frag_of(int w, int W, int c) { return (c >> 1) * 
 // MAXF: row fragments per wave at most.  ABL: timing experiments only (wrong results): 1 = second product without its
 // A-operand loads, 2 = without the LDS reads of the B operand, 4 = two more A tiles in flight.
 template <int FN, int NS, int MAXF, int NT, int BT, int ABL = 0>
-__global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
+__global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
+  // The arguments are read through the kernarg pointer, which every strip of a persistent workgroup sees as a new value: as a by-value
+  // struct the loop-invariant loads of all ~70 words are hoisted out of the strip loop, live across it, and spill (240 VGPRs at 16 waves)
+  typedef const __attribute__((address_space(4))) ConvFusedArgs KArgs;
+  KArgs* ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  KArgs& a = *ap;
   constexpr int BN = FN * 16, W = NT / 64, TW = W / NS, FNS = FN / NS, KG = W / FN;
   static_assert(FN % NS == 0 && W % NS == 0 && W % FN == 0, "team split");
   constexpr int CF_D = ((ABL & 4) ? 2 : 0) + (NT >= 1024 ? 2 : CF_D_DEFAULT);   // 128-register budget at 16 waves: two tiles ahead
   extern __shared__ __attribute__((aligned(16))) double smem[];
+
+  // A persistent launch (a.persist: one workgroup per slot of the chip): the workgroup walks the strips blockIdx, blockIdx + grid, ...
+  // The second workgroup to arrive on a CU holds back for a.stagger ticks of the 100 MHz clock, so that its sweep / first product / epilogue -- the
+  // stretches that leave the matrix pipe thin -- fall into the other's second product and the other's into its own, strip after strip.
+  int cu_word = -1;
+  if (a.persist && a.cu_slots) {
+    int* word = reinterpret_cast<int*>(smem);
+    if (threadIdx.x == 0) {
+      unsigned xcc, hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      cu_word = (int)(((xcc & 7u) << 7) | ((hwid >> 8) & 0x7fu));   // XCC, SE_ID [15:13], SH_ID [12], CU_ID [11:8]
+      word[0] = atomicAdd(a.cu_slots + cu_word, 1);
+    }
+    __syncthreads();
+    const int arrival = word[0];
+    __syncthreads();
+    if ((arrival & 1) && a.stagger > 0) {
+      const long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < a.stagger) __builtin_amdgcn_s_sleep(64);
+    }
+  }
+  int strip_next = blockIdx.x;
+  for (int it = 0;; ++it) {
+  // every strip sees the kernarg pointer and the thread index as new values: nothing of a strip's set-up (argument words, per-lane offsets of every
+  // phase) is then loop-invariant, hoisted and kept live across the whole body -- as plain invariants they cost 240 spilled VGPRs at 16 waves
+  int tid = threadIdx.x;
+  asm volatile("" : "+s"(ap), "+v"(tid));
+  KArgs& a = *ap;
   const int Mp = a.Mp, nf = Mp >> 4, R = a.R;
-  const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
+  const int lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % TW, sp = NS == 1 ? 0 : wave / TW;   // member index within the team, team
-  double* strip = smem;                                  // [Mp][BN], 16-column groups XOR-swizzled by (row & (FN-1))
+  double* strip = smem;                                  // [Mp / 4][FN][4][16]: rows in fours (below)
   double* aux = smem + a.lds_main;                       // images of the strip; after phase 1: [TW][BN] partial sums of A1^2
   double* xn = aux + a.lds_img;                          // [BN] |x_p|^2
-  int* koff = reinterpret_cast<int*>(xn + BN);           // [Lp]
-  // strips of the launch's partial last round are shared by SQ workgroups: each runs phases 0 - 2 and the outputs r = sq, sq + SQ, ...
-  int sidx = blockIdx.x, sq = 0, SQ = 1;
-  if (sidx >= a.split_first) {
-    const int t = sidx - a.split_first;
-    SQ = a.split_q;
-    sidx = a.split_first + t / SQ;
-    sq = t - (sidx - a.split_first) * SQ;
-  }
-  const int j0 = sidx * BN;
+  int* ticket = reinterpret_cast<int*>(xn + BN);         // persistent launch: the next strip of this workgroup
+  int* koff = reinterpret_cast<int*>(xn + BN + 2);       // [Lp]
   const int jmax = a.Kc - 1;
-  CF_TR(0)
-  if (a.trace && lane == 0 && blockIdx.x % 90 == 0 && blockIdx.x / 90 < 8) a.trace[((blockIdx.x / 90) * 16 + wave) * 16 + 10] = (long long)wall_clock64();
-
   // row fragments of this wave: frag_of(wm, TW, c), c < nfw
   int nfw = 0;
 #pragma unroll
@@ -83,6 +105,27 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
   int fr[MAXF];   // fragments beyond the matrix repeat the first one (their loads stay in range, their results are dropped)
 #pragma unroll
   for (int c = 0; c < MAXF; ++c) fr[c] = c < nfw ? frag_of(wm, TW, c) : min(wm, nf - 1);
+  // strips of the launch's partial last round are shared by SQ workgroups: each runs phases 0 - 2 and the outputs r = sq, sq + SQ, ...
+  int sidx = strip_next, sq = 0, SQ = 1;
+  if (sidx >= a.split_first) {
+    const int t = sidx - a.split_first;
+    SQ = a.split_q;
+    sidx = a.split_first + t / SQ;
+    sq = t - (sidx - a.split_first) * SQ;
+  }
+  const int j0 = sidx * BN;
+  int tr_slot = -1;
+  if (a.trace) {
+    const int every = a.persist ? max((int)gridDim.x / 8, 1) : 90;
+    if (blockIdx.x % every == 0 && blockIdx.x / every < 8 && it < 4) tr_slot = (blockIdx.x / every) * 4 + it;
+  }
+  CF_TR(0)
+  if (tr_slot >= 0 && lane == 0) a.trace[(tr_slot * 16 + wave) * 16 + 10] = (long long)wall_clock64();
+  // Two workgroups share a CU in a persistent launch.  The stretches that cannot fill the matrix pipe by themselves (images, sweep, first product,
+  // epilogue: latency- and barrier-bound) issue ahead of the other workgroup's second product, which takes what they leave: at equal or lower
+  // priority a sweep beside a second product took 110 us instead of 25 (profiles/r06_fused_persistent_static_trace.txt) while the second product,
+  // alone on two waves per SIMD, cannot use more than 81 % of the pipe
+  __builtin_amdgcn_s_setprio(3);
 
   // ---- phase 0: images of the strip -> LDS, patch-element offsets, |x|^2 per column -----------------------------
   const int n_first = j0 / a.P;
@@ -103,6 +146,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
         if (i < total) aux[i] = BT == 0 ? t[e] * a.csq : t[e];   // RBF: the sweep's operands carry the kernel's scales (sweep_dev.h)
       }
     }
+    if (it == 0)
     for (int l = tid; l < (BT == 0 ? a.Lz : a.Lp); l += NT) {
       const int ll = l < a.L ? l : 0;
       const int c = ll % a.C, t = ll / a.C;
@@ -142,15 +186,12 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
   __syncthreads();
   CF_TR(1)
 
-  // per-lane constants of the strip accesses: element (row k, column y*16 + lcol) with k & 3 == lrow lives at
-  // k * BN + ((y ^ (lrow & (FN-1))) * 16 + lcol)
-  int bsw[FN];
-#pragma unroll
-  for (int y = 0; y < FN; ++y) bsw[y] = ((y ^ (lrow & (FN - 1))) << 4) + lcol;
-  int bsw_s[FNS];   // the same for this team's column fragments sp*FNS + y
-#pragma unroll
-  for (int y = 0; y < FNS; ++y) bsw_s[y] = (((sp * FNS + y) ^ (lrow & (FN - 1))) << 4) + lcol;
-
+  // The strip in LDS: rows in fours, element (row k, column 16 y + i) at (k >> 2) * 4 BN + 64 y + 16 (k & 3) + i: a B fragment (rows k0 .. k0 + 3 by lrow,
+  // k0 a multiple of 4; columns 16 y + lcol) is 512 contiguous bytes, lane l at l * 8 -- no bank conflicts, and every address of the kernel is the lane
+  // index plus compile-time offsets (column group, sub-step, accumulator row: multiples of 512 bytes, the unit of ds_read2st64_b64) plus a scalar
+  // (k-tile).  On gfx950 a VALU instruction issues in the fp64 MFMA's place: the row-major strip with its column groups XOR-swizzled by the row spent
+  // 10 - 14 of them per k-tile of the second product on addresses (4 - 5 % of its 1024 MFMA cycles), this one spends 1
+  constexpr int QS = 4 * BN;
   // ---- phase 1: K_uf[:, strip] -> strip: this wave's row fragments x its team's FNS column fragments ----------------
   {
     int pb[FNS];
@@ -170,6 +211,8 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
     for (int y = 0; y < FNS; ++y) xnv[y] = xn[(sp * FNS + y) * 16 + lcol];
     constexpr int D4 = 4;
     double ring[D4 + 1][MAXF];
+#pragma unroll
+    for (int c = 0; c < MAXF; ++c) ring[D4][c] = 0.0;   // (defined on every path: an undefined slot would be carried from strip to strip of a persistent workgroup)
     auto ldz = [&](int k4, double (&dst)[MAXF]) {
 #pragma unroll
       for (int c = 0; c < MAXF; ++c) dst[c] = zt[(long)(4 * k4 + lrow) * Mp + 16 * fr[c]];
@@ -225,13 +268,15 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
           for (int y = 0; y < FNS; ++y)
 #pragma unroll
             for (int v = 0; v < 4; ++v) { n1[y * 4 + v] = xnv[y]; n2[y * 4 + v] = znv[BT == 0 ? 0 : c][v]; }
-          a.bk.template eval_n<BT, FNS * 4>(kv, n1, n2);
+          BaseKernel bk;
+          bk.type = a.bk.type; bk.variance = a.bk.variance; bk.p1 = a.bk.p1; bk.p2 = a.bk.p2;
+          bk.template eval_n<BT, FNS * 4>(kv, n1, n2);
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int m = 16 * fr[c] + lrow + 4 * v;
 #pragma unroll
-          for (int y = 0; y < FNS; ++y) strip[m * BN + bsw_s[y]] = (m < a.M) ? kv[y * 4 + v] : 0.0;
+          for (int y = 0; y < FNS; ++y) strip[(4 * fr[c] + v) * QS + (sp * FNS + y) * 64 + lane] = (m < a.M) ? kv[y * 4 + v] : 0.0;
         }
       }
     }
@@ -244,7 +289,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
     for (int idx = tid; idx < Mp * BN; idx += NT) {
       const int m = idx / BN, c = idx - m * BN;
       const int j = j0 + c;
-      if (j <= jmax) out[(long)m * a.ldk + j] = strip[m * BN + ((((c >> 4) ^ (m & (FN - 1))) << 4) | (c & 15))];
+      if (j <= jmax) out[(long)m * a.ldk + j] = strip[(m >> 2) * QS + (c >> 4) * 64 + (m & 3) * 16 + (c & 15)];
     }
   };
   if (a.Kuf_out && sq == 0) store_strip(a.Kuf_out);
@@ -266,15 +311,19 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
   // ---- phase 2: A1 = inv(L) K_uf (lower-triangular W: fragment f needs k-tiles 0 .. f), FNS column fragments per wave ----
   const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.LinvT), 0, Mp * Mp * 8, 0x00020000);
   d4 a1[MAXF][FNS];
+#pragma unroll
+  for (int c = 0; c < MAXF; ++c)
+#pragma unroll
+    for (int y = 0; y < FNS; ++y) a1[c][y] = d4{0.0, 0.0, 0.0, 0.0};
   {
     double s1acc[FNS];
 #pragma unroll
     for (int y = 0; y < FNS; ++y) s1acc[y] = 0.0;
     d4 acc[FNS];
     auto ldb = [&](int kt, int q, double (&dst)[FNS]) {
-      const double* b = strip + (kt * 16 + 4 * q + lrow) * BN;
+      const double* b = strip + (kt * 4 + q) * QS + lane;
 #pragma unroll
-      for (int y = 0; y < FNS; ++y) dst[y] = b[bsw_s[y]];
+      for (int y = 0; y < FNS; ++y) dst[y] = b[(sp * FNS + y) * 64];
     };
     auto mf = [&](double w, const double (&b)[FNS]) {
 #pragma unroll
@@ -300,6 +349,8 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
 #pragma unroll
         for (int y = 0; y < FNS; ++y) acc[y] = d4{0.0, 0.0, 0.0, 0.0};
         double ring[CF_D + 1][4], b0[FNS];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ring[CF_D][q] = 0.0;
 #pragma unroll
         for (int u = 0; u < CF_D; ++u) ldw(lrs, fo + min(u, f) * 16 * Mp * 8, ring[u]);
         ldb(0, 0, b0);
@@ -339,7 +390,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
 #pragma unroll
       for (int y = 0; y < FNS; ++y)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) strip[(16 * fr[c] + lrow + 4 * v) * BN + bsw_s[y]] = a1[c][y][v];
+        for (int v = 0; v < 4; ++v) strip[(4 * fr[c] + v) * QS + (sp * FNS + y) * 64 + lane] = a1[c][y][v];
     }
   }
   __syncthreads();   // A1 published
@@ -359,9 +410,9 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
 #pragma unroll
   for (int y = 0; y < FN; ++y) acc[y] = d4{0.0, 0.0, 0.0, 0.0};
   auto ldb = [&](int kt, int q, double (&dst)[FN]) {
-    const double* b = strip + (kt * 16 + 4 * q + lrow) * BN;
+    const double* b = strip + (kt * 4 + q) * QS + lane;
 #pragma unroll
-    for (int y = 0; y < FN; ++y) dst[y] = (ABL & 2) ? (double)(lane + y + q) : b[bsw[y]];
+    for (int y = 0; y < FN; ++y) dst[y] = (ABL & 2) ? (double)(lane + y + q) : b[y * 64];
   };
   auto mf = [&](double w, const double (&b)[FN]) {
 #pragma unroll
@@ -407,6 +458,8 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
     for (int y = 0; y < FN; ++y) s2acc[y] = 0.0;
     double ring[CF_D + 1][4], b0[FN];
 #pragma unroll
+    for (int q = 0; q < 4; ++q) ring[CF_D][q] = 0.0;
+#pragma unroll
     for (int u = 0; u < CF_D; ++u) { ldw(grs, lsoff(), ring[u]); ladv(); }
     ldb(ck, 0, b0);
     auto step = [&](const double (&w)[4]) {
@@ -451,7 +504,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
       // issue priority falls with progress: the arbiter favours the oldest wave of a SIMD, which then finishes this phase 50 us
       // (of 160) ahead of the youngest and leaves it the pipe to itself at the end; a wave a quarter ahead yields (-1 % kernel time;
       // rotating the priorities per group did the same, pinning the LDS reads ahead of the MFMAs with sched_group_barrier +1 %)
-      set_prio(3 - (4 * t) / total);
+      set_prio(2 - (3 * t) / total);
 #pragma unroll
       for (int u = 0; u <= CF_D; ++u) {
         if (!(ABL & 1)) ldw(grs, lsoff(), ring[(u + CF_D) % (CF_D + 1)]);
@@ -464,7 +517,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
       if (t + u < total) step(ring[u]);
     }
   }
-  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(3);
   CF_TR(6)
 
   // ---- mean = alpha^T A1: wave (y, g) = (wave % FN, wave / FN) takes column fragment y and the k-tiles g, g + KG, ... -------
@@ -477,7 +530,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         w[q] = al[(long)(kt * 16 + 4 * q + lrow) * a.Rp];
-        b[q] = strip[(kt * 16 + 4 * q + lrow) * BN + ((y ^ (lrow & (FN - 1))) << 4) + lcol];
+        b[q] = strip[(kt * 4 + q) * QS + y * 64 + lane];
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) macc = __builtin_amdgcn_mfma_f64_16x16x4f64(w[q], b[q], macc, 0, 0, 0);
@@ -505,6 +558,8 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
   __syncthreads();
 
   CF_TR(8)
+  RngMap rmap;
+  rmap.W = a.rmap.W; rmap.Nl = a.rmap.Nl; rmap.Ng = a.rmap.Ng; rmap.lo = a.rmap.lo;
   // ---- phase 4: var, mean, sample in the N x (P*R) layout (column j, output r at j*R + r) ----------------------------
   for (int idx = tid; idx < BN * R; idx += NT) {
     const int c = idx / R, r = idx - c * R;
@@ -528,13 +583,30 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a) {
       if (a.out_mean) a.out_mean[o] = m;
       if (a.out_var) a.out_var[o] = v;
       if (a.out_sample) {
-        const double zz = a.z ? a.z[o] : philox_normal(a.seed, a.stream_id, rng_index(a.rmap, o));
+        const double zz = a.z ? a.z[o] : philox_normal(a.seed, a.stream_id, rng_index(rmap, o));
         a.out_sample[o] = m + zz * sqrt(v + a.jitter);
       }
     }
   }
   CF_TR(9)
-  if (a.trace && lane == 0 && blockIdx.x % 90 == 0 && blockIdx.x / 90 < 8) a.trace[((blockIdx.x / 90) * 16 + wave) * 16 + 11] = (long long)wall_clock64();
+  if (tr_slot >= 0 && lane == 0) a.trace[(tr_slot * 16 + wave) * 16 + 11] = (long long)wall_clock64();
+  if (!a.persist) break;
+  // the next strip: dealt by arrival (a.dyn: one counter per launch) -- two workgroups share a CU and the one launched first wins every arbitration
+  // between them, so a fixed deal leaves the other with a strip and a half to run alone at the end (profiles/r06_fused_persistent_static_trace.txt)
+  if (tid == 0) ticket[0] = a.dyn ? (int)gridDim.x + atomicAdd(a.dyn, 1) : strip_next + (int)gridDim.x;
+  __syncthreads();   // (and the partial sums are read: the next strip's images may land on them)
+  strip_next = __builtin_amdgcn_readfirstlane(ticket[0]);
+  if (strip_next >= a.n_strips) break;
+  }
+  if (threadIdx.x == 0) {
+    if (cu_word >= 0) atomicSub(ap->cu_slots + cu_word, 1);
+    // the last workgroup to leave puts the counters back for the next launch
+    if (ap->persist && ap->dyn && atomicAdd(ap->dyn + 1, 1) == (int)gridDim.x - 1) {
+      ap->dyn[1] = 0;
+      __threadfence();
+      atomicExch(ap->dyn, 0);
+    }
+  }
 }
 
 // the instantiated shapes: <FN, NS, MAXF, NT>
@@ -551,7 +623,7 @@ template <int FN, int NS, int MAXF, int NT>
 int launch_fused(dcgp_ctx* ctx, const ConvFusedArgs& a, size_t lds) {
   const int BN = FN * 16;
   const long strips = ((long)a.Kc + BN - 1) / BN;
-  const unsigned grid = (unsigned)(a.split_q > 1 ? a.split_first + (strips - a.split_first) * a.split_q : strips);
+  const unsigned grid = (unsigned)(a.persist ? a.persist : (a.split_q > 1 ? a.split_first + (strips - a.split_first) * a.split_q : strips));
   static bool attr_done[64] = {};   // per device: a second ctx on another device of this process needs the opt-in too
   const int dv = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
   if (!attr_done[dv]) {   // more than 64 KB of dynamic LDS needs the opt-in
@@ -619,7 +691,7 @@ bool plan_fused(const dcgp_ctx* ctx, const ConvFusedArgs& a, FusedPlan* p) {
     const long main_d = (long)a.Mp * BN > fin ? (long)a.Mp * BN : fin;
     long img_d = ((long)nimg * a.HWC + 1) & ~1L;
     if (img_d < (long)TW * BN) img_d = (long)TW * BN;
-    const long bytes = (main_d + img_d + BN) * 8 + (long)(a.Lz > a.Lp ? a.Lz : a.Lp) * 4;
+    const long bytes = (main_d + img_d + BN + 2) * 8 + (long)(a.Lz > a.Lp ? a.Lz : a.Lp) * 4;
     if (bytes > 160 * 1024) continue;
     const long strips = a.Kc > 0 ? ((long)a.Kc + BN - 1) / BN : 1;
     // shape 7 (32 columns on 16 waves, the outputs split over two teams): a strip's latency is what a launch of one round costs, and
@@ -660,10 +732,32 @@ int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a_in) {
   ConvFusedArgs a = a_in;
   a.lds_main = p.lds_main; a.lds_img = p.lds_img;
   a.trace = ctx->fused_trace;
-  if (p.split_q > 1 && !a.trace) {
-    const long strips = ((long)a.Kc + kShapes[p.shape].FN * 16 - 1) / (kShapes[p.shape].FN * 16);
+  const long strips = ((long)a.Kc + kShapes[p.shape].FN * 16 - 1) / (kShapes[p.shape].FN * 16);
+  const int n_cus = ctx->n_cus > 0 ? ctx->n_cus : 256;
+  // workgroups a CU holds: LDS (160 KB) and wave slots (the kernels are held to 128 registers: 16 waves of 64 per CU)
+  const long per_cu = std::min<long>(160 * 1024 / (long)p.lds, 1024 / kShapes[p.shape].NT);
+  const bool persist = ctx->opt.fused_persist > 0 && per_cu >= 1 && strips > per_cu * n_cus;
+  if (persist) {
+    a.persist = (int)(per_cu * n_cus);
+    a.n_strips = (int)strips;
+    if (ctx->opt.fused_persist != 2) {   // (2: the fixed deal blockIdx, blockIdx + grid, ... -- A/B)
+      const std::string nm = "fused_dyn" + ctx->ws_tag;   // steps in flight on the two banks run this kernel side by side: a counter pair each
+      const bool fresh = ctx->ws.find(nm) == ctx->ws.end();
+      a.dyn = static_cast<int*>(ws_get(ctx, nm, 2 * sizeof(int)));
+      if (!a.dyn) return DCGP_ERR_ALLOC;
+      if (fresh) HIP_TRY(ctx, hipMemsetAsync(a.dyn, 0, 2 * sizeof(int), ctx->stream));
+    }
+    if (per_cu > 1) {
+      const long us = ctx->opt.fused_stagger >= 0 ? ctx->opt.fused_stagger : 40;
+      a.stagger = (int)(us * 100);
+      bool fresh = ctx->ws.find("fused_cu_slots") == ctx->ws.end();
+      a.cu_slots = static_cast<int*>(ws_get(ctx, "fused_cu_slots", 1024 * sizeof(int)));
+      if (!a.cu_slots) return DCGP_ERR_ALLOC;
+      if (fresh) HIP_TRY(ctx, hipMemsetAsync(a.cu_slots, 0, 1024 * sizeof(int), ctx->stream));
+    }
+  } else if (p.split_q > 1 && !a.trace) {
     a.split_q = p.split_q;
-    a.split_first = (int)(strips - strips % (ctx->n_cus > 0 ? ctx->n_cus : 256));
+    a.split_first = (int)(strips - strips % n_cus);
   }
   ScopedTimer t(ctx, "conv_fused");
 #ifdef DCGP_EXPERIMENTS

@@ -117,6 +117,11 @@ struct ConvFusedArgs {
   int lds_main = 0, lds_img = 0;                           // set by the launcher
   int split_first = 1 << 30, split_q = 1;                  // set by the launcher: strips >= split_first are shared by split_q workgroups (outputs r = q, q + split_q, ...)
   long long* trace = nullptr;                              // debugging aid: phase timestamps (dcgp_debug_set_fused_trace)
+  // set by the launcher: a persistent launch -- one workgroup per slot of the chip, each walking the strips blockIdx, blockIdx + grid, ... < n_strips
+  int persist = 0, n_strips = 0;
+  int stagger = 0;                                         // the second workgroup to arrive on a CU starts this many 100 MHz ticks late
+  int* dyn = nullptr;                                      // [2] {strips dealt beyond the first of every workgroup, workgroups that have left}: zero between launches
+  int* cu_slots = nullptr;                                 // [1024] arrival counters per CU (zero between launches: every workgroup gives its count back)
 };
 // the reverse pass of the same strip (conv_bwd_fused.hip): dK_uf = inv(L)^T [sum_r (S_r A1) o (2 gv_r) + alpha gm^T - 2 A1 o gvs]
 struct ConvBwdArgs {

@@ -337,7 +337,7 @@ int dcgp_allreduce_sum_f64(dcgp_ctx* ctx, double* buf_dev, int n);
  * main_idle_out (may be NULL): bit 0 -- the ctx's main stream has drained (hipStreamQuery), bit 1 -- the comm stream has. */
 int dcgp_debug_comm_gate(dcgp_ctx* ctx, int closed, int* main_idle_out);
 /* Device buffer of 8 x 16 x 16 int64 into which the one-launch conv layer kernel (csrc/conv_fused.hip) stamps the shader
- * clock at its phase boundaries (8 sampled workgroups x 16 waves x 16 stamps); NULL switches it off (tools/fused_trace.py). */
+ * clock at its phase boundaries (8 sampled workgroups x 4 strips of a persistent one x 16 waves x 16 stamps = 8192 words); NULL switches it off (tools/fused_trace.py). */
 int dcgp_debug_set_fused_trace(dcgp_ctx* ctx, long long* buf_dev);
 /* The same for the patch sweeps (csrc/head_units.hip; tools/sweep_trace.py): [n_workgroups][waves per workgroup][8] int64 -- wall clock at entry,
  * shader clock at entry / image staged / set-up done / first unit done / last unit done, wall clock at exit, units run.            */
