@@ -483,6 +483,8 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
         for (int y = 0; y < FN; ++y) {
 #pragma unroll
           for (int v = 0; v < 4; ++v) s2acc[y] = fma(acc[y][v], acc[y][v], s2acc[y]);
+          // (starting a fragment's first MFMAs from the constant 0 in their C operand instead of these sixteen moves, on a second copy of the
+          // k-tile body: +17 us on the cfg2 launch -- profiles/r06_fused_ab.txt)
           acc[y] = d4{0.0, 0.0, 0.0, 0.0};
         }
         if (r_end) {   // output done
@@ -501,10 +503,11 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
     };
     int t = 0;
     for (; t + CF_D + 1 <= total; t += CF_D + 1) {   // full groups: no conditionals around the loads
-      // issue priority falls with progress: the arbiter favours the oldest wave of a SIMD, which then finishes this phase 50 us
-      // (of 160) ahead of the youngest and leaves it the pipe to itself at the end; a wave a quarter ahead yields (-1 % kernel time;
-      // rotating the priorities per group did the same, pinning the LDS reads ahead of the MFMAs with sched_group_barrier +1 %)
-      set_prio(2 - (3 * t) / total);
+      // issue priority falls with progress: the arbiter favours the oldest wave of a SIMD, which then finishes this phase 50 us (of 160) ahead of the
+      // youngest and leaves it the pipe to itself at the end; a wave ahead yields.  The steps shorten towards the end (1/2, 3/4, 9/10 of the stream): what the
+      // waves of a SIMD differ by when they finish is about half the last step.  cfg2 launch: this schedule 576 us, quarters 3..0 579, thirds 2..0 581
+      // (profiles/r06_fused_ab.txt); rotating the priorities per group measured like the quarters, pinning the LDS reads with sched_group_barrier +1 %
+      set_prio(2 * t < total ? 3 : (4 * t < 3 * total ? 2 : (10 * t < 9 * total ? 1 : 0)));
 #pragma unroll
       for (int u = 0; u <= CF_D; ++u) {
         if (!(ABL & 1)) ldw(grs, lsoff(), ring[(u + CF_D) % (CF_D + 1)]);

@@ -157,6 +157,17 @@ struct StreamGuard {
 //   main stream: the data path (sweeps, conditionals, sampling), gated per layer by the side stream's events.
 // pipelined (dcgp_elbo_forward_enqueue): main = 30 CUs of every XCD, side = the other 2, so that the chain of step i + 1 runs
 // under the data path of step i without competing for its CUs; otherwise both streams see the whole chip.
+// what the assembly at the end of a step needs: layer shapes, the status words of the factor groups, the pinned result slot
+void fill_finish(dcgp_model* model, std::vector<FactorGroup>& groups, double scale, int slot, ElboFinish* fin) {
+  const int nl = (int)model->layers.size();
+  fin->nl = nl; fin->scale = scale;
+  for (int l = 0; l < nl; ++l) { fin->M[l] = model->layers[l]->M; fin->R[l] = model->layers[l]->R; fin->white[l] = model->layers[l]->white; }
+  fin->ngroups = (int)groups.size();
+  for (int g = 0; g < fin->ngroups && g < 16; ++g) { fin->info[g] = groups[g].d_info; fin->ninfo[g] = (int)groups[g].K.size(); }
+  fin->host_out = model->h_ring_dev + 8 * slot;   // the last kernel of the step writes the result words into the pinned slot itself
+  fin->host_seq = (double)(model->enq_seq + 1);   // ... and this step's ticket + 1 behind them
+}
+
 int forward_all(dcgp_model* m, const double* X, int N, int S, const double* const* zs, uint64_t seed, int dedup,
                 bool need_kl, bool pipelined, int* rows_last) {
   dcgp_ctx* ctx = m->ctx;
@@ -262,21 +273,27 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     else if (ctx->ev_last_valid) HIP_TRY(ctx, hipStreamWaitEvent(chain_s, ctx->ev_last, 0));    // first use: behind whatever ran last
   }
   int rc = DCGP_OK;
+  // (events only where another stream waits for them: each record is a packet in front of the next launch)
+  const bool xs = chain_s != main_s;
+  // A first layer whose sweep is a launch of its own (the head-first model) is the step's critical path: the operand preparation sits on the MAIN
+  // stream, the sweep directly behind it, and it is the CHAIN that pays the hand-off between streams -- it ends well before the sweep does.  With the
+  // preparation on the chain's stream the sweep started 20.8 us into the step (8 us of preparation + the event), now at ~9.
+  const bool prep_on_main = xs && !first_fused && !ctx->opt.no_early_sweep && !ctx->opt.prep_on_chain;
   {
     PrepArgs pa;
     pa.nl = nl;
     for (int li = 0; li < nl; ++li) pa.l[li] = m->layers[li]->prep_args(m->jitter);
+    if (prep_on_main) ctx->stream = main_s;
     rc = prepare_all(ctx, pa);
   }
-  // (events only where another stream waits for them: each record is a packet in front of the next launch)
-  const bool xs = chain_s != main_s;
   if (rc == DCGP_OK && xs && !first_fused && hipEventRecord(m->ev_sweep[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;   // Z^T, |z|^2: what a sweep needs
+  if (rc == DCGP_OK && prep_on_main && hipStreamWaitEvent(chain_s, m->ev_sweep[bank], 0) != hipSuccess) rc = DCGP_ERR_HIP;
   // The first layer's sweep needs nothing else: it goes to the main stream NOW, in front of the chain's ~12 launches -- enqueued behind
   // them it started when the host was done with those, 60 us after prepare_all had finished (cfg2 head-only: 0.287 -> 0.24 ms).
   bool early0 = false;
   if (rc == DCGP_OK && xs && !first_fused && !ctx->opt.no_early_sweep) {
     ctx->stream = main_s;
-    if (hipStreamWaitEvent(main_s, m->ev_sweep[bank], 0) != hipSuccess) rc = DCGP_ERR_HIP;
+    if (!prep_on_main && hipStreamWaitEvent(main_s, m->ev_sweep[bank], 0) != hipSuccess) rc = DCGP_ERR_HIP;
     int out_rows = 0;
     if (rc == DCGP_OK) rc = layer_step(0, X, rows0, N, &out_rows, 1);
     early0 = rc == DCGP_OK;
@@ -390,7 +407,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   m->gkl_prep_wait = (m->gkl_state && mark_behind_first && chain_s != main_s) ? nl : 0;
 
   // sweeps read Z^T / |z|^2 of this bank (a one-launch first layer waits for its G / alpha, recorded behind them on the same stream)
-  if (chain_s != main_s && !first_fused) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_sweep[bank], 0));
+  if (chain_s != main_s && !first_fused && !prep_on_main) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_sweep[bank], 0));
   const double* F = X;
   int rows = rows0, n_mod = N;
   // Join the side stream where the wait is already satisfied when the main stream gets to it: in front of the last layer when
@@ -582,17 +599,6 @@ int dcgp_elbo_forward_collect(dcgp_model* model, uint64_t ticket, double* out_ho
 
 }  // extern "C"
 
-// what the assembly at the end of a step needs: layer shapes, the status words of the factor groups, the pinned result slot
-static void fill_finish(dcgp_model* model, std::vector<FactorGroup>& groups, double scale, int slot, ElboFinish* fin) {
-  const int nl = (int)model->layers.size();
-  fin->nl = nl; fin->scale = scale;
-  for (int l = 0; l < nl; ++l) { fin->M[l] = model->layers[l]->M; fin->R[l] = model->layers[l]->R; fin->white[l] = model->layers[l]->white; }
-  fin->ngroups = (int)groups.size();
-  for (int g = 0; g < fin->ngroups && g < 16; ++g) { fin->info[g] = groups[g].d_info; fin->ninfo[g] = (int)groups[g].K.size(); }
-  fin->host_out = model->h_ring_dev + 8 * slot;   // the last kernel of the step writes the result words into the pinned slot itself
-  fin->host_seq = (double)(model->enq_seq + 1);   // ... and this step's ticket + 1 behind them
-}
-
 int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t* y, int N, double scale,
                               const double* const* z_per_layer_host, uint64_t seed, int dedup_layer0, uint64_t* ticket,
                               bool pipelined) {
@@ -637,6 +643,10 @@ int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t*
     }
   } slot_guard{model, slot};
   if (!ctx->comm) {
+    // (Measured and dropped, round 6: this launch's work at the end of the head's one-launch conditional -- the last of the R workgroups of a 16-row
+    // strip to arrive runs the rows' expectations, the last workgroup of the launch the sum and the assembly.  cfg2 head-only 0.2210 -> 0.2234 ms, cfg1
+    // 0.1416 -> 0.1462, conv + head +2 us (profiles/r06_tail_ride_and_prep_ab.txt): two levels of agent-scope release/acquire at the end of 200
+    // workgroups cost more than the 13 us launch they replace.)
     // expectations, their sum, the KL pieces where the chain left their ingredients, and the ELBO assembly in one launch
     DCGP_TRY(elbo_tail(ctx, o.mean, o.var, y, rows, N, H.R, model->eps, model->d_ve, inv_s, scal, fin, klt));
   } else {

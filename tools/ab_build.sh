@@ -10,7 +10,8 @@ OBJS=$(ls *.o)
 while [ $# -ge 2 ]; do
   F=$1; E=$2; shift; shift
   sed "$E" $F > ab_${TAG}_$F
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result -c ab_${TAG}_$F -o ab_${TAG}_${F%.hip}.o
+  X=""; [ "$F" = conv_fused.hip ] && X="-mllvm -disable-machine-licm"   # (the Makefile's per-file flag)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result $X -c ab_${TAG}_$F -o ab_${TAG}_${F%.hip}.o
   OBJS=$(echo $OBJS | tr ' ' '\n' | grep -v "^${F%.hip}.o$" | tr '\n' ' ')
   OBJS="$OBJS ab_${TAG}_${F%.hip}.o"
   rm -f ab_${TAG}_$F
