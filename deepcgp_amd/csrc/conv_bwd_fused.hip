@@ -11,7 +11,7 @@
 //     dA1 = sum_r (S_r A1) o (2 gv_r) + ...,        S_r = G_r G_r^T  (M x M, symmetric, parameter-only: R small products per step)
 // -- ONE dense product per r on the LDS-resident strip of A1, exactly the forward kernel's second product (conv_fused.hip)
 // with a scaled accumulation in place of the sum of squares; T and dT are never formed.  Same machinery: the strip
-// [Mp][64] XOR-swizzled in LDS as the B operand, the A operand (S_r, then inv(L)) streamed from L2 straight into MFMA A
+// [Mp][64] in LDS (row quads) as the B operand, the A operand (S_r, then inv(L)) streamed from L2 straight into MFMA A
 // registers two k-tiles ahead, wave w owning the 16 rows of fragment w for all r (dense S_r: every wave carries the same
 // R * Mp/16 k-tiles), no barrier inside the k loops.  dA1 leaves the registers once, into the strip, as the B operand of
 // the closing triangular product; HBM traffic is the strip of A1 in and the strip of dK_uf out.
@@ -24,6 +24,7 @@ namespace {
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int CB_NT = 1024, CB_D = 2;
+#define CB_SB __builtin_amdgcn_sched_barrier(0)   // the LDS reads stay one sub-step ahead of the MFMAs, as written (see conv_fused.hip)
 
 template <int CB_FN>
 __global__ __launch_bounds__(CB_NT) void conv_bwd_fused_kernel(ConvBwdArgs a) {
@@ -34,7 +35,10 @@ __global__ __launch_bounds__(CB_NT) void conv_bwd_fused_kernel(ConvBwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool live = wave < nf;
   const int fw = live ? wave : nf - 1;                  // idle waves shadow the last fragment (loads in range, results dropped)
-  double* strip = smem;                                 // [Mp][BN], 16-column groups XOR-swizzled by (row & (FN - 1))
+  // the strip in LDS in row quads, as in conv_fused.hip: element (row k, column 16 y + i) at (k >> 2) * 4 BN + 64 y + 16 (k & 3) + i -- a B fragment is 512
+  // contiguous bytes (lane l at 8 l), every address the lane index + immediates + a scalar: one VALU instruction per k-tile where the XOR-swizzled rows took ten
+  constexpr int QS = 4 * CB_BN;
+  double* strip = smem;                                 // [Mp / 4][FN][4][16]
   double* gvl = strip + (long)Mp * CB_BN;               // [R][64]   2 gv[j][r]
   double* gml = gvl + R * CB_BN;                        // [Rk][64]  gm[j][r], zero rows beyond R
   double* gsl = gml + Rk * CB_BN;                       // [64]      -2 gvs[j]
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(CB_NT) void conv_bwd_fused_kernel(ConvBwdArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int idx = i0 + e * CB_NT + tid, m = idx >> CB_SH, c = idx & (CB_BN - 1);
-      if (idx < Mp * CB_BN) strip[m * CB_BN + ((((c >> 4) ^ (m & (CB_FN - 1))) << 4) | (c & 15))] = t[e];
+      if (idx < Mp * CB_BN) strip[(m >> 2) * QS + (c >> 4) * 64 + (m & 3) * 16 + (c & 15)] = t[e];
     }
   }
   for (int idx = tid; idx < Rk * CB_BN; idx += CB_NT) {
@@ -62,9 +66,6 @@ __global__ __launch_bounds__(CB_NT) void conv_bwd_fused_kernel(ConvBwdArgs a) {
   }
   if (tid < CB_BN) gsl[tid] = (j0 + tid < a.Kc) ? -2.0 * a.gvs[j0 + tid] : 0.0;
 
-  int bsw[CB_FN];   // element (row k, column y*16 + lcol) with k & 3 == lrow lives at k * 64 + bsw[y]
-#pragma unroll
-  for (int y = 0; y < CB_FN; ++y) bsw[y] = ((y ^ (lrow & (CB_FN - 1))) << 4) + lcol;
   unsigned voff[4];   // lane (lrow, lcol) of k-substep q of a k-tile needs Wt[16 kt + 4q + lrow][16 f + lcol]
 #pragma unroll
   for (int q = 0; q < 4; ++q) voff[q] = (unsigned)(((4 * q + lrow) * Mp + lcol) * 8);
@@ -79,9 +80,9 @@ __global__ __launch_bounds__(CB_NT) void conv_bwd_fused_kernel(ConvBwdArgs a) {
 #pragma unroll
   for (int y = 0; y < CB_FN; ++y) { acc[y] = d4{0.0, 0.0, 0.0, 0.0}; dA[y] = d4{0.0, 0.0, 0.0, 0.0}; }
   auto ldb = [&](int kt, int q, double (&dst)[CB_FN]) {
-    const double* b = strip + (kt * 16 + 4 * q + lrow) * CB_BN;
+    const double* b = strip + (kt * 4 + q) * QS + lane;
 #pragma unroll
-    for (int y = 0; y < CB_FN; ++y) dst[y] = b[bsw[y]];
+    for (int y = 0; y < CB_FN; ++y) dst[y] = b[y * 64];
   };
   auto mf = [&](double w, const double (&b)[CB_FN]) {
 #pragma unroll
@@ -91,13 +92,21 @@ __global__ __launch_bounds__(CB_NT) void conv_bwd_fused_kernel(ConvBwdArgs a) {
   auto tile = [&](int kt, int kt_next, const double (&w)[4], double (&b0)[CB_FN]) {
     double b1[CB_FN];
     ldb(kt, 1, b1);
+    CB_SB;
     mf(w[0], b0);
+    CB_SB;
     ldb(kt, 2, b0);
+    CB_SB;
     mf(w[1], b1);
+    CB_SB;
     ldb(kt, 3, b1);
+    CB_SB;
     mf(w[2], b0);
+    CB_SB;
     ldb(kt_next, 0, b0);
+    CB_SB;
     mf(w[3], b1);
+    CB_SB;
   };
   __syncthreads();   // strip resident
 
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(CB_NT) void conv_bwd_fused_kernel(ConvBwdArgs a) {
     for (int y = 0; y < CB_FN; ++y) {
       const double gs = gsl[y * 16 + lcol];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) dA[y][v] = fma(gs, strip[(16 * fw + lrow + 4 * v) * CB_BN + bsw[y]], dA[y][v]);
+      for (int v = 0; v < 4; ++v) dA[y][v] = fma(gs, strip[(4 * fw + v) * QS + y * 64 + lane], dA[y][v]);
     }
   }
   __syncthreads();   // every wave is done with the strip of A1
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(CB_NT) void conv_bwd_fused_kernel(ConvBwdArgs a) {
 #pragma unroll
     for (int y = 0; y < CB_FN; ++y)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) strip[(16 * fw + lrow + 4 * v) * CB_BN + bsw[y]] = dA[y][v];
+      for (int v = 0; v < 4; ++v) strip[(4 * fw + v) * QS + y * 64 + lane] = dA[y][v];
   }
   __syncthreads();   // dA1 published
   // ---- dK_uf = inv(L)^T dA1: Wt[k][i] = inv(L)[k][i], upper-triangular product (k-tiles fw .. nf-1) ----

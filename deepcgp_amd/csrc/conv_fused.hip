@@ -24,6 +24,12 @@
 namespace {
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// the scheduler otherwise sinks each sub-step's LDS reads behind the previous sub-step's MFMAs and into the same registers: one buffer, every
+// sub-step waits a full LDS latency (the source order -- reads one sub-step ahead -- is what is meant)
+#define CF_SB __builtin_amdgcn_sched_barrier(0)
+#define CF_P1 50
+#define CF_P2 75
+#define CF_P3 90
 constexpr int CF_D_DEFAULT = 3;   // A-operand k-tiles in flight per wave beside the one being multiplied
 
 __device__ __forceinline__ void set_prio(int p) {   // s_setprio takes an immediate
@@ -423,13 +429,21 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
   auto tile = [&](int kt, int kt_next, const double (&w)[4], double (&b0)[FN]) {
     double b1[FN];
     ldb(kt, 1, b1);
+    CF_SB;
     mf(w[0], b0);
+    CF_SB;
     ldb(kt, 2, b0);
+    CF_SB;
     mf(w[1], b1);
+    CF_SB;
     ldb(kt, 3, b1);
+    CF_SB;
     mf(w[2], b0);
+    CF_SB;
     ldb(kt_next, 0, b0);
+    CF_SB;
     mf(w[3], b1);
+    CF_SB;
   };
   const int r0 = sq + SQ * sp, rstep = SQ * NS;
   const int nr = r0 < R ? (R - 1 - r0) / rstep + 1 : 0;   // outputs of this team
@@ -507,7 +521,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
       // youngest and leaves it the pipe to itself at the end; a wave ahead yields.  The steps shorten towards the end (1/2, 3/4, 9/10 of the stream): what the
       // waves of a SIMD differ by when they finish is about half the last step.  cfg2 launch: this schedule 576 us, quarters 3..0 579, thirds 2..0 581
       // (profiles/r06_fused_ab.txt); rotating the priorities per group measured like the quarters, pinning the LDS reads with sched_group_barrier +1 %
-      set_prio(2 * t < total ? 3 : (4 * t < 3 * total ? 2 : (10 * t < 9 * total ? 1 : 0)));
+      set_prio(100 * t < CF_P1 * total ? 3 : (100 * t < CF_P2 * total ? 2 : (100 * t < CF_P3 * total ? 1 : 0)));
 #pragma unroll
       for (int u = 0; u <= CF_D; ++u) {
         if (!(ABL & 1)) ldw(grs, lsoff(), ring[(u + CF_D) % (CF_D + 1)]);
