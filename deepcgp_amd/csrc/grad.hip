@@ -1761,6 +1761,13 @@ static int opt_enqueue(dcgp_model* model, const char* who, bool sgd, double lr, 
   if (nl > 8) return ctx_fail(ctx, DCGP_ERR_ARG, "%s: at most 8 layers", who);
   const bool comm_sharded = ctx->comm && ctx->nranks > 1 && model->grad_exchange == 1 && model->grad_scattered;
   const bool sharded = comm_sharded || vranks > 0;
+  ++model->param_version;   // the parameters change: parameter-only state of earlier steps is not reused (model_state.h)
+  // Moments are rank-local in exchange mode 1: a rank holds m / v of its own shard only.  A full update on top of them (exchange mode 0, or an
+  // optimiser step behind dcgp_elbo_grad) would move every element outside the shard with stale or zero moments -- differently on every rank.
+  if (!sgd && !comm_sharded && vranks == 0 && model->sharded_steps > 0)
+    return ctx_fail(ctx, DCGP_ERR_ARG, "%s: %llu sharded Adam steps were taken on this model (exchange mode 1): its moments cover this rank's shard only, "
+                    "a full update would let the replicas diverge", who, (unsigned long long)model->sharded_steps);
+  if (comm_sharded && !sgd) ++model->sharded_steps;
   const int nranks = vranks > 0 ? vranks : ctx->nranks, rank = vranks > 0 ? 0 : ctx->rank;
   OptArgs a{};
   a.sgd = sgd ? 1 : 0; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.status = status;
@@ -1847,6 +1854,9 @@ int dcgp_model_adam_step(dcgp_model* model, double lr, double beta1, double beta
 // dcgp_elbo_grad alone always all-reduces (its caller wants the whole gradient).
 int dcgp_model_set_grad_exchange(dcgp_model* model, int mode) {
   if (!model || (mode != 0 && mode != 1)) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "set_grad_exchange: mode 0 or 1") : DCGP_ERR_ARG;
+  if (mode == 0 && model->grad_exchange == 1 && model->sharded_steps > 0)
+    return ctx_fail(model->ctx, DCGP_ERR_ARG, "set_grad_exchange: %llu sharded Adam steps were taken: the moments are rank-local (each rank holds its own shard's), "
+                    "the all-reduce route cannot continue from them", (unsigned long long)model->sharded_steps);
   model->grad_exchange = mode;
   return DCGP_OK;
 }

@@ -182,7 +182,12 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     return ctx_fail(ctx, DCGP_ERR_ARG, "forward: %d images from image %d on overrun the declared global batch of %d (dcgp_model_set_shard)", N,
                     m->shard_lo, m->shard_global);
   DCGP_TRY(ensure_events(m));
-  const int bank = m->bank ^ 1;
+  // The chain of the previous step stands if no parameter was written since and this step may use it (model_state.h: factor_reuse): same bank, no
+  // preparation, no factorisation, no G / alpha, no KL launches -- the step is its data path.
+  const bool reuse = !pipelined && !m->grad_follows && !m->keep_state && m->chain_version == m->param_version && m->chain_with_kl == need_kl &&
+                     m->factor_reuse >= (need_kl ? 2 : 1) && !ctx->opt.no_factor_reuse;
+  if (!reuse) m->chain_version = 0;   // (stays 0 if this step fails on the way)
+  const int bank = reuse ? m->bank : m->bank ^ 1;
   m->bank = bank;
   for (auto& l : m->layers) DCGP_TRY(l->use_bank(bank));
   DCGP_TRY(build_groups(m, bank));
@@ -212,7 +217,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     fa.Mp = L0.Mp; fa.M = L0.M; fa.R = L0.R; fa.Rp = L0.g.Rp; fa.P = L0.v.P; fa.HWC = L0.v.H * L0.v.W * L0.v.C; fa.Lp = L0.Lp; fa.Lz = L0.Lz;
     first_fused = conv_fused_ok(ctx, fa);
   }
-  const hipStream_t chain_s = (pipelined || !first_fused) ? kl_s : main_s;
+  const hipStream_t chain_s = reuse ? main_s : ((pipelined || !first_fused) ? kl_s : main_s);
   // a step on the other main stream than the previous one starts behind it
   if (ctx->ev_last_valid && ctx->last_main != main_s) HIP_TRY(ctx, hipStreamWaitEvent(main_s, ctx->ev_last, 0));
   ctx->last_main = main_s;
@@ -262,6 +267,12 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     }
     return DCGP_OK;
   };
+  int rc = DCGP_OK;
+  const bool xs = chain_s != main_s;
+  const bool prep_on_main = xs && !first_fused && !ctx->opt.no_early_sweep && !ctx->opt.prep_on_chain;
+  bool early0 = false, side_kl = false;
+  if (reuse) ++m->chain_skips;
+  if (!reuse) {
   // ---- the parameter-only chain ----
   ctx->stream = chain_s;
   // its scratch per model and bank: the chains / KL terms of two steps in flight may overlap, and with the deferred copy the tail
@@ -272,13 +283,10 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     if (m->done_valid[bank]) HIP_TRY(ctx, hipStreamWaitEvent(chain_s, m->done_ev[bank], 0));   // the bank's previous reader
     else if (ctx->ev_last_valid) HIP_TRY(ctx, hipStreamWaitEvent(chain_s, ctx->ev_last, 0));    // first use: behind whatever ran last
   }
-  int rc = DCGP_OK;
   // (events only where another stream waits for them: each record is a packet in front of the next launch)
-  const bool xs = chain_s != main_s;
   // A first layer whose sweep is a launch of its own (the head-first model) is the step's critical path: the operand preparation sits on the MAIN
   // stream, the sweep directly behind it, and it is the CHAIN that pays the hand-off between streams -- it ends well before the sweep does.  With the
   // preparation on the chain's stream the sweep started 20.8 us into the step (8 us of preparation + the event), now at ~9.
-  const bool prep_on_main = xs && !first_fused && !ctx->opt.no_early_sweep && !ctx->opt.prep_on_chain;
   {
     PrepArgs pa;
     pa.nl = nl;
@@ -290,7 +298,6 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   if (rc == DCGP_OK && prep_on_main && hipStreamWaitEvent(chain_s, m->ev_sweep[bank], 0) != hipSuccess) rc = DCGP_ERR_HIP;
   // The first layer's sweep needs nothing else: it goes to the main stream NOW, in front of the chain's ~12 launches -- enqueued behind
   // them it started when the host was done with those, 60 us after prepare_all had finished (cfg2 head-only: 0.287 -> 0.24 ms).
-  bool early0 = false;
   if (rc == DCGP_OK && xs && !first_fused && !ctx->opt.no_early_sweep) {
     ctx->stream = main_s;
     if (!prep_on_main && hipStreamWaitEvent(main_s, m->ev_sweep[bank], 0) != hipSuccess) rc = DCGP_ERR_HIP;
@@ -364,7 +371,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       q.ns = kl_ns[li]; q.nsa = kl_nsa[li];
     }
   }
-  const bool side_kl = need_kl && !kl_tail;
+  side_kl = need_kl && !kl_tail;
   for (int li = 0; li < nl && rc == DCGP_OK; ++li) {
     if (!prep_done[li]) rc = cond_prep(ctx, m->layers[li]->g, m->layers[li]->white, m->layers[li]->has_qsqrt);   // generic GEMMs
     if (rc == DCGP_OK && (xs || (li == nl - 1 && side_kl && kl_s != chain_s)) && hipEventRecord(m->ev_prep[bank][li], ctx->stream) != hipSuccess)
@@ -384,6 +391,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       rc = kl_layer(ctx, L.g, Lp, LpinvT, L.white, (mp + std::to_string(li)).c_str(), scal + 4 + 4 * li);
     }
   }
+  }   // !reuse
   const bool kl_join = side_kl && kl_s != main_s;
   if (rc == DCGP_OK && kl_join && hipEventRecord(m->ev_kl[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;
   ctx->stream = main_s;
@@ -393,6 +401,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     hipStreamSynchronize(chain_s);
     return rc;
   }
+  if (!reuse && !pipelined && !m->grad_follows && !m->keep_state) { m->chain_version = m->param_version; m->chain_with_kl = need_kl; }
   // A training step: the parameter-only part of the reverse pass (grad.hip, grad_kl_early) runs beside the forward pass on the auxiliary
   // stream.  Its start is marked behind the FIRST layer (below): that layer's launch fills the chip at the full batch, and forty short
   // launches squeezed in between its rounds cost it more than they gained.  They are enqueued by dcgp_elbo_grad behind the whole forward
@@ -528,7 +537,19 @@ int dcgp_model_set_head(dcgp_model* model, int H, int W, int C, int f, int strid
   return DCGP_OK;
 }
 
+int dcgp_model_set_factor_reuse(dcgp_model* model, int mode) {
+  if (!model || mode < 0 || mode > 2) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "set_factor_reuse: mode 0, 1 or 2") : DCGP_ERR_ARG;
+  model->factor_reuse = mode;
+  return DCGP_OK;
+}
+int dcgp_model_chain_skips(dcgp_model* model, uint64_t* out) {
+  if (!model || !out) return DCGP_ERR_ARG;
+  *out = model->chain_skips;
+  return DCGP_OK;
+}
+
 int dcgp_model_set_param(dcgp_model* model, int layer, const char* which, const double* value_host, size_t count) {
+  if (model) ++model->param_version;   // (whatever becomes of the call: the parameter-only state of earlier steps is not reused)
   if (!model || !which || !value_host) return DCGP_ERR_ARG;
   dcgp_ctx* ctx = model->ctx;
   if (!strcmp(which, "likelihood_epsilon")) {   // model-wide, `layer` is ignored

@@ -40,6 +40,16 @@ struct dcgp_model {
   double* d_ve = nullptr; size_t ve_cap = 0;
   double* d_kd = nullptr; size_t kd_cap = 0;
   int id = 0;
+  // Parameter-only state kept across steps at unchanged parameters.  Every entry point that writes a parameter (set_param, the optimiser
+  // steps, the natural-gradient step) bumps param_version; a step that ran the chain records the version and its bank.  factor_reuse: 0 never, 1 the
+  // evaluation entry points (propagate, predict_y) reuse a valid chain, 2 the forward ELBO as well (evaluation sweeps at one parameter state: the
+  // reference's LogLikelihoodLogger, conv_gp/utils/log.py:55-68) -- never the default for the ELBO step: the reference's step recomputes it.
+  uint64_t param_version = 1, chain_version = 0;
+  bool chain_with_kl = false;   // the recorded chain ran for an ELBO step (KL pieces / deferred factor copy in place)
+  int factor_reuse = 1;
+  uint64_t chain_skips = 0;     // steps that reused it (tests, bench)
+  // multi-rank training: steps taken with the sharded update (exchange mode 1) leave every rank with the Adam moments of its own shard only
+  uint64_t sharded_steps = 0;
   // throughput mode of the forward (dcgp_elbo_forward_enqueue / _collect): results of up to RING steps in flight land in
   // pinned host slots, one event per slot; tickets are handed out and collected in order
   static constexpr int RING = 4;

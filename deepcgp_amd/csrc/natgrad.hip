@@ -111,6 +111,7 @@ extern "C" int dcgp_model_natgrad_step(dcgp_model* model, double gamma, int* inf
   if (!model || !(gamma > 0)) return model ? ctx_fail(model->ctx, DCGP_ERR_ARG, "natgrad_step: bad arguments") : DCGP_ERR_ARG;
   dcgp_ctx* ctx = model->ctx;
   if (info_host) *info_host = 0;
+  ++model->param_version;   // q_mu / q_sqrt change: parameter-only state of earlier steps is not reused (model_state.h)
   const int nl = (int)model->layers.size();
   std::vector<NatGradState*> st(nl, nullptr);
   for (int li = 0; li < nl; ++li) {

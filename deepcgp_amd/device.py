@@ -100,6 +100,8 @@ _SIGS = {
     "dcgp_model_debug_sharded_adam": [_vp, _i, _d, _d, _d, _d, _i],
     "dcgp_shard_range": [C.c_long, _i, _i, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)],
     "dcgp_model_set_trainable": [_vp, _i, C.c_char_p, _i],
+    "dcgp_model_set_factor_reuse": [_vp, _i],
+    "dcgp_model_chain_skips": [_vp, C.POINTER(_u64)],
     "dcgp_model_natgrad_step": [_vp, _d, _ip],
     "dcgp_model_predict_y": [_vp, _vp, _i, _i, C.POINTER(_vp), _u64, _vp, _vp, _ip],
     "dcgp_model_layer_output": [_vp, _i, _vp, _vp, _vp, _ip, _ip],

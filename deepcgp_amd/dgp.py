@@ -318,8 +318,26 @@ class DGP_Base:
         self._build()
         self._ctx._check(dev.lib().dcgp_model_set_grad_exchange(self._model, int(mode)))
 
+    def set_factor_reuse(self, mode):
+        """Parameter-only state across steps (dcgp_model_set_factor_reuse): 0 = every step runs the factorisation chain; 1 (default) = ``propagate`` /
+        ``predict_y`` skip it while no parameter was pushed or stepped since the chain last ran (the reference's AccuracyLogger sweeps a test set at
+        one parameter state, conv_gp/utils/log.py:55-68); 2 = ``compute_log_likelihood`` as well (LogLikelihoodLogger-style sweeps).  Bit-identical
+        results; a training step never reuses it."""
+        self._build()
+        self._ctx._check(dev.lib().dcgp_model_set_factor_reuse(self._model, int(mode)))
+
+    @property
+    def chain_skips(self):
+        """Steps of this model that reused the parameter-only chain of an earlier step (``set_factor_reuse``)."""
+        self._build()
+        out = C.c_uint64(0)
+        self._ctx._check(dev.lib().dcgp_model_chain_skips(self._model, C.byref(out)))
+        return int(out.value)
+
     def debug_sharded_adam(self, ranks, lr, t=None, beta1=0.9, beta2=0.999, epsilon=1e-8):
-        """Debugging aid: ``adam_step`` taken the way ``ranks`` ranks take it in exchange mode 1, played on this one GPU (bit-identical)."""
+        """Debugging aid: ``adam_step`` taken the way ``ranks`` ranks take it in exchange mode 1, played on this one GPU (bit-identical).  Needs the
+        complete gradient of a ``compute_gradients`` call."""
+        self._build()
         self._ctx._check(dev.lib().dcgp_model_debug_sharded_adam(self._model, int(ranks), float(lr), float(beta1), float(beta2), float(epsilon), int(t or 0)))
 
     def sgd_step(self, lr):

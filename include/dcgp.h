@@ -288,6 +288,15 @@ int dcgp_model_propagate(dcgp_model* model, const double* X, int N, int S,
 int dcgp_model_predict_y(dcgp_model* model, const double* X, int N, int S,
                          const double* const* z_per_layer_host, uint64_t seed,
                          double* out_p, double* out_p_mean, int* info_host);
+/* Parameter-only state across steps.  The reference's evaluation loops run hundreds of batches at ONE parameter state (AccuracyLogger /
+ * LogLikelihoodLogger, conv_gp/utils/log.py:55-68; conv_gp/utils/tensorboard.py:22-42), and every session.run of them factors every Kuu again.
+ * Here a step records the parameter version its chain (operand preparation, factorisations, inverses, G / alpha, KL pieces) ran at; every call that writes
+ * a parameter -- dcgp_model_set_param, the Adam / SGD / natural-gradient steps -- starts a new version.  mode 0: never reuse; 1 (default):
+ * dcgp_model_propagate and dcgp_model_predict_y skip the chain while the version stands; 2: the forward ELBO (dcgp_elbo_forward) as well -- for
+ * evaluation sweeps; a TRAINING step's forward pass never reuses it, and bench.py's headline never runs in mode 2 (the reference's step recomputes).
+ * Results are bit-identical to a step that runs the chain.  dcgp_model_chain_skips: steps that reused it so far. */
+int dcgp_model_set_factor_reuse(dcgp_model* model, int mode);
+int dcgp_model_chain_skips(dcgp_model* model, uint64_t* out);
 /* Output of layer `layer` from the most recent forward: sample/mean/var [rows, D_l] device->device copy. */
 int dcgp_model_layer_output(dcgp_model* model, int layer, double* out_sample, double* out_mean,
                             double* out_var, int* rows, int* width);

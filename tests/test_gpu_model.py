@@ -1611,3 +1611,81 @@ def test_allreduce_of_a_step_in_flight_does_not_hold_up_the_next_step(ctx):
         L.dcgp_debug_comm_gate(ctx.handle, 0, None)
         L.dcgp_comm_destroy(ctx.handle)
     model.close()
+
+
+@pytest.mark.parametrize("arch", ["conv_head", "head_only"])
+def test_factor_reuse_at_unchanged_parameters(ctx, arch):
+    """Evaluation sweeps at one parameter state (AccuracyLogger / LogLikelihoodLogger, conv_gp/utils/log.py:55-68): predict_y / propagate skip the
+    parameter-only chain while no parameter was written (default), compute_log_likelihood only in mode 2; results are bit-identical to steps that
+    run it, and every way of writing a parameter -- sync_parameters, an Adam step, a training step -- ends the reuse."""
+    hwc, N, S = (28, 28, 1), 6, 3
+    convs = [(5, 2, 10)] if arch == "conv_head" else []
+    spec = syn.make_spec(hwc, convs, (5, 1), 48, S=S, num_data=1000, seed=21, conv_q_sqrt_scale=0.2)
+    X, Y = syn.make_batch(hwc, N, seed=21)
+    zs = syn.make_noise(spec, N, seed=22)
+    ref = oracle_model(spec, X, Y)
+    model = build_from_spec(spec, X, Y)
+    with ctx.options(no_factor_reuse=1):
+        p0, _ = model.predict_y(X, S, zs=zs)
+        e0 = model.compute_log_likelihood(X, Y, zs=zs)
+    k0 = model.chain_skips
+    assert k0 == 0
+    p1, _ = model.predict_y(X, S, zs=zs)          # runs the chain (the ELBO step before it recorded one with KL pieces: another kind)
+    p2, _ = model.predict_y(X, S, zs=zs)
+    _, Fm, Fv = model.propagate(X, S=S, zs=zs)
+    assert model.chain_skips == k0 + 2             # the second predict_y and propagate
+    assert np.array_equal(p1, p0) and np.array_equal(p2, p0)
+    _, om, ov = ref.propagate(X, S=S, zs=zs)
+    assert rel(Fm[-1], om[-1]) < RTOL and rel(Fv[-1], ov[-1]) < RTOL
+    e1 = model.compute_log_likelihood(X, Y, zs=zs)  # mode 1: the ELBO step always runs the chain
+    assert model.chain_skips == k0 + 2 and e1 == e0
+    model.set_factor_reuse(2)
+    e2 = model.compute_log_likelihood(X, Y, zs=zs)  # same kind of chain as the step before it: reused
+    e3 = model.compute_log_likelihood(X[:5], Y[:5], zs=[z[:, :5] for z in zs])   # another batch, same parameters: reused
+    assert model.chain_skips == k0 + 4 and e2 == e0
+    assert abs(e3 - ref.compute_log_likelihood(X[:5], Y[:5], zs=[z[:, :5] for z in zs])) <= RTOL * abs(e3)
+    # a pushed parameter ends it, and the new value is what the next step sees
+    model.layers[-1].q_mu = model.layers[-1].q_mu + 0.25
+    ref.layers[-1].q_mu = ref.layers[-1].q_mu + 0.25
+    model.sync_parameters()
+    k1 = model.chain_skips
+    e4 = model.compute_log_likelihood(X, Y, zs=zs)
+    assert model.chain_skips == k1 and e4 != e0
+    assert abs(e4 - ref.compute_log_likelihood(X, Y, zs=zs)) <= RTOL * abs(e4)
+    e5 = model.compute_log_likelihood(X, Y, zs=zs)
+    assert model.chain_skips == k1 + 1 and e5 == e4
+    # an optimiser step ends it too; a training step's own forward pass never reuses
+    model.compute_gradients(X, Y, zs=zs)
+    k2 = model.chain_skips
+    model.adam_step(1e-3)
+    e6 = model.compute_log_likelihood(X, Y, zs=zs)
+    assert model.chain_skips == k2 and e6 != e4
+    model.train_step(X, Y, 1e-3, zs=zs)
+    model.train_step(X, Y, 1e-3, zs=zs)
+    assert model.chain_skips == k2
+    model.set_factor_reuse(0)
+    model.predict_y(X, S, zs=zs)
+    model.predict_y(X, S, zs=zs)
+    assert model.chain_skips == k2
+    model.close()
+
+
+def test_persistent_layer_launch_and_prep_placement_are_bit_identical(ctx):
+    """ctx options of round 6: the conv layer kernel as a persistent launch (strips dealt by a device counter or by a fixed stride, one or two
+    workgroups per CU) and the head-first model's operand preparation on either stream give the same ELBO to the last bit."""
+    spec, X, Y = syn.make_config("cfg2_mnist_CH_M256")
+    X, Y = X[:24], Y[:24]                       # 540 strips of 64 columns / 1080 of 32: more than one per slot of the chip
+    model = build_from_spec(spec, X, Y)
+    want = model.compute_log_likelihood(X, Y, seed=3)
+    for kw in (dict(fused_persist=1), dict(fused_persist=2), dict(fused_shape=2, fused_persist=1, fused_stagger=0),
+               dict(fused_shape=2, fused_persist=1, fused_stagger=25), dict(fused_shape=2, fused_persist=2)):
+        with ctx.options(**kw):
+            for rep in range(3):                # (the counters go back to zero behind every launch)
+                assert model.compute_log_likelihood(X, Y, seed=3) == want, kw
+    model.close()
+    spec, X, Y = syn.make_config("cfg2_mnist_H_M256")
+    model = build_from_spec(spec, X[:8], Y[:8])
+    want = model.compute_log_likelihood(X[:8], Y[:8], seed=4)
+    with ctx.options(prep_on_chain=1):
+        assert model.compute_log_likelihood(X[:8], Y[:8], seed=4) == want
+    model.close()
