@@ -602,6 +602,24 @@ def main():
                 model.dedup_layer0 = False
         dt_dedup = informational("dedup", dedup)
 
+    # Evaluation sweeps at ONE parameter state (the reference's LogLikelihoodLogger / AccuracyLogger, conv_gp/utils/log.py:55-68, run hundreds of batches
+    # between two optimiser steps): with dcgp_model_set_factor_reuse(2) a step whose parameters were not written since the last factorisation is its
+    # data path only.  A separately labelled number -- `value` above never runs in this mode (the reference's step recomputes the chain).
+    eval_fixed = None
+    if world == 1:
+        def eval_leg():
+            model.set_factor_reuse(2)
+            try:
+                for i in range(5):
+                    leg.step(i)
+                skips0 = model.chain_skips
+                d, v = leg.timed(args.warmup, args.steps)
+                return {"steps_per_s": args.steps / d, "ms_per_step": 1e3 * d / args.steps, "elbo_identical": bool(v == elbo),
+                        "steps_that_skipped_the_chain": model.chain_skips - skips0, "steps": args.steps}
+            finally:
+                model.set_factor_reuse(1)
+        eval_fixed = informational("eval-at-fixed-parameters", eval_leg)
+
     # once more with every kernel family bracketed, for the informational per-kernel table only
     timing_all = {}
     if not args.profile:
@@ -756,6 +774,10 @@ def main():
             "steps_per_s_two_in_flight": None if pipe is None else args.steps / pipe[0],
             "two_in_flight_elbo_identical": None if pipe is None else pipe[1],
             "steps_per_s_with_exact_layer0_dedup": (args.steps / dt_dedup) if dt_dedup else None,
+            "eval_steps_per_s_at_fixed_parameters": None if not eval_fixed else eval_fixed["steps_per_s"],
+            "eval_at_fixed_parameters": eval_fixed and dict(eval_fixed, note="forward ELBO steps with the parameter-only chain (operand preparation, factorisations, "
+                                                            "inverses, G / alpha, KL pieces) of the first step kept while no parameter is written "
+                                                            "(dcgp_model_set_factor_reuse(2)): evaluation sweeps only, never `value`"),
             "value_and_grad_steps_per_s": (1e3 / grad["value_and_grad_ms"]) if grad.get("value_and_grad_ms") else None,
             "value_and_grad_ms": grad.get("value_and_grad_ms"),
             "train_step_ms_value_grad_adam": grad.get("train_step_ms_value_grad_adam"),
@@ -802,7 +824,9 @@ def main():
                                "launches_sampled": t_dom[0], "sampling": "HIP events on the launch stream around every launch of the kernel, in a loop of %d steps behind the timed region" % n_roof,
                                "stage3_only_flops_per_step": flops_s3,
                                "note": "algorithmic flops: triangular products counted as M^2 per column (SURVEY 8(d)); peak = 78.6 TFLOP/s fp64 MFMA at the "
-                                       "2.4 GHz datasheet clock -- under this kernel the shader clock settles at 2.15-2.3 GHz (tools/fused_trace.py)"}
+                                       "2.4 GHz datasheet clock.  (Earlier rounds read a shader clock of 2.1-2.3 GHz off wall_clock64 inside the kernel and called it "
+                                       "power-limited; rocm-smi beside the looping step reads sclk 2398 MHz at 983 W of the 1400 W cap, and three strips of 446 k cycles "
+                                       "account for the launch at 2.39 GHz: the part is not power-bound here -- profiles/r06_power_and_clock.txt)"}
             # ---- the K_uf half of the metric (layer 0; SURVEY 8(d), conv_gp/layers.py:23-32) ----
             # algorithmic bytes of the sweep as the reference runs it: images in, Z in, K_uf [P, M, N'] out
             bytes_kuf = 8.0 * (rows0 * c["H"] * c["W"] * c["C"] + M * L + float(P) * M * rows0)
