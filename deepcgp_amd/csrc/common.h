@@ -36,7 +36,8 @@ struct DcgpOptions {
   long fused_large = 0;          // the one-launch layer kernel also for M > 256 (narrower strips; measured slower there)
   long fused_shape = -1;         // force one strip shape of the one-launch layer kernel (-1: chosen from the layer)
   long fused_split = -1;         // strips of the layer kernel's partial last round shared by this many workgroups (-1: chosen, 0 / 1: never)
-  long fused_persist = 0;        // the one-launch layer kernel as a persistent launch: one workgroup per slot of the chip walking its strips (-1: chosen; 0: off; 1: on)
+  long fused_persist = -1;       // the one-launch layer kernel as a persistent launch: one workgroup per slot of the chip walking its strips (-1: chosen; 0: off;
+                                 // 1: on, strips dealt by a device counter; 2: on, dealt by a fixed stride)
   long fused_stagger = -1;       // persistent layer kernel: microseconds the second workgroup of a CU holds back (-1: default; 0: none)
   long kl_side = 0;              // KL terms by their own launches on the side stream instead of inside the tail launch
   long no_fused_bwd = 0;         // reverse pass of the conditional by GEMM launches instead of the strip kernel

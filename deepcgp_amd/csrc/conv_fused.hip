@@ -27,6 +27,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // the scheduler otherwise sinks each sub-step's LDS reads behind the previous sub-step's MFMAs and into the same registers: one buffer, every
 // sub-step waits a full LDS latency (the source order -- reads one sub-step ahead -- is what is meant)
 #define CF_SB __builtin_amdgcn_sched_barrier(0)
+#define CF_DW 2
 #define CF_P1 50
 #define CF_P2 75
 #define CF_P3 90
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
   KArgs& a = *ap;
   constexpr int BN = FN * 16, W = NT / 64, TW = W / NS, FNS = FN / NS, KG = W / FN;
   static_assert(FN % NS == 0 && W % NS == 0 && W % FN == 0, "team split");
-  constexpr int CF_D = ((ABL & 4) ? 2 : 0) + (NT >= 1024 ? 2 : CF_D_DEFAULT);   // 128-register budget at 16 waves: two tiles ahead
+  constexpr int CF_D = ((ABL & 4) ? 2 : 0) + (NT >= 1024 ? CF_DW : CF_D_DEFAULT);   // 128-register budget at 16 waves: two tiles ahead
   extern __shared__ __attribute__((aligned(16))) double smem[];
 
   // A persistent launch (a.persist: one workgroup per slot of the chip): the workgroup walks the strips blockIdx, blockIdx + grid, ...
@@ -753,11 +754,15 @@ int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a_in) {
   const int n_cus = ctx->n_cus > 0 ? ctx->n_cus : 256;
   // workgroups a CU holds: LDS (160 KB) and wave slots (the kernels are held to 128 registers: 16 waves of 64 per CU)
   const long per_cu = std::min<long>(160 * 1024 / (long)p.lds, 1024 / kShapes[p.shape].NT);
-  const bool persist = ctx->opt.fused_persist > 0 && per_cu >= 1 && strips > per_cu * n_cus;
+  // chosen (-1): where a workgroup owns its CU and no strip of the last round is shared.  What it buys is the deal, not the persistence: strips handed out
+  // by a device counter to whichever workgroup is free 572 us at cfg2, dealt by a fixed stride 576 -- as many as one workgroup per strip takes
+  // (profiles/r06_fused_ab.txt)
+  const long want = ctx->opt.fused_persist;
+  const bool persist = per_cu >= 1 && strips > per_cu * n_cus && (want > 0 || (want < 0 && per_cu == 1 && p.split_q == 1 && !a.Kuf_out && !a.A1_out));
   if (persist) {
     a.persist = (int)(per_cu * n_cus);
     a.n_strips = (int)strips;
-    if (ctx->opt.fused_persist != 2) {   // (2: the fixed deal blockIdx, blockIdx + grid, ... -- A/B)
+    if (want != 2) {   // (2: the fixed deal blockIdx, blockIdx + grid, ... -- A/B)
       const std::string nm = "fused_dyn" + ctx->ws_tag;   // steps in flight on the two banks run this kernel side by side: a counter pair each
       const bool fresh = ctx->ws.find(nm) == ctx->ws.end();
       a.dyn = static_cast<int*>(ws_get(ctx, nm, 2 * sizeof(int)));
