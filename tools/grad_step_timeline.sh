@@ -1,4 +1,4 @@
-# timeline of one training step (value + gradient) under rocprofv3: tools/r05_gtl.sh <tag> [env...]
+# timeline of one training step (value + gradient) under rocprofv3: tools/grad_step_timeline.sh <tag> [env...]
 T=$1; shift
 export TMPDIR=/tmp; mkdir -p gpurun_out
 env "$@" tools/prof_grad.sh $T cfg2_mnist_CH_M256 20 > gpurun_out/${T}_summary.txt 2>&1

@@ -1,4 +1,4 @@
-# usage: tools/r05_tl.sh <tag> <config> [env...]   -- step timeline of a bench config under rocprofv3
+# usage: tools/step_timeline.sh <tag> <config> [env...]   -- step timeline of a bench config under rocprofv3
 T=$1; C=$2; shift; shift
 export TMPDIR=/tmp; mkdir -p gpurun_out
 env "$@" tools/prof_bench.sh $T --config $C --steps 60 --warmup 20 --no-cpu-baseline --no-grad-leg --no-extra-legs > gpurun_out/${T}_summary.txt 2>&1
