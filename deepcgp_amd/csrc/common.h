@@ -90,8 +90,9 @@ struct dcgp_ctx {
   // parameter-only chain of step i + 1 on the other 2 (hipExtStreamCreateWithCUMask; nullptr when the device is not 8 x 32 CUs)
   hipStream_t stream2b = nullptr;  // second side stream: the chain of a step enqueued while the previous one is in flight (bank 1)
   hipStream_t stream_aux = nullptr;   // short excursions beside the main stream inside a layer (the head's Kdiag)
-  hipStream_t stream_comm = nullptr;  // created on first use: the data term's all-reduce + ELBO assembly of a step kept in flight / followed by its reverse
-                                      // pass, so that the next step's (or the reverse pass's) kernels on the main stream do not queue behind the collective
+  hipStream_t stream_comm = nullptr;  // created on first use: the data term's all-reduce + ELBO assembly of a FORWARD step kept in flight (dcgp_elbo_forward_enqueue
+                                      // with no reverse pass behind it), so that the next step's kernels on the main stream do not queue behind the collective.
+                                      // A training step keeps its collectives on the main stream: one communicator's collectives stay on one stream (model.hip)
   hipEvent_t ev_comm[4] = {};         // main -> comm stream, one per result-ring slot
   int* comm_gate = nullptr;           // debugging aid (dcgp_debug_comm_gate): pinned word; != null: the comm stream's work waits for it to become non-zero
   hipStream_t stream_m = nullptr, stream2_m = nullptr;

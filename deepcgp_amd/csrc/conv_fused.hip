@@ -41,6 +41,14 @@ __device__ __forceinline__ void set_prio(int p) {   // s_setprio takes an immedi
     default: __builtin_amdgcn_s_setprio(3); break;
   }
 }
+// i / d for 0 <= i, d < 2^23 without the ~40-instruction integer division (quarter-rate multiplies among them): the float quotient of i + 1/2,
+// put right by one step where rounding tipped it over (full-rate 24-bit multiply).  A strip's set-up and epilogue held ~560 VALU instructions of
+// divisions per wave -- a third of everything the launch issues outside its MFMAs, and VALU cycles are MFMA cycles on this part.
+__device__ __forceinline__ int fdiv(int i, int d, float inv_d) {
+  int q = (int)(((float)i + 0.5f) * inv_d);
+  const int r = i - (int)__umul24((unsigned)q, (unsigned)d);
+  return q + (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+}
 __device__ __forceinline__ int frag_of(int w, int W, int c) { return (c >> 1) * 2 * W + ((c & 1) ? 2 * W - 1 - w : w); }
 
 // phase timestamps for tools/fused_trace.py: [8 sampled workgroups][4 strips of a persistent workgroup][wave][16] shader-clock ticks
@@ -144,8 +152,9 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int i = i0 + e * NT + tid;
-        const int n = i / a.HWC, o = i - n * a.HWC;
-        t[e] = (i < total) ? a.X[(long)((n_first + n) % a.n_mod) * a.HWC + o] : 0.0;
+        const int n = fdiv(i, a.HWC, a.inv_HWC), o = i - n * a.HWC;
+        const int nn = n_first + n, img = nn - fdiv(nn, a.n_mod, a.inv_nmod) * a.n_mod;
+        t[e] = (i < total) ? a.X[(long)img * a.HWC + o] : 0.0;
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -164,8 +173,8 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
   // LDS offset of the patch of strip column c (columns beyond the matrix repeat the last one: finite, never written out)
   auto patch_off = [&](int c) {
     const int j = min(j0 + c, jmax);
-    const int n = j / a.P, p = j - n * a.P;
-    const int oh = p / a.Wo, ow = p - oh * a.Wo;
+    const int n = fdiv(j, a.P, a.inv_P), p = j - n * a.P;
+    const int oh = fdiv(p, a.Wo, a.inv_Wo), ow = p - oh * a.Wo;
     return (n - n_first) * a.HWC + (oh * a.s * a.W + ow * a.s) * a.C;
   };
   // acos: |z_m|^2 of this lane's accumulator rows: fetched here, needed after the sweep (RBF: the norms ride in the product)
@@ -580,7 +589,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
   rmap.W = a.rmap.W; rmap.Nl = a.rmap.Nl; rmap.Ng = a.rmap.Ng; rmap.lo = a.rmap.lo;
   // ---- phase 4: var, mean, sample in the N x (P*R) layout (column j, output r at j*R + r) ----------------------------
   for (int idx = tid; idx < BN * R; idx += NT) {
-    const int c = idx / R, r = idx - c * R;
+    const int c = fdiv(idx, R, a.inv_R), r = idx - c * R;
     const int j = j0 + c;
     if (j > jmax || (SQ > 1 && r % SQ != sq)) continue;
     double s1 = 0.0, s2 = 0.0, m = 0.0;
@@ -750,6 +759,8 @@ int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a_in) {
   ConvFusedArgs a = a_in;
   a.lds_main = p.lds_main; a.lds_img = p.lds_img;
   a.trace = ctx->fused_trace;
+  if (a.Kc >= (1 << 23) || a.HWC >= (1 << 23)) return ctx_fail(ctx, DCGP_ERR_ARG, "conv_fused: %d columns / %d image elements exceed the kernel's 23-bit index arithmetic", a.Kc, a.HWC);
+  a.inv_HWC = 1.0f / (float)a.HWC; a.inv_nmod = 1.0f / (float)a.n_mod; a.inv_P = 1.0f / (float)a.P; a.inv_Wo = 1.0f / (float)a.Wo; a.inv_R = 1.0f / (float)a.R;
   const long strips = ((long)a.Kc + kShapes[p.shape].FN * 16 - 1) / (kShapes[p.shape].FN * 16);
   const int n_cus = ctx->n_cus > 0 ? ctx->n_cus : 256;
   // workgroups a CU holds: LDS (160 KB) and wave slots (the kernels are held to 128 registers: 16 waves of 64 per CU)

@@ -414,10 +414,11 @@ static int syrk_launch(dcgp_ctx* ctx, const GenGemm& g) {
   double* part = (double*)ws_get(ctx, pname, (size_t)ksplit * g.batch * g.M * g.N * sizeof(double));
   if (!part) return DCGP_ERR_ALLOC;
   const size_t lds = (size_t)(2 * SY_ROWS * SY_LD + 2 * SY_KC) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};   // per device: the attribute is the device's, and a process may hold ctxs on several
+  const int dv = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+  if (!attr_set[dv]) {
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)syrk_kscale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set[dv] = true;
   }
   hipLaunchKernelGGL(syrk_kscale_kernel, dim3(ksplit, g.batch), dim3(SY_NT), lds, ctx->stream, g, kchunk, part, sy_blocks_host());
   LAUNCH_CHECK(ctx);

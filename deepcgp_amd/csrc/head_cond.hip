@@ -316,10 +316,11 @@ int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, i
   a.out_mean = out_mean; a.out_var = out_var;
   a.A1_out = A1_out; a.lda1 = lda1; a.M = g.M;
   const size_t lds = (size_t)(g.Mp * HC_BN + 4 * 16 * 16) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {   // (72 KB at Mp = 512)
+  static bool attr_set[64] = {};   // per device (72 KB at Mp = 512)
+  const int dv = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+  if (!attr_set[dv]) {
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)head_cond_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (HC_MP * HC_BN + 4 * 16 * 16) * 8));
-    attr_set = true;
+    attr_set[dv] = true;
   }
   hipLaunchKernelGGL(head_cond_kernel, dim3((Kc + HC_BN - 1) / HC_BN, g.R), dim3(1024), lds, ctx->stream, a);
   LAUNCH_CHECK(ctx);

@@ -115,6 +115,7 @@ struct ConvFusedArgs {
   int idm = 0;
   double *Kuf_out = nullptr, *A1_out = nullptr; long ldk = 0;   // training step: k-major [Mp][ldk] copies for the reverse pass
   int lds_main = 0, lds_img = 0;                           // set by the launcher
+  float inv_HWC = 0, inv_nmod = 0, inv_P = 0, inv_Wo = 0, inv_R = 0;   // set by the launcher: reciprocals of the kernel's divisors (fdiv)
   int split_first = 1 << 30, split_q = 1;                  // set by the launcher: strips >= split_first are shared by split_q workgroups (outputs r = q, q + split_q, ...)
   long long* trace = nullptr;                              // debugging aid: phase timestamps (dcgp_debug_set_fused_trace)
   // set by the launcher: a persistent launch -- one workgroup per slot of the chip, each walking the strips blockIdx, blockIdx + grid, ... < n_strips

@@ -339,9 +339,10 @@ int dcgp_comm_destroy(dcgp_ctx* ctx);
 int dcgp_comm_count(dcgp_ctx* ctx, int* out_ranks);
 int dcgp_allreduce_sum_f64(dcgp_ctx* ctx, double* buf_dev, int n);
 
-/* ---- debugging aid ----------------------------------------------------------------------------------------------- */
-/* With a communicator, a step kept in flight (dcgp_elbo_forward_enqueue) or followed by its reverse pass hands the data term's all-reduce and
- * the ELBO assembly to a comm stream, so that the next kernels on the main stream do not queue behind the collective.  The gate lets a test
+/* ---- debugging aids: TEST-ONLY entry points (tests/, tools/); nothing of the reference's interface maps onto them and no product path calls them ---- */
+/* With a communicator, a FORWARD step kept in flight (dcgp_elbo_forward_enqueue with no reverse pass behind it) hands the data term's all-reduce and
+ * the ELBO assembly to a comm stream, so that the next kernels on the main stream do not queue behind the collective (a training step keeps its
+ * collectives on the main stream: one communicator's collectives stay on one stream).  The gate lets a test
  * prove it: closed != 0 -- every such all-reduce enqueued from now on first waits (at most ~4 s) for the gate; 0 -- opens and removes it.
  * main_idle_out (may be NULL): bit 0 -- the ctx's main stream has drained (hipStreamQuery), bit 1 -- the comm stream has. */
 int dcgp_debug_comm_gate(dcgp_ctx* ctx, int closed, int* main_idle_out);
