@@ -1486,6 +1486,35 @@ def test_two_gpu_bench_runs_rccl_and_matches_one_rank(ctx):
     assert two["steps_per_s_two_in_flight"] is not None
 
 
+def test_two_gpu_rccl_exchange_modes_agree(ctx):
+    """Skipped unless the box has two GPUs.  The training step's two gradient exchanges over a REAL communicator (ncclAllReduce against
+    ncclReduceScatter -> Adam on the rank's shard -> ncclAllGather, in place on the padded gradient block and the staging block): the same
+    parameters on both ranks and, to rounding of the reduction order, in both modes; a switch back to mode 0 or a full Adam step on top of
+    rank-local moments is refused (tests/rccl_exchange_worker.py; one GPU: the virtual-rank replay of test_sharded_adam_step_equals_the_full_step)."""
+    import subprocess
+    import sys
+    from deepcgp_amd import device as dev
+    from deepcgp_amd.dist import spawn_ranks
+    if dev.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+
+    def run(mode):
+        code = ("import sys; sys.path[:0] = [%r, %r]; from deepcgp_amd.dist import spawn_ranks; "
+                "sys.exit(spawn_ranks(2, [%r, %r]))" % (root, here, os.path.join(here, "rccl_exchange_worker.py"), str(mode)))
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, here]), HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+        out = {ln.split()[0]: np.array([float(v) for v in ln.split()[1:]]) for ln in r.stdout.splitlines() if ln.startswith(("PARAMS", "ELBOS"))}
+        return out["PARAMS"], out["ELBOS"]
+    p0, e0 = run(0)
+    p1, e1 = run(1)
+    assert np.all(np.isfinite(p0)) and np.all(np.isfinite(p1))
+    assert np.max(np.abs(e1 - e0) / np.abs(e0)) < 1e-9, (e0, e1)
+    assert np.max(np.abs(p1 - p0)) < 1e-9 * max(1.0, np.max(np.abs(p0))), np.max(np.abs(p1 - p0))
+
+
 @pytest.mark.parametrize("variant", ["head", "conv"])
 def test_learns_real_digits(ctx, variant):
     """End-to-end learning evidence on REAL images (the reference's only published kind of number is accuracy,
