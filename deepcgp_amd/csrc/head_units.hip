@@ -56,8 +56,15 @@ __device__ __forceinline__ int fdiv_small(int i, float inv_d) { return (int)(((f
 // of tiles for replica-outer stores (row_pass_hold).  The storing forms run at three / two waves per SIMD (168 / 256 registers, no
 // spill): their stores and a spill reload share the wave's in-order memory counter, so a single reload in the tile loop waits for
 // every store issued before it -- the store queue drained once per tile.
+// The arguments are read through the kernarg pointer (constant address space: scalar loads where they are used) instead of as a by-value struct, whose
+// ~90 words the compiler loads up front and then spills (10-76 scalar spills per instantiation, 0-44 this way -- each one a v_writelane / v_readlane, VALU
+// instructions in the sweep's issue slots): cfg5's storing sweep 286 -> 249 us, the others 0-3 % (profiles/r06_sweep_fetch_ab.txt).
+// (Round 6 also tried the reducing form as a persistent launch fetching workgroup indices from a device counter, now that the argument spills of round 2's
+// attempt are gone: slower everywhere -- cfg2 conv + head +27 us, cfg1 +26 -- a finished wave of a persistent workgroup idles until its workgroup is done,
+// in the plain launch its slot goes to the next workgroup at once.)
 template <int NK4, int TL, int WMODE, int NT>
-__global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 3 : HU_WAVES)) void head_units_kernel(HeadUnitsArgs a) {
+__global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 3 : HU_WAVES)) void head_units_kernel(HeadUnitsArgs a_in) {
+  const __attribute__((address_space(4))) HeadUnitsArgs& a = *(const __attribute__((address_space(4))) HeadUnitsArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr bool WRITE = WMODE == 1 || WMODE == 2;
   constexpr bool KEEP = WMODE == 3;
   constexpr int WPG = NT / 64;   // units (waves) per workgroup
