@@ -52,10 +52,10 @@ tools/prof_pipe.sh ${T}s4s cfg2_mnist_CH_M256 60 1 4 > /dev/null 2>&1
 DB=$(find gpurun_out/pipe_${T}s4s -name '*.db' | head -1); python tools/rocpd_timeline.py $DB -6 > gpurun_out/${T}_shard4_step_timeline.txt; tail -1 gpurun_out/pipe_${T}s4s.log >> gpurun_out/${T}_shard4_step_timeline.txt
 # 10. one step of the other configurations and of the training step, kernel by kernel (of THIS code: collected last)
 for c in cfg1_mnist_H_M32 cfg2_mnist_H_M256 cfg3_mnist_3layer_M256 cfg4_cifar_3layer_M384; do
-  tools/step_timeline.sh ${T}tl_$c $c > /dev/null 2>&1; cp gpurun_out/${T}tl_${c}_timeline.txt gpurun_out/${T}_${c}_step_timeline.txt
+  bash tools/step_timeline.sh ${T}tl_$c $c > /dev/null 2>&1; cp gpurun_out/${T}tl_${c}_timeline.txt gpurun_out/${T}_${c}_step_timeline.txt
 done
-tools/grad_step_timeline.sh ${T}gtl > /dev/null 2>&1; cp gpurun_out/${T}gtl_timeline.txt gpurun_out/${T}_grad_step_timeline.txt
-tools/grad_step_timeline.sh ${T}gtld DCGP_DEDUP=1 > /dev/null 2>&1; cp gpurun_out/${T}gtld_timeline.txt gpurun_out/${T}_grad_step_dedup_timeline.txt
+bash tools/grad_step_timeline.sh ${T}gtl > /dev/null 2>&1; cp gpurun_out/${T}gtl_timeline.txt gpurun_out/${T}_grad_step_timeline.txt
+bash tools/grad_step_timeline.sh ${T}gtld DCGP_DEDUP=1 > /dev/null 2>&1; cp gpurun_out/${T}gtld_timeline.txt gpurun_out/${T}_grad_step_dedup_timeline.txt
 # 11. the layer kernel under its launch options, and whether the part is power-bound under it
 python tools/fused_ab.py > gpurun_out/${T}_fused_launch_options.txt 2>&1
 python tools/fused_power.py > gpurun_out/${T}_power_and_clock_final.txt 2>&1
