@@ -696,6 +696,7 @@ bool plan_fused(const dcgp_ctx* ctx, const ConvFusedArgs& a, FusedPlan* p) {
   const int force = (int)ctx->opt.fused_shape;   // A/B experiments (-1: none)
   const int nf = a.Mp / 16;
   if (a.Rp != 16 || a.R > 16 || a.Mp > 1024 || a.Mp % 16) return false;
+  if (a.Kc >= (1 << 23) || a.HWC >= (1 << 23)) return false;   // the kernel's index arithmetic (fdiv) is exact below 2^23: larger layers take the sweep + GEMM route
   // M > 256: the 32- / 16-column strips LDS leaves room for re-fetch the A operands 2 - 4 x as often per MFMA and measure
   // 2 % (M = 384) to 16 % (M = 1024) behind the sweep + 128 x 128-tile GEMM route (87 % of the MFMA peak there); opt-in
   if (nf > 16 && force < 0 && !ctx->opt.fused_large) return false;
@@ -759,7 +760,6 @@ int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a_in) {
   ConvFusedArgs a = a_in;
   a.lds_main = p.lds_main; a.lds_img = p.lds_img;
   a.trace = ctx->fused_trace;
-  if (a.Kc >= (1 << 23) || a.HWC >= (1 << 23)) return ctx_fail(ctx, DCGP_ERR_ARG, "conv_fused: %d columns / %d image elements exceed the kernel's 23-bit index arithmetic", a.Kc, a.HWC);
   a.inv_HWC = 1.0f / (float)a.HWC; a.inv_nmod = 1.0f / (float)a.n_mod; a.inv_P = 1.0f / (float)a.P; a.inv_Wo = 1.0f / (float)a.Wo; a.inv_R = 1.0f / (float)a.R;
   const long strips = ((long)a.Kc + kShapes[p.shape].FN * 16 - 1) / (kShapes[p.shape].FN * 16);
   const int n_cus = ctx->n_cus > 0 ? ctx->n_cus : 256;
