@@ -38,6 +38,8 @@ struct DcgpOptions {
   long fused_split = -1;         // strips of the layer kernel's partial last round shared by this many workgroups (-1: chosen, 0 / 1: never)
   long fused_persist = -1;       // the one-launch layer kernel as a persistent launch: one workgroup per slot of the chip walking its strips (-1: chosen; 0: off;
                                  // 1: on, strips dealt by a device counter; 2: on, dealt by a fixed stride)
+  long fused_pre = -1;           // persistent layer kernel: prologues (sweep + first product) of later strips run by the spare workgroups of a partial first round
+                                 // (-1: chosen by a simulated deal; 0: never; k > 0: up to k per spare workgroup)
   long fused_stagger = -1;       // persistent layer kernel: microseconds the second workgroup of a CU holds back (-1: default; 0: none)
   long kl_side = 0;              // KL terms by their own launches on the side stream instead of inside the tail launch
   long no_fused_bwd = 0;         // reverse pass of the conditional by GEMM launches instead of the strip kernel
@@ -113,6 +115,7 @@ struct dcgp_ctx {
   hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;  // fork / join of a short side-stream excursion inside a layer
   std::string err;
   std::map<std::string, hipGraphExec_t> chain_graphs;   // captured panel-launch sequences of the factorisation chain, by argument set (chol_fused.hip)
+  std::map<std::string, unsigned> fused_pre_epochs;   // per hand-over area of the layer kernel's prologues ahead (conv_fused.hip): launches so far
   std::map<std::string, ChainEpoch> chain_epochs;   // per sync workspace of chol_persist_kernel (chol_fused.hip)
   bool chain_alone = true;   // the factorisation chain about to run has the chip to itself (forward_all: synchronous step, chain on the main stream): the
                              // look-ahead workgroups are then confined to one XCD.  Beside a patch sweep or the previous step's layer kernel that

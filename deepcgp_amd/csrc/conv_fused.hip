@@ -18,6 +18,12 @@
 // inside any k loop (5 barriers per workgroup in all), HBM traffic = the images in and the samples out.
 // Row fragments are dealt to the waves boustrophedon (w, 2W-1-w, 2W+w, ...) so that every wave carries the same number
 // of live k-tiles of the triangular products.
+#include <array>
+#include <map>
+#include <mutex>
+#include <queue>
+#include <vector>
+
 #include "layer.h"
 #include "rng.h"
 
@@ -128,6 +134,16 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
     sidx = a.split_first + t / SQ;
     sq = t - (sidx - a.split_first) * SQ;
   }
+  // Prologues ahead (a.pre_n > 0, a persistent launch whose strips do not fill its last round: DESIGN 4i).  The items of the launch, in the order the
+  // counter deals them: the strips [0, pre_first) whole -- one per workgroup of the partial FIRST round --, then pre_n items that run only phases 0 - 2
+  // of the strips [pre_first, pre_first + pre_n) and leave A1 (the LDS image of the strip) and the partial sums of A1^2 in a.pre_buf: they fill the
+  // first round's spare workgroups; then the remaining strips whole; then the pre_n strips again, which fetch their A1 and go straight to phase 3.
+  // Same arithmetic in the same order as a whole strip: bit-identical.
+  int mode = 0, pre_slot = 0;   // 0: a whole strip; 1: phases 0 - 2 only, A1 left in a.pre_buf; 2: A1 fetched from a.pre_buf, phases 3 - 4
+  if (a.pre_n > 0) {
+    if (strip_next >= a.n_strips) { mode = 2; pre_slot = strip_next - a.n_strips; sidx = a.pre_first + pre_slot; }
+    else if (strip_next >= a.pre_first && strip_next < a.pre_first + a.pre_n) { mode = 1; pre_slot = strip_next - a.pre_first; }
+  }
   const int j0 = sidx * BN;
   int tr_slot = -1;
   if (a.trace) {
@@ -142,6 +158,21 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
   // alone on two waves per SIMD, cannot use more than 81 % of the pipe
   __builtin_amdgcn_s_setprio(3);
 
+  // ---- the A-operand stream ---------------------------------------------------------------------------------------
+  // lane (lrow, lcol) of k-substep q of k-tile kt needs Wt[kt*16 + 4q + lrow][16 f + lcol]: per-lane byte offset voff[q],
+  // everything else (matrix r, k-tile, fragment) is a scalar byte offset
+  unsigned voff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) voff[q] = (unsigned)(((4 * q + lrow) * Mp + lcol) * 8);
+  auto ldw = [&](const __amdgpu_buffer_rsrc_t& rs, int soff, double (&dst)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff[q], soff, 0);
+      __builtin_memcpy(&dst[q], &v, 8);
+    }
+  };
+  constexpr int QS = 4 * BN;
+  if (mode != 2) {
   // ---- phase 0: images of the strip -> LDS, patch-element offsets, |x|^2 per column -----------------------------
   const int n_first = j0 / a.P;
   const int n_last = min(j0 + BN - 1, jmax) / a.P;
@@ -207,7 +238,6 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
   // index plus compile-time offsets (column group, sub-step, accumulator row: multiples of 512 bytes, the unit of ds_read2st64_b64) plus a scalar
   // (k-tile).  On gfx950 a VALU instruction issues in the fp64 MFMA's place: the row-major strip with its column groups XOR-swizzled by the row spent
   // 10 - 14 of them per k-tile of the second product on addresses (4 - 5 % of its 1024 MFMA cycles), this one spends 1
-  constexpr int QS = 4 * BN;
   // ---- phase 1: K_uf[:, strip] -> strip: this wave's row fragments x its team's FNS column fragments ----------------
   {
     int pb[FNS];
@@ -310,20 +340,6 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
   };
   if (a.Kuf_out && sq == 0) store_strip(a.Kuf_out);
 
-  // ---- the A-operand stream ---------------------------------------------------------------------------------------
-  // lane (lrow, lcol) of k-substep q of k-tile kt needs Wt[kt*16 + 4q + lrow][16 f + lcol]: per-lane byte offset voff[q],
-  // everything else (matrix r, k-tile, fragment) is a scalar byte offset
-  unsigned voff[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) voff[q] = (unsigned)(((4 * q + lrow) * Mp + lcol) * 8);
-  auto ldw = [&](const __amdgpu_buffer_rsrc_t& rs, int soff, double (&dst)[4]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff[q], soff, 0);
-      __builtin_memcpy(&dst[q], &v, 8);
-    }
-  };
-
   // ---- phase 2: A1 = inv(L) K_uf (lower-triangular W: fragment f needs k-tiles 0 .. f), FNS column fragments per wave ----
   const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.LinvT), 0, Mp * Mp * 8, 0x00020000);
   d4 a1[MAXF][FNS];
@@ -412,6 +428,46 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
   __syncthreads();   // A1 published
   CF_TR(5)
   if (a.A1_out && sq == 0) store_strip(a.A1_out);
+  if (mode == 1) {
+    // the strip as it lies in LDS and the [TW][BN] partial sums behind it, by coherent (sc1) stores another XCD's loads see (chol_fused.hip: ldg / stg);
+    // acknowledged before the barrier in front of the flag
+    double* __restrict__ dst = a.pre_buf + (long)pre_slot * a.pre_stride;
+    for (int i0 = 0; i0 < Mp * BN; i0 += 8 * NT) {
+      double t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = strip[min(i0 + e * NT + tid, Mp * BN - 1)];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (i0 + e * NT + tid < Mp * BN) __hip_atomic_store(dst + i0 + e * NT + tid, t[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int i = tid; i < TW * BN; i += NT) __hip_atomic_store(dst + Mp * BN + i, aux[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(a.pre_flag + pre_slot, a.pre_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  } else {
+    // ---- A1 of the strip and its partial sums from the workgroup that ran phases 0 - 2 (dealt earlier: it is running or done) ----
+    if (tid == 0) {
+      for (int spin = 0; spin < (1 << 22); ++spin) {   // (bounded: a launch must not hang the device)
+        if (__hip_atomic_load(a.pre_flag + pre_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.pre_epoch) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    const double* __restrict__ src = a.pre_buf + (long)pre_slot * a.pre_stride;
+    for (int i0 = 0; i0 < Mp * BN; i0 += 8 * NT) {
+      double t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = __hip_atomic_load(src + min(i0 + e * NT + tid, Mp * BN - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (i0 + e * NT + tid < Mp * BN) strip[i0 + e * NT + tid] = t[e];
+    }
+    for (int i = tid; i < TW * BN; i += NT) aux[i] = __hip_atomic_load(src + Mp * BN + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    CF_TR(5)
+  }
+  if (mode != 1) {
 
   // ---- phase 3: T_r = G_r^T A1 for r = r0, r0 + rstep, ... (r0 = sp, rstep = NS for a whole strip) (upper-triangular W: fragment f needs k-tiles f .. nf-1): one flat
   // stream over (r, fragment, k-tile), all FN column fragments.  s2 of this wave's i-th output is parked in the lanes with
@@ -616,6 +672,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
     }
   }
   CF_TR(9)
+  }   // mode != 1
   if (tr_slot >= 0 && lane == 0) a.trace[(tr_slot * 16 + wave) * 16 + 11] = (long long)wall_clock64();
   if (!a.persist) break;
   // the next strip: dealt by arrival (a.dyn: one counter per launch) -- two workgroups share a CU and the one launched first wins every arbitration
@@ -623,7 +680,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
   if (tid == 0) ticket[0] = a.dyn ? (int)gridDim.x + atomicAdd(a.dyn, 1) : strip_next + (int)gridDim.x;
   __syncthreads();   // (and the partial sums are read: the next strip's images may land on them)
   strip_next = __builtin_amdgcn_readfirstlane(ticket[0]);
-  if (strip_next >= a.n_strips) break;
+  if (strip_next >= a.n_strips + a.pre_n) break;
   }
   if (threadIdx.x == 0) {
     if (cu_word >= 0) atomicSub(ap->cu_slots + cu_word, 1);
@@ -689,6 +746,62 @@ double last_round(const dcgp_ctx* ctx, const FusedShape& sh, long strips, int R,
     if ((want > 1 && q <= want) || (want < 0 && cost < best - 1e-9)) { best = cost; *q_out = q; }
   }
   return *q_out > 1 ? best : 1.0;
+}
+
+// Prologues ahead.  A persistent launch of `slots` workgroups (one per CU) over `strips` strips runs ceil(strips / slots) strip times, and a partial
+// round leaves slots - rem workgroups idle for a whole one (720 strips on 256 CUs: 3 rounds for 2.81 of work).  Sharing a strip's OUTPUTS between workgroups re-pays
+// its sweep and first product (4h.6: no split wins).  Sharing its PROLOGUE does not: the partial round goes first, its spare workgroups run phases 0 - 2 of
+// later strips (a sixth of a strip each) and leave A1 in memory (132 KB per strip, L2 / Infinity-Cache traffic); those strips then start at the second product.
+// The items are dealt in list order to whichever workgroup is free; this returns the makespan of that deal in units of one output of the second product
+// (sweep + first product 1.75, epilogue 0.3, hand-over 0.2 on either side: the phase times of profiles/r06_fused_phase_trace.txt at M = 256), for n_pre
+// prologues ahead, a hand-over waiting for its prologue where the deal has it so.
+double deal_makespan(long strips, int slots, long n_pre, int R) {
+  const double pro = 1.75, epi = 0.3, io = 0.2;
+  const double F = pro + R + epi, P = pro + io, C = io + R + epi;
+  if (n_pre <= 0) return (double)((strips + slots - 1) / slots) * F;
+  const long rem = strips % slots;
+  std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+  for (int i = 0; i < slots; ++i) free_at.push(0.0);
+  std::vector<double> ready((size_t)n_pre, 0.0);
+  double end = 0.0;
+  auto give = [&](double cost, double not_before) {
+    double t = free_at.top();
+    free_at.pop();
+    if (t < not_before) t = not_before;
+    t += cost;
+    free_at.push(t);
+    if (t > end) end = t;
+    return t;
+  };
+  for (long i = 0; i < rem; ++i) give(F, 0.0);
+  for (long i = 0; i < n_pre; ++i) ready[(size_t)i] = give(P, 0.0);
+  for (long i = 0; i < strips - rem - n_pre; ++i) give(F, 0.0);
+  for (long i = 0; i < n_pre; ++i) give(C, ready[(size_t)i]);
+  return end;
+}
+// the number of prologues ahead for a persistent launch (0: none)
+long plan_prologues(const dcgp_ctx* ctx, long strips, int slots, int R) {
+  const long want = ctx->opt.fused_pre;
+  const long rem = strips % slots, q = strips / slots;
+  if (want == 0 || rem == 0 || q < 1 || q > 16 || R < 2) return 0;
+  static std::mutex mu;
+  static std::map<std::array<long, 4>, long> memo;
+  const std::array<long, 4> key = {strips, (long)slots, (long)R, want};
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = memo.find(key);
+  if (it != memo.end()) return it->second;
+  const long per = want > 0 ? want : (long)((1.75 + R + 0.3) / 1.95);   // prologues a spare workgroup runs in one strip time
+  const long most = std::min<long>((slots - rem) * per, strips - rem);
+  const long step = std::max<long>(slots / 8, 1);
+  long best_n = 0;
+  double best = deal_makespan(strips, slots, 0, R) * (want > 0 ? 2.0 : 0.98);   // chosen: a deal must save 2 %; forced: the best non-zero count
+  for (long n = step; n <= most; n += step) {
+    const double t = deal_makespan(strips, slots, n, R);
+    if (t < best - 1e-9) { best = t; best_n = n; }
+  }
+  if (memo.size() > 256) memo.clear();
+  memo[key] = best_n;
+  return best_n;
 }
 
 // the first instantiated shape (widest strip, most waves) that covers Mp and whose LDS footprint fits
@@ -779,6 +892,27 @@ int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a_in) {
       a.dyn = static_cast<int*>(ws_get(ctx, nm, 2 * sizeof(int)));
       if (!a.dyn) return DCGP_ERR_ALLOC;
       if (fresh) HIP_TRY(ctx, hipMemsetAsync(a.dyn, 0, 2 * sizeof(int), ctx->stream));
+    }
+    if (per_cu == 1 && a.dyn && a.G) {
+      const int TW = kShapes[p.shape].NT / 64 / kShapes[p.shape].NS, BN = kShapes[p.shape].FN * 16;
+      const long n_pre = plan_prologues(ctx, strips, a.persist, a.R);
+      if (n_pre > 0) {
+        a.pre_n = (int)n_pre;
+        a.pre_first = (int)(strips % a.persist);
+        a.pre_stride = (long)a.Mp * BN + (long)TW * BN;
+        const std::string nb = "fused_pre_buf" + ctx->ws_tag, nf = "fused_pre_flag" + ctx->ws_tag;
+        const size_t fbytes = (size_t)n_pre * sizeof(unsigned);
+        const bool fresh = ctx->ws.find(nf) == ctx->ws.end() || ctx->ws[nf].second < fbytes;
+        a.pre_buf = static_cast<double*>(ws_get(ctx, nb, (size_t)n_pre * a.pre_stride * sizeof(double)));
+        a.pre_flag = static_cast<unsigned*>(ws_get(ctx, nf, fbytes));
+        if (!a.pre_buf || !a.pre_flag) return DCGP_ERR_ALLOC;
+        unsigned& epoch = ctx->fused_pre_epochs[nf];
+        if (fresh || epoch == 0xffffffffu) {   // flags compare equal to the launch's epoch: a fresh (or wrapped) area starts from zero
+          HIP_TRY(ctx, hipMemsetAsync(a.pre_flag, 0, ctx->ws[nf].second, ctx->stream));
+          epoch = 0;
+        }
+        a.pre_epoch = ++epoch;
+      }
     }
     if (per_cu > 1) {
       const long us = ctx->opt.fused_stagger >= 0 ? ctx->opt.fused_stagger : 40;

@@ -1707,7 +1707,9 @@ def test_persistent_layer_launch_and_prep_placement_are_bit_identical(ctx):
     model = build_from_spec(spec, X, Y)
     want = model.compute_log_likelihood(X, Y, seed=3)
     for kw in (dict(fused_persist=1), dict(fused_persist=2), dict(fused_shape=2, fused_persist=1, fused_stagger=0),
-               dict(fused_shape=2, fused_persist=1, fused_stagger=25), dict(fused_shape=2, fused_persist=2)):
+               dict(fused_shape=2, fused_persist=1, fused_stagger=25), dict(fused_shape=2, fused_persist=2),
+               # prologues ahead (conv_fused.hip: phases 0 - 2 of later strips in the partial first round's spare workgroups): never, chosen, forced counts
+               dict(fused_pre=0), dict(fused_pre=-1), dict(fused_pre=1), dict(fused_pre=3), dict(fused_pre=9)):
         with ctx.options(**kw):
             for rep in range(3):                # (the counters go back to zero behind every launch)
                 assert model.compute_log_likelihood(X, Y, seed=3) == want, kw
