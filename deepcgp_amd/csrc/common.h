@@ -57,6 +57,8 @@ struct DcgpOptions {
   long head_no_overlap = 0;      // head-first model: the factorisation chain in front of the sweep instead of beside it
   long no_factor_reuse = 0;      // evaluation entry points run the parameter-only chain every time, also at unchanged parameters (A/B)
   long prep_on_chain = 0;        // head-first model: the operand preparation on the chain's stream instead of in front of the sweep on the main stream (A/B)
+  long prep_one_launch = 0;      // head-first model, synchronous step: the operand preparation as ONE launch on the main stream with an event to the chain's stream
+                                 // instead of one launch per stream (A/B)
   long no_early_sweep = 0;       // the first layer's sweep enqueued behind the chain instead of in front of it
   long sync_event = 0;           // wait for the step's event instead of polling its completion word
   long chain_graph = 0;          // the factorisation chain's panel launches replayed from a captured HIP graph (measured slower: see chol_fused.hip)

@@ -26,7 +26,7 @@ const OptSlot kOptSlots[] = {
     {"head_unfused", &DcgpOptions::head_unfused}, {"no_side_stream", &DcgpOptions::no_side_stream}, {"cu_partition", &DcgpOptions::cu_partition},
     {"grad_nofork", &DcgpOptions::grad_nofork}, {"chol_one_launch", &DcgpOptions::chol_one_launch},
     {"chol_no_lookahead", &DcgpOptions::chol_no_lookahead}, {"head_no_overlap", &DcgpOptions::head_no_overlap},
-    {"no_early_sweep", &DcgpOptions::no_early_sweep}, {"prep_on_chain", &DcgpOptions::prep_on_chain}, {"no_factor_reuse", &DcgpOptions::no_factor_reuse}, {"sync_event", &DcgpOptions::sync_event}, {"kuf_upw", &DcgpOptions::kuf_upw},
+    {"no_early_sweep", &DcgpOptions::no_early_sweep}, {"prep_on_chain", &DcgpOptions::prep_on_chain}, {"prep_one_launch", &DcgpOptions::prep_one_launch}, {"no_factor_reuse", &DcgpOptions::no_factor_reuse}, {"sync_event", &DcgpOptions::sync_event}, {"kuf_upw", &DcgpOptions::kuf_upw},
     {"chain_graph", &DcgpOptions::chain_graph}, {"no_rhs_ride", &DcgpOptions::no_rhs_ride}, {"comm_inline", &DcgpOptions::comm_inline}, {"chain_no_iso", &DcgpOptions::chain_no_iso}, {"kuf_no_rep", &DcgpOptions::kuf_no_rep}, {"kuf_stream", &DcgpOptions::kuf_stream},
     {"kuf_wpg", &DcgpOptions::kuf_wpg}, {"kuf_split", &DcgpOptions::kuf_split}, {"head_tail", &DcgpOptions::head_tail},
     {"sweep_occ", &DcgpOptions::sweep_occ}, {"share_kb", &DcgpOptions::share_kb}, {"head_upw", &DcgpOptions::head_upw}, {"no_syrk", &DcgpOptions::no_syrk}, {"grad_dz_main", &DcgpOptions::grad_dz_main},

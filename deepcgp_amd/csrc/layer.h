@@ -53,7 +53,9 @@ struct PrepArgs {
   int nl = 0;
   PrepLayerArgs l[8];
 };
-int prepare_all(dcgp_ctx* ctx, const PrepArgs& a);
+// task_mask: bit t = task t of prep.hip (0 / 1: Kuu of the live / prior Z, 2: Z^T and |z|^2, 3: masked q_sqrt, 4: padded q_mu, 5: the sweeps' scaled Z)
+constexpr unsigned kPrepSweepTasks = (1u << 2) | (1u << 5);   // what a patch sweep reads
+int prepare_all(dcgp_ctx* ctx, const PrepArgs& a, unsigned task_mask = ~0u);
 
 // A = inv(L) Kuf etc. on a k-major Kuf matrix B [Mp x ldb] with Kc columns.
 // Produces partial column sums s1p [nrb1][ldb], s2p [R][nrb3][ldb], and mu [R][ldb].

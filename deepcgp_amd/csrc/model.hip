@@ -272,6 +272,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   // (steps kept in flight: the preparation stays on the chain's stream, where it runs under the previous step's data path -- on the main stream it
   // waited for that step: head-only model 4830 -> 4590 steps/s in flight)
   const bool prep_on_main = xs && !first_fused && !pipelined && !ctx->opt.no_early_sweep && !ctx->opt.prep_on_chain;
+  const bool prep_split = prep_on_main && !ctx->opt.prep_one_launch;
   bool early0 = false, side_kl = false;
   if (reuse) ++m->chain_skips;
   if (!reuse) {
@@ -293,11 +294,20 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     PrepArgs pa;
     pa.nl = nl;
     for (int li = 0; li < nl; ++li) pa.l[li] = m->layers[li]->prep_args(m->jitter);
-    if (prep_on_main) ctx->stream = main_s;
-    rc = prepare_all(ctx, pa);
+    // Round 6, second step: the preparation in TWO launches, each on the stream of its reader -- what a sweep reads (Z^T, |z|^2, the scaled Z) on the
+    // main stream, the Gram matrices and the padded q_sqrt / q_mu on the chain's -- and no event between the streams at the head of the step: the
+    // record was a packet between the preparation and the sweep (7.6 us from one to the other), the wait held the chain back (option prep_one_launch: A/B)
+    if (prep_split) {
+      ctx->stream = main_s;
+      rc = prepare_all(ctx, pa, kPrepSweepTasks);
+      ctx->stream = chain_s;   // (the chain's part is enqueued BEHIND the sweep, below: at the head of a synchronous step the device waits for the host, ~4 us a launch)
+    } else {
+      if (prep_on_main) ctx->stream = main_s;
+      rc = prepare_all(ctx, pa);
+    }
   }
-  if (rc == DCGP_OK && xs && !first_fused && hipEventRecord(m->ev_sweep[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;   // Z^T, |z|^2: what a sweep needs
-  if (rc == DCGP_OK && prep_on_main && hipStreamWaitEvent(chain_s, m->ev_sweep[bank], 0) != hipSuccess) rc = DCGP_ERR_HIP;
+  if (rc == DCGP_OK && xs && !first_fused && !prep_split && hipEventRecord(m->ev_sweep[bank], ctx->stream) != hipSuccess) rc = DCGP_ERR_HIP;   // Z^T, |z|^2: what a sweep needs
+  if (rc == DCGP_OK && prep_on_main && !prep_split && hipStreamWaitEvent(chain_s, m->ev_sweep[bank], 0) != hipSuccess) rc = DCGP_ERR_HIP;
   // The first layer's sweep needs nothing else: it goes to the main stream NOW, in front of the chain's ~12 launches -- enqueued behind
   // them it started when the host was done with those, 60 us after prepare_all had finished (cfg2 head-only: 0.287 -> 0.24 ms).
   if (rc == DCGP_OK && xs && !first_fused && !ctx->opt.no_early_sweep) {
@@ -307,6 +317,12 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     if (rc == DCGP_OK) rc = layer_step(0, X, rows0, N, &out_rows, 1);
     early0 = rc == DCGP_OK;
     ctx->stream = chain_s;
+  }
+  if (rc == DCGP_OK && prep_split) {
+    PrepArgs pa;
+    pa.nl = nl;
+    for (int li = 0; li < nl; ++li) pa.l[li] = m->layers[li]->prep_args(m->jitter);
+    rc = prepare_all(ctx, pa, ~kPrepSweepTasks);
   }
   // with a single factor group its "chol_Lout" scratch stays untouched until the deferred copy runs on the KL stream
   const bool defer = m->groups[bank].size() == 1 && need_kl && !m->keep_state;

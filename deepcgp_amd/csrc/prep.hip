@@ -201,7 +201,7 @@ extern "C" void dcgp_debug_prep_trace(unsigned long long* out, int reset) {
 }
 #endif
 
-int prepare_all(dcgp_ctx* ctx, const PrepArgs& a) {
+int prepare_all(dcgp_ctx* ctx, const PrepArgs& a, unsigned task_mask) {
   if (a.nl <= 0) return DCGP_OK;
   ScopedTimer t(ctx, "prepare");
   // (layer, task) segments with their item counts and a per-item cost (chunks of the patch length for the Gram tiles, 1 otherwise)
@@ -211,13 +211,15 @@ int prepare_all(dcgp_ctx* ctx, const PrepArgs& a) {
   for (int i = 0; i < a.nl; ++i) {
     const PrepLayerArgs& p = a.l[i];
     const int nt = (p.Mp + 15) / 16, chunks = (p.L + 31) / 32, nmb = (p.Mp + 31) / 32, nnb = (p.Mp + 7) / 8;
-    segs[ns++] = {i, 0, nt * nt, 2 + chunks};
-    if (p.Kp) segs[ns++] = {i, 1, nt * nt, 2 + chunks};
-    segs[ns++] = {i, 2, nmb * ((p.Lp + 31) / 32) + nnb, 1};
-    if (p.q_sqrt) segs[ns++] = {i, 3, p.R * ((p.Mp + 15) / 16), 2};
-    segs[ns++] = {i, 4, (p.Mp * p.Rp + 255) / 256, 0};
-    if (p.ZS) segs[ns++] = {i, 5, nmb * ((p.L + 31) / 32) + nnb, 1};
+    auto on = [&](int task) { return (task_mask >> task & 1u) != 0; };
+    if (on(0)) segs[ns++] = {i, 0, nt * nt, 2 + chunks};
+    if (p.Kp && on(1)) segs[ns++] = {i, 1, nt * nt, 2 + chunks};
+    if (on(2)) segs[ns++] = {i, 2, nmb * ((p.Lp + 31) / 32) + nnb, 1};
+    if (p.q_sqrt && on(3)) segs[ns++] = {i, 3, p.R * ((p.Mp + 15) / 16), 2};
+    if (on(4)) segs[ns++] = {i, 4, (p.Mp * p.Rp + 255) / 256, 0};
+    if (p.ZS && on(5)) segs[ns++] = {i, 5, nmb * ((p.L + 31) / 32) + nnb, 1};
   }
+  if (ns == 0) return DCGP_OK;
   std::stable_sort(segs, segs + ns, [](const Seg& x, const Seg& y) { return x.cost > y.cost; });
   PrepPlan plan;
   plan.nseg = ns;

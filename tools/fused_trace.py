@@ -30,9 +30,12 @@ for b in range(32):
         continue
     live = t[b, :, 0] > 0
     wall_us = (t[b, 0, 11] - t[b, 0, 10]) / 100.0           # wall_clock64: 100 MHz
-    print("  wg %d.%d  start %8.2f  duration %7.2f  stage3 %7.2f   wall %7.2f us -> shader clock %.3f GHz" % (
-        b // 4, b % 4, (t[b, live, 0].min() - g0) / GHZ / 1e3, (t[b, live, 9].max() - t[b, live, 0].min()) / GHZ / 1e3,
-        (t[b, live, 6].max() - t[b, live, 5].min()) / GHZ / 1e3, wall_us, (t[b, 0, 9] - t[b, 0, 0]) / wall_us / 1e3))
+    # (prologues ahead, conv_fused.hip: an item that runs phases 0 - 2 only leaves no stamp behind "A1 published", one that fetches A1 none in front of it)
+    kind = "prologue only" if not t[b, 0, 9] else ("A1 fetched" if not t[b, 0, 1] else "whole strip")
+    last = t[b, live, :10].max()
+    print("  wg %d.%d  start %8.2f  duration %7.2f  stage3 %7.2f   wall %7.2f us -> shader clock %.3f GHz  %s" % (
+        b // 4, b % 4, (t[b, live, 0].min() - g0) / GHZ / 1e3, (last - t[b, live, 0].min()) / GHZ / 1e3,
+        (t[b, live, 6].max() - t[b, live, 5].min()) / GHZ / 1e3 if t[b, 0, 9] else 0.0, wall_us, (t[b, 0, :10].max() - t[b, 0, 0]) / wall_us / 1e3, kind))
 names = ["start", "images+xn", "kuf done", "kuf barrier", "stage1 done", "A1 published", "stage3 done", "mean done", "partials", "end"]
 if "--summary" in sys.argv:
     sys.exit(0)

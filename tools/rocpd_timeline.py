@@ -12,7 +12,10 @@ def main(db, which=-3, window_us=None):
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
     sel = "%s, start, end%s" % (name_col, (", " + qcol) if qcol else "")
     rows = c.execute("select %s from kernels order by start" % sel).fetchall()
-    marks = [i for i, r in enumerate(rows) if "prepare_all" in r[0]]
+    marks = []   # (a head-first model prepares in two launches, one per stream, at the head of a step: the first of a cluster marks the step)
+    for i, r in enumerate(rows):
+        if "prepare_all" in r[0] and (not marks or r[1] - rows[marks[-1]][1] > 40e3):
+            marks.append(i)
     lo, hi = marks[int(which)], marks[int(which) + 1]
     t0 = rows[lo][1]
     if window_us:   # steps in flight overlap: every kernel that STARTS within the window, whichever step it belongs to
