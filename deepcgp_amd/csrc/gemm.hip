@@ -177,6 +177,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
   // contiguous 32-row wave tiles they finish 4 : 3 : 2 : 1 and the workgroup holds its LDS and wave slots until the
   // last one is done.  The skip is per fragment and, k being monotone, a sequence of at most five loops
   // (none | frag 0 | both | frag 1 | none) with wave-uniform bounds -- no branch inside a loop body.
+  // LDS addresses of a k-tile (round 6): one per-lane base per A fragment and one for the B operand, moved to the current buffer once per k-tile; sub-step
+  // and column fragment are compile-time offsets, and a wave's column fragments lie WAVES_N * 16 columns (512 bytes at the 16-wave tile) apart, so that
+  // every offset is a multiple of ds_read2st64_b64's unit.  With the fragments side by side the body carried 9 v_add per 16 MFMAs (the B reads paired as
+  // ds_read2_b64, whose 8-bit offsets wanted a fresh base per sub-step) -- VALU instructions issue in the fp64 MFMA's place.  (The body
+  // instantiated per buffer, all offsets immediates: the two copies keep the accumulators in different registers and the 64-register cap spills.)
+  const double* wl0[FM];
+#pragma unroll
+  for (int x = 0; x < FM; ++x) wl0[x] = Ws + lrow * LDW + lcol + frag_off(x);
+  const double* bl0 = Bs + lrow * LDB + wn * 16 + lcol;
   int buf = 0;
   auto steps = [&](int kb, int ke, auto x0c, auto x1c) {
     constexpr int X0 = decltype(x0c)::value, X1 = decltype(x1c)::value;
@@ -184,15 +193,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
       const bool has_next = k0 + BK < khi;
       if (has_next && !(ABL & 1)) load_tile(k0 + BK, buf ^ 1);
       if (X0 < X1) {
-        const double* w = Ws + buf * BK * LDW + lcol;
-        const double* b = Bs + buf * BK * LDB + wn * WNC + lcol;
+        const double* wl[FM];
+#pragma unroll
+        for (int x = 0; x < FM; ++x) wl[x] = wl0[x] + buf * BK * LDW;
+        const double* bl = bl0 + buf * BK * LDB;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
           double av[FM], bv[FN];
 #pragma unroll
-          for (int x = X0; x < X1; ++x) av[x] = (ABL & 8) ? (double)(kk + x) : w[(kk + lrow) * LDW + frag_off(x)];
+          for (int x = X0; x < X1; ++x) av[x] = (ABL & 8) ? (double)(kk + x) : wl[x][kk * LDW];
 #pragma unroll
-          for (int y = 0; y < FN; ++y) bv[y] = (ABL & 8) ? (double)(lane + y) : b[(kk + lrow) * LDB + y * 16];
+          for (int y = 0; y < FN; ++y) bv[y] = (ABL & 8) ? (double)(lane + y) : bl[kk * LDB + y * WAVES_N * 16];
 #pragma unroll
           for (int x = X0; x < X1; ++x)
 #pragma unroll
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
     for (int x = 0; x < FM; ++x)
 #pragma unroll
       for (int y = 0; y < FN; ++y) {
-        int j = j0 + wn * WNC + y * 16 + lcol;
+        int j = j0 + (wn + y * WAVES_N) * 16 + lcol;
         const double cs = (a.cscale && j < a.Kc) ? a.calpha * a.cscale[(long)bzl * a.csBatch + (long)j * a.csCol] : 1.0;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
         for (int v = 0; v < 4; ++v) s += acc[x][y][v] * acc[x][y][v];
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
-      if (lrow == 0) red[wm * BN + wn * WNC + y * 16 + lcol] = s;
+      if (lrow == 0) red[wm * BN + (wn + y * WAVES_N) * 16 + lcol] = s;
     }
     __syncthreads();
     if (tid < BN) {
