@@ -5,7 +5,9 @@ T=$1
 R=$PWD; export TMPDIR=/tmp; mkdir -p gpurun_out
 # 1. the judged bench line (N = 1) and the same under rocprofv3 (per-kernel stats must agree with the in-bench HIP events)
 timeout 600 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
-tools/prof_bench.sh ${T} --steps 200 --warmup 20 > gpurun_out/${T}_profiled_run_summary.txt 2>&1
+# (1000 steps: the layer kernel's first ~30 launches of a process run up to 15 % long -- clock and cache warm-up -- and the CSV's average is over every launch)
+tools/prof_bench.sh ${T} --steps 1000 --warmup 20 > gpurun_out/${T}_profiled_run_summary.txt 2>&1
+cp gpurun_out/prof_${T}_kernel_stats.csv gpurun_out/${T}_kernel_stats.csv
 DB=$(find gpurun_out/prof_${T} -name '*.db' | head -1)
 python tools/rocpd_timeline.py $DB -4 > gpurun_out/${T}_step_timeline.txt
 # 2. steps kept in flight

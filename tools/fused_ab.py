@@ -13,8 +13,8 @@ from deepcgp_amd import device as dev, synthetic as syn          # noqa: E402
 from deepcgp_amd.models import build_from_spec                   # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "cfg2_mnist_CH_M256"
-DEFAULT = ("fused_persist=0 fused_persist=-1 fused_persist=2 fused_persist=1 fused_shape=2,fused_persist=0 fused_shape=2,fused_persist=1,fused_stagger=0 "
-           "fused_shape=2,fused_persist=1,fused_stagger=40 fused_persist=0 fused_persist=-1")
+DEFAULT = ("fused_persist=0 fused_persist=-1 fused_persist=2 fused_persist=1,fused_pre=0 fused_pre=0 fused_pre=-1 fused_pre=3 fused_pre=9 fused_shape=2,fused_persist=0 "
+           "fused_shape=2,fused_persist=1,fused_stagger=0 fused_shape=2,fused_persist=1,fused_stagger=40 fused_persist=0 fused_pre=0 fused_pre=-1")
 sets = os.environ.get("FUSED_AB_SETS", DEFAULT).split()
 spec, X, Y = syn.make_config(name)
 scale = float(spec["num_data"]) / X.shape[0]
