@@ -187,16 +187,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
   for (int x = 0; x < FM; ++x) wl0[x] = Ws + lrow * LDW + lcol + frag_off(x);
   const double* bl0 = Bs + lrow * LDB + wn * 16 + lcol;
   int buf = 0;
+  // a phase walks its k-tiles in PAIRS (current buffer, other buffer): the bases of both are fixed at its entry, so a k-tile carries no address arithmetic at all
   auto steps = [&](int kb, int ke, auto x0c, auto x1c) {
     constexpr int X0 = decltype(x0c)::value, X1 = decltype(x1c)::value;
-    for (int k0 = kb; k0 < ke; k0 += BK) {
-      const bool has_next = k0 + BK < khi;
-      if (has_next && !(ABL & 1)) load_tile(k0 + BK, buf ^ 1);
-      if (X0 < X1) {
-        const double* wl[FM];
+    const double* wc[FM];
+    const double* wo[FM];
 #pragma unroll
-        for (int x = 0; x < FM; ++x) wl[x] = wl0[x] + buf * BK * LDW;
-        const double* bl = bl0 + buf * BK * LDB;
+    for (int x = 0; x < FM; ++x) { wc[x] = wl0[x] + buf * BK * LDW; wo[x] = wl0[x] + (buf ^ 1) * BK * LDW; }
+    const double* bc = bl0 + buf * BK * LDB;
+    const double* bo = bl0 + (buf ^ 1) * BK * LDB;
+    auto tile = [&](int k0, int nbuf, const double* const (&wl)[FM], const double* bl) {
+      const bool has_next = k0 + BK < khi;
+      if (has_next && !(ABL & 1)) load_tile(k0 + BK, nbuf);
+      if (X0 < X1) {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
           double av[FM], bv[FN];
@@ -211,8 +214,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N >= 16) ? 
               acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
         }
       }
-      if (has_next && !(ABL & 2)) store_tile(buf ^ 1);
+      if (has_next && !(ABL & 2)) store_tile(nbuf);
       if (!(ABL & 4)) __syncthreads();
+    };
+    int k0 = kb;
+    for (; k0 + BK < ke; k0 += 2 * BK) {
+      tile(k0, buf ^ 1, wc, bc);
+      tile(k0 + BK, buf, wo, bo);
+    }
+    if (k0 < ke) {
+      tile(k0, buf ^ 1, wc, bc);
       buf ^= 1;
     }
   };
