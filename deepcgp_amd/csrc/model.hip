@@ -273,6 +273,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   // waited for that step: head-only model 4830 -> 4590 steps/s in flight)
   const bool prep_on_main = xs && !first_fused && !pipelined && !ctx->opt.no_early_sweep && !ctx->opt.prep_on_chain;
   const bool prep_split = prep_on_main && !ctx->opt.prep_one_launch;
+  const bool chain_first = prep_split && !m->layers[0]->is_head;
   bool early0 = false, side_kl = false;
   if (reuse) ++m->chain_skips;
   if (!reuse) {
@@ -298,9 +299,14 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     // main stream, the Gram matrices and the padded q_sqrt / q_mu on the chain's -- and no event between the streams at the head of the step: the
     // record was a packet between the preparation and the sweep (7.6 us from one to the other), the wait held the chain back (option prep_one_launch: A/B)
     if (prep_split) {
+      // Which stream's part the host enqueues first is which part gets the chip first.  A model that opens with the head: the sweep is the step's longest
+      // path (170 us against the chain's ~150 beside it) -- its part and the sweep, then the chain's.  A conv layer on the sweep + GEMM route (M > 256): the
+      // CHAIN is (the first product waits for inv(L) long after the sweep is done) -- enqueued behind the sweep its preparation ran 71 us beside it instead
+      // of ~15 and the first product of cfg4 started 53 us later (profiles/r06b_cfg4_cifar_3layer_M384_step_timeline.txt against r06c_*)
+      if (chain_first) rc = prepare_all(ctx, pa, ~kPrepSweepTasks);
       ctx->stream = main_s;
-      rc = prepare_all(ctx, pa, kPrepSweepTasks);
-      ctx->stream = chain_s;   // (the chain's part is enqueued BEHIND the sweep, below: at the head of a synchronous step the device waits for the host, ~4 us a launch)
+      if (rc == DCGP_OK) rc = prepare_all(ctx, pa, kPrepSweepTasks);
+      ctx->stream = chain_s;   // (head first: the chain's part is enqueued BEHIND the sweep, below: at the head of a synchronous step the device waits for the host, ~4 us a launch)
     } else {
       if (prep_on_main) ctx->stream = main_s;
       rc = prepare_all(ctx, pa);
@@ -318,7 +324,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
     early0 = rc == DCGP_OK;
     ctx->stream = chain_s;
   }
-  if (rc == DCGP_OK && prep_split) {
+  if (rc == DCGP_OK && prep_split && !chain_first) {
     PrepArgs pa;
     pa.nl = nl;
     for (int li = 0; li < nl; ++li) pa.l[li] = m->layers[li]->prep_args(m->jitter);
