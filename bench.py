@@ -823,10 +823,16 @@ def main():
                                "algorithmic_flops_per_step": flops_dom, "ms_per_step_in_kernel": per_step_ms,
                                "launches_sampled": t_dom[0], "sampling": "HIP events on the launch stream around every launch of the kernel, in a loop of %d steps behind the timed region" % n_roof,
                                "stage3_only_flops_per_step": flops_s3,
+                               "traffic_note": ("the layer's own HBM bytes are the images in and the samples out (29.5 MB at cfg2: 31 MB measured until round 6's first "
+                                                "session); since the prologues-ahead deal (DESIGN 4i) the counters also see 256 strips of A1 (132 KB each) written by the partial "
+                                                "first round's spare workgroups and fetched back by the workgroups that run their second product: ~35 MB each way plus the "
+                                                "write-through of the sc1 stores, Infinity-Cache resident, bought for 20 us of the launch -- not a re-read of the layer's inputs"
+                                                ) if fused else None,
                                "note": "algorithmic flops: triangular products counted as M^2 per column (SURVEY 8(d)); peak = 78.6 TFLOP/s fp64 MFMA at the "
                                        "2.4 GHz datasheet clock.  (Earlier rounds read a shader clock of 2.1-2.3 GHz off wall_clock64 inside the kernel and called it "
                                        "power-limited; rocm-smi beside the looping step reads sclk 2398 MHz at 983 W of the 1400 W cap, and three strips of 446 k cycles "
-                                       "account for the launch at 2.39 GHz: the part is not power-bound here -- profiles/r06_power_and_clock.txt)"}
+                                       "accounted for the 572 us launch of that build at 2.39 GHz: the part is not power-bound here -- profiles/r06_power_and_clock.txt.  "
+                                       "Since the prologues-ahead deal a CU runs whole + whole + fetched strips, 187 + 186 + 163 us: profiles/r06_fused_phase_trace.txt)"}
             # ---- the K_uf half of the metric (layer 0; SURVEY 8(d), conv_gp/layers.py:23-32) ----
             # algorithmic bytes of the sweep as the reference runs it: images in, Z in, K_uf [P, M, N'] out
             bytes_kuf = 8.0 * (rows0 * c["H"] * c["W"] * c["C"] + M * L + float(P) * M * rows0)

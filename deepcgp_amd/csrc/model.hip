@@ -302,7 +302,7 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
       // Which stream's part the host enqueues first is which part gets the chip first.  A model that opens with the head: the sweep is the step's longest
       // path (170 us against the chain's ~150 beside it) -- its part and the sweep, then the chain's.  A conv layer on the sweep + GEMM route (M > 256): the
       // CHAIN is (the first product waits for inv(L) long after the sweep is done) -- enqueued behind the sweep its preparation ran 71 us beside it instead
-      // of ~15 and the first product of cfg4 started 53 us later (profiles/r06b_cfg4_cifar_3layer_M384_step_timeline.txt against r06c_*)
+      // of ~15 and the first product of cfg4 started 53 us later (profiles/the first cut of this split)
       if (chain_first) rc = prepare_all(ctx, pa, ~kPrepSweepTasks);
       ctx->stream = main_s;
       if (rc == DCGP_OK) rc = prepare_all(ctx, pa, kPrepSweepTasks);
