@@ -251,7 +251,12 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
       for (int y = 0; y < FNS; ++y) kacc[c][y] = d4{0.0, 0.0, 0.0, 0.0};
     // RBF: ZS = sqrt(c) Z^T with the rows (-c |z|^2 / 2 + log2 variance, 1) behind the patch, against columns
     // (sqrt(c) x, 1, -c |x|^2 / 2): the accumulator is log2 of the kernel value (sweep_dev.h, head_units.hip)
-    const double* __restrict__ zt = (BT == 0 ? a.ZS : a.ZT) + lcol;
+    // (through a buffer descriptor: one 32-bit per-lane offset per row fragment, the k sub-step a scalar offset -- as a 64-bit pointer per load the address
+    // arithmetic was ~8 VALU instructions per sub-step in the MFMA stream, more than the sub-step's own 4 MFMAs at a long patch)
+    const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(BT == 0 ? a.ZS : a.ZT), 0, nk4 * 4 * Mp * 8, 0x00020000);
+    unsigned zoff[MAXF];
+#pragma unroll
+    for (int c = 0; c < MAXF; ++c) zoff[c] = (unsigned)((lrow * Mp + 16 * fr[c] + lcol) * 8);
     double xnv[FNS];
 #pragma unroll
     for (int y = 0; y < FNS; ++y) xnv[y] = xn[(sp * FNS + y) * 16 + lcol];
@@ -261,7 +266,10 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
     for (int c = 0; c < MAXF; ++c) ring[D4][c] = 0.0;   // (defined on every path: an undefined slot would be carried from strip to strip of a persistent workgroup)
     auto ldz = [&](int k4, double (&dst)[MAXF]) {
 #pragma unroll
-      for (int c = 0; c < MAXF; ++c) dst[c] = zt[(long)(4 * k4 + lrow) * Mp + 16 * fr[c]];
+      for (int c = 0; c < MAXF; ++c) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(zrs, (int)zoff[c], k4 * 4 * Mp * 8, 0);
+        __builtin_memcpy(&dst[c], &v, 8);
+      }
     };
     auto kstep = [&](int k4, const double (&w)[MAXF]) {
       const int k = 4 * k4 + lrow;
@@ -285,9 +293,37 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
 #pragma unroll
         for (int y = 0; y < FNS; ++y) kacc[c][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[c], bv[y], kacc[c][y], 0, 0, 0);
     };
+    // sub-steps that hold patch elements only (every lane's k < L): the gathered value IS the operand -- the slot selects and the two FMAs per column
+    // fragment of the general sub-step are VALU instructions in the MFMA stream (a long patch, L = 250, walks 62 such sub-steps of 63: cfg3's second layer)
+    // (the patch-element offsets of a group of sub-steps are read a group ahead: offset -> gather -> MFMA inside one sub-step is two LDS round trips)
+    auto kstep_fast = [&](int ko, const double (&w)[MAXF]) {
+      double bv[FNS];
+#pragma unroll
+      for (int y = 0; y < FNS; ++y) bv[y] = aux[pb[y] + ko];
+#pragma unroll
+      for (int c = 0; c < MAXF; ++c)
+#pragma unroll
+        for (int y = 0; y < FNS; ++y) kacc[c][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[c], bv[y], kacc[c][y], 0, 0, 0);
+    };
+    const int nfast = min(a.L >> 2, nk4);
 #pragma unroll
     for (int u = 0; u < D4; ++u) ldz(min(u, nk4 - 1), ring[u]);
     int t = 0;
+    int kc[D4 + 1], kn[D4 + 1];
+#pragma unroll
+    for (int u = 0; u <= D4; ++u) kc[u] = koff[4 * min(u, nk4 - 1) + lrow];
+    for (; t + D4 + 1 <= nfast; t += D4 + 1) {
+#pragma unroll
+      for (int u = 0; u <= D4; ++u) kn[u] = koff[4 * min(t + D4 + 1 + u, nk4 - 1) + lrow];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u <= D4; ++u) {
+        ldz(min(t + u + D4, nk4 - 1), ring[(u + D4) % (D4 + 1)]);
+        kstep_fast(kc[u], ring[u]);
+      }
+#pragma unroll
+      for (int u = 0; u <= D4; ++u) kc[u] = kn[u];
+    }
     for (; t + D4 + 1 <= nk4; t += D4 + 1) {
 #pragma unroll
       for (int u = 0; u <= D4; ++u) {
