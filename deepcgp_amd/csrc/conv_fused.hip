@@ -102,7 +102,19 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
     }
   }
   int strip_next = blockIdx.x;
-  for (int it = 0;; ++it) {
+  if (a.pre_n > 0) {
+    // Prologues ahead: EVERY item, a workgroup's first included, comes off the counter -- an item is then held by a workgroup that is running.  (Dealt by
+    // blockIdx, a prologue item could belong to a workgroup that is not resident yet -- the chip shared with another kernel, a CU-masked stream -- while a
+    // running one already waits for its A1.)
+    int* tk = reinterpret_cast<int*>(smem);
+    if (threadIdx.x == 0) tk[0] = atomicAdd(a.dyn, 1);
+    __syncthreads();
+    strip_next = __builtin_amdgcn_readfirstlane(tk[0]);
+    __syncthreads();
+  }
+  // (a workgroup that starts when every item has been dealt -- more workgroups than CUs it may run on -- has nothing to do but sign off)
+  const int first_limit = a.pre_n > 0 ? a.n_strips + a.pre_n : 0x7fffffff;
+  for (int it = 0; strip_next < first_limit; ++it) {
   // every strip sees the kernarg pointer and the thread index as new values: nothing of a strip's set-up (argument words, per-lane offsets of every
   // phase) is then loop-invariant, hoisted and kept live across the whole body -- as plain invariants they cost 240 spilled VGPRs at 16 waves
   int tid = threadIdx.x;
@@ -139,6 +151,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
   // of the strips [pre_first, pre_first + pre_n) and leave A1 (the LDS image of the strip) and the partial sums of A1^2 in a.pre_buf: they fill the
   // first round's spare workgroups; then the remaining strips whole; then the pre_n strips again, which fetch their A1 and go straight to phase 3.
   // Same arithmetic in the same order as a whole strip: bit-identical.
+  bool pre_fail = false;
   int mode = 0, pre_slot = 0;   // 0: a whole strip; 1: phases 0 - 2 only, A1 left in a.pre_buf; 2: A1 fetched from a.pre_buf, phases 3 - 4
   if (a.pre_n > 0) {
     if (strip_next >= a.n_strips) { mode = 2; pre_slot = strip_next - a.n_strips; sidx = a.pre_first + pre_slot; }
@@ -484,12 +497,17 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
   } else {
     // ---- A1 of the strip and its partial sums from the workgroup that ran phases 0 - 2 (dealt earlier: it is running or done) ----
     if (tid == 0) {
-      for (int spin = 0; spin < (1 << 22); ++spin) {   // (bounded: a launch must not hang the device)
-        if (__hip_atomic_load(a.pre_flag + pre_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.pre_epoch) break;
-        __builtin_amdgcn_s_sleep(2);
+      // (its holder is running and waits for nobody, so this ends within a prologue's time; bounded all the same -- a launch must not hang the device --
+      // and a strip that gave up says so: its samples come out as NaNs)
+      int ok = 0;
+      for (int spin = 0; spin < (1 << 24) && !ok; ++spin) {
+        ok = __hip_atomic_load(a.pre_flag + pre_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.pre_epoch ? 1 : 0;
+        if (!ok) __builtin_amdgcn_s_sleep(2);
       }
+      ticket[1] = ok;
     }
     __syncthreads();
+    pre_fail = ticket[1] == 0;
     const double* __restrict__ src = a.pre_buf + (long)pre_slot * a.pre_stride;
     for (int i0 = 0; i0 < Mp * BN; i0 += 8 * NT) {
       double t[8];
@@ -691,6 +709,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
     }
     for (int g = 0; g < KG; ++g) m += mup[(g * 16 + r) * BN + c];
     const double v = (a.knn - s1) + s2;
+    if (pre_fail) m = __builtin_nan("");
     if (a.idm && r == 0) {   // Conv2dMean (conv_gp/mean_functions.py:28-41): centre pixel of channel 0 onto map 0
       const int n = j / a.P, p = j - n * a.P;
       const int oh = p / a.Wo, ow = p - oh * a.Wo, c0 = a.f / 2;
@@ -713,7 +732,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
   if (!a.persist) break;
   // the next strip: dealt by arrival (a.dyn: one counter per launch) -- two workgroups share a CU and the one launched first wins every arbitration
   // between them, so a fixed deal leaves the other with a strip and a half to run alone at the end (profiles/r06_fused_persistent_static_trace.txt)
-  if (tid == 0) ticket[0] = a.dyn ? (int)gridDim.x + atomicAdd(a.dyn, 1) : strip_next + (int)gridDim.x;
+  if (tid == 0) ticket[0] = a.dyn ? (a.pre_n > 0 ? 0 : (int)gridDim.x) + atomicAdd(a.dyn, 1) : strip_next + (int)gridDim.x;
   __syncthreads();   // (and the partial sums are read: the next strip's images may land on them)
   strip_next = __builtin_amdgcn_readfirstlane(ticket[0]);
   if (strip_next >= a.n_strips + a.pre_n) break;

@@ -1420,6 +1420,39 @@ print("RESULT", " ".join(repr(v) for v in out))
     assert clean == poisoned, (clean, poisoned)
 
 
+def test_prologues_ahead_with_fewer_cus_than_workgroups(ctx):
+    """The layer kernel's prologues ahead (csrc/conv_fused.hip) hand A1 from one workgroup of a launch to another.  On a CU-masked main stream
+    (DCGP_CU_PARTITION=1: steps in flight run their data path on 240 of the 256 CUs) the launch has more workgroups than CUs: some start only when
+    others have left, and none of them may hold an item a running workgroup waits for -- every item, the first included, comes off the device
+    counter.  Same ELBO as the synchronous step on the whole chip, to the last bit, in a fresh process (the switch is read at ctx creation)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from deepcgp_amd import synthetic as syn
+from deepcgp_amd.models import build_from_spec
+spec, X, Y = syn.make_config("cfg2_mnist_CH_M256")
+model = build_from_spec(spec, X, Y)
+out = [model.compute_log_likelihood(X, Y, seed=5)]
+tickets = [model.enqueue_log_likelihood(X, Y, seed=5) for _ in range(3)]
+out += [model.collect_log_likelihood(t) for t in tickets]
+print("RESULT", " ".join(repr(v) for v in out))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env_extra):
+        env = dict(os.environ)
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1]
+        return [float(v) for v in line.split()[1:]]
+    whole, masked, off = run({}), run({"DCGP_CU_PARTITION": "1"}), run({"DCGP_CU_PARTITION": "1", "DCGP_FUSED_PRE": "0"})
+    assert all(np.isfinite(masked)), masked
+    assert len(set(whole)) == 1 and whole == masked == off, (whole, masked, off)
+
+
 def test_one_launch_factorisation_chain_matches_the_launch_per_panel_chain(ctx):
     """DCGP_CHOL_ONE_LAUNCH=1 runs the Cholesky + inverse chain (conv_gp/conditionals.py:29, layers.py:151,156) as ONE launch whose
     workgroups hand panels to each other through flags (csrc/chol_fused.hip, chol_persist_kernel; opt-in: measured slower than the
