@@ -42,6 +42,7 @@ struct DcgpOptions {
                                  // (-1: chosen by a simulated deal; 0: never; k > 0: up to k per spare workgroup)
   long fused_stagger = -1;       // persistent layer kernel: microseconds the second workgroup of a CU holds back (-1: default; 0: none)
   long kl_side = 0;              // KL terms by their own launches on the side stream instead of inside the tail launch
+  long kl_no_ride = 0;           // KL pieces in the tail launch even where the head's one-launch conditional could carry them (A/B)
   long no_fused_bwd = 0;         // reverse pass of the conditional by GEMM launches instead of the strip kernel
   long fused_bwd_min_cols = -1;  // strip kernel of the reverse pass from this many columns on (-1: default 4096)
   long fused_bwd_frags = 0;      // strip width of that kernel in 16-column fragments (0: chosen from the column count; 4, 2, 1)
@@ -85,8 +86,14 @@ bool dcgp_poison(const char* name = nullptr);
 
 struct ChainEpoch { unsigned epoch = 0; int T = 0, np = 0, batch = 0; };   // launches so far of the one-launch factorisation chain on a sync area
 
+struct KlTail;   // layer.h
 struct dcgp_ctx {
   int device = 0;
+  // KL pieces riding the head's one-launch conditional (model.hip sets kl_ride in front of the head layer of an ELBO step; head_cond.hip carries them as
+  // extra workgroups of its launch, clears kl_ride and sets kl_rode; a head on another route leaves them to the tail launch)
+  const KlTail* kl_ride = nullptr;
+  double* kl_ride_scal = nullptr;
+  bool kl_rode = false;
   int n_cus = 256;   // compute units of the device (set at dcgp_ctx_create)
   hipStream_t stream = nullptr;    // the stream launches go to (temporarily swapped to stream2 for the side branch)
   hipStream_t stream2 = nullptr;   // side stream: factorisation chain + KL terms

@@ -14,7 +14,9 @@
 //     * sum_m A1^2, alpha_r^T A1 and sum_m T_r^2 are reduced from the accumulators, and mean / var leave the kernel
 //       in the [column][R] layout the likelihood reads (conv_gp/layers.py:128-134 semantics, full_cov = False).
 // A1 (and stage 1) is recomputed by the R workgroups of a strip: 8 extra MFMA k-tiles each, cheaper than a launch.
+#include <algorithm>
 #include "layer.h"
+#include "tail_dev.h"
 
 namespace {
 
@@ -35,6 +37,10 @@ struct HeadCondArgs {
   double *out_mean, *out_var;              // [Kc][R]
   double* A1_out; long lda1;               // != null: A1 = inv(L) Kzx [M][lda1] is left behind as well (a training step's reverse pass reads it)
   int M;
+  // the KL pieces of the model's layers as workgroups (x < kl.nl, y == R) of this launch (tail_dev.h: kl_pieces_block): parameter-only work that was the
+  // long pole of the tail launch -- a lane's M R / 256 dependent (strided load, log) pairs, ~5 us of its 14 at M = 256 -- and costs nothing beside the
+  // conditional's ~200 workgroups
+  KlTail kl; double* kl_scal;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -48,6 +54,10 @@ __global__ __launch_bounds__(1024, 4) void head_cond_kernel(HeadCondArgs a) {
   double* Bt = hc_smem;                       // [Mp][16]: Kzx strip, then A1
   double* red = hc_smem + a.Mp * HC_BN;       // [4][16][16]
 
+  if ((int)blockIdx.y >= a.R) {   // (only with a.kl.nl > 0)
+    if ((int)blockIdx.x < a.kl.nl) kl_pieces_block(a.kl.l[blockIdx.x], a.kl_scal + 4 + 4 * blockIdx.x, hc_smem);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j0 = blockIdx.x * HC_BN, r = blockIdx.y;
@@ -315,14 +325,25 @@ int head_cond_fused(dcgp_ctx* ctx, const GpMats& g, const double* B, long ldb, i
   a.kd = kd; a.kd_n = kd_n; a.kd_scale = kd_scale; a.Mp = g.Mp; a.R = g.R;
   a.out_mean = out_mean; a.out_var = out_var;
   a.A1_out = A1_out; a.lda1 = lda1; a.M = g.M;
-  const size_t lds = (size_t)(g.Mp * HC_BN + 4 * 16 * 16) * sizeof(double);
+  a.kl.nl = 0; a.kl_scal = nullptr;
+  const int strips = (Kc + HC_BN - 1) / HC_BN;
+  // (worth it from ~1000 diagonal entries per layer on: M = 256, R = 10 -- head-only model 0.2186 -> 0.2160 ms per step; at M = 32 the extra row of
+  // workgroups costs the launch more than the tail saves: 0.1408 -> 0.1418)
+  long kl_work = 0;
+  if (ctx->kl_ride)
+    for (int l = 0; l < ctx->kl_ride->nl; ++l) kl_work = std::max<long>(kl_work, (long)ctx->kl_ride->l[l].M * ctx->kl_ride->l[l].R);
+  if (ctx->kl_ride && ctx->kl_ride->nl <= strips && kl_work >= 1024 && !ctx->opt.kl_no_ride) {
+    a.kl = *ctx->kl_ride; a.kl_scal = ctx->kl_ride_scal;
+    ctx->kl_ride = nullptr; ctx->kl_rode = true;
+  }
+  const size_t lds = (size_t)(g.Mp * HC_BN + 4 * 16 * 16) * sizeof(double);   // (>= the 8 KB of a KL workgroup: Mp >= 16)
   static bool attr_set[64] = {};   // per device (72 KB at Mp = 512)
   const int dv = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
   if (!attr_set[dv]) {
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)head_cond_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (HC_MP * HC_BN + 4 * 16 * 16) * 8));
     attr_set[dv] = true;
   }
-  hipLaunchKernelGGL(head_cond_kernel, dim3((Kc + HC_BN - 1) / HC_BN, g.R), dim3(1024), lds, ctx->stream, a);
+  hipLaunchKernelGGL(head_cond_kernel, dim3(strips, g.R + (a.kl.nl > 0 ? 1 : 0)), dim3(1024), lds, ctx->stream, a);
   LAUNCH_CHECK(ctx);
   return DCGP_OK;
 }

@@ -450,7 +450,11 @@ int forward_all(dcgp_model* m, const double* X, int N, int S, const double* cons
   for (int li = 0; li < nl; ++li) {
     int out_rows = 0;
     if (li == nl - 1 && join_early && kl_join) HIP_TRY(ctx, hipStreamWaitEvent(main_s, m->ev_kl[bank], 0));
-    DCGP_TRY(layer_step(li, F, rows, n_mod, &out_rows, (li == 0 && early0) ? 2 : 3));
+    // the KL pieces ride the head's one-launch conditional where there is one (head_cond.hip); m->kl_rode[bank] says whether they did
+    if (li == nl - 1 && need_kl && m->kl_in_tail[bank]) { ctx->kl_ride = &m->kl_tail[bank]; ctx->kl_ride_scal = scal; ctx->kl_rode = false; }
+    const int rc_l = layer_step(li, F, rows, n_mod, &out_rows, (li == 0 && early0) ? 2 : 3);
+    if (li == nl - 1) { m->kl_rode[bank] = need_kl && m->kl_in_tail[bank] && ctx->kl_rode; ctx->kl_ride = nullptr; ctx->kl_rode = false; }
+    DCGP_TRY(rc_l);
     if (li == 0 && m->gkl_state && mark_behind_first) HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_s));   // (the chain's results are ordered in front of this layer)
     if (!m->layers[li]->is_head) F = m->outs[li].sample;
     rows = out_rows;
@@ -675,7 +679,7 @@ int elbo_forward_enqueue_impl(dcgp_model* model, const double* X, const int32_t*
   if (groups_now.size() > 16) return ctx_fail(ctx, DCGP_ERR_ARG, "model: too many factor groups");
   ElboFinish fin;
   fill_finish(model, groups_now, scale, slot, &fin);
-  const KlTail* klt = model->kl_in_tail[model->bank] ? &model->kl_tail[model->bank] : nullptr;
+  const KlTail* klt = (model->kl_in_tail[model->bank] && !model->kl_rode[model->bank]) ? &model->kl_tail[model->bank] : nullptr;
   // From here on a kernel that writes this slot's completion word (ticket + 1) may be in flight.  If anything below fails the ticket is
   // NOT handed out and the next enqueue reuses slot and ticket: the word is cleared, behind a device sync, so that the stale kernel's
   // write cannot satisfy the retried step's wait early.

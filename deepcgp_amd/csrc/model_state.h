@@ -33,6 +33,7 @@ struct dcgp_model {
   // the KL pieces computed inside the tail launch (layers whose sums prep_solve left behind): per bank, set by forward_all
   KlTail kl_tail[2];
   bool kl_in_tail[2] = {false, false};
+  bool kl_rode[2] = {false, false};   // ... and the head's one-launch conditional of this step carried them (head_cond.hip): the tail launch has none
   // per-layer outputs of the most recent forward
   struct Out { double *sample = nullptr, *mean = nullptr, *var = nullptr; int rows = 0, width = 0; size_t cap = 0; };
   std::vector<Out> outs;

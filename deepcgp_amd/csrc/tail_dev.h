@@ -34,23 +34,26 @@ __device__ __forceinline__ double robustmax_logp(double p, double eps, int K) {
   return p * log(1.0 - eps) + (1.0 - p) * log(eps / (K - 1.0));
 }
 
-// One workgroup (256 threads): the four KL pieces of a layer -- {Mahalanobis, log det q, log det prior, trace}, the layout
-// kl_small_kernel (cond.hip) leaves -- from the strip sums of prep_solve and the diagonals of the factors.
+// One workgroup (>= 256 threads, the first 256 work: the sums and their order do not depend on the launch that carries the block): the four KL
+// pieces of a layer -- {Mahalanobis, log det q, log det prior, trace}, the layout kl_small_kernel (cond.hip) leaves -- from the strip sums of
+// prep_solve and the diagonals of the factors.
 __device__ __forceinline__ void kl_pieces_block(const KlTailLayer& L, double* __restrict__ kl4, double* red /* [4][256] LDS */) {
   const int tid = threadIdx.x, ns = L.ns > 0 ? L.ns : L.Mp / 16, nsa = L.ns > 0 ? L.nsa : 1;
-  double ldq = 0.0, ldp = 0.0, tr = 0.0, mh = 0.0;
-  for (int idx = tid; idx < L.M * L.R; idx += 256) {
-    const int i = idx % L.M, r = idx / L.M;
-    const double d = L.Lq[((long)r * L.Mp + i) * L.Mp + i];
-    ldq += log(d * d);
+  if (tid < 256) {
+    double ldq = 0.0, ldp = 0.0, tr = 0.0, mh = 0.0;
+    for (int idx = tid; idx < L.M * L.R; idx += 256) {
+      const int i = idx % L.M, r = idx / L.M;
+      const double d = L.Lq[((long)r * L.Mp + i) * L.Mp + i];
+      ldq += log(d * d);
+    }
+    for (int i = tid; i < L.M; i += 256) {
+      const double d = L.Lfac[(long)i * L.ldf + i];
+      ldp += log(d * d);
+    }
+    for (int i = tid; i < L.R * ns; i += 256) tr += L.sums[i];
+    for (int i = tid; i < nsa; i += 256) mh += L.sums[(long)L.R * ns + i];
+    red[tid] = mh; red[256 + tid] = ldq; red[512 + tid] = ldp; red[768 + tid] = tr;
   }
-  for (int i = tid; i < L.M; i += 256) {
-    const double d = L.Lfac[(long)i * L.ldf + i];
-    ldp += log(d * d);
-  }
-  for (int i = tid; i < L.R * ns; i += 256) tr += L.sums[i];
-  for (int i = tid; i < nsa; i += 256) mh += L.sums[(long)L.R * ns + i];
-  red[tid] = mh; red[256 + tid] = ldq; red[512 + tid] = ldp; red[768 + tid] = tr;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (tid < o)

@@ -201,6 +201,27 @@ def test_kl_pieces_in_the_tail_launch_match_the_kl_launches(ctx):
     model.close()
 
 
+def test_kl_pieces_riding_the_head_conditional_are_bit_identical(ctx):
+    """From ~1000 diagonal entries per layer on (M R >= 1024) the KL pieces are workgroups of the head's one-launch conditional instead of the tail
+    launch (head_cond.hip; ctx option kl_no_ride keeps them in the tail): same sums in the same order -- ELBO, data term and KL to the bit, synchronous
+    and in flight, head-first and conv + head, and against the oracle."""
+    hwc = (12, 12, 1)
+    for convs in ([], [(3, 2, 4)]):
+        spec = syn.make_spec(hwc, convs, (3, 1), M=128, S=3, num_data=600, seed=41, conv_q_sqrt_scale=0.4)
+        X, Y = syn.make_batch(hwc, 6, seed=41)
+        zs = syn.make_noise(spec, 6, seed=42)
+        model = build_from_spec(spec, X, Y)
+        e, data, kl = model.compute_log_likelihood(X, Y, zs=zs, return_parts=True)
+        ref = oracle_model(spec, X, Y).compute_log_likelihood(X, Y, zs=zs)
+        assert abs(e - ref) <= RTOL * abs(ref)
+        with ctx.options(kl_no_ride=1):
+            assert model.compute_log_likelihood(X, Y, zs=zs, return_parts=True) == (e, data, kl)
+        tickets = [model.enqueue_log_likelihood(X, Y, zs=zs) for _ in range(3)]
+        assert [model.collect_log_likelihood(t) for t in tickets] == [e] * 3
+        assert model.compute_log_likelihood(X, Y, zs=zs, return_parts=True) == (e, data, kl)
+        model.close()
+
+
 def test_enqueued_steps_match_the_synchronous_forward(ctx):
     """dcgp_elbo_forward_enqueue / _collect: several steps in flight (different minibatches, explicit noise or the
     device RNG) hand back bit-identical values to dcgp_elbo_forward, in order; misuse is refused."""
