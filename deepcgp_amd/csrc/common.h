@@ -40,6 +40,8 @@ struct DcgpOptions {
                                  // 1: on, strips dealt by a device counter; 2: on, dealt by a fixed stride)
   long fused_pre = -1;           // persistent layer kernel: prologues (sweep + first product) of later strips run by the spare workgroups of a partial first round
                                  // (-1: chosen by a simulated deal; 0: never; k > 0: up to k per spare workgroup)
+  long fused_parts = -1;         // layer kernel on few strips (< 1.5 rounds of the CUs): every strip's prologue by one item, its outputs by q parts that fetch A1
+                                 // (-1, 0: never -- measured slower at every shard, conv_fused.hip: plan_parts; q > 0: this many parts; -2: q by the simulated deal)
   long fused_stagger = -1;       // persistent layer kernel: microseconds the second workgroup of a CU holds back (-1: default; 0: none)
   long kl_side = 0;              // KL terms by their own launches on the side stream instead of inside the tail launch
   long kl_no_ride = 0;           // KL pieces in the tail launch even where the head's one-launch conditional could carry them (A/B)

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
     __syncthreads();
   }
   // (a workgroup that starts when every item has been dealt -- more workgroups than CUs it may run on -- has nothing to do but sign off)
-  const int first_limit = a.pre_n > 0 ? a.n_strips + a.pre_n : 0x7fffffff;
+  const int first_limit = a.pre_n > 0 ? a.n_strips + a.pre_n * a.pre_sq : 0x7fffffff;
   for (int it = 0; strip_next < first_limit; ++it) {
   // every strip sees the kernarg pointer and the thread index as new values: nothing of a strip's set-up (argument words, per-lane offsets of every
   // phase) is then loop-invariant, hoisted and kept live across the whole body -- as plain invariants they cost 240 spilled VGPRs at 16 waves
@@ -154,7 +154,14 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
   bool pre_fail = false;
   int mode = 0, pre_slot = 0;   // 0: a whole strip; 1: phases 0 - 2 only, A1 left in a.pre_buf; 2: A1 fetched from a.pre_buf, phases 3 - 4
   if (a.pre_n > 0) {
-    if (strip_next >= a.n_strips) { mode = 2; pre_slot = strip_next - a.n_strips; sidx = a.pre_first + pre_slot; }
+    if (strip_next >= a.n_strips) {   // (pre_sq > 1: part sq of the strip's SQ, the split of a shared last round applied to a strip whose A1 is fetched)
+      mode = 2;
+      const int t = strip_next - a.n_strips;
+      SQ = a.pre_sq;
+      pre_slot = SQ > 1 ? t / SQ : t;
+      sq = t - pre_slot * SQ;
+      sidx = a.pre_first + pre_slot;
+    }
     else if (strip_next >= a.pre_first && strip_next < a.pre_first + a.pre_n) { mode = 1; pre_slot = strip_next - a.pre_first; }
   }
   const int j0 = sidx * BN;
@@ -735,7 +742,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
   if (tid == 0) ticket[0] = a.dyn ? (a.pre_n > 0 ? 0 : (int)gridDim.x) + atomicAdd(a.dyn, 1) : strip_next + (int)gridDim.x;
   __syncthreads();   // (and the partial sums are read: the next strip's images may land on them)
   strip_next = __builtin_amdgcn_readfirstlane(ticket[0]);
-  if (strip_next >= a.n_strips + a.pre_n) break;
+  if (strip_next >= a.n_strips + a.pre_n * a.pre_sq) break;
   }
   if (threadIdx.x == 0) {
     if (cu_word >= 0) atomicSub(ap->cu_slots + cu_word, 1);
@@ -833,6 +840,51 @@ double deal_makespan(long strips, int slots, long n_pre, int R) {
   for (long i = 0; i < strips - rem - n_pre; ++i) give(F, 0.0);
   for (long i = 0; i < n_pre; ++i) give(C, ready[(size_t)i]);
   return end;
+}
+// Few strips (a rank's shard of a strongly-scaled batch: strips < 1.5 rounds of the CUs), every one handed over: `strips` prologue items first, then every
+// strip's outputs as SQ parts (part q: r = q, q + SQ, ...; a team of a part runs its outputs in turn) -- what sharing a strip between workgroups always wanted,
+// without re-paying sweep and first product per part.  Makespan of the counter's deal in the units of deal_makespan.
+double deal_makespan_parts(long strips, int slots, int SQ, int R, int NS) {
+  const double pro = 1.75, epi = 0.3, io = 0.2, P = pro + io;
+  std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+  for (int i = 0; i < slots; ++i) free_at.push(0.0);
+  std::vector<double> ready((size_t)strips, 0.0);
+  double end = 0.0;
+  auto give = [&](double cost, double not_before) {
+    double t = free_at.top();
+    free_at.pop();
+    if (t < not_before) t = not_before;
+    t += cost;
+    free_at.push(t);
+    if (t > end) end = t;
+    return t;
+  };
+  for (long i = 0; i < strips; ++i) ready[(size_t)i] = give(P, 0.0);
+  for (long i = 0; i < strips; ++i)
+    for (int q = 0; q < SQ; ++q) {
+      const int nr = q < R ? (R - 1 - q) / SQ + 1 : 0;
+      const double work = NS == 2 ? 2.0 * ((nr + 1) / 2) : (double)nr;   // (two teams: an output costs its team two units)
+      give(io + work + epi, ready[(size_t)i]);
+    }
+  return end;
+}
+// SQ for such a launch (0: not worth it / not wanted), given what the launch would cost without (`legacy_units`).
+// MEASURED (tools/parts_try.py, the 4 / 8 / 16-image shards of the headline batch): correct and bit-identical, and SLOWER than the launches it would replace at
+// every shard and every SQ -- 4 images 109 us (180 strips of 32 columns, one round) against 120-148 us as parts, 8 images 169 against 185-259, 16 images 303-308
+// against 302-421.  A part pays its ticket, the flag, the fetch of the strip, the mean product, two barriers of partial sums and the epilogue (~10 us) for 8-15 us of
+// second product; the simulated deal prices that at 0.5 of an output.  So the deal below never chooses parts by itself any more (fused_parts = -1 is "off"); the
+// form stays reachable through fused_parts = q for tests/test_gpu_ops.py and for a part that is made cheaper one day.
+int plan_parts(const dcgp_ctx* ctx, long strips, int slots, int R, int NS, double legacy_units) {
+  const long want = ctx->opt.fused_parts;   // -1 / 0: off, q > 0: this SQ; -2: chosen by the simulated deal (A/B)
+  if (want == 0 || want == -1 || R < 2 || strips <= 0 || 2 * strips > 3L * slots) return 0;
+  if (want > 0) return (int)std::min<long>(want, R);
+  double best = legacy_units * 0.9;   // a tenth better, or the plain launch stays
+  int best_q = 0;
+  for (int q = 2; q <= R; ++q) {
+    const double t = deal_makespan_parts(strips, slots, q, R, NS);
+    if (t < best - 1e-9) { best = t; best_q = q; }
+  }
+  return best_q;
 }
 // the number of prologues ahead for a persistent launch (0: none)
 long plan_prologues(const dcgp_ctx* ctx, long strips, int slots, int R) {
@@ -937,7 +989,17 @@ int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a_in) {
   // by a device counter to whichever workgroup is free 572 us at cfg2, dealt by a fixed stride 576 -- as many as one workgroup per strip takes
   // (profiles/r06_fused_ab.txt)
   const long want = ctx->opt.fused_persist;
-  const bool persist = per_cu >= 1 && strips > per_cu * n_cus && (want > 0 || (want < 0 && per_cu == 1 && p.split_q == 1 && !a.Kuf_out && !a.A1_out));
+  bool persist = per_cu >= 1 && strips > per_cu * n_cus && (want > 0 || (want < 0 && per_cu == 1 && p.split_q == 1 && !a.Kuf_out && !a.A1_out));
+  // few strips: all of them handed over, their outputs dealt as parts (deal_makespan_parts)
+  int parts_sq = 0;
+  if (!persist && per_cu == 1 && a.G && !a.Kuf_out && !a.A1_out && want != 0 && want != 2) {
+    const FusedShape& sh = kShapes[p.shape];
+    int q_legacy = 1;
+    const double last = last_round(ctx, sh, strips, a.R, true, &q_legacy);
+    const double legacy = ((double)(strips / n_cus) + (strips % n_cus ? last : 0.0)) * (1.75 + a.R + 0.3);
+    parts_sq = plan_parts(ctx, strips, n_cus, a.R, sh.NS, legacy);
+    if (parts_sq > 1) persist = true;
+  }
   if (persist) {
     a.persist = (int)(per_cu * n_cus);
     a.n_strips = (int)strips;
@@ -950,10 +1012,11 @@ int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a_in) {
     }
     if (per_cu == 1 && a.dyn && a.G) {
       const int TW = kShapes[p.shape].NT / 64 / kShapes[p.shape].NS, BN = kShapes[p.shape].FN * 16;
-      const long n_pre = plan_prologues(ctx, strips, a.persist, a.R);
+      const long n_pre = parts_sq > 1 ? strips : plan_prologues(ctx, strips, a.persist, a.R);
       if (n_pre > 0) {
         a.pre_n = (int)n_pre;
-        a.pre_first = (int)(strips % a.persist);
+        a.pre_first = parts_sq > 1 ? 0 : (int)(strips % a.persist);
+        a.pre_sq = parts_sq > 1 ? parts_sq : 1;
         a.pre_stride = (long)a.Mp * BN + (long)TW * BN;
         const std::string nb = "fused_pre_buf" + ctx->ws_tag, nf = "fused_pre_flag" + ctx->ws_tag;
         const size_t fbytes = (size_t)n_pre * sizeof(unsigned);

@@ -30,7 +30,7 @@ const OptSlot kOptSlots[] = {
     {"chain_graph", &DcgpOptions::chain_graph}, {"no_rhs_ride", &DcgpOptions::no_rhs_ride}, {"comm_inline", &DcgpOptions::comm_inline}, {"chain_no_iso", &DcgpOptions::chain_no_iso}, {"kuf_no_rep", &DcgpOptions::kuf_no_rep}, {"kuf_stream", &DcgpOptions::kuf_stream},
     {"kuf_wpg", &DcgpOptions::kuf_wpg}, {"kuf_split", &DcgpOptions::kuf_split}, {"head_tail", &DcgpOptions::head_tail},
     {"sweep_occ", &DcgpOptions::sweep_occ}, {"share_kb", &DcgpOptions::share_kb}, {"head_upw", &DcgpOptions::head_upw}, {"no_syrk", &DcgpOptions::no_syrk}, {"grad_dz_main", &DcgpOptions::grad_dz_main},
-    {"fused_persist", &DcgpOptions::fused_persist}, {"fused_stagger", &DcgpOptions::fused_stagger}, {"fused_pre", &DcgpOptions::fused_pre},
+    {"fused_persist", &DcgpOptions::fused_persist}, {"fused_stagger", &DcgpOptions::fused_stagger}, {"fused_pre", &DcgpOptions::fused_pre}, {"fused_parts", &DcgpOptions::fused_parts},
     {"fused_abl", &DcgpOptions::fused_abl}, {"rb_mixed", &DcgpOptions::rb_mixed},
 };
 }  // namespace

@@ -127,7 +127,9 @@ struct ConvFusedArgs {
   int* cu_slots = nullptr;                                 // [1024] arrival counters per CU (zero between launches: every workgroup gives its count back)
   // set by the launcher: prologues ahead (conv_fused.hip) -- pre_n strips from pre_first on get phases 0 - 2 from the spare workgroups of the partial FIRST
   // round, A1 handed over through pre_buf ([pre_n][pre_stride]: the strip's LDS image, then the partial sums of A1^2) behind pre_flag[slot] == pre_epoch
-  int pre_n = 0, pre_first = 0; long pre_stride = 0;
+  // pre_sq > 1 (a launch of few strips, all of them handed over: pre_first = 0, pre_n = n_strips): a handed-over strip is taken up by pre_sq items, part q
+  // running the outputs r = q, q + pre_sq, ... of the second product
+  int pre_n = 0, pre_first = 0, pre_sq = 1; long pre_stride = 0;
   double* pre_buf = nullptr; unsigned* pre_flag = nullptr; unsigned pre_epoch = 0;
 };
 // the reverse pass of the same strip (conv_bwd_fused.hip): dK_uf = inv(L)^T [sum_r (S_r A1) o (2 gv_r) + alpha gm^T - 2 A1 o gvs]

@@ -401,13 +401,41 @@ def test_fused_strip_shared_by_workgroups(ctx, shape, split, M, N, R):
     Z *= 1.5
     layer = ConvLayer(RBF(v.patch_length, 5.0, 5.0), None, PatchInducingFeatures(Z), v, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
     z = rng.standard_normal((N, layer.num_outputs))
-    with ctx.options(fused_shape=shape, fused_split=0):
+    with ctx.options(fused_shape=shape, fused_split=0, fused_parts=0):
         smp_w, mean_w, var_w = layer._forward(X, z)
-    with ctx.options(fused_shape=shape, fused_split=split):
+    with ctx.options(fused_shape=shape, fused_split=split, fused_parts=0):
         smp, mean, var = layer._forward(X, z)
     np.testing.assert_array_equal(mean, mean_w)
     np.testing.assert_array_equal(var, var_w)
     np.testing.assert_array_equal(smp, smp_w)
+
+
+@pytest.mark.parametrize("shape", [0, 7])
+@pytest.mark.parametrize("parts", [-2, 2, 3, 5, 10])
+@pytest.mark.parametrize("M,N,R", [(70, 3, 10), (256, 4, 10), (96, 2, 3)])
+def test_fused_strips_handed_over_and_dealt_as_parts(ctx, shape, parts, M, N, R):
+    """A layer of few strips (< 1.5 rounds of the CUs: a rank's shard): every strip's sweep + first product by one item of a persistent launch, A1 handed over
+    through memory, its outputs by `fused_parts` items that fetch it (part q: r = q, q + Q, ...; -2: Q chosen by the simulated deal; off by default: measured slower, tools/parts_try.py).  Same instructions on the
+    same operands as the whole-strip launch: bit-identical, also launch after launch (the counters and flag epochs of the hand-over)."""
+    from deepcgp_amd.kernels import RBF, PatchInducingFeatures
+    from deepcgp_amd.layers import ConvLayer
+    from deepcgp_amd.views import FullView
+    rng = np.random.default_rng(11 + M + parts)
+    H, W, C, f, s = 28, 28, 1, 5, 2
+    X = rng.standard_normal((N, H * W * C))
+    v = FullView((H, W), f, C, s)
+    Z, q_mu, q_sqrt = rand_spd_inputs(rng, M, R, v.patch_length, scale=0.05)
+    Z *= 1.5
+    layer = ConvLayer(RBF(v.patch_length, 5.0, 5.0), None, PatchInducingFeatures(Z), v, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
+    z = rng.standard_normal((N, layer.num_outputs))
+    with ctx.options(fused_shape=shape, fused_split=0, fused_parts=0):
+        smp_w, mean_w, var_w = layer._forward(X, z)
+    for _ in range(3):
+        with ctx.options(fused_shape=shape, fused_parts=parts):
+            smp, mean, var = layer._forward(X, z)
+        np.testing.assert_array_equal(mean, mean_w)
+        np.testing.assert_array_equal(var, var_w)
+        np.testing.assert_array_equal(smp, smp_w)
 
 
 def test_conv_layer_identity_mean(ctx):
