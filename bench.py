@@ -670,6 +670,14 @@ def main():
                     leg.barrier()
                     tim = ctx.timing()
                     ctx.timing_enable(0)
+                # ... and the same two launches inside the step as it runs (two streams: they share the chip, each one's events bracket the other's work too)
+                ctx.timing_enable(1)
+                ctx.timing_reset()
+                for i in range(min(n_g, 6)):
+                    cg(2000 + i)
+                leg.barrier()
+                tim_step = ctx.timing()
+                ctx.timing_enable(0)
                 c0 = cfg["convs"][0]
                 P0 = ((cfg["hwc"][0] - c0[0]) // c0[1] + 1) * ((cfg["hwc"][1] - c0[0]) // c0[1] + 1)
                 Kc, M, R = leg.local_batch * S * P0, cfg["M"], c0[2]
@@ -679,12 +687,22 @@ def main():
                 if tb and tw and tb[0] and tw[0]:
                     us_b, us_w = 1e3 * tb[1] / tb[0], 1e3 * tw[1] / tw[0]
                     ach = (f_bwd + f_wr) / ((us_b + us_w) * 1e-6) / 1e12
+                    in_step = None
+                    sb, sw = tim_step.get("conv_bwd_fused"), tim_step.get("grad_wr")
+                    if sb and sw and sb[0] and sw[0]:
+                        ub, uw = 1e3 * sb[1] / sb[0], 1e3 * sw[1] / sw[0]
+                        in_step = {"conv_bwd_fused_avg_us": ub, "w_r_contraction_avg_us": uw,
+                                   "frac_if_fully_overlapped": (f_bwd + f_wr) / (max(ub, uw) * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                   "frac_if_one_after_the_other": (f_bwd + f_wr) / ((ub + uw) * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                   "note": "the two launches as the training step runs them, beside each other on two streams: each one's HIP events bracket "
+                                           "part of the other's work, so the pair's share of the peak lies between the two figures"}
                     g["roofline_train"] = {"kernel": "conv_bwd_fused_kernel + syrk_kscale_kernel (W_r = 2 A1 diag(gv_r) A1^T, with its split-k reduction): the reverse pass's products of the first conv layer",
                                            "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                                            "traffic": None, "algorithmic_flops": f_bwd + f_wr,
                                            "conv_bwd_fused": {"avg_us": us_b, "flops": f_bwd, "tflops": f_bwd / us_b / 1e6},
                                            "w_r_contraction": {"avg_us": us_w, "flops": f_wr, "tflops": f_wr / us_w / 1e6},
                                            "launches_sampled": int(tb[0]),
+                                           "in_step": in_step,
                                            "note": "flops: (2 R + 1) M^2 K + R M^2 K (symmetric / triangular products counted as M^2 per column, as SURVEY 8(d) "
                                                    "counts the forward's); times: HIP events around each launch with the reverse pass on one stream (ctx option "
                                                    "grad_nofork), i.e. each kernel alone on the chip; in the step they overlap on two streams"}
