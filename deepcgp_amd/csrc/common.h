@@ -44,6 +44,7 @@ struct DcgpOptions {
                                  // (-1, 0: never -- measured slower at every shard, conv_fused.hip: plan_parts; q > 0: this many parts; -2: q by the simulated deal)
   long fused_stagger = -1;       // persistent layer kernel: microseconds the second workgroup of a CU holds back (-1: default; 0: none)
   long kl_side = 0;              // KL terms by their own launches on the side stream instead of inside the tail launch
+  long sweep_no_rows = 0;        // long-patch sweeps (5 x 5 x 10 patches) on the generic streamed loop instead of the patch-row form (A/B)
   long kl_no_ride = 0;           // KL pieces in the tail launch even where the head's one-launch conditional could carry them (A/B)
   long no_fused_bwd = 0;         // reverse pass of the conditional by GEMM launches instead of the strip kernel
   long fused_bwd_min_cols = -1;  // strip kernel of the reverse pass from this many columns on (-1: default 4096)

@@ -21,7 +21,7 @@ namespace {
 struct OptSlot { const char* name; long DcgpOptions::*field; };
 const OptSlot kOptSlots[] = {
     {"no_fused_layer", &DcgpOptions::no_fused_layer}, {"fused_large", &DcgpOptions::fused_large}, {"fused_shape", &DcgpOptions::fused_shape}, {"fused_split", &DcgpOptions::fused_split},
-    {"kl_side", &DcgpOptions::kl_side}, {"kl_no_ride", &DcgpOptions::kl_no_ride}, {"no_fused_bwd", &DcgpOptions::no_fused_bwd}, {"fused_bwd_min_cols", &DcgpOptions::fused_bwd_min_cols},
+    {"kl_side", &DcgpOptions::kl_side}, {"kl_no_ride", &DcgpOptions::kl_no_ride}, {"sweep_no_rows", &DcgpOptions::sweep_no_rows}, {"no_fused_bwd", &DcgpOptions::no_fused_bwd}, {"fused_bwd_min_cols", &DcgpOptions::fused_bwd_min_cols},
     {"fused_bwd_frags", &DcgpOptions::fused_bwd_frags}, {"grad_late_kl", &DcgpOptions::grad_late_kl}, {"gemm_tile", &DcgpOptions::gemm_tile}, {"grad_no_keep_k", &DcgpOptions::grad_no_keep_k},
     {"head_unfused", &DcgpOptions::head_unfused}, {"no_side_stream", &DcgpOptions::no_side_stream}, {"cu_partition", &DcgpOptions::cu_partition},
     {"grad_nofork", &DcgpOptions::grad_nofork}, {"chol_one_launch", &DcgpOptions::chol_one_launch},

@@ -70,6 +70,13 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
   constexpr int WPG = NT / 64;   // units (waves) per workgroup
   constexpr bool RES = NK4 > 0;
   constexpr int NKR = RES ? NK4 : 1;
+  // Streamed form with TL > 0 (<0, RW, ...>): the patch is f rows of RW = f C contiguous image elements, RW = 4 n + 2 and f odd (5 x 5 x 10: RW = 50, L = 250 --
+  // every long patch of the BASELINE configurations).  Lane group lrow's element of sub-step s, k = 4 s + lrow, then walks a patch row at +32 bytes per sub-step:
+  // the gathers of a row's n aligned sub-steps are `ds_read_b64 ... offset: 32 i` on ONE per-lane address per fragment and row, two rows and the sub-step that
+  // straddles them are a period of 2 n + 1 sub-steps, and the loop is straight-line code per period.  The generic streamed loop spends 33 VALU instructions per 16
+  // MFMAs on its operands' way (16 gather addresses, 4 offset-table addresses, 11 ring moves: ISA count) and issues at ~75 % of the MFMA rate with four waves per
+  // SIMD (profiles/r06_head_packed_trace.txt); this one ~3 per period of 100.
+  constexpr int RW = RES ? 0 : TL;
   // Register-resident forms: the k slots are dealt so that lane group lrow walks RL CONTIGUOUS patch elements RL lrow .. RL lrow + RL - 1 in
   // sub-steps 0 .. RL - 1 (L = 25: RL = 5, f * C is 5 or 25; L = 16: RL = 4; L = 48: RL = 12 -- RL consecutive elements never straddle a patch
   // row), then what is left in the old order (L = 25: elements 20 + lrow in sub-step 5, 24 and the norm slots in sub-step 6).  The gathers of
@@ -258,8 +265,10 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
   // before the MFMAs of the current one), then 2^t and the weighted row sums.  getA(s): the A operand of sub-step s.
   // `pre`: the caller has already put this group's patch offsets into pb and its sub-step-0 operands into bv (requested
   // before the previous group's epilogue); next_j0 >= 0: do the same for the group that follows.
-  auto group = [&](auto ny_tag, auto&& getA, auto&& getA_raw, int j0, int next_j0, int nyn, double* rdiag, double (&rsum)[4], int (&pb)[4], double (&bv)[4]) {
+  int kd_pa = 0;   // a row pass of the patch Gram matrix (kd_tag true): LDS byte offset of the row patch's first element (the A operand is gathered like the B ones)
+  auto group = [&](auto kd_tag, auto ny_tag, auto&& getA, auto&& getA_raw, int j0, int next_j0, int nyn, double* rdiag, double (&rsum)[4], int (&pb)[4], double (&bv)[4]) {
     constexpr int NY = decltype(ny_tag)::value;
+    constexpr bool KD = decltype(kd_tag)::value;
     d4 acc[NY];
 #pragma unroll
     for (int y = 0; y < NY; ++y) acc[y] = d4{0.0, 0.0, 0.0, 0.0};
@@ -285,6 +294,77 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
           for (int y = 0; y < NY; ++y) bv[y] = bn[y];
         }
         __builtin_amdgcn_sched_barrier(0);   // one sub-step of prefetch, not all of them (the scheduler would hoist every gather: 56 registers)
+      }
+    } else if constexpr (RW > 0) {
+      static_assert(RW % 4 == 2, "patch rows of 4 n + 2 elements: two rows and the sub-step that straddles them are a period of 2 n + 1 sub-steps");
+      constexpr int NA = RW / 4, DA = 5;        // aligned sub-steps per patch row; A-operand sub-steps in flight (Kzx: from global memory)
+      static_assert((2 * NA + 1) % DA == 0, "the ring of A operands closes over a period");
+      const int RS = a.W * a.C * 8;             // bytes from one patch row to the next in the image
+      const int sdl = lrow < 2 ? NA * 32 : RS - 16;   // the straddling sub-step: lane groups 0, 1 end the row, 2, 3 open the next one
+      int pA[NY], pS[NY], pB[NY];
+#pragma unroll
+      for (int y = 0; y < NY; ++y) pA[y] = pb[y] + lrow * 8;
+      int qA = KD ? kd_pa + lrow * 8 : 0, qS = 0, qB = 0;
+      double aq[DA], akd = 0.0;
+      int sc = 0;                               // sub-steps done (the Kzx A operand's scalar offset)
+      if (KD) {
+        akd = ldi(qA);
+      } else {
+#pragma unroll
+        for (int u = 0; u < DA; ++u) aq[u] = getA_raw(min(u, nk4 - 1), 0);
+      }
+      // one sub-step: the gathers of the NEXT one (addresses nx / qn, offset off) go out before this one's MFMAs
+      auto one = [&](int SL, const int (&nx)[NY], int qn, int off, bool more) __attribute__((always_inline)) {   // (SL, off: constants once the callers' loops are unrolled)
+        double bn[NY], an = 0.0;
+        if (more) {
+#pragma unroll
+          for (int y = 0; y < NY; ++y) bn[y] = ldi(nx[y] + off);
+          if (KD) an = ldi(qn + off);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const double av = KD ? akd : aq[SL];
+#pragma unroll
+        for (int y = 0; y < NY; ++y) acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[y], acc[y], 0, 0, 0);
+        if (more) {
+#pragma unroll
+          for (int y = 0; y < NY; ++y) bv[y] = bn[y];
+        }
+        if (KD) akd = an;
+        else aq[SL] = getA_raw(min(sc + DA, nk4 - 1), 0);
+        ++sc;
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // the NA aligned sub-steps of a patch row at `base` (BLK: the ring slot of its first sub-step); `after`: what follows the row
+      auto row_block = [&](int BLK, const int (&base)[NY], int qbase, const int (&after)[NY], int qafter) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          if (i + 1 < NA) one((BLK + i) % DA, base, qbase, 32 * (i + 1), true);
+          else one((BLK + i) % DA, after, qafter, 0, true);
+        }
+      };
+      const int nper = (a.f - 1) >> 1;
+      for (int t = 0; t < nper; ++t) {
+#pragma unroll
+        for (int y = 0; y < NY; ++y) { pS[y] = pA[y] + sdl; pB[y] = pA[y] + (RS + 16); }
+        if (KD) { qS = qA + sdl; qB = qA + (RS + 16); }
+        row_block(0, pA, qA, pS, qS);
+        one(NA % DA, pB, qB, 0, true);               // the straddling sub-step
+#pragma unroll
+        for (int y = 0; y < NY; ++y) pA[y] += 2 * RS;
+        if (KD) qA += 2 * RS;
+        row_block((NA + 1) % DA, pB, qB, pA, qA);
+      }
+      // the last row and the sub-step that carries its last two elements and the two norm slots (lane groups 2, 3 gather the patch's first element: finite, unused)
+#pragma unroll
+      for (int y = 0; y < NY; ++y) pS[y] = lrow < 2 ? pA[y] + NA * 32 : pb[y];
+      row_block(0, pA, qA, pS, qA);
+      {
+        const int sl = nk4 - 1;
+        const double av = KD ? getA(sl) : aq[NA % DA];
+#pragma unroll
+        for (int y = 0; y < NY; ++y) bv[y] = fixB(bv[y], sl, xbv(y));
+#pragma unroll
+        for (int y = 0; y < NY; ++y) acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[y], acc[y], 0, 0, 0);
       }
     } else {
       // Sub-steps [0, sL) hold patch elements only.  They go in chunks of 4: the A operands (global memory for Kzx) and the patch-element
@@ -423,7 +503,7 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
 
   // one row fragment against column fragments [j_lo, j_hi): groups of four, then one group of the remaining 1..3.
   // rdiag != nullptr: receives the share of the first fragment (the diagonal tile of a Kdiag row; rsum must start at zero)
-  auto row_pass = [&](auto&& getA, auto&& getA_raw, int j_lo, int j_hi, double* rdiag, double (&rsum)[4]) {
+  auto row_pass = [&](auto kd_tag, auto&& getA, auto&& getA_raw, int j_lo, int j_hi, double* rdiag, double (&rsum)[4]) {
     const int nfull = (j_hi - j_lo) >> 2, nrem = (j_hi - j_lo) & 3;
     int pb[4];
     double bv[4];
@@ -432,11 +512,11 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
     for (int y = 0; y < 4; ++y) {
       if (y < (nfull ? 4 : nrem)) { pb[y] = pbx(j0 + y); bv[y] = ld0(pb[y]); }
     }
-    for (int g = 0; g < nfull; ++g, j0 += 4) group(T4{}, getA, getA_raw, j0, j0 + 4, g + 1 < nfull ? 4 : nrem, g == 0 ? rdiag : nullptr, rsum, pb, bv);
+    for (int g = 0; g < nfull; ++g, j0 += 4) group(kd_tag, T4{}, getA, getA_raw, j0, j0 + 4, g + 1 < nfull ? 4 : nrem, g == 0 ? rdiag : nullptr, rsum, pb, bv);
     double* rd = nfull == 0 ? rdiag : nullptr;
-    if (nrem == 1) group(T1{}, getA, getA_raw, j0, -1, 0, rd, rsum, pb, bv);
-    else if (nrem == 2) group(T2{}, getA, getA_raw, j0, -1, 0, rd, rsum, pb, bv);
-    else if (nrem == 3) group(T3{}, getA, getA_raw, j0, -1, 0, rd, rsum, pb, bv);
+    if (nrem == 1) group(kd_tag, T1{}, getA, getA_raw, j0, -1, 0, rd, rsum, pb, bv);
+    else if (nrem == 2) group(kd_tag, T2{}, getA, getA_raw, j0, -1, 0, rd, rsum, pb, bv);
+    else if (nrem == 3) group(kd_tag, T3{}, getA, getA_raw, j0, -1, 0, rd, rsum, pb, bv);
   };
 
   // storing form with replicas: the row fragment's tiles in batches of up to 8, each batch evaluated into registers and then stored
@@ -455,14 +535,14 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
       for (int y = 0; y < 4; ++y) {
         if (y < n0) { pb[y] = pbx(jb + y); bv[y] = ld0(pb[y]); }
       }
-      if (n0 == 4) group(T4{}, getA, getA_raw, jb, jb + 4, n1, keep, dummy, pb, bv);
-      else if (n0 == 3) group(T3{}, getA, getA_raw, jb, -1, 0, keep, dummy, pb, bv);
-      else if (n0 == 2) group(T2{}, getA, getA_raw, jb, -1, 0, keep, dummy, pb, bv);
-      else group(T1{}, getA, getA_raw, jb, -1, 0, keep, dummy, pb, bv);
-      if (n1 == 4) group(T4{}, getA, getA_raw, jb + 4, -1, 0, keep + 16, dummy, pb, bv);
-      else if (n1 == 3) group(T3{}, getA, getA_raw, jb + 4, -1, 0, keep + 16, dummy, pb, bv);
-      else if (n1 == 2) group(T2{}, getA, getA_raw, jb + 4, -1, 0, keep + 16, dummy, pb, bv);
-      else if (n1 == 1) group(T1{}, getA, getA_raw, jb + 4, -1, 0, keep + 16, dummy, pb, bv);
+      if (n0 == 4) group(std::false_type{}, T4{}, getA, getA_raw, jb, jb + 4, n1, keep, dummy, pb, bv);
+      else if (n0 == 3) group(std::false_type{}, T3{}, getA, getA_raw, jb, -1, 0, keep, dummy, pb, bv);
+      else if (n0 == 2) group(std::false_type{}, T2{}, getA, getA_raw, jb, -1, 0, keep, dummy, pb, bv);
+      else group(std::false_type{}, T1{}, getA, getA_raw, jb, -1, 0, keep, dummy, pb, bv);
+      if (n1 == 4) group(std::false_type{}, T4{}, getA, getA_raw, jb + 4, -1, 0, keep + 16, dummy, pb, bv);
+      else if (n1 == 3) group(std::false_type{}, T3{}, getA, getA_raw, jb + 4, -1, 0, keep + 16, dummy, pb, bv);
+      else if (n1 == 2) group(std::false_type{}, T2{}, getA, getA_raw, jb + 4, -1, 0, keep + 16, dummy, pb, bv);
+      else if (n1 == 1) group(std::false_type{}, T1{}, getA, getA_raw, jb + 4, -1, 0, keep + 16, dummy, pb, bv);
       int so_r = jb * a.st_jb;
       for (int r = 0; r < st_nrep; ++r, so_r += a.st_rb) {
 #pragma unroll
@@ -522,10 +602,10 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
 #pragma unroll
       for (int s = 0; s < NKR; ++s) areg[s] = ldz(s);
       if (WMODE == 2 && st_hold) row_pass_hold([&](int s) { return areg[s]; }, [&](int s, int) { return areg[RES ? s : 0]; }, uj_lo, uj_hi);
-      else row_pass([&](int s) { return areg[s]; }, [&](int s, int) { return areg[RES ? s : 0]; }, uj_lo, uj_hi, nullptr, rsum);
+      else row_pass(std::false_type{}, [&](int s) { return areg[s]; }, [&](int s, int) { return areg[RES ? s : 0]; }, uj_lo, uj_hi, nullptr, rsum);
     } else {
       if (WMODE == 2 && st_hold) row_pass_hold([&](int s) { return ldz(s); }, [&](int s, int) { return ldz(s); }, uj_lo, uj_hi);
-      else row_pass([&](int s) { return ldz(s); }, [&](int s, int) { return ldz(s); }, uj_lo, uj_hi, nullptr, rsum);
+      else row_pass(std::false_type{}, [&](int s) { return ldz(s); }, [&](int s, int) { return ldz(s); }, uj_lo, uj_hi, nullptr, rsum);
     }
     if (!WRITE) {
 #pragma unroll
@@ -567,9 +647,10 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
         double areg[NKR];
 #pragma unroll
         for (int s = 0; s < NKR; ++s) areg[s] = getA_img(s, kob[s]);
-        row_pass([&](int s) { return areg[s]; }, [&](int s, int) { return areg[RES ? s : 0]; }, j_lo, j_hi, rd, rsum);
+        row_pass(std::true_type{}, [&](int s) { return areg[s]; }, [&](int s, int) { return areg[RES ? s : 0]; }, j_lo, j_hi, rd, rsum);
       } else {
-        row_pass([&](int s) { return getA_img(s, koff[4 * s + lrow]); }, [&](int, int ko) { return ldi(pa + ko); }, j_lo, j_hi, rd, rsum);
+        kd_pa = pa;
+        row_pass(std::true_type{}, [&](int s) { return getA_img(s, koff[4 * s + lrow]); }, [&](int, int ko) { return ldi(pa + ko); }, j_lo, j_hi, rd, rsum);
       }
 #pragma unroll
       for (int v = 0; v < 4; ++v) total = fma(wl[16 * fr + lrow + 4 * v], 2.0 * rsum[v] - rdiag[v], total);   // off-diagonal tiles count twice
@@ -785,6 +866,8 @@ int head_units(dcgp_ctx* ctx, const HeadUnitsArgs& a_in) {
     const size_t claim = (size_t)(160 * 1024 / per_cu) & ~(size_t)255;
     if (claim <= 64 * 1024 && lds < claim) lds = claim;
   }
+  // patch rows of 50 contiguous elements, an odd number of them (5 x 5 x 10): the patch-row form of the streamed loop (kernel: RW); ctx option sweep_no_rows: A/B
+  const bool rw50 = a.f * a.C == 50 && (a.f & 1) && a.L == a.f * a.f * a.C && !ctx->opt.sweep_no_rows;
   ScopedTimer t(ctx, family);
   if (a.kuf) {
     // patch lengths of the first layers (5 x 5 x 1, 4 x 4 x 1, 4 x 4 x 3: MNIST / CIFAR conv0) with the row operand resident in registers
@@ -802,15 +885,21 @@ int head_units(dcgp_ctx* ctx, const HeadUnitsArgs& a_in) {
     if (a.L == 25 && !a.stream_k) HU_STORE(7, 1);
     else if (a.L == 16 && !a.stream_k) HU_STORE(5, 0);
     else if (a.L == 48 && !a.stream_k) HU_STORE(13, 0);
+    else if (rw50) HU_STORE(0, 50);
     else HU_STORE(0, 0);
 #undef HU_STORE
 #undef HU_STORE_W
   } else if (a.kfull) {   // a training step's head: the reducing form that also leaves every kernel value behind
     if (a.L == 25) hipLaunchKernelGGL((head_units_kernel<7, 1, 3, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
+    else if (rw50 && a.wpg == 4) hipLaunchKernelGGL((head_units_kernel<0, 50, 3, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
+    else if (rw50) hipLaunchKernelGGL((head_units_kernel<0, 50, 3, 128>), dim3((unsigned)nwg), dim3(128), lds, ctx->stream, a);
     else if (a.wpg == 4) hipLaunchKernelGGL((head_units_kernel<0, 0, 3, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
     else hipLaunchKernelGGL((head_units_kernel<0, 0, 3, 128>), dim3((unsigned)nwg), dim3(128), lds, ctx->stream, a);
   } else if (a.L == 25) {
     hipLaunchKernelGGL((head_units_kernel<7, 1, 0, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);   // 5 x 5 x 1 patches
+  } else if (rw50) {   // 5 x 5 x 10 patches (every long patch of the BASELINE configurations): the streamed form walking patch rows
+    if (a.wpg == 4) hipLaunchKernelGGL((head_units_kernel<0, 50, 0, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((head_units_kernel<0, 50, 0, 128>), dim3((unsigned)nwg), dim3(128), lds, ctx->stream, a);
   } else if (a.wpg == 4) {
     hipLaunchKernelGGL((head_units_kernel<0, 0, 0, 256>), dim3((unsigned)nwg), dim3(256), lds, ctx->stream, a);
   } else {

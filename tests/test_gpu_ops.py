@@ -605,6 +605,33 @@ def test_head_unit_sweep(ctx, H, W, C, f, s, M, N):
         close(k.Kdiag(X), okk.Kdiag(X), 1e-11, "Kdiag")
 
 
+@pytest.mark.parametrize("H,W,M,N", [(12, 12, 256, 5), (13, 11, 33, 4), (9, 9, 48, 3), (5, 5, 20, 6)])
+def test_patch_row_form_of_the_long_patch_sweeps_is_bit_identical(ctx, H, W, M, N):
+    """5 x 5 x 10 patches (every long patch of the BASELINE configurations) take the streamed sweep in its patch-row form (csrc/head_units.hip, RW: the gathers
+    of a patch row are one per-lane address + immediates, the k loop straight-line code per two rows); the ctx option sweep_no_rows keeps the generic streamed
+    loop.  Same operands into the same MFMAs in the same order: Kzx, Kdiag and the stored K_uf are bit-identical, and equal to the oracle's."""
+    from deepcgp_amd.kernels import RBF, ConvKernel
+    from deepcgp_amd.layers import MultiOutputConvKernel
+    from deepcgp_amd.views import FullView
+    rng = np.random.default_rng(3 * M + H)
+    C, f, s = 10, 5, 1
+    X = rng.standard_normal((N, H * W * C))
+    v, ov = FullView((H, W, C), f, C, s), OFullView((H, W, C), f, C, s)
+    w = rng.standard_normal(v.patch_count)
+    Z = rng.standard_normal((M, v.patch_length)) * 0.5
+    k, okk = ConvKernel(RBF(v.patch_length, 2.0, 7.0), v, w), OConvKernel(ORBF(v.patch_length, 2.0, 7.0), ov, w)
+    mok = MultiOutputConvKernel(RBF(v.patch_length, 2.0, 7.0), H * W * C, v.patch_count)
+    Xi = X.reshape(N, H, W, C)
+    got = (k.Kzx(Z, X), k.Kdiag(X), mok.Kuf(Z, (Xi, v)))
+    with ctx.options(sweep_no_rows=1):
+        old = (k.Kzx(Z, X), k.Kdiag(X), mok.Kuf(Z, (Xi, v)))
+    for g, o in zip(got, old):
+        np.testing.assert_array_equal(g, o)
+    close(got[0], okk.Kzx(Z, X), 1e-11, "Kzx")
+    close(got[1], okk.Kdiag(X), 1e-11, "Kdiag")
+    close(got[2], OMOK(ORBF(v.patch_length, 2.0, 7.0), H * W * C, v.patch_count).Kuf(Z, ov.extract_patches_PNL(Xi)), 1e-12, "Kuf")
+
+
 def test_head_unit_sweep_exp_accuracy(ctx):
     """The unit sweep's 2^t (magic-number split + degree-11 minimax polynomial + ldexp) value by value: one patch per image
     (P = 1, weight 1), one inducing patch at the origin, so Kzx[0, n] = variance * exp(-|x_n|^2 / (2 l^2)).  The exponent reaches the
