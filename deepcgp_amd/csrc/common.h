@@ -277,6 +277,45 @@ __device__ __forceinline__ void exp2_n(double (&t)[N]) {
   for (int i = 0; i < N; ++i) t[i] = __builtin_amdgcn_ldexp(p[i], __double2loint(u[i]));
 }
 
+// 2^t through a table of 2^(j / 256) (256 doubles in LDS, gauss... see exp2_table()): t = n + j / 256 + r with |r| <= 2^-9 by the same magic-number split (the
+// low mantissa word of t + 1.5 * 2^44 is round(256 t)), 2^r - 1 by a degree-4 polynomial (|remainder| < 4e-17), 2^t = ldexp(T_j + T_j (2^r - 1), n):
+// 13 VALU instructions and one LDS read per value against the 16 of exp2_n -- the patch sweeps of short patches are bound by this epilogue (68 of a tile's
+// ~90 VALU instructions beside 7 MFMAs, and VALU instructions issue in the fp64 MFMA's place on this part).  Relative error <= ~1.5 ulp.
+constexpr double kExp2Magic8 = 26388279066624.0;   // 1.5 * 2^44
+template <int N>
+__device__ __forceinline__ void exp2_tab_n(double (&t)[N], const double* tab /* LDS, [256] */) {
+  double u[N], r[N], h[N], T[N];
+  int k[N];
+  const double lo = -1100.0, magic = kExp2Magic8;
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm("v_max_f64 %0, %1, %2" : "=v"(t[i]) : "v"(t[i]), "s"(lo));
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm("v_add_f64 %0, %1, %2" : "=v"(u[i]) : "v"(t[i]), "s"(magic));
+#pragma unroll
+  for (int i = 0; i < N; ++i) k[i] = __double2loint(u[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) T[i] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tab) + ((k[i] << 3) & 0x7f8));
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm("v_add_f64 %0, %1, -%2" : "=v"(r[i]) : "v"(u[i]), "s"(magic));   // rint(256 t) / 256
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm("v_add_f64 %0, %1, -%2" : "=v"(r[i]) : "v"(t[i]), "v"(r[i]));     // |r| <= 2^-9
+  double c4 = 0.0096181291076284772;   // ln(2)^4 / 24
+  asm("" : "+v"(c4));
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(h[i]) : "v"(c4), "v"(r[i]), "s"(0.055504108664821580));   // ln(2)^3 / 6
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(h[i]) : "v"(h[i]), "v"(r[i]), "s"(0.24022650695910072));   // ln(2)^2 / 2
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(h[i]) : "v"(h[i]), "v"(r[i]), "s"(0.69314718055994531));    // ln(2)
+#pragma unroll
+  for (int i = 0; i < N; ++i) h[i] *= r[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) h[i] = fma(T[i], h[i], T[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) t[i] = __builtin_amdgcn_ldexp(h[i], k[i] >> 8);
+}
+const double* exp2_table(struct dcgp_ctx* ctx);   // device: 2^(j / 256), j < 256 (ctx.hip)
+
 // The base kernel of a layer, evaluated from (x.z, |x|^2, |z|^2):
 //   type 0  gpflow RBF:           variance * exp(-(|x|^2 + |z|^2 - 2 x.z) / (2 l^2))     p1 = 1 / l^2 (square_dist form, no clamp)
 //   type 1  gpflow ArcCosine(0):  variance * (pi - theta) / pi,  theta = acos(1e-15 + (1 - 2e-15) cos),
@@ -362,6 +401,7 @@ struct HeadUnitsArgs {
   int share_kb = 0;                                        // A/B: LDS claimed per workgroup beside the factorisation chain, KB (0: 54 = two workgroups per CU)
   int occ_force = -1;                                      // A/B: waves per SIMD the launch is held to through its LDS claim (-1: chosen; 0: no shaping)
   int occ = 0;                                             // chosen by head_units_plan (0: none)
+  const double* exp_tab = nullptr;                         // 2^(j / 256) (exp2_table): staged in LDS by every workgroup
   int tail_mode = -1;                                      // balance of the launch's tail (-1: default levels; 0: equal Kdiag chunks throughout)
   int nfm = 0, nfp = 0, n_kd = 0, upw = 1, wpg = 4;        // set by head_units_plan (call it with kzx / want_kd / kuf already set)
   int nseg = 0; HuSeg seg[6]; long n_wgs = 0;              // the launch's segments and its workgroup count (head_units_plan)

@@ -380,3 +380,17 @@ long col_ld(long columns) {
   return round_up_l(columns, 128);
 #endif
 }
+
+
+// 2^(j / 256), j < 256, for exp2_tab_n (common.h): one workspace per ctx, filled on first use
+const double* exp2_table(dcgp_ctx* ctx) {
+  auto it = ctx->ws.find("exp2_tab256");
+  if (it != ctx->ws.end()) return (const double*)it->second.first;
+  double* d = (double*)ws_get(ctx, "exp2_tab256", 256 * sizeof(double));
+  if (!d) return nullptr;
+  double h[256];
+  for (int j = 0; j < 256; ++j) h[j] = exp2((double)j / 256.0);
+  hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream);
+  hipStreamSynchronize(ctx->stream);
+  return d;
+}

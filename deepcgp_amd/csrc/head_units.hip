@@ -63,7 +63,9 @@ __device__ __forceinline__ int fdiv_small(int i, float inv_d) { return (int)(((f
 // attempt are gone: slower everywhere -- cfg2 conv + head +27 us, cfg1 +26 -- a finished wave of a persistent workgroup idles until its workgroup is done,
 // in the plain launch its slot goes to the next workgroup at once.)
 template <int NK4, int TL, int WMODE, int NT>
-__global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 3 : HU_WAVES)) void head_units_kernel(HeadUnitsArgs a_in) {
+// (aligned(4096): the streamed forms are 40-50 KB of mostly straight-line code and their speed depends on where the code object puts them -- the same binary of the
+// 5 x 5 x 10 head's sweep measured 70.7-71.9 us at one 256-byte-aligned address and 67.7-68.2 at another; page-aligned it is the latter wherever it lands)
+__global__ __attribute__((aligned(4096))) __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 3 : HU_WAVES)) void head_units_kernel(HeadUnitsArgs a_in) {
   const __attribute__((address_space(4))) HeadUnitsArgs& a = *(const __attribute__((address_space(4))) HeadUnitsArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr bool WRITE = WMODE == 1 || WMODE == 2;
   constexpr bool KEEP = WMODE == 3;
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
   double* rs = wl + np16;                               // [H * Wr] row sums of squares (set-up only)
   int* pbl = reinterpret_cast<int*>(rs + ((a.H * (a.W - a.f + 1) + 1) & ~1));   // [np16]  byte offset of the patch's first element in img
   int* koff = pbl + np16;                               // [Lq]    byte offset of patch element l
+  double* etab = reinterpret_cast<double*>(koff + ((a.Lq + 1) & ~1));   // [256]  2^(j / 256) (exp2_tab_n)
   const char* imgb = reinterpret_cast<const char*>(img);
   const int tid = threadIdx.x, lane = tid & 63, lrow = lane >> 4, lcol = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,6 +138,8 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
       const int i = e * NT + tid;
       t[e] = (i < HWC) ? Xn[i] : 0.0;
     }
+    if (RES)
+      for (int i = tid; i < 256; i += NT) etab[i] = a.exp_tab[i];
     for (int l = tid; l < a.Lq; l += NT) {
       const int ll = l < L ? l : 0;
       const int tq = fdiv_small(ll, a.inv_C), c = ll - tq * a.C;
@@ -355,6 +360,8 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
         row_block((NA + 1) % DA, pB, qB, pA, qA);
       }
       // the last row and the sub-step that carries its last two elements and the two norm slots (lane groups 2, 3 gather the patch's first element: finite, unused)
+      // (the last row as a pass of the loop above -- one copy of the row block's code, a third less of it -- measured 66 -> 77-80 us at the 12 x 12 x 10 head: the
+      // selects and the early exit cost the schedule more than the instruction cache gains)
 #pragma unroll
       for (int y = 0; y < NY; ++y) pS[y] = lrow < 2 ? pA[y] + NA * 32 : pb[y];
       row_block(0, pA, qA, pS, qA);
@@ -445,7 +452,15 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
       for (int y = 0; y < YE; ++y)
 #pragma unroll
         for (int v = 0; v < 4; ++v) t[4 * y + v] = acc[y0 + y][v];
+      // short patches (register-resident forms): the epilogue is most of a tile's issue slots -- the table form of 2^t (13 VALU instructions + one LDS read per
+      // value against 16: MNIST head 114.6 -> ~110 us at M = 32, cfg5 head-only 1.923 -> 1.878 ms); long patches are bound by their MFMAs and keep the polynomial
+      // (the table's reads and its staging cost the 12 x 12 x 10 head's sweep 3 us)
+#ifdef HU_EXP_POLY
       exp2_n<4 * YE>(t);
+#else
+      if constexpr (RES) exp2_tab_n<4 * YE>(t, etab);
+      else exp2_n<4 * YE>(t);
+#endif
       if (WRITE) {   // rows m = 16 u + lrow + 4 v, 16 consecutive patches per row: 128-byte segments when sP == 1
 #pragma unroll
         for (int y = 0; y < YE; ++y) {
@@ -674,7 +689,8 @@ __global__ __launch_bounds__(NT, WMODE == 2 ? 2 : ((WMODE == 1 || WMODE == 3) ? 
 
 static size_t head_units_lds(const HeadUnitsArgs& a) {
   return (size_t)(((a.HWC + 1) & ~1) + 2 * a.nfp * 16 + ((a.H * (a.W - a.f + 1) + 1) & ~1)) * sizeof(double) +
-         (size_t)(a.nfp * 16 + a.Lq) * sizeof(int);
+         (size_t)(a.nfp * 16 + ((a.Lq + 1) & ~1)) * sizeof(int) +
+         (((a.L == 25 || a.L == 16 || a.L == 48) && !a.stream_k) ? 256 * sizeof(double) : 0);   // the register-resident forms' table of 2^(j / 256)
 }
 
 bool head_units_ok(const HeadUnitsArgs& a) {
@@ -845,6 +861,8 @@ int head_units(dcgp_ctx* ctx, const HeadUnitsArgs& a_in) {
   const char* family = a.timer ? a.timer : (a.kuf ? "kuf" : "head_sweep");
   if (ctx->sweep_trace && (ctx->sweep_trace_family.empty() || ctx->sweep_trace_family == family)) { a.trace = ctx->sweep_trace; a.trace_wgs = ctx->sweep_trace_wgs; }
   if (a.N <= 0) return DCGP_OK;
+  a.exp_tab = exp2_table(ctx);
+  if (!a.exp_tab) return DCGP_ERR_ALLOC;
   if (a.want_kd && !a.kd) return ctx_fail(ctx, DCGP_ERR_ARG, "head_units: Kdiag partial sums wanted but no buffer (allocate kd [N][n_kd] behind head_units_plan)");
   if (!head_units_ok(a) || a.n_mod <= 0 || a.Lq != round_up(a.L + 2, 4) || a.Mp % 16)
     return ctx_fail(ctx, DCGP_ERR_ARG, "head_units: unsupported shape (image %d doubles, L = %d, Mp = %d)", a.HWC, a.L, a.Mp);
