@@ -68,8 +68,10 @@ __device__ __forceinline__ int frag_of(int w, int W, int c) { return (c >> 1) * 
 // 64-column strip: the fp64 MFMA pipe reaches 92 % of its rate from two waves per SIMD and 98 % from four.
 // MAXF: row fragments per wave at most.  ABL: timing experiments only (wrong results): 1 = second product without its
 // A-operand loads, 2 = without the LDS reads of the B operand, 4 = two more A tiles in flight.
-template <int FN, int NS, int MAXF, int NT, int BT, int ABL = 0>
+// BTP: 0 RBF, 1 ArcCosine, 2 RBF on 5 x 5 x 10 patches (the in-kernel sweep walks patch rows; an instance of its own so that the others do not carry its registers)
+template <int FN, int NS, int MAXF, int NT, int BTP, int ABL = 0>
 __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
+  constexpr int BT = BTP == 1 ? 1 : 0;
   // The arguments are read through the kernarg pointer, which every strip of a persistent workgroup sees as a new value: as a by-value
   // struct the loop-invariant loads of all ~70 words are hoisted out of the strip loop, live across it, and spill (240 VGPRs at 16 waves)
   typedef const __attribute__((address_space(4))) ConvFusedArgs KArgs;
@@ -328,6 +330,46 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
     const int nfast = min(a.L >> 2, nk4);
 #pragma unroll
     for (int u = 0; u < D4; ++u) ldz(min(u, nk4 - 1), ring[u]);
+    // 5 x 5 x 10 patches (a layer behind a 10-map conv layer: cfg3's second layer): f = 5 rows of 50 contiguous image elements, and lane group lrow's element
+    // of sub-step s, k = 4 s + lrow, walks a row at +4 doubles per sub-step -- the 12 aligned sub-steps of a row gather at ONE per-lane address per column fragment +
+    // immediates, two rows and the sub-step that straddles them are a period of 25 (head_units.hip: the patch-row form of the streamed sweep; same operands into
+    // the same MFMAs in the same order).  No offset table, no address per gather.
+    if constexpr (BTP == 2) {   // (the launcher checks: f C == 50, f odd, L == f f C)
+      constexpr int NA = 12;
+      static_assert(D4 + 1 == 5, "the ring of Z sub-steps closes over a period of 25");
+      const int RSd = a.W * a.C;                       // doubles from one patch row to the next in the image
+      const int sdl = lrow < 2 ? NA * 4 : RSd - 2;     // the straddling sub-step: lane groups 0, 1 end the row, 2, 3 open the next
+      int pA[FNS], pS[FNS], pB[FNS];
+#pragma unroll
+      for (int y = 0; y < FNS; ++y) pA[y] = pb[y] + lrow;
+      int sc = 0;
+      auto sub = [&](int SL, const int (&base)[FNS], int off) __attribute__((always_inline)) {   // (SL, off: constants once the callers' loops are unrolled)
+        ldz(min(sc + D4, nk4 - 1), ring[(SL + D4) % (D4 + 1)]);
+        double bv[FNS];
+#pragma unroll
+        for (int y = 0; y < FNS; ++y) bv[y] = aux[base[y] + off];
+#pragma unroll
+        for (int c = 0; c < MAXF; ++c)
+#pragma unroll
+          for (int y = 0; y < FNS; ++y) kacc[c][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[SL][c], bv[y], kacc[c][y], 0, 0, 0);
+        ++sc;
+      };
+      const int nper = (a.f - 1) >> 1;
+      for (int tp = 0; tp < nper; ++tp) {
+#pragma unroll
+        for (int y = 0; y < FNS; ++y) { pS[y] = pA[y] + sdl; pB[y] = pA[y] + (RSd + 2); }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) sub(i % (D4 + 1), pA, 4 * i);
+        sub(NA % (D4 + 1), pS, 0);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) sub((NA + 1 + i) % (D4 + 1), pB, 4 * i);
+#pragma unroll
+        for (int y = 0; y < FNS; ++y) pA[y] += 2 * RSd;
+      }
+#pragma unroll
+      for (int i = 0; i < NA; ++i) sub(i % (D4 + 1), pA, 4 * i);
+      kstep(nk4 - 1, ring[NA % (D4 + 1)]);             // the last two elements and the two norm slots
+    } else {
     int t = 0;
     int kc[D4 + 1], kn[D4 + 1];
 #pragma unroll
@@ -354,6 +396,7 @@ __global__ __launch_bounds__(NT) void conv_fused_kernel(ConvFusedArgs a_in) {
 #pragma unroll
     for (int u = 0; u < D4; ++u)
       if (t + u < nk4) kstep(t + u, ring[u]);
+    }
 #pragma unroll
     for (int c = 0; c < MAXF; ++c) {
       if (c < nfw) {
@@ -777,6 +820,19 @@ int launch_fused(dcgp_ctx* ctx, const ConvFusedArgs& a, size_t lds) {
     hipFuncSetAttribute((const void*)conv_fused_kernel<FN, NS, MAXF, NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done[dv] = true;
   }
+  const bool rows50 = a.bk.type == 0 && a.f * a.C == 50 && (a.f & 1) && a.L == a.f * a.f * a.C && a.Lz == ((a.L + 2 + 3) & ~3) && !a.no_rows;
+  if constexpr (FN == 4 && NS == 2) {   // (the patch-row instance only where such layers run: the 64-column strip on 16 waves)
+    if (rows50) {
+      static bool attr2[64] = {};
+      if (!attr2[dv]) {
+        hipFuncSetAttribute((const void*)conv_fused_kernel<FN, NS, MAXF, NT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr2[dv] = true;
+      }
+      hipLaunchKernelGGL((conv_fused_kernel<FN, NS, MAXF, NT, 2>), dim3(grid), dim3(NT), lds, ctx->stream, a);
+      LAUNCH_CHECK(ctx);
+      return DCGP_OK;
+    }
+  }
   if (a.bk.type == 0) hipLaunchKernelGGL((conv_fused_kernel<FN, NS, MAXF, NT, 0>), dim3(grid), dim3(NT), lds, ctx->stream, a);
   else hipLaunchKernelGGL((conv_fused_kernel<FN, NS, MAXF, NT, 1>), dim3(grid), dim3(NT), lds, ctx->stream, a);
   LAUNCH_CHECK(ctx);
@@ -980,6 +1036,7 @@ int conv_fused(dcgp_ctx* ctx, const ConvFusedArgs& a_in) {
   ConvFusedArgs a = a_in;
   a.lds_main = p.lds_main; a.lds_img = p.lds_img;
   a.trace = ctx->fused_trace;
+  a.no_rows = ctx->opt.sweep_no_rows ? 1 : 0;
   a.inv_HWC = 1.0f / (float)a.HWC; a.inv_nmod = 1.0f / (float)a.n_mod; a.inv_P = 1.0f / (float)a.P; a.inv_Wo = 1.0f / (float)a.Wo; a.inv_R = 1.0f / (float)a.R;
   const long strips = ((long)a.Kc + kShapes[p.shape].FN * 16 - 1) / (kShapes[p.shape].FN * 16);
   const int n_cus = ctx->n_cus > 0 ? ctx->n_cus : 256;

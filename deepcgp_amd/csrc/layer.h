@@ -129,6 +129,7 @@ struct ConvFusedArgs {
   // round, A1 handed over through pre_buf ([pre_n][pre_stride]: the strip's LDS image, then the partial sums of A1^2) behind pre_flag[slot] == pre_epoch
   // pre_sq > 1 (a launch of few strips, all of them handed over: pre_first = 0, pre_n = n_strips): a handed-over strip is taken up by pre_sq items, part q
   // running the outputs r = q, q + pre_sq, ... of the second product
+  int no_rows = 0;                                         // set by the launcher (ctx option sweep_no_rows): 5 x 5 x 10 patches on the generic in-kernel sweep (A/B)
   int pre_n = 0, pre_first = 0, pre_sq = 1; long pre_stride = 0;
   double* pre_buf = nullptr; unsigned* pre_flag = nullptr; unsigned pre_epoch = 0;
 };

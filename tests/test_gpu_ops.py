@@ -632,6 +632,33 @@ def test_patch_row_form_of_the_long_patch_sweeps_is_bit_identical(ctx, H, W, M, 
     close(got[2], OMOK(ORBF(v.patch_length, 2.0, 7.0), H * W * C, v.patch_count).Kuf(Z, ov.extract_patches_PNL(Xi)), 1e-12, "Kuf")
 
 
+@pytest.mark.parametrize("M,N,R", [(256, 3, 10), (70, 2, 3)])
+def test_patch_row_form_of_the_layer_kernels_sweep_is_bit_identical(ctx, M, N, R):
+    """A conv layer on 5 x 5 x 10 patches (cfg3's second layer) in the one-launch layer kernel: its in-kernel sweep walks patch rows (conv_fused.hip, the BTP = 2
+    instance of the 64-column strip); ctx option sweep_no_rows keeps the generic sweep.  Bit-identical, and equal to the unfused route."""
+    from deepcgp_amd.kernels import RBF, PatchInducingFeatures
+    from deepcgp_amd.layers import ConvLayer
+    from deepcgp_amd.views import FullView
+    rng = np.random.default_rng(17 + M)
+    H, W, C, f, s = 12, 12, 10, 5, 1
+    X = rng.standard_normal((N, H * W * C))
+    v = FullView((H, W), f, C, s)
+    Z, q_mu, q_sqrt = rand_spd_inputs(rng, M, R, v.patch_length, scale=0.05)
+    layer = ConvLayer(RBF(v.patch_length, 5.0, 9.0), None, PatchInducingFeatures(Z), v, gp_count=R, q_mu=q_mu, q_sqrt=q_sqrt)
+    z = rng.standard_normal((N, layer.num_outputs))
+    with ctx.options(fused_shape=0):
+        smp, mean, var = layer._forward(X, z)
+    with ctx.options(fused_shape=0, sweep_no_rows=1):
+        smp_g, mean_g, var_g = layer._forward(X, z)
+    with ctx.options(no_fused_layer=1):
+        smp_u, mean_u, var_u = layer._forward(X, z)
+    np.testing.assert_array_equal(mean, mean_g)
+    np.testing.assert_array_equal(var, var_g)
+    np.testing.assert_array_equal(smp, smp_g)
+    close(mean, mean_u, 1e-11, "mean")
+    close(var, var_u, 1e-10, "var")
+
+
 def test_head_unit_sweep_exp_accuracy(ctx):
     """The unit sweep's 2^t (magic-number split + degree-11 minimax polynomial + ldexp) value by value: one patch per image
     (P = 1, weight 1), one inducing patch at the origin, so Kzx[0, n] = variance * exp(-|x_n|^2 / (2 l^2)).  The exponent reaches the
